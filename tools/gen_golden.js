@@ -1,0 +1,460 @@
+'use strict';
+// Golden-vector generator.  Runs ONLY in the build container, where
+// /root/reference exists and Node is present.  It drives the reference
+// implementation itself (dist/elliptic.js = lib/ + vendored bn.js 4.11.9, see
+// SURVEY.md §8c) and writes small JSON fixtures to tests/golden/:
+//
+//   curves.json             preset parameters as the reference holds them
+//   mul_<curve>.json        seeded + edge cases for Point.mul / mulAdd
+//   verify_<curve>.json     ECDSA verify tuples (valid + corrupted)
+//   captured_<curve>.json   every call the reference's OWN mocha suite makes
+//                           into the hot path (Point.mul / mulAdd / jmulAdd /
+//                           ec.verify), captured at the prototype boundary
+//                           (tools/run_ref_tests.js instrumentation)
+//
+// All randomness is SHA-256 counter mode over a fixed seed; rerunning this
+// script reproduces the fixtures byte for byte.
+//
+//   node tools/gen_golden.js [outdir]
+
+var fs = require('fs');
+var path = require('path');
+var crypto = require('crypto');
+var ref = require('./ref_loader').load();
+var elliptic = ref.elliptic;
+var BN = ref.BN;
+
+var OUT = process.argv[2] || path.join(__dirname, '..', 'tests', 'golden');
+
+// ---------------------------------------------------------------- PRNG ----
+function Prng(seed) { this.seed = seed; this.ctr = 0; }
+Prng.prototype.bytes = function(n) {
+  var out = [];
+  while (out.length < n) {
+    var h = crypto.createHash('sha256')
+      .update(this.seed + ':' + (this.ctr++)).digest();
+    for (var i = 0; i < h.length && out.length < n; i++) out.push(h[i]);
+  }
+  return Buffer.from(out);
+};
+Prng.prototype.below = function(n) {          // uniform-ish in [0, n)
+  var len = n.byteLength() + 8;
+  return new BN(this.bytes(len)).umod(n);
+};
+Prng.prototype.bits = function(b) {
+  var x = new BN(this.bytes(Math.ceil(b / 8)));
+  return x.maskn(b);
+};
+
+function hex(bn, bytes) { return bn.toString(16, bytes * 2); }
+
+var SHORT = ['secp256k1', 'p192', 'p224', 'p256', 'p384', 'p521'];
+var COUNTS = { secp256k1: 96, p192: 24, p224: 24, p256: 32, p384: 24,
+  p521: 12, ed25519: 48, curve25519: 32 };
+
+function flen(c) { return c.p.byteLength(); }
+
+function affine(curve, p) {
+  // -> {inf:true} or {x,y} hex, never mutating p
+  if (p.isInfinity()) return { inf: true };
+  var L = flen(curve);
+  if (curve.type === 'short') {
+    if (p.z !== undefined) p = p.toP();
+    return { x: hex(p.getX(), L), y: hex(p.getY(), L) };
+  }
+  if (curve.type === 'edwards') {
+    var q = curve.point(p.x, p.y, p.z, p.t);
+    return { x: hex(q.getX(), L), y: hex(q.getY(), L) };
+  }
+  var m = curve.point(p.x, p.z);
+  return { x: hex(m.getX(), L) };
+}
+
+// ------------------------------------------------------------- curves.json
+function dumpCurves() {
+  var out = {};
+  SHORT.concat(['ed25519', 'curve25519']).forEach(function(name) {
+    var pc = elliptic.curves[name];
+    var c = pc.curve;
+    var L = flen(c);
+    var o = { type: c.type, p: hex(c.p, L), bytes: L };
+    if (c.n) { o.n = hex(c.n, c.n.byteLength()); o.nbits = c.n.bitLength(); }
+    if (c.type === 'short') {
+      o.a = hex(c.a.fromRed(), L); o.b = hex(c.b.fromRed(), L);
+      o.gx = hex(c.g.getX(), L); o.gy = hex(c.g.getY(), L);
+      if (c.endo) {
+        o.beta = hex(c.endo.beta.fromRed(), L);
+        o.lambda = hex(c.endo.lambda, 32);
+        o.basis = c.endo.basis.map(function(v) {
+          return { a: v.a.toString(16), b: v.b.toString(16) };
+        });
+      }
+    } else if (c.type === 'edwards') {
+      o.a = hex(c.a.fromRed(), L); o.c = hex(c.c.fromRed(), L);
+      o.d = hex(c.d.fromRed(), L);
+      o.gx = hex(c.g.getX(), L); o.gy = hex(c.g.getY(), L);
+    } else {
+      o.a = hex(c.a.fromRed(), L); o.b = hex(c.b.fromRed(), L);
+      o.gx = hex(c.g.getX(), L);
+    }
+    out[name] = o;
+  });
+  return out;
+}
+
+// ------------------------------------------------------------ mul_<curve>
+function edgeScalars(c) {
+  var n = c.n;
+  var bits = c.type === 'short' ? flen(c) * 8 : 256;
+  var list = [new BN(0), new BN(1), new BN(2), new BN(3), n.subn(1), n.clone(),
+    n.addn(1), n.subn(2), n.ushrn(1), n.ushrn(1).addn(1),
+    new BN(1).ushln(128), new BN(1).ushln(128).subn(1),
+    new BN(1).ushln(bits - 1)];
+  if (c.type !== 'short' || c.p.bitLength() % 8 === 0)
+    list.push(new BN(1).ushln(bits).subn(1));       // all-ones, > n
+  else
+    list.push(new BN(1).ushln(c.p.bitLength()).subn(1));
+  if (c.endo) list.push(c.endo.lambda.clone(), c.endo.lambda.addn(1),
+    n.sub(c.endo.lambda));
+  return list;
+}
+
+function genShortMul(name) {
+  var pc = elliptic.curves[name];
+  var c = pc.curve;
+  var L = flen(c);
+  var KL = L;                                   // scalar width at the C ABI
+  var rng = new Prng('ellgpu-golden-v1:mul:' + name);
+  var cases = [];
+  var N = COUNTS[name];
+  var i;
+  var G = c.g;
+
+  function rec(op, o) { o.op = op; cases.push(o); }
+  function randPoint() { return G.mul(rng.below(c.n.subn(1)).addn(1)); }
+  // a fresh (table-less) copy of G: forces the reference's variable-base path
+  var G2 = c.point(G.getX(), G.getY());
+
+  // fixed base: precomputed-G path (_fixedNafMul, base.js:52-84)
+  edgeScalars(c).forEach(function(k) {
+    rec('fixed', { k: hex(k, KL), r: affine(c, G.mul(k)) });
+  });
+  for (i = 0; i < N; i++) {
+    var k = rng.below(c.n);
+    rec('fixed', { k: hex(k, KL), r: affine(c, G.mul(k)) });
+  }
+  // variable base: _endoWnafMulAdd (short.js:218-249) / _wnafMul (base.js:86)
+  var P0 = randPoint();
+  edgeScalars(c).forEach(function(k) {
+    rec('var', { k: hex(k, KL), px: hex(P0.getX(), L), py: hex(P0.getY(), L),
+      r: affine(c, P0.mul(k)) });
+  });
+  edgeScalars(c).slice(0, 8).forEach(function(k) {
+    rec('var', { k: hex(k, KL), px: hex(G2.getX(), L), py: hex(G2.getY(), L),
+      r: affine(c, G2.mul(k)) });
+  });
+  for (i = 0; i < N; i++) {
+    var P = randPoint();
+    var kk = (i % 4 === 3) ? rng.bits(L * 8 > c.p.bitLength() ?
+      c.p.bitLength() : L * 8) : rng.below(c.n);
+    rec('var', { k: hex(kk, KL), px: hex(P.getX(), L), py: hex(P.getY(), L),
+      r: affine(c, P.mul(kk)) });
+  }
+  // k1*P1 + k2*P2 (mulAdd, short.js:434-441); P1 = G exercises the mixed
+  // precomputed / fresh path the verify uses.
+  var one = new BN(1);
+  var special = [
+    [G, new BN(5), G2, new BN(7)],
+    [P0, one, P0.neg(), one],                    // -> infinity
+    [P0, one, P0, one],                          // -> doubling inside add
+    [G, new BN(0), P0, new BN(0)],
+    [G, new BN(0), P0, new BN(9)],
+    [G, new BN(9), P0, new BN(0)],
+    [G, c.n.subn(1), G2, one],                   // -G + G
+    [G, c.n.subn(2), G2, new BN(2)],
+    [G, new BN(2), G2.neg(), new BN(2)],
+  ];
+  special.forEach(function(s) {
+    rec('muladd', { k1: hex(s[1], KL), p1x: hex(s[0].getX(), L),
+      p1y: hex(s[0].getY(), L), k2: hex(s[3], KL), p2x: hex(s[2].getX(), L),
+      p2y: hex(s[2].getY(), L), r: affine(c, s[0].mulAdd(s[1], s[2], s[3])) });
+  });
+  for (i = 0; i < Math.ceil(N / 2); i++) {
+    var A = (i & 1) ? randPoint() : G;
+    var B = randPoint();
+    var k1 = rng.below(c.n);
+    var k2 = rng.below(c.n);
+    rec('muladd', { k1: hex(k1, KL), p1x: hex(A.getX(), L),
+      p1y: hex(A.getY(), L), k2: hex(k2, KL), p2x: hex(B.getX(), L),
+      p2y: hex(B.getY(), L), r: affine(c, A.mulAdd(k1, B, k2)) });
+  }
+  return cases;
+}
+
+function genEdwardsMul() {
+  var name = 'ed25519';
+  var c = elliptic.curves[name].curve;
+  // as EDDSA's constructor does (eddsa/index.js:19): gives G its tables
+  c.g.precompute(c.n.bitLength() + 1);
+  var L = 32;
+  var rng = new Prng('ellgpu-golden-v1:mul:' + name);
+  var cases = [];
+  var G = c.g;
+  var N = COUNTS[name];
+  var i;
+  function rec(op, o) { o.op = op; cases.push(o); }
+  function xy(p) { var a = affine(c, p); return a; }
+  edgeScalars(c).forEach(function(k) {
+    rec('fixed', { k: hex(k, L), r: affine(c, G.mul(k)) });
+  });
+  for (i = 0; i < N; i++) {
+    var k = (i % 4 === 3) ? rng.bits(256) : rng.below(c.n);
+    rec('fixed', { k: hex(k, L), r: affine(c, G.mul(k)) });
+  }
+  // variable base, including points with a torsion component (pointFromY of
+  // a random y lands anywhere in the full group of order 8n)
+  var pts = [];
+  for (i = 0; i < N; i++) {
+    if (i % 3 === 2) {
+      for (;;) {
+        var y = rng.below(c.p);
+        try { pts.push(c.pointFromY(y, (i & 1) === 1)); break; } catch (e) { }
+      }
+    } else {
+      var g0 = G.mul(rng.below(c.n.subn(1)).addn(1));
+      pts.push(c.point(g0.getX(), g0.getY()));
+    }
+  }
+  var P0 = pts[0];
+  edgeScalars(c).forEach(function(k) {
+    var a = xy(P0);
+    rec('var', { k: hex(k, L), px: a.x, py: a.y, r: affine(c, P0.mul(k)) });
+  });
+  for (i = 0; i < N; i++) {
+    var kk = (i % 4 === 1) ? rng.bits(256) : rng.below(c.n);
+    var a2 = xy(pts[i]);
+    rec('var', { k: hex(kk, L), px: a2.x, py: a2.y,
+      r: affine(c, pts[i].mul(kk)) });
+  }
+  for (i = 0; i < N / 2; i++) {
+    // reference quirk: Edwards mulAdd only works when one operand carries
+    // precomputed tables (base.js:175 calls toJ(), which Edwards points lack),
+    // so the first operand is always G here.
+    var A = G;
+    var B = pts[(i * 7 + 3) % N];
+    var k1 = rng.below(c.n);
+    var k2 = rng.below(c.n);
+    var aa = xy(A);
+    var bb = xy(B);
+    rec('muladd', { k1: hex(k1, L), p1x: aa.x, p1y: aa.y, k2: hex(k2, L),
+      p2x: bb.x, p2y: bb.y, r: affine(c, A.mulAdd(k1, B, k2)) });
+  }
+  return cases;
+}
+
+function genMontMul() {
+  var name = 'curve25519';
+  var c = elliptic.curves[name].curve;
+  var L = 32;
+  var rng = new Prng('ellgpu-golden-v1:mul:' + name);
+  var cases = [];
+  var G = c.g;
+  var i;
+  function res(p) {
+    // reference: inf.getX() throws; record isInfinity instead
+    if (p.isInfinity()) return { inf: true };
+    return { x: hex(p.getX(), L) };
+  }
+  var ks = [new BN(0), new BN(1), new BN(2), new BN(6),
+    new BN(1).ushln(255).subn(1), new BN(1).ushln(256).subn(1),
+    new BN(1).ushln(254)];
+  ks.forEach(function(k) {
+    cases.push({ op: 'ladder', k: hex(k, L), px: hex(G.getX(), L),
+      r: res(G.mul(k)) });
+  });
+  for (i = 0; i < COUNTS[name]; i++) {
+    var x = (i & 1) ? rng.below(c.p) : G.mul(rng.bits(255)).getX();
+    var P = c.point(x, new BN(1));
+    var k = rng.bits(i % 4 === 2 ? 256 : 255);
+    cases.push({ op: 'ladder', k: hex(k, L), px: hex(x, L), r: res(P.mul(k)) });
+  }
+  return cases;
+}
+
+// --------------------------------------------------------- verify_<curve>
+function genVerify(name) {
+  var pc = elliptic.curves[name];
+  var c = pc.curve;
+  var ec = new elliptic.ec(pc);
+  var L = flen(c);
+  var NL = c.n.byteLength();
+  var rng = new Prng('ellgpu-golden-v1:verify:' + name);
+  var N = Math.ceil(COUNTS[name] * 0.75);
+  var cases = [];
+  function rec(z, zlen, r, s, pub, note) {
+    var zhex = Buffer.from(z).toString('hex');
+    var ok = ec.verify(zhex, { r: r, s: s }, pub);
+    cases.push({ z: zhex, r: hex(r, NL), s: hex(s, NL),
+      qx: hex(pub.getPublic().getX(), L), qy: hex(pub.getPublic().getY(), L),
+      ok: ok, note: note });
+  }
+  for (var i = 0; i < N; i++) {
+    var key = ec.keyFromPrivate(hex(rng.below(c.n.subn(1)).addn(1), NL), 'hex');
+    // hash lengths: the curve's natural digest, and longer/shorter ones to
+    // exercise _truncateToN (ec/index.js:81-108)
+    var zlen = [32, 32, 48, 64, 20][i % 5];
+    var z = rng.bytes(zlen);
+    if (i % 11 === 10) z[0] = 0;                 // leading-zero hash
+    var sig = ec.sign(z, key);
+    var pub = ec.keyFromPublic(key.getPublic());
+    rec(z, zlen, sig.r, sig.s, pub, 'valid');
+    var kind = i % 8;
+    if (kind === 0) { var z2 = Buffer.from(z); z2[zlen - 1] ^= 1;
+      rec(z2, zlen, sig.r, sig.s, pub, 'bad-z'); }
+    if (kind === 1) rec(z, zlen, sig.r.xor(new BN(1).ushln(i % 100)), sig.s,
+      pub, 'bad-r');
+    if (kind === 2) rec(z, zlen, sig.r, sig.s.xor(new BN(2)), pub, 'bad-s');
+    if (kind === 3) rec(z, zlen, sig.r, sig.s,
+      ec.keyFromPublic(key.getPublic().add(c.g)), 'bad-q');
+    if (kind === 4) rec(z, zlen, sig.r, c.n.sub(sig.s), pub, 'neg-s (valid)');
+    if (kind === 5) rec(z, zlen, new BN(0), sig.s, pub, 'r=0');
+    if (kind === 6) rec(z, zlen, sig.r, c.n.clone(), pub, 's=n');
+    if (kind === 7) rec(z, zlen, c.n.clone(), new BN(0), pub, 'r=n,s=0');
+  }
+  return cases;
+}
+
+// ------------------------------------------------- captured_<curve>.json
+// Run the reference's own mocha suite with the hot-path prototypes wrapped.
+function captureFromReferenceTests() {
+  var cap = {};
+  var LIMIT = 48;
+  var byP = {};
+  SHORT.concat(['ed25519', 'curve25519']).forEach(function(name) {
+    byP[elliptic.curves[name].curve.p.toString(16) + ':' +
+        elliptic.curves[name].curve.type] = name;
+    cap[name] = { mul: [], muladd: [], verify: [] };
+  });
+  function nameOf(curve) { return byP[curve.p.toString(16) + ':' + curve.type]; }
+  function seen(list, key) {
+    if (list._keys === undefined)
+      Object.defineProperty(list, '_keys', { value: {}, enumerable: false });
+    if (list._keys[key]) return true;
+    list._keys[key] = 1;
+    return false;
+  }
+  function scalarHex(curve, k) {
+    var L = curve.type === 'short' ? flen(curve) : 32;
+    if (k.isNeg() || k.byteLength() > L) return null;    // outside the C ABI
+    return hex(k, L);
+  }
+  function wrapPoint(proto) {
+    var mul = proto.mul;
+    proto.mul = function(k) {
+      var res = mul.apply(this, arguments);
+      try {
+        var cn = nameOf(this.curve);
+        if (cn && !this.isInfinity()) {
+          var kb = scalarHex(this.curve, BN.isBN(k) ? k : new BN(k, 16));
+          var a = affine(this.curve, this);
+          if (kb !== null) {
+            var o = { k: kb, px: a.x, r: affine(this.curve, res) };
+            if (a.y !== undefined) o.py = a.y;
+            var key = JSON.stringify(o);
+            if (cap[cn].mul.length < LIMIT && !seen(cap[cn].mul, key))
+              cap[cn].mul.push(o);
+          }
+        }
+      } catch (e) { /* capture must never disturb the suite */ }
+      return res;
+    };
+    ['mulAdd', 'jmulAdd'].forEach(function(fn) {
+      var orig = proto[fn];
+      if (!orig) return;
+      proto[fn] = function(k1, p2, k2) {
+        var res = orig.apply(this, arguments);
+        try {
+          var cn = nameOf(this.curve);
+          if (cn && !this.isInfinity() && !p2.isInfinity()) {
+            var a = affine(this.curve, this);
+            var b = affine(this.curve, p2);
+            var h1 = scalarHex(this.curve, k1);
+            var h2 = scalarHex(this.curve, k2);
+            if (h1 !== null && h2 !== null) {
+              var o = { k1: h1, p1x: a.x, p1y: a.y, k2: h2, p2x: b.x,
+                p2y: b.y, r: affine(this.curve, res) };
+              var key = JSON.stringify(o);
+              if (cap[cn].muladd.length < LIMIT && !seen(cap[cn].muladd, key))
+                cap[cn].muladd.push(o);
+            }
+          }
+        } catch (e) { /* ignore */ }
+        return res;
+      };
+    });
+  }
+  wrapPoint(elliptic.curves.secp256k1.curve.g.constructor.prototype);
+  wrapPoint(elliptic.curves.ed25519.curve.g.constructor.prototype);
+  wrapPoint(elliptic.curves.curve25519.curve.g.constructor.prototype);
+
+  var verify = elliptic.ec.prototype.verify;
+  elliptic.ec.prototype.verify = function(msg, signature, key, enc, options) {
+    var res = verify.apply(this, arguments);
+    try {
+      var cn = nameOf(this.curve);
+      if (cn && this.curve.type === 'short') {
+        if (typeof enc === 'object') { options = enc; enc = null; }
+        var kk = this.keyFromPublic(key, enc);
+        var sg = new ref.Signature(signature, 'hex');
+        var z = new BN(msg, 16);
+        var NL = this.n.byteLength();
+        if (!z.isNeg() && z.byteLength() <= 66 && sg.r.byteLength() <= NL &&
+            sg.s.byteLength() <= NL && !sg.r.isNeg() && !sg.s.isNeg()) {
+          var L = flen(this.curve);
+          var o = { z: hex(z, Math.max(z.byteLength(), 1)), r: hex(sg.r, NL),
+            s: hex(sg.s, NL), qx: hex(kk.getPublic().getX(), L),
+            qy: hex(kk.getPublic().getY(), L), ok: res };
+          if (options && options.msgBitLength)
+            o.msgBitLength = options.msgBitLength;
+          var ks = JSON.stringify(o);
+          if (cap[cn].verify.length < LIMIT && !seen(cap[cn].verify, ks))
+            cap[cn].verify.push(o);
+        }
+      }
+    } catch (e) { /* ignore */ }
+    return res;
+  };
+
+  var stats = require('./run_ref_tests').run(ref, { quiet: true });
+  return { cap: cap, stats: stats };
+}
+
+// --------------------------------------------------------------- main ----
+function write(name, obj) {
+  var file = path.join(OUT, name);
+  fs.writeFileSync(file, JSON.stringify(obj, null, 0)
+    .replace(/\},\{/g, '},\n{') + '\n');
+  console.log('wrote', file);
+}
+
+fs.mkdirSync(OUT, { recursive: true });
+write('curves.json', dumpCurves());
+SHORT.forEach(function(name) {
+  write('mul_' + name + '.json', genShortMul(name));
+  write('verify_' + name + '.json', genVerify(name));
+});
+write('mul_ed25519.json', genEdwardsMul());
+write('mul_curve25519.json', genMontMul());
+var c = captureFromReferenceTests();
+console.log('reference suite under capture:', JSON.stringify(c.stats));
+if (c.stats.failed !== 0) throw new Error('reference suite failed under capture');
+Object.keys(c.cap).forEach(function(name) {
+  write('captured_' + name + '.json', c.cap[name]);
+});
+write('MANIFEST.json', {
+  generator: 'tools/gen_golden.js',
+  reference: 'indutny/elliptic ' + elliptic.version +
+    ' (dist/elliptic.js, vendored bn.js 4.11.9)',
+  node: process.version,
+  reference_suite: c.stats,
+});
