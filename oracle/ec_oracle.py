@@ -1,0 +1,962 @@
+"""CPU oracle for the scalar-multiplication hot path of indutny/elliptic 6.6.1.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product path (elliptic_amd/, the
+C ABI, the HIP kernels) may import, call or link anything in this directory;
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, and
+only as the checker.
+
+This is a restatement, on Python integers, of the algorithms the reference
+runs in lib/elliptic/curve/{base,short,edwards,mont}.js, lib/elliptic/utils.js
+and lib/elliptic/ec/index.js (file:line cited per function, relative to
+/root/reference).  It deliberately keeps the reference's structure -- the same
+signed-digit recodings, the same fixed-base comb over "doubles", the same
+interleaved wNAF/JSF ladder with the GLV split, the same Jacobian / extended /
+x-only formulas -- so that it exercises the same exceptional branches.
+
+Parity is PINNED: tests/test_oracle_golden.py checks every function here
+against tests/golden/*.json, which tools/gen_golden.js produced by running the
+reference bundle itself (and the reference's own mocha suite, captured at the
+Point.mul / mulAdd / jmulAdd / ec.verify boundary) in the build container.
+Field arithmetic (bn.js 4.11.9 `red*`) is replaced by Python `%` -- values are
+canonical residues in both, which is all the reference's results depend on.
+"""
+
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+Affine = Optional[Tuple[int, int]]          # None = point at infinity
+Jac = Tuple[int, int, int]                  # Z == 0 -> infinity
+
+
+# --------------------------------------------------------------------------
+# Scalar recoding -- lib/elliptic/utils.js
+# --------------------------------------------------------------------------
+
+def get_naf(num: int, w: int, bits: int) -> List[int]:
+    """utils.js:15-44 getNAF (the reference's non-minimal variant for w>1)."""
+    naf = [0] * (max(num.bit_length(), bits) + 1)
+    ws = 1 << (w + 1)
+    k = num
+    for i in range(len(naf)):
+        mod = k & (ws - 1)
+        if k & 1:
+            if mod > (ws >> 1) - 1:
+                z = (ws >> 1) - mod
+            else:
+                z = mod
+            k -= z
+        else:
+            z = 0
+        naf[i] = z
+        k >>= 1
+    return naf
+
+
+def get_jsf(k1: int, k2: int) -> List[List[int]]:
+    """utils.js:47-101 getJSF (joint sparse form of two non-negative ints)."""
+    jsf: List[List[int]] = [[], []]
+    d1 = d2 = 0
+    while k1 > -d1 or k2 > -d2:
+        m14 = ((k1 & 3) + d1) & 3
+        m24 = ((k2 & 3) + d2) & 3
+        if m14 == 3:
+            m14 = -1
+        if m24 == 3:
+            m24 = -1
+        if (m14 & 1) == 0:
+            u1 = 0
+        else:
+            m8 = ((k1 & 7) + d1) & 7
+            u1 = -m14 if (m8 in (3, 5) and m24 == 2) else m14
+        jsf[0].append(u1)
+        if (m24 & 1) == 0:
+            u2 = 0
+        else:
+            m8 = ((k2 & 7) + d2) & 7
+            u2 = -m24 if (m8 in (3, 5) and m14 == 2) else m24
+        jsf[1].append(u2)
+        if 2 * d1 == u1 + 1:
+            d1 = 1 - d1
+        if 2 * d2 == u2 + 1:
+            d2 = 1 - d2
+        k1 >>= 1
+        k2 >>= 1
+    return jsf
+
+
+def div_round(a: int, n: int) -> int:
+    """bn.js divRound (dist/elliptic.js:6387): round-half-up of a/n, sign-aware."""
+    q, r = divmod(abs(a), n)
+    if 2 * r >= n:
+        q += 1
+    return q if a >= 0 else -q
+
+
+# --------------------------------------------------------------------------
+# Short Weierstrass -- lib/elliptic/curve/short.js + base.js
+# --------------------------------------------------------------------------
+
+@dataclass
+class _Tables:
+    """BasePoint.precomputed (base.js:312-327): naf wnd + doubles step."""
+    naf_wnd: int
+    naf_points: list
+    doubles_step: int
+    doubles_points: list
+
+
+class ShortPoint:
+    """Affine point (short.js:253-281) with optional precomputed tables."""
+
+    __slots__ = ("curve", "x", "y", "pre", "_beta")
+
+    def __init__(self, curve, x, y):
+        self.curve = curve
+        self.x = x
+        self.y = y
+        self.pre: Optional[_Tables] = None
+        self._beta = None
+
+    @property
+    def inf(self):
+        return self.x is None
+
+    def xy(self) -> Affine:
+        return None if self.inf else (self.x, self.y)
+
+    def neg(self, precompute=False):
+        """short.js:458-480 (negates the tables as well when asked)."""
+        if self.inf:
+            return self
+        c = self.curve
+        r = ShortPoint(c, self.x, (-self.y) % c.p)
+        if precompute and self.pre is not None:
+            r.pre = _Tables(self.pre.naf_wnd,
+                            [q.neg() for q in self.pre.naf_points],
+                            self.pre.doubles_step,
+                            [q.neg() for q in self.pre.doubles_points])
+        return r
+
+    def eq(self, o):
+        return self.inf == o.inf and (self.inf or (self.x == o.x and self.y == o.y))
+
+    def add(self, o):
+        """short.js:365-392 affine chord (1 inversion)."""
+        c = self.curve
+        p = c.p
+        if self.inf:
+            return o
+        if o.inf:
+            return self
+        if self.eq(o):
+            return self.dbl()
+        if self.neg().eq(o):
+            return c.point(None, None)
+        if self.x == o.x:
+            return c.point(None, None)
+        cc = (self.y - o.y) % p
+        if cc != 0:
+            cc = cc * pow((self.x - o.x) % p, -1, p) % p
+        nx = (cc * cc - self.x - o.x) % p
+        ny = (cc * (self.x - nx) - self.y) % p
+        return c.point(nx, ny)
+
+    def dbl(self):
+        """short.js:394-412 affine tangent (1 inversion)."""
+        c = self.curve
+        p = c.p
+        if self.inf:
+            return self
+        ys1 = (2 * self.y) % p
+        if ys1 == 0:
+            return c.point(None, None)
+        cc = (3 * self.x * self.x + c.a) * pow(ys1, -1, p) % p
+        nx = (cc * cc - 2 * self.x) % p
+        ny = (cc * (self.x - nx) - self.y) % p
+        return c.point(nx, ny)
+
+    def to_j(self) -> Jac:
+        return (1, 1, 0) if self.inf else (self.x, self.y, 1)
+
+    # --- tables: base.js:312-370 ---------------------------------------
+    def get_naf_points(self, wnd):
+        """base.js:357-370 (odd multiples by AFFINE adds, one inversion each)."""
+        if self.pre is not None:
+            return self.pre.naf_wnd, self.pre.naf_points
+        res = [self]
+        mx = (1 << wnd) - 1
+        d = None if mx == 1 else self.dbl()
+        for i in range(1, mx):
+            res.append(res[i - 1].add(d))
+        return wnd, res
+
+    def get_doubles(self, step, power):
+        """base.js:341-355."""
+        if self.pre is not None:
+            return self.pre.doubles_step, self.pre.doubles_points
+        doubles = [self]
+        acc = self
+        for _ in range(0, power, step):
+            for _ in range(step):
+                acc = acc.dbl()
+            doubles.append(acc)
+        return step, doubles
+
+    def precompute(self, power):
+        """base.js:312-327."""
+        if self.pre is not None:
+            return self
+        w, pts = self.get_naf_points(8)
+        s, dbl = self.get_doubles(4, power)
+        self.pre = _Tables(w, pts, s, dbl)
+        return self
+
+    def has_doubles(self, k: int) -> bool:
+        """base.js:329-338."""
+        if self.pre is None:
+            return False
+        return len(self.pre.doubles_points) >= -(-(k.bit_length() + 1) // self.pre.doubles_step)
+
+    def get_beta(self):
+        """short.js:282-310: (beta*x, y), tables mapped likewise."""
+        c = self.curve
+        if c.endo is None:
+            return None
+        if self._beta is not None:
+            return self._beta
+        b = ShortPoint(c, self.x * c.endo["beta"] % c.p, self.y)
+        if self.pre is not None:
+            mp = lambda q: ShortPoint(c, q.x * c.endo["beta"] % c.p, q.y)
+            b.pre = _Tables(self.pre.naf_wnd, [mp(q) for q in self.pre.naf_points],
+                            self.pre.doubles_step,
+                            [mp(q) for q in self.pre.doubles_points])
+        self._beta = b
+        return b
+
+    # --- public hot-path entry points ------------------------------------
+    def mul(self, k: int):
+        """short.js:422-432."""
+        c = self.curve
+        if self.inf:
+            return self
+        if self.has_doubles(k):
+            return c.fixed_naf_mul(self, k)
+        if c.endo is not None:
+            return c.endo_wnaf_mul_add([self], [k], False)
+        return c.wnaf_mul(self, k)
+
+    def mul_add(self, k1: int, p2, k2: int):
+        """short.js:434-441."""
+        c = self.curve
+        if c.endo is not None:
+            return c.endo_wnaf_mul_add([self, p2], [k1, k2], False)
+        return c.wnaf_mul_add(1, [self, p2], [k1, k2], 2, False)
+
+    def jmul_add(self, k1: int, p2, k2: int) -> Jac:
+        """short.js:443-450 (Jacobian result)."""
+        c = self.curve
+        if c.endo is not None:
+            return c.endo_wnaf_mul_add([self, p2], [k1, k2], True)
+        return c.wnaf_mul_add(1, [self, p2], [k1, k2], 2, True)
+
+
+class ShortCurve:
+    """lib/elliptic/curve/short.js ShortCurve + base.js BaseCurve."""
+
+    def __init__(self, name, p, a, b, n, gx, gy, endo=None):
+        self.name = name
+        self.type = "short"
+        self.p, self.a, self.b, self.n = p, a % p, b % p, n
+        self.zero_a = self.a == 0                       # short.js:17
+        self.three_a = (self.a + 3) % p == 0            # short.js:18
+        self.bit_length = n.bit_length()                # base.js:31
+        self.bytes = (p.bit_length() + 7) // 8
+        self.endo = endo
+        # base.js:33-40 (Maxwell trick enabled when p/n <= 100)
+        self.maxwell = (p // n) <= 100
+        self.g = ShortPoint(self, gx, gy)
+
+    def point(self, x, y):
+        return ShortPoint(self, x, y)
+
+    def validate(self, pt: ShortPoint) -> bool:
+        """short.js:206-216."""
+        if pt.inf:
+            return True
+        p = self.p
+        return (pt.y * pt.y - (pt.x ** 3 + self.a * pt.x + self.b)) % p == 0
+
+    # --- Jacobian formulas: short.js:516-925 -----------------------------
+    def j_is_inf(self, P: Jac) -> bool:
+        return P[2] % self.p == 0
+
+    def j_to_p(self, P: Jac) -> ShortPoint:
+        """short.js:516-526."""
+        if self.j_is_inf(P):
+            return self.point(None, None)
+        p = self.p
+        zinv = pow(P[2], -1, p)
+        zinv2 = zinv * zinv % p
+        return self.point(P[0] * zinv2 % p, P[1] * zinv2 * zinv % p)
+
+    def j_add(self, P: Jac, Q: Jac) -> Jac:
+        """short.js:532-567 (12M+4S; h==0 -> infinity or doubling)."""
+        p = self.p
+        if self.j_is_inf(P):
+            return Q
+        if self.j_is_inf(Q):
+            return P
+        pz2 = Q[2] * Q[2] % p
+        z2 = P[2] * P[2] % p
+        u1 = P[0] * pz2 % p
+        u2 = Q[0] * z2 % p
+        s1 = P[1] * pz2 * Q[2] % p
+        s2 = Q[1] * z2 * P[2] % p
+        h = (u1 - u2) % p
+        r = (s1 - s2) % p
+        if h == 0:
+            if r != 0:
+                return (1, 1, 0)
+            return self.j_dbl(P)
+        h2 = h * h % p
+        h3 = h2 * h % p
+        v = u1 * h2 % p
+        nx = (r * r + h3 - 2 * v) % p
+        ny = (r * (v - nx) - s1 * h3) % p
+        nz = P[2] * Q[2] * h % p
+        return (nx, ny, nz)
+
+    def j_mixed_add(self, P: Jac, q: ShortPoint) -> Jac:
+        """short.js:569-603 (8M+3S)."""
+        p = self.p
+        if self.j_is_inf(P):
+            return q.to_j()
+        if q.inf:
+            return P
+        z2 = P[2] * P[2] % p
+        u1 = P[0]
+        u2 = q.x * z2 % p
+        s1 = P[1]
+        s2 = q.y * z2 * P[2] % p
+        h = (u1 - u2) % p
+        r = (s1 - s2) % p
+        if h == 0:
+            if r != 0:
+                return (1, 1, 0)
+            return self.j_dbl(P)
+        h2 = h * h % p
+        h3 = h2 * h % p
+        v = u1 * h2 % p
+        nx = (r * r + h3 - 2 * v) % p
+        ny = (r * (v - nx) - s1 * h3) % p
+        nz = P[2] * h % p
+        return (nx, ny, nz)
+
+    def j_dbl(self, P: Jac) -> Jac:
+        """short.js:656-830: _zeroDbl (a=0) / _threeDbl (a=-3) / _dbl.
+
+        The three reference variants are algebraically the same doubling
+        (dbl-2009-l / dbl-2001-b / dbl-2007-bl of the EFD); their (X,Y,Z) are
+        projectively equal, and only the affine image is canonical (SURVEY
+        8b), so one formula per case with the reference's Z3 = 2*Y1*Z1.
+        """
+        p = self.p
+        if self.j_is_inf(P):
+            return P
+        X, Y, Z = P
+        yy = Y * Y % p
+        s = 4 * X * yy % p
+        if self.zero_a:
+            m = 3 * X * X % p
+        elif self.three_a:
+            zz = Z * Z % p
+            m = 3 * (X - zz) * (X + zz) % p
+        else:
+            zz = Z * Z % p
+            m = (3 * X * X + self.a * zz * zz) % p
+        nx = (m * m - 2 * s) % p
+        ny = (m * (s - nx) - 8 * yy * yy) % p
+        nz = 2 * Y * Z % p
+        return (nx, ny, nz)
+
+    def j_dblp(self, P: Jac, pw: int) -> Jac:
+        """short.js:605-654 (repeated doubling)."""
+        for _ in range(pw):
+            P = self.j_dbl(P)
+        return P
+
+    def j_eq_x_to_p(self, P: Jac, x: int) -> bool:
+        """short.js:908-925 eqXToP: X == x*Z^2, retrying x += n while x < p."""
+        p = self.p
+        zs = P[2] * P[2] % p
+        rx = x % p * zs % p
+        if P[0] % p == rx:
+            return True
+        xc = x
+        t = self.n % p * zs % p
+        while True:
+            xc += self.n
+            if xc >= p:
+                return False
+            rx = (rx + t) % p
+            if P[0] % p == rx:
+                return True
+
+    # --- ladders: base.js ----------------------------------------------------
+    def fixed_naf_mul(self, pt: ShortPoint, k: int) -> ShortPoint:
+        """base.js:52-84 _fixedNafMul (comb over 'doubles', step 4)."""
+        step, pts = pt.get_doubles(0, 0)
+        naf = get_naf(k, 1, self.bit_length)
+        I = ((1 << (step + 1)) - (2 if step % 2 == 0 else 1)) // 3
+        rep = []
+        for j in range(0, len(naf), step):
+            w = 0
+            for l in range(j + step - 1, j - 1, -1):
+                w = (w << 1) + (naf[l] if l < len(naf) else 0)
+            rep.append(w)
+        a: Jac = (1, 1, 0)
+        b: Jac = (1, 1, 0)
+        for i in range(I, 0, -1):
+            for j, w in enumerate(rep):
+                if w == i:
+                    b = self.j_mixed_add(b, pts[j])
+                elif w == -i:
+                    b = self.j_mixed_add(b, pts[j].neg())
+            a = self.j_add(a, b)
+        return self.j_to_p(a)
+
+    def wnaf_mul(self, pt: ShortPoint, k: int) -> ShortPoint:
+        """base.js:86-126 _wnafMul (w=4 unless the point carries tables)."""
+        w, wnd = pt.get_naf_points(4)
+        naf = get_naf(k, w, self.bit_length)
+        acc: Jac = (1, 1, 0)
+        i = len(naf) - 1
+        while i >= 0:
+            l = 0
+            while i >= 0 and naf[i] == 0:
+                l += 1
+                i -= 1
+            if i >= 0:
+                l += 1
+            acc = self.j_dblp(acc, l)
+            if i < 0:
+                break
+            z = naf[i]
+            q = wnd[(z - 1) >> 1] if z > 0 else wnd[(-z - 1) >> 1].neg()
+            acc = self.j_mixed_add(acc, q)
+            i -= 1
+        return self.j_to_p(acc)
+
+    def wnaf_mul_add(self, def_w, points, coeffs, ln, jacobian_result):
+        """base.js:128-253 _wnafMulAdd (interleaved wNAF, JSF for w=1 pairs)."""
+        wnd_w = [0] * ln
+        wnd: list = [None] * ln
+        naf: list = [None] * ln
+        mx = 0
+        for i in range(ln):
+            wnd_w[i], wnd[i] = points[i].get_naf_points(def_w)
+        i = ln - 1
+        while i >= 1:
+            a, b = i - 1, i
+            if wnd_w[a] != 1 or wnd_w[b] != 1:
+                naf[a] = get_naf(coeffs[a], wnd_w[a], self.bit_length)
+                naf[b] = get_naf(coeffs[b], wnd_w[b], self.bit_length)
+                mx = max(len(naf[a]), len(naf[b]), mx)
+                i -= 2
+                continue
+            comb = [points[a], None, None, points[b]]
+            if points[a].y == points[b].y:                       # base.js:174
+                comb[1] = points[a].add(points[b])
+                comb[2] = ("j", self.j_mixed_add(points[a].to_j(), points[b].neg()))
+            elif points[a].y == (-points[b].y) % self.p:
+                comb[1] = ("j", self.j_mixed_add(points[a].to_j(), points[b]))
+                comb[2] = points[a].add(points[b].neg())
+            else:
+                comb[1] = ("j", self.j_mixed_add(points[a].to_j(), points[b]))
+                comb[2] = ("j", self.j_mixed_add(points[a].to_j(), points[b].neg()))
+            index = [-3, -1, -5, -7, 0, 7, 5, 1, 3]
+            jsf = get_jsf(coeffs[a], coeffs[b])
+            mx = max(len(jsf[0]), mx)
+            naf[a] = [0] * mx
+            naf[b] = [0] * mx
+            for j in range(mx):
+                ja = jsf[0][j] if j < len(jsf[0]) else 0
+                jb = jsf[1][j] if j < len(jsf[1]) else 0
+                naf[a][j] = index[(ja + 1) * 3 + (jb + 1)]
+            wnd[a] = comb
+            i -= 2
+        if ln % 2 == 1 and naf[0] is None:
+            # odd count: base.js leaves naf[0] unset only when ln == 1 is never
+            # called that way by the reference; guard for completeness.
+            naf[0] = get_naf(coeffs[0], wnd_w[0], self.bit_length)
+            mx = max(len(naf[0]), mx)
+
+        def digit(j, i):
+            return naf[j][i] if i < len(naf[j]) else 0
+
+        acc: Jac = (1, 1, 0)
+        i = mx
+        while i >= 0:
+            k = 0
+            tmp = [0] * ln
+            while i >= 0:
+                zero = True
+                for j in range(ln):
+                    tmp[j] = digit(j, i)
+                    if tmp[j] != 0:
+                        zero = False
+                if not zero:
+                    break
+                k += 1
+                i -= 1
+            if i >= 0:
+                k += 1
+            acc = self.j_dblp(acc, k)
+            if i < 0:
+                break
+            for j in range(ln):
+                z = tmp[j]
+                if z == 0:
+                    continue
+                q = wnd[j][(z - 1) >> 1] if z > 0 else wnd[j][(-z - 1) >> 1]
+                neg = z < 0
+                if isinstance(q, tuple):                   # Jacobian comb entry
+                    jq = q[1]
+                    if neg:
+                        jq = (jq[0], (-jq[1]) % self.p, jq[2])
+                    acc = self.j_add(acc, jq)
+                else:
+                    acc = self.j_mixed_add(acc, q.neg() if neg else q)
+            i -= 1
+        return acc if jacobian_result else self.j_to_p(acc)
+
+    def endo_split(self, k: int):
+        """short.js:168-185 _endoSplit."""
+        v1, v2 = self.endo["basis"]
+        c1 = div_round(v2[1] * k, self.n)
+        c2 = div_round(-v1[1] * k, self.n)
+        k1 = k - c1 * v1[0] - c2 * v2[0]
+        k2 = -(c1 * v1[1] + c2 * v2[1])
+        return k1, k2
+
+    def endo_wnaf_mul_add(self, points, coeffs, jacobian_result):
+        """short.js:218-249 _endoWnafMulAdd (GLV)."""
+        npoints, ncoeffs = [], []
+        for pt, k in zip(points, coeffs):
+            k1, k2 = self.endo_split(k)
+            beta = pt.get_beta()
+            if k1 < 0:
+                k1 = -k1
+                pt = pt.neg(True)
+            if k2 < 0:
+                k2 = -k2
+                beta = beta.neg(True)
+            npoints += [pt, beta]
+            ncoeffs += [k1, k2]
+        return self.wnaf_mul_add(1, npoints, ncoeffs, len(npoints), jacobian_result)
+
+
+# --------------------------------------------------------------------------
+# ECDSA verify -- lib/elliptic/ec/index.js
+# --------------------------------------------------------------------------
+
+def truncate_to_n(curve: ShortCurve, msg: int, byte_length: int, trunc_only=False,
+                  bit_length=None) -> int:
+    """ec/index.js:81-108 _truncateToN.  `byte_length` is the length of the
+    caller's buffer / hex string (what 6.6.1 uses, :84-96); `bit_length`
+    mirrors options.msgBitLength."""
+    if bit_length is None:
+        bit_length = byte_length * 8
+    delta = bit_length - curve.n.bit_length()
+    if delta > 0:
+        msg >>= delta
+    if not trunc_only and msg >= curve.n:
+        return msg - curve.n
+    return msg
+
+
+def ecdsa_verify(curve: ShortCurve, msg: int, msg_bytes: int, r: int, s: int,
+                 pub: ShortPoint, msg_bit_length=None) -> bool:
+    """ec/index.js:188-229 EC#verify (after key/signature decoding).
+
+    `curve.g` must carry its tables (EC's constructor calls g.precompute,
+    ec/index.js:36) for the ladder to take the reference's path; the result
+    does not depend on it.
+    """
+    n = curve.n
+    msg = truncate_to_n(curve, msg, msg_bytes, False, msg_bit_length)
+    if r < 1 or r >= n:
+        return False
+    if s < 1 or s >= n:
+        return False
+    sinv = pow(s, -1, n)
+    u1 = sinv * msg % n
+    u2 = sinv * r % n
+    if not curve.maxwell:
+        pt = curve.g.mul_add(u1, pub, u2)
+        if pt.inf:
+            return False
+        return pt.x % n == r
+    jp = curve.g.jmul_add(u1, pub, u2)
+    if curve.j_is_inf(jp):
+        return False
+    return curve.j_eq_x_to_p(jp, r)
+
+
+# --------------------------------------------------------------------------
+# Twisted Edwards -- lib/elliptic/curve/edwards.js  (extended coords, a = -1)
+# --------------------------------------------------------------------------
+
+class EdPoint:
+    """edwards.js:114-153 Point: extended (X, Y, Z, T)."""
+
+    __slots__ = ("curve", "x", "y", "z", "t", "pre")
+
+    def __init__(self, curve, x, y, z=None, t=None):
+        p = curve.p
+        self.curve = curve
+        if x is None and y is None:
+            self.x, self.y, self.z, self.t = 0, 1, 1, 0
+        else:
+            self.x, self.y = x % p, y % p
+            self.z = 1 if z is None else z % p
+            if t is None:
+                # edwards.js:141-147: T = X*Y / Z
+                self.t = self.x * self.y % p
+                if self.z != 1:
+                    self.t = self.t * pow(self.z, -1, p) % p
+            else:
+                self.t = t % p
+        self.pre: Optional[_Tables] = None
+
+    def is_infinity(self):
+        """edwards.js:167-172."""
+        return self.x == 0 and (self.y == self.z)
+
+    def neg(self):
+        c = self.curve
+        return EdPoint(c, (-self.x) % c.p, self.y, self.z, (-self.t) % c.p)
+
+    def dbl(self):
+        """edwards.js:174-205 _extDbl (dbl-2008-hwcd, 4M+4S)."""
+        if self.is_infinity():
+            return self
+        c = self.curve
+        p = c.p
+        a = self.x * self.x % p
+        b = self.y * self.y % p
+        cc = 2 * self.z * self.z % p
+        d = c.a * a % p
+        e = ((self.x + self.y) ** 2 - a - b) % p
+        g = (d + b) % p
+        f = (g - cc) % p
+        h = (d - b) % p
+        return EdPoint(c, e * f % p, g * h % p, f * g % p, e * h % p)
+
+    def add(self, o):
+        """edwards.js:350-360 add -> :279-309 _extAdd (add-2008-hwcd-3, 8M)."""
+        if self.is_infinity():
+            return o
+        if o.is_infinity():
+            return self
+        c = self.curve
+        p = c.p
+        a = (self.y - self.x) * (o.y - o.x) % p
+        b = (self.y + self.x) * (o.y + o.x) % p
+        cc = self.t * c.dd % p * o.t % p
+        d = self.z * 2 * o.z % p
+        e = (b - a) % p
+        f = (d - cc) % p
+        g = (d + cc) % p
+        h = (b + a) % p
+        return EdPoint(c, e * f % p, g * h % p, f * g % p, e * h % p)
+
+    def normalized(self) -> Tuple[int, int]:
+        """edwards.js:377-390 normalize + getX/getY."""
+        p = self.curve.p
+        zi = pow(self.z, -1, p)
+        return self.x * zi % p, self.y * zi % p
+
+    def get_naf_points(self, wnd):
+        if self.pre is not None:
+            return self.pre.naf_wnd, self.pre.naf_points
+        res = [self]
+        mx = (1 << wnd) - 1
+        d = None if mx == 1 else self.dbl()
+        for i in range(1, mx):
+            res.append(res[i - 1].add(d))
+        return wnd, res
+
+    def precompute(self, power):
+        if self.pre is not None:
+            return self
+        w, pts = self.get_naf_points(8)
+        doubles = [self]
+        acc = self
+        for _ in range(0, power, 4):
+            for _ in range(4):
+                acc = acc.dbl()
+            doubles.append(acc)
+        self.pre = _Tables(w, pts, 4, doubles)
+        return self
+
+    def has_doubles(self, k):
+        if self.pre is None:
+            return False
+        return len(self.pre.doubles_points) >= -(-(k.bit_length() + 1) // 4)
+
+    def mul(self, k: int):
+        """edwards.js:362-367."""
+        c = self.curve
+        if self.has_doubles(k):
+            return c.fixed_naf_mul(self, k)
+        return c.wnaf_mul(self, k)
+
+    def mul_add(self, k1, o, k2):
+        """edwards.js:369-371 (reference only works when the pair is not
+        (wnd 1, wnd 1): base.js:175 calls toJ(), absent on Edwards points)."""
+        return self.curve.wnaf_mul_add(1, [self, o], [k1, k2], 2)
+
+
+class EdwardsCurve:
+    """lib/elliptic/curve/edwards.js EdwardsCurve (twisted, a=-1, c=1)."""
+
+    def __init__(self, name, p, a, d, n, gx, gy):
+        self.name = name
+        self.type = "edwards"
+        self.p, self.a, self.d, self.n = p, a % p, d % p, n
+        self.dd = 2 * self.d % p                        # edwards.js:23
+        self.bit_length = n.bit_length()
+        self.bytes = (p.bit_length() + 7) // 8
+        self.g = EdPoint(self, gx, gy)
+
+    def point(self, x, y, z=None, t=None):
+        return EdPoint(self, x, y, z, t)
+
+    def point_from_y(self, y: int, odd: bool) -> EdPoint:
+        """edwards.js:71-97 pointFromY (c = 1)."""
+        p = self.p
+        y %= p
+        y2 = y * y % p
+        lhs = (y2 - 1) % p
+        rhs = (y2 * self.d - self.a) % p                # c2 = 1
+        x2 = lhs * pow(rhs, -1, p) % p
+        if x2 == 0:
+            if odd:
+                raise ValueError("invalid point")
+            return self.point(0, y)
+        x = _sqrt_mod(x2, p)
+        if x is None:
+            raise ValueError("invalid point")
+        if (x & 1) != int(odd):
+            x = (-x) % p
+        return self.point(x, y)
+
+    def fixed_naf_mul(self, pt: EdPoint, k: int) -> EdPoint:
+        """base.js:52-84 with mixedAdd == add == _extAdd (edwards.js:434-435)."""
+        step, pts = pt.pre.doubles_step, pt.pre.doubles_points
+        naf = get_naf(k, 1, self.bit_length)
+        I = ((1 << (step + 1)) - (2 if step % 2 == 0 else 1)) // 3
+        rep = []
+        for j in range(0, len(naf), step):
+            w = 0
+            for l in range(j + step - 1, j - 1, -1):
+                w = (w << 1) + (naf[l] if l < len(naf) else 0)
+            rep.append(w)
+        a = self.point(None, None)
+        b = self.point(None, None)
+        for i in range(I, 0, -1):
+            for j, w in enumerate(rep):
+                if w == i:
+                    b = b.add(pts[j])
+                elif w == -i:
+                    b = b.add(pts[j].neg())
+            a = a.add(b)
+        return a
+
+    def wnaf_mul(self, pt: EdPoint, k: int) -> EdPoint:
+        """base.js:86-126 for type 'projective' (returns un-normalized)."""
+        w, wnd = pt.get_naf_points(4)
+        naf = get_naf(k, w, self.bit_length)
+        acc = self.point(None, None)
+        i = len(naf) - 1
+        while i >= 0:
+            l = 0
+            while i >= 0 and naf[i] == 0:
+                l += 1
+                i -= 1
+            if i >= 0:
+                l += 1
+            for _ in range(l):
+                acc = acc.dbl()
+            if i < 0:
+                break
+            z = naf[i]
+            q = wnd[(z - 1) >> 1] if z > 0 else wnd[(-z - 1) >> 1].neg()
+            acc = acc.add(q)
+            i -= 1
+        return acc
+
+    def wnaf_mul_add(self, def_w, points, coeffs, ln):
+        """base.js:128-253 restricted to the branch Edwards can take
+        (no (1,1) JSF pair, see EdPoint.mul_add)."""
+        wnd_w, wnd, naf = [0] * ln, [None] * ln, [None] * ln
+        for i in range(ln):
+            wnd_w[i], wnd[i] = points[i].get_naf_points(def_w)
+        if ln == 2 and wnd_w[0] == 1 and wnd_w[1] == 1:
+            raise TypeError("points[a].toJ is not a function")   # reference behaviour
+        mx = 0
+        for i in range(ln):
+            naf[i] = get_naf(coeffs[i], wnd_w[i], self.bit_length)
+            mx = max(mx, len(naf[i]))
+        acc = self.point(None, None)
+        for i in range(mx, -1, -1):
+            acc = acc.dbl()
+            for j in range(ln):
+                z = naf[j][i] if i < len(naf[j]) else 0
+                if z == 0:
+                    continue
+                q = wnd[j][(z - 1) >> 1] if z > 0 else wnd[j][(-z - 1) >> 1].neg()
+                acc = acc.add(q)
+        return acc
+
+
+def _sqrt_mod(a: int, p: int) -> Optional[int]:
+    """bn.js Red.sqrt (dist/elliptic.js:7180-7230): p%4==3 -> pow; else
+    Tonelli-Shanks.  Returns the root bn.js returns (either root is accepted by
+    callers, which fix the parity afterwards)."""
+    a %= p
+    if a == 0:
+        return 0
+    if p % 4 == 3:
+        r = pow(a, (p + 1) // 4, p)
+        return r if r * r % p == a else None
+    if pow(a, (p - 1) // 2, p) != 1:
+        return None
+    q, s = p - 1, 0
+    while q % 2 == 0:
+        q //= 2
+        s += 1
+    z = 2
+    while pow(z, (p - 1) // 2, p) != p - 1:
+        z += 1
+    m, c, t, r = s, pow(z, q, p), pow(a, q, p), pow(a, (q + 1) // 2, p)
+    while t != 1:
+        i, t2 = 0, t
+        while t2 != 1:
+            t2 = t2 * t2 % p
+            i += 1
+        b = pow(c, 1 << (m - i - 1), p)
+        m, c = i, b * b % p
+        t, r = t * c % p, r * b % p
+    return r
+
+
+# --------------------------------------------------------------------------
+# Montgomery x-only -- lib/elliptic/curve/mont.js
+# --------------------------------------------------------------------------
+
+class MontCurve:
+    """lib/elliptic/curve/mont.js MontCurve (curve25519: A=486662, B=1)."""
+
+    def __init__(self, name, p, a, b, gx, n=None):
+        self.name = name
+        self.type = "mont"
+        self.p, self.a, self.b, self.n = p, a % p, b % p, n
+        self.a24 = (self.a + 2) * pow(4, -1, p) % p      # mont.js:14-16
+        self.bytes = (p.bit_length() + 7) // 8
+        self.gx = gx
+
+    def dbl(self, P):
+        """mont.js:82-101 (dbl-1987-m-3)."""
+        p = self.p
+        X, Z = P
+        aa = (X + Z) ** 2 % p
+        bb = (X - Z) ** 2 % p
+        c = (aa - bb) % p
+        return aa * bb % p, c * (bb + self.a24 * c) % p
+
+    def diff_add(self, P, Q, D):
+        """mont.js:107-128 (dadd-1987-m-3): P+Q given D = P-Q."""
+        p = self.p
+        a, b = (P[0] + P[1]) % p, (P[0] - P[1]) % p
+        c, d = (Q[0] + Q[1]) % p, (Q[0] - Q[1]) % p
+        da, cb = d * a % p, c * b % p
+        return D[1] * (da + cb) ** 2 % p, D[0] * (da - cb) ** 2 % p
+
+    def mul(self, x: int, k: int):
+        """mont.js:130-153 Point#mul: MSB-first over the exact bit length of
+        k, no clamping.  Returns (X, Z)."""
+        a = (x % self.p, 1)
+        b = (1, 0)                                        # mont.js:32-34
+        c = a
+        for i in range(k.bit_length() - 1, -1, -1):
+            if (k >> i) & 1 == 0:
+                a = self.diff_add(a, b, c)
+                b = self.dbl(b)
+            else:
+                b = self.diff_add(a, b, c)
+                a = self.dbl(a)
+        return b
+
+    def mul_x(self, x: int, k: int) -> Optional[int]:
+        """mul + getX (mont.js:167-178).  None when the result is infinity
+        (Z == 0), where the reference's getX would throw on invm(0)."""
+        X, Z = self.mul(x, k)
+        if Z % self.p == 0:
+            return None
+        return X * pow(Z, -1, self.p) % self.p
+
+
+# --------------------------------------------------------------------------
+# Presets -- lib/elliptic/curves.js:43-206, loaded from the fixture that
+# tools/gen_golden.js dumped out of the reference (tests/golden/curves.json)
+# so that no constant here is hand-typed.
+# --------------------------------------------------------------------------
+
+_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests",
+                       "golden", "curves.json")
+_CACHE: dict = {}
+
+
+def _signed_hex(s: str) -> int:
+    return -int(s[1:], 16) if s.startswith("-") else int(s, 16)
+
+
+def get_curve(name: str, precompute: bool = True):
+    """Instantiate a preset the way `new EC(name)` / `new EDDSA(name)` leaves
+    it: G carries naf(8)+doubles(4) tables (ec/index.js:36, eddsa/index.js:19;
+    secp256k1 ships them precomputed, curves.js:169-205)."""
+    key = (name, precompute)
+    if key in _CACHE:
+        return _CACHE[key]
+    with open(_GOLDEN) as f:
+        c = json.load(f)[name]
+    I = lambda s: int(s, 16)
+    if c["type"] == "short":
+        endo = None
+        if "beta" in c:
+            endo = {"beta": I(c["beta"]), "lambda": I(c["lambda"]),
+                    "basis": [(_signed_hex(v["a"]), _signed_hex(v["b"])) for v in c["basis"]]}
+        cur = ShortCurve(name, I(c["p"]), I(c["a"]), I(c["b"]), I(c["n"]), I(c["gx"]),
+                         I(c["gy"]), endo)
+        if precompute:
+            cur.g.precompute(cur.n.bit_length() + 1)
+    elif c["type"] == "edwards":
+        cur = EdwardsCurve(name, I(c["p"]), I(c["a"]), I(c["d"]), I(c["n"]), I(c["gx"]),
+                           I(c["gy"]))
+        if precompute:
+            cur.g.precompute(cur.n.bit_length() + 1)
+    else:
+        cur = MontCurve(name, I(c["p"]), I(c["a"]), I(c["b"]), I(c["gx"]),
+                        I(c["n"]) if "n" in c else None)
+    _CACHE[key] = cur
+    return cur
+
+
+SHORT_CURVES = ["secp256k1", "p192", "p224", "p256", "p384", "p521"]
+ALL_CURVES = SHORT_CURVES + ["ed25519", "curve25519"]

@@ -1,0 +1,119 @@
+"""Pins oracle/ec_oracle.py to the reference: every fixture under
+tests/golden/ was produced by the reference bundle itself
+(tools/gen_golden.js), including the calls its own mocha suite makes into the
+hot path.  CPU only."""
+import pytest
+
+from oracle import ec_oracle as O
+from golden_util import I, load, mul_cases, res_xy, verify_cases
+
+
+def _aff(pt):
+    return None if pt.inf else (pt.x, pt.y)
+
+
+@pytest.mark.parametrize("name", O.SHORT_CURVES)
+def test_short_mul_matches_reference(name):
+    cur = O.get_curve(name)
+    n_checked = 0
+    for c in mul_cases(name):
+        want = res_xy(c["r"])
+        if c["op"] == "fixed":
+            got = _aff(cur.g.mul(I(c["k"])))
+        elif c["op"] == "var":
+            P = cur.point(I(c["px"]), I(c["py"]))
+            if (P.x, P.y) == (cur.g.x, cur.g.y) and c.get("captured"):
+                P = cur.g                         # reference used its tabled G
+            got = _aff(P.mul(I(c["k"])))
+        else:
+            A = cur.point(I(c["p1x"]), I(c["p1y"]))
+            if (A.x, A.y) == (cur.g.x, cur.g.y):
+                A = cur.g
+            B = cur.point(I(c["p2x"]), I(c["p2y"]))
+            got = _aff(A.mul_add(I(c["k1"]), B, I(c["k2"])))
+        assert got == want, (name, c)
+        n_checked += 1
+    assert n_checked > 50
+
+
+@pytest.mark.parametrize("name", O.SHORT_CURVES)
+def test_fixed_and_var_paths_agree(name):
+    """curve-test.js:170-197: precomputed-G comb vs fresh-G ladder."""
+    cur = O.get_curve(name)
+    fresh = cur.point(cur.g.x, cur.g.y)
+    for c in load("mul_%s.json" % name):
+        if c["op"] != "fixed":
+            continue
+        k = I(c["k"])
+        assert _aff(fresh.mul(k)) == res_xy(c["r"])
+
+
+@pytest.mark.parametrize("name", O.SHORT_CURVES)
+def test_ecdsa_verify_matches_reference(name):
+    cur = O.get_curve(name)
+    seen = {True: 0, False: 0}
+    for c in verify_cases(name):
+        Q = cur.point(I(c["qx"]), I(c["qy"]))
+        got = O.ecdsa_verify(cur, I(c["z"]), len(c["z"]) // 2, I(c["r"]), I(c["s"]), Q,
+                             c.get("msgBitLength"))
+        assert got == c["ok"], (name, c)
+        seen[c["ok"]] += 1
+    assert seen[True] > 5 and seen[False] > 3
+
+
+def test_ed25519_matches_reference():
+    cur = O.get_curve("ed25519")
+    n = 0
+    for c in mul_cases("ed25519"):
+        want = res_xy(c["r"])
+        if c["op"] == "fixed":
+            R = cur.g.mul(I(c["k"]))
+        elif c["op"] == "var":
+            P = cur.point(I(c["px"]), I(c["py"]))
+            if (P.x, P.y) == (cur.g.x, cur.g.y) and c.get("captured"):
+                P = cur.g
+            R = P.mul(I(c["k"]))
+        else:
+            B = cur.point(I(c["p2x"]), I(c["p2y"]))
+            R = cur.g.mul_add(I(c["k1"]), B, I(c["k2"]))
+        got = None if R.is_infinity() else R.normalized()
+        assert got == want, c
+        n += 1
+    assert n > 100
+
+
+def test_curve25519_matches_reference():
+    cur = O.get_curve("curve25519")
+    for c in mul_cases("curve25519"):
+        want = res_xy(c["r"])
+        x = cur.mul_x(I(c["px"]), I(c["k"]))
+        got = None if x is None else (x,)
+        assert got == want, c
+
+
+def test_recoding_properties():
+    import random
+    rnd = random.Random(7)
+    for _ in range(200):
+        k = rnd.getrandbits(256)
+        for w in (1, 4, 7, 8):
+            naf = O.get_naf(k, w, 256)
+            assert sum(d << i for i, d in enumerate(naf)) == k
+            assert all(d == 0 or (d & 1 and abs(d) < (1 << w)) for d in naf)
+        a, b = rnd.getrandbits(128), rnd.getrandbits(128)
+        j = O.get_jsf(a, b)
+        assert sum(d << i for i, d in enumerate(j[0])) == a
+        assert sum(d << i for i, d in enumerate(j[1])) == b
+
+
+def test_endo_split_recomposes():
+    """curve-test.js:163-167."""
+    import random
+    cur = O.get_curve("secp256k1")
+    lam = cur.endo["lambda"]
+    rnd = random.Random(11)
+    for _ in range(300):
+        k = rnd.getrandbits(256)
+        k1, k2 = cur.endo_split(k)
+        assert (k1 + k2 * lam - k) % cur.n == 0
+        assert abs(k1).bit_length() <= 129 and abs(k2).bit_length() <= 129

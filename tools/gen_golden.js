@@ -407,11 +407,19 @@ function captureFromReferenceTests() {
         var kk = this.keyFromPublic(key, enc);
         var sg = new ref.Signature(signature, 'hex');
         var z = new BN(msg, 16);
+        // effective byte length exactly as _truncateToN derives it
+        // (ec/index.js:82-96): BN/number -> value length, array-like ->
+        // .length, anything else -> hex string length
+        var zb;
+        if (BN.isBN(msg) || typeof msg === 'number') zb = z.byteLength();
+        else if (typeof msg === 'object') zb = msg.length;
+        else zb = (msg.toString().length + 1) >>> 1;
         var NL = this.n.byteLength();
-        if (!z.isNeg() && z.byteLength() <= 66 && sg.r.byteLength() <= NL &&
+        if (!z.isNeg() && zb <= 66 && zb >= z.byteLength() && zb > 0 &&
+            sg.r.byteLength() <= NL &&
             sg.s.byteLength() <= NL && !sg.r.isNeg() && !sg.s.isNeg()) {
           var L = flen(this.curve);
-          var o = { z: hex(z, Math.max(z.byteLength(), 1)), r: hex(sg.r, NL),
+          var o = { z: hex(z, zb), r: hex(sg.r, NL),
             s: hex(sg.s, NL), qx: hex(kk.getPublic().getX(), L),
             qy: hex(kk.getPublic().getY(), L), ok: res };
           if (options && options.msgBitLength)
