@@ -1,0 +1,67 @@
+"""ctypes binding of the C ABI declared in include/ellgpu.h.
+
+`load()` opens the in-tree libellgpu.so (built by __graft_entry__.build() /
+elliptic_amd/build.py with hipcc for gfx950).  There is no fallback of any
+kind: if the library is missing this raises, and if it loads on a machine
+without a usable MI355X, `Context()` raises from ellgpu_ctx_create.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "lib", "libellgpu.so")
+
+c_u8p = ctypes.c_void_p      # raw addresses (numpy .ctypes.data / torch .data_ptr())
+
+_SIGS = {
+    "ellgpu_version": (ctypes.c_int, []),
+    "ellgpu_last_error": (ctypes.c_char_p, []),
+    "ellgpu_curve_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "ellgpu_curve_field_bytes": (ctypes.c_int, [ctypes.c_int]),
+    "ellgpu_curve_order_bytes": (ctypes.c_int, [ctypes.c_int]),
+    "ellgpu_device_count": (ctypes.c_int, []),
+    "ellgpu_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "ellgpu_ctx_destroy": (None, [ctypes.c_void_p]),
+    "ellgpu_ctx_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "ellgpu_ctx_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]),
+    "ellgpu_mul_fixed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p]),
+    "ellgpu_mul_var": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "ellgpu_mul_add2": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "ellgpu_ecdsa_verify": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "ellgpu_x25519_ladder": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "ellgpu_mul_fixed_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
+    "ellgpu_mul_var_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
+    "ellgpu_mul_add2_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
+    "ellgpu_ecdsa_verify_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
+    "ellgpu_x25519_ladder_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
+    "ellgpu_probe_valu": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+}
+
+# every symbol include/ellgpu.h declares (tests check the .so exports them all)
+SYMBOLS = sorted(_SIGS)
+
+
+class EllgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ellgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load(path=None, optional=()):
+    path = path or os.environ.get("ELLGPU_LIB") or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise ImportError(
+            "libellgpu.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if name in optional:
+                continue
+            raise
+        fn.restype = res
+        fn.argtypes = args
+    lib._path = path
+    return lib

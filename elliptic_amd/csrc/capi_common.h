@@ -1,0 +1,143 @@
+// ellgpu -- the extern "C" surface of include/ellgpu.h, written once over
+// Engine<ELL_BACKEND>.  Included by capi.hip (ELL_BACKEND = HipBackend, the
+// product) and by tests/hostsim/hostsim.cpp (ELL_BACKEND = LoopBackend, CPU
+// unit-test build of the same code).  The including file must define
+//   ELL_BACKEND            backend type
+//   ell_backend_create(int device, ELL_BACKEND* out, std::string* err) -> int
+//   ell_backend_destroy(ELL_BACKEND*)
+//   ell_device_count() -> int
+// before including this header.
+#pragma once
+
+#include "../../include/ellgpu.h"
+#include "engine.h"
+
+struct ellgpu_ctx {
+  ell::Engine<ELL_BACKEND>* eng;
+};
+
+static thread_local std::string g_last_error;
+
+static int set_err(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+static int finish(ellgpu_ctx* ctx, int rc) {
+  if (rc) g_last_error = ctx->eng->err.empty() ? "ellgpu error" : ctx->eng->err;
+  return rc;
+}
+
+extern "C" {
+
+int ellgpu_version(void) { return ELLGPU_VERSION; }
+const char* ellgpu_last_error(void) { return g_last_error.c_str(); }
+
+int ellgpu_curve_id(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < ell::CURVE_COUNT; i++)
+    if (strcmp(name, ell::curve_info(i)->name) == 0) return i;
+  return -1;
+}
+int ellgpu_curve_field_bytes(int curve) {
+  const ell::CurveInfo* ci = ell::curve_info(curve);
+  return ci ? ci->field_bytes : ELLGPU_E_ARG;
+}
+int ellgpu_curve_order_bytes(int curve) {
+  const ell::CurveInfo* ci = ell::curve_info(curve);
+  return ci ? ci->order_bytes : ELLGPU_E_ARG;
+}
+int ellgpu_device_count(void) { return ell_device_count(); }
+
+int ellgpu_ctx_create(int device, ellgpu_ctx** out) {
+  if (!out) return set_err(ELLGPU_E_ARG, "null out pointer");
+  *out = nullptr;
+  ELL_BACKEND bk;
+  std::string err;
+  int rc = ell_backend_create(device, &bk, &err);
+  if (rc) return set_err(rc, err);
+  ellgpu_ctx* c = new ellgpu_ctx;
+  c->eng = new ell::Engine<ELL_BACKEND>(bk);
+  *out = c;
+  return ELLGPU_OK;
+}
+void ellgpu_ctx_destroy(ellgpu_ctx* ctx) {
+  if (!ctx) return;
+  ctx->eng->bk.sync();
+  ELL_BACKEND bk = ctx->eng->bk;
+  delete ctx->eng;
+  ell_backend_destroy(&bk);
+  delete ctx;
+}
+int ellgpu_ctx_synchronize(ellgpu_ctx* ctx) {
+  if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  return finish(ctx, ctx->eng->bk.sync());
+}
+int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n) {
+  if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  ctx->eng->bk.use_stream(nullptr);
+  return finish(ctx, ctx->eng->reserve(curve, n));
+}
+
+#define ELL_ENTER(ctx, stream)                                      \
+  if (!ctx) return set_err(ELLGPU_E_ARG, "null context");           \
+  ctx->eng->err.clear();                                            \
+  ctx->eng->bk.use_stream(stream);
+
+int ellgpu_mul_fixed(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, uint8_t* out_xy,
+                     uint8_t* out_inf) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->mul_fixed_host(curve, n, k, out_xy, out_inf));
+}
+int ellgpu_mul_var(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, const uint8_t* in_xy,
+                   uint8_t* out_xy, uint8_t* out_inf) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->mul_var_host(curve, n, k, in_xy, out_xy, out_inf));
+}
+int ellgpu_mul_add2(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1, const uint8_t* p1_xy,
+                    const uint8_t* k2, const uint8_t* p2_xy, uint8_t* out_xy, uint8_t* out_inf) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->mul_add2_host(curve, n, k1, p1_xy, k2, p2_xy, out_xy, out_inf));
+}
+int ellgpu_ecdsa_verify(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                        int msg_bits, const uint8_t* r, const uint8_t* s, const uint8_t* pub_xy,
+                        uint8_t* out_ok) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->ecdsa_verify_host(curve, n, hash, hash_len, msg_bits, r, s, pub_xy,
+                                                 out_ok));
+}
+int ellgpu_x25519_ladder(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* in_x,
+                         uint8_t* out_x, uint8_t* out_inf) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->x25519_host(n, k, in_x, out_x, out_inf));
+}
+
+int ellgpu_mul_fixed_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, uint8_t* out_xy,
+                         uint8_t* out_inf, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->mul_fixed_dev(curve, n, k, out_xy, out_inf));
+}
+int ellgpu_mul_var_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
+                       const uint8_t* in_xy, uint8_t* out_xy, uint8_t* out_inf, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->mul_var_dev(curve, n, k, in_xy, out_xy, out_inf));
+}
+int ellgpu_mul_add2_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1,
+                        const uint8_t* p1_xy, const uint8_t* k2, const uint8_t* p2_xy,
+                        uint8_t* out_xy, uint8_t* out_inf, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->mul_add2_dev(curve, n, k1, p1_xy, k2, p2_xy, out_xy, out_inf));
+}
+int ellgpu_ecdsa_verify_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash,
+                            int hash_len, int msg_bits, const uint8_t* r, const uint8_t* s,
+                            const uint8_t* pub_xy, uint8_t* out_ok, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->ecdsa_verify_dev(curve, n, hash, hash_len, msg_bits, r, s, pub_xy,
+                                                out_ok));
+}
+int ellgpu_x25519_ladder_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* in_x,
+                             uint8_t* out_x, uint8_t* out_inf, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->x25519_dev(n, k, in_x, out_x, out_inf));
+}
+
+}  // extern "C"

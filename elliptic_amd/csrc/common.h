@@ -1,0 +1,238 @@
+// ellgpu -- common definitions shared by every device header.
+//
+// All arithmetic code in csrc/*.h is written as plain C++ templates marked
+// ELL_HD.  hipcc compiles them for gfx950 (the product: libellgpu.so); the
+// CPU-only unit tests additionally compile the very same headers with g++
+// (tests/hostsim/) to check the kernels' logic item-by-item against the
+// oracle without a GPU.  That host build is test infrastructure -- it is not
+// linked into libellgpu.so, which has no CPU fallback.
+#pragma once
+
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ELL_HD __host__ __device__ __forceinline__
+#define ELL_HD_NOINLINE __host__ __device__ __noinline__
+#define ELL_UNROLL _Pragma("unroll")
+#define ELL_NOUNROLL _Pragma("nounroll")
+#else
+#define ELL_HD inline
+#define ELL_HD_NOINLINE __attribute__((noinline))
+#define ELL_UNROLL
+#define ELL_NOUNROLL
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ELL_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#else
+#define ELL_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#endif
+
+namespace ell {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef uint8_t u8;
+
+// ---- multi-limb primitives (little-endian 32-bit limbs) -------------------
+
+// r = a + b, returns carry out
+template <int L>
+ELL_HD u32 bn_add(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L]) {
+  u64 c = 0;
+  ELL_UNROLL
+  for (int i = 0; i < L; i++) {
+    c += (u64)a[i] + b[i];
+    r[i] = (u32)c;
+    c >>= 32;
+  }
+  return (u32)c;
+}
+
+// r = a - b, returns borrow out (0/1)
+template <int L>
+ELL_HD u32 bn_sub(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L]) {
+  u32 br = 0;
+  ELL_UNROLL
+  for (int i = 0; i < L; i++) {
+    u64 t = (u64)a[i] - b[i] - br;
+    r[i] = (u32)t;
+    br = (u32)(t >> 63);
+  }
+  return br;
+}
+
+// a >= b ?
+template <int L>
+ELL_HD bool bn_geq(const u32 (&a)[L], const u32 (&b)[L]) {
+  u32 br = 0;
+  ELL_UNROLL
+  for (int i = 0; i < L; i++) {
+    u64 t = (u64)a[i] - b[i] - br;
+    br = (u32)(t >> 63);
+  }
+  return br == 0;
+}
+
+template <int L>
+ELL_HD bool bn_is_zero(const u32 (&a)[L]) {
+  u32 o = 0;
+  ELL_UNROLL
+  for (int i = 0; i < L; i++) o |= a[i];
+  return o == 0;
+}
+
+template <int L>
+ELL_HD bool bn_eq(const u32 (&a)[L], const u32 (&b)[L]) {
+  u32 o = 0;
+  ELL_UNROLL
+  for (int i = 0; i < L; i++) o |= a[i] ^ b[i];
+  return o == 0;
+}
+
+template <int L>
+ELL_HD void bn_copy(u32 (&r)[L], const u32 (&a)[L]) {
+  ELL_UNROLL
+  for (int i = 0; i < L; i++) r[i] = a[i];
+}
+
+template <int L>
+ELL_HD void bn_zero(u32 (&r)[L]) {
+  ELL_UNROLL
+  for (int i = 0; i < L; i++) r[i] = 0;
+}
+
+// r = c ? a : b   (branch-free; compiles to v_cndmask)
+template <int L>
+ELL_HD void bn_select(u32 (&r)[L], bool c, const u32 (&a)[L], const u32 (&b)[L]) {
+  ELL_UNROLL
+  for (int i = 0; i < L; i++) r[i] = c ? a[i] : b[i];
+}
+
+// full product r[0..LA+LB) = a * b   (operand scanning; one v_mad_u64_u32 per
+// partial product, the 64-bit accumulator carries the row's running carry)
+template <int LA, int LB>
+ELL_HD void bn_mul_wide(u32 (&r)[LA + LB], const u32 (&a)[LA], const u32 (&b)[LB]) {
+  {
+    u32 carry = 0;
+    ELL_UNROLL
+    for (int j = 0; j < LB; j++) {
+      u64 t = (u64)a[0] * b[j] + carry;
+      r[j] = (u32)t;
+      carry = (u32)(t >> 32);
+    }
+    r[LB] = carry;
+  }
+  ELL_UNROLL
+  for (int i = 1; i < LA; i++) {
+    u32 carry = 0;
+    ELL_UNROLL
+    for (int j = 0; j < LB; j++) {
+      u64 t = (u64)a[i] * b[j] + r[i + j] + carry;
+      r[i + j] = (u32)t;
+      carry = (u32)(t >> 32);
+    }
+    r[i + LB] = carry;
+  }
+}
+
+// full square r[0..2L) = a^2: off-diagonal products once, doubled, plus the
+// diagonal (L(L-1)/2 + L multiplies instead of L^2)
+template <int L>
+ELL_HD void bn_sqr_wide(u32 (&r)[2 * L], const u32 (&a)[L]) {
+  ELL_UNROLL
+  for (int i = 0; i < 2 * L; i++) r[i] = 0;
+  // off-diagonal: sum_{i<j} a_i a_j 2^(32(i+j))
+  ELL_UNROLL
+  for (int i = 0; i < L - 1; i++) {
+    u32 carry = 0;
+    ELL_UNROLL
+    for (int j = i + 1; j < L; j++) {
+      u64 t = (u64)a[i] * a[j] + r[i + j] + carry;
+      r[i + j] = (u32)t;
+      carry = (u32)(t >> 32);
+    }
+    r[i + L] = carry;
+  }
+  // double
+  {
+    u32 top = 0;
+    ELL_UNROLL
+    for (int i = 1; i < 2 * L; i++) {
+      u32 v = r[i];
+      r[i] = (v << 1) | top;
+      top = v >> 31;
+    }
+  }
+  // add diagonal squares
+  {
+    u32 carry = 0;
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) {
+      u64 t = (u64)a[i] * a[i] + r[2 * i] + carry;
+      r[2 * i] = (u32)t;
+      u64 u = (u64)r[2 * i + 1] + (u32)(t >> 32);
+      r[2 * i + 1] = (u32)u;
+      carry = (u32)(u >> 32);
+    }
+  }
+}
+
+// ---- byte <-> limb conversion (big-endian bytes at the API) ---------------
+
+ELL_HD u32 load_be32(const u8* p) {
+  return ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3];
+}
+
+ELL_HD u32 bswap32(u32 v) { return __builtin_bswap32(v); }
+
+// nb bytes big-endian -> L limbs little-endian (nb <= 4L; high limbs zero).
+// When nb is a multiple of 4 and p is 4-byte aligned (every fixed-width field
+// of the C ABI except the 66-byte p521 ones) this is L dword loads + bswaps.
+template <int L>
+ELL_HD void load_be(u32 (&r)[L], const u8* p, int nb) {
+  if ((nb & 3) == 0 && (((uintptr_t)p) & 3) == 0) {
+    const u32* w = (const u32*)p;
+    int nw = nb >> 2;
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) r[i] = (i < nw) ? bswap32(w[nw - 1 - i]) : 0u;
+    return;
+  }
+  ELL_UNROLL
+  for (int i = 0; i < L; i++) {
+    u32 v = 0;
+    ELL_UNROLL
+    for (int b = 0; b < 4; b++) {
+      int idx = nb - 1 - (4 * i + b);          // byte of weight 2^(8(4i+b))
+      if (idx >= 0) v |= (u32)p[idx] << (8 * b);
+    }
+    r[i] = v;
+  }
+}
+
+template <int L>
+ELL_HD void store_be(u8* p, const u32 (&a)[L], int nb) {
+  if ((nb & 3) == 0 && (((uintptr_t)p) & 3) == 0) {
+    u32* w = (u32*)p;
+    int nw = nb >> 2;
+    ELL_UNROLL
+    for (int i = 0; i < L; i++)
+      if (i < nw) w[nw - 1 - i] = bswap32(a[i]);
+    return;
+  }
+  ELL_UNROLL
+  for (int i = 0; i < L; i++) {
+    ELL_UNROLL
+    for (int b = 0; b < 4; b++) {
+      int idx = nb - 1 - (4 * i + b);
+      if (idx >= 0) p[idx] = (u8)(a[i] >> (8 * b));
+    }
+  }
+}
+
+// little-endian bytes (ed25519 / x25519 wire order is handled by the host
+// layer; the C ABI is big-endian everywhere, see include/ellgpu.h)
+
+}  // namespace ell

@@ -1,0 +1,52 @@
+// ellgpu -- curve descriptions (compile-time traits) for the reference's
+// short-Weierstrass presets (lib/elliptic/curves.js:43-134,176-206).
+#pragma once
+
+#include "curve_consts.h"
+#include "fp.h"
+
+namespace ell {
+
+// C-ABI curve ids (include/ellgpu.h)
+enum CurveId {
+  CURVE_SECP256K1 = 0,
+  CURVE_P192 = 1,
+  CURVE_P224 = 2,
+  CURVE_P256 = 3,
+  CURVE_P384 = 4,
+  CURVE_P521 = 5,
+  CURVE_ED25519 = 6,
+  CURVE_CURVE25519 = 7,
+  CURVE_COUNT = 8
+};
+
+struct CvSecp256k1 {
+  typedef FpK256 F;
+  typedef FpMont<consts::SECP256K1_N> Fn;
+  typedef consts::SECP256K1_C C;
+  static constexpr int A_KIND = 0;
+  static constexpr bool ENDO = true;
+  static constexpr int ID = CURVE_SECP256K1;
+  ELL_HD static typename F::El gx() { typename F::El r; for (int i = 0; i < 8; i++) r.v[i] = C::gx_plain[i]; return r; }
+  ELL_HD static typename F::El gy() { typename F::El r; for (int i = 0; i < 8; i++) r.v[i] = C::gy_plain[i]; return r; }
+};
+
+template <class CP, class CN, class CC, int ID_>
+struct CvNist {
+  typedef FpMont<CP> F;
+  typedef FpMont<CN> Fn;
+  typedef CC C;
+  static constexpr int A_KIND = 3;
+  static constexpr bool ENDO = false;
+  static constexpr int ID = ID_;
+  ELL_HD static typename F::El gx() { typename F::El r; for (int i = 0; i < F::L; i++) r.v[i] = C::gx_mont[i]; return r; }
+  ELL_HD static typename F::El gy() { typename F::El r; for (int i = 0; i < F::L; i++) r.v[i] = C::gy_mont[i]; return r; }
+};
+
+typedef CvNist<consts::P192_P, consts::P192_N, consts::P192_C, CURVE_P192> CvP192;
+typedef CvNist<consts::P224_P, consts::P224_N, consts::P224_C, CURVE_P224> CvP224;
+typedef CvNist<consts::P256_P, consts::P256_N, consts::P256_C, CURVE_P256> CvP256;
+typedef CvNist<consts::P384_P, consts::P384_N, consts::P384_C, CURVE_P384> CvP384;
+typedef CvNist<consts::P521_P, consts::P521_N, consts::P521_C, CURVE_P521> CvP521;
+
+}  // namespace ell

@@ -1,0 +1,271 @@
+// ellgpu -- ed25519 (twisted Edwards, a = -1) in extended coordinates.
+//
+// Replaces lib/elliptic/curve/edwards.js Point#mul / mulAdd / jmulAdd
+// (:362-375) and the base.js ladders they call, plus normalize (:377-390):
+//   dbl       <- _extDbl (edwards.js:174-205, dbl-2008-hwcd, 4M+4S)
+//   add       <- _extAdd (edwards.js:279-309, add-2008-hwcd-3, 8M) with the
+//                second operand pre-transformed to (Y+X, Y-X, 2Z, 2dT)
+// The a = -1 addition law is complete on ed25519 (d is a non-square), so a
+// lane never needs an exceptional branch: identity, doubling and inverse pairs
+// all come out of the same formula.  Ladder shape as in ladder.h: signed 4-bit
+// fixed windows for a variable base, 8-bit comb for G.
+#pragma once
+
+#include "curve_consts.h"
+#include "ladder.h"
+
+namespace ell {
+
+struct EdWork {
+  typedef Fp25519 F;
+  typedef F::El El;
+  typedef consts::ED25519_C C;
+  static constexpr int L = 8;
+  static constexpr int BYTES = 32;
+  static constexpr int NNIB = 64;
+  static constexpr int NWIN = 65;              // 64 signed windows + the carry window
+  static constexpr int COMB_W = 32;
+  static constexpr int COMB_ENTRIES = 32 * 255;
+
+  // Extended point (X, Y, Z, T) -- or, for table entries, the "cached" form
+  // (Y+X, Y-X, 2Z, 2dT) stored in the same four slots.
+  struct P {
+    El a, b, c, d;
+  };
+
+  ELL_HD static El const_dd() {
+    El r;
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) r.v[i] = C::dd[i];
+    return r;
+  }
+  ELL_HD static P identity() {
+    P r; r.a = F::zero(); r.b = F::one(); r.c = F::one(); r.d = F::zero(); return r;
+  }
+  ELL_HD static P from_affine(const El& x, const El& y) {
+    P r; r.a = x; r.b = y; r.c = F::one(); r.d = F::mul(x, y); return r;
+  }
+  ELL_HD static P to_cached(const P& p) {
+    P r;
+    r.a = F::add(p.b, p.a);
+    r.b = F::sub(p.b, p.a);
+    r.c = F::dbl(p.c);
+    r.d = F::mul(p.d, const_dd());
+    return r;
+  }
+  ELL_HD static P cached_identity() {
+    P r; r.a = F::one(); r.b = F::one(); r.c = F::dbl(F::one()); r.d = F::zero(); return r;
+  }
+  // -Q for a cached Q: swap (Y+X, Y-X), negate 2dT
+  ELL_HD static P cached_cneg(const P& q, bool neg) {
+    P r;
+    r.a = fe_select<F>(neg, q.b, q.a);
+    r.b = fe_select<F>(neg, q.a, q.b);
+    r.c = q.c;
+    r.d = fe_select<F>(neg, F::neg(q.d), q.d);
+    return r;
+  }
+  ELL_HD static P select(bool c, const P& x, const P& y) {
+    P r;
+    r.a = fe_select<F>(c, x.a, y.a);
+    r.b = fe_select<F>(c, x.b, y.b);
+    r.c = fe_select<F>(c, x.c, y.c);
+    r.d = fe_select<F>(c, x.d, y.d);
+    return r;
+  }
+  ELL_HD static P dbl(const P& p) {
+    El A = F::sqr(p.a);
+    El B = F::sqr(p.b);
+    El Cc = F::dbl(F::sqr(p.c));
+    El D = F::neg(A);
+    El E = F::sub(F::sub(F::sqr(F::add(p.a, p.b)), A), B);
+    El G = F::add(D, B);
+    El Ff = F::sub(G, Cc);
+    El H = F::sub(D, B);
+    P r;
+    r.a = F::mul(E, Ff);
+    r.b = F::mul(G, H);
+    r.d = F::mul(E, H);
+    r.c = F::mul(Ff, G);
+    return r;
+  }
+  // p (extended) + q (cached); !do_add returns p
+  ELL_HD static P add(const P& p, const P& q, bool do_add = true) {
+    El A = F::mul(F::sub(p.b, p.a), q.b);
+    El B = F::mul(F::add(p.b, p.a), q.a);
+    El Cc = F::mul(p.d, q.d);
+    El D = F::mul(p.c, q.c);
+    El E = F::sub(B, A);
+    El Ff = F::sub(D, Cc);
+    El G = F::add(D, Cc);
+    El H = F::add(B, A);
+    P r;
+    r.a = F::mul(E, Ff);
+    r.b = F::mul(G, H);
+    r.d = F::mul(E, H);
+    r.c = F::mul(Ff, G);
+    return select(do_add, r, p);
+  }
+
+  ELL_HD static El load_fe(const u8* p) {
+    u32 t[8];
+    load_be<8>(t, p, 32);
+    return F::from_plain(t);
+  }
+  ELL_HD static P load_affine(const u8* xy, size_t i) {
+    El x = load_fe(xy + i * 64);
+    El y = load_fe(xy + i * 64 + 32);
+    return from_affine(x, y);
+  }
+  ELL_HD static void store_ext(u32* ext, size_t n, size_t i, const P& p) {
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++) {
+      ext[(size_t)(0 * 8 + l) * n + i] = p.a.v[l];
+      ext[(size_t)(1 * 8 + l) * n + i] = p.b.v[l];
+      ext[(size_t)(2 * 8 + l) * n + i] = p.c.v[l];
+    }
+  }
+
+  // tbl[j-1] = cached(j*P), j = 1..8
+  ELL_HD static void build_table8(P* tbl, const P& p) {
+    P pc = to_cached(p);
+    tbl[0] = p;
+    ELL_NOUNROLL
+    for (int j = 2; j <= 8; j++) {
+      P t;
+      if (j & 1) t = add(tbl[j - 2], pc);
+      else t = dbl(tbl[j / 2 - 1]);
+      tbl[j - 1] = t;
+    }
+    ELL_NOUNROLL
+    for (int j = 0; j < 8; j++) tbl[j] = to_cached(tbl[j]);
+  }
+
+  template <int NS>
+  ELL_HD static P run_w4(const DigitStore& ds, const P* tbl) {
+    P acc = identity();
+    ELL_NOUNROLL
+    for (int w = NWIN - 1; w >= 0; w--) {
+      if (w != NWIN - 1) {
+        ELL_NOUNROLL
+        for (int j = 0; j < 4; j++) acc = dbl(acc);
+      }
+      ELL_NOUNROLL
+      for (int s = 0; s < NS; s++) {
+        int d = ds.get(w * NS + s);
+        int ad = d < 0 ? -d : d;
+        int e = ad ? ad - 1 : 0;
+        P q = cached_cneg(tbl[s * 8 + e], d < 0);
+        acc = add(acc, q, ad != 0);
+      }
+    }
+    return acc;
+  }
+
+  ELL_HD static P comb_mul(const u32 (&k)[8], const P* comb) {
+    u32 kk[8];
+    bn_copy<8>(kk, k);
+    P acc = identity();
+    ELL_NOUNROLL
+    for (int w = 0; w < COMB_W; w++) {
+      u32 d = kk[0] & 255u;
+      ELL_UNROLL
+      for (int i = 0; i < 7; i++) kk[i] = (kk[i] >> 8) | (kk[i + 1] << 24);
+      kk[7] >>= 8;
+      u32 e = d ? d - 1 : 0;
+      acc = add(acc, comb[w * 255 + e], d != 0);
+    }
+    return acc;
+  }
+
+  // ---- work items ----------------------------------------------------------------
+  ELL_HD static void mul_var(size_t i, size_t n, const u8* ks, const u8* xy, P* tbl_all,
+                             const DigitStore& ds, u32* ext) {
+    u32 k[8];
+    load_be<8>(k, ks + i * 32, 32);
+    P p = load_affine(xy, i);
+    P* tbl = tbl_all + i * 8;
+    build_table8(tbl, p);
+    recode_w4<8, NNIB, true>(k, ds, 0, 1);
+    store_ext(ext, n, i, run_w4<1>(ds, tbl));
+  }
+  ELL_HD static void mul_fixed(size_t i, size_t n, const u8* ks, const P* comb, u32* ext) {
+    u32 k[8];
+    load_be<8>(k, ks + i * 32, 32);
+    store_ext(ext, n, i, comb_mul(k, comb));
+  }
+  ELL_HD static void mul_add_g(size_t i, size_t n, const u8* k1s, const u8* k2s, const u8* xy2,
+                               const P* comb, P* tbl_all, const DigitStore& ds, u32* ext) {
+    u32 k1[8], k2[8];
+    load_be<8>(k1, k1s + i * 32, 32);
+    load_be<8>(k2, k2s + i * 32, 32);
+    P p2 = load_affine(xy2, i);
+    P* tbl = tbl_all + i * 8;
+    build_table8(tbl, p2);
+    recode_w4<8, NNIB, true>(k2, ds, 0, 1);
+    P b = run_w4<1>(ds, tbl);
+    P a = comb_mul(k1, comb);
+    store_ext(ext, n, i, add(a, to_cached(b)));
+  }
+  ELL_HD static void mul_add2(size_t i, size_t n, const u8* k1s, const u8* xy1, const u8* k2s,
+                              const u8* xy2, P* tbl_all, const DigitStore& ds, u32* ext) {
+    u32 k1[8], k2[8];
+    load_be<8>(k1, k1s + i * 32, 32);
+    load_be<8>(k2, k2s + i * 32, 32);
+    P* tbl = tbl_all + i * 16;
+    build_table8(tbl, load_affine(xy1, i));
+    build_table8(tbl + 8, load_affine(xy2, i));
+    recode_w4<8, NNIB, true>(k1, ds, 0, 2);
+    recode_w4<8, NNIB, true>(k2, ds, 1, 2);
+    store_ext(ext, n, i, run_w4<2>(ds, tbl));
+  }
+
+  // (X:Y:Z) -> affine (x, y) with one inversion per K items (normalize,
+  // edwards.js:377-390).  out_inf mirrors Point#isInfinity (edwards.js:167-172):
+  // x == 0 && y == 1.  raw != null stores cached(x, y, 1, xy) for the comb.
+  ELL_HD static void normalize(size_t t, size_t T, size_t n, int K, const u32* ext, u32* pre,
+                               u8* out_xy, u8* out_inf, P* raw) {
+    El acc = F::one();
+    ELL_NOUNROLL
+    for (int j = 0; j < K; j++) {
+      size_t i = t + (size_t)j * T;
+      if (i >= n) break;
+      El z;
+      ELL_UNROLL
+      for (int l = 0; l < 8; l++) z.v[l] = ext[(size_t)(2 * 8 + l) * n + i];
+      // Z == 0 cannot happen for a point on the curve (complete formulas); an
+      // off-curve input must still not poison the other K-1 items of the batch
+      z = fe_select<F>(F::is_zero(z), F::one(), z);
+      ELL_UNROLL
+      for (int l = 0; l < 8; l++) pre[(size_t)l * n + i] = acc.v[l];
+      acc = F::mul(acc, z);
+    }
+    El inv = F::inv(acc);
+    ELL_NOUNROLL
+    for (int j = K - 1; j >= 0; j--) {
+      size_t i = t + (size_t)j * T;
+      if (i >= n) continue;
+      El X, Y, Z, pr;
+      ELL_UNROLL
+      for (int l = 0; l < 8; l++) {
+        X.v[l] = ext[(size_t)(0 * 8 + l) * n + i];
+        Y.v[l] = ext[(size_t)(1 * 8 + l) * n + i];
+        Z.v[l] = ext[(size_t)(2 * 8 + l) * n + i];
+        pr.v[l] = pre[(size_t)l * n + i];
+      }
+      Z = fe_select<F>(F::is_zero(Z), F::one(), Z);
+      El zinv = F::mul(inv, pr);
+      inv = F::mul(inv, Z);
+      El x = F::mul(X, zinv);
+      El y = F::mul(Y, zinv);
+      if (out_xy) {
+        store_be<8>(out_xy + i * 64, x.v, 32);
+        store_be<8>(out_xy + i * 64 + 32, y.v, 32);
+      }
+      if (out_inf) out_inf[i] = (F::is_zero(x) && F::eq(y, F::one())) ? 1 : 0;
+      if (raw) raw[i] = to_cached(from_affine(x, y));
+    }
+  }
+};
+
+}  // namespace ell

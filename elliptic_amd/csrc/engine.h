@@ -1,0 +1,632 @@
+// ellgpu -- host-side engine: batch orchestration above the per-item work
+// functions.  Templated on a backend BK that supplies memory and launches:
+//
+//   HipBackend  (capi.hip)          hipMalloc / hipMemcpyAsync / kernel launches on
+//                                   one stream of one MI355X -- the product.
+//   LoopBackend (tests/hostsim)     malloc / memcpy / a for-loop over thread ids --
+//                                   CPU-only unit tests of the same code; never
+//                                   shipped, never selected at run time.
+//
+// A launch is `bk.launch(functor, nthreads)`: the functor's operator()(tid, ds)
+// runs once per thread id with a DigitStore of Fn::DS_PER_LANE bytes per lane.
+#pragma once
+
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "edwards.h"
+#include "mont.h"
+#include "work.h"
+
+namespace ell {
+
+enum { E_OK = 0, E_NODEVICE = -1, E_ARG = -2, E_HIP = -3, E_NOMEM = -4, E_UNSUPPORTED = -5 };
+
+// ---- functors (one per kernel) ------------------------------------------------
+template <class CV>
+struct FnMulVar {
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
+  size_t n; const u8* k; const u8* xy; typename W::J* tbl; u32* jac;
+  ELL_HD void operator()(size_t i, const DigitStore& ds) const {
+    if (i < n) W::mul_var(i, n, k, xy, tbl, ds, jac);
+  }
+};
+template <class CV>
+struct FnMulAdd2 {
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = W::NWIN * W::NSV * 2;
+  size_t n; const u8* k1; const u8* xy1; const u8* k2; const u8* xy2; typename W::J* tbl; u32* jac;
+  ELL_HD void operator()(size_t i, const DigitStore& ds) const {
+    if (i < n) W::mul_add2(i, n, k1, xy1, k2, xy2, tbl, ds, jac);
+  }
+};
+template <class CV>
+struct FnMulAddG {
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
+  size_t n; const u8* k1; const u8* k2; const u8* xy2; const typename W::A* comb;
+  typename W::J* tbl; u32* jac;
+  ELL_HD void operator()(size_t i, const DigitStore& ds) const {
+    if (i < n) W::mul_add_g_item(i, n, k1, k2, xy2, comb, tbl, ds, jac);
+  }
+};
+template <class CV>
+struct FnMulFixed {
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* k; const typename W::A* comb; u32* jac;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::mul_fixed(i, n, k, comb, jac);
+  }
+};
+template <class CV>
+struct FnNormalize {
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t T; size_t n; int K; const u32* jac; u32* pre; u8* out_xy; u8* out_inf;
+  typename W::A* raw;
+  ELL_HD void operator()(size_t t, const DigitStore&) const {
+    if (t < T) W::normalize(t, T, n, K, jac, pre, out_xy, out_inf, raw);
+  }
+};
+template <class CV>
+struct FnEcdsaPrep {
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t T; size_t n; int K; const u8* hash; int hash_len; int shift; const u8* r; const u8* s;
+  u32* pre; u32* u12; u8* valid;
+  ELL_HD void operator()(size_t t, const DigitStore&) const {
+    if (t < T) W::ecdsa_prep(t, T, n, K, hash, hash_len, shift, r, s, pre, u12, valid);
+  }
+};
+template <class CV>
+struct FnEcdsaMain {
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
+  size_t n; const u32* u12; const u8* valid; const u8* r; const u8* pub;
+  const typename W::A* comb; typename W::J* tbl; u8* ok;
+  ELL_HD void operator()(size_t i, const DigitStore& ds) const {
+    if (i < n) W::ecdsa_main(i, n, u12, valid, r, pub, comb, tbl, ds, ok);
+  }
+};
+
+// Edwards / Montgomery functors
+struct FnEdMulVar {
+  static constexpr int DS_PER_LANE = EdWork::NWIN;
+  size_t n; const u8* k; const u8* xy; EdWork::P* tbl; u32* ext;
+  ELL_HD void operator()(size_t i, const DigitStore& ds) const {
+    if (i < n) EdWork::mul_var(i, n, k, xy, tbl, ds, ext);
+  }
+};
+struct FnEdMulFixed {
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* k; const EdWork::P* comb; u32* ext;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) EdWork::mul_fixed(i, n, k, comb, ext);
+  }
+};
+struct FnEdMulAddG {
+  static constexpr int DS_PER_LANE = EdWork::NWIN;
+  size_t n; const u8* k1; const u8* k2; const u8* xy2; const EdWork::P* comb; EdWork::P* tbl;
+  u32* ext;
+  ELL_HD void operator()(size_t i, const DigitStore& ds) const {
+    if (i < n) EdWork::mul_add_g(i, n, k1, k2, xy2, comb, tbl, ds, ext);
+  }
+};
+struct FnEdMulAdd2 {
+  static constexpr int DS_PER_LANE = EdWork::NWIN * 2;
+  size_t n; const u8* k1; const u8* xy1; const u8* k2; const u8* xy2; EdWork::P* tbl; u32* ext;
+  ELL_HD void operator()(size_t i, const DigitStore& ds) const {
+    if (i < n) EdWork::mul_add2(i, n, k1, xy1, k2, xy2, tbl, ds, ext);
+  }
+};
+struct FnEdNormalize {
+  static constexpr int DS_PER_LANE = 0;
+  size_t T; size_t n; int K; const u32* ext; u32* pre; u8* out_xy; u8* out_inf; EdWork::P* raw;
+  ELL_HD void operator()(size_t t, const DigitStore&) const {
+    if (t < T) EdWork::normalize(t, T, n, K, ext, pre, out_xy, out_inf, raw);
+  }
+};
+struct FnX25519 {
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* k; const u8* x; u32* xz;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) MontWork::ladder(i, n, k, x, xz);
+  }
+};
+struct FnX25519Normalize {
+  static constexpr int DS_PER_LANE = 0;
+  size_t T; size_t n; int K; const u32* xz; u32* pre; u8* out_x; u8* out_inf;
+  ELL_HD void operator()(size_t t, const DigitStore&) const {
+    if (t < T) MontWork::normalize(t, T, n, K, xz, pre, out_x, out_inf);
+  }
+};
+
+// ---- curve metadata ----------------------------------------------------------
+struct CurveInfo {
+  const char* name;
+  int field_bytes;
+  int order_bytes;
+  int order_bits;
+};
+inline const CurveInfo* curve_info(int id) {
+  static const CurveInfo tab[CURVE_COUNT] = {
+      {"secp256k1", 32, 32, 256}, {"p192", 24, 24, 192}, {"p224", 28, 28, 224},
+      {"p256", 32, 32, 256},      {"p384", 48, 48, 384}, {"p521", 66, 66, 521},
+      {"ed25519", 32, 32, 253},   {"curve25519", 32, 32, 253}};
+  if (id < 0 || id >= CURVE_COUNT) return nullptr;
+  return &tab[id];
+}
+
+// ---- the engine ----------------------------------------------------------------
+template <class BK>
+class Engine {
+ public:
+  BK bk;
+  std::string err;
+  static constexpr int INV_BATCH = 16;        // items per field inversion (Montgomery's trick)
+  static constexpr size_t CHUNK = 1u << 21;   // max items per launch (bounds the scratch arena)
+
+  explicit Engine(const BK& b) : bk(b) {
+    for (int i = 0; i < CURVE_COUNT; i++) comb_[i] = nullptr;
+  }
+  ~Engine() {
+    for (int i = 0; i < CURVE_COUNT; i++)
+      if (comb_[i]) bk.free_(comb_[i]);
+    for (auto& s : scratch_)
+      if (s.p) bk.free_(s.p);
+    for (auto& s : staging_)
+      if (s.p) bk.free_(s.p);
+  }
+
+  // ---- scratch arena: a few grow-only device buffers ----------------------
+  struct Buf { void* p = nullptr; size_t cap = 0; };
+  enum { S_TBL = 0, S_JAC, S_PRE, S_U12, S_VALID, S_COUNT };
+  enum { G_IN0 = 0, G_IN1, G_IN2, G_IN3, G_IN4, G_OUT0, G_OUT1, G_COUNT };
+
+  void* grow(Buf& b, size_t bytes) {
+    if (bytes <= b.cap) return b.p;
+    if (b.p) { bk.sync(); bk.free_(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 8;
+    b.p = bk.alloc(want);
+    if (!b.p) { b.p = bk.alloc(bytes); want = bytes; }
+    if (!b.p) return nullptr;
+    b.cap = want;
+    return b.p;
+  }
+  void* scratch(int which, size_t bytes) { return grow(scratch_[which], bytes); }
+  void* staging(int which, size_t bytes) { return grow(staging_[which], bytes); }
+
+  int fail(int code, const char* msg) { err = msg; return code; }
+
+  // ---- fixed-base comb tables, built on the device with our own kernels ----
+  template <class CV>
+  int ensure_comb() {
+    typedef Work<CV> W;
+    if (comb_[CV::ID]) return E_OK;
+    const size_t n = W::COMB_ENTRIES;
+    const int B = W::BYTES;
+    std::vector<u8> ks(n * B, 0), pts(n * 2 * B, 0);
+    u8 g[2 * 66];
+    {
+      u32 gx[W::L], gy[W::L];
+      for (int i = 0; i < W::L; i++) { gx[i] = W::C::gx_plain[i]; gy[i] = W::C::gy_plain[i]; }
+      store_be<W::L>(g, gx, B);
+      store_be<W::L>(g + B, gy, B);
+    }
+    for (int w = 0; w < W::COMB_W; w++)
+      for (int d = 1; d <= 255; d++) {
+        size_t i = (size_t)w * 255 + (d - 1);
+        ks[i * B + (B - 1 - w)] = (u8)d;                 // d << (8w), big-endian
+        memcpy(&pts[i * 2 * B], g, 2 * B);
+      }
+    void* comb = bk.alloc(n * sizeof(typename W::A));
+    u8* dk = (u8*)bk.alloc(ks.size());
+    u8* dp = (u8*)bk.alloc(pts.size());
+    if (!comb || !dk || !dp) return fail(E_NOMEM, "comb table allocation failed");
+    bk.h2d(dk, ks.data(), ks.size());
+    bk.h2d(dp, pts.data(), pts.size());
+    int rc = mul_var_chunk<CV>(n, dk, dp, nullptr, nullptr, (typename W::A*)comb);
+    bk.sync();
+    bk.free_(dk);
+    bk.free_(dp);
+    if (rc) { bk.free_(comb); return rc; }
+    comb_[CV::ID] = comb;
+    return E_OK;
+  }
+
+  template <class CV>
+  int normalize_chunk(size_t n, const u32* jac, u8* out_xy, u8* out_inf, typename Work<CV>::A* raw) {
+    typedef Work<CV> W;
+    u32* pre = (u32*)scratch(S_PRE, n * W::L * 4);
+    if (!pre) return fail(E_NOMEM, "scratch allocation failed");
+    size_t T = (n + INV_BATCH - 1) / INV_BATCH;
+    FnNormalize<CV> f{T, n, INV_BATCH, jac, pre, out_xy, out_inf, raw};
+    bk.launch(f, T);
+    return E_OK;
+  }
+
+  template <class CV>
+  int mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u8* out_inf,
+                    typename Work<CV>::A* raw) {
+    typedef Work<CV> W;
+    typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::J));
+    u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+    if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
+    FnMulVar<CV> f{n, k, xy, tbl, jac};
+    bk.launch(f, n);
+    return normalize_chunk<CV>(n, jac, out_xy, out_inf, raw);
+  }
+
+  template <class CV>
+  int mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf) {
+    typedef Work<CV> W;
+    u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+    if (!jac) return fail(E_NOMEM, "scratch allocation failed");
+    FnMulFixed<CV> f{n, k, (const typename W::A*)comb_[CV::ID], jac};
+    bk.launch(f, n);
+    return normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
+  }
+
+  template <class CV>
+  int mul_add2_chunk(size_t n, const u8* k1, const u8* xy1, const u8* k2, const u8* xy2,
+                     u8* out_xy, u8* out_inf) {
+    typedef Work<CV> W;
+    u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+    if (!jac) return fail(E_NOMEM, "scratch allocation failed");
+    if (xy1) {
+      typename W::J* tbl =
+          (typename W::J*)scratch(S_TBL, n * 2 * W::TBL1 * sizeof(typename W::J));
+      if (!tbl) return fail(E_NOMEM, "scratch allocation failed");
+      FnMulAdd2<CV> f{n, k1, xy1, k2, xy2, tbl, jac};
+      bk.launch(f, n);
+    } else {
+      typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::J));
+      if (!tbl) return fail(E_NOMEM, "scratch allocation failed");
+      FnMulAddG<CV> f{n, k1, k2, xy2, (const typename W::A*)comb_[CV::ID], tbl, jac};
+      bk.launch(f, n);
+    }
+    return normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
+  }
+
+  template <class CV>
+  int ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* r, const u8* s,
+                  const u8* pub, u8* ok) {
+    typedef Work<CV> W;
+    typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::J));
+    u32* pre = (u32*)scratch(S_PRE, n * (W::LN > W::L ? W::LN : W::L) * 4);
+    u32* u12 = (u32*)scratch(S_U12, n * 2 * W::LN * 4);
+    u8* valid = (u8*)scratch(S_VALID, n);
+    if (!tbl || !pre || !u12 || !valid) return fail(E_NOMEM, "scratch allocation failed");
+    size_t T = (n + INV_BATCH - 1) / INV_BATCH;
+    FnEcdsaPrep<CV> f1{T, n, INV_BATCH, hash, hash_len, shift, r, s, pre, u12, valid};
+    bk.launch(f1, T);
+    FnEcdsaMain<CV> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
+    bk.launch(f2, n);
+    return E_OK;
+  }
+
+  // ---- Edwards / Montgomery -------------------------------------------------
+  int ensure_ed_comb() {
+    if (comb_[CURVE_ED25519]) return E_OK;
+    const size_t n = EdWork::COMB_ENTRIES;
+    std::vector<u8> ks(n * 32, 0), pts(n * 64, 0);
+    u8 g[64];
+    {
+      u32 gx[8], gy[8];
+      for (int i = 0; i < 8; i++) { gx[i] = consts::ED25519_C::gx_plain[i]; gy[i] = consts::ED25519_C::gy_plain[i]; }
+      store_be<8>(g, gx, 32);
+      store_be<8>(g + 32, gy, 32);
+    }
+    for (int w = 0; w < EdWork::COMB_W; w++)
+      for (int d = 1; d <= 255; d++) {
+        size_t i = (size_t)w * 255 + (d - 1);
+        ks[i * 32 + (31 - w)] = (u8)d;
+        memcpy(&pts[i * 64], g, 64);
+      }
+    void* comb = bk.alloc(n * sizeof(EdWork::P));
+    u8* dk = (u8*)bk.alloc(ks.size());
+    u8* dp = (u8*)bk.alloc(pts.size());
+    if (!comb || !dk || !dp) return fail(E_NOMEM, "comb table allocation failed");
+    bk.h2d(dk, ks.data(), ks.size());
+    bk.h2d(dp, pts.data(), pts.size());
+    int rc = ed_mul_var_chunk(n, dk, dp, nullptr, nullptr, (EdWork::P*)comb);
+    bk.sync();
+    bk.free_(dk);
+    bk.free_(dp);
+    if (rc) { bk.free_(comb); return rc; }
+    comb_[CURVE_ED25519] = comb;
+    return E_OK;
+  }
+  int ed_normalize_chunk(size_t n, const u32* ext, u8* out_xy, u8* out_inf, EdWork::P* raw) {
+    u32* pre = (u32*)scratch(S_PRE, n * 8 * 4);
+    if (!pre) return fail(E_NOMEM, "scratch allocation failed");
+    size_t T = (n + INV_BATCH - 1) / INV_BATCH;
+    FnEdNormalize f{T, n, INV_BATCH, ext, pre, out_xy, out_inf, raw};
+    bk.launch(f, T);
+    return E_OK;
+  }
+  int ed_mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u8* out_inf, EdWork::P* raw) {
+    EdWork::P* tbl = (EdWork::P*)scratch(S_TBL, n * 8 * sizeof(EdWork::P));
+    u32* ext = (u32*)scratch(S_JAC, n * 4 * 8 * 4);
+    if (!tbl || !ext) return fail(E_NOMEM, "scratch allocation failed");
+    FnEdMulVar f{n, k, xy, tbl, ext};
+    bk.launch(f, n);
+    return ed_normalize_chunk(n, ext, out_xy, out_inf, raw);
+  }
+  int ed_mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf) {
+    u32* ext = (u32*)scratch(S_JAC, n * 4 * 8 * 4);
+    if (!ext) return fail(E_NOMEM, "scratch allocation failed");
+    FnEdMulFixed f{n, k, (const EdWork::P*)comb_[CURVE_ED25519], ext};
+    bk.launch(f, n);
+    return ed_normalize_chunk(n, ext, out_xy, out_inf, nullptr);
+  }
+  int ed_mul_add2_chunk(size_t n, const u8* k1, const u8* xy1, const u8* k2, const u8* xy2,
+                        u8* out_xy, u8* out_inf) {
+    u32* ext = (u32*)scratch(S_JAC, n * 4 * 8 * 4);
+    EdWork::P* tbl = (EdWork::P*)scratch(S_TBL, n * 16 * sizeof(EdWork::P));
+    if (!tbl || !ext) return fail(E_NOMEM, "scratch allocation failed");
+    if (xy1) {
+      FnEdMulAdd2 f{n, k1, xy1, k2, xy2, tbl, ext};
+      bk.launch(f, n);
+    } else {
+      FnEdMulAddG f{n, k1, k2, xy2, (const EdWork::P*)comb_[CURVE_ED25519], tbl, ext};
+      bk.launch(f, n);
+    }
+    return ed_normalize_chunk(n, ext, out_xy, out_inf, nullptr);
+  }
+  int x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf) {
+    u32* xz = (u32*)scratch(S_JAC, n * 2 * 8 * 4);
+    u32* pre = (u32*)scratch(S_PRE, n * 8 * 4);
+    if (!xz || !pre) return fail(E_NOMEM, "scratch allocation failed");
+    FnX25519 f{n, k, x, xz};
+    bk.launch(f, n);
+    size_t T = (n + INV_BATCH - 1) / INV_BATCH;
+    FnX25519Normalize g{T, n, INV_BATCH, xz, pre, out_x, out_inf};
+    bk.launch(g, T);
+    return E_OK;
+  }
+
+  // ---- dispatch over curves (device pointers) --------------------------------
+#define ELL_SHORT_DISPATCH(curve, CALL)                         \
+  switch (curve) {                                              \
+    case CURVE_SECP256K1: { typedef CvSecp256k1 CV; CALL; } break; \
+    case CURVE_P192: { typedef CvP192 CV; CALL; } break;           \
+    case CURVE_P224: { typedef CvP224 CV; CALL; } break;           \
+    case CURVE_P256: { typedef CvP256 CV; CALL; } break;           \
+    case CURVE_P384: { typedef CvP384 CV; CALL; } break;           \
+    case CURVE_P521: { typedef CvP521 CV; CALL; } break;           \
+    default: return fail(E_ARG, "unknown curve id");            \
+  }
+
+  int prepare_curve(int curve) {
+    if (curve == CURVE_ED25519) return ensure_ed_comb();
+    if (curve == CURVE_CURVE25519) return E_OK;
+    int rc = E_OK;
+    ELL_SHORT_DISPATCH(curve, rc = ensure_comb<CV>());
+    return rc;
+  }
+
+  int mul_fixed_dev(int curve, size_t n, const u8* k, u8* out_xy, u8* out_inf) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (curve == CURVE_CURVE25519)
+      return fail(E_UNSUPPORTED, "curve25519 has no affine fixed-base form; use x25519_ladder");
+    if (n && (!k || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
+    int rc = prepare_curve(curve);
+    if (rc) return rc;
+    const size_t B = ci->field_bytes;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      if (curve == CURVE_ED25519) rc = ed_mul_fixed_chunk(m, k + o * B, out_xy + o * 2 * B, out_inf + o);
+      else ELL_SHORT_DISPATCH(curve, rc = mul_fixed_chunk<CV>(m, k + o * B, out_xy + o * 2 * B, out_inf + o));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+
+  int mul_var_dev(int curve, size_t n, const u8* k, const u8* xy, u8* out_xy, u8* out_inf) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (curve == CURVE_CURVE25519)
+      return fail(E_UNSUPPORTED, "curve25519 is x-only; use x25519_ladder");
+    if (n && (!k || !xy || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
+    const size_t B = ci->field_bytes;
+    int rc = E_OK;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      if (curve == CURVE_ED25519)
+        rc = ed_mul_var_chunk(m, k + o * B, xy + o * 2 * B, out_xy + o * 2 * B, out_inf + o, nullptr);
+      else
+        ELL_SHORT_DISPATCH(curve, rc = mul_var_chunk<CV>(m, k + o * B, xy + o * 2 * B,
+                                                         out_xy + o * 2 * B, out_inf + o, nullptr));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+
+  int mul_add2_dev(int curve, size_t n, const u8* k1, const u8* xy1, const u8* k2, const u8* xy2,
+                   u8* out_xy, u8* out_inf) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (curve == CURVE_CURVE25519)
+      return fail(E_UNSUPPORTED, "Not supported on Montgomery curve");     // mont.js:155-157
+    if (n && (!k1 || !k2 || !xy2 || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
+    int rc = E_OK;
+    if (!xy1) { rc = prepare_curve(curve); if (rc) return rc; }
+    const size_t B = ci->field_bytes;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      const u8* p1 = xy1 ? xy1 + o * 2 * B : nullptr;
+      if (curve == CURVE_ED25519)
+        rc = ed_mul_add2_chunk(m, k1 + o * B, p1, k2 + o * B, xy2 + o * 2 * B, out_xy + o * 2 * B,
+                               out_inf + o);
+      else
+        ELL_SHORT_DISPATCH(curve, rc = mul_add2_chunk<CV>(m, k1 + o * B, p1, k2 + o * B,
+                                                          xy2 + o * 2 * B, out_xy + o * 2 * B,
+                                                          out_inf + o));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+
+  int ecdsa_verify_dev(int curve, size_t n, const u8* hash, int hash_len, int msg_bits,
+                       const u8* r, const u8* s, const u8* pub, u8* ok) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (curve >= CURVE_ED25519)
+      return fail(E_UNSUPPORTED, "ECDSA verify is implemented for the short Weierstrass presets");
+    if (n && (!hash || !r || !s || !pub || !ok)) return fail(E_ARG, "null pointer");
+    if (hash_len <= 0 || msg_bits < 0) return fail(E_ARG, "bad hash_len / msg_bits");
+    // _truncateToN (ec/index.js:97-102): delta = bitLength - n.bitLength()
+    int bits = msg_bits ? msg_bits : hash_len * 8;
+    int shift = bits - ci->order_bits;
+    if (shift < 0) shift = 0;
+    int ln = (ci->order_bits + 31) / 32;
+    if (hash_len * 8 - shift > 32 * ln || hash_len - (shift >> 3) > 4 * (ln + 1))
+      return fail(E_ARG, "hash_len / msg_bits combination leaves more bits than the order width");
+    int rc = prepare_curve(curve);
+    if (rc) return rc;
+    const size_t B = ci->field_bytes, NB = ci->order_bytes;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      ELL_SHORT_DISPATCH(curve, rc = ecdsa_chunk<CV>(m, hash + o * hash_len, hash_len, shift,
+                                                     r + o * NB, s + o * NB, pub + o * 2 * B,
+                                                     ok + o));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+
+  int x25519_dev(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf) {
+    if (n && (!k || !x || !out_x || !out_inf)) return fail(E_ARG, "null pointer");
+    int rc = E_OK;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      rc = x25519_chunk(m, k + o * 32, x + o * 32, out_x + o * 32, out_inf + o);
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+
+  // ---- host-buffer wrappers: stage through device buffers --------------------
+  struct Stage {
+    Engine* e; int slot; void* d = nullptr; void* h = nullptr; size_t bytes = 0;
+  };
+  u8* put(int slot, const void* host, size_t bytes) {
+    if (!host) return nullptr;
+    u8* d = (u8*)staging(slot, bytes ? bytes : 1);
+    if (d && bytes) bk.h2d(d, host, bytes);
+    return d;
+  }
+  u8* out_buf(int slot, size_t bytes) { return (u8*)staging(slot, bytes ? bytes : 1); }
+
+  int mul_fixed_host(int curve, size_t n, const u8* k, u8* out_xy, u8* out_inf) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (n && (!k || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
+    size_t B = ci->field_bytes;
+    u8* dk = put(G_IN0, k, n * B);
+    u8* dxy = out_buf(G_OUT0, n * 2 * B);
+    u8* dinf = out_buf(G_OUT1, n);
+    if (!dk || !dxy || !dinf) return fail(E_NOMEM, "staging allocation failed");
+    int rc = mul_fixed_dev(curve, n, dk, dxy, dinf);
+    if (rc) return rc;
+    bk.d2h(out_xy, dxy, n * 2 * B);
+    bk.d2h(out_inf, dinf, n);
+    return bk.sync();
+  }
+  int mul_var_host(int curve, size_t n, const u8* k, const u8* xy, u8* out_xy, u8* out_inf) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (n && (!k || !xy || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
+    size_t B = ci->field_bytes;
+    u8* dk = put(G_IN0, k, n * B);
+    u8* dp = put(G_IN1, xy, n * 2 * B);
+    u8* dxy = out_buf(G_OUT0, n * 2 * B);
+    u8* dinf = out_buf(G_OUT1, n);
+    if (!dk || !dp || !dxy || !dinf) return fail(E_NOMEM, "staging allocation failed");
+    int rc = mul_var_dev(curve, n, dk, dp, dxy, dinf);
+    if (rc) return rc;
+    bk.d2h(out_xy, dxy, n * 2 * B);
+    bk.d2h(out_inf, dinf, n);
+    return bk.sync();
+  }
+  int mul_add2_host(int curve, size_t n, const u8* k1, const u8* xy1, const u8* k2,
+                    const u8* xy2, u8* out_xy, u8* out_inf) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (n && (!k1 || !k2 || !xy2 || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
+    size_t B = ci->field_bytes;
+    u8* d1 = put(G_IN0, k1, n * B);
+    u8* dp1 = xy1 ? put(G_IN1, xy1, n * 2 * B) : nullptr;
+    u8* d2 = put(G_IN2, k2, n * B);
+    u8* dp2 = put(G_IN3, xy2, n * 2 * B);
+    u8* dxy = out_buf(G_OUT0, n * 2 * B);
+    u8* dinf = out_buf(G_OUT1, n);
+    if (!d1 || !d2 || !dp2 || !dxy || !dinf || (xy1 && !dp1))
+      return fail(E_NOMEM, "staging allocation failed");
+    int rc = mul_add2_dev(curve, n, d1, dp1, d2, dp2, dxy, dinf);
+    if (rc) return rc;
+    bk.d2h(out_xy, dxy, n * 2 * B);
+    bk.d2h(out_inf, dinf, n);
+    return bk.sync();
+  }
+  int ecdsa_verify_host(int curve, size_t n, const u8* hash, int hash_len, int msg_bits,
+                        const u8* r, const u8* s, const u8* pub, u8* ok) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (n && (!hash || !r || !s || !pub || !ok)) return fail(E_ARG, "null pointer");
+    if (hash_len <= 0) return fail(E_ARG, "bad hash_len");
+    size_t B = ci->field_bytes, NB = ci->order_bytes;
+    u8* dh = put(G_IN0, hash, n * (size_t)hash_len);
+    u8* dr = put(G_IN1, r, n * NB);
+    u8* dsg = put(G_IN2, s, n * NB);
+    u8* dq = put(G_IN3, pub, n * 2 * B);
+    u8* dok = out_buf(G_OUT0, n);
+    if (!dh || !dr || !dsg || !dq || !dok) return fail(E_NOMEM, "staging allocation failed");
+    int rc = ecdsa_verify_dev(curve, n, dh, hash_len, msg_bits, dr, dsg, dq, dok);
+    if (rc) return rc;
+    bk.d2h(ok, dok, n);
+    return bk.sync();
+  }
+  int x25519_host(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf) {
+    if (n && (!k || !x || !out_x || !out_inf)) return fail(E_ARG, "null pointer");
+    u8* dk = put(G_IN0, k, n * 32);
+    u8* dx = put(G_IN1, x, n * 32);
+    u8* dox = out_buf(G_OUT0, n * 32);
+    u8* dinf = out_buf(G_OUT1, n);
+    if (!dk || !dx || !dox || !dinf) return fail(E_NOMEM, "staging allocation failed");
+    int rc = x25519_dev(n, dk, dx, dox, dinf);
+    if (rc) return rc;
+    bk.d2h(out_x, dox, n * 32);
+    bk.d2h(out_inf, dinf, n);
+    return bk.sync();
+  }
+
+  int reserve(int curve, size_t n) {
+    // run a dummy-sized allocation pass by touching the arena the way a verify /
+    // mul_add2 batch of n items would
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    int rc = prepare_curve(curve);
+    if (rc) return rc;
+    size_t m = n < CHUNK ? n : CHUNK;
+    size_t L = (size_t)(ci->field_bytes + 3) / 4;
+    size_t ent = (curve == CURVE_ED25519) ? 16 * 4 * L * 4 : 32 * 3 * L * 4;
+    if (!scratch(S_TBL, m * ent) || !scratch(S_JAC, m * 4 * L * 4) || !scratch(S_PRE, m * L * 4) ||
+        !scratch(S_U12, m * 2 * L * 4) || !scratch(S_VALID, m))
+      return fail(E_NOMEM, "scratch allocation failed");
+    return E_OK;
+  }
+
+ private:
+  void* comb_[CURVE_COUNT];
+  Buf scratch_[S_COUNT];
+  Buf staging_[G_COUNT];
+};
+
+}  // namespace ell

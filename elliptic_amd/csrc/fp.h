@@ -1,0 +1,399 @@
+// ellgpu -- prime-field arithmetic, one field element per lane, limbs in VGPRs.
+//
+// Three field families, all exposing the same static interface (L, El, add,
+// sub, neg, dbl, mul, sqr, inv, is_zero, eq, from_plain, to_plain, one, zero):
+//
+//   FpK256      p = 2^256 - 2^32 - 977 (secp256k1): plain residues, the
+//               512-bit product is folded with 2^256 == 2^32 + 977.
+//   Fp25519     p = 2^255 - 19: plain residues, folded with 2^256 == 38.
+//   FpMont<P>   any odd modulus (NIST primes, and every group order n):
+//               Montgomery residues (x*R mod p, R = 2^(32L)), CIOS multiply.
+//
+// They replace bn.js `Red`+`K256` / `Red`+`P25519` / `Mont` contexts
+// (reference: dist/elliptic.js:6888-7381) -- internal representation is ours;
+// every value that leaves a kernel is converted to the canonical residue, which
+// is all the reference's results depend on.
+//
+// Every element is kept fully reduced in [0, p) after every operation, so
+// is_zero/eq are limb compares and the exceptional branches of the group law
+// can be detected exactly.
+#pragma once
+
+#include "common.h"
+
+namespace ell {
+
+template <int N>
+struct Fe {
+  u32 v[N];
+};
+
+// --------------------------------------------------------------------------
+// helpers shared by the field families
+// --------------------------------------------------------------------------
+
+// r = (a + b) mod p, inputs in [0,p)
+template <int L>
+ELL_HD void mod_add(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L], const u32 (&p)[L]) {
+  u32 t[L], s[L];
+  u32 c = bn_add<L>(t, a, b);
+  u32 br = bn_sub<L>(s, t, p);
+  // result is s when the true sum (c:t) >= p, i.e. when c==1 or no borrow
+  bool use_s = (c != 0) || (br == 0);
+  bn_select<L>(r, use_s, s, t);
+}
+
+template <int L>
+ELL_HD void mod_sub(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L], const u32 (&p)[L]) {
+  u32 t[L], s[L];
+  u32 br = bn_sub<L>(t, a, b);
+  bn_add<L>(s, t, p);
+  bn_select<L>(r, br != 0, s, t);
+}
+
+// --------------------------------------------------------------------------
+// secp256k1 base field
+// --------------------------------------------------------------------------
+struct FpK256 {
+  static constexpr int L = 8;
+  typedef Fe<8> El;
+  static constexpr u32 C0 = 977u;  // p = 2^256 - 2^32 - 977
+
+  ELL_HD static void get_p(u32 (&p)[8]) {
+    p[0] = 0xFFFFFC2Fu; p[1] = 0xFFFFFFFEu;
+    ELL_UNROLL
+    for (int i = 2; i < 8; i++) p[i] = 0xFFFFFFFFu;
+  }
+  ELL_HD static El zero() { El r; bn_zero<8>(r.v); return r; }
+  ELL_HD static El one() { El r; bn_zero<8>(r.v); r.v[0] = 1; return r; }
+  ELL_HD static El from_plain(const u32 (&a)[8]) {        // a < 2^256, reduce once
+    u32 p[8]; get_p(p);
+    u32 s[8];
+    u32 br = bn_sub<8>(s, a, p);
+    El r; bn_select<8>(r.v, br == 0, s, a);
+    return r;
+  }
+  ELL_HD static void to_plain(u32 (&r)[8], const El& a) { bn_copy<8>(r, a.v); }
+  ELL_HD static bool is_zero(const El& a) { return bn_is_zero<8>(a.v); }
+  ELL_HD static bool eq(const El& a, const El& b) { return bn_eq<8>(a.v, b.v); }
+  ELL_HD static bool is_odd(const El& a) { return a.v[0] & 1; }
+
+  ELL_HD static El add(const El& a, const El& b) {
+    u32 p[8]; get_p(p);
+    El r; mod_add<8>(r.v, a.v, b.v, p); return r;
+  }
+  ELL_HD static El sub(const El& a, const El& b) {
+    u32 p[8]; get_p(p);
+    El r; mod_sub<8>(r.v, a.v, b.v, p); return r;
+  }
+  ELL_HD static El neg(const El& a) { return sub(zero(), a); }
+  ELL_HD static El dbl(const El& a) { return add(a, a); }
+
+  // fold a 512-bit value t[0..16) to [0,p): 2^256 == 2^32 + 977 (mod p)
+  ELL_HD static El reduce_wide(const u32 (&t)[16]) {
+    // u = lo + hi*977 + (hi << 32)      (10 limbs)
+    u32 u[10];
+    u32 carry = 0;
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) {
+      u64 x = (u64)t[8 + i] * C0 + t[i] + carry;
+      u[i] = (u32)x;
+      carry = (u32)(x >> 32);
+    }
+    u[8] = carry;
+    u64 c = 0;
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) {
+      c += (u64)u[i + 1] + t[8 + i];
+      u[i + 1] = (u32)c;
+      c >>= 32;
+    }
+    u[9] = (u32)c;
+    // second fold: T = u[8] + u[9]*2^32 (< 2^34);  r = u[0..8) + T*977 + (T<<32)
+    u32 r[8];
+    u64 x = (u64)u[8] * C0 + u[0];
+    r[0] = (u32)x;
+    x = (x >> 32) + (u64)u[9] * C0 + u[1] + u[8];
+    r[1] = (u32)x;
+    x = (x >> 32) + (u64)u[2] + u[9];
+    r[2] = (u32)x;
+    u32 cy = (u32)(x >> 32);
+    ELL_UNROLL
+    for (int i = 3; i < 8; i++) {
+      u64 y = (u64)u[i] + cy;
+      r[i] = (u32)y;
+      cy = (u32)(y >> 32);
+    }
+    // value = cy*2^256 + r  < 2^256 + 2^67: subtract p once if needed
+    u32 p[8]; get_p(p);
+    u32 s[8];
+    u32 br = bn_sub<8>(s, r, p);
+    El out;
+    bn_select<8>(out.v, (cy != 0) || (br == 0), s, r);
+    return out;
+  }
+  ELL_HD static El mul(const El& a, const El& b) {
+    u32 t[16];
+    bn_mul_wide<8, 8>(t, a.v, b.v);
+    return reduce_wide(t);
+  }
+  ELL_HD static El sqr(const El& a) {
+    u32 t[16];
+    bn_sqr_wide<8>(t, a.v);
+    return reduce_wide(t);
+  }
+  // a * small constant (< 2^32)
+  ELL_HD static El mul_small(const El& a, u32 k) {
+    u32 t[16];
+    u32 carry = 0;
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) {
+      u64 x = (u64)a.v[i] * k + carry;
+      t[i] = (u32)x;
+      carry = (u32)(x >> 32);
+    }
+    t[8] = carry;
+    ELL_UNROLL
+    for (int i = 9; i < 16; i++) t[i] = 0;
+    return reduce_wide(t);
+  }
+  ELL_HD static El sqr_n(El a, int n) {
+    ELL_NOUNROLL
+    for (int i = 0; i < n; i++) a = sqr(a);
+    return a;
+  }
+  // a^(p-2): addition chain over the run structure of p-2
+  // (223 ones, 0, 22 ones, 0000, 1, 0, 11, 0, 1)  -- 255 S + 15 M
+  static ELL_HD_NOINLINE El inv(const El& a) {
+    El x2 = mul(sqr(a), a);
+    El x3 = mul(sqr(x2), a);
+    El x6 = mul(sqr_n(x3, 3), x3);
+    El x9 = mul(sqr_n(x6, 3), x3);
+    El x11 = mul(sqr_n(x9, 2), x2);
+    El x22 = mul(sqr_n(x11, 11), x11);
+    El x44 = mul(sqr_n(x22, 22), x22);
+    El x88 = mul(sqr_n(x44, 44), x44);
+    El x176 = mul(sqr_n(x88, 88), x88);
+    El x220 = mul(sqr_n(x176, 44), x44);
+    El x223 = mul(sqr_n(x220, 3), x3);
+    El t = mul(sqr_n(x223, 23), x22);
+    t = mul(sqr_n(t, 5), a);
+    t = mul(sqr_n(t, 3), x2);
+    t = mul(sqr_n(t, 2), a);
+    return t;
+  }
+};
+
+// --------------------------------------------------------------------------
+// GF(2^255 - 19)
+// --------------------------------------------------------------------------
+struct Fp25519 {
+  static constexpr int L = 8;
+  typedef Fe<8> El;
+
+  ELL_HD static void get_p(u32 (&p)[8]) {
+    p[0] = 0xFFFFFFEDu;
+    ELL_UNROLL
+    for (int i = 1; i < 7; i++) p[i] = 0xFFFFFFFFu;
+    p[7] = 0x7FFFFFFFu;
+  }
+  ELL_HD static El zero() { El r; bn_zero<8>(r.v); return r; }
+  ELL_HD static El one() { El r; bn_zero<8>(r.v); r.v[0] = 1; return r; }
+  // canonicalise any 256-bit value
+  ELL_HD static El from_plain(const u32 (&a)[8]) {
+    // fold bit 255: a = lo255 + 19*b255   (< 2^255 + 19)
+    u32 r[8];
+    u32 top = a[7] >> 31;
+    u64 c = (u64)a[0] + 19u * top;
+    r[0] = (u32)c; c >>= 32;
+    ELL_UNROLL
+    for (int i = 1; i < 7; i++) { c += a[i]; r[i] = (u32)c; c >>= 32; }
+    c += (a[7] & 0x7FFFFFFFu);
+    r[7] = (u32)c;
+    u32 p[8]; get_p(p);
+    u32 s[8];
+    u32 br = bn_sub<8>(s, r, p);
+    El out; bn_select<8>(out.v, br == 0, s, r);
+    return out;
+  }
+  ELL_HD static void to_plain(u32 (&r)[8], const El& a) { bn_copy<8>(r, a.v); }
+  ELL_HD static bool is_zero(const El& a) { return bn_is_zero<8>(a.v); }
+  ELL_HD static bool eq(const El& a, const El& b) { return bn_eq<8>(a.v, b.v); }
+  ELL_HD static bool is_odd(const El& a) { return a.v[0] & 1; }
+  ELL_HD static El add(const El& a, const El& b) {
+    u32 p[8]; get_p(p);
+    El r; mod_add<8>(r.v, a.v, b.v, p); return r;
+  }
+  ELL_HD static El sub(const El& a, const El& b) {
+    u32 p[8]; get_p(p);
+    El r; mod_sub<8>(r.v, a.v, b.v, p); return r;
+  }
+  ELL_HD static El neg(const El& a) { return sub(zero(), a); }
+  ELL_HD static El dbl(const El& a) { return add(a, a); }
+
+  ELL_HD static El reduce_wide(const u32 (&t)[16]) {
+    // u = lo + 38*hi  (9 limbs, u[8] < 39)
+    u32 u[8];
+    u32 carry = 0;
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) {
+      u64 x = (u64)t[8 + i] * 38u + t[i] + carry;
+      u[i] = (u32)x;
+      carry = (u32)(x >> 32);
+    }
+    // fold carry*2^256 == carry*38, and bit 255 == 19, in one pass
+    u32 top = u[7] >> 31;
+    u[7] &= 0x7FFFFFFFu;
+    u64 c = (u64)u[0] + (u64)carry * 38u + 19u * top;
+    u32 r[8];
+    r[0] = (u32)c; c >>= 32;
+    ELL_UNROLL
+    for (int i = 1; i < 8; i++) { c += u[i]; r[i] = (u32)c; c >>= 32; }
+    // r < 2^255 + 2^12: at most one more bit-255 fold, then one subtract
+    return from_plain(r);
+  }
+  ELL_HD static El mul(const El& a, const El& b) {
+    u32 t[16];
+    bn_mul_wide<8, 8>(t, a.v, b.v);
+    return reduce_wide(t);
+  }
+  ELL_HD static El sqr(const El& a) {
+    u32 t[16];
+    bn_sqr_wide<8>(t, a.v);
+    return reduce_wide(t);
+  }
+  ELL_HD static El sqr_n(El a, int n) {
+    ELL_NOUNROLL
+    for (int i = 0; i < n; i++) a = sqr(a);
+    return a;
+  }
+  // a^(p-2) = a^(2^255 - 21): the classic 254 S + 11 M chain
+  static ELL_HD_NOINLINE El inv(const El& z) {
+    El z2 = sqr(z);
+    El z9 = mul(sqr_n(z2, 2), z);
+    El z11 = mul(z9, z2);
+    El z2_5_0 = mul(sqr(z11), z9);
+    El z2_10_0 = mul(sqr_n(z2_5_0, 5), z2_5_0);
+    El z2_20_0 = mul(sqr_n(z2_10_0, 10), z2_10_0);
+    El z2_40_0 = mul(sqr_n(z2_20_0, 20), z2_20_0);
+    El z2_50_0 = mul(sqr_n(z2_40_0, 10), z2_10_0);
+    El z2_100_0 = mul(sqr_n(z2_50_0, 50), z2_50_0);
+    El z2_200_0 = mul(sqr_n(z2_100_0, 100), z2_100_0);
+    El z2_250_0 = mul(sqr_n(z2_200_0, 50), z2_50_0);
+    return mul(sqr_n(z2_250_0, 5), z11);
+  }
+};
+
+// --------------------------------------------------------------------------
+// Generic odd modulus, Montgomery form.  P supplies:
+//   static constexpr int L; u32 p[L]; u32 n0 (= -p^-1 mod 2^32);
+//   u32 one[L] (= R mod p); u32 r2[L] (= R^2 mod p); u32 pm2[L] (= p - 2)
+// --------------------------------------------------------------------------
+template <class P>
+struct FpMont {
+  static constexpr int L = P::L;
+  typedef Fe<P::L> El;
+
+  ELL_HD static void get_p(u32 (&p)[L]) {
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) p[i] = P::p[i];
+  }
+  ELL_HD static El zero() { El r; bn_zero<L>(r.v); return r; }
+  ELL_HD static El one() {
+    El r;
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) r.v[i] = P::one[i];
+    return r;
+  }
+  ELL_HD static bool is_zero(const El& a) { return bn_is_zero<L>(a.v); }
+  ELL_HD static bool eq(const El& a, const El& b) { return bn_eq<L>(a.v, b.v); }
+  ELL_HD static El add(const El& a, const El& b) {
+    u32 p[L]; get_p(p);
+    El r; mod_add<L>(r.v, a.v, b.v, p); return r;
+  }
+  ELL_HD static El sub(const El& a, const El& b) {
+    u32 p[L]; get_p(p);
+    El r; mod_sub<L>(r.v, a.v, b.v, p); return r;
+  }
+  ELL_HD static El neg(const El& a) { return sub(zero(), a); }
+  ELL_HD static El dbl(const El& a) { return add(a, a); }
+
+  // CIOS Montgomery product: a*b*R^-1 mod p  (2L^2 + L multiplies)
+  ELL_HD static El mul(const El& a, const El& b) {
+    u32 t[L + 2];
+    ELL_UNROLL
+    for (int i = 0; i < L + 2; i++) t[i] = 0;
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) {
+      u32 carry = 0;
+      ELL_UNROLL
+      for (int j = 0; j < L; j++) {
+        u64 x = (u64)a.v[i] * b.v[j] + t[j] + carry;
+        t[j] = (u32)x;
+        carry = (u32)(x >> 32);
+      }
+      u64 y = (u64)t[L] + carry;
+      t[L] = (u32)y;
+      t[L + 1] = (u32)(y >> 32);
+      u32 m = t[0] * P::n0;
+      u64 x = (u64)m * P::p[0] + t[0];
+      carry = (u32)(x >> 32);
+      ELL_UNROLL
+      for (int j = 1; j < L; j++) {
+        x = (u64)m * P::p[j] + t[j] + carry;
+        t[j - 1] = (u32)x;
+        carry = (u32)(x >> 32);
+      }
+      y = (u64)t[L] + carry;
+      t[L - 1] = (u32)y;
+      t[L] = t[L + 1] + (u32)(y >> 32);
+    }
+    u32 p[L]; get_p(p);
+    u32 r[L], s[L];
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) r[i] = t[i];
+    u32 br = bn_sub<L>(s, r, p);
+    El out;
+    bn_select<L>(out.v, (t[L] != 0) || (br == 0), s, r);
+    return out;
+  }
+  ELL_HD static El sqr(const El& a) { return mul(a, a); }
+
+  ELL_HD static El from_plain(const u32 (&a)[L]) {      // a < 2^(32L): a*R mod p
+    El x, r2;
+    // a may be >= p (scalars are not reduced by the caller): the Montgomery
+    // product only needs a < R and b < p for a fully reduced result
+    bn_copy<L>(x.v, a);
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) r2.v[i] = P::r2[i];
+    return mul(x, r2);
+  }
+  ELL_HD static void to_plain(u32 (&r)[L], const El& a) {
+    El o; bn_zero<L>(o.v); o.v[0] = 1;
+    El x = mul(a, o);
+    bn_copy<L>(r, x.v);
+  }
+  ELL_HD static bool is_odd(const El& a) {
+    u32 r[L]; to_plain(r, a); return r[0] & 1;
+  }
+  ELL_HD static El sqr_n(El a, int n) {
+    ELL_NOUNROLL
+    for (int i = 0; i < n; i++) a = sqr(a);
+    return a;
+  }
+  // a^(p-2), left-to-right binary over the constant exponent.  The exponent
+  // bit is wave-uniform, so the multiply is a scalar branch, not divergence.
+  // (Amortised over a whole batch by Montgomery's trick, see normalize.)
+  static ELL_HD_NOINLINE El inv(const El& a) {
+    El r = one();
+    ELL_NOUNROLL
+    for (int w = 32 * L - 1; w >= 0; w--) {
+      r = sqr(r);
+      u32 bit = (P::pm2[w >> 5] >> (w & 31)) & 1u;
+      if (bit) r = mul(r, a);
+    }
+    return r;
+  }
+};
+
+}  // namespace ell

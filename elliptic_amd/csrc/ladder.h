@@ -1,0 +1,229 @@
+// ellgpu -- scalar recoding, per-lane window tables, ladders and the
+// fixed-base comb for short Weierstrass curves.
+//
+// What the reference does with data-dependent wNAF / JSF digit strings
+// (lib/elliptic/curve/base.js:52-253, utils.js:15-101) is done here with
+// REGULAR recodings so that the 64 lanes of a wavefront -- each working on its
+// own (scalar, point) -- execute the same add/double sequence:
+//
+//   variable base  signed fixed 4-bit windows (digits -8..7 via a bias, so no
+//                  carry chain), 8-entry table {1..8}P per lane in HBM/L2
+//                  scratch, one add per window, every lane adds at the same
+//                  step (a zero digit is a select, not a branch);
+//   secp256k1      GLV first (k = k1 + k2*lambda, |k1|,|k2| < 2^129), two
+//                  33-window ladders sharing the doublings
+//                  (replaces _endoSplit/_endoWnafMulAdd, short.js:168-249);
+//   fixed base     unsigned 8-bit comb over a table of d*2^(8w)*G, no
+//                  doublings at all (replaces _fixedNafMul, base.js:52-84).
+//
+// Group results are independent of the recoding, so outputs stay bit-exact.
+#pragma once
+
+#include "curves.h"
+#include "short.h"
+
+namespace ell {
+
+// Per-lane digit strings.  On the GPU `base` points into LDS at the lane's
+// column and `stride` is the workgroup size (bank-conflict-free byte
+// columns); in the host simulation it is a plain array with stride 1.
+struct DigitStore {
+  signed char* base;
+  int stride;
+  ELL_HD void set(int idx, int d) const { base[idx * stride] = (signed char)d; }
+  ELL_HD int get(int idx) const { return base[idx * stride]; }
+};
+
+// number of limbs needed for NNIB nibbles plus one carry bit
+template <int NNIB>
+struct RecodeLimbs {
+  static constexpr int LK = (NNIB * 4) / 32 + 1;
+};
+
+// Signed 4-bit recoding of k < 16^NNIB into windows [0, NNIB) with digits
+// -8..7, plus (TOP) one more window holding the 0/1 carry:
+//   k + sum_i 8*16^i = sum_i nib_i 16^i   =>   k = sum_i (nib_i - 8) 16^i (+ top*16^NNIB)
+// Digits are written to ds at index w*NS + s.
+template <int LW, int NNIB, bool TOP>
+ELL_HD void recode_w4(const u32 (&k)[LW], const DigitStore& ds, int s, int NS) {
+  constexpr int LK = RecodeLimbs<NNIB>::LK;
+  u32 kp[LK];
+  u64 c = 0;
+  ELL_UNROLL
+  for (int i = 0; i < LK; i++) {
+    // bias limb i: nibbles 8 for nibble index < NNIB
+    u32 b = 0;
+    ELL_UNROLL
+    for (int j = 0; j < 8; j++)
+      if (8 * i + j < NNIB) b |= 8u << (4 * j);
+    c += (u64)(i < LW ? k[i] : 0u) + b;
+    kp[i] = (u32)c;
+    c >>= 32;
+  }
+  ELL_UNROLL
+  for (int i = 0; i < NNIB; i++) {
+    int nib = (int)((kp[i >> 3] >> (4 * (i & 7))) & 15u);
+    ds.set(i * NS + s, nib - 8);
+  }
+  if (TOP) {
+    int nib = (int)((kp[NNIB >> 3] >> (4 * (NNIB & 7))) & 15u);
+    ds.set(NNIB * NS + s, nib);
+  }
+}
+
+template <class CV>
+struct Ladder {
+  typedef typename CV::F F;
+  typedef typename F::El El;
+  typedef ShortOps<CV> G;
+  typedef Jac<F> J;
+  typedef Aff<F> A;
+
+  // tbl[j-1] = j*P for j = 1..8 (Jacobian, distinct Z)
+  ELL_HD static void build_table8(J* tbl, const A& p) {
+    tbl[0] = G::from_affine(p);
+    ELL_NOUNROLL
+    for (int j = 2; j <= 8; j++) {
+      J t;
+      if (j & 1) t = G::add_mixed(tbl[j - 2], p);
+      else t = G::dbl(tbl[j / 2 - 1]);
+      tbl[j - 1] = t;
+    }
+  }
+
+  // acc = sum_s k_s * P_s, digits from ds (NWIN windows of NS digits), tables
+  // tbl[s*8 + (|d|-1)], point s negated when bit s of negmask is set.
+  template <int NS, int NWIN>
+  ELL_HD static J run_w4(const DigitStore& ds, const J* tbl, u32 negmask) {
+    J acc = G::infinity();
+    ELL_NOUNROLL
+    for (int w = NWIN - 1; w >= 0; w--) {
+      if (w != NWIN - 1) {
+        ELL_NOUNROLL
+        for (int j = 0; j < 4; j++) acc = G::dbl(acc);
+      }
+      ELL_NOUNROLL
+      for (int s = 0; s < NS; s++) {
+        int d = ds.get(w * NS + s);
+        int ad = d < 0 ? -d : d;
+        bool neg = (d < 0) != (((negmask >> s) & 1u) != 0);
+        int e = ad ? ad - 1 : 0;
+        J q = tbl[s * 8 + e];
+        q = G::cneg(q, neg);
+        acc = G::add(acc, q, ad != 0);
+      }
+    }
+    return acc;
+  }
+
+  // fixed-base comb: sum_w d_w * 2^(8w) * G with d_w the w-th byte of k;
+  // comb[w*255 + d-1] = d * 2^(8w) * G (affine, field-internal form).
+  template <int LK, int W>
+  ELL_HD static J comb_mul(const u32 (&k)[LK], const A* comb) {
+    u32 kk[LK];
+    bn_copy<LK>(kk, k);
+    J acc = G::infinity();
+    ELL_NOUNROLL
+    for (int w = 0; w < W; w++) {
+      u32 d = kk[0] & 255u;
+      ELL_UNROLL
+      for (int i = 0; i < LK - 1; i++) kk[i] = (kk[i] >> 8) | (kk[i + 1] << 24);
+      kk[LK - 1] >>= 8;
+      u32 e = d ? d - 1 : 0;
+      A q = comb[w * 255 + e];
+      acc = G::add_mixed(acc, q, d != 0);
+    }
+    return acc;
+  }
+};
+
+// --------------------------------------------------------------------------
+// GLV decomposition for secp256k1 (replaces ShortCurve#_endoSplit,
+// lib/elliptic/curve/short.js:168-185).  c1 = round(b2*k/n), c2 =
+// round(-b1*k/n) are taken as the top 128 bits of k*g with g = round(2^384 *
+// b/n); an off-by-one in c only moves (k1,k2) by one lattice vector, so
+// k1 + k2*lambda == k (mod n) holds exactly and |k1|,|k2| < 2^129.
+// --------------------------------------------------------------------------
+ELL_HD void glv_mul_shift384(u32 (&c)[4], const u32 (&k)[8], const u32 (&g)[8]) {
+  u32 t[16];
+  bn_mul_wide<8, 8>(t, k, g);
+  // + 2^383, then >> 384
+  u64 x = (u64)t[11] + 0x80000000u;
+  u32 cy = (u32)(x >> 32);
+  ELL_UNROLL
+  for (int i = 0; i < 4; i++) {
+    u64 y = (u64)t[12 + i] + cy;
+    c[i] = (u32)y;
+    cy = (u32)(y >> 32);
+  }
+}
+
+// |x| for a 9-limb two's complement value; returns sign
+ELL_HD bool abs9(u32 (&r)[9]) {
+  bool neg = (r[8] >> 31) != 0;
+  u32 m = neg ? 0xFFFFFFFFu : 0u;
+  u64 c = neg ? 1 : 0;
+  ELL_UNROLL
+  for (int i = 0; i < 9; i++) {
+    c += (u64)(r[i] ^ m);
+    r[i] = (u32)c;
+    c >>= 32;
+  }
+  return neg;
+}
+
+ELL_HD void glv_split(const u32 (&k)[8], u32 (&k1)[5], bool& neg1, u32 (&k2)[5], bool& neg2) {
+  typedef consts::SECP256K1_C C;
+  u32 g1[8], g2[8], a1[4], mb1[4], a2[5], b2[4];
+  ELL_UNROLL
+  for (int i = 0; i < 8; i++) { g1[i] = C::glv_g1[i]; g2[i] = C::glv_g2[i]; }
+  ELL_UNROLL
+  for (int i = 0; i < 4; i++) { a1[i] = C::glv_a1[i]; mb1[i] = C::glv_mb1[i]; b2[i] = C::glv_b2[i]; }
+  ELL_UNROLL
+  for (int i = 0; i < 5; i++) a2[i] = C::glv_a2[i];
+  u32 c1[4], c2[4];
+  glv_mul_shift384(c1, k, g1);
+  glv_mul_shift384(c2, k, g2);
+  // k1 = k - c1*a1 - c2*a2
+  u32 p1[8], p2[9];
+  bn_mul_wide<4, 4>(p1, c1, a1);
+  bn_mul_wide<4, 5>(p2, c2, a2);
+  u32 r[9];
+  {
+    u32 br = 0;
+    ELL_UNROLL
+    for (int i = 0; i < 9; i++) {
+      u64 t = (u64)(i < 8 ? k[i] : 0u) - (i < 8 ? p1[i] : 0u) - br;
+      r[i] = (u32)t;
+      br = (u32)(t >> 63);
+    }
+    br = 0;
+    ELL_UNROLL
+    for (int i = 0; i < 9; i++) {
+      u64 t = (u64)r[i] - p2[i] - br;
+      r[i] = (u32)t;
+      br = (u32)(t >> 63);
+    }
+  }
+  neg1 = abs9(r);
+  ELL_UNROLL
+  for (int i = 0; i < 5; i++) k1[i] = r[i];
+  // k2 = -(c1*b1 + c2*b2) = c1*|b1| - c2*b2
+  u32 q1[8], q2[8];
+  bn_mul_wide<4, 4>(q1, c1, mb1);
+  bn_mul_wide<4, 4>(q2, c2, b2);
+  {
+    u32 br = 0;
+    ELL_UNROLL
+    for (int i = 0; i < 9; i++) {
+      u64 t = (u64)(i < 8 ? q1[i] : 0u) - (i < 8 ? q2[i] : 0u) - br;
+      r[i] = (u32)t;
+      br = (u32)(t >> 63);
+    }
+  }
+  neg2 = abs9(r);
+  ELL_UNROLL
+  for (int i = 0; i < 5; i++) k2[i] = r[i];
+}
+
+}  // namespace ell

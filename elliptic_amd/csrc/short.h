@@ -1,0 +1,147 @@
+// ellgpu -- short Weierstrass group law in Jacobian coordinates.
+//
+// Replaces the reference's JPoint (lib/elliptic/curve/short.js:482-938):
+//   dbl        <- JPoint#dbl/_zeroDbl/_threeDbl (short.js:656-800)
+//   add_mixed  <- JPoint#mixedAdd              (short.js:569-603)
+//   add        <- JPoint#add                   (short.js:532-567)
+// Only the AFFINE image of a result is canonical, so the
+// formulas are the EFD ones best suited to a branch-free SIMT lane, not the
+// reference's; the exceptional cases the reference branches on (operand at
+// infinity, P == Q -> doubling, P == -Q -> infinity) are all honoured:
+// infinity and P == -Q by selects, P == Q by a rarely-taken branch.
+//
+// A curve description CV supplies: F (field), A_KIND (0: a=0, 3: a=-3).
+#pragma once
+
+#include "fp.h"
+
+namespace ell {
+
+template <class F>
+struct Jac {
+  typename F::El X, Y, Z;      // Z == 0 <=> infinity
+};
+
+template <class F>
+struct Aff {
+  typename F::El x, y;
+};
+
+template <class F>
+ELL_HD typename F::El fe_select(bool c, const typename F::El& a, const typename F::El& b) {
+  typename F::El r;
+  bn_select<F::L>(r.v, c, a.v, b.v);
+  return r;
+}
+
+template <class CV>
+struct ShortOps {
+  typedef typename CV::F F;
+  typedef typename F::El El;
+  typedef Jac<F> J;
+  typedef Aff<F> A;
+
+  ELL_HD static J infinity() {
+    J r; r.X = F::one(); r.Y = F::one(); r.Z = F::zero(); return r;
+  }
+  ELL_HD static bool is_inf(const J& p) { return F::is_zero(p.Z); }
+  ELL_HD static J from_affine(const A& q) {
+    J r; r.X = q.x; r.Y = q.y; r.Z = F::one(); return r;
+  }
+  ELL_HD static J select(bool c, const J& a, const J& b) {
+    J r;
+    r.X = fe_select<F>(c, a.X, b.X);
+    r.Y = fe_select<F>(c, a.Y, b.Y);
+    r.Z = fe_select<F>(c, a.Z, b.Z);
+    return r;
+  }
+  ELL_HD static J cneg(const J& p, bool neg) {
+    J r = p;
+    r.Y = fe_select<F>(neg, F::neg(p.Y), p.Y);
+    return r;
+  }
+
+  // 2P.  Z == 0 (infinity) and Y == 0 (order-2 point) both give Z3 == 0.
+  ELL_HD static J dbl(const J& p) {
+    J r;
+    if (CV::A_KIND == 0) {
+      // dbl-2009-l, a = 0: 2M + 5S
+      El a = F::sqr(p.X);
+      El b = F::sqr(p.Y);
+      El c = F::sqr(b);
+      El t = F::sqr(F::add(p.X, b));
+      t = F::sub(F::sub(t, a), c);
+      El d = F::dbl(t);
+      El e = F::add(F::dbl(a), a);
+      El f = F::sqr(e);
+      r.X = F::sub(f, F::dbl(d));
+      El c8 = F::dbl(F::dbl(F::dbl(c)));
+      r.Z = F::dbl(F::mul(p.Y, p.Z));
+      r.Y = F::sub(F::mul(e, F::sub(d, r.X)), c8);
+    } else {
+      // dbl-2001-b, a = -3: 3M + 5S
+      El delta = F::sqr(p.Z);
+      El gamma = F::sqr(p.Y);
+      El beta = F::mul(p.X, gamma);
+      El t = F::mul(F::sub(p.X, delta), F::add(p.X, delta));
+      El alpha = F::add(F::dbl(t), t);
+      El beta4 = F::dbl(F::dbl(beta));
+      r.X = F::sub(F::sqr(alpha), F::dbl(beta4));
+      El yz = F::sqr(F::add(p.Y, p.Z));
+      r.Z = F::sub(F::sub(yz, gamma), delta);
+      El g2 = F::sqr(gamma);
+      El g8 = F::dbl(F::dbl(F::dbl(g2)));
+      r.Y = F::sub(F::mul(alpha, F::sub(beta4, r.X)), g8);
+    }
+    return r;
+  }
+
+  // P + Q, Q affine and finite; if !do_add returns P unchanged.  8M + 3S.
+  ELL_HD static J add_mixed(const J& p, const A& q, bool do_add = true) {
+    El z1z1 = F::sqr(p.Z);
+    El u2 = F::mul(q.x, z1z1);
+    El s2 = F::mul(q.y, F::mul(p.Z, z1z1));
+    El h = F::sub(u2, p.X);
+    El rr = F::sub(s2, p.Y);
+    El hh = F::sqr(h);
+    El hhh = F::mul(h, hh);
+    El v = F::mul(p.X, hh);
+    J r;
+    r.X = F::sub(F::sub(F::sqr(rr), hhh), F::dbl(v));
+    r.Y = F::sub(F::mul(rr, F::sub(v, r.X)), F::mul(p.Y, hhh));
+    r.Z = F::mul(p.Z, h);          // h == 0, rr != 0  ->  Z3 = 0: infinity
+    bool pinf = F::is_zero(p.Z);
+    bool same = F::is_zero(h) && F::is_zero(rr) && !pinf;
+    if (ELL_UNLIKELY(same && do_add)) r = dbl(from_affine(q));   // P == Q
+    r = select(pinf, from_affine(q), r);                         // O + Q = Q
+    return select(do_add, r, p);
+  }
+
+  // P + Q, both Jacobian; if !do_add returns P unchanged.  12M + 4S.
+  ELL_HD static J add(const J& p, const J& q, bool do_add = true) {
+    El z1z1 = F::sqr(p.Z);
+    El z2z2 = F::sqr(q.Z);
+    El u1 = F::mul(p.X, z2z2);
+    El u2 = F::mul(q.X, z1z1);
+    El s1 = F::mul(p.Y, F::mul(q.Z, z2z2));
+    El s2 = F::mul(q.Y, F::mul(p.Z, z1z1));
+    El h = F::sub(u2, u1);
+    El rr = F::sub(s2, s1);
+    El hh = F::sqr(h);
+    El hhh = F::mul(h, hh);
+    El v = F::mul(u1, hh);
+    J r;
+    r.X = F::sub(F::sub(F::sqr(rr), hhh), F::dbl(v));
+    r.Y = F::sub(F::mul(rr, F::sub(v, r.X)), F::mul(s1, hhh));
+    r.Z = F::mul(F::mul(p.Z, q.Z), h);
+    bool pinf = F::is_zero(p.Z);
+    bool qinf = F::is_zero(q.Z);
+    bool same = F::is_zero(h) && F::is_zero(rr) && !pinf && !qinf;
+    if (ELL_UNLIKELY(same && do_add)) r = dbl(p);                // P == Q
+    r = select(pinf, q, r);                                      // O + Q = Q
+    r = select(qinf, p, r);                                      // P + O = P
+    return select(do_add, r, p);
+  }
+};
+
+}  // namespace ell

@@ -1,0 +1,328 @@
+// ellgpu -- per-item work functions for short Weierstrass curves.
+//
+// Each function does the work of ONE GPU thread; the kernels in kernels.hip
+// call them with i = global thread id, tests/hostsim calls them in a loop on
+// the CPU.  Memory layouts (all device buffers):
+//
+//   scalars / coordinates at the C ABI   big-endian, fixed width BYTES, item-major
+//   jac   Jacobian results               SoA  jac[(c*L + limb)*n + i], c = X,Y,Z, field-internal form
+//   tbl   per-item window tables         AoS  tbl[i*ENTRIES + e] (Jac structs)
+//   comb  fixed-base table               AoS  comb[w*255 + d-1]  (Aff structs, field-internal form)
+//   pre   batch-inversion prefixes       SoA  pre[limb*n + i]
+//   u12   ECDSA u1,u2                    SoA  u12[(c*LN + limb)*n + i], plain residues mod n
+#pragma once
+
+#include "ladder.h"
+
+namespace ell {
+
+template <class CV>
+struct Work {
+  typedef typename CV::F F;
+  typedef typename CV::Fn Fn;
+  typedef typename CV::C C;
+  typedef typename F::El El;
+  typedef typename Fn::El Nl;
+  typedef ShortOps<CV> G;
+  typedef Ladder<CV> LD;
+  typedef Jac<F> J;
+  typedef Aff<F> A;
+
+  static constexpr int L = F::L;
+  static constexpr int LN = Fn::L;
+  static constexpr int BYTES = C::BYTES;
+  static constexpr int NBYTES = C::NBYTES;
+  static constexpr bool ENDO = CV::ENDO;
+  // variable-base ladder geometry (see ladder.h)
+  static constexpr int NSV = ENDO ? 2 : 1;                 // digit strings per (k, P)
+  static constexpr int NNIB = ENDO ? 33 : 2 * BYTES;
+  static constexpr bool TOP = !ENDO;
+  static constexpr int NWIN = NNIB + (TOP ? 1 : 0);
+  static constexpr int TBL1 = 8 * NSV;                     // table entries per (k, P)
+  static constexpr int COMB_W = BYTES;                     // 8-bit comb windows
+  static constexpr int COMB_ENTRIES = COMB_W * 255;
+
+  // ---- I/O helpers -------------------------------------------------------
+  ELL_HD static El load_fe(const u8* p) {
+    u32 t[L];
+    load_be<L>(t, p, BYTES);
+    return F::from_plain(t);
+  }
+  ELL_HD static void store_fe(u8* p, const El& a) {
+    u32 t[L];
+    F::to_plain(t, a);
+    store_be<L>(p, t, BYTES);
+  }
+  ELL_HD static A load_affine(const u8* xy, size_t i) {
+    A a;
+    a.x = load_fe(xy + i * 2 * BYTES);
+    a.y = load_fe(xy + i * 2 * BYTES + BYTES);
+    return a;
+  }
+  ELL_HD static void store_jac(u32* jac, size_t n, size_t i, const J& p) {
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) {
+      jac[(size_t)(0 * L + l) * n + i] = p.X.v[l];
+      jac[(size_t)(1 * L + l) * n + i] = p.Y.v[l];
+      jac[(size_t)(2 * L + l) * n + i] = p.Z.v[l];
+    }
+  }
+  ELL_HD static J load_jac(const u32* jac, size_t n, size_t i) {
+    J p;
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) {
+      p.X.v[l] = jac[(size_t)(0 * L + l) * n + i];
+      p.Y.v[l] = jac[(size_t)(1 * L + l) * n + i];
+      p.Z.v[l] = jac[(size_t)(2 * L + l) * n + i];
+    }
+    return p;
+  }
+
+  // ---- variable base -----------------------------------------------------
+  // Recode k and build the window table(s) of P into digit slots
+  // [s0, s0+NSV) of an NS-string store and table entries tbl[0 .. TBL1).
+  ELL_HD static void prepare_var(const u32 (&k)[L], const A& p, const DigitStore& ds, int s0,
+                                 int NS, J* tbl, u32& negmask) {
+    LD::build_table8(tbl, p);
+    if constexpr (ENDO) {
+      u32 k1[5], k2[5];
+      bool n1, n2;
+      glv_split(k, k1, n1, k2, n2);
+      recode_w4<5, NNIB, false>(k1, ds, s0, NS);
+      recode_w4<5, NNIB, false>(k2, ds, s0 + 1, NS);
+      negmask |= (n1 ? 1u : 0u) << s0;
+      negmask |= (n2 ? 1u : 0u) << (s0 + 1);
+      // lambda*P table: (beta*X, Y, Z)   (short.js:282-310 _getBeta)
+      El beta;
+      ELL_UNROLL
+      for (int i = 0; i < L; i++) beta.v[i] = C::beta[i];
+      ELL_NOUNROLL
+      for (int e = 0; e < 8; e++) {
+        J t = tbl[e];
+        t.X = F::mul(t.X, beta);
+        tbl[8 + e] = t;
+      }
+    } else {
+      recode_w4<L, NNIB, true>(k, ds, s0, NS);
+    }
+  }
+
+  // k*P -> Jacobian (Point#mul's ladder: short.js:422-432 -> base.js:86-126 /
+  // short.js:218-249)
+  ELL_HD static void mul_var(size_t i, size_t n, const u8* ks, const u8* xy, J* tbl_all,
+                             const DigitStore& ds, u32* jac) {
+    u32 k[L];
+    load_be<L>(k, ks + i * BYTES, BYTES);
+    A p = load_affine(xy, i);
+    J* tbl = tbl_all + i * TBL1;
+    u32 negmask = 0;
+    prepare_var(k, p, ds, 0, NSV, tbl, negmask);
+    J r = LD::template run_w4<NSV, NWIN>(ds, tbl, negmask);
+    store_jac(jac, n, i, r);
+  }
+
+  // k1*P1 + k2*P2 -> Jacobian, both points per-item (mulAdd/jmulAdd,
+  // short.js:434-450 -> base.js:128-253): one ladder, shared doublings
+  ELL_HD static void mul_add2(size_t i, size_t n, const u8* k1s, const u8* xy1, const u8* k2s,
+                              const u8* xy2, J* tbl_all, const DigitStore& ds, u32* jac) {
+    u32 k1[L], k2[L];
+    load_be<L>(k1, k1s + i * BYTES, BYTES);
+    load_be<L>(k2, k2s + i * BYTES, BYTES);
+    A p1 = load_affine(xy1, i);
+    A p2 = load_affine(xy2, i);
+    J* tbl = tbl_all + i * 2 * TBL1;
+    u32 negmask = 0;
+    prepare_var(k1, p1, ds, 0, 2 * NSV, tbl, negmask);
+    prepare_var(k2, p2, ds, NSV, 2 * NSV, tbl + TBL1, negmask);
+    J r = LD::template run_w4<2 * NSV, NWIN>(ds, tbl, negmask);
+    store_jac(jac, n, i, r);
+  }
+
+  // k1*G + k2*P2 -> Jacobian (the shape ECDSA verify uses): comb for G, window
+  // ladder for P2, one final Jacobian add
+  ELL_HD static J mul_add_g(const u32 (&k1)[L], const u32 (&k2)[L], const A& p2, const A* comb,
+                            J* tbl, const DigitStore& ds) {
+    u32 negmask = 0;
+    prepare_var(k2, p2, ds, 0, NSV, tbl, negmask);
+    J b = LD::template run_w4<NSV, NWIN>(ds, tbl, negmask);
+    J a = LD::template comb_mul<L, COMB_W>(k1, comb);
+    return G::add(a, b);
+  }
+  ELL_HD static void mul_add_g_item(size_t i, size_t n, const u8* k1s, const u8* k2s,
+                                    const u8* xy2, const A* comb, J* tbl_all,
+                                    const DigitStore& ds, u32* jac) {
+    u32 k1[L], k2[L];
+    load_be<L>(k1, k1s + i * BYTES, BYTES);
+    load_be<L>(k2, k2s + i * BYTES, BYTES);
+    A p2 = load_affine(xy2, i);
+    J r = mul_add_g(k1, k2, p2, comb, tbl_all + i * TBL1, ds);
+    store_jac(jac, n, i, r);
+  }
+
+  // ---- fixed base ----------------------------------------------------------
+  // k*G -> Jacobian (replaces _fixedNafMul, base.js:52-84)
+  ELL_HD static void mul_fixed(size_t i, size_t n, const u8* ks, const A* comb, u32* jac) {
+    u32 k[L];
+    load_be<L>(k, ks + i * BYTES, BYTES);
+    J r = LD::template comb_mul<L, COMB_W>(k, comb);
+    store_jac(jac, n, i, r);
+  }
+
+  // ---- Jacobian -> affine with Montgomery's trick ------------------------------
+  // Thread t converts items t, t+T, t+2T, ... (< n), K of them, with ONE field
+  // inversion (replaces the per-point redInvm of JPoint#toP, short.js:516-526).
+  // out_xy: big-endian x||y (zeroed for infinity), out_inf: 1 = infinity.
+  // raw_aff != null: additionally store the affine point in field-internal
+  // form (used to build the comb tables).
+  ELL_HD static void normalize(size_t t, size_t T, size_t n, int K, const u32* jac, u32* pre,
+                               u8* out_xy, u8* out_inf, A* raw_aff) {
+    El acc = F::one();
+    ELL_NOUNROLL
+    for (int j = 0; j < K; j++) {
+      size_t i = t + (size_t)j * T;
+      if (i >= n) break;
+      El z;
+      ELL_UNROLL
+      for (int l = 0; l < L; l++) z.v[l] = jac[(size_t)(2 * L + l) * n + i];
+      bool inf = F::is_zero(z);
+      z = fe_select<F>(inf, F::one(), z);
+      ELL_UNROLL
+      for (int l = 0; l < L; l++) pre[(size_t)l * n + i] = acc.v[l];
+      acc = F::mul(acc, z);
+    }
+    El inv = F::inv(acc);
+    ELL_NOUNROLL
+    for (int j = K - 1; j >= 0; j--) {
+      size_t i = t + (size_t)j * T;
+      if (i >= n) continue;
+      J p = load_jac(jac, n, i);
+      bool inf = F::is_zero(p.Z);
+      El z = fe_select<F>(inf, F::one(), p.Z);
+      El pr;
+      ELL_UNROLL
+      for (int l = 0; l < L; l++) pr.v[l] = pre[(size_t)l * n + i];
+      El zinv = F::mul(inv, pr);
+      inv = F::mul(inv, z);
+      El zi2 = F::sqr(zinv);
+      El x = F::mul(p.X, zi2);
+      El y = F::mul(p.Y, F::mul(zi2, zinv));
+      if (inf) { x = F::zero(); y = F::zero(); }
+      if (out_xy) {
+        store_fe(out_xy + i * 2 * BYTES, x);
+        store_fe(out_xy + i * 2 * BYTES + BYTES, y);
+      }
+      if (out_inf) out_inf[i] = inf ? 1 : 0;
+      if (raw_aff) { raw_aff[i].x = x; raw_aff[i].y = y; }
+    }
+  }
+
+  // ---- ECDSA verify (ec/index.js:188-229) ---------------------------------------
+  // z = H >> shift for the hash_len-byte big-endian H  (_truncateToN,
+  // ec/index.js:81-108; shift = max(0, msgBits - n.bitLength()))
+  ELL_HD static void load_hash(u32 (&e)[LN], const u8* h, int hash_len, int shift) {
+    int hb = hash_len - (shift >> 3);
+    int bs = shift & 7;
+    u32 t[LN + 1];
+    if (hb <= 0) {
+      bn_zero<LN>(e);
+      return;
+    }
+    load_be<LN + 1>(t, h, hb);
+    ELL_UNROLL
+    for (int i = 0; i < LN; i++) e[i] = bs ? ((t[i] >> bs) | (t[i + 1] << (32 - bs))) : t[i];
+  }
+
+  ELL_HD static bool scalar_in_range(const u32 (&x)[LN]) {      // 1 <= x < n
+    u32 nn[LN];
+    ELL_UNROLL
+    for (int i = 0; i < LN; i++) nn[i] = C::n[i];
+    return !bn_is_zero<LN>(x) && !bn_geq<LN>(x, nn);
+  }
+
+  // Pass 1: thread t handles items t, t+T, ... (K of them): range checks,
+  // s^-1 mod n for all K with one inversion, u1 = z/s, u2 = r/s.
+  ELL_HD static void ecdsa_prep(size_t t, size_t T, size_t n, int K, const u8* hash,
+                                int hash_len, int shift, const u8* rs, const u8* ss, u32* pre,
+                                u32* u12, u8* valid) {
+    Nl acc = Fn::one();
+    ELL_NOUNROLL
+    for (int j = 0; j < K; j++) {
+      size_t i = t + (size_t)j * T;
+      if (i >= n) break;
+      u32 r[LN], s[LN];
+      load_be<LN>(r, rs + i * NBYTES, NBYTES);
+      load_be<LN>(s, ss + i * NBYTES, NBYTES);
+      bool ok = scalar_in_range(r) && scalar_in_range(s);
+      valid[i] = ok ? 1 : 0;
+      Nl sm = Fn::from_plain(s);
+      sm = fe_select<Fn>(ok, sm, Fn::one());
+      ELL_UNROLL
+      for (int l = 0; l < LN; l++) pre[(size_t)l * n + i] = acc.v[l];
+      acc = Fn::mul(acc, sm);
+    }
+    Nl inv = Fn::inv(acc);
+    ELL_NOUNROLL
+    for (int j = K - 1; j >= 0; j--) {
+      size_t i = t + (size_t)j * T;
+      if (i >= n) continue;
+      u32 r[LN], s[LN], e[LN];
+      load_be<LN>(r, rs + i * NBYTES, NBYTES);
+      load_be<LN>(s, ss + i * NBYTES, NBYTES);
+      load_hash(e, hash + i * (size_t)hash_len, hash_len, shift);
+      bool ok = valid[i] != 0;
+      Nl sm = fe_select<Fn>(ok, Fn::from_plain(s), Fn::one());
+      Nl pr;
+      ELL_UNROLL
+      for (int l = 0; l < LN; l++) pr.v[l] = pre[(size_t)l * n + i];
+      Nl w = Fn::mul(inv, pr);                       // s^-1
+      inv = Fn::mul(inv, sm);
+      Nl u1 = Fn::mul(Fn::from_plain(e), w);
+      Nl u2 = Fn::mul(Fn::from_plain(r), w);
+      u32 p1[LN], p2[LN];
+      Fn::to_plain(p1, u1);
+      Fn::to_plain(p2, u2);
+      ELL_UNROLL
+      for (int l = 0; l < LN; l++) {
+        u12[(size_t)(0 * LN + l) * n + i] = ok ? p1[l] : 0u;
+        u12[(size_t)(1 * LN + l) * n + i] = ok ? p2[l] : 0u;
+      }
+    }
+  }
+
+  // JPoint#eqXToP (short.js:908-925): X == r*Z^2, retry with r+n while < p.
+  // (for every preset p < 2n, so one retry at most)
+  ELL_HD static bool eq_x_to_p(const J& p, const u32 (&r)[LN]) {
+    static_assert(LN <= L, "order wider than field");
+    u32 rx[L], pp[L];
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) { rx[i] = i < LN ? r[i] : 0u; pp[i] = C::p[i]; }
+    El zz = F::sqr(p.Z);
+    if (F::eq(p.X, F::mul(F::from_plain(rx), zz))) return true;
+    u32 nn[L], rn[L];
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) nn[i] = i < LN ? C::n[i] : 0u;
+    u32 cy = bn_add<L>(rn, rx, nn);
+    if (cy || bn_geq<L>(rn, pp)) return false;
+    return F::eq(p.X, F::mul(F::from_plain(rn), zz));
+  }
+
+  // Pass 2: R = u1*G + u2*Q, accept iff R != O and R.x == r (mod n)
+  ELL_HD static void ecdsa_main(size_t i, size_t n, const u32* u12, const u8* valid,
+                                const u8* rs, const u8* pub_xy, const A* comb, J* tbl_all,
+                                const DigitStore& ds, u8* out_ok) {
+    u32 u1[L], u2[L], r[LN];
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) {
+      u1[l] = l < LN ? u12[(size_t)(0 * LN + l) * n + i] : 0u;
+      u2[l] = l < LN ? u12[(size_t)(1 * LN + l) * n + i] : 0u;
+    }
+    load_be<LN>(r, rs + i * NBYTES, NBYTES);
+    A q = load_affine(pub_xy, i);
+    J p = mul_add_g(u1, u2, q, comb, tbl_all + i * TBL1, ds);
+    bool ok = valid[i] != 0 && !G::is_inf(p);
+    ok = ok && eq_x_to_p(p, r);
+    out_ok[i] = ok ? 1 : 0;
+  }
+};
+
+}  // namespace ell

@@ -1,0 +1,193 @@
+"""Host-side batch engine over the C ABI (include/ellgpu.h).
+
+One `Context` = one MI355X + one HIP stream (one process per GPU).  Two calling
+styles, matching the two halves of the C ABI:
+
+  * host buffers (numpy uint8 arrays / bytes): `mul_fixed`, `mul_var`,
+    `mul_add2`, `ecdsa_verify`, `x25519` -- synchronous, what the N-API addon
+    does for the patched JS library;
+  * device buffers (torch.uint8 CUDA tensors): the `*_dev` methods -- inputs and
+    outputs stay resident in HBM, work is enqueued on torch's current stream
+    (bench.py, multi-GPU sharding).
+
+All integers are fixed-width big-endian byte strings (see include/ellgpu.h).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+CURVES = ["secp256k1", "p192", "p224", "p256", "p384", "p521", "ed25519", "curve25519"]
+CURVE_ID = {n: i for i, n in enumerate(CURVES)}
+FIELD_BYTES = {"secp256k1": 32, "p192": 24, "p224": 28, "p256": 32, "p384": 48, "p521": 66,
+               "ed25519": 32, "curve25519": 32}
+ORDER_BYTES = dict(FIELD_BYTES)
+
+
+def _u8(a, shape=None):
+    if isinstance(a, (bytes, bytearray, memoryview)):
+        a = np.frombuffer(bytes(a), dtype=np.uint8)
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def ints_to_be(values, width):
+    """list of ints -> (n, width) uint8 big-endian array"""
+    out = np.zeros((len(values), width), dtype=np.uint8)
+    for i, v in enumerate(values):
+        out[i] = np.frombuffer(int(v).to_bytes(width, "big"), dtype=np.uint8)
+    return out
+
+
+def be_to_ints(arr):
+    arr = np.asarray(arr, dtype=np.uint8)
+    return [int.from_bytes(row.tobytes(), "big") for row in arr]
+
+
+class Context:
+    def __init__(self, device=0, lib_path=None):
+        self._lib = _lib.load(lib_path) if not hasattr(lib_path, "ellgpu_version") else lib_path
+        self._ctx = ctypes.c_void_p()
+        rc = self._lib.ellgpu_ctx_create(int(device), ctypes.byref(self._ctx))
+        if rc != 0:
+            raise _lib.EllgpuError(rc, self._lib.ellgpu_last_error().decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.ellgpu_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _lib.EllgpuError(rc, self._lib.ellgpu_last_error().decode())
+
+    @staticmethod
+    def _cid(curve):
+        return CURVE_ID[curve] if isinstance(curve, str) else int(curve)
+
+    def synchronize(self):
+        self._check(self._lib.ellgpu_ctx_synchronize(self._ctx))
+
+    def reserve(self, curve, n):
+        self._check(self._lib.ellgpu_ctx_reserve(self._ctx, self._cid(curve), int(n)))
+
+    # ---- host buffers -------------------------------------------------------
+    def mul_fixed(self, curve, k):
+        B = FIELD_BYTES[curve]
+        k = _u8(k, (-1, B))
+        n = k.shape[0]
+        out = np.zeros((n, 2 * B), np.uint8)
+        inf = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_mul_fixed(self._ctx, self._cid(curve), n, k.ctypes.data,
+                                               out.ctypes.data, inf.ctypes.data))
+        return out, inf
+
+    def mul_var(self, curve, k, xy):
+        B = FIELD_BYTES[curve]
+        k = _u8(k, (-1, B))
+        xy = _u8(xy, (-1, 2 * B))
+        n = k.shape[0]
+        assert xy.shape[0] == n
+        out = np.zeros((n, 2 * B), np.uint8)
+        inf = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_mul_var(self._ctx, self._cid(curve), n, k.ctypes.data,
+                                             xy.ctypes.data, out.ctypes.data, inf.ctypes.data))
+        return out, inf
+
+    def mul_add2(self, curve, k1, p1, k2, p2):
+        """k1*P1 + k2*P2; p1=None means P1 = G."""
+        B = FIELD_BYTES[curve]
+        k1 = _u8(k1, (-1, B))
+        k2 = _u8(k2, (-1, B))
+        p2 = _u8(p2, (-1, 2 * B))
+        n = k1.shape[0]
+        p1p = None
+        if p1 is not None:
+            p1 = _u8(p1, (-1, 2 * B))
+            p1p = p1.ctypes.data
+        out = np.zeros((n, 2 * B), np.uint8)
+        inf = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_mul_add2(self._ctx, self._cid(curve), n, k1.ctypes.data, p1p,
+                                              k2.ctypes.data, p2.ctypes.data, out.ctypes.data,
+                                              inf.ctypes.data))
+        return out, inf
+
+    def ecdsa_verify(self, curve, hashes, r, s, pub, msg_bits=0):
+        B, NB = FIELD_BYTES[curve], ORDER_BYTES[curve]
+        hashes = _u8(hashes)
+        if hashes.ndim != 2:
+            raise ValueError("hashes must be (n, hash_len)")
+        n, hash_len = hashes.shape
+        r = _u8(r, (-1, NB))
+        s = _u8(s, (-1, NB))
+        pub = _u8(pub, (-1, 2 * B))
+        ok = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_ecdsa_verify(self._ctx, self._cid(curve), n, hashes.ctypes.data,
+                                                  hash_len, int(msg_bits), r.ctypes.data,
+                                                  s.ctypes.data, pub.ctypes.data, ok.ctypes.data))
+        return ok
+
+    def x25519(self, k, x):
+        k = _u8(k, (-1, 32))
+        x = _u8(x, (-1, 32))
+        n = k.shape[0]
+        out = np.zeros((n, 32), np.uint8)
+        inf = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_x25519_ladder(self._ctx, n, k.ctypes.data, x.ctypes.data,
+                                                   out.ctypes.data, inf.ctypes.data))
+        return out, inf
+
+    # ---- device buffers (torch CUDA uint8 tensors) ------------------------------
+    @staticmethod
+    def _stream():
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def mul_fixed_dev(self, curve, k, out_xy, out_inf):
+        n = k.shape[0]
+        self._check(self._lib.ellgpu_mul_fixed_dev(self._ctx, self._cid(curve), n, k.data_ptr(),
+                                                   out_xy.data_ptr(), out_inf.data_ptr(),
+                                                   self._stream()))
+
+    def mul_var_dev(self, curve, k, xy, out_xy, out_inf):
+        n = k.shape[0]
+        self._check(self._lib.ellgpu_mul_var_dev(self._ctx, self._cid(curve), n, k.data_ptr(),
+                                                 xy.data_ptr(), out_xy.data_ptr(),
+                                                 out_inf.data_ptr(), self._stream()))
+
+    def mul_add2_dev(self, curve, k1, p1, k2, p2, out_xy, out_inf):
+        n = k1.shape[0]
+        self._check(self._lib.ellgpu_mul_add2_dev(self._ctx, self._cid(curve), n, k1.data_ptr(),
+                                                  None if p1 is None else p1.data_ptr(),
+                                                  k2.data_ptr(), p2.data_ptr(), out_xy.data_ptr(),
+                                                  out_inf.data_ptr(), self._stream()))
+
+    def ecdsa_verify_dev(self, curve, hashes, r, s, pub, out_ok, msg_bits=0):
+        n, hash_len = hashes.shape
+        self._check(self._lib.ellgpu_ecdsa_verify_dev(self._ctx, self._cid(curve), n,
+                                                      hashes.data_ptr(), hash_len, int(msg_bits),
+                                                      r.data_ptr(), s.data_ptr(), pub.data_ptr(),
+                                                      out_ok.data_ptr(), self._stream()))
+
+    def x25519_dev(self, k, x, out_x, out_inf):
+        n = k.shape[0]
+        self._check(self._lib.ellgpu_x25519_ladder_dev(self._ctx, n, k.data_ptr(), x.data_ptr(),
+                                                       out_x.data_ptr(), out_inf.data_ptr(),
+                                                       self._stream()))
+
+    def probe_valu(self, kind, blocks, iters):
+        ms = ctypes.c_double()
+        ops = ctypes.c_double()
+        self._check(self._lib.ellgpu_probe_valu(self._ctx, kind, blocks, iters, ctypes.byref(ms),
+                                                ctypes.byref(ops)))
+        return ms.value, ops.value

@@ -1,0 +1,152 @@
+/*
+ * ellgpu.h -- C ABI of libellgpu.so, the MI355X (gfx950) batched elliptic-curve
+ * scalar-multiplication engine that stands behind indutny/elliptic's
+ * Point.mul / mulAdd / jmulAdd / ec.verify hot path.
+ *
+ * The reference (pure JavaScript, /root/reference) has NO FFI or plugin
+ * interface; its only seam is a set of synchronous, one-item-per-call
+ * prototype methods.  Each entry point below is the batched form of one of
+ * them -- the function an N-API addon binds so that a patched
+ * `elliptic` routes that method here:
+ *
+ *   ellgpu_mul_fixed     <- Point#mul on a precomputed G  -> BaseCurve#_fixedNafMul
+ *                           lib/elliptic/curve/short.js:422-427, base.js:52-84
+ *                           (edwards.js:362-365 for ed25519)
+ *   ellgpu_mul_var       <- Point#mul, variable base      -> _endoWnafMulAdd / _wnafMul
+ *                           short.js:428-431, 218-249; base.js:86-126; edwards.js:366
+ *   ellgpu_mul_add2      <- Point#mulAdd / jmulAdd        -> _wnafMulAdd
+ *                           short.js:434-450; base.js:128-253; edwards.js:369-375
+ *   ellgpu_ecdsa_verify  <- EC#verify after key/signature decoding
+ *                           lib/elliptic/ec/index.js:188-229 (_truncateToN :81-108,
+ *                           JPoint#eqXToP short.js:908-925)
+ *   ellgpu_x25519_ladder <- mont Point#mul + getX         lib/elliptic/curve/mont.js:130-178
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  All integers (scalars, coordinates, r, s)
+ *     are fixed-width BIG-ENDIAN byte strings, item-major, exactly what
+ *     BN#toArray('be', len) / SEC1 04||x||y give (base.js:298-306): width =
+ *     ellgpu_curve_field_bytes() for scalars and coordinates,
+ *     ellgpu_curve_order_bytes() for r and s.  Scalars are NOT reduced mod n by
+ *     the callee, matching the reference (any value of that width is accepted).
+ *   - Points are affine x||y.  A result at infinity is reported through
+ *     out_inf[i] = 1 with its x||y zeroed (the reference returns
+ *     curve.point(null, null), short.js:253-256; for ed25519 the identity (0,1)
+ *     is an ordinary point and out_inf mirrors Point#isInfinity()).
+ *   - Input points are assumed to be on the curve, as in the reference
+ *     (Point#mul does not validate).  Infinity as an INPUT is not representable;
+ *     the JS layer short-circuits it exactly as short.js:424-425 does.
+ *   - Per-item failures (bad r/s range, result at infinity) are per-item
+ *     status bytes, never errors: EC#verify returns false, it does not throw
+ *     (ec/index.js:199-202,222-223).
+ *   - Every function returns 0 on success or a negative ELLGPU_E_* code;
+ *     ellgpu_last_error() gives a thread-local message.  There is NO CPU
+ *     fallback: without a usable gfx950 device ellgpu_ctx_create fails.
+ *   - A context is bound to one device and owns one HIP stream; calls on one
+ *     context are serialised by the caller (one process / thread per GPU, see
+ *     DESIGN.md multi-GPU).  Host-buffer entry points are synchronous.
+ *     The *_dev entry points take DEVICE pointers, enqueue on the given
+ *     hipStream_t (passed as void*, NULL = the context's stream) and return
+ *     without synchronising; outputs are valid once that stream is.
+ */
+#ifndef ELLGPU_H
+#define ELLGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELLGPU_VERSION 0x000100
+
+/* curve ids (names are the reference's preset names, lib/elliptic/curves.js) */
+#define ELLGPU_SECP256K1 0
+#define ELLGPU_P192 1
+#define ELLGPU_P224 2
+#define ELLGPU_P256 3
+#define ELLGPU_P384 4
+#define ELLGPU_P521 5
+#define ELLGPU_ED25519 6
+#define ELLGPU_CURVE25519 7
+
+#define ELLGPU_OK 0
+#define ELLGPU_E_NODEVICE (-1)  /* no gfx950 device / HIP runtime failure at init */
+#define ELLGPU_E_ARG (-2)       /* bad argument (unknown curve, NULL pointer, unsupported width) */
+#define ELLGPU_E_HIP (-3)       /* HIP runtime error during the call */
+#define ELLGPU_E_NOMEM (-4)     /* device allocation failed */
+#define ELLGPU_E_UNSUPPORTED (-5) /* operation not defined for this curve (e.g. mulAdd on curve25519, mont.js:155) */
+
+typedef struct ellgpu_ctx ellgpu_ctx;
+
+int ellgpu_version(void);
+const char* ellgpu_last_error(void);
+
+int ellgpu_curve_id(const char* name);       /* "secp256k1", "p192", ... ; -1 if unknown */
+int ellgpu_curve_field_bytes(int curve);     /* 32, 24, 28, 32, 48, 66, 32, 32 */
+int ellgpu_curve_order_bytes(int curve);     /* byte length of n */
+
+int ellgpu_device_count(void);               /* number of visible HIP devices, <0 on error */
+int ellgpu_ctx_create(int device, ellgpu_ctx** out);
+void ellgpu_ctx_destroy(ellgpu_ctx* ctx);
+int ellgpu_ctx_synchronize(ellgpu_ctx* ctx);
+
+/* ---- host-buffer entry points (what the N-API addon binds) -------------- */
+
+/* out[i] = k[i] * G */
+int ellgpu_mul_fixed(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
+                     uint8_t* out_xy, uint8_t* out_inf);
+/* out[i] = k[i] * P[i] */
+int ellgpu_mul_var(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
+                   const uint8_t* in_xy, uint8_t* out_xy, uint8_t* out_inf);
+/* out[i] = k1[i] * P1[i] + k2[i] * P2[i];  p1_xy == NULL means P1 = G */
+int ellgpu_mul_add2(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1,
+                    const uint8_t* p1_xy, const uint8_t* k2, const uint8_t* p2_xy,
+                    uint8_t* out_xy, uint8_t* out_inf);
+/* out_ok[i] = EC#verify(hash[i], {r[i], s[i]}, pub[i]).
+ * hash: n x hash_len bytes, the message digest exactly as the caller would
+ * pass it to EC#verify as an array (its length, not its value, drives the
+ * truncation: ec/index.js:86-96).  msg_bits = 0 means hash_len*8; otherwise it
+ * is options.msgBitLength (ec/index.js:97-100).  Requires
+ * hash_len*8 - max(0, msg_bits - n.bitLength()) <= 8*order_bytes rounded up to
+ * 32 bits. */
+int ellgpu_ecdsa_verify(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash,
+                        int hash_len, int msg_bits, const uint8_t* r, const uint8_t* s,
+                        const uint8_t* pub_xy, uint8_t* out_ok);
+/* x-only Montgomery ladder on curve25519: out_x[i] = x(k[i] * (in_x[i], .));
+ * out_inf[i] = 1 when the result is the point at infinity (Z == 0), where the
+ * reference's getX() would throw. */
+int ellgpu_x25519_ladder(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* in_x,
+                         uint8_t* out_x, uint8_t* out_inf);
+
+/* ---- device-buffer entry points (inputs/outputs resident in HBM) -------- */
+int ellgpu_mul_fixed_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
+                         uint8_t* out_xy, uint8_t* out_inf, void* stream);
+int ellgpu_mul_var_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
+                       const uint8_t* in_xy, uint8_t* out_xy, uint8_t* out_inf, void* stream);
+int ellgpu_mul_add2_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1,
+                        const uint8_t* p1_xy, const uint8_t* k2, const uint8_t* p2_xy,
+                        uint8_t* out_xy, uint8_t* out_inf, void* stream);
+int ellgpu_ecdsa_verify_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash,
+                            int hash_len, int msg_bits, const uint8_t* r, const uint8_t* s,
+                            const uint8_t* pub_xy, uint8_t* out_ok, void* stream);
+int ellgpu_x25519_ladder_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* in_x,
+                             uint8_t* out_x, uint8_t* out_inf, void* stream);
+
+/* Pre-size the context's scratch arena for batches of up to n items of `curve`
+ * (otherwise it grows on first use); also builds the curve's fixed-base table. */
+int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n);
+
+/* ---- measurement helper --------------------------------------------------
+ * Integer-VALU roofline probe: runs `iters` dependent-free 32x32+64 -> 64 bit
+ * multiply-accumulates (v_mad_u64_u32) per lane on `blocks` x 256 lanes and
+ * returns the elapsed milliseconds measured with HIP events.  kind: 0 =
+ * v_mad_u64_u32, 1 = v_mul_lo_u32 + v_mul_hi_u32 pair, 2 = v_mad_u32_u24,
+ * 3 = v_add_co/addc pair.  Used by bench.py to set the VALU peak. */
+int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iters, double* ms_out,
+                      double* ops_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELLGPU_H */

@@ -1,0 +1,113 @@
+// tests/hostsim -- CPU-only unit-test build of the device code.
+//
+// TEST INFRASTRUCTURE.  This compiles elliptic_amd/csrc/*.h (the very headers
+// the HIP kernels are made of) with g++ and runs each "thread" in a for-loop,
+// so that kernel LOGIC (field arithmetic, group law, recodings, ladders, batch
+// inversion, ECDSA pre/post-processing, the engine's chunking) can be checked
+// against the oracle in a container without a GPU.  It exports the same C ABI
+// as libellgpu.so plus a few white-box probes.  It is built only by the tests
+// (tests/hostsim/build.py -> tests/hostsim/_build/libellgpu_hostsim.so), is
+// never loaded by elliptic_amd, and is not a fallback for anything.
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../elliptic_amd/csrc/engine.h"
+
+namespace ell {
+struct LoopBackend {
+  void use_stream(void*) {}
+  void* alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+  void free_(void* p) { free(p); }
+  void h2d(void* d, const void* h, size_t bytes) { memcpy(d, h, bytes); }
+  void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
+  int sync() { return 0; }
+  template <class Fn>
+  void launch(const Fn& f, size_t nthreads) {
+    signed char digits[Fn::DS_PER_LANE > 0 ? Fn::DS_PER_LANE : 1];
+    DigitStore ds{digits, 1};
+    for (size_t t = 0; t < nthreads; t++) f(t, ds);
+  }
+};
+}  // namespace ell
+
+#define ELL_BACKEND ell::LoopBackend
+static int ell_backend_create(int, ell::LoopBackend*, std::string*) { return 0; }
+static void ell_backend_destroy(ell::LoopBackend*) {}
+static int ell_device_count() { return 1; }
+
+#include "../../elliptic_amd/csrc/capi_common.h"
+
+// ---- white-box probes (hostsim only) -------------------------------------------
+using namespace ell;
+
+template <class F>
+static void field_op(int op, const u32* a, const u32* b, u32* r) {
+  typename F::El x, y, z;
+  u32 ta[F::L], tb[F::L], tr[F::L];
+  for (int i = 0; i < F::L; i++) { ta[i] = a[i]; tb[i] = b[i]; }
+  x = F::from_plain(ta);
+  y = F::from_plain(tb);
+  switch (op) {
+    case 0: z = F::add(x, y); break;
+    case 1: z = F::sub(x, y); break;
+    case 2: z = F::mul(x, y); break;
+    case 3: z = F::sqr(x); break;
+    case 4: z = F::inv(x); break;
+    case 5: z = F::neg(x); break;
+    default: z = x;
+  }
+  F::to_plain(tr, z);
+  for (int i = 0; i < F::L; i++) r[i] = tr[i];
+}
+
+extern "C" {
+// field: 0 k256, 1 25519, 2.. mont(curve p): 10+curve -> base field, 20+curve -> order field
+int hs_field_limbs(int field) {
+  switch (field) {
+    case 0: case 1: return 8;
+    case 10: return 8; case 11: return 6; case 12: return 7; case 13: return 8; case 14: return 12; case 15: return 17;
+    case 20: return 8; case 21: return 6; case 22: return 7; case 23: return 8; case 24: return 12; case 25: return 17;
+    case 26: return 8;
+  }
+  return -1;
+}
+int hs_field_op(int field, int op, const u32* a, const u32* b, u32* r) {
+  switch (field) {
+    case 0: field_op<FpK256>(op, a, b, r); break;
+    case 1: field_op<Fp25519>(op, a, b, r); break;
+    case 10: field_op<FpMont<consts::SECP256K1_P>>(op, a, b, r); break;
+    case 11: field_op<CvP192::F>(op, a, b, r); break;
+    case 12: field_op<CvP224::F>(op, a, b, r); break;
+    case 13: field_op<CvP256::F>(op, a, b, r); break;
+    case 14: field_op<CvP384::F>(op, a, b, r); break;
+    case 15: field_op<CvP521::F>(op, a, b, r); break;
+    case 20: field_op<CvSecp256k1::Fn>(op, a, b, r); break;
+    case 21: field_op<CvP192::Fn>(op, a, b, r); break;
+    case 22: field_op<CvP224::Fn>(op, a, b, r); break;
+    case 23: field_op<CvP256::Fn>(op, a, b, r); break;
+    case 24: field_op<CvP384::Fn>(op, a, b, r); break;
+    case 25: field_op<CvP521::Fn>(op, a, b, r); break;
+    case 26: field_op<FpMont<consts::ED25519_N>>(op, a, b, r); break;
+    default: return -1;
+  }
+  return 0;
+}
+// GLV split of a 256-bit k (8 LE limbs): k1, k2 as 5 LE limbs + sign flags
+void hs_glv_split(const u32* k, u32* k1, int* neg1, u32* k2, int* neg2) {
+  u32 kk[8], a[5], b[5];
+  bool n1, n2;
+  for (int i = 0; i < 8; i++) kk[i] = k[i];
+  glv_split(kk, a, n1, b, n2);
+  for (int i = 0; i < 5; i++) { k1[i] = a[i]; k2[i] = b[i]; }
+  *neg1 = n1; *neg2 = n2;
+}
+// signed 4-bit recoding probe: NNIB = 64 with carry window (65 digits)
+void hs_recode64(const u32* k, signed char* digits) {
+  u32 kk[8];
+  for (int i = 0; i < 8; i++) kk[i] = k[i];
+  DigitStore ds{digits, 1};
+  recode_w4<8, 64, true>(kk, ds, 0, 1);
+}
+}

@@ -1,0 +1,105 @@
+"""Parity checks shared by the CPU (hostsim) and GPU test modules: drive a
+Context through the C ABI and compare with the golden fixtures (reference
+outputs) and with the oracle."""
+import numpy as np
+
+from elliptic_amd import FIELD_BYTES, ORDER_BYTES, be_to_ints, ints_to_be
+from golden_util import I, mul_cases, res_xy, verify_cases
+
+
+def _res_from(out, inf, i, B, xonly=False):
+    if inf[i]:
+        return None
+    x = int.from_bytes(out[i, :B].tobytes(), "big")
+    if xonly:
+        return (x,)
+    y = int.from_bytes(out[i, B:2 * B].tobytes(), "big")
+    return (x, y)
+
+
+def check_mul_golden(ctx, curve):
+    """every golden mul/muladd case of `curve` (seeded, edge, and captured from
+    the reference's own test-suite) through the batched C ABI."""
+    B = FIELD_BYTES[curve]
+    cases = mul_cases(curve)
+    fixed = [c for c in cases if c["op"] == "fixed"]
+    var = [c for c in cases if c["op"] == "var"]
+    madd = [c for c in cases if c["op"] == "muladd"]
+    n_checked = 0
+    if fixed:
+        out, inf = ctx.mul_fixed(curve, ints_to_be([I(c["k"]) for c in fixed], B))
+        for i, c in enumerate(fixed):
+            want = res_xy(c["r"])
+            got = _res_from(out, inf, i, B)
+            assert got == want, ("fixed", curve, c)
+            n_checked += 1
+    if var:
+        ks = ints_to_be([I(c["k"]) for c in var], B)
+        pts = np.concatenate([ints_to_be([I(c["px"]) for c in var], B),
+                              ints_to_be([I(c["py"]) for c in var], B)], axis=1)
+        out, inf = ctx.mul_var(curve, ks, pts)
+        for i, c in enumerate(var):
+            assert _res_from(out, inf, i, B) == res_xy(c["r"]), ("var", curve, c)
+            n_checked += 1
+    if madd:
+        k1 = ints_to_be([I(c["k1"]) for c in madd], B)
+        k2 = ints_to_be([I(c["k2"]) for c in madd], B)
+        p1 = np.concatenate([ints_to_be([I(c["p1x"]) for c in madd], B),
+                             ints_to_be([I(c["p1y"]) for c in madd], B)], axis=1)
+        p2 = np.concatenate([ints_to_be([I(c["p2x"]) for c in madd], B),
+                             ints_to_be([I(c["p2y"]) for c in madd], B)], axis=1)
+        out, inf = ctx.mul_add2(curve, k1, p1, k2, p2)
+        for i, c in enumerate(madd):
+            assert _res_from(out, inf, i, B) == res_xy(c["r"]), ("muladd", curve, c)
+            n_checked += 1
+        # the P1 = G form (comb + ladder), on the cases whose first point is G
+        from oracle import ec_oracle as O
+        cur = O.get_curve(curve)
+        if curve == "ed25519":
+            gx, gy = cur.g.x, cur.g.y
+        else:
+            gx, gy = cur.g.x, cur.g.y
+        gi = [i for i, c in enumerate(madd) if (I(c["p1x"]), I(c["p1y"])) == (gx, gy)]
+        if gi:
+            out, inf = ctx.mul_add2(curve, k1[gi], None, k2[gi], p2[gi])
+            for j, i in enumerate(gi):
+                assert _res_from(out, inf, j, B) == res_xy(madd[i]["r"]), ("muladd-G", curve, madd[i])
+                n_checked += 1
+    return n_checked
+
+
+def check_x25519_golden(ctx):
+    cases = mul_cases("curve25519")
+    ks = ints_to_be([I(c["k"]) for c in cases], 32)
+    xs = ints_to_be([I(c["px"]) for c in cases], 32)
+    out, inf = ctx.x25519(ks, xs)
+    for i, c in enumerate(cases):
+        assert _res_from(out, inf, i, 32, xonly=True) == res_xy(c["r"]), c
+    return len(cases)
+
+
+def check_verify_golden(ctx, curve):
+    """golden ECDSA verify tuples, grouped by (hash length, msgBitLength)."""
+    B, NB = FIELD_BYTES[curve], ORDER_BYTES[curve]
+    groups = {}
+    for c in verify_cases(curve):
+        key = (len(c["z"]) // 2, c.get("msgBitLength", 0))
+        groups.setdefault(key, []).append(c)
+    n_checked = 0
+    for (hlen, mbits), cs in groups.items():
+        hashes = ints_to_be([I(c["z"]) for c in cs], hlen)
+        r = ints_to_be([I(c["r"]) for c in cs], NB)
+        s = ints_to_be([I(c["s"]) for c in cs], NB)
+        pub = np.concatenate([ints_to_be([I(c["qx"]) for c in cs], B),
+                              ints_to_be([I(c["qy"]) for c in cs], B)], axis=1)
+        nlimb_bits = 32 * ((NB * 8 + 31) // 32)
+        from oracle import ec_oracle as O
+        nbits = O.get_curve(curve).n.bit_length()
+        bits = mbits or hlen * 8
+        if hlen * 8 - max(0, bits - nbits) > nlimb_bits:
+            continue                      # outside the C ABI's documented domain
+        ok = ctx.ecdsa_verify(curve, hashes, r, s, pub, msg_bits=mbits)
+        for i, c in enumerate(cs):
+            assert bool(ok[i]) == c["ok"], (curve, c)
+            n_checked += 1
+    return n_checked

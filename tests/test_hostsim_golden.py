@@ -1,0 +1,138 @@
+"""CPU-only checks of the DEVICE CODE's logic: tests/hostsim compiles the same
+headers the HIP kernels are built from with g++ and runs every thread in a
+loop.  These tests drive that build through the same C ABI as libellgpu.so and
+compare with the reference's golden vectors.  (The GPU parity tests proper are
+in test_gpu_parity.py, -m gpu.)"""
+import ctypes
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from hostsim.build import build as build_hostsim  # noqa: E402
+
+import elliptic_amd  # noqa: E402
+from elliptic_amd import _lib  # noqa: E402
+import parity_checks as PC  # noqa: E402
+from oracle import ec_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hs():
+    path = build_hostsim()
+    lib = _lib.load(path, optional=("ellgpu_probe_valu",))
+    return lib
+
+
+@pytest.fixture(scope="module")
+def ctx(hs):
+    c = elliptic_amd.Context(0, lib_path=hs)
+    yield c
+    c.close()
+
+
+FIELDS = {
+    0: int(O.get_curve("secp256k1", False).p), 1: 2 ** 255 - 19,
+    10: O.get_curve("secp256k1", False).p, 11: O.get_curve("p192", False).p,
+    12: O.get_curve("p224", False).p, 13: O.get_curve("p256", False).p,
+    14: O.get_curve("p384", False).p, 15: O.get_curve("p521", False).p,
+    20: O.get_curve("secp256k1", False).n, 21: O.get_curve("p192", False).n,
+    22: O.get_curve("p224", False).n, 23: O.get_curve("p256", False).n,
+    24: O.get_curve("p384", False).n, 25: O.get_curve("p521", False).n,
+    26: O.get_curve("ed25519", False).n,
+}
+
+
+def _limbs(x, L):
+    return (ctypes.c_uint32 * L)(*[(x >> (32 * i)) & 0xFFFFFFFF for i in range(L)])
+
+
+def _val(arr):
+    return sum(int(v) << (32 * i) for i, v in enumerate(arr))
+
+
+@pytest.mark.parametrize("field", sorted(FIELDS))
+def test_field_ops(hs, field):
+    p = FIELDS[field]
+    L = hs.hs_field_limbs(field)
+    rnd = random.Random(1000 + field)
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, 2 ** (32 * L) - 1 if field in (0, 1) else p - 3,
+            2 ** 32 - 1, 2 ** 64, p >> 1]
+    vals = [(a % (2 ** (32 * L))) for a in edge] + [rnd.randrange(p) for _ in range(60)]
+    for a in vals:
+        for b in (vals[rnd.randrange(len(vals))], rnd.randrange(p), p - 1):
+            for op, fn in ((0, lambda x, y: (x + y) % p), (1, lambda x, y: (x - y) % p),
+                           (2, lambda x, y: x * y % p), (3, lambda x, y: x * x % p),
+                           (5, lambda x, y: (-x) % p)):
+                r = (ctypes.c_uint32 * L)()
+                assert hs.hs_field_op(field, op, _limbs(a, L), _limbs(b, L), r) == 0
+                assert _val(r) == fn(a % p, b % p), (field, op, hex(a), hex(b))
+    for a in vals[:20]:
+        if a % p == 0:
+            continue
+        r = (ctypes.c_uint32 * L)()
+        hs.hs_field_op(field, 4, _limbs(a, L), _limbs(0, L), r)
+        assert _val(r) == pow(a % p, -1, p)
+
+
+def test_glv_split(hs):
+    cur = O.get_curve("secp256k1", False)
+    lam, n = cur.endo["lambda"], cur.n
+    rnd = random.Random(5)
+    ks = [0, 1, 2, n - 1, n, n + 1, 2 ** 256 - 1, lam, lam + 1, n - lam, 2 ** 128, 2 ** 255]
+    ks += [rnd.getrandbits(256) for _ in range(3000)]
+    worst = 0
+    for k in ks:
+        k1 = (ctypes.c_uint32 * 5)()
+        k2 = (ctypes.c_uint32 * 5)()
+        n1, n2 = ctypes.c_int(), ctypes.c_int()
+        hs.hs_glv_split(_limbs(k, 8), k1, ctypes.byref(n1), k2, ctypes.byref(n2))
+        a, b = _val(k1), _val(k2)
+        if n1.value:
+            a = -a
+        if n2.value:
+            b = -b
+        assert (a + b * lam - k) % n == 0
+        worst = max(worst, abs(a).bit_length(), abs(b).bit_length())
+    # the 33-nibble recoding without a carry window needs |k| < 2^131
+    assert worst <= 129, worst
+
+
+def test_recode_w4(hs):
+    rnd = random.Random(9)
+    for k in [0, 1, 7, 8, 9, 2 ** 256 - 1, 2 ** 255, 0x8888 << 240] + [rnd.getrandbits(256) for _ in range(300)]:
+        d = (ctypes.c_byte * 65)()
+        hs.hs_recode64(_limbs(k, 8), d)
+        ds = list(d)
+        assert all(-8 <= x <= 7 for x in ds[:64]) and ds[64] in (0, 1)
+        assert sum(x * 16 ** i for i, x in enumerate(ds)) == k
+
+
+@pytest.mark.parametrize("curve", O.SHORT_CURVES + ["ed25519"])
+def test_mul_golden(ctx, curve):
+    assert PC.check_mul_golden(ctx, curve) > 50
+
+
+def test_x25519_golden(ctx):
+    assert PC.check_x25519_golden(ctx) > 30
+
+
+@pytest.mark.parametrize("curve", O.SHORT_CURVES)
+def test_verify_golden(ctx, curve):
+    assert PC.check_verify_golden(ctx, curve) > 15
+
+
+def test_error_paths(ctx, hs):
+    with pytest.raises(elliptic_amd.EllgpuError):
+        ctx.mul_fixed("curve25519", np.zeros((1, 32), np.uint8))
+    with pytest.raises(elliptic_amd.EllgpuError) as e:
+        ctx.mul_add2("curve25519", np.zeros((1, 32), np.uint8), None, np.zeros((1, 32), np.uint8),
+                     np.zeros((1, 64), np.uint8))
+    assert "Not supported on Montgomery curve" in str(e.value)      # mont.js:155-157
+    assert hs.ellgpu_curve_id(b"secp256k1") == 0 and hs.ellgpu_curve_id(b"nope") == -1
+    # empty batch is a no-op
+    out, inf = ctx.mul_fixed("secp256k1", np.zeros((0, 32), np.uint8))
+    assert out.shape == (0, 64)
