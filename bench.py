@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- secp256k1 ECDSA verify batch throughput on N MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric "EC
+scalar-mults/sec (secp256k1 verify batch)" is quoted on): a batch of 2^20
+synthetic (hash, r, s, pubkey) tuples per GPU, 1 % of them corrupted, already
+resident in HBM; one "step" = one pass of the hot path (ellgpu_ecdsa_verify_dev:
+range checks, batched s^-1 mod n, u1*G + u2*Q with GLV, projective x-compare)
+over the whole batch.  Weak scaling: every rank owns its own 2^20 tuples, the
+only collective is the final gather of the ok-masks (RCCL all_gather).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# algorithmic work per unit, SURVEY.md 8(d): reference field mul+sqr count x
+# (2*8^2 + 8) 32-bit MACs; bytes = 160 in + 1 out
+MACS_PER_VERIFY = 2236 * 136
+BYTES_PER_VERIFY = 161
+HBM_PEAK_GBS = 8000.0
+
+SECP_N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+
+
+def xof(seed: str, nbytes: int) -> np.ndarray:
+    return np.frombuffer(hashlib.shake_256(seed.encode()).digest(nbytes), dtype=np.uint8)
+
+
+def make_signatures(ctx, n, seed, corrupt_every=100):
+    """n synthetic secp256k1 signatures, all distinct keys/nonces, built without
+    any modular inversion: pick d, k, s; r = x(kG) mod n; z = s*k - r*d mod n.
+    Every `corrupt_every`-th tuple gets one bit flipped in z, r or s.
+    Returns (hash, r, s, pub, expected_ok) as numpy arrays."""
+    from elliptic_amd import ints_to_be
+    N = SECP_N
+    raw = xof(seed + ":d", n * 40).reshape(n, 40)
+    ds = [int.from_bytes(row.tobytes(), "big") % (N - 1) + 1 for row in raw]
+    raw = xof(seed + ":k", n * 40).reshape(n, 40)
+    ks = [int.from_bytes(row.tobytes(), "big") % (N - 1) + 1 for row in raw]
+    raw = xof(seed + ":s", n * 40).reshape(n, 40)
+    ss = [int.from_bytes(row.tobytes(), "big") % (N - 1) + 1 for row in raw]
+    pub, inf = ctx.mul_fixed("secp256k1", ints_to_be(ds, 32))
+    assert not inf.any()
+    R, inf = ctx.mul_fixed("secp256k1", ints_to_be(ks, 32))
+    assert not inf.any()
+    rs, zs = [], []
+    for i in range(n):
+        r = int.from_bytes(R[i, :32].tobytes(), "big") % N
+        rs.append(r)
+        zs.append((ss[i] * ks[i] - r * ds[i]) % N)
+    h = ints_to_be(zs, 32)
+    r = ints_to_be(rs, 32)
+    s = ints_to_be(ss, 32)
+    ok = np.ones(n, np.uint8)
+    ok[np.array(rs) == 0] = 0
+    idx = np.arange(0, n, corrupt_every)
+    for j, i in enumerate(idx):
+        which = (h, r, s)[j % 3]
+        which[i, 31 - (j % 8)] ^= 1 << (j % 7)
+        ok[i] = 0
+    return h, r, s, pub, ok
+
+
+def cpu_baseline(h, r, s, pub, ok, budget_s=15.0):
+    """The oracle (CPU restatement of the reference's algorithm, oracle/) timed on
+    this host on a bounded sample of the same tuples.  Checker only."""
+    built = None
+    try:
+        from oracle import c_oracle
+        built = c_oracle.load()
+    except Exception:
+        built = None
+    from elliptic_amd import be_to_ints
+    if built is not None:
+        return c_oracle.bench_verify(built, h, r, s, pub, ok, budget_s)
+    from oracle import ec_oracle as O
+    cur = O.get_curve("secp256k1")
+    m = min(len(ok), 4000)
+    zs, rs, ss = be_to_ints(h[:m]), be_to_ints(r[:m]), be_to_ints(s[:m])
+    qx, qy = be_to_ints(pub[:m, :32]), be_to_ints(pub[:m, 32:])
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(m):
+        got = O.ecdsa_verify(cur, zs[i], 32, rs[i], ss[i], cur.point(qx[i], qy[i]))
+        assert got == bool(ok[i]), "oracle disagrees with the expected mask at %d" % i
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "verifies/s", "cores": 1, "kind": "port",
+            "sample": "first %d tuples of the rank-0 batch, oracle/ec_oracle.py (python ints), 1 thread" % done}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="tuples per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
+                         "--nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import elliptic_amd
+    ctx = elliptic_amd.Context(local_rank)
+    n = args.batch
+    h, r, s, pub, expect = make_signatures(ctx, n, "ellgpu-bench-v1:3:rank%d" % rank)
+    dev = torch.device("cuda", local_rank)
+    dh, dr, dsg, dq = (torch.from_numpy(x).to(dev) for x in (h, r, s, pub))
+    dok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    gathered = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(world)] if world > 1 else None
+    ctx.reserve("secp256k1", n)
+
+    def step():
+        ctx.ecdsa_verify_dev("secp256k1", dh, dr, dsg, dq, dok)
+        if world > 1:
+            dist.all_gather(gathered, dok)          # the final gather, RCCL over xGMI
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    # parity at full size: the mask must equal the expected one exactly
+    got = dok.cpu().numpy()
+    if not np.array_equal(got, expect):
+        bad = int((got != expect).sum())
+        raise SystemExit("PARITY FAILURE: %d of %d verify results differ from the expected mask" % (bad, n))
+
+    ctx.set_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timing = ctx.get_timing()
+    ctx.set_timing(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total = n * world * args.steps
+        value = total / dt
+        cnt, main_ms = timing.get("ecdsa_main", (0, 0.0))
+        pcnt, prep_ms = timing.get("ecdsa_prep", (0, 0.0))
+        k_ms = main_ms / max(cnt, 1)
+        # integer-VALU peak: dependency-free v_mad_u64_u32 stream on every CU
+        ms, ops = ctx.probe_valu(0, 256 * 8 * 4, 4096)
+        peak_gmacs = ops / (ms * 1e-3) / 1e9
+        ach_gmacs = n * MACS_PER_VERIFY / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
+        ach_gbs = n * BYTES_PER_VERIFY / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
+        out = {
+            "metric": "secp256k1 ECDSA verify batch throughput (1 verify = 1 double-scalar mult u1*G+u2*Q)",
+            "value": value,
+            "unit": "verifies/s",
+            "scalar_mults_per_s": 2 * value,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "secp256k1 ECDSA verify (GLV variable-base + fixed-base comb), "
+                                   "batch=2^20 tuples per GPU resident in HBM, 1% corrupted"
+                                   if n == 1 << 20 else "secp256k1 ECDSA verify, batch=%d per GPU" % n,
+                       "batch_per_gpu": n, "parallelism": "shard%d" % world,
+                       "parity": "ok-mask == expected mask on all %d tuples" % n},
+            "roofline": {
+                "bound": "valu_int32_mac",
+                "kernel": "ecdsa_main",
+                "achieved": ach_gmacs, "peak": peak_gmacs, "unit": "GMAC/s",
+                "frac": ach_gmacs / peak_gmacs if peak_gmacs else None,
+                "kernel_ms": k_ms, "prep_kernel_ms": prep_ms / max(pcnt, 1),
+                "alg_macs_per_unit": MACS_PER_VERIFY,
+                "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach_gbs / HBM_PEAK_GBS, "alg_bytes_per_unit": BYTES_PER_VERIFY},
+                "traffic": None,
+            },
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(h, r, s, pub, expect)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

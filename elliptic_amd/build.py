@@ -1,0 +1,112 @@
+"""Build elliptic_amd/lib/libellgpu.so with hipcc for gfx950.
+
+The kernels are instantiated per (curve, operation group) in separate
+translation units (csrc/inst.hip with -DELL_INST_CURVE / -DELL_INST_GROUP) so
+that they compile in parallel; objects are cached under csrc/_obj keyed by a
+hash of every source file and the flags.  hipcc cross-compiles without a GPU.
+
+    python -m elliptic_amd.build [-j N] [--force]
+"""
+import argparse
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libellgpu.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+CURVES = ["CvP521", "CvP384", "CvP256", "CvSecp256k1", "CvP224", "CvP192"]   # slowest first
+GROUPS = [4, 2, 3, 0, 1]
+
+
+def units():
+    u = []
+    for c in CURVES:
+        for g in GROUPS:
+            u.append(("inst_%s_g%d" % (c, g), "inst.hip", ["-DELL_INST_CURVE=" + c, "-DELL_INST_GROUP=%d" % g]))
+    for g in (10, 11, 12):
+        u.append(("inst_g%d" % g, "inst.hip", ["-DELL_INST_GROUP=%d" % g]))
+    u.append(("capi", "capi.hip", []))
+    return u
+
+
+def source_digest():
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))
+    files = [os.path.join(CSRC, f) for f in files] + [os.path.join(HERE, "..", "include", "ellgpu.h")]
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def compile_one(args):
+    name, src, defs, digest, extra = args
+    obj = os.path.join(OBJ, "%s.%s.o" % (name, digest))
+    if os.path.exists(obj):
+        return name, obj, 0.0, ""
+    t0 = time.time()
+    cmd = [HIPCC] + FLAGS + extra + defs + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (name, " ".join(cmd), p.stderr[-4000:]))
+    os.replace(obj + ".tmp", obj)
+    return name, obj, time.time() - t0, p.stderr
+
+
+def build(jobs=None, force=False, verbose=True, remarks=False):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    digest = source_digest()
+    stamp = os.path.join(LIBDIR, "libellgpu.stamp")
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
+        if verbose:
+            print("libellgpu.so up to date (%s)" % digest)
+        return LIB
+    # drop objects of older source states
+    for f in os.listdir(OBJ):
+        if digest not in f:
+            os.remove(os.path.join(OBJ, f))
+    jobs = jobs or max(1, (os.cpu_count() or 2))
+    extra = ["-Rpass-analysis=kernel-resource-usage"] if remarks else []
+    work = [(n, s, d, digest, extra) for (n, s, d) in units()]
+    objs = []
+    log = []
+    t0 = time.time()
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        for name, obj, dt, err in ex.map(compile_one, work):
+            objs.append(obj)
+            log.append(err)
+            if verbose and dt:
+                print("  compiled %-28s %6.1fs" % (name, dt), flush=True)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("link failed:\n" + p.stderr[-4000:])
+    os.replace(LIB + ".tmp", LIB)
+    with open(stamp, "w") as f:
+        f.write(digest)
+    if remarks:
+        with open(os.path.join(OBJ, "resource_usage.log"), "w") as f:
+            f.write("\n".join(log))
+    if verbose:
+        print("built %s in %.1fs" % (LIB, time.time() - t0))
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-j", type=int, default=None)
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--remarks", action="store_true", help="keep kernel-resource-usage remarks in csrc/_obj/resource_usage.log")
+    a = ap.parse_args()
+    build(a.j, a.force, True, a.remarks)

@@ -1,0 +1,146 @@
+// ellgpu -- libellgpu.so: the C ABI over Engine<HipBackend> (gfx950 / MI355X),
+// context creation, and the integer-VALU roofline probe.  The kernels themselves
+// are instantiated per (curve, operation) in inst.hip; all curve arithmetic is in
+// the headers; there is no vendor library and no CPU path behind this library.
+#include "engine_extern.h"
+
+namespace ell {
+
+// ---- integer-VALU roofline probe ----------------------------------------------
+// Each lane runs `iters` rounds of 16 independent 32x32+64->64 multiply-adds
+// (or the comparison instruction mixes); nothing is loaded inside the loop.
+template <int KIND>
+__global__ void __launch_bounds__(256) k_probe(u32* out, int iters, u32 seed) {
+  u32 a = seed + threadIdx.x * 2654435761u, b = a ^ 0x9E3779B9u;
+  u64 acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) acc[j] = (u64)(a + j) << 7;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      if (KIND == 0) {
+        acc[j] = (u64)a * b + acc[j];                       // v_mad_u64_u32
+      } else if (KIND == 1) {
+        u32 lo = a * (u32)acc[j];                           // v_mul_lo_u32
+        u32 hi = __umulhi(b, (u32)acc[j]);                  // v_mul_hi_u32
+        acc[j] = ((u64)hi << 32) | lo;
+      } else if (KIND == 2) {
+        u32 lo = __umul24((u32)acc[j], a) + b;   // v_mad_u32_u24
+        acc[j] = ((u64)(u32)(acc[j] >> 32) << 32) | lo;
+      } else {
+        acc[j] = acc[j] + (((u64)b << 32) | a);             // v_add_co + v_addc
+      }
+    }
+    a += 0x1234567u;
+    b ^= a;
+  }
+  u64 s = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) s ^= acc[j];
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = (u32)s ^ (u32)(s >> 32);
+}
+
+}  // namespace ell
+
+#define ELL_BACKEND ell::HipBackend
+
+static int ell_device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return n;
+}
+static int ell_backend_create(int device, ell::HipBackend* bk, std::string* err) {
+  int n = ell_device_count();
+  if (n <= 0) { *err = "no HIP device visible (libellgpu has no CPU fallback)"; return ell::E_NODEVICE; }
+  if (device < 0 || device >= n) { *err = "device index out of range"; return ell::E_ARG; }
+  if (hipSetDevice(device) != hipSuccess) { *err = "hipSetDevice failed"; return ell::E_NODEVICE; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { *err = "hipGetDeviceProperties failed"; return ell::E_NODEVICE; }
+  std::string arch = prop.gcnArchName;
+  if (arch.rfind("gfx950", 0) != 0) {
+    *err = "device is " + arch + ", libellgpu is built for gfx950 (MI355X) only";
+    return ell::E_NODEVICE;
+  }
+  bk->device = device;
+  if (hipStreamCreateWithFlags(&bk->own, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; return ell::E_HIP; }
+  bk->cur = bk->own;
+  bk->timed = new std::vector<ell::TimedLaunch>();
+  return ell::E_OK;
+}
+static void ell_backend_destroy(ell::HipBackend* bk) {
+  if (bk->own) (void)hipStreamDestroy(bk->own);
+  bk->own = nullptr;
+  if (bk->timed) {
+    for (auto& t : *bk->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+    delete bk->timed;
+    bk->timed = nullptr;
+  }
+}
+
+#include "capi_common.h"
+
+extern "C" int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iters, double* ms_out,
+                                 double* ops_out) {
+  ELL_ENTER(ctx, nullptr);
+  if (blocks <= 0 || iters <= 0 || !ms_out || !ops_out) return set_err(ELLGPU_E_ARG, "bad probe arguments");
+  ell::HipBackend& bk = ctx->eng->bk;
+  ell::u32* out = (ell::u32*)bk.alloc((size_t)blocks * 256 * 4);
+  if (!out) return set_err(ELLGPU_E_NOMEM, "probe allocation failed");
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; rep++) {           // first pass warms up clocks / code
+    (void)hipEventRecord(e0, bk.cur);
+    switch (kind) {
+      case 0: hipLaunchKernelGGL(ell::k_probe<0>, dim3(blocks), dim3(256), 0, bk.cur, out, iters, 12345u); break;
+      case 1: hipLaunchKernelGGL(ell::k_probe<1>, dim3(blocks), dim3(256), 0, bk.cur, out, iters, 12345u); break;
+      case 2: hipLaunchKernelGGL(ell::k_probe<2>, dim3(blocks), dim3(256), 0, bk.cur, out, iters, 12345u); break;
+      default: hipLaunchKernelGGL(ell::k_probe<3>, dim3(blocks), dim3(256), 0, bk.cur, out, iters, 12345u); break;
+    }
+    (void)hipEventRecord(e1, bk.cur);
+    (void)hipEventSynchronize(e1);
+  }
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  bk.free_(out);
+  *ms_out = ms;
+  *ops_out = (double)blocks * 256.0 * (double)iters * 16.0;
+  return finish(ctx, bk.sync());
+}
+
+// Per-kernel timing (HIP events recorded around every launch on the stream the
+// kernel runs on).  ellgpu_ctx_set_timing(ctx, 1) starts a fresh recording;
+// ellgpu_ctx_get_timing synchronises and writes one line per kernel name:
+// "<name> <launches> <total_ms>\n".  Returns the number of bytes written.
+extern "C" int ellgpu_ctx_set_timing(ellgpu_ctx* ctx, int on) {
+  if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  ell::HipBackend& bk = ctx->eng->bk;
+  for (auto& t : *bk.timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+  bk.timed->clear();
+  bk.timing = on != 0;
+  return ELLGPU_OK;
+}
+extern "C" int ellgpu_ctx_get_timing(ellgpu_ctx* ctx, char* buf, size_t cap) {
+  if (!ctx || !buf || !cap) return set_err(ELLGPU_E_ARG, "bad arguments");
+  ell::HipBackend& bk = ctx->eng->bk;
+  (void)hipDeviceSynchronize();
+  std::map<std::string, std::pair<int, double>> acc;
+  for (auto& t : *bk.timed) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, t.e0, t.e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+    auto& a = acc[t.name];
+    a.first += 1;
+    a.second += ms;
+  }
+  std::string out;
+  for (auto& kv : acc) {
+    char line[160];
+    snprintf(line, sizeof line, "%s %d %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    out += line;
+  }
+  if (out.size() + 1 > cap) return set_err(ELLGPU_E_ARG, "timing buffer too small");
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return (int)out.size();
+}

@@ -27,6 +27,7 @@ enum { E_OK = 0, E_NODEVICE = -1, E_ARG = -2, E_HIP = -3, E_NOMEM = -4, E_UNSUPP
 // ---- functors (one per kernel) ------------------------------------------------
 template <class CV>
 struct FnMulVar {
+  static constexpr const char* NAME = "mul_var";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
   size_t n; const u8* k; const u8* xy; typename W::J* tbl; u32* jac;
@@ -36,6 +37,7 @@ struct FnMulVar {
 };
 template <class CV>
 struct FnMulAdd2 {
+  static constexpr const char* NAME = "mul_add2";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV * 2;
   size_t n; const u8* k1; const u8* xy1; const u8* k2; const u8* xy2; typename W::J* tbl; u32* jac;
@@ -45,6 +47,7 @@ struct FnMulAdd2 {
 };
 template <class CV>
 struct FnMulAddG {
+  static constexpr const char* NAME = "mul_add_g";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
   size_t n; const u8* k1; const u8* k2; const u8* xy2; const typename W::A* comb;
@@ -55,6 +58,7 @@ struct FnMulAddG {
 };
 template <class CV>
 struct FnMulFixed {
+  static constexpr const char* NAME = "mul_fixed";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = 0;
   size_t n; const u8* k; const typename W::A* comb; u32* jac;
@@ -64,6 +68,7 @@ struct FnMulFixed {
 };
 template <class CV>
 struct FnNormalize {
+  static constexpr const char* NAME = "normalize";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = 0;
   size_t T; size_t n; int K; const u32* jac; u32* pre; u8* out_xy; u8* out_inf;
@@ -74,6 +79,7 @@ struct FnNormalize {
 };
 template <class CV>
 struct FnEcdsaPrep {
+  static constexpr const char* NAME = "ecdsa_prep";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = 0;
   size_t T; size_t n; int K; const u8* hash; int hash_len; int shift; const u8* r; const u8* s;
@@ -84,6 +90,7 @@ struct FnEcdsaPrep {
 };
 template <class CV>
 struct FnEcdsaMain {
+  static constexpr const char* NAME = "ecdsa_main";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
   size_t n; const u32* u12; const u8* valid; const u8* r; const u8* pub;
@@ -95,6 +102,7 @@ struct FnEcdsaMain {
 
 // Edwards / Montgomery functors
 struct FnEdMulVar {
+  static constexpr const char* NAME = "ed_mul_var";
   static constexpr int DS_PER_LANE = EdWork::NWIN;
   size_t n; const u8* k; const u8* xy; EdWork::P* tbl; u32* ext;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
@@ -102,6 +110,7 @@ struct FnEdMulVar {
   }
 };
 struct FnEdMulFixed {
+  static constexpr const char* NAME = "ed_mul_fixed";
   static constexpr int DS_PER_LANE = 0;
   size_t n; const u8* k; const EdWork::P* comb; u32* ext;
   ELL_HD void operator()(size_t i, const DigitStore&) const {
@@ -109,6 +118,7 @@ struct FnEdMulFixed {
   }
 };
 struct FnEdMulAddG {
+  static constexpr const char* NAME = "ed_mul_add_g";
   static constexpr int DS_PER_LANE = EdWork::NWIN;
   size_t n; const u8* k1; const u8* k2; const u8* xy2; const EdWork::P* comb; EdWork::P* tbl;
   u32* ext;
@@ -117,6 +127,7 @@ struct FnEdMulAddG {
   }
 };
 struct FnEdMulAdd2 {
+  static constexpr const char* NAME = "ed_mul_add2";
   static constexpr int DS_PER_LANE = EdWork::NWIN * 2;
   size_t n; const u8* k1; const u8* xy1; const u8* k2; const u8* xy2; EdWork::P* tbl; u32* ext;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
@@ -124,6 +135,7 @@ struct FnEdMulAdd2 {
   }
 };
 struct FnEdNormalize {
+  static constexpr const char* NAME = "ed_normalize";
   static constexpr int DS_PER_LANE = 0;
   size_t T; size_t n; int K; const u32* ext; u32* pre; u8* out_xy; u8* out_inf; EdWork::P* raw;
   ELL_HD void operator()(size_t t, const DigitStore&) const {
@@ -131,6 +143,7 @@ struct FnEdNormalize {
   }
 };
 struct FnX25519 {
+  static constexpr const char* NAME = "x25519_ladder";
   static constexpr int DS_PER_LANE = 0;
   size_t n; const u8* k; const u8* x; u32* xz;
   ELL_HD void operator()(size_t i, const DigitStore&) const {
@@ -138,6 +151,7 @@ struct FnX25519 {
   }
 };
 struct FnX25519Normalize {
+  static constexpr const char* NAME = "x25519_normalize";
   static constexpr int DS_PER_LANE = 0;
   size_t T; size_t n; int K; const u32* xz; u32* pre; u8* out_x; u8* out_inf;
   ELL_HD void operator()(size_t t, const DigitStore&) const {
@@ -204,191 +218,36 @@ class Engine {
 
   // ---- fixed-base comb tables, built on the device with our own kernels ----
   template <class CV>
-  int ensure_comb() {
-    typedef Work<CV> W;
-    if (comb_[CV::ID]) return E_OK;
-    const size_t n = W::COMB_ENTRIES;
-    const int B = W::BYTES;
-    std::vector<u8> ks(n * B, 0), pts(n * 2 * B, 0);
-    u8 g[2 * 66];
-    {
-      u32 gx[W::L], gy[W::L];
-      for (int i = 0; i < W::L; i++) { gx[i] = W::C::gx_plain[i]; gy[i] = W::C::gy_plain[i]; }
-      store_be<W::L>(g, gx, B);
-      store_be<W::L>(g + B, gy, B);
-    }
-    for (int w = 0; w < W::COMB_W; w++)
-      for (int d = 1; d <= 255; d++) {
-        size_t i = (size_t)w * 255 + (d - 1);
-        ks[i * B + (B - 1 - w)] = (u8)d;                 // d << (8w), big-endian
-        memcpy(&pts[i * 2 * B], g, 2 * B);
-      }
-    void* comb = bk.alloc(n * sizeof(typename W::A));
-    u8* dk = (u8*)bk.alloc(ks.size());
-    u8* dp = (u8*)bk.alloc(pts.size());
-    if (!comb || !dk || !dp) return fail(E_NOMEM, "comb table allocation failed");
-    bk.h2d(dk, ks.data(), ks.size());
-    bk.h2d(dp, pts.data(), pts.size());
-    int rc = mul_var_chunk<CV>(n, dk, dp, nullptr, nullptr, (typename W::A*)comb);
-    bk.sync();
-    bk.free_(dk);
-    bk.free_(dp);
-    if (rc) { bk.free_(comb); return rc; }
-    comb_[CV::ID] = comb;
-    return E_OK;
-  }
-
+  int ensure_comb();
   template <class CV>
-  int normalize_chunk(size_t n, const u32* jac, u8* out_xy, u8* out_inf, typename Work<CV>::A* raw) {
-    typedef Work<CV> W;
-    u32* pre = (u32*)scratch(S_PRE, n * W::L * 4);
-    if (!pre) return fail(E_NOMEM, "scratch allocation failed");
-    size_t T = (n + INV_BATCH - 1) / INV_BATCH;
-    FnNormalize<CV> f{T, n, INV_BATCH, jac, pre, out_xy, out_inf, raw};
-    bk.launch(f, T);
-    return E_OK;
-  }
-
+  int normalize_chunk(size_t n, const u32* jac, u8* out_xy, u8* out_inf, typename Work<CV>::A* raw);
   template <class CV>
   int mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u8* out_inf,
-                    typename Work<CV>::A* raw) {
-    typedef Work<CV> W;
-    typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::J));
-    u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
-    if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
-    FnMulVar<CV> f{n, k, xy, tbl, jac};
-    bk.launch(f, n);
-    return normalize_chunk<CV>(n, jac, out_xy, out_inf, raw);
-  }
-
+                    typename Work<CV>::A* raw);
   template <class CV>
-  int mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf) {
-    typedef Work<CV> W;
-    u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
-    if (!jac) return fail(E_NOMEM, "scratch allocation failed");
-    FnMulFixed<CV> f{n, k, (const typename W::A*)comb_[CV::ID], jac};
-    bk.launch(f, n);
-    return normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
-  }
-
+  int mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf);
   template <class CV>
   int mul_add2_chunk(size_t n, const u8* k1, const u8* xy1, const u8* k2, const u8* xy2,
-                     u8* out_xy, u8* out_inf) {
-    typedef Work<CV> W;
-    u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
-    if (!jac) return fail(E_NOMEM, "scratch allocation failed");
-    if (xy1) {
-      typename W::J* tbl =
-          (typename W::J*)scratch(S_TBL, n * 2 * W::TBL1 * sizeof(typename W::J));
-      if (!tbl) return fail(E_NOMEM, "scratch allocation failed");
-      FnMulAdd2<CV> f{n, k1, xy1, k2, xy2, tbl, jac};
-      bk.launch(f, n);
-    } else {
-      typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::J));
-      if (!tbl) return fail(E_NOMEM, "scratch allocation failed");
-      FnMulAddG<CV> f{n, k1, k2, xy2, (const typename W::A*)comb_[CV::ID], tbl, jac};
-      bk.launch(f, n);
-    }
-    return normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
-  }
-
+                     u8* out_xy, u8* out_inf);
+  template <class CV>
+  int mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* xy2, u8* out_xy,
+                      u8* out_inf);
   template <class CV>
   int ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* r, const u8* s,
-                  const u8* pub, u8* ok) {
-    typedef Work<CV> W;
-    typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::J));
-    u32* pre = (u32*)scratch(S_PRE, n * (W::LN > W::L ? W::LN : W::L) * 4);
-    u32* u12 = (u32*)scratch(S_U12, n * 2 * W::LN * 4);
-    u8* valid = (u8*)scratch(S_VALID, n);
-    if (!tbl || !pre || !u12 || !valid) return fail(E_NOMEM, "scratch allocation failed");
-    size_t T = (n + INV_BATCH - 1) / INV_BATCH;
-    FnEcdsaPrep<CV> f1{T, n, INV_BATCH, hash, hash_len, shift, r, s, pre, u12, valid};
-    bk.launch(f1, T);
-    FnEcdsaMain<CV> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
-    bk.launch(f2, n);
-    return E_OK;
-  }
-
-  // ---- Edwards / Montgomery -------------------------------------------------
-  int ensure_ed_comb() {
-    if (comb_[CURVE_ED25519]) return E_OK;
-    const size_t n = EdWork::COMB_ENTRIES;
-    std::vector<u8> ks(n * 32, 0), pts(n * 64, 0);
-    u8 g[64];
-    {
-      u32 gx[8], gy[8];
-      for (int i = 0; i < 8; i++) { gx[i] = consts::ED25519_C::gx_plain[i]; gy[i] = consts::ED25519_C::gy_plain[i]; }
-      store_be<8>(g, gx, 32);
-      store_be<8>(g + 32, gy, 32);
-    }
-    for (int w = 0; w < EdWork::COMB_W; w++)
-      for (int d = 1; d <= 255; d++) {
-        size_t i = (size_t)w * 255 + (d - 1);
-        ks[i * 32 + (31 - w)] = (u8)d;
-        memcpy(&pts[i * 64], g, 64);
-      }
-    void* comb = bk.alloc(n * sizeof(EdWork::P));
-    u8* dk = (u8*)bk.alloc(ks.size());
-    u8* dp = (u8*)bk.alloc(pts.size());
-    if (!comb || !dk || !dp) return fail(E_NOMEM, "comb table allocation failed");
-    bk.h2d(dk, ks.data(), ks.size());
-    bk.h2d(dp, pts.data(), pts.size());
-    int rc = ed_mul_var_chunk(n, dk, dp, nullptr, nullptr, (EdWork::P*)comb);
-    bk.sync();
-    bk.free_(dk);
-    bk.free_(dp);
-    if (rc) { bk.free_(comb); return rc; }
-    comb_[CURVE_ED25519] = comb;
-    return E_OK;
-  }
-  int ed_normalize_chunk(size_t n, const u32* ext, u8* out_xy, u8* out_inf, EdWork::P* raw) {
-    u32* pre = (u32*)scratch(S_PRE, n * 8 * 4);
-    if (!pre) return fail(E_NOMEM, "scratch allocation failed");
-    size_t T = (n + INV_BATCH - 1) / INV_BATCH;
-    FnEdNormalize f{T, n, INV_BATCH, ext, pre, out_xy, out_inf, raw};
-    bk.launch(f, T);
-    return E_OK;
-  }
-  int ed_mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u8* out_inf, EdWork::P* raw) {
-    EdWork::P* tbl = (EdWork::P*)scratch(S_TBL, n * 8 * sizeof(EdWork::P));
-    u32* ext = (u32*)scratch(S_JAC, n * 4 * 8 * 4);
-    if (!tbl || !ext) return fail(E_NOMEM, "scratch allocation failed");
-    FnEdMulVar f{n, k, xy, tbl, ext};
-    bk.launch(f, n);
-    return ed_normalize_chunk(n, ext, out_xy, out_inf, raw);
-  }
-  int ed_mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf) {
-    u32* ext = (u32*)scratch(S_JAC, n * 4 * 8 * 4);
-    if (!ext) return fail(E_NOMEM, "scratch allocation failed");
-    FnEdMulFixed f{n, k, (const EdWork::P*)comb_[CURVE_ED25519], ext};
-    bk.launch(f, n);
-    return ed_normalize_chunk(n, ext, out_xy, out_inf, nullptr);
-  }
+                  const u8* pub, u8* ok);
+  template <int U = 0>
+  int ensure_ed_comb();
+  template <int U = 0>
+  int ed_normalize_chunk(size_t n, const u32* ext, u8* out_xy, u8* out_inf, EdWork::P* raw);
+  template <int U = 0>
+  int ed_mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u8* out_inf, EdWork::P* raw);
+  template <int U = 0>
+  int ed_mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf);
+  template <int U = 0>
   int ed_mul_add2_chunk(size_t n, const u8* k1, const u8* xy1, const u8* k2, const u8* xy2,
-                        u8* out_xy, u8* out_inf) {
-    u32* ext = (u32*)scratch(S_JAC, n * 4 * 8 * 4);
-    EdWork::P* tbl = (EdWork::P*)scratch(S_TBL, n * 16 * sizeof(EdWork::P));
-    if (!tbl || !ext) return fail(E_NOMEM, "scratch allocation failed");
-    if (xy1) {
-      FnEdMulAdd2 f{n, k1, xy1, k2, xy2, tbl, ext};
-      bk.launch(f, n);
-    } else {
-      FnEdMulAddG f{n, k1, k2, xy2, (const EdWork::P*)comb_[CURVE_ED25519], tbl, ext};
-      bk.launch(f, n);
-    }
-    return ed_normalize_chunk(n, ext, out_xy, out_inf, nullptr);
-  }
-  int x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf) {
-    u32* xz = (u32*)scratch(S_JAC, n * 2 * 8 * 4);
-    u32* pre = (u32*)scratch(S_PRE, n * 8 * 4);
-    if (!xz || !pre) return fail(E_NOMEM, "scratch allocation failed");
-    FnX25519 f{n, k, x, xz};
-    bk.launch(f, n);
-    size_t T = (n + INV_BATCH - 1) / INV_BATCH;
-    FnX25519Normalize g{T, n, INV_BATCH, xz, pre, out_x, out_inf};
-    bk.launch(g, T);
-    return E_OK;
-  }
+                        u8* out_xy, u8* out_inf);
+  template <int U = 0>
+  int x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf);
 
   // ---- dispatch over curves (device pointers) --------------------------------
 #define ELL_SHORT_DISPATCH(curve, CALL)                         \
@@ -465,9 +324,12 @@ class Engine {
         rc = ed_mul_add2_chunk(m, k1 + o * B, p1, k2 + o * B, xy2 + o * 2 * B, out_xy + o * 2 * B,
                                out_inf + o);
       else
-        ELL_SHORT_DISPATCH(curve, rc = mul_add2_chunk<CV>(m, k1 + o * B, p1, k2 + o * B,
-                                                          xy2 + o * 2 * B, out_xy + o * 2 * B,
-                                                          out_inf + o));
+        ELL_SHORT_DISPATCH(curve, rc = p1 ? mul_add2_chunk<CV>(m, k1 + o * B, p1, k2 + o * B,
+                                                               xy2 + o * 2 * B, out_xy + o * 2 * B,
+                                                               out_inf + o)
+                                              : mul_add_g_chunk<CV>(m, k1 + o * B, k2 + o * B,
+                                                                    xy2 + o * 2 * B,
+                                                                    out_xy + o * 2 * B, out_inf + o));
       if (rc) return rc;
     }
     return E_OK;
@@ -628,5 +490,228 @@ class Engine {
   Buf scratch_[S_COUNT];
   Buf staging_[G_COUNT];
 };
+
+// ---- out-of-class definitions of the per-(curve, operation) members: NOT inline, so that
+// `extern template` (engine_extern.h) really keeps their kernels out of other TUs ----
+template <class BK>
+template <class CV>
+int Engine<BK>::ensure_comb() {
+  typedef Work<CV> W;
+  if (comb_[CV::ID]) return E_OK;
+  const size_t n = W::COMB_ENTRIES;
+  const int B = W::BYTES;
+  std::vector<u8> ks(n * B, 0), pts(n * 2 * B, 0);
+  u8 g[2 * 66];
+  {
+    u32 gx[W::L], gy[W::L];
+    for (int i = 0; i < W::L; i++) { gx[i] = W::C::gx_plain[i]; gy[i] = W::C::gy_plain[i]; }
+    store_be<W::L>(g, gx, B);
+    store_be<W::L>(g + B, gy, B);
+  }
+  for (int w = 0; w < W::COMB_W; w++)
+    for (int d = 1; d <= 255; d++) {
+      size_t i = (size_t)w * 255 + (d - 1);
+      ks[i * B + (B - 1 - w)] = (u8)d;                 // d << (8w), big-endian
+      memcpy(&pts[i * 2 * B], g, 2 * B);
+    }
+  void* comb = bk.alloc(n * sizeof(typename W::A));
+  u8* dk = (u8*)bk.alloc(ks.size());
+  u8* dp = (u8*)bk.alloc(pts.size());
+  if (!comb || !dk || !dp) return fail(E_NOMEM, "comb table allocation failed");
+  bk.h2d(dk, ks.data(), ks.size());
+  bk.h2d(dp, pts.data(), pts.size());
+  int rc = mul_var_chunk<CV>(n, dk, dp, nullptr, nullptr, (typename W::A*)comb);
+  bk.sync();
+  bk.free_(dk);
+  bk.free_(dp);
+  if (rc) { bk.free_(comb); return rc; }
+  comb_[CV::ID] = comb;
+  return E_OK;
+}
+
+
+template <class BK>
+template <class CV>
+int Engine<BK>::normalize_chunk(size_t n, const u32* jac, u8* out_xy, u8* out_inf, typename Work<CV>::A* raw) {
+  typedef Work<CV> W;
+  u32* pre = (u32*)scratch(S_PRE, n * W::L * 4);
+  if (!pre) return fail(E_NOMEM, "scratch allocation failed");
+  size_t T = (n + INV_BATCH - 1) / INV_BATCH;
+  FnNormalize<CV> f{T, n, INV_BATCH, jac, pre, out_xy, out_inf, raw};
+  bk.launch(f, T);
+  return E_OK;
+}
+
+
+template <class BK>
+template <class CV>
+int Engine<BK>::mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u8* out_inf,
+                  typename Work<CV>::A* raw) {
+  typedef Work<CV> W;
+  typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::J));
+  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+  if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
+  FnMulVar<CV> f{n, k, xy, tbl, jac};
+  bk.launch(f, n);
+  return normalize_chunk<CV>(n, jac, out_xy, out_inf, raw);
+}
+
+
+template <class BK>
+template <class CV>
+int Engine<BK>::mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf) {
+  typedef Work<CV> W;
+  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+  if (!jac) return fail(E_NOMEM, "scratch allocation failed");
+  FnMulFixed<CV> f{n, k, (const typename W::A*)comb_[CV::ID], jac};
+  bk.launch(f, n);
+  return normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
+}
+
+
+template <class BK>
+template <class CV>
+int Engine<BK>::mul_add2_chunk(size_t n, const u8* k1, const u8* xy1, const u8* k2, const u8* xy2,
+                   u8* out_xy, u8* out_inf) {
+  typedef Work<CV> W;
+  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+  typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * 2 * W::TBL1 * sizeof(typename W::J));
+  if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
+  FnMulAdd2<CV> f{n, k1, xy1, k2, xy2, tbl, jac};
+  bk.launch(f, n);
+  return normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
+}
+
+template <class BK>
+template <class CV>
+int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* xy2, u8* out_xy,
+                    u8* out_inf) {
+  typedef Work<CV> W;
+  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+  typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::J));
+  if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
+  FnMulAddG<CV> f{n, k1, k2, xy2, (const typename W::A*)comb_[CV::ID], tbl, jac};
+  bk.launch(f, n);
+  return normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
+}
+
+
+template <class BK>
+template <class CV>
+int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* r, const u8* s,
+                const u8* pub, u8* ok) {
+  typedef Work<CV> W;
+  typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::J));
+  u32* pre = (u32*)scratch(S_PRE, n * (W::LN > W::L ? W::LN : W::L) * 4);
+  u32* u12 = (u32*)scratch(S_U12, n * 2 * W::LN * 4);
+  u8* valid = (u8*)scratch(S_VALID, n);
+  if (!tbl || !pre || !u12 || !valid) return fail(E_NOMEM, "scratch allocation failed");
+  size_t T = (n + INV_BATCH - 1) / INV_BATCH;
+  FnEcdsaPrep<CV> f1{T, n, INV_BATCH, hash, hash_len, shift, r, s, pre, u12, valid};
+  bk.launch(f1, T);
+  FnEcdsaMain<CV> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
+  bk.launch(f2, n);
+  return E_OK;
+}
+
+// ---- Edwards / Montgomery -------------------------------------------------
+
+template <class BK>
+template <int U>
+int Engine<BK>::ensure_ed_comb() {
+  if (comb_[CURVE_ED25519]) return E_OK;
+  const size_t n = EdWork::COMB_ENTRIES;
+  std::vector<u8> ks(n * 32, 0), pts(n * 64, 0);
+  u8 g[64];
+  {
+    u32 gx[8], gy[8];
+    for (int i = 0; i < 8; i++) { gx[i] = consts::ED25519_C::gx_plain[i]; gy[i] = consts::ED25519_C::gy_plain[i]; }
+    store_be<8>(g, gx, 32);
+    store_be<8>(g + 32, gy, 32);
+  }
+  for (int w = 0; w < EdWork::COMB_W; w++)
+    for (int d = 1; d <= 255; d++) {
+      size_t i = (size_t)w * 255 + (d - 1);
+      ks[i * 32 + (31 - w)] = (u8)d;
+      memcpy(&pts[i * 64], g, 64);
+    }
+  void* comb = bk.alloc(n * sizeof(EdWork::P));
+  u8* dk = (u8*)bk.alloc(ks.size());
+  u8* dp = (u8*)bk.alloc(pts.size());
+  if (!comb || !dk || !dp) return fail(E_NOMEM, "comb table allocation failed");
+  bk.h2d(dk, ks.data(), ks.size());
+  bk.h2d(dp, pts.data(), pts.size());
+  int rc = ed_mul_var_chunk(n, dk, dp, nullptr, nullptr, (EdWork::P*)comb);
+  bk.sync();
+  bk.free_(dk);
+  bk.free_(dp);
+  if (rc) { bk.free_(comb); return rc; }
+  comb_[CURVE_ED25519] = comb;
+  return E_OK;
+}
+
+template <class BK>
+template <int U>
+int Engine<BK>::ed_normalize_chunk(size_t n, const u32* ext, u8* out_xy, u8* out_inf, EdWork::P* raw) {
+  u32* pre = (u32*)scratch(S_PRE, n * 8 * 4);
+  if (!pre) return fail(E_NOMEM, "scratch allocation failed");
+  size_t T = (n + INV_BATCH - 1) / INV_BATCH;
+  FnEdNormalize f{T, n, INV_BATCH, ext, pre, out_xy, out_inf, raw};
+  bk.launch(f, T);
+  return E_OK;
+}
+
+template <class BK>
+template <int U>
+int Engine<BK>::ed_mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u8* out_inf, EdWork::P* raw) {
+  EdWork::P* tbl = (EdWork::P*)scratch(S_TBL, n * 8 * sizeof(EdWork::P));
+  u32* ext = (u32*)scratch(S_JAC, n * 4 * 8 * 4);
+  if (!tbl || !ext) return fail(E_NOMEM, "scratch allocation failed");
+  FnEdMulVar f{n, k, xy, tbl, ext};
+  bk.launch(f, n);
+  return ed_normalize_chunk(n, ext, out_xy, out_inf, raw);
+}
+
+template <class BK>
+template <int U>
+int Engine<BK>::ed_mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf) {
+  u32* ext = (u32*)scratch(S_JAC, n * 4 * 8 * 4);
+  if (!ext) return fail(E_NOMEM, "scratch allocation failed");
+  FnEdMulFixed f{n, k, (const EdWork::P*)comb_[CURVE_ED25519], ext};
+  bk.launch(f, n);
+  return ed_normalize_chunk(n, ext, out_xy, out_inf, nullptr);
+}
+
+template <class BK>
+template <int U>
+int Engine<BK>::ed_mul_add2_chunk(size_t n, const u8* k1, const u8* xy1, const u8* k2, const u8* xy2,
+                      u8* out_xy, u8* out_inf) {
+  u32* ext = (u32*)scratch(S_JAC, n * 4 * 8 * 4);
+  EdWork::P* tbl = (EdWork::P*)scratch(S_TBL, n * 16 * sizeof(EdWork::P));
+  if (!tbl || !ext) return fail(E_NOMEM, "scratch allocation failed");
+  if (xy1) {
+    FnEdMulAdd2 f{n, k1, xy1, k2, xy2, tbl, ext};
+    bk.launch(f, n);
+  } else {
+    FnEdMulAddG f{n, k1, k2, xy2, (const EdWork::P*)comb_[CURVE_ED25519], tbl, ext};
+    bk.launch(f, n);
+  }
+  return ed_normalize_chunk(n, ext, out_xy, out_inf, nullptr);
+}
+
+template <class BK>
+template <int U>
+int Engine<BK>::x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf) {
+  u32* xz = (u32*)scratch(S_JAC, n * 2 * 8 * 4);
+  u32* pre = (u32*)scratch(S_PRE, n * 8 * 4);
+  if (!xz || !pre) return fail(E_NOMEM, "scratch allocation failed");
+  FnX25519 f{n, k, x, xz};
+  bk.launch(f, n);
+  size_t T = (n + INV_BATCH - 1) / INV_BATCH;
+  FnX25519Normalize g{T, n, INV_BATCH, xz, pre, out_x, out_inf};
+  bk.launch(g, T);
+  return E_OK;
+}
+
 
 }  // namespace ell

@@ -1,0 +1,51 @@
+// ellgpu -- explicit-instantiation plumbing so that the (curve x operation)
+// kernels compile in separate translation units (inst.hip, built in parallel by
+// elliptic_amd/build.py) instead of one 20-minute TU.
+#pragma once
+
+#include "hip_backend.h"
+
+namespace ell {
+
+#define ELL_FOR_SHORT_CURVES(X) X(CvSecp256k1) X(CvP192) X(CvP224) X(CvP256) X(CvP384) X(CvP521)
+
+#define ELL_DECL_G0(KW, CV)                                                                        \
+  KW template int Engine<HipBackend>::mul_var_chunk<CV>(size_t, const u8*, const u8*, u8*, u8*,    \
+                                                        Work<CV>::A*);                             \
+  KW template int Engine<HipBackend>::normalize_chunk<CV>(size_t, const u32*, u8*, u8*,            \
+                                                          Work<CV>::A*);                           \
+  KW template int Engine<HipBackend>::ensure_comb<CV>();
+#define ELL_DECL_G1(KW, CV) \
+  KW template int Engine<HipBackend>::mul_fixed_chunk<CV>(size_t, const u8*, u8*, u8*);
+#define ELL_DECL_G2(KW, CV)                                                                  \
+  KW template int Engine<HipBackend>::mul_add2_chunk<CV>(size_t, const u8*, const u8*,       \
+                                                         const u8*, const u8*, u8*, u8*);
+#define ELL_DECL_G3(KW, CV)                                                                   \
+  KW template int Engine<HipBackend>::mul_add_g_chunk<CV>(size_t, const u8*, const u8*,       \
+                                                          const u8*, u8*, u8*);
+#define ELL_DECL_G4(KW, CV)                                                                       \
+  KW template int Engine<HipBackend>::ecdsa_chunk<CV>(size_t, const u8*, int, int, const u8*,     \
+                                                      const u8*, const u8*, u8*);
+
+#define ELL_DECL_ED0(KW)                                                                          \
+  KW template int Engine<HipBackend>::ensure_ed_comb<0>();                                        \
+  KW template int Engine<HipBackend>::ed_normalize_chunk<0>(size_t, const u32*, u8*, u8*,         \
+                                                            EdWork::P*);                          \
+  KW template int Engine<HipBackend>::ed_mul_var_chunk<0>(size_t, const u8*, const u8*, u8*, u8*, \
+                                                          EdWork::P*);
+#define ELL_DECL_ED1(KW)                                                                     \
+  KW template int Engine<HipBackend>::ed_mul_fixed_chunk<0>(size_t, const u8*, u8*, u8*);    \
+  KW template int Engine<HipBackend>::ed_mul_add2_chunk<0>(size_t, const u8*, const u8*,     \
+                                                           const u8*, const u8*, u8*, u8*);
+#define ELL_DECL_X(KW) \
+  KW template int Engine<HipBackend>::x25519_chunk<0>(size_t, const u8*, const u8*, u8*, u8*);
+
+// everything is extern by default ...
+#define ELL_EXT_ALL(CV) \
+  ELL_DECL_G0(extern, CV) ELL_DECL_G1(extern, CV) ELL_DECL_G2(extern, CV) ELL_DECL_G3(extern, CV) ELL_DECL_G4(extern, CV)
+ELL_FOR_SHORT_CURVES(ELL_EXT_ALL)
+ELL_DECL_ED0(extern)
+ELL_DECL_ED1(extern)
+ELL_DECL_X(extern)
+
+}  // namespace ell

@@ -1,0 +1,86 @@
+// ellgpu -- HIP backend for Engine<> (gfx950 / MI355X): device memory, copies
+// and the one generic kernel template that runs every functor of engine.h.
+//
+// Launch geometry: one item per lane, 128-lane workgroups (2 wavefronts), the
+// functor's per-lane digit strings staged in LDS as byte columns (lane-major:
+// the 64 lanes of a wave read 64 consecutive bytes, conflict-free).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+namespace ell {
+
+constexpr int BLOCK = 128;
+
+template <class Fn>
+__global__ void __launch_bounds__(BLOCK) k_run(const Fn f, size_t nthreads) {
+  __shared__ signed char lds_digits[(Fn::DS_PER_LANE > 0 ? Fn::DS_PER_LANE : 1) * BLOCK];
+  size_t tid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  DigitStore ds{lds_digits + threadIdx.x, BLOCK};
+  f(tid, ds);
+}
+
+struct TimedLaunch {
+  const char* name;
+  hipEvent_t e0, e1;
+};
+
+struct HipBackend {
+  int device = 0;
+  hipStream_t own = nullptr;       // the context's stream
+  hipStream_t cur = nullptr;       // stream used by the current call
+  int last = 0;                    // sticky hipError_t of the current call
+  bool timing = false;             // record HIP events around every launch
+  std::vector<TimedLaunch>* timed = nullptr;
+
+  void use_stream(void* s) {
+    (void)hipSetDevice(device);
+    cur = s ? (hipStream_t)s : own;
+    last = 0;
+  }
+  void note(hipError_t e) {
+    if (e != hipSuccess && !last) last = (int)e;
+  }
+  void* alloc(size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+  }
+  void free_(void* p) { note(hipFree(p)); }
+  void h2d(void* d, const void* h, size_t bytes) {
+    note(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, cur));
+  }
+  void d2h(void* h, const void* d, size_t bytes) {
+    note(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, cur));
+  }
+  int sync() {
+    note(hipStreamSynchronize(cur ? cur : own));
+    return last ? E_HIP : E_OK;
+  }
+  template <class Fn>
+  void launch(const Fn& f, size_t nthreads) {
+    if (nthreads == 0) return;
+    unsigned blocks = (unsigned)((nthreads + BLOCK - 1) / BLOCK);
+    TimedLaunch t{Fn::NAME, nullptr, nullptr};
+    if (timing && timed) {
+      note(hipEventCreate(&t.e0));
+      note(hipEventCreate(&t.e1));
+      note(hipEventRecord(t.e0, cur));
+    }
+    hipLaunchKernelGGL(k_run<Fn>, dim3(blocks), dim3(BLOCK), 0, cur, f, nthreads);
+    note(hipGetLastError());
+    if (timing && timed) {
+      note(hipEventRecord(t.e1, cur));
+      timed->push_back(t);
+    }
+  }
+};
+
+}  // namespace ell

@@ -1,0 +1,27 @@
+// ellgpu -- one translation unit per (curve, operation group): explicit
+// instantiation of the Engine<HipBackend> member that launches the kernels.
+//   hipcc -c inst.hip -DELL_INST_CURVE=CvP384 -DELL_INST_GROUP=4   (see build.py)
+#include "engine_extern.h"
+
+namespace ell {
+#define ELL_NOKW
+#if ELL_INST_GROUP == 0
+ELL_DECL_G0(ELL_NOKW, ELL_INST_CURVE)
+#elif ELL_INST_GROUP == 1
+ELL_DECL_G1(ELL_NOKW, ELL_INST_CURVE)
+#elif ELL_INST_GROUP == 2
+ELL_DECL_G2(ELL_NOKW, ELL_INST_CURVE)
+#elif ELL_INST_GROUP == 3
+ELL_DECL_G3(ELL_NOKW, ELL_INST_CURVE)
+#elif ELL_INST_GROUP == 4
+ELL_DECL_G4(ELL_NOKW, ELL_INST_CURVE)
+#elif ELL_INST_GROUP == 10
+ELL_DECL_ED0(ELL_NOKW)
+#elif ELL_INST_GROUP == 11
+ELL_DECL_ED1(ELL_NOKW)
+#elif ELL_INST_GROUP == 12
+ELL_DECL_X(ELL_NOKW)
+#else
+#error "unknown ELL_INST_GROUP"
+#endif
+}  // namespace ell

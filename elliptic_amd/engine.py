@@ -185,6 +185,21 @@ class Context:
                                                        out_x.data_ptr(), out_inf.data_ptr(),
                                                        self._stream()))
 
+    def set_timing(self, on=True):
+        self._check(self._lib.ellgpu_ctx_set_timing(self._ctx, 1 if on else 0))
+
+    def get_timing(self):
+        """-> {kernel name: (launches, total_ms)} since set_timing(True)"""
+        buf = ctypes.create_string_buffer(8192)
+        rc = self._lib.ellgpu_ctx_get_timing(self._ctx, buf, 8192)
+        if rc < 0:
+            self._check(rc)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            out[name] = (int(cnt), float(ms))
+        return out
+
     def probe_valu(self, kind, blocks, iters):
         ms = ctypes.c_double()
         ops = ctypes.c_double()

@@ -146,6 +146,13 @@ int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n);
 int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iters, double* ms_out,
                       double* ops_out);
 
+/* Per-kernel timing with HIP events recorded on the stream each kernel is
+ * launched on.  set_timing(ctx, 1) starts a fresh recording, set_timing(ctx, 0)
+ * stops it; get_timing synchronises the device and writes one text line per
+ * kernel name, "<name> <launches> <total_ms>\n", returning the byte count. */
+int ellgpu_ctx_set_timing(ellgpu_ctx* ctx, int on);
+int ellgpu_ctx_get_timing(ellgpu_ctx* ctx, char* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,162 @@
+"""GPU parity tests proper (-m gpu): libellgpu.so's HIP kernels, called through
+the C ABI, against (1) the reference's golden vectors, (2) the oracle on seeded
+random inputs, (3) size-independent properties at BASELINE.json's full sizes."""
+import hashlib
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import elliptic_amd  # noqa: E402
+from elliptic_amd import be_to_ints, ints_to_be  # noqa: E402
+import parity_checks as PC  # noqa: E402
+from oracle import ec_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = elliptic_amd.Context(0)          # raises if libellgpu.so or the GPU is missing
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("curve", O.SHORT_CURVES + ["ed25519"])
+def test_mul_golden(ctx, curve):
+    assert PC.check_mul_golden(ctx, curve) > 50
+
+
+def test_x25519_golden(ctx):
+    assert PC.check_x25519_golden(ctx) > 30
+
+
+@pytest.mark.parametrize("curve", O.SHORT_CURVES)
+def test_verify_golden(ctx, curve):
+    assert PC.check_verify_golden(ctx, curve) > 15
+
+
+def _xy(arr, i, B):
+    return (int.from_bytes(arr[i, :B].tobytes(), "big"), int.from_bytes(arr[i, B:].tobytes(), "big"))
+
+
+@pytest.mark.parametrize("curve,count", [("secp256k1", 600), ("p256", 150), ("p384", 60), ("p521", 24),
+                                         ("p224", 80), ("p192", 80)])
+def test_random_vs_oracle(ctx, curve, count):
+    """seeded random scalars/points: fixed, variable, mulAdd against the oracle"""
+    cur = O.get_curve(curve)
+    B = elliptic_amd.FIELD_BYTES[curve]
+    rnd = random.Random("gpu-parity:" + curve)
+    ds = [rnd.randrange(1, cur.n) for _ in range(count)]
+    ks = [rnd.randrange(0, 1 << (8 * B if curve != "p521" else 521)) for _ in range(count)]
+    pub, inf = ctx.mul_fixed(curve, ints_to_be(ds, B))
+    assert not inf.any()
+    for i in range(0, count, 7):
+        w = cur.g.mul(ds[i])
+        assert _xy(pub, i, B) == (w.x, w.y)
+    out, inf = ctx.mul_var(curve, ints_to_be(ks, B), pub)
+    for i in range(count):
+        w = cur.point(*_xy(pub, i, B)).mul(ks[i])
+        got = None if inf[i] else _xy(out, i, B)
+        assert got == (None if w.inf else (w.x, w.y)), (curve, i)
+    m = count // 3
+    k2 = [rnd.randrange(0, cur.n) for _ in range(m)]
+    out, inf = ctx.mul_add2(curve, ints_to_be(ks[:m], B), None, ints_to_be(k2, B), pub[:m])
+    out2, inf2 = ctx.mul_add2(curve, ints_to_be(ks[:m], B), np.tile(ints_to_be([cur.g.x, cur.g.y], B).reshape(1, -1), (m, 1)),
+                              ints_to_be(k2, B), pub[:m])
+    assert np.array_equal(out, out2) and np.array_equal(inf, inf2)
+    for i in range(0, m, 3):
+        w = cur.g.mul_add(ks[i], cur.point(*_xy(pub, i, B)), k2[i])
+        got = None if inf[i] else _xy(out, i, B)
+        assert got == (None if w.inf else (w.x, w.y)), (curve, i)
+
+
+def test_ed25519_and_x25519_random_vs_oracle(ctx):
+    cur = O.get_curve("ed25519")
+    rnd = random.Random("gpu-parity:ed")
+    n = 120
+    ds = [rnd.randrange(1, cur.n) for _ in range(n)]
+    ks = [rnd.randrange(0, 1 << 256) for _ in range(n)]
+    pub, inf = ctx.mul_fixed("ed25519", ints_to_be(ds, 32))
+    out, inf = ctx.mul_var("ed25519", ints_to_be(ks, 32), pub)
+    for i in range(n):
+        R = cur.point(*_xy(pub, i, 32)).mul(ks[i])
+        assert _xy(out, i, 32) == R.normalized()
+        assert bool(inf[i]) == R.is_infinity()
+    mc = O.get_curve("curve25519")
+    xs = [rnd.randrange(1, mc.p) for _ in range(n)]
+    out, inf = ctx.x25519(ints_to_be(ks, 32), ints_to_be(xs, 32))
+    for i in range(n):
+        w = mc.mul_x(xs[i], ks[i])
+        got = None if inf[i] else int.from_bytes(out[i].tobytes(), "big")
+        assert got == w
+
+
+def test_ragged_and_empty_batches(ctx):
+    cur = O.get_curve("secp256k1")
+    for n in (0, 1, 63, 64, 65, 127, 129, 1000):
+        ks = ints_to_be([(i * 0x9E3779B97F4A7C15 + 1) % cur.n for i in range(n)], 32)
+        out, inf = ctx.mul_fixed("secp256k1", ks)
+        assert out.shape == (n, 64)
+        for i in (0, n - 1) if n else ():
+            w = cur.g.mul(int.from_bytes(ks[i].tobytes(), "big"))
+            assert _xy(out, i, 32) == (w.x, w.y)
+
+
+def _make_sigs(ctx, n, seed):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.make_signatures(ctx, n, seed)
+
+
+def test_full_size_verify_mask_and_device_api(ctx):
+    """BASELINE configs[2] at full size (2^20 tuples, 1% corrupted): the ok-mask
+    must equal the construction's expected mask exactly; host and device entry
+    points must agree; a seeded subset is re-checked with the oracle."""
+    import torch
+    n = 1 << 20
+    h, r, s, pub, expect = _make_sigs(ctx, n, "gpu-test-fullsize")
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(x).to(dev) for x in (h, r, s, pub)]
+    ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ctx.ecdsa_verify_dev("secp256k1", t[0], t[1], t[2], t[3], ok)
+    torch.cuda.synchronize()
+    got = ok.cpu().numpy()
+    assert np.array_equal(got, expect)
+    assert int(expect.sum()) == n - (n + 99) // 100
+    m = 5000
+    assert np.array_equal(ctx.ecdsa_verify("secp256k1", h[:m], r[:m], s[:m], pub[:m]), expect[:m])
+    cur = O.get_curve("secp256k1")
+    rnd = random.Random(77)
+    for i in [0, 100, 200, 300] + [rnd.randrange(n) for _ in range(300)]:
+        want = O.ecdsa_verify(cur, int.from_bytes(h[i].tobytes(), "big"), 32,
+                              int.from_bytes(r[i].tobytes(), "big"), int.from_bytes(s[i].tobytes(), "big"),
+                              cur.point(*_xy(pub, i, 32)))
+        assert want == bool(expect[i])
+
+
+def test_full_size_group_properties(ctx):
+    """size-independent properties on 2^18 items: (a*G)*b == (b*G)*a, fixed ==
+    variable base on G, k1*G + k2*G == (k1+k2)*G."""
+    n = 1 << 18
+    N = O.get_curve("secp256k1").n
+    raw = np.frombuffer(hashlib.shake_256(b"gpu-prop").digest(n * 64), dtype=np.uint8).reshape(n, 64)
+    a, b = np.ascontiguousarray(raw[:, :32]), np.ascontiguousarray(raw[:, 32:])
+    A, _ = ctx.mul_fixed("secp256k1", a)
+    Bp, _ = ctx.mul_fixed("secp256k1", b)
+    AB, i1 = ctx.mul_var("secp256k1", b, A)
+    BA, i2 = ctx.mul_var("secp256k1", a, Bp)
+    assert np.array_equal(AB, BA) and np.array_equal(i1, i2)
+    cur = O.get_curve("secp256k1")
+    G = np.tile(ints_to_be([cur.g.x, cur.g.y], 32).reshape(1, 64), (n, 1))
+    Av, _ = ctx.mul_var("secp256k1", a, G)
+    assert np.array_equal(A, Av)
+    m = 1 << 14
+    S, _ = ctx.mul_add2("secp256k1", a[:m], None, b[:m], G[:m])
+    sums = [(x + y) % N for x, y in zip(be_to_ints(a[:m]), be_to_ints(b[:m]))]
+    S2, _ = ctx.mul_fixed("secp256k1", ints_to_be(sums, 32))
+    assert np.array_equal(S, S2)
