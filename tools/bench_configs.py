@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Secondary throughput table for the other BASELINE.json configs (not the
+bench.py headline): fixed-base G*k, variable-base P*k (secp256k1), ed25519 P*k,
+p384 P*k, x25519 -- kernel-only, inputs resident in HBM.  GPU box only.
+
+    python tools/bench_configs.py [--reps 3]
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import elliptic_amd
+
+
+def rnd(seed, n, w):
+    return np.frombuffer(hashlib.shake_256(seed.encode()).digest(n * w), dtype=np.uint8).reshape(n, w).copy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    ctx = elliptic_amd.Context(0)
+    dev = torch.device("cuda", 0)
+    rows = []
+
+    def timed(name, n, fn):
+        fn()
+        torch.cuda.synchronize()
+        ctx.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(a.reps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.reps
+        tm = ctx.get_timing()
+        ctx.set_timing(False)
+        rows.append({"config": name, "n": n, "items_per_s": n / dt, "ms": dt * 1e3,
+                     "kernels_ms": {k: v[1] / v[0] for k, v in tm.items()}})
+        print(json.dumps(rows[-1]), flush=True)
+
+    for curve, n in (("secp256k1", 1 << 20), ("p256", 1 << 19), ("p384", 1 << 18), ("p521", 1 << 16),
+                     ("ed25519", 1 << 20)):
+        B = elliptic_amd.FIELD_BYTES[curve]
+        k = rnd("cfg:k:" + curve, n, B)
+        if curve == "p521":
+            k[:, 0] &= 1
+        d = rnd("cfg:d:" + curve, n, B)
+        if curve == "p521":
+            d[:, 0] &= 1
+        dk, dd = torch.from_numpy(k).to(dev), torch.from_numpy(d).to(dev)
+        pts = torch.zeros((n, 2 * B), dtype=torch.uint8, device=dev)
+        out = torch.zeros((n, 2 * B), dtype=torch.uint8, device=dev)
+        inf = torch.zeros(n, dtype=torch.uint8, device=dev)
+        timed("%s fixed-base G*k" % curve, n, lambda: ctx.mul_fixed_dev(curve, dd, pts, inf))
+        timed("%s variable-base P*k" % curve, n, lambda: ctx.mul_var_dev(curve, dk, pts, out, inf))
+        timed("%s k1*G + k2*P" % curve, n, lambda: ctx.mul_add2_dev(curve, dd, None, dk, pts, out, inf))
+    n = 1 << 20
+    k = torch.from_numpy(rnd("cfg:k:x", n, 32)).to(dev)
+    x = torch.from_numpy(rnd("cfg:x:x", n, 32)).to(dev)
+    ox = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    inf = torch.zeros(n, dtype=torch.uint8, device=dev)
+    timed("curve25519 x-only ladder", n, lambda: ctx.x25519_dev(k, x, ox, inf))
+
+
+if __name__ == "__main__":
+    main()
