@@ -1,0 +1,82 @@
+"""Pins oracle/ec_oracle.c (the C port used for bulk checks and the
+cpu_baseline) to the reference's golden vectors, and to the Python oracle on
+seeded random inputs.  CPU only."""
+import random
+
+import numpy as np
+import pytest
+
+from elliptic_amd import ints_to_be
+from golden_util import I, mul_cases, res_xy, verify_cases
+from oracle import c_oracle as C
+from oracle import ec_oracle as O
+
+BYTES = {"secp256k1": 32, "p192": 24, "p224": 28, "p256": 32, "p384": 48, "p521": 66}
+
+
+def _res(out, inf, i, B):
+    if inf[i]:
+        return None
+    return (int.from_bytes(out[i, :B].tobytes(), "big"), int.from_bytes(out[i, B:].tobytes(), "big"))
+
+
+@pytest.mark.parametrize("name", O.SHORT_CURVES)
+def test_c_oracle_mul_golden(name):
+    B = BYTES[name]
+    cur = O.get_curve(name)
+    cases = mul_cases(name)
+    fixed = [c for c in cases if c["op"] == "fixed"]
+    out, inf = C.mul(name, ints_to_be([I(c["k"]) for c in fixed], B))
+    for i, c in enumerate(fixed):
+        assert _res(out, inf, i, B) == res_xy(c["r"]), c
+    var = [c for c in cases if c["op"] == "var"]
+    pts = np.concatenate([ints_to_be([I(c["px"]) for c in var], B), ints_to_be([I(c["py"]) for c in var], B)], axis=1)
+    out, inf = C.mul(name, ints_to_be([I(c["k"]) for c in var], B), pts)
+    for i, c in enumerate(var):
+        assert _res(out, inf, i, B) == res_xy(c["r"]), c
+    madd = [c for c in cases if c["op"] == "muladd"]
+    k1 = ints_to_be([I(c["k1"]) for c in madd], B)
+    k2 = ints_to_be([I(c["k2"]) for c in madd], B)
+    p1 = np.concatenate([ints_to_be([I(c["p1x"]) for c in madd], B), ints_to_be([I(c["p1y"]) for c in madd], B)], axis=1)
+    p2 = np.concatenate([ints_to_be([I(c["p2x"]) for c in madd], B), ints_to_be([I(c["p2y"]) for c in madd], B)], axis=1)
+    out, inf = C.mul_add(name, k1, p1, k2, p2)
+    for i, c in enumerate(madd):
+        assert _res(out, inf, i, B) == res_xy(c["r"]), c
+    gi = [i for i, c in enumerate(madd) if (I(c["p1x"]), I(c["p1y"])) == (cur.g.x, cur.g.y)]
+    out, inf = C.mul_add(name, k1[gi], None, k2[gi], p2[gi])
+    for j, i in enumerate(gi):
+        assert _res(out, inf, j, B) == res_xy(madd[i]["r"]), madd[i]
+
+
+@pytest.mark.parametrize("name", O.SHORT_CURVES)
+def test_c_oracle_verify_golden(name):
+    B = BYTES[name]
+    groups = {}
+    for c in verify_cases(name):
+        groups.setdefault((len(c["z"]) // 2, c.get("msgBitLength", 0)), []).append(c)
+    n = 0
+    for (hl, mb), cs in groups.items():
+        ok = C.verify(name, ints_to_be([I(c["z"]) for c in cs], hl), ints_to_be([I(c["r"]) for c in cs], B),
+                      ints_to_be([I(c["s"]) for c in cs], B),
+                      np.concatenate([ints_to_be([I(c["qx"]) for c in cs], B), ints_to_be([I(c["qy"]) for c in cs], B)], axis=1),
+                      msg_bits=mb)
+        for i, c in enumerate(cs):
+            assert bool(ok[i]) == c["ok"], c
+            n += 1
+    assert n > 15
+
+
+def test_c_oracle_vs_python_oracle_random():
+    cur = O.get_curve("secp256k1")
+    rnd = random.Random(31337)
+    n = 200
+    ks = [rnd.getrandbits(256) for _ in range(n)]
+    ds = [rnd.randrange(1, cur.n) for _ in range(n)]
+    pub, inf = C.mul("secp256k1", ints_to_be(ds, 32))
+    out, inf = C.mul("secp256k1", ints_to_be(ks, 32), pub)
+    for i in range(0, n, 5):
+        w = cur.g.mul(ds[i]).mul(ks[i])
+        assert _res(out, inf, i, 32) == (None if w.inf else (w.x, w.y))
+    ok1 = C.verify("secp256k1", ints_to_be(ks, 32), ints_to_be(ds, 32), ints_to_be(ds[::-1], 32), pub)
+    ok8 = C.verify("secp256k1", ints_to_be(ks, 32), ints_to_be(ds, 32), ints_to_be(ds[::-1], 32), pub, threads=4)
+    assert np.array_equal(ok1, ok8) and not ok1.any()

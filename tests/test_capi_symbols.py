@@ -1,0 +1,81 @@
+"""CPU-side checks of the drop-in boundary: libellgpu.so (cross-compiled for
+gfx950 by elliptic_amd/build.py) loads and exports every symbol include/ellgpu.h
+declares; without a GPU the product path fails loudly instead of falling back."""
+import ctypes
+import os
+import re
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "ellgpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ellgpu_\w+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from elliptic_amd import build as b
+    if not os.path.exists(b.LIB):
+        if shutil.which("hipcc") is None and not os.path.exists(b.HIPCC):
+            pytest.skip("hipcc not available and libellgpu.so not built")
+        b.build(verbose=False)
+    return b.LIB
+
+
+def test_header_symbols_all_exported(lib_path):
+    from elliptic_amd import _lib
+    lib = ctypes.CDLL(lib_path)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libellgpu.so does not export %s" % n
+    # and the Python binding table covers the header
+    assert set(names) == set(_lib.SYMBOLS)
+
+
+def test_metadata_calls_work_without_gpu(lib_path):
+    from elliptic_amd import _lib
+    lib = _lib.load(lib_path)
+    assert lib.ellgpu_version() == 0x000100
+    for i, (name, fb) in enumerate([("secp256k1", 32), ("p192", 24), ("p224", 28), ("p256", 32),
+                                    ("p384", 48), ("p521", 66), ("ed25519", 32), ("curve25519", 32)]):
+        assert lib.ellgpu_curve_id(name.encode()) == i
+        assert lib.ellgpu_curve_field_bytes(i) == fb
+        assert lib.ellgpu_curve_order_bytes(i) == fb
+    assert lib.ellgpu_curve_id(b"brainpool") == -1
+
+
+def test_no_cpu_fallback(lib_path):
+    """on a box without an MI355X the product must refuse to run"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import elliptic_amd
+    with pytest.raises(elliptic_amd.EllgpuError) as e:
+        elliptic_amd.Context(0)
+    assert e.value.code == -1
+
+
+def test_product_does_not_reference_oracle():
+    """nothing under elliptic_amd/ or include/ may import or link oracle/"""
+    bad = []
+    for base in ("elliptic_amd", "include"):
+        for dp, dn, fn in os.walk(os.path.join(ROOT, base)):
+            if "_obj" in dp or "node_modules" in dp:
+                continue
+            for f in fn:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".c", ".js")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"(from|import)\s+oracle|oracle/|ec_oracle|hostsim\.so|libellgpu_hostsim", txt):
+                        if f == "common.h" or f == "engine.h" or f == "capi_common.h":
+                            # comments that NAME the test build are fine; code references are not
+                            code = re.sub(r"//.*", "", txt)
+                            if not re.search(r"oracle|hostsim", code):
+                                continue
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,80 @@
+"""The N>1 path on CPU: world_size-2 gloo process group, each rank verifies its
+contiguous shard (through the hostsim build of the device code, since this
+container has no GPU) and the masks are gathered -- the same
+elliptic_amd.sharding code bench.py uses with backend "nccl" on MI355X."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+from elliptic_amd.sharding import shard_range  # noqa: E402
+
+
+def test_shard_ranges_cover_exactly():
+    for n in (0, 1, 2, 7, 8, 9, 1000, 1 << 20):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, lib_path, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import elliptic_amd
+        from elliptic_amd import _lib
+        from elliptic_amd.sharding import ShardedVerifier
+        from golden_util import I, verify_cases
+        from elliptic_amd import ints_to_be
+        lib = _lib.load(lib_path, optional=("ellgpu_probe_valu", "ellgpu_ctx_set_timing", "ellgpu_ctx_get_timing"))
+        ctx = elliptic_amd.Context(0, lib_path=lib)
+        cs = [c for c in verify_cases("secp256k1") if len(c["z"]) == 64 and "msgBitLength" not in c][:n]
+        h = ints_to_be([I(c["z"]) for c in cs], 32)
+        r = ints_to_be([I(c["r"]) for c in cs], 32)
+        s = ints_to_be([I(c["s"]) for c in cs], 32)
+        pub = np.concatenate([ints_to_be([I(c["qx"]) for c in cs], 32), ints_to_be([I(c["qy"]) for c in cs], 32)], axis=1)
+        sv = ShardedVerifier(ctx, "secp256k1", dist=dist)
+        ok = sv.verify(h, r, s, pub).numpy()
+        want = np.array([1 if c["ok"] else 0 for c in cs], np.uint8)
+        q.put((rank, bool(np.array_equal(ok, want)), len(cs)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [37])
+def test_world2_sharded_verify_matches_reference(n):
+    from hostsim.build import build as build_hostsim
+    lib_path = build_hostsim()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_worker, args=(r, 2, port, lib_path, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res) and all(r[2] == n for r in res)
