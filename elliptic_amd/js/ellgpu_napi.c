@@ -1,0 +1,222 @@
+/*
+ * ellgpu_napi.c -- Node N-API addon: the JavaScript-side binding of the C ABI
+ * in include/ellgpu.h.  It marshals flat Buffers (fixed-width big-endian
+ * integers, exactly BN#toArray('be', len)) into libellgpu.so and back; no curve
+ * arithmetic lives here.  The library is dlopen()ed from an explicit path
+ * (default ../lib/libellgpu.so next to this addon), so the same addon can be
+ * pointed at the CPU unit-test build of the device code in a GPU-less
+ * container (tests only, see tests/test_js_install.py).
+ *
+ *   gcc -shared -fPIC -I/usr/include/node -o ellgpu.node ellgpu_napi.c -ldl
+ *
+ * Exports:  open(path) -> true
+ *           createContext(device) -> external
+ *           destroyContext(ctx)
+ *           curveId(name), fieldBytes(id), orderBytes(id), deviceCount()
+ *           mulFixed(ctx, curve, k) -> {xy, inf}
+ *           mulVar(ctx, curve, k, xy) -> {xy, inf}
+ *           mulAdd2(ctx, curve, k1, p1|null, k2, p2) -> {xy, inf}
+ *           ecdsaVerify(ctx, curve, hash, hashLen, msgBits, r, s, pub) -> Buffer(ok)
+ *           x25519(ctx, k, x) -> {x, inf}
+ * Errors from the library are thrown as plain `Error(message)`, the
+ * reference's convention (minimalistic-assert, dist/elliptic.js:8832-8835).
+ */
+#include <dlfcn.h>
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct ellgpu_ctx ellgpu_ctx;
+static struct {
+  void* h;
+  const char* (*last_error)(void);
+  int (*curve_id)(const char*);
+  int (*field_bytes)(int);
+  int (*order_bytes)(int);
+  int (*device_count)(void);
+  int (*ctx_create)(int, ellgpu_ctx**);
+  void (*ctx_destroy)(ellgpu_ctx*);
+  int (*mul_fixed)(ellgpu_ctx*, int, size_t, const uint8_t*, uint8_t*, uint8_t*);
+  int (*mul_var)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
+  int (*mul_add2)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, const uint8_t*,
+                  const uint8_t*, uint8_t*, uint8_t*);
+  int (*ecdsa_verify)(ellgpu_ctx*, int, size_t, const uint8_t*, int, int, const uint8_t*,
+                      const uint8_t*, const uint8_t*, uint8_t*);
+  int (*x25519)(ellgpu_ctx*, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
+} L;
+
+#define THROW(env, msg) do { napi_throw_error((env), NULL, (msg)); return NULL; } while (0)
+#define CHECK(env, call) do { if ((call) != napi_ok) THROW(env, "N-API call failed"); } while (0)
+
+static napi_value lib_error(napi_env env) {
+  const char* m = L.last_error ? L.last_error() : "ellgpu error";
+  napi_throw_error(env, NULL, m && *m ? m : "ellgpu error");
+  return NULL;
+}
+static int need_lib(napi_env env) {
+  if (!L.h) { napi_throw_error(env, NULL, "ellgpu: library not opened (call open(path) first)"); return 0; }
+  return 1;
+}
+
+static napi_value fn_open(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  char path[4096]; size_t len = 0;
+  if (argc < 1 || napi_get_value_string_utf8(env, argv[0], path, sizeof path, &len) != napi_ok)
+    THROW(env, "open(path): path string required");
+  void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) { char msg[4400]; snprintf(msg, sizeof msg, "ellgpu: cannot load %s: %s", path, dlerror()); THROW(env, msg); }
+#define SYM(field, name) do { *(void**)(&L.field) = dlsym(h, name); if (!L.field) { char m_[256]; \
+    snprintf(m_, sizeof m_, "ellgpu: %s missing from library", name); dlclose(h); THROW(env, m_); } } while (0)
+  SYM(last_error, "ellgpu_last_error"); SYM(curve_id, "ellgpu_curve_id");
+  SYM(field_bytes, "ellgpu_curve_field_bytes"); SYM(order_bytes, "ellgpu_curve_order_bytes");
+  SYM(device_count, "ellgpu_device_count"); SYM(ctx_create, "ellgpu_ctx_create");
+  SYM(ctx_destroy, "ellgpu_ctx_destroy"); SYM(mul_fixed, "ellgpu_mul_fixed"); SYM(mul_var, "ellgpu_mul_var");
+  SYM(mul_add2, "ellgpu_mul_add2"); SYM(ecdsa_verify, "ellgpu_ecdsa_verify"); SYM(x25519, "ellgpu_x25519_ladder");
+  L.h = h;
+  napi_value t; CHECK(env, napi_get_boolean(env, 1, &t));
+  return t;
+}
+
+static void ctx_finalize(napi_env env, void* data, void* hint) {
+  (void)env; (void)hint;
+  if (data && L.ctx_destroy) L.ctx_destroy((ellgpu_ctx*)data);
+}
+static napi_value fn_create(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 1; napi_value argv[1]; int32_t dev = 0;
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc >= 1) napi_get_value_int32(env, argv[0], &dev);
+  ellgpu_ctx* c = NULL;
+  if (L.ctx_create(dev, &c) != 0) return lib_error(env);
+  napi_value ext; CHECK(env, napi_create_external(env, c, ctx_finalize, NULL, &ext));
+  return ext;
+}
+static ellgpu_ctx* get_ctx(napi_env env, napi_value v) {
+  void* p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_error(env, NULL, "ellgpu: bad context"); return NULL; }
+  return (ellgpu_ctx*)p;
+}
+static int get_buf(napi_env env, napi_value v, const uint8_t** p, size_t* len, int allow_null) {
+  napi_valuetype t; napi_typeof(env, v, &t);
+  if (allow_null && (t == napi_null || t == napi_undefined)) { *p = NULL; *len = 0; return 1; }
+  bool isbuf = 0; napi_is_buffer(env, v, &isbuf);
+  if (!isbuf) { napi_throw_error(env, NULL, "ellgpu: Buffer expected"); return 0; }
+  void* d; if (napi_get_buffer_info(env, v, &d, len) != napi_ok) { napi_throw_error(env, NULL, "ellgpu: bad Buffer"); return 0; }
+  *p = (const uint8_t*)d; return 1;
+}
+static napi_value mk_result(napi_env env, const char* k1, napi_value a, const char* k2, napi_value b) {
+  napi_value o; CHECK(env, napi_create_object(env, &o));
+  CHECK(env, napi_set_named_property(env, o, k1, a));
+  CHECK(env, napi_set_named_property(env, o, k2, b));
+  return o;
+}
+static napi_value fn_curve_id(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 1; napi_value argv[1]; char name[64]; size_t len;
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (napi_get_value_string_utf8(env, argv[0], name, sizeof name, &len) != napi_ok) THROW(env, "curveId(name)");
+  napi_value r; CHECK(env, napi_create_int32(env, L.curve_id(name), &r)); return r;
+}
+static napi_value int_fn(napi_env env, napi_callback_info info, int which) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 1; napi_value argv[1]; int32_t id = 0;
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc >= 1) napi_get_value_int32(env, argv[0], &id);
+  int v = which == 0 ? L.field_bytes(id) : which == 1 ? L.order_bytes(id) : L.device_count();
+  napi_value r; CHECK(env, napi_create_int32(env, v, &r)); return r;
+}
+static napi_value fn_field_bytes(napi_env e, napi_callback_info i) { return int_fn(e, i, 0); }
+static napi_value fn_order_bytes(napi_env e, napi_callback_info i) { return int_fn(e, i, 1); }
+static napi_value fn_device_count(napi_env e, napi_callback_info i) { return int_fn(e, i, 2); }
+
+static napi_value fn_destroy(napi_env env, napi_callback_info info) {
+  /* contexts are released by the GC finalizer; explicit destroy is a no-op hook */
+  (void)info; napi_value u; napi_get_undefined(env, &u); return u;
+}
+
+/* mulFixed / mulVar / mulAdd2 share the output shape */
+static napi_value mul_common(napi_env env, napi_callback_info info, int kind) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 6; napi_value argv[6];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  int32_t curve; if (napi_get_value_int32(env, argv[1], &curve) != napi_ok) THROW(env, "curve id expected");
+  int B = L.field_bytes(curve); if (B <= 0) THROW(env, "unknown curve id");
+  const uint8_t *k1 = 0, *p1 = 0, *k2 = 0, *p2 = 0; size_t l1 = 0, lp1 = 0, l2 = 0, lp2 = 0;
+  if (!get_buf(env, argv[2], &k1, &l1, 0)) return NULL;
+  if (l1 % (size_t)B) THROW(env, "scalar buffer length is not a multiple of the field width");
+  size_t n = l1 / (size_t)B;
+  if (kind == 1) { if (!get_buf(env, argv[3], &p1, &lp1, 0)) return NULL; if (lp1 != n * 2 * (size_t)B) THROW(env, "point buffer length mismatch"); }
+  if (kind == 2) {
+    if (!get_buf(env, argv[3], &p1, &lp1, 1)) return NULL;
+    if (!get_buf(env, argv[4], &k2, &l2, 0)) return NULL;
+    if (!get_buf(env, argv[5], &p2, &lp2, 0)) return NULL;
+    if ((p1 && lp1 != n * 2 * (size_t)B) || l2 != l1 || lp2 != n * 2 * (size_t)B) THROW(env, "buffer length mismatch");
+  }
+  napi_value bxy, binf; void *dxy, *dinf;
+  CHECK(env, napi_create_buffer(env, n * 2 * (size_t)B, &dxy, &bxy));
+  CHECK(env, napi_create_buffer(env, n, &dinf, &binf));
+  int rc = kind == 0 ? L.mul_fixed(c, curve, n, k1, (uint8_t*)dxy, (uint8_t*)dinf)
+         : kind == 1 ? L.mul_var(c, curve, n, k1, p1, (uint8_t*)dxy, (uint8_t*)dinf)
+                     : L.mul_add2(c, curve, n, k1, p1, k2, p2, (uint8_t*)dxy, (uint8_t*)dinf);
+  if (rc != 0) return lib_error(env);
+  return mk_result(env, "xy", bxy, "inf", binf);
+}
+static napi_value fn_mul_fixed(napi_env e, napi_callback_info i) { return mul_common(e, i, 0); }
+static napi_value fn_mul_var(napi_env e, napi_callback_info i) { return mul_common(e, i, 1); }
+static napi_value fn_mul_add2(napi_env e, napi_callback_info i) { return mul_common(e, i, 2); }
+
+static napi_value fn_verify(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 8; napi_value argv[8];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  int32_t curve, hl, mb;
+  if (napi_get_value_int32(env, argv[1], &curve) != napi_ok || napi_get_value_int32(env, argv[3], &hl) != napi_ok ||
+      napi_get_value_int32(env, argv[4], &mb) != napi_ok) THROW(env, "ecdsaVerify(ctx, curve, hash, hashLen, msgBits, r, s, pub)");
+  int B = L.field_bytes(curve), NB = L.order_bytes(curve);
+  if (B <= 0 || hl <= 0) THROW(env, "bad curve / hashLen");
+  const uint8_t *h, *r, *s, *q; size_t lh, lr, ls, lq;
+  if (!get_buf(env, argv[2], &h, &lh, 0) || !get_buf(env, argv[5], &r, &lr, 0) ||
+      !get_buf(env, argv[6], &s, &ls, 0) || !get_buf(env, argv[7], &q, &lq, 0)) return NULL;
+  if (lh % (size_t)hl) THROW(env, "hash buffer length is not a multiple of hashLen");
+  size_t n = lh / (size_t)hl;
+  if (lr != n * (size_t)NB || ls != n * (size_t)NB || lq != n * 2 * (size_t)B) THROW(env, "buffer length mismatch");
+  napi_value bok; void* dok; CHECK(env, napi_create_buffer(env, n, &dok, &bok));
+  if (L.ecdsa_verify(c, curve, n, h, hl, mb, r, s, q, (uint8_t*)dok) != 0) return lib_error(env);
+  return bok;
+}
+static napi_value fn_x25519(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 3; napi_value argv[3];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  const uint8_t *k, *x; size_t lk, lx;
+  if (!get_buf(env, argv[1], &k, &lk, 0) || !get_buf(env, argv[2], &x, &lx, 0)) return NULL;
+  if (lk % 32 || lx != lk) THROW(env, "buffer length mismatch");
+  size_t n = lk / 32;
+  napi_value bx, binf; void *dx, *dinf;
+  CHECK(env, napi_create_buffer(env, n * 32, &dx, &bx));
+  CHECK(env, napi_create_buffer(env, n, &dinf, &binf));
+  if (L.x25519(c, n, k, x, (uint8_t*)dx, (uint8_t*)dinf) != 0) return lib_error(env);
+  return mk_result(env, "x", bx, "inf", binf);
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+  struct { const char* name; napi_callback fn; } fns[] = {
+    {"open", fn_open}, {"createContext", fn_create}, {"destroyContext", fn_destroy},
+    {"curveId", fn_curve_id}, {"fieldBytes", fn_field_bytes}, {"orderBytes", fn_order_bytes},
+    {"deviceCount", fn_device_count}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
+    {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519},
+  };
+  for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
+    napi_value f;
+    if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
+    if (napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) return NULL;
+  }
+  return exports;
+}
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

@@ -1,0 +1,247 @@
+'use strict';
+// ellgpu -- JavaScript host layer: routes indutny/elliptic's scalar-multiplication
+// hot path to libellgpu.so (MI355X) through the N-API addon, and adds the batch
+// API the reference does not have.
+//
+//   var elliptic = require('elliptic');
+//   var ellgpu = require('elliptic_amd/js').install(elliptic);      // patch in place
+//   ec.verify(msg, sig, key)            // unchanged API, now one GPU launch per call
+//   ellgpu.ecdsaVerifyBatch('secp256k1', {hashes, hashLen, r, s, pub})   // flat Buffers
+//
+// What install() replaces (reference file:line):
+//   BaseCurve#_fixedNafMul      lib/elliptic/curve/base.js:52-84
+//   BaseCurve#_wnafMul          lib/elliptic/curve/base.js:86-126
+//   BaseCurve#_wnafMulAdd       lib/elliptic/curve/base.js:128-253   (len == 2)
+//   ShortCurve#_endoWnafMulAdd  lib/elliptic/curve/short.js:218-249
+//   mont Point#mul              lib/elliptic/curve/mont.js:130-153
+// Contracts kept: same signatures; a NEW point object of the same class on the
+// same curve is returned; infinity is curve.point(null, null) (short/mont) or the
+// identity (edwards); jacobianResult=true returns an object with isInfinity() /
+// eqXToP() (the affine result lifted with Z = 1); k is not reduced mod n; inputs
+// are never mutated.  Anything outside the engine's domain -- a curve that is not
+// one of the reference's presets (the toy curves of test/curve-test.js), a scalar
+// wider than the curve's byte length, a negative scalar -- is handed to the
+// reference's own original method, untouched.
+
+var path = require('path');
+
+var CURVES = ['secp256k1', 'p192', 'p224', 'p256', 'p384', 'p521', 'ed25519',
+  'curve25519'];
+
+function Engine(options) {
+  options = options || {};
+  this.addon = options.addon || require(options.addonPath ||
+    path.join(__dirname, 'ellgpu.node'));
+  this.addon.open(options.libPath || process.env.ELLGPU_LIB ||
+    path.join(__dirname, '..', 'lib', 'libellgpu.so'));
+  this.ctx = this.addon.createContext(options.device | 0);
+  this.stats = { gpuCalls: 0, gpuItems: 0, passthrough: 0 };
+}
+
+Engine.prototype._id = function _id(curve) {
+  var id = typeof curve === 'number' ? curve : this.addon.curveId(curve);
+  if (id < 0) throw new Error('Unknown curve ' + curve);
+  return id;
+};
+
+// ---- batch API on flat Buffers (fixed-width big-endian, item-major) ----------
+// scalars: n x B bytes; points: n x 2B bytes (x||y) or null for the generator.
+// -> { xy: Buffer(n x 2B), inf: Buffer(n) }
+Engine.prototype.mulBatch = function mulBatch(curve, scalars, points) {
+  var id = this._id(curve);
+  var n = scalars.length / this.addon.fieldBytes(id);
+  this.stats.gpuCalls++; this.stats.gpuItems += n;
+  return points ? this.addon.mulVar(this.ctx, id, scalars, points) :
+    this.addon.mulFixed(this.ctx, id, scalars);
+};
+// k1*P1 + k2*P2 per item; points1 == null means P1 = G
+Engine.prototype.mulAddBatch = function mulAddBatch(curve, k1, points1, k2,
+  points2) {
+  var id = this._id(curve);
+  this.stats.gpuCalls++;
+  this.stats.gpuItems += k1.length / this.addon.fieldBytes(id);
+  return this.addon.mulAdd2(this.ctx, id, k1, points1 || null, k2, points2);
+};
+// o = { hashes: Buffer(n x hashLen), hashLen, msgBits (0 = hashLen*8),
+//       r: Buffer(n x NB), s: Buffer(n x NB), pub: Buffer(n x 2B) } -> Buffer(n) of 0/1
+Engine.prototype.ecdsaVerifyBatch = function ecdsaVerifyBatch(curve, o) {
+  var id = this._id(curve);
+  this.stats.gpuCalls++; this.stats.gpuItems += o.hashes.length / o.hashLen;
+  return this.addon.ecdsaVerify(this.ctx, id, o.hashes, o.hashLen,
+    o.msgBits | 0, o.r, o.s, o.pub);
+};
+Engine.prototype.x25519Batch = function x25519Batch(scalars, xs) {
+  this.stats.gpuCalls++; this.stats.gpuItems += scalars.length / 32;
+  return this.addon.x25519(this.ctx, scalars, xs);
+};
+
+// ---- install(): prototype patch on a user-supplied elliptic instance ----------
+function install(elliptic, options) {
+  var eng = new Engine(options);
+  var BN = elliptic.curves.secp256k1.curve.p.constructor;
+  var addon = eng.addon;
+
+  // preset lookup: a curve object is in the engine's domain iff its
+  // (type, p, generator) equal one of the reference's presets
+  var presets = {};
+  CURVES.forEach(function(name) {
+    var c = elliptic.curves[name].curve;
+    presets[c.type + ':' + c.p.toString(16)] = { name: name, id: addon.curveId(name),
+      B: addon.fieldBytes(addon.curveId(name)), g: c.g };
+  });
+  function domain(curve) {
+    if (curve._ellgpu !== undefined) return curve._ellgpu;
+    var d = presets[curve.type + ':' + curve.p.toString(16)] || null;
+    if (d && curve.type === 'short') {
+      var ref = elliptic.curves[d.name].curve;
+      if (curve.a.fromRed().cmp(ref.a.fromRed()) !== 0 ||
+          curve.b.fromRed().cmp(ref.b.fromRed()) !== 0) d = null;
+    } else if (d && curve.type === 'edwards') {
+      var re = elliptic.curves[d.name].curve;
+      if (curve.a.fromRed().cmp(re.a.fromRed()) !== 0 ||
+          curve.d.fromRed().cmp(re.d.fromRed()) !== 0 || !curve.extended) d = null;
+    } else if (d && curve.type === 'mont') {
+      if (curve.a.fromRed().cmp(elliptic.curves[d.name].curve.a.fromRed()) !== 0)
+        d = null;
+    }
+    Object.defineProperty(curve, '_ellgpu', { value: d, enumerable: false,
+      writable: true });
+    return d;
+  }
+  function scalarBuf(k, B) {
+    if (!BN.isBN(k) || k.isNeg() || k.byteLength() > B) return null;
+    return Buffer.from(k.toArray('be', B));
+  }
+  // affine (x, y) of a point without mutating it; null for infinity
+  function affineBuf(curve, p, B) {
+    if (p.isInfinity()) return null;
+    var x, y;
+    if (curve.type === 'short') { x = p.getX(); y = p.getY(); }
+    else {
+      var q = curve.point(p.x, p.y, p.z, p.t);        // clone: getX() normalizes in place
+      x = q.getX(); y = q.getY();
+    }
+    return Buffer.concat([Buffer.from(x.toArray('be', B)),
+      Buffer.from(y.toArray('be', B))]);
+  }
+  function isG(curve, d, p) {
+    if (curve.type === 'short')
+      return !p.inf && p.x.cmp(curve.g.x) === 0 && p.y.cmp(curve.g.y) === 0;
+    return p === curve.g;
+  }
+  function resultPoint(curve, d, r, jacobian) {
+    var B = d.B;
+    var pt;
+    if (curve.type === 'short') {
+      pt = r.inf[0] ? curve.point(null, null) :
+        curve.point(new BN(r.xy.slice(0, B)), new BN(r.xy.slice(B, 2 * B)));
+      return jacobian ? pt.toJ() : pt;
+    }
+    // edwards: identity is an ordinary point
+    return curve.point(new BN(r.xy.slice(0, B)), new BN(r.xy.slice(B, 2 * B)));
+  }
+
+  var base = elliptic.curve.base.prototype;
+  var short = elliptic.curve.short.prototype;
+  var orig = {
+    fixedNafMul: base._fixedNafMul,
+    wnafMul: base._wnafMul,
+    wnafMulAdd: base._wnafMulAdd,
+    endoWnafMulAdd: short._endoWnafMulAdd,
+  };
+
+  function mul1(curve, p, k, origFn, origArgs) {
+    var d = curve.type === 'mont' ? null : domain(curve);
+    var kb = d && scalarBuf(k, d.B);
+    var pb = kb && affineBuf(curve, p, d.B);
+    if (!d || !kb || !pb) { eng.stats.passthrough++; return origFn.apply(curve, origArgs); }
+    var r = isG(curve, d, p) ? eng.mulBatch(d.id, kb, null) : eng.mulBatch(d.id, kb, pb);
+    return resultPoint(curve, d, r, false);
+  }
+  function mulAdd(curve, p1, k1, p2, k2, jacobian, origFn, origArgs) {
+    var d = curve.type === 'mont' ? null : domain(curve);
+    var b1 = d && scalarBuf(k1, d.B);
+    var b2 = b1 && scalarBuf(k2, d.B);
+    var q1 = b2 && affineBuf(curve, p1, d.B);
+    var q2 = q1 && affineBuf(curve, p2, d.B);
+    if (!q2) { eng.stats.passthrough++; return origFn.apply(curve, origArgs); }
+    var r = eng.mulAddBatch(d.id, b1, isG(curve, d, p1) ? null : q1, b2, q2);
+    return resultPoint(curve, d, r, jacobian);
+  }
+
+  base._fixedNafMul = function _fixedNafMul(p, k) {
+    return mul1(this, p, k, orig.fixedNafMul, arguments);
+  };
+  base._wnafMul = function _wnafMul(p, k) {
+    return mul1(this, p, k, orig.wnafMul, arguments);
+  };
+  base._wnafMulAdd = function _wnafMulAdd(defW, points, coeffs, len,
+    jacobianResult) {
+    if (len !== 2) { eng.stats.passthrough++; return orig.wnafMulAdd.apply(this, arguments); }
+    return mulAdd(this, points[0], coeffs[0], points[1], coeffs[1], !!jacobianResult,
+      orig.wnafMulAdd, arguments);
+  };
+  short._endoWnafMulAdd = function _endoWnafMulAdd(points, coeffs,
+    jacobianResult) {
+    if (points.length === 1) {
+      var r = mul1(this, points[0], coeffs[0], orig.endoWnafMulAdd, arguments);
+      return jacobianResult && r.toJ ? r.toJ() : r;
+    }
+    if (points.length === 2)
+      return mulAdd(this, points[0], coeffs[0], points[1], coeffs[1],
+        !!jacobianResult, orig.endoWnafMulAdd, arguments);
+    eng.stats.passthrough++;
+    return orig.endoWnafMulAdd.apply(this, arguments);
+  };
+
+  // Montgomery x-only ladder (Point class is not exported: reach it as
+  // eddsa/index.js:22 does, through an instance)
+  var montProto = elliptic.curves.curve25519.curve.g.constructor.prototype;
+  orig.montMul = montProto.mul;
+  montProto.mul = function mul(k) {
+    var d = domain(this.curve);
+    var kb = d && scalarBuf(k, 32);
+    if (!kb || this.isInfinity()) { eng.stats.passthrough++; return orig.montMul.apply(this, arguments); }
+    var x = this.curve.point(this.x, this.z).getX();
+    var r = eng.x25519Batch(kb, Buffer.from(x.toArray('be', 32)));
+    if (r.inf[0]) return this.curve.point(null, null);
+    return this.curve.point(new BN(r.x), new BN(1));
+  };
+
+  eng.uninstall = function uninstall() {
+    base._fixedNafMul = orig.fixedNafMul;
+    base._wnafMul = orig.wnafMul;
+    base._wnafMulAdd = orig.wnafMulAdd;
+    short._endoWnafMulAdd = orig.endoWnafMulAdd;
+    montProto.mul = orig.montMul;
+  };
+
+  // EC#verify over many signatures with the reference's own decoding
+  // (keyFromPublic, Signature, _truncateToN's length rule) and ONE launch.
+  // items: [{ msg: Buffer|Array, signature, key, enc? }] -> [bool]
+  eng.verifyMany = function verifyMany(ec, items) {
+    var d = domain(ec.curve);
+    if (!d || ec.curve.type !== 'short') throw new Error('verifyMany: unsupported curve');
+    var NB = ec.n.byteLength();
+    var Signature = ec.sign('00', ec.keyFromPrivate('01', 'hex')).constructor;
+    var hl = items.length ? items[0].msg.length : 1;
+    var hs = [], rs = [], ss = [], qs = [], pre = [];
+    items.forEach(function(it, i) {
+      if (it.msg.length !== hl) throw new Error('verifyMany: digests must share one length');
+      var key = ec.keyFromPublic(it.key, it.enc);
+      var sig = new Signature(it.signature, 'hex');
+      var bad = sig.r.isNeg() || sig.s.isNeg() || sig.r.byteLength() > NB || sig.s.byteLength() > NB;
+      pre[i] = !bad;
+      hs.push(Buffer.from(it.msg));
+      rs.push(Buffer.from((bad ? new BN(0) : sig.r).toArray('be', NB)));
+      ss.push(Buffer.from((bad ? new BN(0) : sig.s).toArray('be', NB)));
+      qs.push(affineBuf(ec.curve, key.getPublic(), d.B));
+    });
+    var ok = eng.ecdsaVerifyBatch(d.id, { hashes: Buffer.concat(hs), hashLen: hl, msgBits: 0,
+      r: Buffer.concat(rs), s: Buffer.concat(ss), pub: Buffer.concat(qs) });
+    return items.map(function(_, i) { return pre[i] && ok[i] === 1; });
+  };
+  return eng;
+}
+
+module.exports = { install: install, Engine: Engine, CURVES: CURVES };

@@ -1,0 +1,74 @@
+'use strict';
+// GPU-box self-test of the JS batch API: drives libellgpu.so through the N-API
+// addon and compares with the golden fixtures (reference outputs) under
+// tests/golden/.  Needs neither the reference nor mocha.
+//   node elliptic_amd/js/selftest.js [libPath]
+var fs = require('fs');
+var path = require('path');
+var ellgpu = require('./index.js');
+
+var GOLD = path.join(__dirname, '..', '..', 'tests', 'golden');
+var eng = new ellgpu.Engine({ libPath: process.argv[2] || process.env.ELLGPU_LIB });
+var checked = 0;
+
+function hexBuf(list, width) {
+  return Buffer.concat(list.map(function(h) {
+    var b = Buffer.from(h.length % 2 ? '0' + h : h, 'hex');
+    if (b.length > width) throw new Error('value wider than field');
+    return Buffer.concat([Buffer.alloc(width - b.length), b]);
+  }));
+}
+function check(r, i, B, want, what) {
+  var gotInf = r.inf[i] === 1;
+  if (want.inf) { if (!gotInf) throw new Error(what + ': expected infinity at ' + i); }
+  else {
+    var x = r.xy.slice(i * 2 * B, i * 2 * B + B).toString('hex');
+    var y = r.xy.slice(i * 2 * B + B, (i + 1) * 2 * B).toString('hex');
+    if (gotInf || x !== want.x || y !== want.y) throw new Error(what + ': mismatch at ' + i);
+  }
+  checked++;
+}
+
+['secp256k1', 'p192', 'p224', 'p256', 'p384', 'p521', 'ed25519'].forEach(function(name) {
+  var B = eng.addon.fieldBytes(eng.addon.curveId(name));
+  var cases = JSON.parse(fs.readFileSync(path.join(GOLD, 'mul_' + name + '.json')));
+  var fixed = cases.filter(function(c) { return c.op === 'fixed'; });
+  var r = eng.mulBatch(name, hexBuf(fixed.map(function(c) { return c.k; }), B), null);
+  fixed.forEach(function(c, i) { check(r, i, B, c.r, name + ' fixed'); });
+  var vr = cases.filter(function(c) { return c.op === 'var'; });
+  r = eng.mulBatch(name, hexBuf(vr.map(function(c) { return c.k; }), B),
+    Buffer.concat(vr.map(function(c) { return hexBuf([c.px, c.py], B); })));
+  vr.forEach(function(c, i) { check(r, i, B, c.r, name + ' var'); });
+  var ma = cases.filter(function(c) { return c.op === 'muladd'; });
+  r = eng.mulAddBatch(name, hexBuf(ma.map(function(c) { return c.k1; }), B),
+    Buffer.concat(ma.map(function(c) { return hexBuf([c.p1x, c.p1y], B); })),
+    hexBuf(ma.map(function(c) { return c.k2; }), B),
+    Buffer.concat(ma.map(function(c) { return hexBuf([c.p2x, c.p2y], B); })));
+  ma.forEach(function(c, i) { check(r, i, B, c.r, name + ' muladd'); });
+  if (name === 'ed25519') return;
+  var vs = JSON.parse(fs.readFileSync(path.join(GOLD, 'verify_' + name + '.json')));
+  var groups = {};
+  vs.forEach(function(c) { var k = c.z.length / 2; (groups[k] = groups[k] || []).push(c); });
+  Object.keys(groups).forEach(function(hl) {
+    var cs = groups[hl]; hl = +hl;
+    var nbits = { secp256k1: 256, p192: 192, p224: 224, p256: 256, p384: 384, p521: 521 }[name];
+    if (hl * 8 - Math.max(0, hl * 8 - nbits) > 32 * Math.ceil(nbits / 32)) return;
+    var ok = eng.ecdsaVerifyBatch(name, { hashes: hexBuf(cs.map(function(c) { return c.z; }), hl),
+      hashLen: hl, msgBits: 0, r: hexBuf(cs.map(function(c) { return c.r; }), B),
+      s: hexBuf(cs.map(function(c) { return c.s; }), B),
+      pub: Buffer.concat(cs.map(function(c) { return hexBuf([c.qx, c.qy], B); })) });
+    cs.forEach(function(c, i) {
+      if ((ok[i] === 1) !== c.ok) throw new Error(name + ' verify mismatch: ' + JSON.stringify(c));
+      checked++;
+    });
+  });
+});
+var lc = JSON.parse(fs.readFileSync(path.join(GOLD, 'mul_curve25519.json')));
+var rr = eng.x25519Batch(hexBuf(lc.map(function(c) { return c.k; }), 32), hexBuf(lc.map(function(c) { return c.px; }), 32));
+lc.forEach(function(c, i) {
+  var inf = rr.inf[i] === 1;
+  if (c.r.inf ? !inf : (inf || rr.x.slice(i * 32, i * 32 + 32).toString('hex') !== c.r.x))
+    throw new Error('x25519 mismatch at ' + i);
+  checked++;
+});
+console.log(JSON.stringify({ ok: true, checked: checked, engine: eng.stats }));

@@ -12,6 +12,8 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../elliptic_amd/csrc/engine.h"
 
@@ -23,11 +25,24 @@ struct LoopBackend {
   void h2d(void* d, const void* h, size_t bytes) { memcpy(d, h, bytes); }
   void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
   int sync() { return 0; }
+  // "threads" of a launch are independent, so the loop is split over the host
+  // cores (only to keep the CPU test-suite short)
   template <class Fn>
   void launch(const Fn& f, size_t nthreads) {
-    signed char digits[Fn::DS_PER_LANE > 0 ? Fn::DS_PER_LANE : 1];
-    DigitStore ds{digits, 1};
-    for (size_t t = 0; t < nthreads; t++) f(t, ds);
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nw = hw ? hw : 1;
+    if (nthreads < 64) nw = 1;
+    std::vector<std::thread> pool;
+    for (size_t w = 0; w < nw; w++) {
+      size_t lo = nthreads * w / nw, hi = nthreads * (w + 1) / nw;
+      auto body = [&f, lo, hi]() {
+        signed char digits[Fn::DS_PER_LANE > 0 ? Fn::DS_PER_LANE : 1];
+        DigitStore ds{digits, 1};
+        for (size_t t = lo; t < hi; t++) f(t, ds);
+      };
+      if (nw == 1) body(); else pool.emplace_back(body);
+    }
+    for (auto& th : pool) th.join();
   }
 };
 }  // namespace ell

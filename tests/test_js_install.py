@@ -1,0 +1,63 @@
+"""The JavaScript host layer (elliptic_amd/js: N-API addon + install() patch).
+
+CPU: the reference's own, unmodified mocha suite must pass with install()
+applied to the reference library; in this GPU-less container the addon is
+pointed at the CPU unit-test build of the device code (tests/hostsim), so what
+is exercised is the marshalling, the prototype patch and the device code's
+logic.  Needs Node and /root/reference (build container only).
+GPU (-m gpu): the batch API through the addon on the real libellgpu.so against
+the golden fixtures."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _addon():
+    from elliptic_amd.js import build as jb
+    p = jb.build()
+    if p is None:
+        pytest.skip("node headers / gcc not available")
+    return p
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_reference_suite_passes_with_install_patch():
+    if not os.path.exists("/root/reference/dist/elliptic.js"):
+        pytest.skip("reference checkout not present (GPU box)")
+    _addon()
+    from hostsim.build import build as build_hostsim
+    env = dict(os.environ, ELLGPU_LIB=build_hostsim())
+    p = subprocess.run(["node", os.path.join(ROOT, "tools", "run_ref_tests_patched.js")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["failed"] == 0 and res["passed"] == res["total"] >= 226
+    # the patched methods really were the ones running
+    assert res["engine"]["gpuCalls"] > 500 and res["engine"]["passthrough"] < 20
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_js_batch_api_hostsim():
+    _addon()
+    from hostsim.build import build as build_hostsim
+    p = subprocess.run(["node", os.path.join(ROOT, "elliptic_amd", "js", "selftest.js"), build_hostsim()],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert json.loads(p.stdout.strip().splitlines()[-1])["checked"] > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_js_batch_api_gpu():
+    _addon()
+    p = subprocess.run(["node", os.path.join(ROOT, "elliptic_amd", "js", "selftest.js")],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert json.loads(p.stdout.strip().splitlines()[-1])["checked"] > 1000
