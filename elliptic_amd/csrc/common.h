@@ -38,17 +38,42 @@ typedef uint8_t u8;
 
 // ---- multi-limb primitives (little-endian 32-bit limbs) -------------------
 
+// Carry primitives.  clang's __builtin_addc/__builtin_subc lower to genuine
+// v_add_co_u32 / v_addc_co_u32 chains on gfx950 (the u64-widening idiom does
+// not: it becomes v_lshl_add_u64 + v_mov pairs, 4x the instructions) and the
+// compiler pads the VCC read-after-write hazard itself.
+ELL_HD u32 addc32(u32 a, u32 b, u32 cin, u32& cout) {
+#if defined(__clang__)
+  unsigned co;
+  u32 r = __builtin_addc(a, b, cin, &co);
+  cout = co;
+  return r;
+#else
+  u64 t = (u64)a + b + cin;
+  cout = (u32)(t >> 32);
+  return (u32)t;
+#endif
+}
+ELL_HD u32 subb32(u32 a, u32 b, u32 bin, u32& bout) {
+#if defined(__clang__)
+  unsigned bo;
+  u32 r = __builtin_subc(a, b, bin, &bo);
+  bout = bo;
+  return r;
+#else
+  u64 t = (u64)a - b - bin;
+  bout = (u32)(t >> 63);
+  return (u32)t;
+#endif
+}
+
 // r = a + b, returns carry out
 template <int L>
 ELL_HD u32 bn_add(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L]) {
-  u64 c = 0;
+  u32 c = 0;
   ELL_UNROLL
-  for (int i = 0; i < L; i++) {
-    c += (u64)a[i] + b[i];
-    r[i] = (u32)c;
-    c >>= 32;
-  }
-  return (u32)c;
+  for (int i = 0; i < L; i++) r[i] = addc32(a[i], b[i], c, c);
+  return c;
 }
 
 // r = a - b, returns borrow out (0/1)
@@ -56,11 +81,7 @@ template <int L>
 ELL_HD u32 bn_sub(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L]) {
   u32 br = 0;
   ELL_UNROLL
-  for (int i = 0; i < L; i++) {
-    u64 t = (u64)a[i] - b[i] - br;
-    r[i] = (u32)t;
-    br = (u32)(t >> 63);
-  }
+  for (int i = 0; i < L; i++) r[i] = subb32(a[i], b[i], br, br);
   return br;
 }
 
@@ -69,10 +90,7 @@ template <int L>
 ELL_HD bool bn_geq(const u32 (&a)[L], const u32 (&b)[L]) {
   u32 br = 0;
   ELL_UNROLL
-  for (int i = 0; i < L; i++) {
-    u64 t = (u64)a[i] - b[i] - br;
-    br = (u32)(t >> 63);
-  }
+  for (int i = 0; i < L; i++) (void)subb32(a[i], b[i], br, br);
   return br == 0;
 }
 

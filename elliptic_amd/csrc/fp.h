@@ -20,6 +20,7 @@
 #pragma once
 
 #include "common.h"
+#include "mul_asm.h"
 
 namespace ell {
 
@@ -27,6 +28,47 @@ template <int N>
 struct Fe {
   u32 v[N];
 };
+
+// Wide product / square of L-limb integers.  Device code uses the generated
+// v_mad_u64_u32 + carry-out blocks of mul_asm.h; host passes (hipcc's host side
+// and the CPU unit-test build) use the portable operand-scanning code.
+template <int L>
+ELL_HD void fe_mul_wide(u32 (&r)[2 * L], const u32 (&a)[L], const u32 (&b)[L]) {
+#if defined(ELL_HAVE_MUL_ASM)
+  if constexpr (L == 6) masm::mul_wide_6(r, a, b);
+  else if constexpr (L == 7) masm::mul_wide_7(r, a, b);
+  else if constexpr (L == 8) masm::mul_wide_8(r, a, b);
+  else if constexpr (L == 12) masm::mul_wide_12(r, a, b);
+  else if constexpr (L == 17) masm::mul_wide_17(r, a, b);
+  else bn_mul_wide<L, L>(r, a, b);
+#else
+  bn_mul_wide<L, L>(r, a, b);
+#endif
+}
+template <int L>
+ELL_HD void fe_sqr_wide(u32 (&r)[2 * L], const u32 (&a)[L]) {
+#if defined(ELL_HAVE_MUL_ASM)
+  u32 off[2 * L];
+  if constexpr (L == 6) masm::sqr_offdiag_6(off, a);
+  else if constexpr (L == 7) masm::sqr_offdiag_7(off, a);
+  else if constexpr (L == 8) masm::sqr_offdiag_8(off, a);
+  else if constexpr (L == 12) masm::sqr_offdiag_12(off, a);
+  else if constexpr (L == 17) masm::sqr_offdiag_17(off, a);
+  else { bn_sqr_wide<L>(r, a); return; }
+  // r = 2*off + sum_i a_i^2 2^(64 i): the squares sit in disjoint 64-bit slots
+  u32 c = 0;
+  ELL_UNROLL
+  for (int i = 0; i < L; i++) {
+    u64 d = (u64)a[i] * a[i];
+    u32 lo2 = (off[2 * i] << 1) | (i ? (off[2 * i - 1] >> 31) : 0u);
+    u32 hi2 = (off[2 * i + 1] << 1) | (off[2 * i] >> 31);
+    r[2 * i] = addc32(lo2, (u32)d, c, c);
+    r[2 * i + 1] = addc32(hi2, (u32)(d >> 32), c, c);
+  }
+#else
+  bn_sqr_wide<L>(r, a);
+#endif
+}
 
 // --------------------------------------------------------------------------
 // helpers shared by the field families
@@ -89,57 +131,66 @@ struct FpK256 {
   ELL_HD static El neg(const El& a) { return sub(zero(), a); }
   ELL_HD static El dbl(const El& a) { return add(a, a); }
 
-  // fold a 512-bit value t[0..16) to [0,p): 2^256 == 2^32 + 977 (mod p)
+  // fold a 512-bit value t[0..16) to [0,p): 2^256 == 2^32 + 977 (mod p).
+  // Written with explicit carry chains (addc32) so that gfx950 gets
+  // v_add_co/v_addc instead of 64-bit add + move pairs.
   ELL_HD static El reduce_wide(const u32 (&t)[16]) {
-    // u = lo + hi*977 + (hi << 32)      (10 limbs)
+    // v = hi * 977: eight independent 32x10-bit products
+    u32 pl[8], ph[8];
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) {
+      u64 x = (u64)t[8 + i] * C0;
+      pl[i] = (u32)x;
+      ph[i] = (u32)(x >> 32);
+    }
+    // w = v + (hi << 32)                      (10 limbs)
+    u32 w[10];
+    u32 c = 0;
+    w[0] = pl[0];
+    ELL_UNROLL
+    for (int i = 1; i < 8; i++) w[i] = addc32(pl[i], ph[i - 1], c, c);
+    w[8] = ph[7] + c;                          // < 2^10 + 1
+    c = 0;
+    ELL_UNROLL
+    for (int i = 1; i < 9; i++) w[i] = addc32(w[i], t[8 + i - 1], c, c);
+    w[9] = c;
+    // u = lo + w                              (u[8] + u[9]*2^32 = T < 2^34)
     u32 u[10];
-    u32 carry = 0;
+    c = 0;
     ELL_UNROLL
-    for (int i = 0; i < 8; i++) {
-      u64 x = (u64)t[8 + i] * C0 + t[i] + carry;
-      u[i] = (u32)x;
-      carry = (u32)(x >> 32);
-    }
-    u[8] = carry;
-    u64 c = 0;
-    ELL_UNROLL
-    for (int i = 0; i < 8; i++) {
-      c += (u64)u[i + 1] + t[8 + i];
-      u[i + 1] = (u32)c;
-      c >>= 32;
-    }
-    u[9] = (u32)c;
-    // second fold: T = u[8] + u[9]*2^32 (< 2^34);  r = u[0..8) + T*977 + (T<<32)
+    for (int i = 0; i < 8; i++) u[i] = addc32(t[i], w[i], c, c);
+    u[8] = addc32(w[8], 0, c, c);
+    u[9] = w[9] + c;
+    // second fold: r = u[0..8) + T*977 + (T << 32)
+    u64 q = (u64)u[8] * C0;
+    u32 t0 = (u32)q;
+    u32 t1 = (u32)(q >> 32) + u[9] * C0;       // < 2^10 + 2^12
+    u32 cy;
+    t1 = addc32(t1, u[8], 0, cy);
+    u32 t2 = u[9] + cy;
     u32 r[8];
-    u64 x = (u64)u[8] * C0 + u[0];
-    r[0] = (u32)x;
-    x = (x >> 32) + (u64)u[9] * C0 + u[1] + u[8];
-    r[1] = (u32)x;
-    x = (x >> 32) + (u64)u[2] + u[9];
-    r[2] = (u32)x;
-    u32 cy = (u32)(x >> 32);
+    c = 0;
+    r[0] = addc32(u[0], t0, c, c);
+    r[1] = addc32(u[1], t1, c, c);
+    r[2] = addc32(u[2], t2, c, c);
     ELL_UNROLL
-    for (int i = 3; i < 8; i++) {
-      u64 y = (u64)u[i] + cy;
-      r[i] = (u32)y;
-      cy = (u32)(y >> 32);
-    }
-    // value = cy*2^256 + r  < 2^256 + 2^67: subtract p once if needed
+    for (int i = 3; i < 8; i++) r[i] = addc32(u[i], 0, c, c);
+    // value = c*2^256 + r  < 2^256 + 2^67: subtract p once if needed
     u32 p[8]; get_p(p);
     u32 s[8];
     u32 br = bn_sub<8>(s, r, p);
     El out;
-    bn_select<8>(out.v, (cy != 0) || (br == 0), s, r);
+    bn_select<8>(out.v, (c != 0) || (br == 0), s, r);
     return out;
   }
   ELL_HD static El mul(const El& a, const El& b) {
     u32 t[16];
-    bn_mul_wide<8, 8>(t, a.v, b.v);
+    fe_mul_wide<8>(t, a.v, b.v);
     return reduce_wide(t);
   }
   ELL_HD static El sqr(const El& a) {
     u32 t[16];
-    bn_sqr_wide<8>(t, a.v);
+    fe_sqr_wide<8>(t, a.v);
     return reduce_wide(t);
   }
   // a * small constant (< 2^32)
@@ -204,12 +255,11 @@ struct Fp25519 {
     // fold bit 255: a = lo255 + 19*b255   (< 2^255 + 19)
     u32 r[8];
     u32 top = a[7] >> 31;
-    u64 c = (u64)a[0] + 19u * top;
-    r[0] = (u32)c; c >>= 32;
+    u32 c = 0;
+    r[0] = addc32(a[0], 19u * top, c, c);
     ELL_UNROLL
-    for (int i = 1; i < 7; i++) { c += a[i]; r[i] = (u32)c; c >>= 32; }
-    c += (a[7] & 0x7FFFFFFFu);
-    r[7] = (u32)c;
+    for (int i = 1; i < 7; i++) r[i] = addc32(a[i], 0, c, c);
+    r[7] = (a[7] & 0x7FFFFFFFu) + c;
     u32 p[8]; get_p(p);
     u32 s[8];
     u32 br = bn_sub<8>(s, r, p);
@@ -232,34 +282,45 @@ struct Fp25519 {
   ELL_HD static El dbl(const El& a) { return add(a, a); }
 
   ELL_HD static El reduce_wide(const u32 (&t)[16]) {
-    // u = lo + 38*hi  (9 limbs, u[8] < 39)
-    u32 u[8];
-    u32 carry = 0;
+    // v = 38*hi: eight independent 32x6-bit products; u = lo + v (9 limbs)
+    u32 pl[8], ph[8];
     ELL_UNROLL
     for (int i = 0; i < 8; i++) {
-      u64 x = (u64)t[8 + i] * 38u + t[i] + carry;
-      u[i] = (u32)x;
-      carry = (u32)(x >> 32);
+      u64 x = (u64)t[8 + i] * 38u;
+      pl[i] = (u32)x;
+      ph[i] = (u32)(x >> 32);
     }
+    u32 w[9];
+    u32 c = 0;
+    w[0] = pl[0];
+    ELL_UNROLL
+    for (int i = 1; i < 8; i++) w[i] = addc32(pl[i], ph[i - 1], c, c);
+    w[8] = ph[7] + c;
+    u32 u[8];
+    c = 0;
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) u[i] = addc32(t[i], w[i], c, c);
+    u32 carry = w[8] + c;                       // < 40
     // fold carry*2^256 == carry*38, and bit 255 == 19, in one pass
     u32 top = u[7] >> 31;
     u[7] &= 0x7FFFFFFFu;
-    u64 c = (u64)u[0] + (u64)carry * 38u + 19u * top;
+    u32 add0 = carry * 38u + 19u * top;
     u32 r[8];
-    r[0] = (u32)c; c >>= 32;
+    c = 0;
+    r[0] = addc32(u[0], add0, c, c);
     ELL_UNROLL
-    for (int i = 1; i < 8; i++) { c += u[i]; r[i] = (u32)c; c >>= 32; }
+    for (int i = 1; i < 8; i++) r[i] = addc32(u[i], 0, c, c);
     // r < 2^255 + 2^12: at most one more bit-255 fold, then one subtract
     return from_plain(r);
   }
   ELL_HD static El mul(const El& a, const El& b) {
     u32 t[16];
-    bn_mul_wide<8, 8>(t, a.v, b.v);
+    fe_mul_wide<8>(t, a.v, b.v);
     return reduce_wide(t);
   }
   ELL_HD static El sqr(const El& a) {
     u32 t[16];
-    bn_sqr_wide<8>(t, a.v);
+    fe_sqr_wide<8>(t, a.v);
     return reduce_wide(t);
   }
   ELL_HD static El sqr_n(El a, int n) {

@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Generate elliptic_amd/csrc/mul_asm.h: gfx950 inline-asm multiply-accumulate
+blocks for the wide product / square of L-limb integers.
+
+Why asm: the C idiom `(u64)a*b + r + carry` compiles on gfx950 to one
+v_mad_u64_u32 plus ~4 v_mov/v_lshl_add_u64 per partial product.  The hardware
+has what is needed -- v_mad_u64_u32 D(64) = a*b + C(64) with a carry-out into
+an SGPR pair, and v_addc_co_u32 -- but the compiler never uses the carry-out.
+
+Scheme (product scanning, two columns per block): columns k (even) and k+1
+each own a 96-bit accumulator (64-bit VGPR pair + 32-bit extension):
+    v_mad_u64_u32  acc, sN, a_i, b_j, acc        ; 64-bit accumulate, carry -> sN
+    v_addc_co_u32  ext, sD, 0, ext, sN           ; extension += carry
+The two columns' chains are independent, and the generator interleaves them so
+that every carry is consumed at least 3 issue slots after it is produced (the
+VALU-writes-SGPR -> VALU-reads-it-as-carry hazard on gfx950 needs 2 wait
+states; nothing pads the inside of an asm statement, so the generator inserts
+`s_nop` where interleaving cannot).  Combining the two accumulators of a block
+and handing the carry to the next block is left to compiler-visible C++
+(__builtin_addc chains, which hipcc pads itself).
+
+    python tools/gen_mul_asm.py        # writes elliptic_amd/csrc/mul_asm.h
+"""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DST = os.path.join(ROOT, "elliptic_amd", "csrc", "mul_asm.h")
+
+MIN_DIST = 3          # consumer position - producer position
+NSREG = 4             # carry SGPR pairs in flight
+
+
+def schedule(prods_a, prods_b, a_has_carry_in, b_has_carry_in=False):
+    """-> list of instruction tuples:
+       ('mad', acc, i, j, sreg|None)   acc in 'A','B'; sreg None => carry impossible, addend literal 0
+       ('addc', acc, sreg)
+       ('nop',)"""
+    pend = []                     # (pos, acc, sreg)
+    free = list(range(NSREG))
+    seq = []
+    qa, qb = list(prods_a), list(prods_b)
+    first = {"A": not a_has_carry_in, "B": not b_has_carry_in}   # first product into a zero accumulator cannot carry
+    turn = "A"
+    while qa or qb or pend:
+        pos = len(seq)
+        if pend and pos - pend[0][0] >= MIN_DIST:
+            _, acc, s = pend.pop(0)
+            seq.append(("addc", acc, s))
+            free.append(s)
+            continue
+        # pick a stream: alternate, prefer the longer one when the other is empty
+        pick = None
+        order = [turn, "B" if turn == "A" else "A"]
+        for t in order:
+            q = qa if t == "A" else qb
+            if q:
+                pick = t
+                break
+        if pick is not None and (free or first[pick]):
+            q = qa if pick == "A" else qb
+            i, j = q.pop(0)
+            if first[pick]:
+                seq.append(("mad0", pick, i, j))
+                first[pick] = False
+            else:
+                s = free.pop(0)
+                seq.append(("mad", pick, i, j, s))
+                pend.append((pos, pick, s))
+            turn = "B" if pick == "A" else "A"
+            continue
+        seq.append(("nop",))
+    return seq
+
+
+def emit_block(name, prods_a, prods_b, a_has_carry_in, square=False, b_has_carry_in=False):
+    """C++ function with one asm statement.  Operands: A (u64 +v), A2 (u32 +v),
+    B (u64 +v), B2 (u32 +v), used a_i / b_j ("v"), carry sgprs (=&s)."""
+    seq = schedule(prods_a, prods_b, a_has_carry_in, b_has_carry_in)
+    used_a = sorted({i for (i, j) in prods_a + prods_b})
+    used_b = sorted({j for (i, j) in prods_a + prods_b})
+    if square:
+        used_a = sorted(set(used_a) | set(used_b))
+        used_b = []
+    args = ["u64& A", "u32& A2", "u64& B", "u32& B2"]
+    args += ["u32 a%d" % i for i in used_a] + ["u32 b%d" % j for j in used_b]
+    lines = []
+    for ins in seq:
+        if ins[0] == "nop":
+            lines.append("s_nop 0")
+        elif ins[0] == "mad0":
+            _, acc, i, j = ins
+            bj = ("%%[a%d]" % j) if square else ("%%[b%d]" % j)
+            # accumulator known to be zero: product alone cannot overflow 64 bits
+            lines.append("v_mad_u64_u32 %%[%s], %%[sd], %%[a%d], %s, 0" % (acc, i, bj))
+        elif ins[0] == "mad":
+            _, acc, i, j, s = ins
+            bj = ("%%[a%d]" % j) if square else ("%%[b%d]" % j)
+            lines.append("v_mad_u64_u32 %%[%s], %%[s%d], %%[a%d], %s, %%[%s]" % (acc, s, i, bj, acc))
+        else:
+            _, acc, s = ins
+            lines.append("v_addc_co_u32_e64 %%[%s2], %%[sd], 0, %%[%s2], %%[s%d]" % (acc, acc, s))
+    # if B receives no product its zero-initialised inputs pass through untouched
+    body = "\\n\\t".join(lines)
+    outs = ['[A] "+v"(A)', '[A2] "+v"(A2)', '[B] "+v"(B)', '[B2] "+v"(B2)']
+    outs += ['[s%d] "=&s"(s%d)' % (k, k) for k in range(NSREG)] + ['[sd] "=&s"(sd)']
+    ins_ = ['[a%d] "v"(a%d)' % (i, i) for i in used_a] + ['[b%d] "v"(b%d)' % (j, j) for j in used_b]
+    code = "ELL_DEVASM void %s(%s) {\n" % (name, ", ".join(args))
+    code += "  u64 %s, sd;\n" % ", ".join("s%d" % k for k in range(NSREG))
+    code += '  asm("%s"\n      : %s\n      : %s\n      : );\n' % (body, ", ".join(outs), ", ".join(ins_) if ins_ else "")
+    code += "  (void)sd;" + "".join(" (void)s%d;" % k for k in range(NSREG)) + "\n}\n\n"
+    nmad = sum(1 for x in seq if x[0] in ("mad", "mad0"))
+    nadd = sum(1 for x in seq if x[0] == "addc")
+    nnop = sum(1 for x in seq if x[0] == "nop")
+    return code, used_a, used_b, (nmad, nadd, nnop)
+
+
+CHUNK = 8   # distinct a-limbs per asm statement (inline asm allows 30 operands)
+
+
+def emit_chunked(base, pa, pb, a_cin, square=False):
+    """split a column pair's products into asm statements of <= CHUNK a-limbs each;
+    returns (code, [(name, used_a, used_b)], stats)"""
+    idx = sorted({i for (i, j) in pa + pb})
+    code = ""
+    calls = []
+    stats = [0, 0, 0]
+    a_in, b_in = a_cin, False
+    for c in range(0, max(len(idx), 1), CHUNK):
+        sel = set(idx[c:c + CHUNK])
+        ca = [(i, j) for (i, j) in pa if i in sel]
+        cb = [(i, j) for (i, j) in pb if i in sel]
+        if not ca and not cb:
+            continue
+        name = "%s_%d" % (base, c // CHUNK)
+        cd, ua, ub, st = emit_block(name, ca, cb, a_in, square, b_in)
+        code += cd
+        calls.append((name, ua, ub))
+        for t in range(3):
+            stats[t] += st[t]
+        if ca:
+            a_in = True
+        if cb:
+            b_in = True
+    return code, calls, stats
+
+
+def gen_mul(L):
+    """full product of two L-limb numbers -> 2L limbs"""
+    out = []
+    calls = []
+    stats = [0, 0, 0]
+    for k in range(0, 2 * L - 1, 2):
+        pa = [(i, k - i) for i in range(L) if 0 <= k - i < L]
+        pb = [(i, k + 1 - i) for i in range(L) if 0 <= k + 1 - i < L]
+        code, cl, st = emit_chunked("mulblk%d_%d" % (L, k), pa, pb, k > 0)
+        out.append(code)
+        calls.append((k, cl))
+        for t in range(3):
+            stats[t] += st[t]
+    fn = "// r[0..%d) = a * b   (%d v_mad_u64_u32, %d v_addc, %d s_nop in asm + C++ combines)\n" % (2 * L, *stats)
+    fn += "ELL_DEVASM void mul_wide_%d(u32 (&r)[%d], const u32 (&a)[%d], const u32 (&b)[%d]) {\n" % (L, 2 * L, L, L)
+    fn += "  u64 A = 0; u32 A2 = 0;\n"
+    for (k, cl) in calls:
+        fn += "  { u64 B = 0; u32 B2 = 0;\n"
+        for (name, ua, ub) in cl:
+            fn += "    %s(A, A2, B, B2%s%s);\n" % (name, "".join(", a[%d]" % i for i in ua), "".join(", b[%d]" % j for j in ub))
+        fn += "    r[%d] = (u32)A;\n" % k
+        fn += "    u32 c; u32 t1 = addc32((u32)(A >> 32), (u32)B, 0, c);\n"
+        fn += "    u32 n0 = addc32(A2, (u32)(B >> 32), c, c);\n"
+        fn += "    u32 n1 = B2 + c;\n"
+        fn += "    r[%d] = t1;\n" % (k + 1)
+        fn += "    A = ((u64)n1 << 32) | n0; A2 = 0; }\n"
+    fn += "}\n\n"
+    return "".join(out) + fn
+
+
+def gen_sqr_off(L):
+    """off-diagonal half: sum_{i<j} a_i a_j 2^(32(i+j)) -> 2L limbs (top limb 0)"""
+    out = []
+    calls = []
+    stats = [0, 0, 0]
+    for k in range(0, 2 * L - 1, 2):
+        pa = [(i, k - i) for i in range(L) if 0 <= k - i < L and i < k - i]
+        pb = [(i, k + 1 - i) for i in range(L) if 0 <= k + 1 - i < L and i < k + 1 - i]
+        if not pa and not pb:
+            calls.append((k, []))
+            continue
+        code, cl, st = emit_chunked("sqrblk%d_%d" % (L, k), pa, pb, k > 0, square=True)
+        out.append(code)
+        calls.append((k, cl))
+        for t in range(3):
+            stats[t] += st[t]
+    fn = "// r[0..%d) = sum_{i<j} a_i*a_j*2^(32(i+j))   (%d v_mad_u64_u32, %d v_addc, %d s_nop)\n" % (2 * L, *stats)
+    fn += "ELL_DEVASM void sqr_offdiag_%d(u32 (&r)[%d], const u32 (&a)[%d]) {\n" % (L, 2 * L, L)
+    fn += "  u64 A = 0; u32 A2 = 0;\n"
+    for (k, cl) in calls:
+        fn += "  { u64 B = 0; u32 B2 = 0;\n"
+        for (name, ua, ub) in cl:
+            fn += "    %s(A, A2, B, B2%s);\n" % (name, "".join(", a[%d]" % i for i in ua))
+        fn += "    r[%d] = (u32)A;\n" % k
+        fn += "    u32 c; u32 t1 = addc32((u32)(A >> 32), (u32)B, 0, c);\n"
+        fn += "    u32 n0 = addc32(A2, (u32)(B >> 32), c, c);\n"
+        fn += "    u32 n1 = B2 + c;\n"
+        fn += "    r[%d] = t1;\n" % (k + 1)
+        fn += "    A = ((u64)n1 << 32) | n0; A2 = 0; }\n"
+    fn += "}\n\n"
+    return "".join(out) + fn
+
+
+def main():
+    hdr = ('// GENERATED by tools/gen_mul_asm.py -- do not edit.\n'
+           '// gfx950 inline-asm multiply-accumulate blocks (v_mad_u64_u32 with carry-out into an\n'
+           '// SGPR pair + v_addc_co_u32), hazard-spaced by the generator.  Device compilation only;\n'
+           '// host passes (hipcc host side, tests/hostsim) use the portable code in common.h.\n'
+           '#pragma once\n#include "common.h"\n\n'
+           '#if defined(__HIP_DEVICE_COMPILE__)\n'
+           '#define ELL_HAVE_MUL_ASM 1\n'
+           '#define ELL_DEVASM __device__ __forceinline__\n'
+           'namespace ell {\nnamespace masm {\n\n')
+    body = ""
+    for L in (6, 7, 8, 12, 17):
+        body += gen_mul(L)
+        body += gen_sqr_off(L)
+    tail = "}  // namespace masm\n}  // namespace ell\n#endif  // __HIP_DEVICE_COMPILE__\n"
+    with open(DST, "w") as f:
+        f.write(hdr + body + tail)
+    print("wrote", DST, len(body.splitlines()), "lines")
+
+
+if __name__ == "__main__":
+    main()
