@@ -63,6 +63,33 @@ def compile_one(args):
     return name, obj, time.time() - t0, p.stderr
 
 
+def build_dev_k256(verbose=True):
+    """secp256k1-only developer library (lib/libellgpu_dev.so, ~40 s): use with
+    ELLGPU_LIB=elliptic_amd/lib/libellgpu_dev.so for kernel iteration."""
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    digest = "dev" + source_digest()
+    work = [("inst_CvSecp256k1_g%d" % g, "inst.hip", ["-DELL_INST_CURVE=CvSecp256k1", "-DELL_INST_GROUP=%d" % g,
+                                                      "-DELL_ONLY_K256"], digest, []) for g in GROUPS]
+    for g in (10, 11, 12):       # ed25519 / x25519 units are referenced by the engine, keep them linkable
+        work.append(("inst_g%d" % g, "inst.hip", ["-DELL_INST_GROUP=%d" % g, "-DELL_ONLY_K256"], digest, []))
+    work.append(("capi", "capi.hip", ["-DELL_ONLY_K256"], digest, []))
+    for f in os.listdir(OBJ):
+        if ".dev" in f and digest not in f:
+            os.remove(os.path.join(OBJ, f))
+    t0 = time.time()
+    with cf.ThreadPoolExecutor(max_workers=8) as ex:
+        objs = [r[1] for r in ex.map(compile_one, work)]
+    out = os.path.join(LIBDIR, "libellgpu_dev.so")
+    p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs,
+                       capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("link failed:\n" + p.stderr[-4000:])
+    if verbose:
+        print("built %s in %.1fs" % (out, time.time() - t0))
+    return out
+
+
 def build(jobs=None, force=False, verbose=True, remarks=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -74,7 +101,7 @@ def build(jobs=None, force=False, verbose=True, remarks=False):
         return LIB
     # drop objects of older source states
     for f in os.listdir(OBJ):
-        if digest not in f:
+        if digest not in f and ".dev" not in f and f.endswith(".o"):
             os.remove(os.path.join(OBJ, f))
     jobs = jobs or max(1, (os.cpu_count() or 2))
     extra = ["-Rpass-analysis=kernel-resource-usage"] if remarks else []
@@ -108,5 +135,9 @@ if __name__ == "__main__":
     ap.add_argument("-j", type=int, default=None)
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--remarks", action="store_true", help="keep kernel-resource-usage remarks in csrc/_obj/resource_usage.log")
+    ap.add_argument("--dev-k256", action="store_true", help="secp256k1-only developer library")
     a = ap.parse_args()
-    build(a.j, a.force, True, a.remarks)
+    if a.dev_k256:
+        build_dev_k256()
+    else:
+        build(a.j, a.force, True, a.remarks)

@@ -30,7 +30,7 @@ struct FnMulVar {
   static constexpr const char* NAME = "mul_var";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
-  size_t n; const u8* k; const u8* xy; typename W::J* tbl; u32* jac;
+  size_t n; const u8* k; const u8* xy; typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) W::mul_var(i, n, k, xy, tbl, ds, jac);
   }
@@ -51,7 +51,7 @@ struct FnMulAddG {
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
   size_t n; const u8* k1; const u8* k2; const u8* xy2; const typename W::A* comb;
-  typename W::J* tbl; u32* jac;
+  typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) W::mul_add_g_item(i, n, k1, k2, xy2, comb, tbl, ds, jac);
   }
@@ -92,9 +92,10 @@ template <class CV>
 struct FnEcdsaMain {
   static constexpr const char* NAME = "ecdsa_main";
   typedef Work<CV> W;
+  static constexpr int MIN_WAVES = W::L <= 8 ? 3 : 1;      // <= 168 VGPRs for 256-bit curves
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
   size_t n; const u32* u12; const u8* valid; const u8* r; const u8* pub;
-  const typename W::A* comb; typename W::J* tbl; u8* ok;
+  const typename W::A* comb; typename W::VT* tbl; u8* ok;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) W::ecdsa_main(i, n, u12, valid, r, pub, comb, tbl, ds, ok);
   }
@@ -250,6 +251,15 @@ class Engine {
   int x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf);
 
   // ---- dispatch over curves (device pointers) --------------------------------
+#if defined(ELL_ONLY_K256)
+// developer build (elliptic_amd/build.py --dev-k256): secp256k1 kernels only, for fast
+// kernel iteration; every other curve reports E_UNSUPPORTED
+#define ELL_SHORT_DISPATCH(curve, CALL)                         \
+  switch (curve) {                                              \
+    case CURVE_SECP256K1: { typedef CvSecp256k1 CV; CALL; } break; \
+    default: return fail(E_UNSUPPORTED, "developer build: secp256k1 only"); \
+  }
+#else
 #define ELL_SHORT_DISPATCH(curve, CALL)                         \
   switch (curve) {                                              \
     case CURVE_SECP256K1: { typedef CvSecp256k1 CV; CALL; } break; \
@@ -260,8 +270,12 @@ class Engine {
     case CURVE_P521: { typedef CvP521 CV; CALL; } break;           \
     default: return fail(E_ARG, "unknown curve id");            \
   }
+#endif
 
   int prepare_curve(int curve) {
+#if defined(ELL_ONLY_K256)
+    if (curve != CURVE_SECP256K1) return fail(E_UNSUPPORTED, "developer build: secp256k1 only");
+#endif
     if (curve == CURVE_ED25519) return ensure_ed_comb();
     if (curve == CURVE_CURVE25519) return E_OK;
     int rc = E_OK;
@@ -548,7 +562,7 @@ template <class CV>
 int Engine<BK>::mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u8* out_inf,
                   typename Work<CV>::A* raw) {
   typedef Work<CV> W;
-  typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::J));
+  typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::VT));
   u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
   FnMulVar<CV> f{n, k, xy, tbl, jac};
@@ -588,7 +602,7 @@ int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* 
                     u8* out_inf) {
   typedef Work<CV> W;
   u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
-  typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::J));
+  typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::VT));
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
   FnMulAddG<CV> f{n, k1, k2, xy2, (const typename W::A*)comb_[CV::ID], tbl, jac};
   bk.launch(f, n);
@@ -601,7 +615,7 @@ template <class CV>
 int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* r, const u8* s,
                 const u8* pub, u8* ok) {
   typedef Work<CV> W;
-  typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::J));
+  typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::VT));
   u32* pre = (u32*)scratch(S_PRE, n * (W::LN > W::L ? W::LN : W::L) * 4);
   u32* u12 = (u32*)scratch(S_U12, n * 2 * W::LN * 4);
   u8* valid = (u8*)scratch(S_VALID, n);

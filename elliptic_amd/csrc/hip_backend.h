@@ -18,8 +18,15 @@ namespace ell {
 
 constexpr int BLOCK = 128;
 
+// Fn::MIN_WAVES (optional, default 1) = waves per SIMD the register allocator must
+// leave room for (__launch_bounds__'s second argument counts waves per SIMD here).
+template <class Fn, class = void>
+struct MinWaves { static constexpr int value = 1; };
 template <class Fn>
-__global__ void __launch_bounds__(BLOCK) k_run(const Fn f, size_t nthreads) {
+struct MinWaves<Fn, decltype((void)Fn::MIN_WAVES)> { static constexpr int value = Fn::MIN_WAVES; };
+
+template <class Fn>
+__global__ void __launch_bounds__(BLOCK, MinWaves<Fn>::value) k_run(const Fn f, size_t nthreads) {
   __shared__ signed char lds_digits[(Fn::DS_PER_LANE > 0 ? Fn::DS_PER_LANE : 1) * BLOCK];
   size_t tid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   DigitStore ds{lds_digits + threadIdx.x, BLOCK};

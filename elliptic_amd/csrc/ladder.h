@@ -71,6 +71,27 @@ ELL_HD void recode_w4(const u32 (&k)[LW], const DigitStore& ds, int s, int NS) {
   }
 }
 
+// Signed ODD 4-bit recoding of an odd k < 2^(4*NW): with the bit 2^(4*NW) forced on,
+//   k = sum_i d_i 16^i,  d_i = 2*((k' >> (4i+1)) & 15) - 15  in {+-1, +-3, ..., +-15}
+// (every window non-zero, so the ladder adds at every step and needs only the eight
+// odd multiples).  Digits go to ds at index w*NS + s.
+template <int LW, int NW>
+ELL_HD void recode_odd_w4(const u32 (&k)[LW], const DigitStore& ds, int s, int NS) {
+  constexpr int LK = (4 * NW) / 32 + 1;
+  u32 kp[LK + 1];
+  ELL_UNROLL
+  for (int i = 0; i < LK + 1; i++) kp[i] = i < LW ? k[i] : 0u;
+  kp[(4 * NW) >> 5] |= 1u << ((4 * NW) & 31);
+  ELL_UNROLL
+  for (int i = 0; i < NW; i++) {
+    const int bit = 4 * i + 1;
+    const int li = bit >> 5, sh = bit & 31;
+    u32 v = kp[li] >> sh;
+    if (sh > 28) v |= kp[li + 1] << (32 - sh);
+    ds.set(i * NS + s, 2 * (int)(v & 15u) - 15);
+  }
+}
+
 template <class CV>
 struct Ladder {
   typedef typename CV::F F;
@@ -89,6 +110,75 @@ struct Ladder {
       else t = G::dbl(tbl[j / 2 - 1]);
       tbl[j - 1] = t;
     }
+  }
+
+  // Effective-affine table of the odd multiples {1,3,...,15}*P (a = 0 curves only):
+  // with d = 2P = (Xd, Yd, Zd), the map (x, y) -> (x Zd^2, y Zd^3) sends the curve to an
+  // isomorphic one (same a = 0 formulas) on which d is AFFINE, so each next odd multiple is
+  // one mixed add; rescaling every entry to the last entry's Z then makes the whole table
+  // affine on a second isomorphic curve.  The ladder runs there with 8M+3S mixed adds
+  // (instead of 12M+4S) and its result is mapped back by one multiplication of Z by
+  // zg = Z_last * Zd.   tbl[0..8) = table, tbl[8..16) is used as scratch for the ratios.
+  ELL_HD static void build_table_odd8(A* tbl, const A& p, El& zg) {
+    J d = G::dbl(G::from_affine(p));
+    El zd2 = F::sqr(d.Z);
+    El zd3 = F::mul(zd2, d.Z);
+    A dd; dd.x = d.X; dd.y = d.Y;
+    J t;
+    t.X = F::mul(p.x, zd2);
+    t.Y = F::mul(p.y, zd3);
+    t.Z = F::one();
+    tbl[0].x = t.X; tbl[0].y = t.Y;
+    ELL_NOUNROLL
+    for (int i = 1; i < 8; i++) {
+      El h;
+      t = G::add_mixed_zr(t, dd, h);
+      tbl[i].x = t.X; tbl[i].y = t.Y;
+      tbl[8 + i].x = h;
+    }
+    zg = F::mul(t.Z, d.Z);
+    El zr = F::one();
+    ELL_NOUNROLL
+    for (int i = 6; i >= 0; i--) {
+      zr = F::mul(zr, tbl[8 + i + 1].x);
+      El zr2 = F::sqr(zr);
+      A e = tbl[i];
+      e.x = F::mul(e.x, zr2);
+      e.y = F::mul(e.y, F::mul(zr2, zr));
+      tbl[i] = e;
+    }
+  }
+
+  // acc = sum_s k_s * P_s on the effective-affine curve: digits odd (recode_odd_w4), tables
+  // tbl[s*8 + (|d|-1)/2] affine, point s negated when bit s of negmask is set; afterwards
+  // P_s is subtracted once where bit s of evenmask is set (k_s had been made odd by +1).
+  template <int NS, int NW>
+  ELL_HD static J run_odd_w4(const DigitStore& ds, const A* tbl, u32 negmask, u32 evenmask) {
+    J acc = G::infinity();
+    ELL_NOUNROLL
+    for (int w = NW - 1; w >= 0; w--) {
+      if (w != NW - 1) {
+        ELL_NOUNROLL
+        for (int j = 0; j < 4; j++) acc = G::dbl(acc);
+      }
+      ELL_NOUNROLL
+      for (int s = 0; s < NS; s++) {
+        int d = ds.get(w * NS + s);
+        int ad = d < 0 ? -d : d;
+        bool neg = (d < 0) != (((negmask >> s) & 1u) != 0);
+        A q = tbl[s * 8 + ((ad - 1) >> 1)];
+        q.y = fe_select<F>(neg, F::neg(q.y), q.y);
+        acc = G::add_mixed(acc, q);
+      }
+    }
+    ELL_NOUNROLL
+    for (int s = 0; s < NS; s++) {
+      A q = tbl[s * 8];
+      bool neg = ((negmask >> s) & 1u) == 0;          // subtract sign_s * P_s
+      q.y = fe_select<F>(neg, F::neg(q.y), q.y);
+      acc = G::add_mixed(acc, q, ((evenmask >> s) & 1u) != 0);
+    }
+    return acc;
   }
 
   // acc = sum_s k_s * P_s, digits from ds (NWIN windows of NS digits), tables

@@ -117,6 +117,24 @@ struct ShortOps {
     return select(do_add, r, p);
   }
 
+  // P + Q for table building: no exceptional cases are possible (P = j*Q0, Q = 2*Q0 on a
+  // prime-order curve), returns the ratio h with Z3 = Z1 * h.  8M + 3S.
+  ELL_HD static J add_mixed_zr(const J& p, const A& q, El& h) {
+    El z1z1 = F::sqr(p.Z);
+    El u2 = F::mul(q.x, z1z1);
+    El s2 = F::mul(q.y, F::mul(p.Z, z1z1));
+    h = F::sub(u2, p.X);
+    El rr = F::sub(s2, p.Y);
+    El hh = F::sqr(h);
+    El hhh = F::mul(h, hh);
+    El v = F::mul(p.X, hh);
+    J r;
+    r.X = F::sub(F::sub(F::sqr(rr), hhh), F::dbl(v));
+    r.Y = F::sub(F::mul(rr, F::sub(v, r.X)), F::mul(p.Y, hhh));
+    r.Z = F::mul(p.Z, h);
+    return r;
+  }
+
   // P + Q, both Jacobian; if !do_add returns P unchanged.  12M + 4S.
   ELL_HD static J add(const J& p, const J& q, bool do_add = true) {
     El z1z1 = F::sqr(p.Z);

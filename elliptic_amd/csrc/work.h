@@ -12,6 +12,8 @@
 //   u12   ECDSA u1,u2                    SoA  u12[(c*LN + limb)*n + i], plain residues mod n
 #pragma once
 
+#include <type_traits>
+
 #include "ladder.h"
 
 namespace ell {
@@ -39,6 +41,9 @@ struct Work {
   static constexpr bool TOP = !ENDO;
   static constexpr int NWIN = NNIB + (TOP ? 1 : 0);
   static constexpr int TBL1 = 8 * NSV;                     // table entries per (k, P)
+  // element type of the variable-base window table: affine on the effective-affine curve
+  // for secp256k1 (ladder.h build_table_odd8), Jacobian otherwise
+  typedef typename std::conditional<ENDO, A, J>::type VT;
   static constexpr int COMB_W = BYTES;                     // 8-bit comb windows
   static constexpr int COMB_ENTRIES = COMB_W * 255;
 
@@ -107,17 +112,51 @@ struct Work {
     }
   }
 
+  // k*P for one (k, P), result in true Jacobian coordinates.  secp256k1: GLV split, odd
+  // signed digits, effective-affine tables of P and lambda*P (mixed adds only); other
+  // curves: signed 4-bit windows over a Jacobian table.
+  ELL_HD static J var_ladder(const u32 (&k)[L], const A& p, VT* tbl, const DigitStore& ds) {
+    if constexpr (ENDO) {
+      u32 k1[5], k2[5];
+      bool n1, n2;
+      glv_split(k, k1, n1, k2, n2);
+      u32 evenmask = ((k1[0] & 1u) ? 0u : 1u) | ((k2[0] & 1u) ? 0u : 2u);
+      k1[0] |= 1u;                                  // k even -> k + 1, P subtracted at the end
+      k2[0] |= 1u;
+      recode_odd_w4<5, NNIB>(k1, ds, 0, 2);
+      recode_odd_w4<5, NNIB>(k2, ds, 1, 2);
+      u32 negmask = (n1 ? 1u : 0u) | (n2 ? 2u : 0u);
+      El zg;
+      LD::build_table_odd8(tbl, p, zg);
+      // lambda*P table: (beta*x, y)   (short.js:282-310 _getBeta); beta commutes with the
+      // isomorphisms, which only scale x and y
+      El beta;
+      ELL_UNROLL
+      for (int i = 0; i < L; i++) beta.v[i] = C::beta[i];
+      ELL_NOUNROLL
+      for (int e = 0; e < 8; e++) {
+        A t = tbl[e];
+        t.x = F::mul(t.x, beta);
+        tbl[8 + e] = t;
+      }
+      J r = LD::template run_odd_w4<2, NNIB>(ds, tbl, negmask, evenmask);
+      r.Z = F::mul(r.Z, zg);
+      return r;
+    } else {
+      u32 negmask = 0;
+      prepare_var(k, p, ds, 0, NSV, tbl, negmask);
+      return LD::template run_w4<NSV, NWIN>(ds, tbl, negmask);
+    }
+  }
+
   // k*P -> Jacobian (Point#mul's ladder: short.js:422-432 -> base.js:86-126 /
   // short.js:218-249)
-  ELL_HD static void mul_var(size_t i, size_t n, const u8* ks, const u8* xy, J* tbl_all,
+  ELL_HD static void mul_var(size_t i, size_t n, const u8* ks, const u8* xy, VT* tbl_all,
                              const DigitStore& ds, u32* jac) {
     u32 k[L];
     load_be<L>(k, ks + i * BYTES, BYTES);
     A p = load_affine(xy, i);
-    J* tbl = tbl_all + i * TBL1;
-    u32 negmask = 0;
-    prepare_var(k, p, ds, 0, NSV, tbl, negmask);
-    J r = LD::template run_w4<NSV, NWIN>(ds, tbl, negmask);
+    J r = var_ladder(k, p, tbl_all + i * TBL1, ds);
     store_jac(jac, n, i, r);
   }
 
@@ -141,15 +180,13 @@ struct Work {
   // k1*G + k2*P2 -> Jacobian (the shape ECDSA verify uses): comb for G, window
   // ladder for P2, one final Jacobian add
   ELL_HD static J mul_add_g(const u32 (&k1)[L], const u32 (&k2)[L], const A& p2, const A* comb,
-                            J* tbl, const DigitStore& ds) {
-    u32 negmask = 0;
-    prepare_var(k2, p2, ds, 0, NSV, tbl, negmask);
-    J b = LD::template run_w4<NSV, NWIN>(ds, tbl, negmask);
+                            VT* tbl, const DigitStore& ds) {
+    J b = var_ladder(k2, p2, tbl, ds);
     J a = LD::template comb_mul<L, COMB_W>(k1, comb);
     return G::add(a, b);
   }
   ELL_HD static void mul_add_g_item(size_t i, size_t n, const u8* k1s, const u8* k2s,
-                                    const u8* xy2, const A* comb, J* tbl_all,
+                                    const u8* xy2, const A* comb, VT* tbl_all,
                                     const DigitStore& ds, u32* jac) {
     u32 k1[L], k2[L];
     load_be<L>(k1, k1s + i * BYTES, BYTES);
@@ -308,7 +345,7 @@ struct Work {
 
   // Pass 2: R = u1*G + u2*Q, accept iff R != O and R.x == r (mod n)
   ELL_HD static void ecdsa_main(size_t i, size_t n, const u32* u12, const u8* valid,
-                                const u8* rs, const u8* pub_xy, const A* comb, J* tbl_all,
+                                const u8* rs, const u8* pub_xy, const A* comb, VT* tbl_all,
                                 const DigitStore& ds, u8* out_ok) {
     u32 u1[L], u2[L], r[LN];
     ELL_UNROLL
