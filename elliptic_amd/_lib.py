@@ -36,6 +36,7 @@ _SIGS = {
     "ellgpu_x25519_ladder_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
     "ellgpu_ctx_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "ellgpu_ctx_get_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]),
+    "ellgpu_debug_field_op": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p]),
     "ellgpu_probe_valu": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 

@@ -63,23 +63,29 @@ def compile_one(args):
     return name, obj, time.time() - t0, p.stderr
 
 
-def build_dev_k256(verbose=True):
+def build_dev_k256(verbose=True, curve="CvSecp256k1"):
     """secp256k1-only developer library (lib/libellgpu_dev.so, ~40 s): use with
     ELLGPU_LIB=elliptic_amd/lib/libellgpu_dev.so for kernel iteration."""
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     digest = "dev" + source_digest()
-    work = [("inst_CvSecp256k1_g%d" % g, "inst.hip", ["-DELL_INST_CURVE=CvSecp256k1", "-DELL_INST_GROUP=%d" % g,
-                                                      "-DELL_ONLY_K256"], digest, []) for g in GROUPS]
+    cid = {"CvSecp256k1": 0, "CvP192": 1, "CvP224": 2, "CvP256": 3, "CvP384": 4, "CvP521": 5}[curve]
+    dflag = "-DELL_ONLY_CURVE=%d" % cid
+    tflag = "-DELL_ONLY_TYPE=" + curve
+    work = [("inst_%s_g%d" % (curve, g), "inst.hip", ["-DELL_INST_CURVE=" + curve, "-DELL_INST_GROUP=%d" % g,
+                                                      dflag, tflag], digest, ["-Rpass-analysis=kernel-resource-usage"]) for g in GROUPS]
     for g in (10, 11, 12):       # ed25519 / x25519 units are referenced by the engine, keep them linkable
-        work.append(("inst_g%d" % g, "inst.hip", ["-DELL_INST_GROUP=%d" % g, "-DELL_ONLY_K256"], digest, []))
-    work.append(("capi", "capi.hip", ["-DELL_ONLY_K256"], digest, []))
+        work.append(("inst_g%d" % g, "inst.hip", ["-DELL_INST_GROUP=%d" % g, dflag, tflag], digest, []))
+    work.append(("capi_%s" % curve, "capi.hip", [dflag, tflag], digest, []))
     for f in os.listdir(OBJ):
         if ".dev" in f and digest not in f:
             os.remove(os.path.join(OBJ, f))
     t0 = time.time()
     with cf.ThreadPoolExecutor(max_workers=8) as ex:
-        objs = [r[1] for r in ex.map(compile_one, work)]
+        res = list(ex.map(compile_one, work))
+    objs = [r[1] for r in res]
+    with open(os.path.join(OBJ, "resource_usage_dev.log"), "w") as f:
+        f.write("\n".join(r[3] for r in res))
     out = os.path.join(LIBDIR, "libellgpu_dev.so")
     p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs,
                        capture_output=True, text=True)
@@ -136,8 +142,9 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--remarks", action="store_true", help="keep kernel-resource-usage remarks in csrc/_obj/resource_usage.log")
     ap.add_argument("--dev-k256", action="store_true", help="secp256k1-only developer library")
+    ap.add_argument("--dev", default=None, help="single-curve developer library, e.g. --dev CvP384")
     a = ap.parse_args()
-    if a.dev_k256:
-        build_dev_k256()
+    if a.dev_k256 or a.dev:
+        build_dev_k256(curve=a.dev or "CvSecp256k1")
     else:
         build(a.j, a.force, True, a.remarks)

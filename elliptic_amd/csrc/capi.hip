@@ -40,6 +40,30 @@ __global__ void __launch_bounds__(256) k_probe(u32* out, int iters, u32 seed) {
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = (u32)s ^ (u32)(s >> 32);
 }
 
+// ---- white-box probe: one field operation per lane (tests/test_gpu_field.py) ----
+template <class F>
+__global__ void k_field_op(int op, size_t n, const u32* a, const u32* b, u32* r) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 ta[F::L], tb[F::L], tr[F::L];
+  for (int l = 0; l < F::L; l++) { ta[l] = a[i * F::L + l]; tb[l] = b[i * F::L + l]; }
+  typename F::El x = F::from_plain(ta), y = F::from_plain(tb), z;
+  switch (op) {
+    case 0: z = F::add(x, y); break;
+    case 1: z = F::sub(x, y); break;
+    case 2: z = F::mul(x, y); break;
+    case 3: z = F::sqr(x); break;
+    case 4: z = F::inv(x); break;
+    default: z = F::neg(x); break;
+  }
+  F::to_plain(tr, z);
+  for (int l = 0; l < F::L; l++) r[i * F::L + l] = tr[l];
+}
+template <class F>
+static void run_field_op(HipBackend& bk, int op, size_t n, const u32* a, const u32* b, u32* r) {
+  hipLaunchKernelGGL(k_field_op<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, bk.cur, op, n, a, b, r);
+}
+
 }  // namespace ell
 
 #define ELL_BACKEND ell::HipBackend
@@ -143,4 +167,50 @@ extern "C" int ellgpu_ctx_get_timing(ellgpu_ctx* ctx, char* buf, size_t cap) {
   if (out.size() + 1 > cap) return set_err(ELLGPU_E_ARG, "timing buffer too small");
   memcpy(buf, out.c_str(), out.size() + 1);
   return (int)out.size();
+}
+
+// White-box probe (tests only): r[i] = a[i] <op> b[i] in one of the engine's fields, n items
+// of `limbs` 32-bit little-endian limbs each (host pointers).  field: 0 secp256k1 p,
+// 1 2^255-19, 10+c base field of short curve c as FpMont, 20+c order field of curve c
+// (26 = ed25519 order).  op: 0 add, 1 sub, 2 mul, 3 sqr, 4 inv, 5 neg.
+extern "C" int ellgpu_debug_field_op(ellgpu_ctx* ctx, int field, int op, size_t n, const uint32_t* a,
+                                     const uint32_t* b, uint32_t* r) {
+  using namespace ell;
+  ELL_ENTER(ctx, nullptr);
+  int L = 0;
+  switch (field) {
+    case 0: case 1: case 10: case 13: case 20: case 23: case 26: L = 8; break;
+    case 11: case 21: L = 6; break;
+    case 12: case 22: L = 7; break;
+    case 14: case 24: L = 12; break;
+    case 15: case 25: L = 17; break;
+    default: return set_err(ELLGPU_E_ARG, "unknown field id");
+  }
+  HipBackend& bk = ctx->eng->bk;
+  size_t bytes = n * (size_t)L * 4;
+  u32* da = (u32*)bk.alloc(bytes); u32* db = (u32*)bk.alloc(bytes); u32* dr = (u32*)bk.alloc(bytes);
+  if (!da || !db || !dr) return set_err(ELLGPU_E_NOMEM, "probe allocation failed");
+  bk.h2d(da, a, bytes); bk.h2d(db, b, bytes);
+  switch (field) {
+    case 0: run_field_op<FpK256>(bk, op, n, da, db, dr); break;
+    case 1: run_field_op<Fp25519>(bk, op, n, da, db, dr); break;
+    case 10: run_field_op<FpMont<consts::SECP256K1_P>>(bk, op, n, da, db, dr); break;
+    case 11: run_field_op<CvP192::F>(bk, op, n, da, db, dr); break;
+    case 12: run_field_op<CvP224::F>(bk, op, n, da, db, dr); break;
+    case 13: run_field_op<CvP256::F>(bk, op, n, da, db, dr); break;
+    case 14: run_field_op<CvP384::F>(bk, op, n, da, db, dr); break;
+    case 15: run_field_op<CvP521::F>(bk, op, n, da, db, dr); break;
+    case 20: run_field_op<CvSecp256k1::Fn>(bk, op, n, da, db, dr); break;
+    case 21: run_field_op<CvP192::Fn>(bk, op, n, da, db, dr); break;
+    case 22: run_field_op<CvP224::Fn>(bk, op, n, da, db, dr); break;
+    case 23: run_field_op<CvP256::Fn>(bk, op, n, da, db, dr); break;
+    case 24: run_field_op<CvP384::Fn>(bk, op, n, da, db, dr); break;
+    case 25: run_field_op<CvP521::Fn>(bk, op, n, da, db, dr); break;
+    case 26: run_field_op<FpMont<consts::ED25519_N>>(bk, op, n, da, db, dr); break;
+  }
+  bk.note(hipGetLastError());
+  bk.d2h(r, dr, bytes);
+  int rc = bk.sync();
+  bk.free_(da); bk.free_(db); bk.free_(dr);
+  return finish(ctx, rc);
 }

@@ -251,13 +251,13 @@ class Engine {
   int x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf);
 
   // ---- dispatch over curves (device pointers) --------------------------------
-#if defined(ELL_ONLY_K256)
-// developer build (elliptic_amd/build.py --dev-k256): secp256k1 kernels only, for fast
-// kernel iteration; every other curve reports E_UNSUPPORTED
+#if defined(ELL_ONLY_CURVE)
+// developer build (elliptic_amd/build.py --dev <curve>): one short curve's kernels only, for
+// fast kernel iteration; every other short curve reports E_UNSUPPORTED
 #define ELL_SHORT_DISPATCH(curve, CALL)                         \
   switch (curve) {                                              \
-    case CURVE_SECP256K1: { typedef CvSecp256k1 CV; CALL; } break; \
-    default: return fail(E_UNSUPPORTED, "developer build: secp256k1 only"); \
+    case ELL_ONLY_CURVE: { typedef ELL_ONLY_TYPE CV; CALL; } break; \
+    default: return fail(E_UNSUPPORTED, "developer build: single curve only"); \
   }
 #else
 #define ELL_SHORT_DISPATCH(curve, CALL)                         \
@@ -273,8 +273,8 @@ class Engine {
 #endif
 
   int prepare_curve(int curve) {
-#if defined(ELL_ONLY_K256)
-    if (curve != CURVE_SECP256K1) return fail(E_UNSUPPORTED, "developer build: secp256k1 only");
+#if defined(ELL_ONLY_CURVE)
+    if (curve < CURVE_ED25519 && curve != ELL_ONLY_CURVE) return fail(E_UNSUPPORTED, "developer build: single curve only");
 #endif
     if (curve == CURVE_ED25519) return ensure_ed_comb();
     if (curve == CURVE_CURVE25519) return E_OK;

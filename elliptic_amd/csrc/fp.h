@@ -34,7 +34,7 @@ struct Fe {
 // and the CPU unit-test build) use the portable operand-scanning code.
 template <int L>
 ELL_HD void fe_mul_wide(u32 (&r)[2 * L], const u32 (&a)[L], const u32 (&b)[L]) {
-#if defined(ELL_HAVE_MUL_ASM)
+#if defined(ELL_HAVE_MUL_ASM) && !defined(ELL_NO_ASM_MUL)
   if constexpr (L == 6) masm::mul_wide_6(r, a, b);
   else if constexpr (L == 7) masm::mul_wide_7(r, a, b);
   else if constexpr (L == 8) masm::mul_wide_8(r, a, b);
@@ -47,7 +47,7 @@ ELL_HD void fe_mul_wide(u32 (&r)[2 * L], const u32 (&a)[L], const u32 (&b)[L]) {
 }
 template <int L>
 ELL_HD void fe_sqr_wide(u32 (&r)[2 * L], const u32 (&a)[L]) {
-#if defined(ELL_HAVE_MUL_ASM)
+#if defined(ELL_HAVE_MUL_ASM) && !defined(ELL_NO_ASM_MUL)
   u32 off[2 * L];
   if constexpr (L == 6) masm::sqr_offdiag_6(off, a);
   else if constexpr (L == 7) masm::sqr_offdiag_7(off, a);
@@ -379,8 +379,57 @@ struct FpMont {
   ELL_HD static El neg(const El& a) { return sub(zero(), a); }
   ELL_HD static El dbl(const El& a) { return add(a, a); }
 
-  // CIOS Montgomery product: a*b*R^-1 mod p  (2L^2 + L multiplies)
-  ELL_HD static El mul(const El& a, const El& b) {
+  // Montgomery reduction of a 2L-limb value: t * R^-1 mod p, row by row with explicit
+  // carry chains (L multiplies by the constant limbs of p + 2L add-with-carry per row).
+  ELL_HD static El redc(u32 (&t)[2 * L]) {
+    u32 top = 0;
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) {
+      u32 m = t[i] * P::n0;
+      u32 lo[L], hi[L];
+      ELL_UNROLL
+      for (int j = 0; j < L; j++) {
+        u64 x = (u64)m * P::p[j];
+        lo[j] = (u32)x;
+        hi[j] = (u32)(x >> 32);
+      }
+      // u = m*p as L+1 limbs, then t[i .. i+L] += u
+      u32 u[L + 1];
+      u32 c = 0;
+      u[0] = lo[0];
+      ELL_UNROLL
+      for (int j = 1; j < L; j++) u[j] = addc32(lo[j], hi[j - 1], c, c);
+      u[L] = hi[L - 1] + c;
+      c = 0;
+      ELL_UNROLL
+      for (int j = 0; j < L; j++) t[i + j] = addc32(t[i + j], u[j], c, c);
+      if (i + L < 2 * L) {
+        u32 c1, c2;
+        u32 y = addc32(t[i + L], u[L], c, c1);
+        t[i + L] = addc32(y, 0, top, c2);
+        top = c1 + c2;
+      }
+    }
+    // NB: for i = L-1 the row's top limb is t[2L-1]; `top` is the 2^(64L... ) overflow bit
+    u32 p[L]; get_p(p);
+    u32 r[L], sres[L];
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) r[i] = t[L + i];
+    u32 br = bn_sub<L>(sres, r, p);
+    El out;
+    bn_select<L>(out.v, (top != 0) || (br == 0), sres, r);
+    return out;
+  }
+
+  // Montgomery product a*b*R^-1 mod p.  Device: wide product from the generated
+  // v_mad_u64_u32 blocks, then redc().  Host passes: classic CIOS (2L^2 + L multiplies).
+  ELL_HD static El mul_inline(const El& a, const El& b) {
+#if defined(ELL_HAVE_MUL_ASM) || defined(ELL_TEST_REDC)
+    u32 t[2 * L];
+    fe_mul_wide<L>(t, a.v, b.v);
+    return redc(t);
+#else
+
     u32 t[L + 2];
     ELL_UNROLL
     for (int i = 0; i < L + 2; i++) t[i] = 0;
@@ -417,8 +466,34 @@ struct FpMont {
     El out;
     bn_select<L>(out.v, (t[L] != 0) || (br == 0), s, r);
     return out;
+  #endif
   }
-  ELL_HD static El sqr(const El& a) { return mul(a, a); }
+  ELL_HD static El sqr_inline(const El& a) {
+#if defined(ELL_HAVE_MUL_ASM) || defined(ELL_TEST_REDC)
+    u32 t[2 * L];
+    fe_sqr_wide<L>(t, a.v);
+    return redc(t);
+#else
+    return mul_inline(a, a);
+#endif
+  }
+  // Wide moduli (>= 12 limbs): the multiply is a real function call.  Fully inlined, a
+  // p384/p521 point addition keeps ~10 field elements plus the product rows live and the
+  // allocator ends at 256 VGPRs + AGPR spills (1 wave/SIMD); as a call the multiply's
+  // temporaries die at its return.
+  static ELL_HD_NOINLINE El mul_call(El a, El b) { return mul_inline(a, b); }
+  static ELL_HD_NOINLINE El sqr_call(El a) { return sqr_inline(a); }
+#ifndef ELL_MONT_CALL_MINL
+#define ELL_MONT_CALL_MINL 12
+#endif
+  ELL_HD static El mul(const El& a, const El& b) {
+    if constexpr (L >= ELL_MONT_CALL_MINL) return mul_call(a, b);
+    else return mul_inline(a, b);
+  }
+  ELL_HD static El sqr(const El& a) {
+    if constexpr (L >= ELL_MONT_CALL_MINL) return sqr_call(a);
+    else return sqr_inline(a);
+  }
 
   ELL_HD static El from_plain(const u32 (&a)[L]) {      // a < 2^(32L): a*R mod p
     El x, r2;

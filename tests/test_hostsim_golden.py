@@ -23,7 +23,7 @@ from oracle import ec_oracle as O  # noqa: E402
 @pytest.fixture(scope="module")
 def hs():
     path = build_hostsim()
-    lib = _lib.load(path, optional=("ellgpu_probe_valu", "ellgpu_ctx_set_timing", "ellgpu_ctx_get_timing"))
+    lib = _lib.load(path, optional=("ellgpu_probe_valu", "ellgpu_ctx_set_timing", "ellgpu_ctx_get_timing", "ellgpu_debug_field_op"))
     return lib
 
 

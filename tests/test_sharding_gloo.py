@@ -47,7 +47,7 @@ def _worker(rank, world, port, lib_path, n, q):
         from elliptic_amd.sharding import ShardedVerifier
         from golden_util import I, verify_cases
         from elliptic_amd import ints_to_be
-        lib = _lib.load(lib_path, optional=("ellgpu_probe_valu", "ellgpu_ctx_set_timing", "ellgpu_ctx_get_timing"))
+        lib = _lib.load(lib_path, optional=("ellgpu_probe_valu", "ellgpu_ctx_set_timing", "ellgpu_ctx_get_timing", "ellgpu_debug_field_op"))
         ctx = elliptic_amd.Context(0, lib_path=lib)
         cs = [c for c in verify_cases("secp256k1") if len(c["z"]) == 64 and "msgBitLength" not in c][:n]
         h = ints_to_be([I(c["z"]) for c in cs], 32)

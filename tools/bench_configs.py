@@ -26,6 +26,7 @@ def rnd(seed, n, w):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--curves", default="", help="comma list; default all")
     a = ap.parse_args()
     ctx = elliptic_amd.Context(0)
     dev = torch.device("cuda", 0)
@@ -46,8 +47,11 @@ def main():
                      "kernels_ms": {k: v[1] / v[0] for k, v in tm.items()}})
         print(json.dumps(rows[-1]), flush=True)
 
+    only = [c for c in a.curves.split(",") if c]
     for curve, n in (("secp256k1", 1 << 20), ("p256", 1 << 19), ("p384", 1 << 18), ("p521", 1 << 16),
                      ("ed25519", 1 << 20)):
+        if only and curve not in only:
+            continue
         B = elliptic_amd.FIELD_BYTES[curve]
         k = rnd("cfg:k:" + curve, n, B)
         if curve == "p521":
@@ -62,6 +66,8 @@ def main():
         timed("%s fixed-base G*k" % curve, n, lambda: ctx.mul_fixed_dev(curve, dd, pts, inf))
         timed("%s variable-base P*k" % curve, n, lambda: ctx.mul_var_dev(curve, dk, pts, out, inf))
         timed("%s k1*G + k2*P" % curve, n, lambda: ctx.mul_add2_dev(curve, dd, None, dk, pts, out, inf))
+    if only and "curve25519" not in only:
+        return
     n = 1 << 20
     k = torch.from_numpy(rnd("cfg:k:x", n, 32)).to(dev)
     x = torch.from_numpy(rnd("cfg:x:x", n, 32)).to(dev)

@@ -72,41 +72,90 @@ def schedule(prods_a, prods_b, a_has_carry_in, b_has_carry_in=False):
     return seq
 
 
-def emit_block(name, prods_a, prods_b, a_has_carry_in, square=False, b_has_carry_in=False):
-    """C++ function with one asm statement.  Operands: A (u64 +v), A2 (u32 +v),
-    B (u64 +v), B2 (u32 +v), used a_i / b_j ("v"), carry sgprs (=&s)."""
-    seq = schedule(prods_a, prods_b, a_has_carry_in, b_has_carry_in)
+def emit_block(name, prods_a, prods_b, a_has_carry_in, square=False, b_has_carry_in=False,
+               cont=False):
+    """C++ function with one asm statement.
+
+    Every VGPR the statement writes is an EARLY-CLOBBER output ("=&v") distinct from all
+    inputs: the statement writes its accumulators long before it has read its last input,
+    and with tied "+v" operands LLVM may give an input that holds the same VALUE as an
+    accumulator's initial value (e.g. a constant-zero limb and a zero-initialised
+    accumulator) the accumulator's own register.  Incoming accumulator values are therefore
+    separate read-only inputs (Ai/A2i/Bi/B2i), consumed by the first instruction that
+    touches the accumulator.
+      cont=False: first statement of a column pair: A comes in (if a_has_carry_in), A2, B, B2
+                  start at zero.
+      cont=True : continuation statement: all four come in."""
+    seq = schedule(prods_a, prods_b, a_has_carry_in or cont, b_has_carry_in or cont)
     used_a = sorted({i for (i, j) in prods_a + prods_b})
     used_b = sorted({j for (i, j) in prods_a + prods_b})
     if square:
         used_a = sorted(set(used_a) | set(used_b))
         used_b = []
+    a_in = a_has_carry_in or cont          # A has an incoming value
+    a2_in = cont
+    b_in = cont
+    b2_in = cont
     args = ["u64& A", "u32& A2", "u64& B", "u32& B2"]
     args += ["u32 a%d" % i for i in used_a] + ["u32 b%d" % j for j in used_b]
     lines = []
+    touched = {"A": False, "A2": False, "B": False, "B2": False}
+    has_in = {"A": a_in, "A2": a2_in, "B": b_in, "B2": b2_in}
     for ins in seq:
         if ins[0] == "nop":
             lines.append("s_nop 0")
         elif ins[0] == "mad0":
             _, acc, i, j = ins
             bj = ("%%[a%d]" % j) if square else ("%%[b%d]" % j)
-            # accumulator known to be zero: product alone cannot overflow 64 bits
+            assert not has_in[acc] and not touched[acc]
             lines.append("v_mad_u64_u32 %%[%s], %%[sd], %%[a%d], %s, 0" % (acc, i, bj))
+            touched[acc] = True
         elif ins[0] == "mad":
-            _, acc, i, j, s = ins
+            _, acc, i, j, sr = ins
             bj = ("%%[a%d]" % j) if square else ("%%[b%d]" % j)
-            lines.append("v_mad_u64_u32 %%[%s], %%[s%d], %%[a%d], %s, %%[%s]" % (acc, s, i, bj, acc))
+            src = ("%%[%s]" % acc) if touched[acc] else ("%%[%si]" % acc)
+            assert touched[acc] or has_in[acc]
+            lines.append("v_mad_u64_u32 %%[%s], %%[s%d], %%[a%d], %s, %s" % (acc, sr, i, bj, src))
+            touched[acc] = True
         else:
-            _, acc, s = ins
-            lines.append("v_addc_co_u32_e64 %%[%s2], %%[sd], 0, %%[%s2], %%[s%d]" % (acc, acc, s))
-    # if B receives no product its zero-initialised inputs pass through untouched
+            _, acc, sr = ins
+            e = acc + "2"
+            if touched[e]:
+                src = "%%[%s]" % e
+            elif has_in[e]:
+                src = "%%[%si]" % e
+            else:
+                src = "0"
+            lines.append("v_addc_co_u32_e64 %%[%s], %%[sd], 0, %s, %%[s%d]" % (e, src, sr))
+            touched[e] = True
+    # accumulators this statement never touched still have to be produced
+    pre = []
+    for acc in ("A", "B"):
+        if not touched[acc]:
+            pre.append("v_mov_b64 %%[%s], %s" % (acc, ("%%[%si]" % acc) if has_in[acc] else "0"))
+            touched[acc] = True
+    for e in ("A2", "B2"):
+        if not touched[e]:
+            pre.append("v_mov_b32 %%[%s], %s" % (e, ("%%[%si]" % e) if has_in[e] else "0"))
+            touched[e] = True
+    lines = lines + pre          # moves go last: they only copy inputs / constants
     body = "\\n\\t".join(lines)
-    outs = ['[A] "+v"(A)', '[A2] "+v"(A2)', '[B] "+v"(B)', '[B2] "+v"(B2)']
+    outs = ['[A] "=&v"(Ao)', '[A2] "=&v"(A2o)', '[B] "=&v"(Bo)', '[B2] "=&v"(B2o)']
     outs += ['[s%d] "=&s"(s%d)' % (k, k) for k in range(NSREG)] + ['[sd] "=&s"(sd)']
-    ins_ = ['[a%d] "v"(a%d)' % (i, i) for i in used_a] + ['[b%d] "v"(b%d)' % (j, j) for j in used_b]
+    ins_ = []
+    if a_in:
+        ins_.append('[Ai] "v"(A)')
+    if a2_in:
+        ins_.append('[A2i] "v"(A2)')
+    if b_in:
+        ins_.append('[Bi] "v"(B)')
+    if b2_in:
+        ins_.append('[B2i] "v"(B2)')
+    ins_ += ['[a%d] "v"(a%d)' % (i, i) for i in used_a] + ['[b%d] "v"(b%d)' % (j, j) for j in used_b]
     code = "ELL_DEVASM void %s(%s) {\n" % (name, ", ".join(args))
-    code += "  u64 %s, sd;\n" % ", ".join("s%d" % k for k in range(NSREG))
-    code += '  asm("%s"\n      : %s\n      : %s\n      : );\n' % (body, ", ".join(outs), ", ".join(ins_) if ins_ else "")
+    code += "  u64 %s, sd, Ao, Bo;\n  u32 A2o, B2o;\n" % ", ".join("s%d" % k for k in range(NSREG))
+    code += '  asm("%s"\n      : %s\n      : %s\n      : );\n' % (body, ", ".join(outs), ", ".join(ins_))
+    code += "  A = Ao; A2 = A2o; B = Bo; B2 = B2o;\n"
     code += "  (void)sd;" + "".join(" (void)s%d;" % k for k in range(NSREG)) + "\n}\n\n"
     nmad = sum(1 for x in seq if x[0] in ("mad", "mad0"))
     nadd = sum(1 for x in seq if x[0] == "addc")
@@ -132,7 +181,7 @@ def emit_chunked(base, pa, pb, a_cin, square=False):
         if not ca and not cb:
             continue
         name = "%s_%d" % (base, c // CHUNK)
-        cd, ua, ub, st = emit_block(name, ca, cb, a_in, square, b_in)
+        cd, ua, ub, st = emit_block(name, ca, cb, a_cin if c == 0 else True, square, False, cont=(c > 0))
         code += cd
         calls.append((name, ua, ub))
         for t in range(3):
