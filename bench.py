@@ -105,6 +105,29 @@ def cpu_baseline(h, r, s, pub, ok, budget_s=15.0):
             "sample": "first %d tuples of the rank-0 batch, oracle/ec_oracle.py (python ints), 1 thread" % done}
 
 
+def traffic_from_profiles():
+    """HBM bytes per ecdsa_main launch from the newest committed rocprofv3 PMC summary
+    (profiles/*pmc_fetch_write*.txt; FETCH_SIZE / WRITE_SIZE are reported in KiB and were
+    collected in separate --pmc passes).  The gfx950 x2 correction of FETCH_SIZE applies to
+    wide coalesced streams; this kernel's fetches are 16-byte-per-lane table gathers, for which
+    the factor is uncalibrated, so both figures are returned."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_write*.txt")))
+    if not files:
+        return None
+    txt = open(files[-1]).read()
+    f = re.search(r"FnEcdsaMain<CvSecp256k1>>\s+FETCH_SIZE\s+\d+\s+n=\d+\s+per_dispatch=(\d+)", txt)
+    w = re.search(r"FnEcdsaMain<CvSecp256k1>>\s+WRITE_SIZE\s+\d+\s+n=\d+\s+per_dispatch=(\d+)", txt)
+    if not f or not w:
+        return None
+    fetch, write = int(f.group(1)) * 1024, int(w.group(1)) * 1024
+    return {"bytes_per_launch": fetch + write, "bytes_per_launch_fetch_x2": 2 * fetch + write,
+            "fetch_bytes": fetch, "write_bytes": write, "source": os.path.relpath(files[-1], ROOT),
+            "note": "per 2^20-tuple launch; dominated by the per-lane window tables (1 KiB written, "
+                    "~4.2 KiB gathered per verify), see DESIGN.md section 3"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +135,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1 << 20, help="tuples per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (self-test of the N>1 flow)")
+    ap.add_argument("--force-device", type=int, default=None,
+                    help="self-test only: every rank uses this device (lets the N>1 flow run on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,12 +148,17 @@ def main():
                          "--nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    if args.force_device is not None:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     import elliptic_amd
     ctx = elliptic_amd.Context(local_rank)
@@ -142,7 +173,11 @@ def main():
     def step():
         ctx.ecdsa_verify_dev("secp256k1", dh, dr, dsg, dq, dok)
         if world > 1:
-            dist.all_gather(gathered, dok)          # the final gather, RCCL over xGMI
+            if args.dist_backend == "nccl":
+                dist.all_gather(gathered, dok)      # the final gather, RCCL over xGMI
+            else:                                   # gloo self-test: host tensors
+                hg = [torch.zeros(n, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(hg, dok.cpu())
 
     for _ in range(args.warmup):
         step()
@@ -167,7 +202,7 @@ def main():
     timing = ctx.get_timing()
     ctx.set_timing(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -210,7 +245,7 @@ def main():
                 "alg_macs_per_unit": MACS_PER_VERIFY,
                 "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach_gbs / HBM_PEAK_GBS, "alg_bytes_per_unit": BYTES_PER_VERIFY},
-                "traffic": None,
+                "traffic": traffic_from_profiles() if n == 1 << 20 else None,
             },
         }
         if world == 1 and not args.no_cpu:

@@ -14,6 +14,10 @@
 #include "curve_consts.h"
 #include "ladder.h"
 
+#ifndef ELL_COMB_BITS_256
+#define ELL_COMB_BITS_256 16
+#endif
+
 namespace ell {
 
 struct EdWork {
@@ -24,8 +28,10 @@ struct EdWork {
   static constexpr int BYTES = 32;
   static constexpr int NNIB = 64;
   static constexpr int NWIN = 65;              // 64 signed windows + the carry window
-  static constexpr int COMB_W = 32;
-  static constexpr int COMB_ENTRIES = 32 * 255;
+  static constexpr int COMB_BITS = ELL_COMB_BITS_256;   // 16-bit comb windows: 16 adds per k*G
+  static constexpr int COMB_W = 256 / COMB_BITS;
+  static constexpr int COMB_DIG = (1 << COMB_BITS) - 1;
+  static constexpr size_t COMB_ENTRIES = (size_t)COMB_W * COMB_DIG;
 
   // Extended point (X, Y, Z, T) -- or, for table entries, the "cached" form
   // (Y+X, Y-X, 2Z, 2dT) stored in the same four slots.
@@ -168,12 +174,12 @@ struct EdWork {
     P acc = identity();
     ELL_NOUNROLL
     for (int w = 0; w < COMB_W; w++) {
-      u32 d = kk[0] & 255u;
+      u32 d = kk[0] & (u32)COMB_DIG;
       ELL_UNROLL
-      for (int i = 0; i < 7; i++) kk[i] = (kk[i] >> 8) | (kk[i + 1] << 24);
-      kk[7] >>= 8;
+      for (int i = 0; i < 7; i++) kk[i] = (kk[i] >> COMB_BITS) | (kk[i + 1] << (32 - COMB_BITS));
+      kk[7] >>= COMB_BITS;
       u32 e = d ? d - 1 : 0;
-      acc = add(acc, comb[w * 255 + e], d != 0);
+      acc = add(acc, comb[(size_t)w * COMB_DIG + e], d != 0);
     }
     return acc;
   }

@@ -523,9 +523,12 @@ int Engine<BK>::ensure_comb() {
     store_be<W::L>(g + B, gy, B);
   }
   for (int w = 0; w < W::COMB_W; w++)
-    for (int d = 1; d <= 255; d++) {
-      size_t i = (size_t)w * 255 + (d - 1);
-      ks[i * B + (B - 1 - w)] = (u8)d;                 // d << (8w), big-endian
+    for (int d = 1; d <= W::COMB_DIG; d++) {
+      size_t i = (size_t)w * W::COMB_DIG + (d - 1);
+      // d << (COMB_BITS*w), big-endian (COMB_BITS is 8 or 16: whole bytes)
+      int byte0 = w * (W::COMB_BITS / 8);
+      for (int bb = 0; bb < W::COMB_BITS / 8; bb++)
+        if (byte0 + bb < B) ks[i * B + (B - 1 - (byte0 + bb))] = (u8)(d >> (8 * bb));
       memcpy(&pts[i * 2 * B], g, 2 * B);
     }
   void* comb = bk.alloc(n * sizeof(typename W::A));
@@ -644,9 +647,10 @@ int Engine<BK>::ensure_ed_comb() {
     store_be<8>(g + 32, gy, 32);
   }
   for (int w = 0; w < EdWork::COMB_W; w++)
-    for (int d = 1; d <= 255; d++) {
-      size_t i = (size_t)w * 255 + (d - 1);
-      ks[i * 32 + (31 - w)] = (u8)d;
+    for (int d = 1; d <= EdWork::COMB_DIG; d++) {
+      size_t i = (size_t)w * EdWork::COMB_DIG + (d - 1);
+      int byte0 = w * (EdWork::COMB_BITS / 8);
+      for (int bb = 0; bb < EdWork::COMB_BITS / 8; bb++) ks[i * 32 + (31 - (byte0 + bb))] = (u8)(d >> (8 * bb));
       memcpy(&pts[i * 64], g, 64);
     }
   void* comb = bk.alloc(n * sizeof(EdWork::P));

@@ -206,21 +206,22 @@ struct Ladder {
     return acc;
   }
 
-  // fixed-base comb: sum_w d_w * 2^(8w) * G with d_w the w-th byte of k;
-  // comb[w*255 + d-1] = d * 2^(8w) * G (affine, field-internal form).
-  template <int LK, int W>
+  // fixed-base comb: sum_w d_w * 2^(CB*w) * G with d_w the w-th CB-bit digit of k (CB = 8
+  // or 16); comb[w*(2^CB - 1) + d-1] = d * 2^(CB*w) * G (affine, field-internal form).
+  template <int LK, int W, int CB>
   ELL_HD static J comb_mul(const u32 (&k)[LK], const A* comb) {
+    constexpr u32 MASK = (1u << CB) - 1u;
     u32 kk[LK];
     bn_copy<LK>(kk, k);
     J acc = G::infinity();
     ELL_NOUNROLL
     for (int w = 0; w < W; w++) {
-      u32 d = kk[0] & 255u;
+      u32 d = kk[0] & MASK;
       ELL_UNROLL
-      for (int i = 0; i < LK - 1; i++) kk[i] = (kk[i] >> 8) | (kk[i + 1] << 24);
-      kk[LK - 1] >>= 8;
+      for (int i = 0; i < LK - 1; i++) kk[i] = (kk[i] >> CB) | (kk[i + 1] << (32 - CB));
+      kk[LK - 1] >>= CB;
       u32 e = d ? d - 1 : 0;
-      A q = comb[w * 255 + e];
+      A q = comb[(size_t)w * MASK + e];
       acc = G::add_mixed(acc, q, d != 0);
     }
     return acc;

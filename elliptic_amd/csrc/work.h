@@ -16,6 +16,12 @@
 
 #include "ladder.h"
 
+// comb window width for the 256-bit curves (the CPU unit-test build of these headers
+// overrides it with 8 so that it does not have to generate 2^20-entry tables on the host)
+#ifndef ELL_COMB_BITS_256
+#define ELL_COMB_BITS_256 16
+#endif
+
 namespace ell {
 
 template <class CV>
@@ -44,8 +50,13 @@ struct Work {
   // element type of the variable-base window table: affine on the effective-affine curve
   // for secp256k1 (ladder.h build_table_odd8), Jacobian otherwise
   typedef typename std::conditional<ENDO, A, J>::type VT;
-  static constexpr int COMB_W = BYTES;                     // 8-bit comb windows
-  static constexpr int COMB_ENTRIES = COMB_W * 255;
+  // fixed-base comb: COMB_BITS-bit unsigned windows, table of d * 2^(COMB_BITS*w) * G.
+  // 16-bit windows for the 256-bit curves (16 adds per k*G, 67 MB table that lives in
+  // MALL/HBM and is gathered 64 B at a time); 8-bit windows otherwise.
+  static constexpr int COMB_BITS = (L == 8) ? ELL_COMB_BITS_256 : 8;
+  static constexpr int COMB_W = (8 * BYTES + COMB_BITS - 1) / COMB_BITS;
+  static constexpr int COMB_DIG = (1 << COMB_BITS) - 1;    // non-zero digits per window
+  static constexpr size_t COMB_ENTRIES = (size_t)COMB_W * COMB_DIG;
 
   // ---- I/O helpers -------------------------------------------------------
   ELL_HD static El load_fe(const u8* p) {
@@ -182,7 +193,7 @@ struct Work {
   ELL_HD static J mul_add_g(const u32 (&k1)[L], const u32 (&k2)[L], const A& p2, const A* comb,
                             VT* tbl, const DigitStore& ds) {
     J b = var_ladder(k2, p2, tbl, ds);
-    J a = LD::template comb_mul<L, COMB_W>(k1, comb);
+    J a = LD::template comb_mul<L, COMB_W, COMB_BITS>(k1, comb);
     return G::add(a, b);
   }
   ELL_HD static void mul_add_g_item(size_t i, size_t n, const u8* k1s, const u8* k2s,
@@ -201,7 +212,7 @@ struct Work {
   ELL_HD static void mul_fixed(size_t i, size_t n, const u8* ks, const A* comb, u32* jac) {
     u32 k[L];
     load_be<L>(k, ks + i * BYTES, BYTES);
-    J r = LD::template comb_mul<L, COMB_W>(k, comb);
+    J r = LD::template comb_mul<L, COMB_W, COMB_BITS>(k, comb);
     store_jac(jac, n, i, r);
   }
 

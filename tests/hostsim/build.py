@@ -27,7 +27,7 @@ def build(force=False):
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing", "-pthread",
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing", "-pthread", "-DELL_COMB_BITS_256=8",
            "-o", LIB, os.path.join(HERE, "hostsim.cpp")]
     subprocess.run(cmd, check=True)
     with open(stamp, "w") as f:
