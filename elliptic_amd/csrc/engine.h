@@ -20,6 +20,10 @@
 #include "mont.h"
 #include "work.h"
 
+#ifndef ELL_ECDSA_MIN_WAVES
+#define ELL_ECDSA_MIN_WAVES 3
+#endif
+
 namespace ell {
 
 enum { E_OK = 0, E_NODEVICE = -1, E_ARG = -2, E_HIP = -3, E_NOMEM = -4, E_UNSUPPORTED = -5 };
@@ -92,7 +96,7 @@ template <class CV>
 struct FnEcdsaMain {
   static constexpr const char* NAME = "ecdsa_main";
   typedef Work<CV> W;
-  static constexpr int MIN_WAVES = W::L <= 8 ? 3 : 1;      // <= 168 VGPRs for 256-bit curves
+  static constexpr int MIN_WAVES = W::L <= 8 ? ELL_ECDSA_MIN_WAVES : 1;      // <= 168 VGPRs for 256-bit curves
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
   size_t n; const u32* u12; const u8* valid; const u8* r; const u8* pub;
   const typename W::A* comb; typename W::VT* tbl; u8* ok;
