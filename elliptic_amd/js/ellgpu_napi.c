@@ -18,6 +18,12 @@
  *           mulAdd2(ctx, curve, k1, p1|null, k2, p2) -> {xy, inf}
  *           ecdsaVerify(ctx, curve, hash, hashLen, msgBits, r, s, pub) -> Buffer(ok)
  *           x25519(ctx, k, x) -> {x, inf}
+ *           callAsync(op, ctx, curve, hashLen, msgBits, b0, b1, b2, b3) -> Promise
+ *             op 0 mulFixed(b0=k) 1 mulVar(k, xy) 2 mulAdd2(k1, p1|null, k2, p2)
+ *             3 ecdsaVerify(hash, r, s, pub) 4 x25519(k, x); runs on a libuv worker
+ *             thread (napi_async_work) so the JS thread is not blocked; resolves to the
+ *             same value the synchronous form returns.  One call per context at a time:
+ *             index.js serialises them.
  * Errors from the library are thrown as plain `Error(message)`, the
  * reference's convention (minimalistic-assert, dist/elliptic.js:8832-8835).
  */
@@ -205,12 +211,119 @@ static napi_value fn_x25519(napi_env env, napi_callback_info info) {
   return mk_result(env, "x", bx, "inf", binf);
 }
 
+/* ---- asynchronous form: napi_async_work + Promise ---------------------------------- */
+typedef struct {
+  napi_async_work work;
+  napi_deferred deferred;
+  napi_ref refs[4];
+  int nrefs;
+  int op, curve, hash_len, msg_bits, B, NB;
+  ellgpu_ctx* ctx;
+  const uint8_t* in[4];
+  size_t n;
+  uint8_t* out0; size_t out0_len;      /* xy / ok / x */
+  uint8_t* out1; size_t out1_len;      /* inf */
+  int rc;
+  char err[512];
+} async_job;
+
+static void job_execute(napi_env env, void* data) {
+  (void)env;
+  async_job* j = (async_job*)data;
+  switch (j->op) {
+    case 0: j->rc = L.mul_fixed(j->ctx, j->curve, j->n, j->in[0], j->out0, j->out1); break;
+    case 1: j->rc = L.mul_var(j->ctx, j->curve, j->n, j->in[0], j->in[1], j->out0, j->out1); break;
+    case 2: j->rc = L.mul_add2(j->ctx, j->curve, j->n, j->in[0], j->in[1], j->in[2], j->in[3], j->out0, j->out1); break;
+    case 3: j->rc = L.ecdsa_verify(j->ctx, j->curve, j->n, j->in[0], j->hash_len, j->msg_bits, j->in[1], j->in[2], j->in[3], j->out0); break;
+    default: j->rc = L.x25519(j->ctx, j->n, j->in[0], j->in[1], j->out0, j->out1); break;
+  }
+  if (j->rc != 0) {               /* last_error is thread-local: read it on this thread */
+    const char* m = L.last_error();
+    snprintf(j->err, sizeof j->err, "%s", m && *m ? m : "ellgpu error");
+  }
+}
+static void free_cb(napi_env env, void* data, void* hint) { (void)env; (void)hint; free(data); }
+static void job_complete(napi_env env, napi_status status, void* data) {
+  async_job* j = (async_job*)data;
+  napi_value result = NULL;
+  if (status == napi_ok && j->rc == 0) {
+    napi_value b0, b1;
+    napi_create_external_buffer(env, j->out0_len, j->out0, free_cb, NULL, &b0);
+    j->out0 = NULL;
+    if (j->op == 3) result = b0;
+    else {
+      napi_create_external_buffer(env, j->out1_len, j->out1, free_cb, NULL, &b1);
+      j->out1 = NULL;
+      napi_create_object(env, &result);
+      napi_set_named_property(env, result, j->op == 4 ? "x" : "xy", b0);
+      napi_set_named_property(env, result, "inf", b1);
+    }
+    napi_resolve_deferred(env, j->deferred, result);
+  } else {
+    napi_value msg, errv;
+    napi_create_string_utf8(env, j->rc ? j->err : "ellgpu: async work cancelled", NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &errv);
+    napi_reject_deferred(env, j->deferred, errv);
+  }
+  for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
+  napi_delete_async_work(env, j->work);
+  free(j->out0); free(j->out1); free(j);
+}
+static napi_value fn_call_async(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 9; napi_value argv[9];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 9) THROW(env, "callAsync(op, ctx, curve, hashLen, msgBits, b0, b1, b2, b3)");
+  async_job* j = (async_job*)calloc(1, sizeof *j);
+  int32_t op, curve, hl, mb;
+  napi_get_value_int32(env, argv[0], &op);
+  j->ctx = get_ctx(env, argv[1]);
+  if (!j->ctx) { free(j); return NULL; }
+  napi_get_value_int32(env, argv[2], &curve); napi_get_value_int32(env, argv[3], &hl); napi_get_value_int32(env, argv[4], &mb);
+  j->op = op; j->curve = op == 4 ? 7 : curve; j->hash_len = hl; j->msg_bits = mb;
+  j->B = L.field_bytes(j->curve); j->NB = L.order_bytes(j->curve);
+  if (op < 0 || op > 4 || j->B <= 0) { free(j); THROW(env, "callAsync: bad op / curve"); }
+  size_t len[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    if (!get_buf(env, argv[5 + i], &j->in[i], &len[i], 1)) { free(j); return NULL; }
+    if (j->in[i]) napi_create_reference(env, argv[5 + i], 1, &j->refs[j->nrefs++]);   /* keep alive */
+  }
+  size_t B = (size_t)j->B, NB = (size_t)j->NB;
+  int ok = 1;
+  switch (op) {
+    case 0: j->n = len[0] / B; ok = j->in[0] && len[0] % B == 0; break;
+    case 1: j->n = len[0] / B; ok = j->in[0] && j->in[1] && len[0] % B == 0 && len[1] == j->n * 2 * B; break;
+    case 2: j->n = len[0] / B; ok = j->in[0] && j->in[2] && j->in[3] && len[0] % B == 0 && len[2] == len[0] &&
+                                     len[3] == j->n * 2 * B && (!j->in[1] || len[1] == j->n * 2 * B); break;
+    case 3: ok = hl > 0 && j->in[0] && j->in[1] && j->in[2] && j->in[3] && len[0] % (size_t)hl == 0;
+            j->n = ok ? len[0] / (size_t)hl : 0;
+            ok = ok && len[1] == j->n * NB && len[2] == j->n * NB && len[3] == j->n * 2 * B; break;
+    default: j->n = len[0] / 32; ok = j->in[0] && j->in[1] && len[0] % 32 == 0 && len[1] == len[0]; break;
+  }
+  if (!ok) {
+    for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
+    free(j);
+    THROW(env, "callAsync: buffer length mismatch");
+  }
+  j->out0_len = op == 3 ? j->n : op == 4 ? j->n * 32 : j->n * 2 * B;
+  j->out1_len = op == 3 ? 0 : j->n;
+  j->out0 = (uint8_t*)malloc(j->out0_len ? j->out0_len : 1);
+  j->out1 = (uint8_t*)malloc(j->out1_len ? j->out1_len : 1);
+  napi_value promise, name;
+  CHECK(env, napi_create_promise(env, &j->deferred, &promise));
+  CHECK(env, napi_create_string_utf8(env, "ellgpu", NAPI_AUTO_LENGTH, &name));
+  CHECK(env, napi_create_async_work(env, NULL, name, job_execute, job_complete, j, &j->work));
+  CHECK(env, napi_queue_async_work(env, j->work));
+  return promise;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
     {"open", fn_open}, {"createContext", fn_create}, {"destroyContext", fn_destroy},
     {"curveId", fn_curve_id}, {"fieldBytes", fn_field_bytes}, {"orderBytes", fn_order_bytes},
     {"deviceCount", fn_device_count}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
     {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519},
+    {"callAsync", fn_call_async},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

@@ -75,6 +75,34 @@ Engine.prototype.x25519Batch = function x25519Batch(scalars, xs) {
   return this.addon.x25519(this.ctx, scalars, xs);
 };
 
+// ---- asynchronous batch API: same arguments, returns a Promise; the work runs on a
+// libuv worker thread (napi_async_work), so the JS thread stays responsive during a large
+// batch.  A context processes one call at a time, so calls are chained.
+Engine.prototype._async = function _async(op, curve, hashLen, msgBits, b0, b1, b2, b3) {
+  var self = this;
+  var id = op === 4 ? 7 : this._id(curve);
+  var run = function() {
+    self.stats.gpuCalls++;
+    return self.addon.callAsync(op, self.ctx, id, hashLen | 0, msgBits | 0, b0 || null,
+      b1 || null, b2 || null, b3 || null);
+  };
+  var p = (this._tail || Promise.resolve()).then(run, run);
+  this._tail = p.catch(function() {});
+  return p;
+};
+Engine.prototype.mulBatchAsync = function(curve, scalars, points) {
+  return points ? this._async(1, curve, 0, 0, scalars, points) : this._async(0, curve, 0, 0, scalars);
+};
+Engine.prototype.mulAddBatchAsync = function(curve, k1, points1, k2, points2) {
+  return this._async(2, curve, 0, 0, k1, points1 || null, k2, points2);
+};
+Engine.prototype.ecdsaVerifyBatchAsync = function(curve, o) {
+  return this._async(3, curve, o.hashLen, o.msgBits | 0, o.hashes, o.r, o.s, o.pub);
+};
+Engine.prototype.x25519BatchAsync = function(scalars, xs) {
+  return this._async(4, 7, 0, 0, scalars, xs);
+};
+
 // ---- install(): prototype patch on a user-supplied elliptic instance ----------
 function install(elliptic, options) {
   var eng = new Engine(options);

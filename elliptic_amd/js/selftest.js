@@ -71,4 +71,33 @@ lc.forEach(function(c, i) {
     throw new Error('x25519 mismatch at ' + i);
   checked++;
 });
-console.log(JSON.stringify({ ok: true, checked: checked, engine: eng.stats }));
+// asynchronous forms must give byte-identical results, also when queued back to back
+(function() {
+  var B = 32;
+  var cases = JSON.parse(fs.readFileSync(path.join(GOLD, 'mul_secp256k1.json')));
+  var fixed = cases.filter(function(c) { return c.op === 'fixed'; });
+  var vr = cases.filter(function(c) { return c.op === 'var'; });
+  var kf = hexBuf(fixed.map(function(c) { return c.k; }), B);
+  var kv = hexBuf(vr.map(function(c) { return c.k; }), B);
+  var pv = Buffer.concat(vr.map(function(c) { return hexBuf([c.px, c.py], B); }));
+  var vs = JSON.parse(fs.readFileSync(path.join(GOLD, 'verify_secp256k1.json')))
+    .filter(function(c) { return c.z.length === 64; });
+  var vo = { hashes: hexBuf(vs.map(function(c) { return c.z; }), 32), hashLen: 32, msgBits: 0,
+    r: hexBuf(vs.map(function(c) { return c.r; }), B), s: hexBuf(vs.map(function(c) { return c.s; }), B),
+    pub: Buffer.concat(vs.map(function(c) { return hexBuf([c.qx, c.qy], B); })) };
+  var s1 = eng.mulBatch('secp256k1', kf, null);
+  var s2 = eng.mulBatch('secp256k1', kv, pv);
+  var s3 = eng.ecdsaVerifyBatch('secp256k1', vo);
+  Promise.all([eng.mulBatchAsync('secp256k1', kf, null), eng.mulBatchAsync('secp256k1', kv, pv),
+    eng.ecdsaVerifyBatchAsync('secp256k1', vo),
+    eng.mulBatchAsync('secp256k1', Buffer.alloc(31), null).then(function() { return 'no error'; },
+      function(e) { return 'rejected: ' + e.message; })])
+    .then(function(r) {
+      if (!r[0].xy.equals(s1.xy) || !r[0].inf.equals(s1.inf)) throw new Error('async mulFixed differs');
+      if (!r[1].xy.equals(s2.xy) || !r[1].inf.equals(s2.inf)) throw new Error('async mulVar differs');
+      if (!r[2].equals(s3)) throw new Error('async verify differs');
+      if (r[3].indexOf('rejected') !== 0) throw new Error('bad-length async call was not rejected');
+      checked += fixed.length + vr.length + vs.length;
+      console.log(JSON.stringify({ ok: true, checked: checked, async: true, engine: eng.stats }));
+    }).catch(function(e) { console.error(e); process.exit(1); });
+})();
