@@ -111,6 +111,17 @@ int ellgpu_x25519_ladder(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint
   return finish(ctx, ctx->eng->x25519_host(n, k, in_x, out_x, out_inf));
 }
 
+int ellgpu_decompress(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, const uint8_t* odd,
+                      uint8_t* out_xy, uint8_t* out_ok) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->decompress_host(curve, n, v, odd, out_xy, out_ok));
+}
+int ellgpu_decompress_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, const uint8_t* odd,
+                          uint8_t* out_xy, uint8_t* out_ok, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->decompress_dev(curve, n, v, odd, out_xy, out_ok));
+}
+
 int ellgpu_mul_fixed_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, uint8_t* out_xy,
                          uint8_t* out_inf, void* stream) {
   ELL_ENTER(ctx, stream);

@@ -226,6 +226,31 @@ struct EdWork {
     store_ext(ext, n, i, run_w4<2>(ds, tbl));
   }
 
+  // EdwardsCurve#pointFromY (edwards.js:71-97, c = 1, a = -1): x^2 = (y^2 - 1)/(d y^2 + 1),
+  // x with the requested parity.  ok = 0 when there is no such point -- also for the
+  // reference's two throwing corner cases: x = 0 with odd requested, and d y^2 + 1 == 0.
+  ELL_HD static void decompress(size_t i, const u8* ys, const u8* odd, u8* out_xy, u8* out_ok) {
+    El y = load_fe(ys + i * 32);
+    El d;
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++) d.v[l] = C::d[l];
+    El y2 = F::sqr(y);
+    El u = F::sub(y2, F::one());
+    El v = F::add(F::mul(y2, d), F::one());
+    El x;
+    bool ok = F::sqrt_ratio(x, u, v);
+    bool want_odd = odd[i] != 0;
+    bool xzero = F::is_zero(x);
+    ok = ok && !F::is_zero(v) && !(xzero && want_odd);
+    bool is_odd = (x.v[0] & 1u) != 0;
+    El xn = F::neg(x);
+    bn_select<8>(x.v, is_odd != want_odd, xn.v, x.v);
+    if (!ok) { x = F::zero(); y = F::zero(); }
+    store_be<8>(out_xy + i * 64, x.v, 32);
+    store_be<8>(out_xy + i * 64 + 32, y.v, 32);
+    out_ok[i] = ok ? 1 : 0;
+  }
+
   // (X:Y:Z) -> affine (x, y) with one inversion per K items (normalize,
   // edwards.js:377-390).  out_inf mirrors Point#isInfinity (edwards.js:167-172):
   // x == 0 && y == 1.  raw != null stores cached(x, y, 1, xy) for the comb.

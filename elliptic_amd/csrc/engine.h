@@ -105,6 +105,25 @@ struct FnEcdsaMain {
   }
 };
 
+template <class CV>
+struct FnDecompress {
+  static constexpr const char* NAME = "decompress";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* x; const u8* odd; u8* out_xy; u8* out_ok;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if constexpr (CV::F::HAS_SQRT) { if (i < n) W::decompress(i, x, odd, out_xy, out_ok); }
+  }
+};
+struct FnEdDecompress {
+  static constexpr const char* NAME = "ed_decompress";
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* y; const u8* odd; u8* out_xy; u8* out_ok;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) EdWork::decompress(i, y, odd, out_xy, out_ok);
+  }
+};
+
 // Edwards / Montgomery functors
 struct FnEdMulVar {
   static constexpr const char* NAME = "ed_mul_var";
@@ -253,6 +272,10 @@ class Engine {
                         u8* out_xy, u8* out_inf);
   template <int U = 0>
   int x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf);
+  template <class CV>
+  int decompress_chunk(size_t n, const u8* x, const u8* odd, u8* out_xy, u8* out_ok);
+  template <int U = 0>
+  int ed_decompress_chunk(size_t n, const u8* y, const u8* odd, u8* out_xy, u8* out_ok);
 
   // ---- dispatch over curves (device pointers) --------------------------------
 #if defined(ELL_ONLY_CURVE)
@@ -390,6 +413,39 @@ class Engine {
       if (rc) return rc;
     }
     return E_OK;
+  }
+
+  // point decompression: short curves from x (pointFromX), ed25519 from y (pointFromY)
+  int decompress_dev(int curve, size_t n, const u8* v, const u8* odd, u8* out_xy, u8* out_ok) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (curve == CURVE_CURVE25519) return fail(E_UNSUPPORTED, "curve25519 points are x-only");
+    if (n && (!v || !odd || !out_xy || !out_ok)) return fail(E_ARG, "null pointer");
+    const size_t B = ci->field_bytes;
+    int rc = E_OK;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      if (curve == CURVE_ED25519) rc = ed_decompress_chunk(m, v + o * B, odd + o, out_xy + o * 2 * B, out_ok + o);
+      else ELL_SHORT_DISPATCH(curve, rc = decompress_chunk<CV>(m, v + o * B, odd + o, out_xy + o * 2 * B, out_ok + o));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+  int decompress_host(int curve, size_t n, const u8* v, const u8* odd, u8* out_xy, u8* out_ok) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (n && (!v || !odd || !out_xy || !out_ok)) return fail(E_ARG, "null pointer");
+    size_t B = ci->field_bytes;
+    u8* dv = put(G_IN0, v, n * B);
+    u8* dodd = put(G_IN1, odd, n);
+    u8* dxy = out_buf(G_OUT0, n * 2 * B);
+    u8* dok = out_buf(G_OUT1, n);
+    if (!dv || !dodd || !dxy || !dok) return fail(E_NOMEM, "staging allocation failed");
+    int rc = decompress_dev(curve, n, dv, dodd, dxy, dok);
+    if (rc) return rc;
+    bk.d2h(out_xy, dxy, n * 2 * B);
+    bk.d2h(out_ok, dok, n);
+    return bk.sync();
   }
 
   // ---- host-buffer wrappers: stage through device buffers --------------------
@@ -735,5 +791,24 @@ int Engine<BK>::x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* 
   return E_OK;
 }
 
+
+template <class BK>
+template <class CV>
+int Engine<BK>::decompress_chunk(size_t n, const u8* x, const u8* odd, u8* out_xy, u8* out_ok) {
+  if constexpr (!CV::F::HAS_SQRT) {
+    return fail(E_UNSUPPORTED, "point decompression needs p = 3 (mod 4) (not p224)");
+  } else {
+    FnDecompress<CV> f{n, x, odd, out_xy, out_ok};
+    bk.launch(f, n);
+    return E_OK;
+  }
+}
+template <class BK>
+template <int U>
+int Engine<BK>::ed_decompress_chunk(size_t n, const u8* y, const u8* odd, u8* out_xy, u8* out_ok) {
+  FnEdDecompress f{n, y, odd, out_xy, out_ok};
+  bk.launch(f, n);
+  return E_OK;
+}
 
 }  // namespace ell

@@ -27,6 +27,11 @@ namespace ell {
   KW template int Engine<HipBackend>::ecdsa_chunk<CV>(size_t, const u8*, int, int, const u8*,     \
                                                       const u8*, const u8*, u8*);
 
+#define ELL_DECL_G5(KW, CV) \
+  KW template int Engine<HipBackend>::decompress_chunk<CV>(size_t, const u8*, const u8*, u8*, u8*);
+#define ELL_DECL_ED2(KW) \
+  KW template int Engine<HipBackend>::ed_decompress_chunk<0>(size_t, const u8*, const u8*, u8*, u8*);
+
 #define ELL_DECL_ED0(KW)                                                                          \
   KW template int Engine<HipBackend>::ensure_ed_comb<0>();                                        \
   KW template int Engine<HipBackend>::ed_normalize_chunk<0>(size_t, const u32*, u8*, u8*,         \
@@ -42,10 +47,12 @@ namespace ell {
 
 // everything is extern by default ...
 #define ELL_EXT_ALL(CV) \
-  ELL_DECL_G0(extern, CV) ELL_DECL_G1(extern, CV) ELL_DECL_G2(extern, CV) ELL_DECL_G3(extern, CV) ELL_DECL_G4(extern, CV)
+  ELL_DECL_G0(extern, CV) ELL_DECL_G1(extern, CV) ELL_DECL_G2(extern, CV) ELL_DECL_G3(extern, CV) ELL_DECL_G4(extern, CV) \
+  ELL_DECL_G5(extern, CV)
 ELL_FOR_SHORT_CURVES(ELL_EXT_ALL)
 ELL_DECL_ED0(extern)
 ELL_DECL_ED1(extern)
 ELL_DECL_X(extern)
+ELL_DECL_ED2(extern)
 
 }  // namespace ell

@@ -233,6 +233,26 @@ struct FpK256 {
     t = mul(sqr_n(t, 2), a);
     return t;
   }
+  // a^((p+1)/4): a square root of a when a is a square (p = 3 mod 4).  The exponent is
+  // 223 ones, 0, 22 ones, 0000, 11, 00 in binary -- 253 S + 13 M.  (bn.js Red#sqrt,
+  // dist/elliptic.js:7180-7190, takes the same power.)
+  static constexpr bool HAS_SQRT = true;
+  static ELL_HD_NOINLINE El sqrt(const El& a) {
+    El x2 = mul(sqr(a), a);
+    El x3 = mul(sqr(x2), a);
+    El x6 = mul(sqr_n(x3, 3), x3);
+    El x9 = mul(sqr_n(x6, 3), x3);
+    El x11 = mul(sqr_n(x9, 2), x2);
+    El x22 = mul(sqr_n(x11, 11), x11);
+    El x44 = mul(sqr_n(x22, 22), x22);
+    El x88 = mul(sqr_n(x44, 44), x44);
+    El x176 = mul(sqr_n(x88, 88), x88);
+    El x220 = mul(sqr_n(x176, 44), x44);
+    El x223 = mul(sqr_n(x220, 3), x3);
+    El t = mul(sqr_n(x223, 23), x22);
+    t = mul(sqr_n(t, 6), x2);
+    return sqr_n(t, 2);
+  }
 };
 
 // --------------------------------------------------------------------------
@@ -342,6 +362,43 @@ struct Fp25519 {
     El z2_200_0 = mul(sqr_n(z2_100_0, 100), z2_100_0);
     El z2_250_0 = mul(sqr_n(z2_200_0, 50), z2_50_0);
     return mul(sqr_n(z2_250_0, 5), z11);
+  }
+  // z^((p-5)/8) = z^(2^252 - 3): the building block of the square root of a ratio
+  static ELL_HD_NOINLINE El pow22523(const El& z) {
+    El z2 = sqr(z);
+    El z9 = mul(sqr_n(z2, 2), z);
+    El z11 = mul(z9, z2);
+    El z2_5_0 = mul(sqr(z11), z9);
+    El z2_10_0 = mul(sqr_n(z2_5_0, 5), z2_5_0);
+    El z2_20_0 = mul(sqr_n(z2_10_0, 10), z2_10_0);
+    El z2_40_0 = mul(sqr_n(z2_20_0, 20), z2_20_0);
+    El z2_50_0 = mul(sqr_n(z2_40_0, 10), z2_10_0);
+    El z2_100_0 = mul(sqr_n(z2_50_0, 50), z2_50_0);
+    El z2_200_0 = mul(sqr_n(z2_100_0, 100), z2_100_0);
+    El z2_250_0 = mul(sqr_n(z2_200_0, 50), z2_50_0);
+    return mul(sqr_n(z2_250_0, 2), z);
+  }
+  // sqrt(-1) = 2^((p-1)/4)
+  ELL_HD static El sqrt_m1() {
+    El r;
+    const u32 c[8] = {0x4A0EA0B0u, 0xC4EE1B27u, 0xAD2FE478u, 0x2F431806u,
+                      0x3DFBD7A7u, 0x2B4D0099u, 0x4FC1DF0Bu, 0x2B832480u};
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) r.v[i] = c[i];
+    return r;
+  }
+  // x with v*x^2 == u, if one exists (p = 5 mod 8): candidate u v^3 (u v^7)^((p-5)/8),
+  // multiplied by sqrt(-1) when v x^2 == -u.  Returns false when u/v is not a square.
+  ELL_HD static bool sqrt_ratio(El& x, const El& u, const El& v) {
+    El v3 = mul(sqr(v), v);
+    El v7 = mul(sqr(v3), v);
+    El r = mul(mul(u, v3), pow22523(mul(u, v7)));
+    El chk = mul(v, sqr(r));
+    bool ok1 = eq(chk, u);
+    bool ok2 = eq(chk, neg(u));
+    El r2 = mul(r, sqrt_m1());
+    bn_select<8>(x.v, ok1, r.v, r2.v);
+    return ok1 || ok2;
   }
 };
 
@@ -516,6 +573,18 @@ struct FpMont {
     ELL_NOUNROLL
     for (int i = 0; i < n; i++) a = sqr(a);
     return a;
+  }
+  // a^((p+1)/4): square root for p = 3 (mod 4) (bn.js Red#sqrt takes the same power)
+  static constexpr bool HAS_SQRT = P::P3MOD4;
+  static ELL_HD_NOINLINE El sqrt(const El& a) {
+    El r = one();
+    ELL_NOUNROLL
+    for (int w = 32 * L - 1; w >= 0; w--) {
+      r = sqr(r);
+      u32 bit = (P::pp1d4[w >> 5] >> (w & 31)) & 1u;
+      if (bit) r = mul(r, a);
+    }
+    return r;
   }
   // a^(p-2), left-to-right binary over the constant exponent.  The exponent
   // bit is wave-uniform, so the multiply is a scalar branch, not divergence.

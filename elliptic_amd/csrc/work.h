@@ -216,6 +216,36 @@ struct Work {
     store_jac(jac, n, i, r);
   }
 
+  // ---- point decompression (ShortCurve#pointFromX, short.js:187-204) --------------
+  // y = sqrt(x^3 + a x + b) with the requested parity; ok = 0 ('invalid point') when x is
+  // not the abscissa of a curve point.  One exponentiation per item.
+  ELL_HD static void decompress(size_t i, const u8* xs, const u8* odd, u8* out_xy, u8* out_ok) {
+    El x = load_fe(xs + i * BYTES);
+    u32 bp[L];
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) bp[l] = C::b_plain[l];
+    El b = F::from_plain(bp);
+    El x2 = F::sqr(x);
+    El rhs;
+    if (CV::A_KIND == 0) rhs = F::add(F::mul(x2, x), b);
+    else {
+      El three = F::add(F::one(), F::dbl(F::one()));
+      rhs = F::add(F::mul(F::sub(x2, three), x), b);          // x^3 - 3x + b
+    }
+    El y = F::sqrt(rhs);
+    bool ok = F::eq(F::sqr(y), rhs);
+    u32 yp[L];
+    F::to_plain(yp, y);
+    bool want_odd = odd[i] != 0;
+    bool is_odd = (yp[0] & 1u) != 0;
+    El yn = F::neg(y);
+    y = fe_select<F>(is_odd != want_odd, yn, y);
+    if (!ok) { x = F::zero(); y = F::zero(); }
+    store_fe(out_xy + i * 2 * BYTES, x);
+    store_fe(out_xy + i * 2 * BYTES + BYTES, y);
+    out_ok[i] = ok ? 1 : 0;
+  }
+
   // ---- Jacobian -> affine with Montgomery's trick ------------------------------
   // Thread t converts items t, t+T, t+2T, ... (< n), K of them, with ONE field
   // inversion (replaces the per-point redInvm of JPoint#toP, short.js:516-526).

@@ -137,6 +137,24 @@ class Context:
                                                   s.ctypes.data, pub.ctypes.data, ok.ctypes.data))
         return ok
 
+    def decompress(self, curve, v, odd):
+        """pointFromX (short curves, v = x) / pointFromY (ed25519, v = y) -> (xy, ok)"""
+        B = FIELD_BYTES[curve]
+        v = _u8(v, (-1, B))
+        n = v.shape[0]
+        odd = _u8(odd, (n,))
+        out = np.zeros((n, 2 * B), np.uint8)
+        ok = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_decompress(self._ctx, self._cid(curve), n, v.ctypes.data,
+                                                odd.ctypes.data, out.ctypes.data, ok.ctypes.data))
+        return out, ok
+
+    def decompress_dev(self, curve, v, odd, out_xy, out_ok):
+        n = v.shape[0]
+        self._check(self._lib.ellgpu_decompress_dev(self._ctx, self._cid(curve), n, v.data_ptr(),
+                                                    odd.data_ptr(), out_xy.data_ptr(),
+                                                    out_ok.data_ptr(), self._stream()))
+
     def x25519(self, k, x):
         k = _u8(k, (-1, 32))
         x = _u8(x, (-1, 32))

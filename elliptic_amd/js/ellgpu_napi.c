@@ -18,6 +18,7 @@
  *           mulAdd2(ctx, curve, k1, p1|null, k2, p2) -> {xy, inf}
  *           ecdsaVerify(ctx, curve, hash, hashLen, msgBits, r, s, pub) -> Buffer(ok)
  *           x25519(ctx, k, x) -> {x, inf}
+ *           decompress(ctx, curve, v, odd) -> {xy, ok}
  *           callAsync(op, ctx, curve, hashLen, msgBits, b0, b1, b2, b3) -> Promise
  *             op 0 mulFixed(b0=k) 1 mulVar(k, xy) 2 mulAdd2(k1, p1|null, k2, p2)
  *             3 ecdsaVerify(hash, r, s, pub) 4 x25519(k, x); runs on a libuv worker
@@ -51,6 +52,7 @@ static struct {
   int (*ecdsa_verify)(ellgpu_ctx*, int, size_t, const uint8_t*, int, int, const uint8_t*,
                       const uint8_t*, const uint8_t*, uint8_t*);
   int (*x25519)(ellgpu_ctx*, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
+  int (*decompress)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
 } L;
 
 #define THROW(env, msg) do { napi_throw_error((env), NULL, (msg)); return NULL; } while (0)
@@ -81,6 +83,7 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   SYM(device_count, "ellgpu_device_count"); SYM(ctx_create, "ellgpu_ctx_create");
   SYM(ctx_destroy, "ellgpu_ctx_destroy"); SYM(mul_fixed, "ellgpu_mul_fixed"); SYM(mul_var, "ellgpu_mul_var");
   SYM(mul_add2, "ellgpu_mul_add2"); SYM(ecdsa_verify, "ellgpu_ecdsa_verify"); SYM(x25519, "ellgpu_x25519_ladder");
+  SYM(decompress, "ellgpu_decompress");
   L.h = h;
   napi_value t; CHECK(env, napi_get_boolean(env, 1, &t));
   return t;
@@ -211,6 +214,24 @@ static napi_value fn_x25519(napi_env env, napi_callback_info info) {
   return mk_result(env, "x", bx, "inf", binf);
 }
 
+static napi_value fn_decompress(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 4; napi_value argv[4];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  int32_t curve; if (napi_get_value_int32(env, argv[1], &curve) != napi_ok) THROW(env, "curve id expected");
+  int B = L.field_bytes(curve); if (B <= 0) THROW(env, "unknown curve id");
+  const uint8_t *v, *odd; size_t lv, lo;
+  if (!get_buf(env, argv[2], &v, &lv, 0) || !get_buf(env, argv[3], &odd, &lo, 0)) return NULL;
+  if (lv % (size_t)B || lo != lv / (size_t)B) THROW(env, "buffer length mismatch");
+  size_t n = lo;
+  napi_value bxy, bok; void *dxy, *dok;
+  CHECK(env, napi_create_buffer(env, n * 2 * (size_t)B, &dxy, &bxy));
+  CHECK(env, napi_create_buffer(env, n, &dok, &bok));
+  if (L.decompress(c, curve, n, v, odd, (uint8_t*)dxy, (uint8_t*)dok) != 0) return lib_error(env);
+  return mk_result(env, "xy", bxy, "ok", bok);
+}
+
 /* ---- asynchronous form: napi_async_work + Promise ---------------------------------- */
 typedef struct {
   napi_async_work work;
@@ -323,7 +344,7 @@ static napi_value init(napi_env env, napi_value exports) {
     {"curveId", fn_curve_id}, {"fieldBytes", fn_field_bytes}, {"orderBytes", fn_order_bytes},
     {"deviceCount", fn_device_count}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
     {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519},
-    {"callAsync", fn_call_async},
+    {"callAsync", fn_call_async}, {"decompress", fn_decompress},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

@@ -75,6 +75,14 @@ Engine.prototype.x25519Batch = function x25519Batch(scalars, xs) {
   return this.addon.x25519(this.ctx, scalars, xs);
 };
 
+// pointFromX (short curves: values = x) / pointFromY (ed25519: values = y), parity per item
+// in `odd` (Buffer of 0/1) -> { xy: Buffer(n x 2B), ok: Buffer(n) }  (ok = 0: 'invalid point')
+Engine.prototype.decompressBatch = function decompressBatch(curve, values, odd) {
+  var id = this._id(curve);
+  this.stats.gpuCalls++; this.stats.gpuItems += odd.length;
+  return this.addon.decompress(this.ctx, id, values, odd);
+};
+
 // ---- asynchronous batch API: same arguments, returns a Promise; the work runs on a
 // libuv worker thread (napi_async_work), so the JS thread stays responsive during a large
 // batch.  A context processes one call at a time, so calls are chained.
@@ -222,6 +230,36 @@ function install(elliptic, options) {
     return orig.endoWnafMulAdd.apply(this, arguments);
   };
 
+  // point decompression: ShortCurve#pointFromX (short.js:187-204) and
+  // EdwardsCurve#pointFromY (edwards.js:71-97); same 'invalid point' error
+  orig.pointFromX = short.pointFromX;
+  short.pointFromX = function pointFromX(x, odd) {
+    var d = domain(this);
+    var xb = new BN(x, 16);
+    if (xb.red) xb = xb.fromRed();
+    if (!d || d.name === 'p224' || xb.isNeg() || xb.byteLength() > d.B) {
+      eng.stats.passthrough++;
+      return orig.pointFromX.apply(this, arguments);
+    }
+    var r = eng.decompressBatch(d.id, Buffer.from(xb.toArray('be', d.B)), Buffer.from([odd ? 1 : 0]));
+    if (!r.ok[0]) throw new Error('invalid point');
+    return this.point(new BN(r.xy.slice(0, d.B)), new BN(r.xy.slice(d.B, 2 * d.B)));
+  };
+  var edw = elliptic.curve.edwards.prototype;
+  orig.pointFromY = edw.pointFromY;
+  edw.pointFromY = function pointFromY(y, odd) {
+    var d = domain(this);
+    var yb = new BN(y, 16);
+    if (yb.red) yb = yb.fromRed();
+    if (!d || yb.isNeg() || yb.byteLength() > d.B) {
+      eng.stats.passthrough++;
+      return orig.pointFromY.apply(this, arguments);
+    }
+    var r = eng.decompressBatch(d.id, Buffer.from(yb.toArray('be', d.B)), Buffer.from([odd ? 1 : 0]));
+    if (!r.ok[0]) throw new Error('invalid point');
+    return this.point(new BN(r.xy.slice(0, d.B)), new BN(r.xy.slice(d.B, 2 * d.B)));
+  };
+
   // Montgomery x-only ladder (Point class is not exported: reach it as
   // eddsa/index.js:22 does, through an instance)
   var montProto = elliptic.curves.curve25519.curve.g.constructor.prototype;
@@ -242,6 +280,8 @@ function install(elliptic, options) {
     base._wnafMulAdd = orig.wnafMulAdd;
     short._endoWnafMulAdd = orig.endoWnafMulAdd;
     montProto.mul = orig.montMul;
+    short.pointFromX = orig.pointFromX;
+    edw.pointFromY = orig.pointFromY;
   };
 
   // EC#verify over many signatures with the reference's own decoding

@@ -63,6 +63,20 @@ function check(r, i, B, want, what) {
     });
   });
 });
+['secp256k1', 'p192', 'p256', 'p384', 'p521', 'ed25519'].forEach(function(name) {
+  var B = eng.addon.fieldBytes(eng.addon.curveId(name));
+  var cs = JSON.parse(fs.readFileSync(path.join(GOLD, 'decompress_' + name + '.json')));
+  var r = eng.decompressBatch(name, hexBuf(cs.map(function(c) { return c.v; }), B),
+    Buffer.from(cs.map(function(c) { return c.odd ? 1 : 0; })));
+  cs.forEach(function(c, i) {
+    var valid = !c.r.invalid;
+    if ((r.ok[i] === 1) !== valid) throw new Error(name + ' decompress validity mismatch at ' + i);
+    if (valid && (r.xy.slice(i * 2 * B, i * 2 * B + B).toString('hex') !== c.r.x ||
+        r.xy.slice(i * 2 * B + B, (i + 1) * 2 * B).toString('hex') !== c.r.y))
+      throw new Error(name + ' decompress mismatch at ' + i);
+    checked++;
+  });
+});
 var lc = JSON.parse(fs.readFileSync(path.join(GOLD, 'mul_curve25519.json')));
 var rr = eng.x25519Batch(hexBuf(lc.map(function(c) { return c.k; }), 32), hexBuf(lc.map(function(c) { return c.px; }), 32));
 lc.forEach(function(c, i) {

@@ -119,6 +119,18 @@ int ellgpu_ecdsa_verify(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* has
 int ellgpu_x25519_ladder(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* in_x,
                          uint8_t* out_x, uint8_t* out_inf);
 
+/* Point decompression.  Short curves: ShortCurve#pointFromX
+ * (lib/elliptic/curve/short.js:187-204) -- v[i] is the abscissa, the result has
+ * y = sqrt(x^3 + a x + b) with parity odd[i] (SEC1 02/03 prefixes: odd = prefix & 1,
+ * base.js:283-289).  ed25519: EdwardsCurve#pointFromY (edwards.js:71-97) -- v[i] is y, the
+ * result has the x of parity odd[i].  out_ok[i] = 0 (x||y zeroed) where the reference
+ * throws 'invalid point'.  Needs p = 3 (mod 4) on short curves: p224 returns
+ * ELLGPU_E_UNSUPPORTED (the reference's generic Tonelli-Shanks stays in JavaScript). */
+int ellgpu_decompress(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, const uint8_t* odd,
+                      uint8_t* out_xy, uint8_t* out_ok);
+int ellgpu_decompress_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, const uint8_t* odd,
+                          uint8_t* out_xy, uint8_t* out_ok, void* stream);
+
 /* ---- device-buffer entry points (inputs/outputs resident in HBM) -------- */
 int ellgpu_mul_fixed_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
                          uint8_t* out_xy, uint8_t* out_inf, void* stream);

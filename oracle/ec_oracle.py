@@ -283,6 +283,19 @@ class ShortCurve:
     def point(self, x, y):
         return ShortPoint(self, x, y)
 
+    def point_from_x(self, x: int, odd: bool) -> ShortPoint:
+        """short.js:187-204 pointFromX: y = sqrt(x^3 + a x + b), parity fixed up;
+        raises ValueError('invalid point') when x is not on the curve."""
+        p = self.p
+        x %= p
+        y2 = (x * x % p * x + self.a * x + self.b) % p
+        y = _sqrt_mod(y2, p)
+        if y is None or (y * y - y2) % p != 0:
+            raise ValueError("invalid point")
+        if bool(y & 1) != bool(odd):
+            y = (-y) % p
+        return self.point(x, y)
+
     def validate(self, pt: ShortPoint) -> bool:
         """short.js:206-216."""
         if pt.inf:
@@ -744,6 +757,8 @@ class EdwardsCurve:
         y2 = y * y % p
         lhs = (y2 - 1) % p
         rhs = (y2 * self.d - self.a) % p                # c2 = 1
+        if rhs == 0:
+            raise ValueError("invalid point")            # reference: redInvm(0) asserts
         x2 = lhs * pow(rhs, -1, p) % p
         if x2 == 0:
             if odd:

@@ -103,3 +103,24 @@ def check_verify_golden(ctx, curve):
             assert bool(ok[i]) == c["ok"], (curve, c)
             n_checked += 1
     return n_checked
+
+
+def check_decompress_golden(ctx, curve):
+    """pointFromX / pointFromY goldens (valid and invalid abscissae, both parities)"""
+    from golden_util import load
+    B = FIELD_BYTES[curve]
+    cases = load("decompress_%s.json" % curve)
+    v = ints_to_be([I(c["v"]) for c in cases], B)
+    odd = np.array([1 if c["odd"] else 0 for c in cases], np.uint8)
+    out, ok = ctx.decompress(curve, v, odd)
+    n_inv = 0
+    for i, c in enumerate(cases):
+        if "invalid" in c["r"]:
+            assert ok[i] == 0, (curve, c)
+            n_inv += 1
+        else:
+            assert ok[i] == 1, (curve, c)
+            got = (int.from_bytes(out[i, :B].tobytes(), "big"), int.from_bytes(out[i, B:].tobytes(), "big"))
+            assert got == (I(c["r"]["x"]), I(c["r"]["y"])), (curve, c)
+    assert n_inv > 3
+    return len(cases)

@@ -40,6 +40,24 @@ def test_verify_golden(ctx, curve):
     assert PC.check_verify_golden(ctx, curve) > 15
 
 
+@pytest.mark.parametrize("curve", ["secp256k1", "p192", "p256", "p384", "p521", "ed25519"])
+def test_decompress_golden(ctx, curve):
+    assert PC.check_decompress_golden(ctx, curve) > 40
+
+
+def test_decompress_roundtrip_full_size(ctx):
+    """2^18 public keys: decompress(x, parity(y)) must give back y exactly, and feeding the
+    decompressed keys to the verifier must give the same mask as the original keys."""
+    n = 1 << 18
+    h, r, s, pub, expect = _make_sigs(ctx, n, "gpu-test-decompress")
+    odd = (pub[:, 63] & 1).astype(np.uint8)
+    out, ok = ctx.decompress("secp256k1", np.ascontiguousarray(pub[:, :32]), odd)
+    assert ok.all() and np.array_equal(out, pub)
+    out2, ok2 = ctx.decompress("secp256k1", np.ascontiguousarray(pub[:, :32]), 1 - odd)
+    assert ok2.all() and np.array_equal(out2[:, :32], pub[:, :32]) and not np.array_equal(out2[:, 32:], pub[:, 32:])
+    assert np.array_equal(ctx.ecdsa_verify("secp256k1", h, r, s, out), expect)
+
+
 def _xy(arr, i, B):
     return (int.from_bytes(arr[i, :B].tobytes(), "big"), int.from_bytes(arr[i, B:].tobytes(), "big"))
 

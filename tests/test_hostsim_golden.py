@@ -125,6 +125,17 @@ def test_verify_golden(ctx, curve):
     assert PC.check_verify_golden(ctx, curve) > 15
 
 
+@pytest.mark.parametrize("curve", ["secp256k1", "p192", "p256", "p384", "p521", "ed25519"])
+def test_decompress_golden(ctx, curve):
+    assert PC.check_decompress_golden(ctx, curve) > 40
+
+
+def test_decompress_unsupported(ctx):
+    with pytest.raises(elliptic_amd.EllgpuError) as e:
+        ctx.decompress("p224", np.zeros((1, 28), np.uint8), np.zeros(1, np.uint8))
+    assert e.value.code == -5
+
+
 def test_error_paths(ctx, hs):
     with pytest.raises(elliptic_amd.EllgpuError):
         ctx.mul_fixed("curve25519", np.zeros((1, 32), np.uint8))

@@ -117,3 +117,24 @@ def test_endo_split_recomposes():
         k1, k2 = cur.endo_split(k)
         assert (k1 + k2 * lam - k) % cur.n == 0
         assert abs(k1).bit_length() <= 129 and abs(k2).bit_length() <= 129
+
+
+@pytest.mark.parametrize("name", ["secp256k1", "p192", "p256", "p384", "p521", "ed25519"])
+def test_decompress_matches_reference(name):
+    """pointFromX / pointFromY (short.js:187-204, edwards.js:71-97)"""
+    cur = O.get_curve(name)
+    n_inv = 0
+    for c in load("decompress_%s.json" % name):
+        try:
+            if name == "ed25519":
+                pt = cur.point_from_y(I(c["v"]), c["odd"])
+                got = pt.normalized()
+            else:
+                pt = cur.point_from_x(I(c["v"]), c["odd"])
+                got = (pt.x, pt.y)
+        except ValueError:
+            got = None
+        want = None if "invalid" in c["r"] else (I(c["r"]["x"]), I(c["r"]["y"]))
+        assert got == want, (name, c)
+        n_inv += want is None
+    assert n_inv > 3

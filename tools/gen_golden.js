@@ -12,8 +12,10 @@
 //                           ec.verify), captured at the prototype boundary
 //                           (tools/run_ref_tests.js instrumentation)
 //
-// All randomness is SHA-256 counter mode over a fixed seed; rerunning this
-// script reproduces the fixtures byte for byte.
+// All randomness of the seeded fixtures is SHA-256 counter mode over a fixed seed, so
+// rerunning this script reproduces them byte for byte; captured_*.json depends on the
+// reference suite's own key generation and differs from run to run (every capture is
+// still an input/output pair of the reference).
 //
 //   node tools/gen_golden.js [outdir]
 
@@ -324,6 +326,41 @@ function genVerify(name) {
   return cases;
 }
 
+// ---------------------------------------------------- decompress_<curve>.json
+// ShortCurve#pointFromX (short.js:187-204) / EdwardsCurve#pointFromY
+// (edwards.js:71-97): valid and invalid abscissae, both parities.
+function genDecompress(name) {
+  var c = elliptic.curves[name].curve;
+  var L = flen(c);
+  var rng = new Prng('ellgpu-golden-v1:decompress:' + name);
+  var cases = [];
+  var N = COUNTS[name];
+  function one(v, odd) {
+    var o = { v: hex(v, L), odd: odd };
+    try {
+      var p = c.type === 'short' ? c.pointFromX(v, odd) : c.pointFromY(v, odd);
+      o.r = affine(c, p);
+      if (c.type !== 'short' && p.isInfinity()) o.r = { x: hex(p.getX(), L), y: hex(p.getY(), L) };
+    } catch (e) {
+      o.r = { invalid: e.message };
+    }
+    cases.push(o);
+  }
+  for (var i = 0; i < N; i++) {
+    var P = c.g.mul(rng.below(c.n.subn(1)).addn(1));
+    var v = c.type === 'short' ? P.getX() : P.getY();
+    one(v, (i & 1) === 1);
+    one(v, (i & 1) === 0);
+    one(rng.below(c.p), (i & 2) === 2);            // ~half of these are not on the curve
+  }
+  [new BN(0), new BN(1), new BN(2), new BN(3), c.p.subn(1), c.p.subn(2), c.p.clone(), c.p.addn(1)]
+    .forEach(function(v) {
+      if (v.byteLength() > L) return;
+      one(v, false); one(v, true);
+    });
+  return cases;
+}
+
 // ------------------------------------------------- captured_<curve>.json
 // Run the reference's own mocha suite with the hot-path prototypes wrapped.
 function captureFromReferenceTests() {
@@ -450,6 +487,9 @@ write('curves.json', dumpCurves());
 SHORT.forEach(function(name) {
   write('mul_' + name + '.json', genShortMul(name));
   write('verify_' + name + '.json', genVerify(name));
+});
+['secp256k1', 'p192', 'p256', 'p384', 'p521', 'ed25519'].forEach(function(name) {
+  write('decompress_' + name + '.json', genDecompress(name));
 });
 write('mul_ed25519.json', genEdwardsMul());
 write('mul_curve25519.json', genMontMul());
