@@ -24,11 +24,7 @@
 #define ELL_NOUNROLL
 #endif
 
-#if defined(__HIP_DEVICE_COMPILE__)
 #define ELL_UNLIKELY(x) __builtin_expect(!!(x), 0)
-#else
-#define ELL_UNLIKELY(x) __builtin_expect(!!(x), 0)
-#endif
 
 namespace ell {
 
@@ -199,10 +195,6 @@ ELL_HD void bn_sqr_wide(u32 (&r)[2 * L], const u32 (&a)[L]) {
 }
 
 // ---- byte <-> limb conversion (big-endian bytes at the API) ---------------
-
-ELL_HD u32 load_be32(const u8* p) {
-  return ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3];
-}
 
 ELL_HD u32 bswap32(u32 v) { return __builtin_bswap32(v); }
 

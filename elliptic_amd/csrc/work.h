@@ -1,13 +1,14 @@
 // ellgpu -- per-item work functions for short Weierstrass curves.
 //
-// Each function does the work of ONE GPU thread; the kernels in kernels.hip
-// call them with i = global thread id, tests/hostsim calls them in a loop on
-// the CPU.  Memory layouts (all device buffers):
+// Each function does the work of ONE GPU thread; the kernel template k_run<Fn>
+// (hip_backend.h) calls them through the functors of engine.h with i = global thread
+// id, tests/hostsim calls them in a loop on the CPU.  Memory layouts (all device buffers):
 //
 //   scalars / coordinates at the C ABI   big-endian, fixed width BYTES, item-major
 //   jac   Jacobian results               SoA  jac[(c*L + limb)*n + i], c = X,Y,Z, field-internal form
-//   tbl   per-item window tables         AoS  tbl[i*ENTRIES + e] (Jac structs)
-//   comb  fixed-base table               AoS  comb[w*255 + d-1]  (Aff structs, field-internal form)
+//   tbl   per-item window tables         AoS  tbl[i*ENTRIES + e] (affine entries on the effective-
+//                                             affine curve for secp256k1, Jacobian otherwise)
+//   comb  fixed-base table               AoS  comb[w*(2^c - 1) + d-1]  (Aff structs, field-internal form)
 //   pre   batch-inversion prefixes       SoA  pre[limb*n + i]
 //   u12   ECDSA u1,u2                    SoA  u12[(c*LN + limb)*n + i], plain residues mod n
 #pragma once
