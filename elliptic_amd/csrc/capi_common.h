@@ -122,6 +122,21 @@ int ellgpu_decompress_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v
   return finish(ctx, ctx->eng->decompress_dev(curve, n, v, odd, out_xy, out_ok));
 }
 
+int ellgpu_eddsa_verify(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off,
+                        size_t msg_len, const uint8_t* sigs, const uint8_t* pubs, uint8_t* out_ok,
+                        uint8_t* out_err) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->eddsa_verify_host(n, msgs, (const ell::u64*)msg_off, msg_len, sigs, pubs,
+                                                 out_ok, out_err));
+}
+int ellgpu_eddsa_verify_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off,
+                            size_t msg_len, const uint8_t* sigs, const uint8_t* pubs,
+                            uint8_t* out_ok, uint8_t* out_err, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->eddsa_verify_dev(n, msgs, (const ell::u64*)msg_off, msg_len, sigs, pubs,
+                                                out_ok, out_err));
+}
+
 int ellgpu_mul_fixed_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, uint8_t* out_xy,
                          uint8_t* out_inf, void* stream) {
   ELL_ENTER(ctx, stream);

@@ -13,6 +13,7 @@
 
 #include "curve_consts.h"
 #include "ladder.h"
+#include "sha512.h"
 
 #ifndef ELL_COMB_BITS_256
 #define ELL_COMB_BITS_256 16
@@ -249,6 +250,86 @@ struct EdWork {
     store_be<8>(out_xy + i * 64, x.v, 32);
     store_be<8>(out_xy + i * 64 + 32, y.v, 32);
     out_ok[i] = ok ? 1 : 0;
+  }
+
+  // decodePoint (eddsa/index.js:99-109) of a 32-byte little-endian encoding: y with the
+  // top bit cleared (reduced mod p like BN#toRed), the top bit is x's parity.
+  ELL_HD static bool decode_point(P& out, const u8* enc) {
+    u32 t[8];
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++)
+      t[l] = (u32)enc[4 * l] | ((u32)enc[4 * l + 1] << 8) | ((u32)enc[4 * l + 2] << 16) |
+             ((u32)enc[4 * l + 3] << 24);
+    bool want_odd = (t[7] >> 31) != 0;
+    t[7] &= 0x7FFFFFFFu;
+    El y = F::from_plain(t);
+    El d;
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++) d.v[l] = C::d[l];
+    El y2 = F::sqr(y);
+    El u = F::sub(y2, F::one());
+    El v = F::add(F::mul(y2, d), F::one());
+    El x;
+    bool ok = F::sqrt_ratio(x, u, v);
+    ok = ok && !F::is_zero(v) && !(F::is_zero(x) && want_odd);
+    bool is_odd = (x.v[0] & 1u) != 0;
+    El xn = F::neg(x);
+    bn_select<8>(x.v, is_odd != want_odd, xn.v, x.v);
+    out = from_affine(x, y);
+    return ok;
+  }
+
+  // EDDSA#verify (eddsa/index.js:52-63): S < n, h = SHA-512(R || A || M) mod n (hashInt
+  // :65-70, little-endian), accept iff R + h*A == S*G.  ok = 0/1; err = 1 where the
+  // reference throws (R or A does not decode to a curve point) -- only evaluated when S < n,
+  // as in the reference.  sig = R || S and pub = A in their 32-byte wire encodings.
+  ELL_HD static void eddsa_verify(size_t i, const u8* msg, u64 msg_len, const u8* sig,
+                                  const u8* pub, const P* comb, P* tbl_all, const DigitStore& ds,
+                                  u8* out_ok, u8* out_err) {
+    typedef FpMont<consts::ED25519_N> Fn;
+    u32 S[8], nn[8];
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++) {
+      const u8* q = sig + 32 + 4 * l;
+      S[l] = (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16) | ((u32)q[3] << 24);
+      nn[l] = C::n[l];
+    }
+    bool s_ok = !bn_geq<8>(S, nn);
+    u8 digest[64];
+    Sha512::hash3(digest, sig, 32, pub, 32, msg, msg_len);
+    // h = (hi * 2^256 + lo) mod n: the Montgomery image of hi IS hi * 2^256 mod n
+    u32 lo[8], hi[8];
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++) {
+      lo[l] = (u32)digest[4 * l] | ((u32)digest[4 * l + 1] << 8) | ((u32)digest[4 * l + 2] << 16) |
+              ((u32)digest[4 * l + 3] << 24);
+      hi[l] = (u32)digest[32 + 4 * l] | ((u32)digest[32 + 4 * l + 1] << 8) |
+              ((u32)digest[32 + 4 * l + 2] << 16) | ((u32)digest[32 + 4 * l + 3] << 24);
+    }
+    Fn::El hm = Fn::from_plain(hi);
+    u32 lor[8];
+    Fn::to_plain(lor, Fn::from_plain(lo));
+    Fn::El lom;
+    bn_copy<8>(lom.v, lor);
+    Fn::El hsum = Fn::add(hm, lom);
+    u32 h[8];
+    bn_copy<8>(h, hsum.v);
+
+    P A, R;
+    bool a_ok = decode_point(A, pub);
+    bool r_ok = decode_point(R, sig);
+    P* tbl = tbl_all + i * 8;
+    build_table8(tbl, A);
+    recode_w4<8, NNIB, true>(h, ds, 0, 1);
+    P hA = run_w4<1>(ds, tbl);
+    P lhs = add(hA, to_cached(R));
+    P SG = comb_mul(S, comb);
+    // projective equality (Point#eq compares the normalized coordinates, edwards.js:409-413)
+    bool same = F::eq(F::mul(lhs.a, SG.c), F::mul(SG.a, lhs.c)) &&
+                F::eq(F::mul(lhs.b, SG.c), F::mul(SG.b, lhs.c));
+    bool bad = s_ok && !(a_ok && r_ok);
+    out_ok[i] = (s_ok && a_ok && r_ok && same) ? 1 : 0;
+    if (out_err) out_err[i] = bad ? 1 : 0;
   }
 
   // (X:Y:Z) -> affine (x, y) with one inversion per K items (normalize,

@@ -124,6 +124,19 @@ struct FnEdDecompress {
   }
 };
 
+struct FnEddsaVerify {
+  static constexpr const char* NAME = "eddsa_verify";
+  static constexpr int DS_PER_LANE = EdWork::NWIN;
+  size_t n; const u8* msgs; const u64* off; size_t msg_len; const u8* sigs; const u8* pubs;
+  const EdWork::P* comb; EdWork::P* tbl; u8* ok; u8* err;
+  ELL_HD void operator()(size_t i, const DigitStore& ds) const {
+    if (i >= n) return;
+    const u8* m = off ? msgs + off[i] : msgs + i * msg_len;
+    u64 len = off ? off[i + 1] - off[i] : (u64)msg_len;
+    EdWork::eddsa_verify(i, m, len, sigs + i * 64, pubs + i * 32, comb, tbl, ds, ok, err);
+  }
+};
+
 // Edwards / Montgomery functors
 struct FnEdMulVar {
   static constexpr const char* NAME = "ed_mul_var";
@@ -276,6 +289,9 @@ class Engine {
   int decompress_chunk(size_t n, const u8* x, const u8* odd, u8* out_xy, u8* out_ok);
   template <int U = 0>
   int ed_decompress_chunk(size_t n, const u8* y, const u8* odd, u8* out_xy, u8* out_ok);
+  template <int U = 0>
+  int eddsa_chunk(size_t n, size_t o, const u8* msgs, const u64* off, size_t msg_len, const u8* sigs,
+                  const u8* pubs, u8* ok, u8* err);
 
   // ---- dispatch over curves (device pointers) --------------------------------
 #if defined(ELL_ONLY_CURVE)
@@ -413,6 +429,39 @@ class Engine {
       if (rc) return rc;
     }
     return E_OK;
+  }
+
+  // EdDSA (ed25519) verify.  msgs: concatenated message bytes; off (n+1 offsets, device
+  // memory for the _dev form) or, if null, a uniform stride msg_len.
+  int eddsa_verify_dev(size_t n, const u8* msgs, const u64* off, size_t msg_len, const u8* sigs,
+                       const u8* pubs, u8* ok, u8* err) {
+    if (n && (!sigs || !pubs || !ok || (!msgs && (off || msg_len)))) return fail(E_ARG, "null pointer");
+    int rc = prepare_curve(CURVE_ED25519);
+    if (rc) return rc;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      rc = eddsa_chunk(m, o, msgs, off, msg_len, sigs, pubs, ok, err);
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+  int eddsa_verify_host(size_t n, const u8* msgs, const u64* off, size_t msg_len, const u8* sigs,
+                        const u8* pubs, u8* ok, u8* err) {
+    if (n && (!sigs || !pubs || !ok)) return fail(E_ARG, "null pointer");
+    size_t total = off ? (size_t)off[n] : n * msg_len;
+    if (total && !msgs) return fail(E_ARG, "null message pointer");
+    u8* dm = put(G_IN0, msgs ? msgs : (const u8*)"", total);
+    u64* doff = off ? (u64*)put(G_IN1, off, (n + 1) * sizeof(u64)) : nullptr;
+    u8* dsg = put(G_IN2, sigs, n * 64);
+    u8* dpk = put(G_IN3, pubs, n * 32);
+    u8* dok = out_buf(G_OUT0, n);
+    u8* derr = out_buf(G_OUT1, n);
+    if (!dm || !dsg || !dpk || !dok || !derr || (off && !doff)) return fail(E_NOMEM, "staging allocation failed");
+    int rc = eddsa_verify_dev(n, dm, doff, msg_len, dsg, dpk, dok, derr);
+    if (rc) return rc;
+    bk.d2h(ok, dok, n);
+    if (err) bk.d2h(err, derr, n);
+    return bk.sync();
   }
 
   // point decompression: short curves from x (pointFromX), ed25519 from y (pointFromY)
@@ -807,6 +856,19 @@ template <class BK>
 template <int U>
 int Engine<BK>::ed_decompress_chunk(size_t n, const u8* y, const u8* odd, u8* out_xy, u8* out_ok) {
   FnEdDecompress f{n, y, odd, out_xy, out_ok};
+  bk.launch(f, n);
+  return E_OK;
+}
+
+template <class BK>
+template <int U>
+int Engine<BK>::eddsa_chunk(size_t n, size_t o, const u8* msgs, const u64* off, size_t msg_len,
+                            const u8* sigs, const u8* pubs, u8* ok, u8* err) {
+  EdWork::P* tbl = (EdWork::P*)scratch(S_TBL, n * 8 * sizeof(EdWork::P));
+  if (!tbl) return fail(E_NOMEM, "scratch allocation failed");
+  FnEddsaVerify f{n, off ? msgs : msgs + o * msg_len, off ? off + o : nullptr, msg_len,
+                  sigs + o * 64, pubs + o * 32, (const EdWork::P*)comb_[CURVE_ED25519], tbl,
+                  ok + o, err ? err + o : nullptr};
   bk.launch(f, n);
   return E_OK;
 }

@@ -31,6 +31,9 @@ namespace ell {
   KW template int Engine<HipBackend>::decompress_chunk<CV>(size_t, const u8*, const u8*, u8*, u8*);
 #define ELL_DECL_ED2(KW) \
   KW template int Engine<HipBackend>::ed_decompress_chunk<0>(size_t, const u8*, const u8*, u8*, u8*);
+#define ELL_DECL_ED3(KW)                                                                          \
+  KW template int Engine<HipBackend>::eddsa_chunk<0>(size_t, size_t, const u8*, const u64*, size_t, \
+                                                     const u8*, const u8*, u8*, u8*);
 
 #define ELL_DECL_ED0(KW)                                                                          \
   KW template int Engine<HipBackend>::ensure_ed_comb<0>();                                        \
@@ -54,5 +57,6 @@ ELL_DECL_ED0(extern)
 ELL_DECL_ED1(extern)
 ELL_DECL_X(extern)
 ELL_DECL_ED2(extern)
+ELL_DECL_ED3(extern)
 
 }  // namespace ell

@@ -155,6 +155,35 @@ class Context:
                                                     odd.data_ptr(), out_xy.data_ptr(),
                                                     out_ok.data_ptr(), self._stream()))
 
+    def eddsa_verify(self, msgs, sigs, pubs):
+        """ed25519 EdDSA verify.  msgs: list of bytes objects (any lengths) or an (n, len)
+        uint8 array; sigs (n, 64), pubs (n, 32) in wire encoding.  -> (ok, err) uint8 arrays"""
+        sigs = _u8(sigs, (-1, 64))
+        n = sigs.shape[0]
+        pubs = _u8(pubs, (n, 32))
+        ok = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.uint8)
+        if isinstance(msgs, np.ndarray) and msgs.ndim == 2:
+            m = np.ascontiguousarray(msgs, np.uint8)
+            off_p, mlen = None, m.shape[1]
+        else:
+            off = np.zeros(n + 1, np.uint64)
+            off[1:] = np.cumsum([len(x) for x in msgs])
+            m = np.frombuffer(b"".join(bytes(x) for x in msgs) or b"\0", dtype=np.uint8)
+            off_p, mlen = off.ctypes.data, 0
+            self._keep = off
+        self._check(self._lib.ellgpu_eddsa_verify(self._ctx, n, m.ctypes.data, off_p, mlen,
+                                                  sigs.ctypes.data, pubs.ctypes.data, ok.ctypes.data,
+                                                  err.ctypes.data))
+        return ok, err
+
+    def eddsa_verify_dev(self, msgs, msg_len, sigs, pubs, out_ok, out_err=None, msg_off=None):
+        n = sigs.shape[0]
+        self._check(self._lib.ellgpu_eddsa_verify_dev(
+            self._ctx, n, msgs.data_ptr(), None if msg_off is None else msg_off.data_ptr(), int(msg_len),
+            sigs.data_ptr(), pubs.data_ptr(), out_ok.data_ptr(),
+            None if out_err is None else out_err.data_ptr(), self._stream()))
+
     def x25519(self, k, x):
         k = _u8(k, (-1, 32))
         x = _u8(x, (-1, 32))

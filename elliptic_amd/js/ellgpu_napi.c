@@ -19,6 +19,8 @@
  *           ecdsaVerify(ctx, curve, hash, hashLen, msgBits, r, s, pub) -> Buffer(ok)
  *           x25519(ctx, k, x) -> {x, inf}
  *           decompress(ctx, curve, v, odd) -> {xy, ok}
+ *           eddsaVerify(ctx, msgs, offsets|null, msgLen, sigs, pubs) -> {ok, err}
+ *             offsets: Buffer of n+1 little-endian uint64 byte offsets into msgs
  *           callAsync(op, ctx, curve, hashLen, msgBits, b0, b1, b2, b3) -> Promise
  *             op 0 mulFixed(b0=k) 1 mulVar(k, xy) 2 mulAdd2(k1, p1|null, k2, p2)
  *             3 ecdsaVerify(hash, r, s, pub) 4 x25519(k, x); runs on a libuv worker
@@ -53,6 +55,8 @@ static struct {
                       const uint8_t*, const uint8_t*, uint8_t*);
   int (*x25519)(ellgpu_ctx*, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
   int (*decompress)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
+  int (*eddsa_verify)(ellgpu_ctx*, size_t, const uint8_t*, const uint64_t*, size_t, const uint8_t*,
+                      const uint8_t*, uint8_t*, uint8_t*);
 } L;
 
 #define THROW(env, msg) do { napi_throw_error((env), NULL, (msg)); return NULL; } while (0)
@@ -84,6 +88,7 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   SYM(ctx_destroy, "ellgpu_ctx_destroy"); SYM(mul_fixed, "ellgpu_mul_fixed"); SYM(mul_var, "ellgpu_mul_var");
   SYM(mul_add2, "ellgpu_mul_add2"); SYM(ecdsa_verify, "ellgpu_ecdsa_verify"); SYM(x25519, "ellgpu_x25519_ladder");
   SYM(decompress, "ellgpu_decompress");
+  SYM(eddsa_verify, "ellgpu_eddsa_verify");
   L.h = h;
   napi_value t; CHECK(env, napi_get_boolean(env, 1, &t));
   return t;
@@ -232,6 +237,29 @@ static napi_value fn_decompress(napi_env env, napi_callback_info info) {
   return mk_result(env, "xy", bxy, "ok", bok);
 }
 
+static napi_value fn_eddsa_verify(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 6; napi_value argv[6];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  const uint8_t *m, *off, *sg, *pk; size_t lm, loff, lsg, lpk; int32_t mlen = 0;
+  if (!get_buf(env, argv[1], &m, &lm, 1) || !get_buf(env, argv[2], &off, &loff, 1) ||
+      !get_buf(env, argv[4], &sg, &lsg, 0) || !get_buf(env, argv[5], &pk, &lpk, 0)) return NULL;
+  napi_get_value_int32(env, argv[3], &mlen);
+  if (lsg % 64 || lpk != lsg / 2) THROW(env, "buffer length mismatch");
+  size_t n = lsg / 64;
+  if (off) {
+    if (loff != (n + 1) * 8 || ((uintptr_t)off & 7)) THROW(env, "offsets must be an aligned Buffer of n+1 uint64");
+    if (((const uint64_t*)off)[n] > lm) THROW(env, "offsets exceed the message buffer");
+  } else if ((size_t)mlen * n > lm) THROW(env, "message buffer too short");
+  napi_value bok, berr; void *dok, *derr;
+  CHECK(env, napi_create_buffer(env, n, &dok, &bok));
+  CHECK(env, napi_create_buffer(env, n, &derr, &berr));
+  if (L.eddsa_verify(c, n, m, (const uint64_t*)off, (size_t)mlen, sg, pk, (uint8_t*)dok, (uint8_t*)derr) != 0)
+    return lib_error(env);
+  return mk_result(env, "ok", bok, "err", berr);
+}
+
 /* ---- asynchronous form: napi_async_work + Promise ---------------------------------- */
 typedef struct {
   napi_async_work work;
@@ -345,6 +373,7 @@ static napi_value init(napi_env env, napi_value exports) {
     {"deviceCount", fn_device_count}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
     {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519},
     {"callAsync", fn_call_async}, {"decompress", fn_decompress},
+    {"eddsaVerify", fn_eddsa_verify},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

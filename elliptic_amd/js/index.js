@@ -83,6 +83,22 @@ Engine.prototype.decompressBatch = function decompressBatch(curve, values, odd) 
   return this.addon.decompress(this.ctx, id, values, odd);
 };
 
+// ed25519 EdDSA verify.  msgs: array of Buffers (any lengths); sigs: Buffer(n x 64) of R||S;
+// pubs: Buffer(n x 32).  -> { ok: Buffer(n), err: Buffer(n) }  (err = 1 where the
+// reference throws: R or A is not a curve point)
+Engine.prototype.eddsaVerifyBatch = function eddsaVerifyBatch(msgs, sigs, pubs) {
+  var n = msgs.length;
+  var off = Buffer.alloc((n + 1) * 8);
+  var pos = 0;
+  for (var i = 0; i < n; i++) {
+    off.writeUInt32LE(pos >>> 0, i * 8); off.writeUInt32LE(Math.floor(pos / 4294967296), i * 8 + 4);
+    pos += msgs[i].length;
+  }
+  off.writeUInt32LE(pos >>> 0, n * 8); off.writeUInt32LE(Math.floor(pos / 4294967296), n * 8 + 4);
+  this.stats.gpuCalls++; this.stats.gpuItems += n;
+  return this.addon.eddsaVerify(this.ctx, Buffer.concat(msgs), off, 0, sigs, pubs);
+};
+
 // ---- asynchronous batch API: same arguments, returns a Promise; the work runs on a
 // libuv worker thread (napi_async_work), so the JS thread stays responsive during a large
 // batch.  A context processes one call at a time, so calls are chained.
@@ -260,6 +276,30 @@ function install(elliptic, options) {
     return this.point(new BN(r.xy.slice(0, d.B)), new BN(r.xy.slice(d.B, 2 * d.B)));
   };
 
+  // EDDSA#verify (eddsa/index.js:52-63) for ed25519: one launch does SHA-512, both point
+  // decodings, S*G, h*A and the comparison.  Same results: false for S >= n, an Error where
+  // the reference throws on an undecodable R or A.
+  var eddsaProto = elliptic.eddsa.prototype;
+  orig.eddsaVerify = eddsaProto.verify;
+  eddsaProto.verify = function verify(message, sig, pub) {
+    var d = domain(this.curve);
+    var utils = elliptic.utils;
+    try {
+      if (!d || d.name !== 'ed25519') throw null;
+      var m = Buffer.from(utils.parseBytes(message));
+      var sg = this.makeSignature(sig);
+      var sb = Buffer.from(sg.toBytes());
+      var pb = Buffer.from(this.keyFromPublic(pub).pubBytes());
+      if (sb.length !== 64 || pb.length !== 32) throw null;
+    } catch (e) {
+      eng.stats.passthrough++;
+      return orig.eddsaVerify.apply(this, arguments);
+    }
+    var r = eng.eddsaVerifyBatch([m], sb, pb);
+    if (r.err[0]) throw new Error('invalid point');
+    return r.ok[0] === 1;
+  };
+
   // Montgomery x-only ladder (Point class is not exported: reach it as
   // eddsa/index.js:22 does, through an instance)
   var montProto = elliptic.curves.curve25519.curve.g.constructor.prototype;
@@ -281,6 +321,7 @@ function install(elliptic, options) {
     short._endoWnafMulAdd = orig.endoWnafMulAdd;
     montProto.mul = orig.montMul;
     short.pointFromX = orig.pointFromX;
+    eddsaProto.verify = orig.eddsaVerify;
     edw.pointFromY = orig.pointFromY;
   };
 

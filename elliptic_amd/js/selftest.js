@@ -77,6 +77,17 @@ function check(r, i, B, want, what) {
     checked++;
   });
 });
+(function() {
+  var cs = JSON.parse(fs.readFileSync(path.join(GOLD, 'eddsa_verify_ed25519.json')));
+  var r = eng.eddsaVerifyBatch(cs.map(function(c) { return Buffer.from(c.msg, 'hex'); }),
+    Buffer.concat(cs.map(function(c) { return Buffer.from(c.sig, 'hex'); })),
+    Buffer.concat(cs.map(function(c) { return Buffer.from(c.pub, 'hex'); })));
+  cs.forEach(function(c, i) {
+    if (c.throws ? !(r.err[i] === 1 && r.ok[i] === 0) : (r.err[i] !== 0 || (r.ok[i] === 1) !== c.ok))
+      throw new Error('eddsa verify mismatch at ' + i);
+    checked++;
+  });
+})();
 var lc = JSON.parse(fs.readFileSync(path.join(GOLD, 'mul_curve25519.json')));
 var rr = eng.x25519Batch(hexBuf(lc.map(function(c) { return c.k; }), 32), hexBuf(lc.map(function(c) { return c.px; }), 32));
 lc.forEach(function(c, i) {

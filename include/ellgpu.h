@@ -131,6 +131,21 @@ int ellgpu_decompress(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, co
 int ellgpu_decompress_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, const uint8_t* odd,
                           uint8_t* out_xy, uint8_t* out_ok, void* stream);
 
+/* EdDSA (ed25519) verify: out_ok[i] = EDDSA#verify(msg_i, sig_i, pub_i),
+ * lib/elliptic/eddsa/index.js:52-63 -- S < n, h = SHA-512(R || A || M) mod n (hashInt :65-70),
+ * accept iff R + h*A == S*G.  Wire formats as the reference takes them: sig = R || S (64 bytes,
+ * little-endian encodings, eddsa/signature.js), pub = A (32 bytes), raw message bytes.
+ * Messages are concatenated in `msgs`; msg_off = n+1 byte offsets (message i is
+ * msgs[msg_off[i] .. msg_off[i+1])), or NULL for a uniform length msg_len.
+ * out_err (may be NULL): 1 where the reference THROWS instead of returning -- R or A does not
+ * decode to a curve point (decodePoint -> pointFromY, eddsa/index.js:99-109); out_ok is 0 there. */
+int ellgpu_eddsa_verify(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off,
+                        size_t msg_len, const uint8_t* sigs, const uint8_t* pubs, uint8_t* out_ok,
+                        uint8_t* out_err);
+int ellgpu_eddsa_verify_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off,
+                            size_t msg_len, const uint8_t* sigs, const uint8_t* pubs,
+                            uint8_t* out_ok, uint8_t* out_err, void* stream);
+
 /* ---- device-buffer entry points (inputs/outputs resident in HBM) -------- */
 int ellgpu_mul_fixed_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
                          uint8_t* out_xy, uint8_t* out_inf, void* stream);

@@ -840,6 +840,30 @@ class EdwardsCurve:
         return acc
 
 
+def ed_decode_point(curve: "EdwardsCurve", data: bytes) -> EdPoint:
+    """eddsa/index.js:99-109 decodePoint: y = LE int with the top bit cleared, top bit = x parity"""
+    b = bytearray(data)
+    odd = (b[-1] & 0x80) != 0
+    b[-1] &= 0x7F
+    return curve.point_from_y(int.from_bytes(bytes(b), "little"), odd)
+
+
+def eddsa_verify(curve: "EdwardsCurve", msg: bytes, sig: bytes, pub: bytes) -> bool:
+    """eddsa/index.js:52-63 EDDSA#verify (ed25519, SHA-512).  Raises ValueError where the
+    reference throws (an R or A that does not decode to a curve point)."""
+    import hashlib
+    assert len(sig) == 64 and len(pub) == 32
+    S = int.from_bytes(sig[32:], "little")
+    if S >= curve.n:
+        return False
+    h = int.from_bytes(hashlib.sha512(sig[:32] + pub + msg).digest(), "little") % curve.n   # hashInt :65-70
+    SG = curve.g.mul(S)
+    A = ed_decode_point(curve, pub)
+    R = ed_decode_point(curve, sig[:32])
+    lhs = R.add(A.mul(h))
+    return lhs.normalized() == SG.normalized()
+
+
 def _sqrt_mod(a: int, p: int) -> Optional[int]:
     """bn.js Red.sqrt (dist/elliptic.js:7180-7230): p%4==3 -> pow; else
     Tonelli-Shanks.  Returns the root bn.js returns (either root is accepted by

@@ -124,3 +124,27 @@ def check_decompress_golden(ctx, curve):
             assert got == (I(c["r"]["x"]), I(c["r"]["y"])), (curve, c)
     assert n_inv > 3
     return len(cases)
+
+
+def check_eddsa_golden(ctx):
+    """EDDSA#verify goldens: the reference's sign.input vectors + corrupted / malformed ones"""
+    from golden_util import load
+    cases = load("eddsa_verify_ed25519.json")
+    msgs = [bytes.fromhex(c["msg"]) for c in cases]
+    sigs = np.frombuffer(b"".join(bytes.fromhex(c["sig"]) for c in cases), np.uint8).reshape(-1, 64)
+    pubs = np.frombuffer(b"".join(bytes.fromhex(c["pub"]) for c in cases), np.uint8).reshape(-1, 32)
+    ok, err = ctx.eddsa_verify(msgs, sigs, pubs)
+    for i, c in enumerate(cases):
+        if "throws" in c:
+            assert err[i] == 1 and ok[i] == 0, c
+        else:
+            assert err[i] == 0 and bool(ok[i]) == c["ok"], c
+    # uniform-length form on the subset that shares the most common length
+    from collections import Counter
+    L = Counter(len(m) for m in msgs).most_common(1)[0][0]
+    idx = [i for i, m in enumerate(msgs) if len(m) == L]
+    if L > 0 and len(idx) > 1:
+        arr = np.frombuffer(b"".join(msgs[i] for i in idx), np.uint8).reshape(len(idx), L)
+        ok2, err2 = ctx.eddsa_verify(arr, sigs[idx], pubs[idx])
+        assert np.array_equal(ok2, ok[idx]) and np.array_equal(err2, err[idx])
+    return len(cases)

@@ -58,6 +58,50 @@ def test_decompress_roundtrip_full_size(ctx):
     assert np.array_equal(ctx.ecdsa_verify("secp256k1", h, r, s, out), expect)
 
 
+def test_eddsa_verify_golden(ctx):
+    assert PC.check_eddsa_golden(ctx) > 200
+
+
+def test_eddsa_full_size_mask(ctx):
+    """2^18 synthetic ed25519 signatures (A = aG, R = rG, S = r + h*a, built with the engine's
+    own fixed-base kernel and hashlib), every 100th corrupted: exact mask, no decode errors;
+    a seeded subset re-checked with the oracle."""
+    import torch
+    cur = O.get_curve("ed25519")
+    n, mlen = 1 << 18, 48
+    rnd = np.frombuffer(hashlib.shake_256(b"eddsa-fullsize").digest(n * (64 + mlen)), dtype=np.uint8)
+    a = [int.from_bytes(rnd[i * 32:(i + 1) * 32].tobytes(), "little") % cur.n for i in range(n)]
+    rr = [int.from_bytes(rnd[(n + i) * 32:(n + i + 1) * 32].tobytes(), "little") % cur.n for i in range(n)]
+    msgs = rnd[2 * n * 32:].reshape(n, mlen).copy()
+    A, _ = ctx.mul_fixed("ed25519", ints_to_be(a, 32))
+    R, _ = ctx.mul_fixed("ed25519", ints_to_be(rr, 32))
+
+    def enc(P):
+        y = P[:, 32:][:, ::-1].copy()
+        y[:, 31] |= ((P[:, 31] & 1) << 7).astype(np.uint8)
+        return y
+    Ae, Re = enc(A), enc(R)
+    sig = np.zeros((n, 64), np.uint8)
+    sig[:, :32] = Re
+    for i in range(n):
+        h = int.from_bytes(hashlib.sha512(Re[i].tobytes() + Ae[i].tobytes() + msgs[i].tobytes()).digest(), "little") % cur.n
+        sig[i, 32:] = np.frombuffer(((rr[i] + h * a[i]) % cur.n).to_bytes(32, "little"), np.uint8)
+    expect = np.ones(n, np.uint8)
+    for j in range(0, n, 100):
+        sig[j, 33 + (j % 20)] ^= 1 << (j % 7)
+        expect[j] = 0
+    dev = torch.device("cuda", 0)
+    dm, ds, dp = [torch.from_numpy(x).to(dev) for x in (msgs, sig, Ae)]
+    ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    err = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ctx.eddsa_verify_dev(dm, mlen, ds, dp, ok, err)
+    torch.cuda.synchronize()
+    assert np.array_equal(ok.cpu().numpy(), expect) and not err.any()
+    rs = random.Random(5)
+    for i in [0, 100, 200] + [rs.randrange(n) for _ in range(60)]:
+        assert O.eddsa_verify(cur, msgs[i].tobytes(), sig[i].tobytes(), Ae[i].tobytes()) == bool(expect[i])
+
+
 def _xy(arr, i, B):
     return (int.from_bytes(arr[i, :B].tobytes(), "big"), int.from_bytes(arr[i, B:].tobytes(), "big"))
 

@@ -136,6 +136,10 @@ def test_decompress_unsupported(ctx):
     assert e.value.code == -5
 
 
+def test_eddsa_verify_golden(ctx):
+    assert PC.check_eddsa_golden(ctx) > 200
+
+
 def test_error_paths(ctx, hs):
     with pytest.raises(elliptic_amd.EllgpuError):
         ctx.mul_fixed("curve25519", np.zeros((1, 32), np.uint8))

@@ -138,3 +138,18 @@ def test_decompress_matches_reference(name):
         assert got == want, (name, c)
         n_inv += want is None
     assert n_inv > 3
+
+
+def test_eddsa_verify_matches_reference():
+    """EDDSA#verify on the reference's own sign.input vectors + corrupted variants"""
+    cur = O.get_curve("ed25519")
+    seen = {True: 0, False: 0, "throws": 0}
+    for c in load("eddsa_verify_ed25519.json"):
+        try:
+            got = O.eddsa_verify(cur, bytes.fromhex(c["msg"]), bytes.fromhex(c["sig"]), bytes.fromhex(c["pub"]))
+        except ValueError:
+            got = "throws"
+        want = "throws" if "throws" in c else c["ok"]
+        assert got == want, c
+        seen[want] += 1
+    assert seen[True] > 50 and seen[False] > 30 and seen["throws"] > 3

@@ -361,6 +361,51 @@ function genDecompress(name) {
   return cases;
 }
 
+// ------------------------------------------------------ eddsa_verify_ed25519.json
+// EDDSA#verify (eddsa/index.js:52-63) on the official ed25519 sign.input vectors the
+// reference ships (test/fixtures/sign.input), plus corrupted / malformed variants.
+// Result: ok = true|false, or throws = message when the reference throws.
+function genEddsa() {
+  var ed = new elliptic.eddsa('ed25519');
+  var rng = new Prng('ellgpu-golden-v1:eddsa');
+  var lines = fs.readFileSync(path.join(ref.root, 'test', 'fixtures', 'sign.input'), 'utf8')
+    .split('\n').filter(function(l) { return l.length; });
+  var cases = [];
+  function rec(msg, sig, pub, note) {
+    var o = { msg: msg, sig: sig, pub: pub, note: note };
+    try { o.ok = ed.verify(msg.length ? Buffer.from(msg, 'hex').toJSON().data : [], sig, pub); }
+    catch (e) { o.throws = e.message; }
+    cases.push(o);
+  }
+  function flip(hexs, byte, bit) {
+    var b = Buffer.from(hexs, 'hex'); b[byte] ^= 1 << bit; return b.toString('hex');
+  }
+  var picks = [];
+  for (var i = 0; i < 96; i++) picks.push(i);
+  [127, 128, 129, 200, 255, 256, 400, 511, 512, 700, 1023].forEach(function(i) { picks.push(i); });
+  picks.forEach(function(i, j) {
+    var f = lines[i].split(':');
+    var pub = f[1];
+    var msg = f[2];
+    var sig = f[3].slice(0, 128);
+    rec(msg, sig, pub, 'sign.input line ' + i);
+    var kind = j % 8;
+    if (kind === 0) rec(msg.length ? flip(msg, 0, 0) : '00', sig, pub, 'bad msg');
+    if (kind === 1) rec(msg, flip(sig, 40, 3), pub, 'bad S');
+    if (kind === 2) rec(msg, flip(sig, 5, 1), pub, 'bad R');
+    if (kind === 3) rec(msg, sig, flip(pub, 7, 2), 'bad A');
+    if (kind === 4) {                                  // S + n (>= n): must be rejected
+      var S = new BN(Buffer.from(sig.slice(64), 'hex'), 'le').add(ed.curve.n);
+      if (S.byteLength() <= 32)
+        rec(msg, sig.slice(0, 64) + Buffer.from(S.toArray('le', 32)).toString('hex'), pub, 'S+n');
+    }
+    if (kind === 5) rec(msg, flip(sig, 31, 7), pub, 'R sign bit flipped');
+    if (kind === 6) rec(msg, sig, flip(pub, 31, 7), 'A sign bit flipped');
+    if (kind === 7) rec(msg, rng.bytes(64).toString('hex'), pub, 'random sig');
+  });
+  return cases;
+}
+
 // ------------------------------------------------- captured_<curve>.json
 // Run the reference's own mocha suite with the hot-path prototypes wrapped.
 function captureFromReferenceTests() {
@@ -491,6 +536,7 @@ SHORT.forEach(function(name) {
 ['secp256k1', 'p192', 'p256', 'p384', 'p521', 'ed25519'].forEach(function(name) {
   write('decompress_' + name + '.json', genDecompress(name));
 });
+write('eddsa_verify_ed25519.json', genEddsa());
 write('mul_ed25519.json', genEdwardsMul());
 write('mul_curve25519.json', genMontMul());
 var c = captureFromReferenceTests();
