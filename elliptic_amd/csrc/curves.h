@@ -27,26 +27,24 @@ struct CvSecp256k1 {
   static constexpr int A_KIND = 0;
   static constexpr bool ENDO = true;
   static constexpr int ID = CURVE_SECP256K1;
-  ELL_HD static typename F::El gx() { typename F::El r; for (int i = 0; i < 8; i++) r.v[i] = C::gx_plain[i]; return r; }
-  ELL_HD static typename F::El gy() { typename F::El r; for (int i = 0; i < 8; i++) r.v[i] = C::gy_plain[i]; return r; }
 };
 
-template <class CP, class CN, class CC, int ID_>
+// NIST curves (a = -3): FIELD is the base-field arithmetic -- Solinas reduction for p256 /
+// p384, generic Montgomery for p192 / p224 / p521; the order field is always Montgomery.
+template <class FIELD, class CN, class CC, int ID_>
 struct CvNist {
-  typedef FpMont<CP> F;
+  typedef FIELD F;
   typedef FpMont<CN> Fn;
   typedef CC C;
   static constexpr int A_KIND = 3;
   static constexpr bool ENDO = false;
   static constexpr int ID = ID_;
-  ELL_HD static typename F::El gx() { typename F::El r; for (int i = 0; i < F::L; i++) r.v[i] = C::gx_mont[i]; return r; }
-  ELL_HD static typename F::El gy() { typename F::El r; for (int i = 0; i < F::L; i++) r.v[i] = C::gy_mont[i]; return r; }
 };
 
-typedef CvNist<consts::P192_P, consts::P192_N, consts::P192_C, CURVE_P192> CvP192;
-typedef CvNist<consts::P224_P, consts::P224_N, consts::P224_C, CURVE_P224> CvP224;
-typedef CvNist<consts::P256_P, consts::P256_N, consts::P256_C, CURVE_P256> CvP256;
-typedef CvNist<consts::P384_P, consts::P384_N, consts::P384_C, CURVE_P384> CvP384;
-typedef CvNist<consts::P521_P, consts::P521_N, consts::P521_C, CURVE_P521> CvP521;
+typedef CvNist<FpMont<consts::P192_P>, consts::P192_N, consts::P192_C, CURVE_P192> CvP192;
+typedef CvNist<FpMont<consts::P224_P>, consts::P224_N, consts::P224_C, CURVE_P224> CvP224;
+typedef CvNist<FpSolinas<SolP256>, consts::P256_N, consts::P256_C, CURVE_P256> CvP256;
+typedef CvNist<FpSolinas<SolP384>, consts::P384_N, consts::P384_C, CURVE_P384> CvP384;
+typedef CvNist<FpMont<consts::P521_P>, consts::P521_N, consts::P521_C, CURVE_P521> CvP521;
 
 }  // namespace ell

@@ -20,7 +20,13 @@
 #pragma once
 
 #include "common.h"
+#include "curve_consts.h"
 #include "mul_asm.h"
+
+// field multiplies of moduli with at least this many limbs are real function calls
+#ifndef ELL_MONT_CALL_MINL
+#define ELL_MONT_CALL_MINL 12
+#endif
 
 namespace ell {
 
@@ -540,9 +546,6 @@ struct FpMont {
   // temporaries die at its return.
   static ELL_HD_NOINLINE El mul_call(El a, El b) { return mul_inline(a, b); }
   static ELL_HD_NOINLINE El sqr_call(El a) { return sqr_inline(a); }
-#ifndef ELL_MONT_CALL_MINL
-#define ELL_MONT_CALL_MINL 12
-#endif
   ELL_HD static El mul(const El& a, const El& b) {
     if constexpr (L >= ELL_MONT_CALL_MINL) return mul_call(a, b);
     else return mul_inline(a, b);
@@ -598,6 +601,188 @@ struct FpMont {
       if (bit) r = mul(r, a);
     }
     return r;
+  }
+};
+
+// --------------------------------------------------------------------------
+// NIST primes with Solinas (generalised-Mersenne) reduction: plain residues, the 2L-word
+// product is folded by the word-level sums of FIPS 186-4 D.2 -- additions only, no
+// multiplies (a Montgomery reduction spends another L^2 multiplies here).
+// R supplies: MP (Montgomery-style constant struct with p, pm2, pp1d4), the term table
+//   NPOS, NNEG, pos[NPOS][L], neg[NNEG][L]  (source word index, -1 = zero word; a vector
+//   listed twice is added twice), and mul_delta(d, out) = d * (2^(32L) - p) for small d.
+// --------------------------------------------------------------------------
+template <class R>
+struct FpSolinas {
+  typedef typename R::MP MP;
+  static constexpr int L = MP::L;
+  typedef Fe<MP::L> El;
+  static constexpr bool HAS_SQRT = MP::P3MOD4;
+
+  ELL_HD static void get_p(u32 (&p)[L]) {
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) p[i] = MP::p[i];
+  }
+  ELL_HD static El zero() { El r; bn_zero<L>(r.v); return r; }
+  ELL_HD static El one() { El r; bn_zero<L>(r.v); r.v[0] = 1; return r; }
+  ELL_HD static El from_plain(const u32 (&a)[L]) {        // a < 2^(32L) < 2p
+    u32 p[L]; get_p(p);
+    u32 s[L];
+    u32 br = bn_sub<L>(s, a, p);
+    El r; bn_select<L>(r.v, br == 0, s, a);
+    return r;
+  }
+  ELL_HD static void to_plain(u32 (&r)[L], const El& a) { bn_copy<L>(r, a.v); }
+  ELL_HD static bool is_zero(const El& a) { return bn_is_zero<L>(a.v); }
+  ELL_HD static bool eq(const El& a, const El& b) { return bn_eq<L>(a.v, b.v); }
+  ELL_HD static bool is_odd(const El& a) { return a.v[0] & 1; }
+  ELL_HD static El add(const El& a, const El& b) {
+    u32 p[L]; get_p(p);
+    El r; mod_add<L>(r.v, a.v, b.v, p); return r;
+  }
+  ELL_HD static El sub(const El& a, const El& b) {
+    u32 p[L]; get_p(p);
+    El r; mod_sub<L>(r.v, a.v, b.v, p); return r;
+  }
+  ELL_HD static El neg(const El& a) { return sub(zero(), a); }
+  ELL_HD static El dbl(const El& a) { return add(a, a); }
+
+  ELL_HD static El reduce_wide(const u32 (&t)[2 * L]) {
+    u32 r[L];
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) r[i] = t[i];
+    int top = 0;                                   // value = top * 2^(32L) + r
+    ELL_UNROLL
+    for (int k = 0; k < R::NPOS; k++) {
+      u32 c = 0;
+      ELL_UNROLL
+      for (int i = 0; i < L; i++) {
+        const int w = R::pos[k][i];
+        r[i] = addc32(r[i], w >= 0 ? t[w >= 0 ? w : 0] : 0u, c, c);
+      }
+      top += (int)c;
+    }
+    ELL_UNROLL
+    for (int k = 0; k < R::NNEG; k++) {
+      u32 b = 0;
+      ELL_UNROLL
+      for (int i = 0; i < L; i++) {
+        const int w = R::neg[k][i];
+        r[i] = subb32(r[i], w >= 0 ? t[w >= 0 ? w : 0] : 0u, b, b);
+      }
+      top -= (int)b;
+    }
+    // 2^(32L) == delta (mod p): V' = r + top*delta lies in (-p, 2p)
+    bool negt = top < 0;
+    u32 d = (u32)(negt ? -top : top);
+    u32 dd[L];
+    R::mul_delta(d, dd);
+    u32 mask = negt ? 0xFFFFFFFFu : 0u;
+    u32 c = negt ? 1u : 0u;
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) r[i] = addc32(r[i], dd[i] ^ mask, c, c);
+    // add case: c = overflow beyond 2^(32L);  subtract case: c == 0 means the result is negative
+    u32 p[L]; get_p(p);
+    u32 sm[L], sp[L];
+    u32 bs = bn_sub<L>(sm, r, p);
+    bn_add<L>(sp, r, p);
+    bool is_neg = negt && (c == 0);
+    bool over = (!negt && c != 0) || (bs == 0);
+    El out;
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) out.v[i] = is_neg ? sp[i] : (over ? sm[i] : r[i]);
+    return out;
+  }
+  ELL_HD static El mul_inline(const El& a, const El& b) {
+    u32 t[2 * L];
+    fe_mul_wide<L>(t, a.v, b.v);
+    return reduce_wide(t);
+  }
+  ELL_HD static El sqr_inline(const El& a) {
+    u32 t[2 * L];
+    fe_sqr_wide<L>(t, a.v);
+    return reduce_wide(t);
+  }
+  static ELL_HD_NOINLINE El mul_call(El a, El b) { return mul_inline(a, b); }
+  static ELL_HD_NOINLINE El sqr_call(El a) { return sqr_inline(a); }
+  ELL_HD static El mul(const El& a, const El& b) {
+    if constexpr (L >= ELL_MONT_CALL_MINL) return mul_call(a, b);
+    else return mul_inline(a, b);
+  }
+  ELL_HD static El sqr(const El& a) {
+    if constexpr (L >= ELL_MONT_CALL_MINL) return sqr_call(a);
+    else return sqr_inline(a);
+  }
+  ELL_HD static El sqr_n(El a, int n) {
+    ELL_NOUNROLL
+    for (int i = 0; i < n; i++) a = sqr(a);
+    return a;
+  }
+  ELL_HD static El pow_const(const El& a, const u32 (&e)[L]) {
+    El r = one();
+    ELL_NOUNROLL
+    for (int w = 32 * L - 1; w >= 0; w--) {
+      r = sqr(r);
+      u32 bit = (e[w >> 5] >> (w & 31)) & 1u;
+      if (bit) r = mul(r, a);
+    }
+    return r;
+  }
+  static ELL_HD_NOINLINE El inv(const El& a) { return pow_const(a, MP::pm2); }
+  static ELL_HD_NOINLINE El sqrt(const El& a) { return pow_const(a, MP::pp1d4); }
+};
+
+// p256 = 2^256 - 2^224 + 2^192 + 2^96 - 1  (FIPS 186-4 D.2.3):
+//   r = T + 2 S1 + 2 S2 + S3 + S4 - D1 - D2 - D3 - D4, words listed least significant first
+struct SolP256 {
+  typedef consts::P256_P MP;
+  static constexpr int NPOS = 6, NNEG = 4;
+  static constexpr signed char pos[6][8] = {
+      {-1, -1, -1, 11, 12, 13, 14, 15},   // S1
+      {-1, -1, -1, 11, 12, 13, 14, 15},   // S1 again
+      {-1, -1, -1, 12, 13, 14, 15, -1},   // S2
+      {-1, -1, -1, 12, 13, 14, 15, -1},   // S2 again
+      {8, 9, 10, -1, -1, -1, 14, 15},     // S3
+      {9, 10, 11, 13, 14, 15, 13, 8},     // S4
+  };
+  static constexpr signed char neg[4][8] = {
+      {11, 12, 13, -1, -1, -1, 8, 10},    // D1
+      {12, 13, 14, 15, -1, -1, 9, 11},    // D2
+      {13, 14, 15, 8, 9, 10, -1, 12},     // D3
+      {14, 15, -1, 9, 10, 11, -1, 13},    // D4
+  };
+  // d * (2^224 - 2^192 - 2^96 + 1)
+  ELL_HD static void mul_delta(u32 d, u32 (&o)[8]) {
+    u32 x[8] = {d, 0, 0, 0, 0, 0, 0, d};
+    u32 y[8] = {0, 0, 0, d, 0, 0, d, 0};
+    bn_sub<8>(o, x, y);
+  }
+};
+
+// p384 = 2^384 - 2^128 - 2^96 + 2^32 - 1  (FIPS 186-4 D.2.4):
+//   r = T + 2 S1 + S2 + S3 + S4 + S5 + S6 - D1 - D2 - D3
+struct SolP384 {
+  typedef consts::P384_P MP;
+  static constexpr int NPOS = 7, NNEG = 3;
+  static constexpr signed char pos[7][12] = {
+      {-1, -1, -1, -1, 21, 22, 23, -1, -1, -1, -1, -1},   // S1
+      {-1, -1, -1, -1, 21, 22, 23, -1, -1, -1, -1, -1},   // S1 again
+      {12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23},   // S2
+      {21, 22, 23, 12, 13, 14, 15, 16, 17, 18, 19, 20},   // S3
+      {-1, 23, -1, 20, 12, 13, 14, 15, 16, 17, 18, 19},   // S4
+      {-1, -1, -1, -1, 20, 21, 22, 23, -1, -1, -1, -1},   // S5
+      {20, -1, -1, 21, 22, 23, -1, -1, -1, -1, -1, -1},   // S6
+  };
+  static constexpr signed char neg[3][12] = {
+      {23, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22},   // D1
+      {-1, 20, 21, 22, 23, -1, -1, -1, -1, -1, -1, -1},   // D2
+      {-1, -1, -1, 23, 23, -1, -1, -1, -1, -1, -1, -1},   // D3
+  };
+  // d * (2^128 + 2^96 - 2^32 + 1)
+  ELL_HD static void mul_delta(u32 d, u32 (&o)[12]) {
+    u32 x[12] = {d, 0, 0, d, d, 0, 0, 0, 0, 0, 0, 0};
+    u32 y[12] = {0, d, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bn_sub<12>(o, x, y);
   }
 };
 
