@@ -122,6 +122,22 @@ int ellgpu_decompress_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v
   return finish(ctx, ctx->eng->decompress_dev(curve, n, v, odd, out_xy, out_ok));
 }
 
+int ellgpu_ecdsa_sign(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len, int msg_bits,
+                      const uint8_t* priv, const uint8_t* nonces, int canonical, uint8_t* out_r,
+                      uint8_t* out_s, uint8_t* out_recid, uint8_t* out_ok) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->ecdsa_sign_host(curve, n, hash, hash_len, msg_bits, priv, nonces, canonical,
+                                               out_r, out_s, out_recid, out_ok));
+}
+int ellgpu_ecdsa_sign_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                          int msg_bits, const uint8_t* priv, const uint8_t* nonces, int canonical,
+                          uint8_t* out_r, uint8_t* out_s, uint8_t* out_recid, uint8_t* out_ok,
+                          void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->ecdsa_sign_dev(curve, n, hash, hash_len, msg_bits, priv, nonces, canonical,
+                                              out_r, out_s, out_recid, out_ok));
+}
+
 int ellgpu_eddsa_verify(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off,
                         size_t msg_len, const uint8_t* sigs, const uint8_t* pubs, uint8_t* out_ok,
                         uint8_t* out_err) {

@@ -106,6 +106,29 @@ struct FnEcdsaMain {
 };
 
 template <class CV>
+struct FnSignMul {
+  static constexpr const char* NAME = "sign_mul";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* nonces; const typename W::A* comb; u32* jac;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::sign_mul(i, n, nonces, comb, jac);
+  }
+};
+template <class CV>
+struct FnSignFinish {
+  static constexpr const char* NAME = "sign_finish";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t T; size_t n; int K; const u8* hash; int hash_len; int shift; const u8* priv;
+  const u8* nonces; const u8* kg_xy; const u8* kg_inf; int canonical; u32* pre;
+  u8* out_r; u8* out_s; u8* out_recid; u8* out_ok;
+  ELL_HD void operator()(size_t t, const DigitStore&) const {
+    if (t < T) W::sign_finish(t, T, n, K, hash, hash_len, shift, priv, nonces, kg_xy, kg_inf, canonical,
+                              pre, out_r, out_s, out_recid, out_ok);
+  }
+};
+template <class CV>
 struct FnDecompress {
   static constexpr const char* NAME = "decompress";
   typedef Work<CV> W;
@@ -287,6 +310,9 @@ class Engine {
   int x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf);
   template <class CV>
   int decompress_chunk(size_t n, const u8* x, const u8* odd, u8* out_xy, u8* out_ok);
+  template <class CV>
+  int sign_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* priv, const u8* nonces,
+                 int canonical, u8* out_r, u8* out_s, u8* out_recid, u8* out_ok);
   template <int U = 0>
   int ed_decompress_chunk(size_t n, const u8* y, const u8* odd, u8* out_xy, u8* out_ok);
   template <int U = 0>
@@ -429,6 +455,59 @@ class Engine {
       if (rc) return rc;
     }
     return E_OK;
+  }
+
+  // ECDSA sign with caller-supplied nonces (one pass of EC#sign's loop per item)
+  int ecdsa_sign_dev(int curve, size_t n, const u8* hash, int hash_len, int msg_bits, const u8* priv,
+                     const u8* nonces, int canonical, u8* out_r, u8* out_s, u8* out_recid, u8* out_ok) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (curve >= CURVE_ED25519)
+      return fail(E_UNSUPPORTED, "ECDSA sign is implemented for the short Weierstrass presets");
+    if (n && (!hash || !priv || !nonces || !out_r || !out_s || !out_recid || !out_ok))
+      return fail(E_ARG, "null pointer");
+    if (hash_len <= 0 || msg_bits < 0) return fail(E_ARG, "bad hash_len / msg_bits");
+    int bits = msg_bits ? msg_bits : hash_len * 8;
+    int shift = bits - ci->order_bits;
+    if (shift < 0) shift = 0;
+    int ln = (ci->order_bits + 31) / 32;
+    if (hash_len * 8 - shift > 32 * ln || hash_len - (shift >> 3) > 4 * (ln + 1))
+      return fail(E_ARG, "hash_len / msg_bits combination leaves more bits than the order width");
+    int rc = prepare_curve(curve);
+    if (rc) return rc;
+    const size_t NB = ci->order_bytes;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      ELL_SHORT_DISPATCH(curve, rc = sign_chunk<CV>(m, hash + o * hash_len, hash_len, shift, priv + o * NB,
+                                                    nonces + o * NB, canonical, out_r + o * NB,
+                                                    out_s + o * NB, out_recid + o, out_ok + o));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+  int ecdsa_sign_host(int curve, size_t n, const u8* hash, int hash_len, int msg_bits, const u8* priv,
+                      const u8* nonces, int canonical, u8* out_r, u8* out_s, u8* out_recid, u8* out_ok) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (n && (!hash || !priv || !nonces || !out_r || !out_s || !out_recid || !out_ok))
+      return fail(E_ARG, "null pointer");
+    if (hash_len <= 0) return fail(E_ARG, "bad hash_len");
+    size_t NB = ci->order_bytes;
+    u8* dh = put(G_IN0, hash, n * (size_t)hash_len);
+    u8* dd = put(G_IN1, priv, n * NB);
+    u8* dk = put(G_IN2, nonces, n * NB);
+    u8* dr = out_buf(G_OUT0, n * NB * 2 + 2 * n);
+    if (!dh || !dd || !dk || !dr) return fail(E_NOMEM, "staging allocation failed");
+    u8* dsg = dr + n * NB;
+    u8* drec = dsg + n * NB;
+    u8* dok = drec + n;
+    int rc = ecdsa_sign_dev(curve, n, dh, hash_len, msg_bits, dd, dk, canonical, dr, dsg, drec, dok);
+    if (rc) return rc;
+    bk.d2h(out_r, dr, n * NB);
+    bk.d2h(out_s, dsg, n * NB);
+    bk.d2h(out_recid, drec, n);
+    bk.d2h(out_ok, dok, n);
+    return bk.sync();
   }
 
   // EdDSA (ed25519) verify.  msgs: concatenated message bytes; off (n+1 offsets, device
@@ -870,6 +949,29 @@ int Engine<BK>::eddsa_chunk(size_t n, size_t o, const u8* msgs, const u64* off, 
                   sigs + o * 64, pubs + o * 32, (const EdWork::P*)comb_[CURVE_ED25519], tbl,
                   ok + o, err ? err + o : nullptr};
   bk.launch(f, n);
+  return E_OK;
+}
+
+template <class BK>
+template <class CV>
+int Engine<BK>::sign_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* priv,
+                           const u8* nonces, int canonical, u8* out_r, u8* out_s, u8* out_recid,
+                           u8* out_ok) {
+  typedef Work<CV> W;
+  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+  u8* kg = (u8*)scratch(S_U12, n * (2 * W::BYTES + 1));          // k*G affine + infinity flags
+  if (!jac || !kg) return fail(E_NOMEM, "scratch allocation failed");
+  u8* kg_inf = kg + n * 2 * W::BYTES;
+  FnSignMul<CV> f1{n, nonces, (const typename W::A*)comb_[CV::ID], jac};
+  bk.launch(f1, n);
+  int rc = normalize_chunk<CV>(n, jac, kg, kg_inf, nullptr);
+  if (rc) return rc;
+  u32* pre = (u32*)scratch(S_PRE, n * (W::LN > W::L ? W::LN : W::L) * 4);
+  if (!pre) return fail(E_NOMEM, "scratch allocation failed");
+  size_t T = (n + INV_BATCH - 1) / INV_BATCH;
+  FnSignFinish<CV> f2{T, n, INV_BATCH, hash, hash_len, shift, priv, nonces, kg, kg_inf, canonical, pre,
+                      out_r, out_s, out_recid, out_ok};
+  bk.launch(f2, T);
   return E_OK;
 }
 

@@ -368,6 +368,112 @@ struct Work {
     }
   }
 
+  // ---- ECDSA sign for supplied nonces (ec/index.js:110-186, one pass of its loop) ----
+  // nonce K (NBYTES big-endian, as HmacDRBG#generate returns it) -> k = _truncateToN(K, true):
+  // K reaches it as a BN, so the shift is 8*byteLength(value) - n.bitLength() when positive
+  // (:153-156) -- only p521 (521-bit n in 66 bytes) ever shifts.
+  ELL_HD static void load_nonce(u32 (&k)[LN], const u8* kb) {
+    u32 t[LN];
+    load_be<LN>(t, kb, NBYTES);
+    constexpr int SH = 8 * NBYTES - C::NBITS;             // 0 except for p521 (7)
+    if (SH > 0) {
+      // top byte non-zero <=> byteLength == NBYTES <=> shift
+      bool full = (t[(NBYTES - 1) / 4] >> (8 * ((NBYTES - 1) % 4))) != 0;
+      ELL_UNROLL
+      for (int i = 0; i < LN; i++) {
+        u32 hi = i + 1 < LN ? t[i + 1] : 0u;
+        u32 sh = SH > 0 ? ((t[i] >> (SH & 31)) | (hi << ((32 - SH) & 31))) : t[i];
+        k[i] = full ? sh : t[i];
+      }
+    } else {
+      bn_copy<LN>(k, t);
+    }
+  }
+  // pass A: k*G (comb) for every nonce -> Jacobian scratch (then normalize -> affine)
+  ELL_HD static void sign_mul(size_t i, size_t n, const u8* nonces, const A* comb, u32* jac) {
+    u32 k[LN], kk[L];
+    load_nonce(k, nonces + i * NBYTES);
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) kk[l] = l < LN ? k[l] : 0u;
+    J r = LD::template comb_mul<L, COMB_W, COMB_BITS>(kk, comb);
+    store_jac(jac, n, i, r);
+  }
+  // pass B: thread t finishes items t, t+T, ...: r = x mod n, s = k^-1 (z + r d) mod n with
+  // one inversion per K items, recovery parameter, optional low-s form.  ok = 0 where the
+  // reference would go on to its next nonce (k <= 1, k >= n-1, k*G = O, r = 0, s = 0).
+  ELL_HD static void sign_finish(size_t t, size_t T, size_t n, int K, const u8* hash, int hash_len,
+                                 int shift, const u8* priv, const u8* nonces, const u8* kg_xy,
+                                 const u8* kg_inf, int canonical, u32* pre, u8* out_r, u8* out_s,
+                                 u8* out_recid, u8* out_ok) {
+    u32 nn[LN], nm1[LN], one1[LN];
+    ELL_UNROLL
+    for (int l = 0; l < LN; l++) { nn[l] = C::n[l]; one1[l] = l == 0 ? 1u : 0u; }
+    bn_sub<LN>(nm1, nn, one1);
+    Nl acc = Fn::one();
+    ELL_NOUNROLL
+    for (int j = 0; j < K; j++) {
+      size_t i = t + (size_t)j * T;
+      if (i >= n) break;
+      u32 k[LN];
+      load_nonce(k, nonces + i * NBYTES);
+      bool ok = !bn_is_zero<LN>(k) && !bn_eq<LN>(k, one1) && !bn_geq<LN>(k, nm1) && kg_inf[i] == 0;
+      out_ok[i] = ok ? 1 : 0;
+      Nl km = fe_select<Fn>(ok, Fn::from_plain(k), Fn::one());
+      ELL_UNROLL
+      for (int l = 0; l < LN; l++) pre[(size_t)l * n + i] = acc.v[l];
+      acc = Fn::mul(acc, km);
+    }
+    Nl inv = Fn::inv(acc);
+    ELL_NOUNROLL
+    for (int j = K - 1; j >= 0; j--) {
+      size_t i = t + (size_t)j * T;
+      if (i >= n) continue;
+      u32 k[LN], e[LN], d[LN], x[L], y[L];
+      load_nonce(k, nonces + i * NBYTES);
+      load_hash(e, hash + i * (size_t)hash_len, hash_len, shift);
+      load_be<LN>(d, priv + i * NBYTES, NBYTES);
+      load_be<L>(x, kg_xy + i * 2 * BYTES, BYTES);
+      load_be<L>(y, kg_xy + i * 2 * BYTES + BYTES, BYTES);
+      bool ok = out_ok[i] != 0;
+      Nl km = fe_select<Fn>(ok, Fn::from_plain(k), Fn::one());
+      Nl pr;
+      ELL_UNROLL
+      for (int l = 0; l < LN; l++) pr.v[l] = pre[(size_t)l * n + i];
+      Nl kinv = Fn::mul(inv, pr);
+      inv = Fn::mul(inv, km);
+      // r = x mod n: x < p < 2n for every preset, so at most one subtraction
+      static_assert(LN <= L, "order wider than field");
+      u32 nx[L], xr[L];
+      ELL_UNROLL
+      for (int l = 0; l < L; l++) nx[l] = l < LN ? C::n[l] : 0u;
+      u32 br = bn_sub<L>(xr, x, nx);
+      bool wrapped = br == 0;                         // x >= n
+      u32 r[LN];
+      ELL_UNROLL
+      for (int l = 0; l < LN; l++) r[l] = wrapped ? xr[l] : x[l];
+      Nl rm = Fn::from_plain(r);
+      Nl sm = Fn::mul(kinv, Fn::add(Fn::mul(rm, Fn::from_plain(d)), Fn::from_plain(e)));
+      u32 sp[LN];
+      Fn::to_plain(sp, sm);
+      ok = ok && !bn_is_zero<LN>(r) && !bn_is_zero<LN>(sp);
+      u32 recid = (y[0] & 1u) | (wrapped ? 2u : 0u);
+      // low-s form: s > n >> 1  ->  s = n - s, recid ^= 1
+      u32 nh[LN], ns[LN];
+      ELL_UNROLL
+      for (int l = 0; l < LN; l++) nh[l] = (nn[l] >> 1) | (l + 1 < LN ? nn[l + 1] << 31 : 0u);
+      bool high = canonical && !bn_geq<LN>(nh, sp);
+      bn_sub<LN>(ns, nn, sp);
+      ELL_UNROLL
+      for (int l = 0; l < LN; l++) sp[l] = high ? ns[l] : sp[l];
+      if (high) recid ^= 1u;
+      if (!ok) { bn_zero<LN>(r); bn_zero<LN>(sp); recid = 0; }
+      store_be<LN>(out_r + i * NBYTES, r, NBYTES);
+      store_be<LN>(out_s + i * NBYTES, sp, NBYTES);
+      out_recid[i] = (u8)recid;
+      out_ok[i] = ok ? 1 : 0;
+    }
+  }
+
   // JPoint#eqXToP (short.js:908-925): X == r*Z^2, retry with r+n while < p.
   // (for every preset p < 2n, so one retry at most)
   ELL_HD static bool eq_x_to_p(const J& p, const u32 (&r)[LN]) {

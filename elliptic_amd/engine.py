@@ -155,6 +155,31 @@ class Context:
                                                     odd.data_ptr(), out_xy.data_ptr(),
                                                     out_ok.data_ptr(), self._stream()))
 
+    def ecdsa_sign(self, curve, hashes, priv, nonces, canonical=False, msg_bits=0):
+        """one pass of EC#sign per item for supplied nonces -> (r, s, recid, ok)"""
+        NB = ORDER_BYTES[curve]
+        hashes = _u8(hashes)
+        n, hash_len = hashes.shape
+        priv = _u8(priv, (n, NB))
+        nonces = _u8(nonces, (n, NB))
+        r = np.zeros((n, NB), np.uint8)
+        s = np.zeros((n, NB), np.uint8)
+        rec = np.zeros(n, np.uint8)
+        ok = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_ecdsa_sign(self._ctx, self._cid(curve), n, hashes.ctypes.data, hash_len,
+                                                int(msg_bits), priv.ctypes.data, nonces.ctypes.data,
+                                                1 if canonical else 0, r.ctypes.data, s.ctypes.data,
+                                                rec.ctypes.data, ok.ctypes.data))
+        return r, s, rec, ok
+
+    def ecdsa_sign_dev(self, curve, hashes, priv, nonces, out_r, out_s, out_recid, out_ok, canonical=False,
+                       msg_bits=0):
+        n, hash_len = hashes.shape
+        self._check(self._lib.ellgpu_ecdsa_sign_dev(self._ctx, self._cid(curve), n, hashes.data_ptr(), hash_len,
+                                                    int(msg_bits), priv.data_ptr(), nonces.data_ptr(),
+                                                    1 if canonical else 0, out_r.data_ptr(), out_s.data_ptr(),
+                                                    out_recid.data_ptr(), out_ok.data_ptr(), self._stream()))
+
     def eddsa_verify(self, msgs, sigs, pubs):
         """ed25519 EdDSA verify.  msgs: list of bytes objects (any lengths) or an (n, len)
         uint8 array; sigs (n, 64), pubs (n, 32) in wire encoding.  -> (ok, err) uint8 arrays"""

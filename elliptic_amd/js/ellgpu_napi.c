@@ -19,6 +19,8 @@
  *           ecdsaVerify(ctx, curve, hash, hashLen, msgBits, r, s, pub) -> Buffer(ok)
  *           x25519(ctx, k, x) -> {x, inf}
  *           decompress(ctx, curve, v, odd) -> {xy, ok}
+ *           ecdsaSign(ctx, curve, hash, hashLen, msgBits, priv, nonces, canonical)
+ *             -> {r, s, recid, ok}
  *           eddsaVerify(ctx, msgs, offsets|null, msgLen, sigs, pubs) -> {ok, err}
  *             offsets: Buffer of n+1 little-endian uint64 byte offsets into msgs
  *           callAsync(op, ctx, curve, hashLen, msgBits, b0, b1, b2, b3) -> Promise
@@ -55,6 +57,8 @@ static struct {
                       const uint8_t*, const uint8_t*, uint8_t*);
   int (*x25519)(ellgpu_ctx*, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
   int (*decompress)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
+  int (*ecdsa_sign)(ellgpu_ctx*, int, size_t, const uint8_t*, int, int, const uint8_t*, const uint8_t*,
+                    int, uint8_t*, uint8_t*, uint8_t*, uint8_t*);
   int (*eddsa_verify)(ellgpu_ctx*, size_t, const uint8_t*, const uint64_t*, size_t, const uint8_t*,
                       const uint8_t*, uint8_t*, uint8_t*);
 } L;
@@ -89,6 +93,7 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   SYM(mul_add2, "ellgpu_mul_add2"); SYM(ecdsa_verify, "ellgpu_ecdsa_verify"); SYM(x25519, "ellgpu_x25519_ladder");
   SYM(decompress, "ellgpu_decompress");
   SYM(eddsa_verify, "ellgpu_eddsa_verify");
+  SYM(ecdsa_sign, "ellgpu_ecdsa_sign");
   L.h = h;
   napi_value t; CHECK(env, napi_get_boolean(env, 1, &t));
   return t;
@@ -237,6 +242,37 @@ static napi_value fn_decompress(napi_env env, napi_callback_info info) {
   return mk_result(env, "xy", bxy, "ok", bok);
 }
 
+static napi_value fn_sign(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 8; napi_value argv[8];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  int32_t curve, hl, mb; bool canon = 0;
+  if (napi_get_value_int32(env, argv[1], &curve) != napi_ok || napi_get_value_int32(env, argv[3], &hl) != napi_ok ||
+      napi_get_value_int32(env, argv[4], &mb) != napi_ok) THROW(env, "ecdsaSign(ctx, curve, hash, hashLen, msgBits, priv, nonces, canonical)");
+  napi_get_value_bool(env, argv[7], &canon);
+  int NB = L.order_bytes(curve);
+  if (NB <= 0 || hl <= 0) THROW(env, "bad curve / hashLen");
+  const uint8_t *h, *d, *k; size_t lh, ld, lk;
+  if (!get_buf(env, argv[2], &h, &lh, 0) || !get_buf(env, argv[5], &d, &ld, 0) || !get_buf(env, argv[6], &k, &lk, 0)) return NULL;
+  if (lh % (size_t)hl) THROW(env, "hash buffer length is not a multiple of hashLen");
+  size_t n = lh / (size_t)hl;
+  if (ld != n * (size_t)NB || lk != ld) THROW(env, "buffer length mismatch");
+  napi_value br, bs, brec, bok, o; void *dr, *dsg, *drec, *dok;
+  CHECK(env, napi_create_buffer(env, n * (size_t)NB, &dr, &br));
+  CHECK(env, napi_create_buffer(env, n * (size_t)NB, &dsg, &bs));
+  CHECK(env, napi_create_buffer(env, n, &drec, &brec));
+  CHECK(env, napi_create_buffer(env, n, &dok, &bok));
+  if (L.ecdsa_sign(c, curve, n, h, hl, mb, d, k, canon ? 1 : 0, (uint8_t*)dr, (uint8_t*)dsg, (uint8_t*)drec, (uint8_t*)dok) != 0)
+    return lib_error(env);
+  CHECK(env, napi_create_object(env, &o));
+  CHECK(env, napi_set_named_property(env, o, "r", br));
+  CHECK(env, napi_set_named_property(env, o, "s", bs));
+  CHECK(env, napi_set_named_property(env, o, "recid", brec));
+  CHECK(env, napi_set_named_property(env, o, "ok", bok));
+  return o;
+}
+
 static napi_value fn_eddsa_verify(napi_env env, napi_callback_info info) {
   if (!need_lib(env)) return NULL;
   size_t argc = 6; napi_value argv[6];
@@ -373,7 +409,7 @@ static napi_value init(napi_env env, napi_value exports) {
     {"deviceCount", fn_device_count}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
     {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519},
     {"callAsync", fn_call_async}, {"decompress", fn_decompress},
-    {"eddsaVerify", fn_eddsa_verify},
+    {"eddsaVerify", fn_eddsa_verify}, {"ecdsaSign", fn_sign},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

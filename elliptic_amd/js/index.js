@@ -83,6 +83,16 @@ Engine.prototype.decompressBatch = function decompressBatch(curve, values, odd) 
   return this.addon.decompress(this.ctx, id, values, odd);
 };
 
+// ECDSA sign for supplied nonces (one pass of EC#sign's loop per item, ec/index.js:153-185).
+// o = { hashes, hashLen, msgBits, priv: Buffer(n x NB), nonces: Buffer(n x NB), canonical }
+// -> { r, s, recid, ok }   (ok = 0: the reference would try its next nonce)
+Engine.prototype.ecdsaSignBatch = function ecdsaSignBatch(curve, o) {
+  var id = this._id(curve);
+  this.stats.gpuCalls++; this.stats.gpuItems += o.hashes.length / o.hashLen;
+  return this.addon.ecdsaSign(this.ctx, id, o.hashes, o.hashLen, o.msgBits | 0, o.priv, o.nonces,
+    !!o.canonical);
+};
+
 // ed25519 EdDSA verify.  msgs: array of Buffers (any lengths); sigs: Buffer(n x 64) of R||S;
 // pubs: Buffer(n x 32).  -> { ok: Buffer(n), err: Buffer(n) }  (err = 1 where the
 // reference throws: R or A is not a curve point)

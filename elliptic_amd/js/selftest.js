@@ -77,6 +77,25 @@ function check(r, i, B, want, what) {
     checked++;
   });
 });
+['secp256k1', 'p192', 'p224', 'p256', 'p384', 'p521'].forEach(function(name) {
+  var NB = eng.addon.orderBytes(eng.addon.curveId(name));
+  var all = JSON.parse(fs.readFileSync(path.join(GOLD, 'sign_' + name + '.json')));
+  var groups = {};
+  all.forEach(function(c) { var k = (c.z.length / 2) + ':' + c.canonical; (groups[k] = groups[k] || []).push(c); });
+  Object.keys(groups).forEach(function(key) {
+    var cs = groups[key];
+    var hl = +key.split(':')[0];
+    var r = eng.ecdsaSignBatch(name, { hashes: hexBuf(cs.map(function(c) { return c.z; }), hl), hashLen: hl,
+      msgBits: 0, priv: hexBuf(cs.map(function(c) { return c.d; }), NB),
+      nonces: hexBuf(cs.map(function(c) { return c.k; }), NB), canonical: cs[0].canonical });
+    cs.forEach(function(c, i) {
+      if (c.rejected ? r.ok[i] !== 0 : (r.ok[i] !== 1 || r.r.slice(i * NB, (i + 1) * NB).toString('hex') !== c.r ||
+          r.s.slice(i * NB, (i + 1) * NB).toString('hex') !== c.s || r.recid[i] !== c.recid))
+        throw new Error(name + ' sign mismatch: ' + JSON.stringify(c));
+      checked++;
+    });
+  });
+});
 (function() {
   var cs = JSON.parse(fs.readFileSync(path.join(GOLD, 'eddsa_verify_ed25519.json')));
   var r = eng.eddsaVerifyBatch(cs.map(function(c) { return Buffer.from(c.msg, 'hex'); }),

@@ -131,6 +131,21 @@ int ellgpu_decompress(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, co
 int ellgpu_decompress_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, const uint8_t* odd,
                           uint8_t* out_xy, uint8_t* out_ok, void* stream);
 
+/* ECDSA sign for caller-supplied nonces: one pass of EC#sign's loop per item
+ * (lib/elliptic/ec/index.js:153-185): k = _truncateToN(nonce, true), R = k*G (fixed-base comb),
+ * r = R.x mod n, s = k^-1 (z + r d) mod n (k^-1 batched), recoveryParam (:174-175), and with
+ * canonical != 0 the low-s form (:178-181).  The nonce itself (HMAC-DRBG / RFC 6979, ec/index.js
+ * :143-155) is hashing and stays with the caller.  hash / hash_len / msg_bits as for verify;
+ * priv and nonces: n x order_bytes big-endian.  out_ok[i] = 0 (r, s zeroed) where the reference
+ * would go on to its next nonce: k <= 1, k >= n-1, k*G at infinity, r = 0 or s = 0. */
+int ellgpu_ecdsa_sign(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len, int msg_bits,
+                      const uint8_t* priv, const uint8_t* nonces, int canonical, uint8_t* out_r,
+                      uint8_t* out_s, uint8_t* out_recid, uint8_t* out_ok);
+int ellgpu_ecdsa_sign_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                          int msg_bits, const uint8_t* priv, const uint8_t* nonces, int canonical,
+                          uint8_t* out_r, uint8_t* out_s, uint8_t* out_recid, uint8_t* out_ok,
+                          void* stream);
+
 /* EdDSA (ed25519) verify: out_ok[i] = EDDSA#verify(msg_i, sig_i, pub_i),
  * lib/elliptic/eddsa/index.js:52-63 -- S < n, h = SHA-512(R || A || M) mod n (hashInt :65-70),
  * accept iff R + h*A == S*G.  Wire formats as the reference takes them: sig = R || S (64 bytes,

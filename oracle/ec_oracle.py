@@ -620,6 +620,33 @@ def ecdsa_verify(curve: ShortCurve, msg: int, msg_bytes: int, r: int, s: int,
     return curve.j_eq_x_to_p(jp, r)
 
 
+def ecdsa_sign(curve: ShortCurve, msg: int, msg_bytes: int, d: int, k_bytes: bytes, canonical=False,
+               msg_bit_length=None):
+    """ec/index.js:110-186 EC#sign for ONE supplied nonce (options.k(0)): returns
+    (r, s, recoveryParam), or None where the reference would move on to the next nonce."""
+    n = curve.n
+    e = truncate_to_n(curve, msg, msg_bytes, False, msg_bit_length)
+    kv = int.from_bytes(k_bytes, "big")
+    # :153-156: the nonce reaches _truncateToN as a BN, so its byte length is that of the VALUE
+    k = truncate_to_n(curve, kv, (kv.bit_length() + 7) // 8, True)
+    if k <= 1 or k >= n - 1:                                                         # :157-158
+        return None
+    kp = curve.g.mul(k)
+    if kp.inf:
+        return None
+    r = kp.x % n
+    if r == 0:
+        return None
+    s = pow(k, -1, n) * (r * d + e) % n
+    if s == 0:
+        return None
+    recid = (1 if kp.y & 1 else 0) | (2 if kp.x != r else 0)
+    if canonical and s > n >> 1:
+        s = n - s
+        recid ^= 1
+    return r, s, recid
+
+
 # --------------------------------------------------------------------------
 # Twisted Edwards -- lib/elliptic/curve/edwards.js  (extended coords, a = -1)
 # --------------------------------------------------------------------------

@@ -148,3 +148,25 @@ def check_eddsa_golden(ctx):
         ok2, err2 = ctx.eddsa_verify(arr, sigs[idx], pubs[idx])
         assert np.array_equal(ok2, ok[idx]) and np.array_equal(err2, err[idx])
     return len(cases)
+
+
+def check_sign_golden(ctx, curve):
+    """EC#sign with supplied nonces: (hash, d, k) -> (r, s, recoveryParam) or 'next nonce'"""
+    from golden_util import load
+    NB = ORDER_BYTES[curve]
+    groups = {}
+    for c in load("sign_%s.json" % curve):
+        groups.setdefault((len(c["z"]) // 2, c["canonical"]), []).append(c)
+    n_checked = 0
+    for (hl, canon), cs in groups.items():
+        r, s, rec, ok = ctx.ecdsa_sign(curve, ints_to_be([I(c["z"]) for c in cs], hl),
+                                       ints_to_be([I(c["d"]) for c in cs], NB),
+                                       ints_to_be([I(c["k"]) for c in cs], NB), canonical=canon)
+        for i, c in enumerate(cs):
+            if c.get("rejected"):
+                assert ok[i] == 0, (curve, c)
+            else:
+                got = (int.from_bytes(r[i].tobytes(), "big"), int.from_bytes(s[i].tobytes(), "big"), int(rec[i]))
+                assert ok[i] == 1 and got == (I(c["r"]), I(c["s"]), c["recid"]), (curve, c)
+            n_checked += 1
+    return n_checked

@@ -62,6 +62,33 @@ def test_eddsa_verify_golden(ctx):
     assert PC.check_eddsa_golden(ctx) > 200
 
 
+@pytest.mark.parametrize("curve", O.SHORT_CURVES)
+def test_sign_golden(ctx, curve):
+    assert PC.check_sign_golden(ctx, curve) >= 12
+
+
+def test_sign_then_verify_full_size(ctx):
+    """2^18 signatures made by the engine (random d, k, z) must all verify with the engine's
+    verifier against the matching public keys, low-s form respected; a subset vs the oracle."""
+    n = 1 << 18
+    cur = O.get_curve("secp256k1")
+    raw = np.frombuffer(hashlib.shake_256(b"sign-fullsize").digest(n * 96), dtype=np.uint8).reshape(n, 96)
+    z, d, k = (np.ascontiguousarray(raw[:, a:a + 32]) for a in (0, 32, 64))
+    d[:, 0] &= 0x7F
+    k[:, 0] &= 0x7F                                   # < n for sure
+    r, s, rec, ok = ctx.ecdsa_sign("secp256k1", z, d, k, canonical=True)
+    assert ok.all()
+    pub, inf = ctx.mul_fixed("secp256k1", d)
+    assert np.array_equal(ctx.ecdsa_verify("secp256k1", z, r, s, pub), np.ones(n, np.uint8))
+    half = cur.n >> 1
+    rs = random.Random(3)
+    for i in [0, 1, 2] + [rs.randrange(n) for _ in range(200)]:
+        want = O.ecdsa_sign(cur, int.from_bytes(z[i].tobytes(), "big"), 32, int.from_bytes(d[i].tobytes(), "big"),
+                            k[i].tobytes(), canonical=True)
+        got = (int.from_bytes(r[i].tobytes(), "big"), int.from_bytes(s[i].tobytes(), "big"), int(rec[i]))
+        assert got == want and got[1] <= half
+
+
 def test_eddsa_full_size_mask(ctx):
     """2^18 synthetic ed25519 signatures (A = aG, R = rG, S = r + h*a, built with the engine's
     own fixed-base kernel and hashlib), every 100th corrupted: exact mask, no decode errors;

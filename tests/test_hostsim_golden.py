@@ -136,6 +136,11 @@ def test_decompress_unsupported(ctx):
     assert e.value.code == -5
 
 
+@pytest.mark.parametrize("curve", O.SHORT_CURVES)
+def test_sign_golden(ctx, curve):
+    assert PC.check_sign_golden(ctx, curve) >= 12
+
+
 def test_eddsa_verify_golden(ctx):
     assert PC.check_eddsa_golden(ctx) > 200
 

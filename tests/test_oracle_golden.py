@@ -153,3 +153,17 @@ def test_eddsa_verify_matches_reference():
         assert got == want, c
         seen[want] += 1
     assert seen[True] > 50 and seen[False] > 30 and seen["throws"] > 3
+
+
+@pytest.mark.parametrize("name", O.SHORT_CURVES)
+def test_ecdsa_sign_matches_reference(name):
+    cur = O.get_curve(name)
+    rej = 0
+    for c in load("sign_%s.json" % name):
+        got = O.ecdsa_sign(cur, I(c["z"]), len(c["z"]) // 2, I(c["d"]), bytes.fromhex(c["k"]), c["canonical"])
+        if c.get("rejected"):
+            assert got is None, c
+            rej += 1
+        else:
+            assert got == (I(c["r"]), I(c["s"]), c["recid"]), c
+    assert rej >= 3

@@ -406,6 +406,51 @@ function genEddsa() {
   return cases;
 }
 
+// ------------------------------------------------------------- sign_<curve>.json
+// EC#sign (ec/index.js:110-186) with the nonce supplied through options.k, so that
+// (hash, d, k) -> (r, s, recoveryParam) is a pure function; rejected nonces (k <= 1,
+// k >= n-1, r == 0, s == 0) are recorded as rejected: true.
+function genSign(name) {
+  var pc = elliptic.curves[name];
+  var ec = new elliptic.ec(pc);
+  var c = pc.curve;
+  var NB = c.n.byteLength();
+  var rng = new Prng('ellgpu-golden-v1:sign:' + name);
+  var cases = [];
+  var N = Math.ceil(COUNTS[name] / 2);
+  function one(z, d, k, canonical) {
+    var o = { z: Buffer.from(z).toString('hex'), d: hex(d, NB), k: Buffer.from(k).toString('hex'),
+      canonical: canonical };
+    var calls = 0;
+    try {
+      var sig = ec.sign(z, ec.keyFromPrivate(hex(d, NB), 'hex'), { canonical: canonical,
+        k: function(iter) { calls++; if (iter > 0) throw new Error('REJECTED'); return new BN(k); } });
+      o.r = hex(sig.r, NB); o.s = hex(sig.s, NB); o.recid = sig.recoveryParam;
+    } catch (e) {
+      if (e.message !== 'REJECTED') throw e;
+      o.rejected = true;
+    }
+    cases.push(o);
+  }
+  for (var i = 0; i < N; i++) {
+    var zlen = [32, 32, 48, 64, 20][i % 5];
+    var z = rng.bytes(zlen);
+    var d = rng.below(c.n.subn(1)).addn(1);
+    var k = rng.bytes(NB);
+    if (NB * 8 === c.n.bitLength() && i % 3 === 0) k = Buffer.from(rng.below(c.n).toArray('be', NB));
+    one(z, d, k, (i & 1) === 1);
+  }
+  var z0 = rng.bytes(32);
+  var d0 = rng.below(c.n.subn(1)).addn(1);
+  [new BN(0), new BN(1), new BN(2), c.n.subn(2), c.n.subn(1), c.n.clone()].forEach(function(kv) {
+    // nonce bytes are truncated by bits like a digest (_truncateToN(k, true)), so place the
+    // value such that it survives the shift
+    var shift = NB * 8 - c.n.bitLength();
+    one(z0, d0, Buffer.from(kv.ushln(shift).toArray('be', NB)), true);
+  });
+  return cases;
+}
+
 // ------------------------------------------------- captured_<curve>.json
 // Run the reference's own mocha suite with the hot-path prototypes wrapped.
 function captureFromReferenceTests() {
@@ -532,6 +577,7 @@ write('curves.json', dumpCurves());
 SHORT.forEach(function(name) {
   write('mul_' + name + '.json', genShortMul(name));
   write('verify_' + name + '.json', genVerify(name));
+  write('sign_' + name + '.json', genSign(name));
 });
 ['secp256k1', 'p192', 'p256', 'p384', 'p521', 'ed25519'].forEach(function(name) {
   write('decompress_' + name + '.json', genDecompress(name));
