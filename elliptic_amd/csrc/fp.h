@@ -99,6 +99,24 @@ ELL_HD void mod_sub(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L], const u32
   bn_select<L>(r, br != 0, s, t);
 }
 
+// Final step of a reduction whose value c*2^(32L) + r is known to be < 2p, for a modulus
+// whose top limb is 2^32 - 1 (p within 2^-32 of 2^(32L)): both "c != 0" and "r >= p" are then
+// vanishingly rare for every lane of a wave, so the subtraction sits behind a branch that is
+// (almost) never taken instead of costing 2L instructions on every multiply.  The result is
+// identical to the branch-free form.
+template <int L>
+ELL_HD void cond_sub_rare(u32 (&r)[L], u32 c, const u32 (&p)[L]) {
+  // r >= p needs r's top limb to be all ones (p's is): cheap necessary condition first
+  bool maybe = (c != 0) || (r[L - 1] == 0xFFFFFFFFu);
+  if (ELL_UNLIKELY(maybe)) {
+    u32 s[L];
+    u32 br = bn_sub<L>(s, r, p);
+    bool take = (c != 0) || (br == 0);
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) r[i] = take ? s[i] : r[i];
+  }
+}
+
 // --------------------------------------------------------------------------
 // secp256k1 base field
 // --------------------------------------------------------------------------
@@ -126,13 +144,35 @@ struct FpK256 {
   ELL_HD static bool eq(const El& a, const El& b) { return bn_eq<8>(a.v, b.v); }
   ELL_HD static bool is_odd(const El& a) { return a.v[0] & 1; }
 
+  // a + b mod p with p = 2^256 - delta, delta = 2^32 + 977: when the 256-bit sum carries out,
+  // subtracting p is adding delta (and the result is then < p - 1, no second carry); without a
+  // carry the sum is canonical unless it lies in [p, 2^256) -- rare, behind a branch.
   ELL_HD static El add(const El& a, const El& b) {
+    u32 t[8];
+    u32 c = bn_add<8>(t, a.v, b.v);
+    u32 d0 = c ? C0 : 0u, d1 = c;
+    u32 cc = 0;
+    El r;
+    r.v[0] = addc32(t[0], d0, cc, cc);
+    r.v[1] = addc32(t[1], d1, cc, cc);
+    ELL_UNROLL
+    for (int i = 2; i < 8; i++) r.v[i] = addc32(t[i], 0, cc, cc);
     u32 p[8]; get_p(p);
-    El r; mod_add<8>(r.v, a.v, b.v, p); return r;
+    cond_sub_rare<8>(r.v, 0, p);
+    return r;
   }
+  // a - b mod p: on borrow, adding p is subtracting delta; the result is canonical either way
   ELL_HD static El sub(const El& a, const El& b) {
-    u32 p[8]; get_p(p);
-    El r; mod_sub<8>(r.v, a.v, b.v, p); return r;
+    u32 t[8];
+    u32 bw = bn_sub<8>(t, a.v, b.v);
+    u32 d0 = bw ? C0 : 0u, d1 = bw;
+    u32 bb = 0;
+    El r;
+    r.v[0] = subb32(t[0], d0, bb, bb);
+    r.v[1] = subb32(t[1], d1, bb, bb);
+    ELL_UNROLL
+    for (int i = 2; i < 8; i++) r.v[i] = subb32(t[i], 0, bb, bb);
+    return r;
   }
   ELL_HD static El neg(const El& a) { return sub(zero(), a); }
   ELL_HD static El dbl(const El& a) { return add(a, a); }
@@ -181,12 +221,11 @@ struct FpK256 {
     r[2] = addc32(u[2], t2, c, c);
     ELL_UNROLL
     for (int i = 3; i < 8; i++) r[i] = addc32(u[i], 0, c, c);
-    // value = c*2^256 + r  < 2^256 + 2^67: subtract p once if needed
+    // value = c*2^256 + r  < 2^256 + 2^67: subtract p once if needed (rare)
     u32 p[8]; get_p(p);
-    u32 s[8];
-    u32 br = bn_sub<8>(s, r, p);
+    cond_sub_rare<8>(r, c, p);
     El out;
-    bn_select<8>(out.v, (c != 0) || (br == 0), s, r);
+    bn_copy<8>(out.v, r);
     return out;
   }
   ELL_HD static El mul(const El& a, const El& b) {
@@ -475,12 +514,18 @@ struct FpMont {
     }
     // NB: for i = L-1 the row's top limb is t[2L-1]; `top` is the 2^(64L... ) overflow bit
     u32 p[L]; get_p(p);
-    u32 r[L], sres[L];
+    u32 r[L];
     ELL_UNROLL
     for (int i = 0; i < L; i++) r[i] = t[L + i];
-    u32 br = bn_sub<L>(sres, r, p);
     El out;
-    bn_select<L>(out.v, (top != 0) || (br == 0), sres, r);
+    if constexpr (P::p[L - 1] == 0xFFFFFFFFu) {
+      cond_sub_rare<L>(r, top, p);
+      bn_copy<L>(out.v, r);
+    } else {
+      u32 sres[L];
+      u32 br = bn_sub<L>(sres, r, p);
+      bn_select<L>(out.v, (top != 0) || (br == 0), sres, r);
+    }
     return out;
   }
 

@@ -54,8 +54,12 @@ def test_field_ops_gpu(ctx, field):
     top = (1 << (32 * L)) - 1
     edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, p >> 1, (1 << 32) - 1, 1 << 32, (1 << 64) - 1,
             top % p, (top >> 1) % p, int("ffffffff00000000" * L, 16) % p, int("00000000ffffffff" * L, 16) % p]
-    a = edge + [rnd.randrange(p) for _ in range(1500)]
-    b = [edge[(i * 7 + 3) % len(edge)] for i in range(len(edge))] + [rnd.randrange(p) for _ in range(1500)]
+    import math
+    rare = [(2, (p + 1) // 2), (3, (p + 2) // 3), (math.isqrt(p) + 1, math.isqrt(p) + 1),
+            (math.isqrt(p) + 1, math.isqrt(p) + 2), (p - 1, p - 1), (p - 1, 2),   # land in [p, 2^(32L))
+            (1, p - 1), (p - 1, 1), (2, p - 1), (p - 2, 2), (p - 2, 3), (0, 1), (1, 2), (0, p - 1)]   # sums / differences at the wrap
+    a = edge + [x for x, _ in rare] + [rnd.randrange(p) for _ in range(1500)]
+    b = [edge[(i * 7 + 3) % len(edge)] for i in range(len(edge))] + [y for _, y in rare] + [rnd.randrange(p) for _ in range(1500)]
     n = len(a)
     A, B = _pack(a, L), _pack(b, L)
     for op, fn in ((0, lambda x, y: (x + y) % p), (1, lambda x, y: (x - y) % p), (2, lambda x, y: x * y % p),

@@ -62,6 +62,14 @@ def test_field_ops(hs, field):
     edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, 2 ** (32 * L) - 1 if field in (0, 1) else p - 3,
             2 ** 32 - 1, 2 ** 64, p >> 1]
     vals = [(a % (2 ** (32 * L))) for a in edge] + [rnd.randrange(p) for _ in range(60)]
+    # products that land in [p, 2^(32L)) before the final (rarely taken) subtraction
+    import math
+    for a, b in [(2, (p + 1) // 2), (3, (p + 2) // 3), (math.isqrt(p) + 1, math.isqrt(p) + 1),
+                 (math.isqrt(p) + 1, math.isqrt(p) + 2), (p - 1, p - 1), (p - 1, 2)]:
+        for op, fn in ((2, lambda x, y: x * y % p), (3, lambda x, y: x * x % p)):
+            r = (ctypes.c_uint32 * L)()
+            assert hs.hs_field_op(field, op, _limbs(a, L), _limbs(b, L), r) == 0
+            assert _val(r) == fn(a % p, b % p), (field, op, hex(a), hex(b))
     for a in vals:
         for b in (vals[rnd.randrange(len(vals))], rnd.randrange(p), p - 1):
             for op, fn in ((0, lambda x, y: (x + y) % p), (1, lambda x, y: (x - y) % p),
