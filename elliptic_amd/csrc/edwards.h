@@ -60,9 +60,6 @@ struct EdWork {
     r.d = F::mul(p.d, const_dd());
     return r;
   }
-  ELL_HD static P cached_identity() {
-    P r; r.a = F::one(); r.b = F::one(); r.c = F::dbl(F::one()); r.d = F::zero(); return r;
-  }
   // -Q for a cached Q: swap (Y+X, Y-X), negate 2dT
   ELL_HD static P cached_cneg(const P& q, bool neg) {
     P r;

@@ -577,9 +577,6 @@ class Engine {
   }
 
   // ---- host-buffer wrappers: stage through device buffers --------------------
-  struct Stage {
-    Engine* e; int slot; void* d = nullptr; void* h = nullptr; size_t bytes = 0;
-  };
   u8* put(int slot, const void* host, size_t bytes) {
     if (!host) return nullptr;
     u8* d = (u8*)staging(slot, bytes ? bytes : 1);

@@ -238,21 +238,6 @@ struct FpK256 {
     fe_sqr_wide<8>(t, a.v);
     return reduce_wide(t);
   }
-  // a * small constant (< 2^32)
-  ELL_HD static El mul_small(const El& a, u32 k) {
-    u32 t[16];
-    u32 carry = 0;
-    ELL_UNROLL
-    for (int i = 0; i < 8; i++) {
-      u64 x = (u64)a.v[i] * k + carry;
-      t[i] = (u32)x;
-      carry = (u32)(x >> 32);
-    }
-    t[8] = carry;
-    ELL_UNROLL
-    for (int i = 9; i < 16; i++) t[i] = 0;
-    return reduce_wide(t);
-  }
   ELL_HD static El sqr_n(El a, int n) {
     ELL_NOUNROLL
     for (int i = 0; i < n; i++) a = sqr(a);
@@ -829,6 +814,121 @@ struct SolP384 {
     u32 y[12] = {0, d, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bn_sub<12>(o, x, y);
   }
+};
+
+// --------------------------------------------------------------------------
+// GF(2^521 - 1) (NIST P-521): Mersenne prime, plain residues in 17 limbs.  The 1042-bit
+// product folds as lo521 + (N >> 521): two shifted add chains, no multiplies.
+// --------------------------------------------------------------------------
+struct FpP521 {
+  typedef consts::P521_P MP;
+  static constexpr int L = 17;
+  typedef Fe<17> El;
+  static constexpr bool HAS_SQRT = true;
+
+  ELL_HD static void get_p(u32 (&p)[17]) {
+    ELL_UNROLL
+    for (int i = 0; i < 16; i++) p[i] = 0xFFFFFFFFu;
+    p[16] = 0x1FFu;
+  }
+  ELL_HD static El zero() { El r; bn_zero<17>(r.v); return r; }
+  ELL_HD static El one() { El r; bn_zero<17>(r.v); r.v[0] = 1; return r; }
+  ELL_HD static bool is_zero(const El& a) { return bn_is_zero<17>(a.v); }
+  ELL_HD static bool eq(const El& a, const El& b) { return bn_eq<17>(a.v, b.v); }
+  ELL_HD static bool is_odd(const El& a) { return a.v[0] & 1; }
+  ELL_HD static void to_plain(u32 (&r)[17], const El& a) { bn_copy<17>(r, a.v); }
+  ELL_HD static El add(const El& a, const El& b) {
+    u32 p[17]; get_p(p);
+    El r; mod_add<17>(r.v, a.v, b.v, p); return r;
+  }
+  ELL_HD static El sub(const El& a, const El& b) {
+    u32 p[17]; get_p(p);
+    El r; mod_sub<17>(r.v, a.v, b.v, p); return r;
+  }
+  ELL_HD static El neg(const El& a) { return sub(zero(), a); }
+  ELL_HD static El dbl(const El& a) { return add(a, a); }
+
+  // value < 2^1088 in 34 limbs -> [0, p)
+  ELL_HD static El reduce_wide(const u32 (&t)[34]) {
+    u32 lo[17], hi[17];
+    ELL_UNROLL
+    for (int i = 0; i < 16; i++) lo[i] = t[i];
+    lo[16] = t[16] & 0x1FFu;
+    ELL_UNROLL
+    for (int i = 0; i < 17; i++) hi[i] = (t[16 + i] >> 9) | (i + 17 < 34 ? t[17 + i] << 23 : 0u);
+    // hi may have up to 544 + ... bits when called from from_plain-sized inputs; for a product of
+    // two residues it is < 2^521
+    u32 r[17];
+    u32 c = bn_add<17>(r, lo, hi);                 // < 2^522 (+ c for oversized inputs)
+    // fold everything from bit 521 up once more
+    u32 f = (r[16] >> 9) | (c << 23);
+    r[16] &= 0x1FFu;
+    u32 cc = 0;
+    r[0] = addc32(r[0], f, cc, cc);
+    ELL_UNROLL
+    for (int i = 1; i < 17; i++) r[i] = addc32(r[i], 0, cc, cc);
+    // now r <= 2^521: one more (rare) fold of bit 521, then r == p -> 0
+    bool top = (r[16] >> 9) != 0;
+    bool allones = true;
+    ELL_UNROLL
+    for (int i = 0; i < 16; i++) allones = allones && (r[i] == 0xFFFFFFFFu);
+    allones = allones && (r[16] == 0x1FFu);
+    if (ELL_UNLIKELY(top || allones)) {
+      if (top) {                                   // r == 2^521  ->  1
+        bn_zero<17>(r);
+        r[0] = 1;
+      } else {
+        bn_zero<17>(r);
+      }
+    }
+    El out;
+    bn_copy<17>(out.v, r);
+    return out;
+  }
+  ELL_HD static El from_plain(const u32 (&a)[17]) {           // a < 2^544
+    u32 t[34];
+    ELL_UNROLL
+    for (int i = 0; i < 34; i++) t[i] = i < 17 ? a[i] : 0u;
+    return reduce_wide(t);
+  }
+  ELL_HD static El mul_inline(const El& a, const El& b) {
+    u32 t[34];
+    fe_mul_wide<17>(t, a.v, b.v);
+    return reduce_wide(t);
+  }
+  ELL_HD static El sqr_inline(const El& a) {
+    u32 t[34];
+    fe_sqr_wide<17>(t, a.v);
+    return reduce_wide(t);
+  }
+  static ELL_HD_NOINLINE El mul_call(El a, El b) { return mul_inline(a, b); }
+  static ELL_HD_NOINLINE El sqr_call(El a) { return sqr_inline(a); }
+  ELL_HD static El mul(const El& a, const El& b) { return mul_call(a, b); }
+  ELL_HD static El sqr(const El& a) { return sqr_call(a); }
+  ELL_HD static El sqr_n(El a, int n) {
+    ELL_NOUNROLL
+    for (int i = 0; i < n; i++) a = sqr(a);
+    return a;
+  }
+  // a^(2^521 - 3) = (a^(2^519 - 1))^4 * a, with f(k) = a^(2^k - 1): f(2k) = f(k)^(2^k) f(k)
+  static ELL_HD_NOINLINE El inv(const El& a) {
+    El f1 = a;
+    El f2 = mul(sqr(f1), f1);
+    El f3 = mul(sqr(f2), a);
+    El f4 = mul(sqr_n(f2, 2), f2);
+    El f7 = mul(sqr_n(f4, 3), f3);
+    El f8 = mul(sqr_n(f4, 4), f4);
+    El f16 = mul(sqr_n(f8, 8), f8);
+    El f32 = mul(sqr_n(f16, 16), f16);
+    El f64 = mul(sqr_n(f32, 32), f32);
+    El f128 = mul(sqr_n(f64, 64), f64);
+    El f256 = mul(sqr_n(f128, 128), f128);
+    El f512 = mul(sqr_n(f256, 256), f256);
+    El f519 = mul(sqr_n(f512, 7), f7);
+    return mul(sqr_n(f519, 2), a);
+  }
+  // (p + 1) / 4 = 2^519: the square root is 519 squarings
+  static ELL_HD_NOINLINE El sqrt(const El& a) { return sqr_n(a, 519); }
 };
 
 }  // namespace ell

@@ -86,6 +86,23 @@ def test_field_ops(hs, field):
         assert _val(r) == pow(a % p, -1, p)
 
 
+def test_p521_from_plain_overrange(hs):
+    """The Mersenne fold must canonicalise any 17-limb input (decompress hands raw 66-byte
+    values to from_plain): p -> 0, 2^521 -> 1, all-ones limbs, ..."""
+    p = FIELDS[15]
+    L = 17
+    rnd = random.Random(77)
+    vals = [p, p + 1, 2 * p, 2 * p + 1, 2 ** 521, 2 ** 522 - 1, 2 ** 528 - 1, 2 ** 544 - 1,
+            2 ** 544 - 2 ** 521, (2 ** 23 - 1) * p, (2 ** 23 - 1) * p + p - 1]
+    vals += [rnd.getrandbits(544) for _ in range(200)]
+    for a in vals:
+        r = (ctypes.c_uint32 * L)()
+        assert hs.hs_field_op(15, 9, _limbs(a, L), _limbs(0, L), r) == 0
+        assert _val(r) == a % p, hex(a)
+        assert hs.hs_field_op(15, 2, _limbs(a, L), _limbs(a, L), r) == 0
+        assert _val(r) == a * a % p, hex(a)
+
+
 def test_glv_split(hs):
     cur = O.get_curve("secp256k1", False)
     lam, n = cur.endo["lambda"], cur.n
