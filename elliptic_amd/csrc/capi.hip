@@ -88,12 +88,21 @@ static int ell_backend_create(int device, ell::HipBackend* bk, std::string* err)
   bk->device = device;
   if (hipStreamCreateWithFlags(&bk->own, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; return ell::E_HIP; }
   bk->cur = bk->own;
+  if (hipStreamCreateWithFlags(&bk->copy, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&bk->own2, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; return ell::E_HIP; }
+  for (int i = 0; i < ell::HipBackend::RING; i++)
+    if (hipEventCreateWithFlags(&bk->ring[i], hipEventDisableTiming) != hipSuccess) { *err = "hipEventCreate failed"; return ell::E_HIP; }
   bk->timed = new std::vector<ell::TimedLaunch>();
   return ell::E_OK;
 }
 static void ell_backend_destroy(ell::HipBackend* bk) {
   if (bk->own) (void)hipStreamDestroy(bk->own);
   bk->own = nullptr;
+  if (bk->copy) (void)hipStreamDestroy(bk->copy);
+  if (bk->own2) (void)hipStreamDestroy(bk->own2);
+  bk->copy = bk->own2 = nullptr;
+  for (int i = 0; i < ell::HipBackend::RING; i++)
+    if (bk->ring[i]) { (void)hipEventDestroy(bk->ring[i]); bk->ring[i] = nullptr; }
   if (bk->timed) {
     for (auto& t : *bk->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     delete bk->timed;

@@ -250,8 +250,9 @@ class Engine {
   ~Engine() {
     for (int i = 0; i < CURVE_COUNT; i++)
       if (comb_[i]) bk.free_(comb_[i]);
-    for (auto& s : scratch_)
-      if (s.p) bk.free_(s.p);
+    for (auto& a : scratch_)
+      for (auto& s : a)
+        if (s.p) bk.free_(s.p);
     for (auto& s : staging_)
       if (s.p) bk.free_(s.p);
   }
@@ -271,7 +272,7 @@ class Engine {
     b.cap = want;
     return b.p;
   }
-  void* scratch(int which, size_t bytes) { return grow(scratch_[which], bytes); }
+  void* scratch(int which, size_t bytes) { return grow(scratch_[lane_][which], bytes); }
   void* staging(int which, size_t bytes) { return grow(staging_[which], bytes); }
 
   int fail(int code, const char* msg) { err = msg; return code; }
@@ -585,6 +586,50 @@ class Engine {
   }
   u8* out_buf(int slot, size_t bytes) { return (u8*)staging(slot, bytes ? bytes : 1); }
 
+  // Host-buffer calls are software-pipelined: the batch is cut into chunks that alternate
+  // between two compute lanes (stream + scratch arena each), so chunk c+1's wavefronts fill
+  // the SIMDs as chunk c's drain (a lone chunk pays ~1 ms of ramp-down at 1 wave round), and
+  // chunk c+1's H2D / chunk c-1's D2H run on the copy stream while chunk c computes.  The
+  // first chunk is one residency quantum so that compute starts early.  body(o, m) launches
+  // items [o, o+m) on the current lane.
+  struct HostIn { u8* dev; const u8* host; size_t stride; };
+  struct HostOut { u8* host; const u8* dev; size_t stride; };
+  template <class Body>
+  int pipelined(size_t n, const HostIn* ins, int nin, const HostOut* outs, int nout, Body body) {
+    size_t q = bk.pipeline_quantum(), step = q;
+    size_t o = 0, po = 0, pm = 0;
+    int pev = -1, rc = E_OK;
+    for (int c = 0; o < n && !rc; c++) {
+      size_t m = n - o;
+      if (m > step + step / 2) m = step;          // a short tail is absorbed by the last chunk
+      for (int i = 0; i < nin; i++)
+        if (ins[i].host)
+          bk.h2d_copy(ins[i].dev + o * ins[i].stride, ins[i].host + o * ins[i].stride, m * ins[i].stride);
+      lane_ = c & 1;
+      bk.select_lane(lane_);
+      bk.copies_before_compute();
+      rc = body(o, m);
+      int ev = bk.mark_compute();
+      if (pev >= 0) {
+        bk.copy_after(pev);
+        for (int i = 0; i < nout; i++)
+          bk.d2h_copy(outs[i].host + po * outs[i].stride, outs[i].dev + po * outs[i].stride, pm * outs[i].stride);
+      }
+      pev = ev; po = o; pm = m;
+      o += m;
+      step = 4 * q;                               // measured: every chunk boundary costs ~0.4 ms
+    }
+    if (pev >= 0 && !rc) {
+      bk.copy_after(pev);
+      for (int i = 0; i < nout; i++)
+        bk.d2h_copy(outs[i].host + po * outs[i].stride, outs[i].dev + po * outs[i].stride, pm * outs[i].stride);
+    }
+    lane_ = 0;
+    bk.select_lane(0);
+    int rs = bk.sync_lanes();
+    return rc ? rc : rs;
+  }
+
   int mul_fixed_host(int curve, size_t n, const u8* k, u8* out_xy, u8* out_inf) {
     const CurveInfo* ci = curve_info(curve);
     if (!ci) return fail(E_ARG, "unknown curve id");
@@ -605,16 +650,16 @@ class Engine {
     if (!ci) return fail(E_ARG, "unknown curve id");
     if (n && (!k || !xy || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
     size_t B = ci->field_bytes;
-    u8* dk = put(G_IN0, k, n * B);
-    u8* dp = put(G_IN1, xy, n * 2 * B);
+    u8* dk = out_buf(G_IN0, n * B);
+    u8* dp = out_buf(G_IN1, n * 2 * B);
     u8* dxy = out_buf(G_OUT0, n * 2 * B);
     u8* dinf = out_buf(G_OUT1, n);
     if (!dk || !dp || !dxy || !dinf) return fail(E_NOMEM, "staging allocation failed");
-    int rc = mul_var_dev(curve, n, dk, dp, dxy, dinf);
-    if (rc) return rc;
-    bk.d2h(out_xy, dxy, n * 2 * B);
-    bk.d2h(out_inf, dinf, n);
-    return bk.sync();
+    HostIn ins[2] = {{dk, k, B}, {dp, xy, 2 * B}};
+    HostOut outs[2] = {{out_xy, dxy, 2 * B}, {out_inf, dinf, 1}};
+    return pipelined(n, ins, 2, outs, 2, [&](size_t o, size_t m) {
+      return mul_var_dev(curve, m, dk + o * B, dp + o * 2 * B, dxy + o * 2 * B, dinf + o);
+    });
   }
   int mul_add2_host(int curve, size_t n, const u8* k1, const u8* xy1, const u8* k2,
                     const u8* xy2, u8* out_xy, u8* out_inf) {
@@ -622,19 +667,20 @@ class Engine {
     if (!ci) return fail(E_ARG, "unknown curve id");
     if (n && (!k1 || !k2 || !xy2 || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
     size_t B = ci->field_bytes;
-    u8* d1 = put(G_IN0, k1, n * B);
-    u8* dp1 = xy1 ? put(G_IN1, xy1, n * 2 * B) : nullptr;
-    u8* d2 = put(G_IN2, k2, n * B);
-    u8* dp2 = put(G_IN3, xy2, n * 2 * B);
+    u8* d1 = out_buf(G_IN0, n * B);
+    u8* dp1 = xy1 ? out_buf(G_IN1, n * 2 * B) : nullptr;
+    u8* d2 = out_buf(G_IN2, n * B);
+    u8* dp2 = out_buf(G_IN3, n * 2 * B);
     u8* dxy = out_buf(G_OUT0, n * 2 * B);
     u8* dinf = out_buf(G_OUT1, n);
     if (!d1 || !d2 || !dp2 || !dxy || !dinf || (xy1 && !dp1))
       return fail(E_NOMEM, "staging allocation failed");
-    int rc = mul_add2_dev(curve, n, d1, dp1, d2, dp2, dxy, dinf);
-    if (rc) return rc;
-    bk.d2h(out_xy, dxy, n * 2 * B);
-    bk.d2h(out_inf, dinf, n);
-    return bk.sync();
+    HostIn ins[4] = {{d1, k1, B}, {dp1, xy1, 2 * B}, {d2, k2, B}, {dp2, xy2, 2 * B}};
+    HostOut outs[2] = {{out_xy, dxy, 2 * B}, {out_inf, dinf, 1}};
+    return pipelined(n, ins, 4, outs, 2, [&](size_t o, size_t m) {
+      return mul_add2_dev(curve, m, d1 + o * B, dp1 ? dp1 + o * 2 * B : nullptr, d2 + o * B,
+                          dp2 + o * 2 * B, dxy + o * 2 * B, dinf + o);
+    });
   }
   int ecdsa_verify_host(int curve, size_t n, const u8* hash, int hash_len, int msg_bits,
                         const u8* r, const u8* s, const u8* pub, u8* ok) {
@@ -643,29 +689,32 @@ class Engine {
     if (n && (!hash || !r || !s || !pub || !ok)) return fail(E_ARG, "null pointer");
     if (hash_len <= 0) return fail(E_ARG, "bad hash_len");
     size_t B = ci->field_bytes, NB = ci->order_bytes;
-    u8* dh = put(G_IN0, hash, n * (size_t)hash_len);
-    u8* dr = put(G_IN1, r, n * NB);
-    u8* dsg = put(G_IN2, s, n * NB);
-    u8* dq = put(G_IN3, pub, n * 2 * B);
+    size_t HL = (size_t)hash_len;
+    u8* dh = out_buf(G_IN0, n * HL);
+    u8* dr = out_buf(G_IN1, n * NB);
+    u8* dsg = out_buf(G_IN2, n * NB);
+    u8* dq = out_buf(G_IN3, n * 2 * B);
     u8* dok = out_buf(G_OUT0, n);
     if (!dh || !dr || !dsg || !dq || !dok) return fail(E_NOMEM, "staging allocation failed");
-    int rc = ecdsa_verify_dev(curve, n, dh, hash_len, msg_bits, dr, dsg, dq, dok);
-    if (rc) return rc;
-    bk.d2h(ok, dok, n);
-    return bk.sync();
+    HostIn ins[4] = {{dh, hash, HL}, {dr, r, NB}, {dsg, s, NB}, {dq, pub, 2 * B}};
+    HostOut outs[1] = {{ok, dok, 1}};
+    return pipelined(n, ins, 4, outs, 1, [&](size_t o, size_t m) {
+      return ecdsa_verify_dev(curve, m, dh + o * HL, hash_len, msg_bits, dr + o * NB, dsg + o * NB,
+                              dq + o * 2 * B, dok + o);
+    });
   }
   int x25519_host(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf) {
     if (n && (!k || !x || !out_x || !out_inf)) return fail(E_ARG, "null pointer");
-    u8* dk = put(G_IN0, k, n * 32);
-    u8* dx = put(G_IN1, x, n * 32);
+    u8* dk = out_buf(G_IN0, n * 32);
+    u8* dx = out_buf(G_IN1, n * 32);
     u8* dox = out_buf(G_OUT0, n * 32);
     u8* dinf = out_buf(G_OUT1, n);
     if (!dk || !dx || !dox || !dinf) return fail(E_NOMEM, "staging allocation failed");
-    int rc = x25519_dev(n, dk, dx, dox, dinf);
-    if (rc) return rc;
-    bk.d2h(out_x, dox, n * 32);
-    bk.d2h(out_inf, dinf, n);
-    return bk.sync();
+    HostIn ins[2] = {{dk, k, 32}, {dx, x, 32}};
+    HostOut outs[2] = {{out_x, dox, 32}, {out_inf, dinf, 1}};
+    return pipelined(n, ins, 2, outs, 2, [&](size_t o, size_t m) {
+      return x25519_dev(m, dk + o * 32, dx + o * 32, dox + o * 32, dinf + o);
+    });
   }
 
   int reserve(int curve, size_t n) {
@@ -686,7 +735,8 @@ class Engine {
 
  private:
   void* comb_[CURVE_COUNT];
-  Buf scratch_[S_COUNT];
+  Buf scratch_[2][S_COUNT];   // one scratch arena per compute lane (see pipelined())
+  int lane_ = 0;
   Buf staging_[G_COUNT];
 };
 

@@ -42,6 +42,11 @@ struct HipBackend {
   int device = 0;
   hipStream_t own = nullptr;       // the context's stream
   hipStream_t cur = nullptr;       // stream used by the current call
+  hipStream_t own2 = nullptr;      // second compute lane of the host-buffer entry points
+  hipStream_t copy = nullptr;      // H2D / D2H of the host-buffer entry points
+  static constexpr int RING = 8;
+  hipEvent_t ring[RING] = {};      // cross-stream dependencies (reused round-robin)
+  unsigned ring_i = 0;
   int last = 0;                    // sticky hipError_t of the current call
   bool timing = false;             // record HIP events around every launch
   std::vector<TimedLaunch>* timed = nullptr;
@@ -69,6 +74,37 @@ struct HipBackend {
   }
   int sync() {
     note(hipStreamSynchronize(cur ? cur : own));
+    return last ? E_HIP : E_OK;
+  }
+  // ---- copy stream for the pipelined host-buffer entry points (Engine::pipelined) ----
+  // items resident in one round of wavefronts at 3 waves/SIMD (256 CUs x 4 SIMDs x 3 x 64)
+  static size_t pipeline_quantum() { return (size_t)256 * 4 * 3 * 64; }
+  void h2d_copy(void* d, const void* h, size_t bytes) {
+    if (bytes) note(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, copy));
+  }
+  void d2h_copy(void* h, const void* d, size_t bytes) {
+    if (bytes) note(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, copy));
+  }
+  // the compute stream waits for every copy queued so far
+  void copies_before_compute() {
+    hipEvent_t e = ring[ring_i++ % RING];
+    note(hipEventRecord(e, copy));
+    note(hipStreamWaitEvent(cur, e, 0));
+  }
+  // returns a handle for "everything launched on the compute stream so far"
+  int mark_compute() {
+    int i = ring_i++ % RING;
+    note(hipEventRecord(ring[i], cur));
+    return i;
+  }
+  void copy_after(int ev) { note(hipStreamWaitEvent(copy, ring[ev], 0)); }
+  // compute lane 0 = the context's stream, lane 1 = a second stream for alternate chunks
+  void select_lane(int lane) { cur = lane ? own2 : own; }
+  // wait for the copy stream and both lanes
+  int sync_lanes() {
+    note(hipStreamSynchronize(copy));
+    note(hipStreamSynchronize(own2));
+    note(hipStreamSynchronize(own));
     return last ? E_HIP : E_OK;
   }
   template <class Fn>

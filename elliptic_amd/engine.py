@@ -92,14 +92,20 @@ class Context:
                                                out.ctypes.data, inf.ctypes.data))
         return out, inf
 
-    def mul_var(self, curve, k, xy):
+    def mul_var(self, curve, k, xy, out=None):
+        """out: optional (xy, inf) uint8 arrays to write into (reusing result buffers spares a
+        large batch the page faults of freshly allocated memory)."""
         B = FIELD_BYTES[curve]
         k = _u8(k, (-1, B))
         xy = _u8(xy, (-1, 2 * B))
         n = k.shape[0]
         assert xy.shape[0] == n
-        out = np.zeros((n, 2 * B), np.uint8)
-        inf = np.zeros(n, np.uint8)
+        if out is None:
+            out, inf = np.zeros((n, 2 * B), np.uint8), np.zeros(n, np.uint8)
+        else:
+            out, inf = out
+            assert out.dtype == np.uint8 and out.shape == (n, 2 * B) and out.flags.c_contiguous
+            assert inf.dtype == np.uint8 and inf.shape == (n,) and inf.flags.c_contiguous
         self._check(self._lib.ellgpu_mul_var(self._ctx, self._cid(curve), n, k.ctypes.data,
                                              xy.ctypes.data, out.ctypes.data, inf.ctypes.data))
         return out, inf

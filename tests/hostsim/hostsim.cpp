@@ -25,6 +25,15 @@ struct LoopBackend {
   void h2d(void* d, const void* h, size_t bytes) { memcpy(d, h, bytes); }
   void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
   int sync() { return 0; }
+  // Engine::pipelined: tiny quantum so that ordinary test batches are cut into several chunks
+  static size_t pipeline_quantum() { return 8; }
+  void h2d_copy(void* d, const void* h, size_t bytes) { memcpy(d, h, bytes); }
+  void d2h_copy(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
+  void copies_before_compute() {}
+  int mark_compute() { return 0; }
+  void copy_after(int) {}
+  void select_lane(int) {}
+  int sync_lanes() { return 0; }
   // "threads" of a launch are independent, so the loop is split over the host
   // cores (only to keep the CPU test-suite short)
   template <class Fn>

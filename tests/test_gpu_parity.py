@@ -217,8 +217,17 @@ def test_full_size_verify_mask_and_device_api(ctx):
     got = ok.cpu().numpy()
     assert np.array_equal(got, expect)
     assert int(expect.sum()) == n - (n + 99) // 100
-    m = 5000
-    assert np.array_equal(ctx.ecdsa_verify("secp256k1", h[:m], r[:m], s[:m], pub[:m]), expect[:m])
+    # host-buffer entry point: pipelined in chunks over two lanes + a copy stream; cut sizes
+    # around the residency quantum (196608 items) must not change the mask
+    for m in (5000, 196608 + 7, 300000, n):
+        assert np.array_equal(ctx.ecdsa_verify("secp256k1", h[:m], r[:m], s[:m], pub[:m]), expect[:m]), m
+    m = 700001
+    xy_h, inf_h = ctx.mul_var("secp256k1", r[:m], pub[:m])
+    xy_d = torch.zeros((m, 64), dtype=torch.uint8, device=dev)
+    inf_d = torch.zeros(m, dtype=torch.uint8, device=dev)
+    ctx.mul_var_dev("secp256k1", t[1][:m], t[3][:m], xy_d, inf_d)
+    torch.cuda.synchronize()
+    assert np.array_equal(xy_h, xy_d.cpu().numpy()) and np.array_equal(inf_h, inf_d.cpu().numpy())
     cur = O.get_curve("secp256k1")
     rnd = random.Random(77)
     for i in [0, 100, 200, 300] + [rnd.randrange(n) for _ in range(300)]:

@@ -170,6 +170,48 @@ def test_eddsa_verify_golden(ctx):
     assert PC.check_eddsa_golden(ctx) > 200
 
 
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 13, 41, 203])
+def test_host_pipeline_chunks(ctx, n):
+    """The host-buffer entry points cut a batch into chunks on two alternating lanes (the
+    hostsim quantum is 8 items, so these sizes give 1..7 chunks incl. an absorbed tail);
+    results must not depend on the cut.  Checked against the C oracle item by item."""
+    from oracle import c_oracle
+    rnd = np.random.default_rng(1234 + n)
+    d = rnd.integers(0, 256, (n, 32), dtype=np.uint8)
+    k = rnd.integers(0, 256, (n, 32), dtype=np.uint8)
+    k2 = rnd.integers(0, 256, (n, 32), dtype=np.uint8)
+    k[0] = 0                                     # infinity in the first chunk
+    pts, inf = c_oracle.mul("secp256k1", d)
+    assert not inf.any()
+    want = c_oracle.mul("secp256k1", k, pts)
+    got = ctx.mul_var("secp256k1", k, pts)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+    bufs = (np.full((n, 64), 0xAA, np.uint8), np.full(n, 0xAA, np.uint8))
+    got = ctx.mul_var("secp256k1", k, pts, out=bufs)
+    assert got[0] is bufs[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+    want = c_oracle.mul_add("secp256k1", k, None, k2, pts)
+    got = ctx.mul_add2("secp256k1", k, None, k2, pts)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+    want = c_oracle.mul_add("secp256k1", k, pts[::-1].copy(), k2, pts)
+    got = ctx.mul_add2("secp256k1", k, pts[::-1].copy(), k2, pts)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+    # verify: valid signatures built from the oracle's own k*G, every third one corrupted
+    N = int(O.get_curve("secp256k1", False).n)
+    ds = [int.from_bytes(row.tobytes(), "big") % (N - 1) + 1 for row in d]
+    ks = [int.from_bytes(row.tobytes(), "big") % (N - 1) + 1 for row in k2]
+    ss = [int.from_bytes(row.tobytes(), "big") % (N - 1) + 1 for row in rnd.integers(0, 256, (n, 32), dtype=np.uint8)]
+    pub, _ = c_oracle.mul("secp256k1", elliptic_amd.ints_to_be(ds, 32))
+    R, _ = c_oracle.mul("secp256k1", elliptic_amd.ints_to_be(ks, 32))
+    rs = [int.from_bytes(R[i, :32].tobytes(), "big") % N for i in range(n)]
+    zs = [(ss[i] * ks[i] - rs[i] * ds[i]) % N for i in range(n)]
+    h, r, s_ = (elliptic_amd.ints_to_be(v, 32) for v in (zs, rs, ss))
+    h[::3, 31] ^= 1
+    want = c_oracle.verify("secp256k1", h, r, s_, pub)
+    got = ctx.ecdsa_verify("secp256k1", h, r, s_, pub)
+    assert np.array_equal(got, want)
+    assert want[1::3].all() and not want[::3].any()
+
+
 def test_error_paths(ctx, hs):
     with pytest.raises(elliptic_amd.EllgpuError):
         ctx.mul_fixed("curve25519", np.zeros((1, 32), np.uint8))

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive throughput of the host-buffer entry points (what the N-API addon and any
+other FFI caller sees): ellgpu_ecdsa_verify / ellgpu_mul_var on pageable numpy buffers,
+H2D + kernels + D2H inside the timed region.  GPU box only; never bench.py's `value`.
+
+    python tools/bench_host_path.py [--n 1048576] [--reps 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import bench
+import elliptic_amd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=1 << 20)
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    ctx = elliptic_amd.Context(0)
+    hz, hr, hs, hq, want = bench.make_signatures(ctx, a.n, "host-path")
+
+    def timed(name, fn, check):
+        out = fn()
+        assert check(out), name + ": parity"
+        t = []
+        for _ in range(a.reps):
+            t0 = time.perf_counter()
+            fn()
+            t.append(time.perf_counter() - t0)
+        best, mean = min(t), sum(t) / len(t)
+        print(json.dumps({"config": name, "n": a.n, "items_per_s_best": a.n / best,
+                          "items_per_s_mean": a.n / mean, "ms_best": best * 1e3}), flush=True)
+
+    timed("secp256k1 ecdsa_verify, host buffers (H2D 160 B + D2H 1 B per item)",
+          lambda: ctx.ecdsa_verify("secp256k1", hz, hr, hs, hq),
+          lambda ok: np.array_equal(np.asarray(ok).astype(np.uint8), want.astype(np.uint8)))
+    xy0, inf0 = ctx.mul_var("secp256k1", hr, hq)
+    timed("secp256k1 mul_var, host buffers (H2D 96 B + D2H 65 B per item)",
+          lambda: ctx.mul_var("secp256k1", hr, hq),
+          lambda o: np.array_equal(o[0], xy0) and np.array_equal(o[1], inf0))
+    bufs = (np.zeros_like(xy0), np.zeros_like(inf0))
+    timed("secp256k1 mul_var, host buffers, result buffers reused",
+          lambda: ctx.mul_var("secp256k1", hr, hq, out=bufs),
+          lambda o: np.array_equal(o[0], xy0) and np.array_equal(o[1], inf0))
+
+
+if __name__ == "__main__":
+    main()
