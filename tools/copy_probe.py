@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""H2D / D2H rates for pageable, pinned and freshly allocated host memory on the GPU box
+(background for Engine::pipelined).  GPU box only.
+
+    python tools/copy_probe.py
+"""
 import time, sys, os
 import numpy as np, torch
 def t(fn, reps=5):
