@@ -433,6 +433,62 @@ struct Fp25519 {
 };
 
 // --------------------------------------------------------------------------
+// a^e for a compile-time constant exponent: left-to-right sliding window over odd powers
+// a, a^3, ..., a^(2^W - 1) (W = 4 up to 8 limbs, 3 above: the table lives in VGPRs).  The
+// exponent is the same for every lane, so window scanning is scalar work and the choice of
+// table entry is a uniform branch, not divergence.  ~L*32 squarings + L*32/(W+1) multiplies
+// against L*32 + popcount(e) for plain square-and-multiply (the NIST primes and group orders
+// are mostly one bits).
+// --------------------------------------------------------------------------
+template <class F, int L>
+ELL_HD typename F::El pow_const_window(const typename F::El& a, const u32 (&e)[L]) {
+  typedef typename F::El El;
+  constexpr int W = L <= 8 ? 4 : 3;
+  constexpr int T = 1 << (W - 1);
+  El tbl[T];
+  tbl[0] = a;
+  {
+    El a2 = F::sqr(a);
+    ELL_UNROLL
+    for (int i = 1; i < T; i++) tbl[i] = F::mul(tbl[i - 1], a2);
+  }
+  El r = F::one();
+  bool started = false;
+  int i = 32 * L - 1;
+  ELL_NOUNROLL
+  while (i >= 0) {
+    if (!((e[i >> 5] >> (i & 31)) & 1u)) {
+      if (started) r = F::sqr(r);
+      i--;
+      continue;
+    }
+    int j = i - W + 1 < 0 ? 0 : i - W + 1;
+    while (!((e[j >> 5] >> (j & 31)) & 1u)) j++;          // window [i..j] ends in a one bit
+    u32 val = 0;
+    for (int b = i; b >= j; b--) val = (val << 1) | ((e[b >> 5] >> (b & 31)) & 1u);
+    if (started) {
+      ELL_NOUNROLL
+      for (int b = i; b >= j; b--) r = F::sqr(r);
+    }
+    El m;
+    switch (val >> 1) {                                     // uniform: a scalar branch
+      case 0: m = tbl[0]; break;
+      case 1: m = tbl[1]; break;
+      case 2: m = tbl[2]; break;
+      case 3: m = tbl[3]; break;
+      case 4: m = tbl[T > 4 ? 4 : 0]; break;
+      case 5: m = tbl[T > 4 ? 5 : 0]; break;
+      case 6: m = tbl[T > 4 ? 6 : 0]; break;
+      default: m = tbl[T > 4 ? 7 : 0]; break;
+    }
+    r = started ? F::mul(r, m) : m;
+    started = true;
+    i = j - 1;
+  }
+  return r;
+}
+
+// --------------------------------------------------------------------------
 // Generic odd modulus, Montgomery form.  P supplies:
 //   static constexpr int L; u32 p[L]; u32 n0 (= -p^-1 mod 2^32);
 //   u32 one[L] (= R mod p); u32 r2[L] (= R^2 mod p); u32 pm2[L] (= p - 2)
@@ -609,29 +665,9 @@ struct FpMont {
   }
   // a^((p+1)/4): square root for p = 3 (mod 4) (bn.js Red#sqrt takes the same power)
   static constexpr bool HAS_SQRT = P::P3MOD4;
-  static ELL_HD_NOINLINE El sqrt(const El& a) {
-    El r = one();
-    ELL_NOUNROLL
-    for (int w = 32 * L - 1; w >= 0; w--) {
-      r = sqr(r);
-      u32 bit = (P::pp1d4[w >> 5] >> (w & 31)) & 1u;
-      if (bit) r = mul(r, a);
-    }
-    return r;
-  }
-  // a^(p-2), left-to-right binary over the constant exponent.  The exponent
-  // bit is wave-uniform, so the multiply is a scalar branch, not divergence.
-  // (Amortised over a whole batch by Montgomery's trick, see normalize.)
-  static ELL_HD_NOINLINE El inv(const El& a) {
-    El r = one();
-    ELL_NOUNROLL
-    for (int w = 32 * L - 1; w >= 0; w--) {
-      r = sqr(r);
-      u32 bit = (P::pm2[w >> 5] >> (w & 31)) & 1u;
-      if (bit) r = mul(r, a);
-    }
-    return r;
-  }
+  static ELL_HD_NOINLINE El sqrt(const El& a) { return pow_const_window<FpMont<P>, L>(a, P::pp1d4); }
+  // a^(p-2) (amortised over a whole batch by Montgomery's trick, see normalize)
+  static ELL_HD_NOINLINE El inv(const El& a) { return pow_const_window<FpMont<P>, L>(a, P::pm2); }
 };
 
 // --------------------------------------------------------------------------
@@ -748,18 +784,8 @@ struct FpSolinas {
     for (int i = 0; i < n; i++) a = sqr(a);
     return a;
   }
-  ELL_HD static El pow_const(const El& a, const u32 (&e)[L]) {
-    El r = one();
-    ELL_NOUNROLL
-    for (int w = 32 * L - 1; w >= 0; w--) {
-      r = sqr(r);
-      u32 bit = (e[w >> 5] >> (w & 31)) & 1u;
-      if (bit) r = mul(r, a);
-    }
-    return r;
-  }
-  static ELL_HD_NOINLINE El inv(const El& a) { return pow_const(a, MP::pm2); }
-  static ELL_HD_NOINLINE El sqrt(const El& a) { return pow_const(a, MP::pp1d4); }
+  static ELL_HD_NOINLINE El inv(const El& a) { return pow_const_window<FpSolinas<R>, L>(a, MP::pm2); }
+  static ELL_HD_NOINLINE El sqrt(const El& a) { return pow_const_window<FpSolinas<R>, L>(a, MP::pp1d4); }
 };
 
 // p256 = 2^256 - 2^224 + 2^192 + 2^96 - 1  (FIPS 186-4 D.2.3):
