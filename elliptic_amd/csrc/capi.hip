@@ -40,6 +40,41 @@ __global__ void __launch_bounds__(256) k_probe(u32* out, int iters, u32 seed) {
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = (u32)s ^ (u32)(s >> 32);
 }
 
+// ---- field-layer throughput probe: `iters` dependent secp256k1 field / group operations per
+// lane, one wavefront per workgroup so that `blocks` sets the number of resident waves per
+// SIMD (1024 blocks = 1 wave on each SIMD).  kind: 10 mul chain, 11 sqr chain, 12 two
+// interleaved mul chains, 13 add+sub chain, 14 Jacobian doubling chain, 15 mixed-add chain.
+template <int KIND>
+__global__ void __launch_bounds__(64) k_probe_field(u32* out, int iters, u32 seed) {
+  typedef FpK256 F;
+  typedef ShortOps<CvSecp256k1> G;
+  F::El x, y, z;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    x.v[i] = seed * (i + 1) + threadIdx.x * 2654435761u;
+    y.v[i] = (seed ^ 0x9E3779B9u) * (i + 3) + threadIdx.x;
+    z.v[i] = seed + i * 0x1234567u + threadIdx.x * 7u;
+  }
+  x.v[7] &= 0x7FFFFFFFu; y.v[7] &= 0x7FFFFFFFu; z.v[7] &= 0x7FFFFFFFu;
+  G::J p;
+  p.X = x; p.Y = y; p.Z = z;
+  G::A q;
+  q.x = y; q.y = z;
+#pragma nounroll
+  for (int it = 0; it < iters; it++) {
+    if (KIND == 10) x = F::mul(x, y);
+    else if (KIND == 11) x = F::sqr(x);
+    else if (KIND == 12) { x = F::mul(x, y); z = F::mul(z, y); }
+    else if (KIND == 13) { x = F::add(x, y); x = F::sub(x, z); }
+    else if (KIND == 14) p = G::dbl(p);
+    else p = G::add_mixed(p, q);
+  }
+  u32 acc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc ^= x.v[i] ^ z.v[i] ^ p.X.v[i] ^ p.Y.v[i] ^ p.Z.v[i];
+  out[(size_t)blockIdx.x * 64 + threadIdx.x] = acc;
+}
+
 // ---- white-box probe: one field operation per lane (tests/test_gpu_field.py) ----
 template <class F>
 __global__ void k_field_op(int op, size_t n, const u32* a, const u32* b, u32* r) {
@@ -128,7 +163,15 @@ extern "C" int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iter
       case 0: hipLaunchKernelGGL(ell::k_probe<0>, dim3(blocks), dim3(256), 0, bk.cur, out, iters, 12345u); break;
       case 1: hipLaunchKernelGGL(ell::k_probe<1>, dim3(blocks), dim3(256), 0, bk.cur, out, iters, 12345u); break;
       case 2: hipLaunchKernelGGL(ell::k_probe<2>, dim3(blocks), dim3(256), 0, bk.cur, out, iters, 12345u); break;
-      default: hipLaunchKernelGGL(ell::k_probe<3>, dim3(blocks), dim3(256), 0, bk.cur, out, iters, 12345u); break;
+      case 3: hipLaunchKernelGGL(ell::k_probe<3>, dim3(blocks), dim3(256), 0, bk.cur, out, iters, 12345u); break;
+      case 10: hipLaunchKernelGGL(ell::k_probe_field<10>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 11: hipLaunchKernelGGL(ell::k_probe_field<11>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 12: hipLaunchKernelGGL(ell::k_probe_field<12>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 13: hipLaunchKernelGGL(ell::k_probe_field<13>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 14: hipLaunchKernelGGL(ell::k_probe_field<14>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 15: hipLaunchKernelGGL(ell::k_probe_field<15>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      default: bk.free_(out); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+               return set_err(ELLGPU_E_ARG, "unknown probe kind");
     }
     (void)hipEventRecord(e1, bk.cur);
     (void)hipEventSynchronize(e1);
@@ -139,7 +182,8 @@ extern "C" int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iter
   (void)hipEventDestroy(e1);
   bk.free_(out);
   *ms_out = ms;
-  *ops_out = (double)blocks * 256.0 * (double)iters * 16.0;
+  *ops_out = kind < 10 ? (double)blocks * 256.0 * (double)iters * 16.0
+                       : (double)blocks * 64.0 * (double)iters * (kind == 12 || kind == 13 ? 2.0 : 1.0);
   return finish(ctx, bk.sync());
 }
 

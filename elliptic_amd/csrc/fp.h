@@ -145,8 +145,10 @@ struct FpK256 {
   ELL_HD static bool is_odd(const El& a) { return a.v[0] & 1; }
 
   // a + b mod p with p = 2^256 - delta, delta = 2^32 + 977: when the 256-bit sum carries out,
-  // subtracting p is adding delta (and the result is then < p - 1, no second carry); without a
-  // carry the sum is canonical unless it lies in [p, 2^256) -- rare, behind a branch.
+  // subtracting p is adding delta to the two low limbs (the result is then < p - 1, no second
+  // carry out).  Everything beyond that is rare for every lane of a wave and sits behind one
+  // branch: a carry out of limb 1 (needs limb 1 of the sum = 2^32 - 1) that has to ripple
+  // through limbs 2..7, and a carry-less sum in [p, 2^256) (needs limb 7 = 2^32 - 1).
   ELL_HD static El add(const El& a, const El& b) {
     u32 t[8];
     u32 c = bn_add<8>(t, a.v, b.v);
@@ -156,12 +158,22 @@ struct FpK256 {
     r.v[0] = addc32(t[0], d0, cc, cc);
     r.v[1] = addc32(t[1], d1, cc, cc);
     ELL_UNROLL
-    for (int i = 2; i < 8; i++) r.v[i] = addc32(t[i], 0, cc, cc);
-    u32 p[8]; get_p(p);
-    cond_sub_rare<8>(r.v, 0, p);
+    for (int i = 2; i < 8; i++) r.v[i] = t[i];
+    if (ELL_UNLIKELY(cc != 0 || t[7] == 0xFFFFFFFFu)) {
+      ELL_UNROLL
+      for (int i = 2; i < 8; i++) r.v[i] = addc32(t[i], 0, cc, cc);
+      if (c == 0) {                       // no fold happened: the sum may lie in [p, 2^256)
+        u32 p[8]; get_p(p);
+        u32 s[8];
+        u32 br = bn_sub<8>(s, r.v, p);
+        ELL_UNROLL
+        for (int i = 0; i < 8; i++) r.v[i] = br ? r.v[i] : s[i];
+      }
+    }
     return r;
   }
-  // a - b mod p: on borrow, adding p is subtracting delta; the result is canonical either way
+  // a - b mod p: on borrow, adding p is subtracting delta from the two low limbs; a borrow out
+  // of limb 1 (rare) ripples through limbs 2..7.  The result is canonical either way.
   ELL_HD static El sub(const El& a, const El& b) {
     u32 t[8];
     u32 bw = bn_sub<8>(t, a.v, b.v);
@@ -171,7 +183,11 @@ struct FpK256 {
     r.v[0] = subb32(t[0], d0, bb, bb);
     r.v[1] = subb32(t[1], d1, bb, bb);
     ELL_UNROLL
-    for (int i = 2; i < 8; i++) r.v[i] = subb32(t[i], 0, bb, bb);
+    for (int i = 2; i < 8; i++) r.v[i] = t[i];
+    if (ELL_UNLIKELY(bb != 0)) {
+      ELL_UNROLL
+      for (int i = 2; i < 8; i++) r.v[i] = subb32(t[i], 0, bb, bb);
+    }
     return r;
   }
   ELL_HD static El neg(const El& a) { return sub(zero(), a); }
@@ -214,18 +230,25 @@ struct FpK256 {
     u32 cy;
     t1 = addc32(t1, u[8], 0, cy);
     u32 t2 = u[9] + cy;
-    u32 r[8];
-    c = 0;
-    r[0] = addc32(u[0], t0, c, c);
-    r[1] = addc32(u[1], t1, c, c);
-    r[2] = addc32(u[2], t2, c, c);
-    ELL_UNROLL
-    for (int i = 3; i < 8; i++) r[i] = addc32(u[i], 0, c, c);
-    // value = c*2^256 + r  < 2^256 + 2^67: subtract p once if needed (rare)
-    u32 p[8]; get_p(p);
-    cond_sub_rare<8>(r, c, p);
     El out;
-    bn_copy<8>(out.v, r);
+    c = 0;
+    out.v[0] = addc32(u[0], t0, c, c);
+    out.v[1] = addc32(u[1], t1, c, c);
+    out.v[2] = addc32(u[2], t2, c, c);
+    ELL_UNROLL
+    for (int i = 3; i < 8; i++) out.v[i] = u[i];
+    // t2 <= 4, so a carry out of limb 2 is rare, and so is a value in [p, 2^256) (needs limb 7
+    // = 2^32 - 1): ripple / subtract p behind one branch.  value = c*2^256 + r < 2^256 + 2^67.
+    if (ELL_UNLIKELY(c != 0 || u[7] == 0xFFFFFFFFu)) {
+      ELL_UNROLL
+      for (int i = 3; i < 8; i++) out.v[i] = addc32(u[i], 0, c, c);
+      u32 p[8]; get_p(p);
+      u32 s[8];
+      u32 br = bn_sub<8>(s, out.v, p);
+      bool take = (c != 0) || (br == 0);
+      ELL_UNROLL
+      for (int i = 0; i < 8; i++) out.v[i] = take ? s[i] : out.v[i];
+    }
     return out;
   }
   ELL_HD static El mul(const El& a, const El& b) {
@@ -320,13 +343,47 @@ struct Fp25519 {
   ELL_HD static bool is_zero(const El& a) { return bn_is_zero<8>(a.v); }
   ELL_HD static bool eq(const El& a, const El& b) { return bn_eq<8>(a.v, b.v); }
   ELL_HD static bool is_odd(const El& a) { return a.v[0] & 1; }
-  ELL_HD static El add(const El& a, const El& b) {
-    u32 p[8]; get_p(p);
-    El r; mod_add<8>(r.v, a.v, b.v, p); return r;
+  // r = u + add0 for u < 2^255 and a small add0, canonicalised: the carry out of limb 0 and a
+  // value in [p, 2^255 + add0) (needs limbs 1..6 all ones) are both rare for every lane of a
+  // wave, so the ripple and the final subtraction sit behind one branch.
+  ELL_HD static El finish(const u32 (&u)[8], u32 add0) {
+    El r;
+    u32 c = 0;
+    r.v[0] = addc32(u[0], add0, c, c);
+    ELL_UNROLL
+    for (int i = 1; i < 8; i++) r.v[i] = u[i];
+    if (ELL_UNLIKELY(c != 0 || u[7] == 0x7FFFFFFFu)) {
+      ELL_UNROLL
+      for (int i = 1; i < 8; i++) r.v[i] = addc32(u[i], 0, c, c);
+      r = from_plain(r.v);
+    }
+    return r;
   }
+  // a + b < 2^256: fold bit 255 (2^255 == 19); the sum is < 2p, so one fold canonicalises it
+  // except for the 19 values in [p, 2^255) (rare, see finish)
+  ELL_HD static El add(const El& a, const El& b) {
+    u32 t[8];
+    bn_add<8>(t, a.v, b.v);
+    u32 top = t[7] >> 31;
+    t[7] &= 0x7FFFFFFFu;
+    return finish(t, top ? 19u : 0u);
+  }
+  // a - b: on borrow the wrapped difference is v + 2^256 with bit 255 set, and v + p is that
+  // minus 2^255 minus 19
   ELL_HD static El sub(const El& a, const El& b) {
-    u32 p[8]; get_p(p);
-    El r; mod_sub<8>(r.v, a.v, b.v, p); return r;
+    u32 t[8];
+    u32 bw = bn_sub<8>(t, a.v, b.v);
+    t[7] &= 0x7FFFFFFFu;                         // bit 255 is set exactly when bw is
+    El r;
+    u32 bb = 0;
+    r.v[0] = subb32(t[0], bw ? 19u : 0u, bb, bb);
+    ELL_UNROLL
+    for (int i = 1; i < 8; i++) r.v[i] = t[i];
+    if (ELL_UNLIKELY(bb != 0)) {
+      ELL_UNROLL
+      for (int i = 1; i < 8; i++) r.v[i] = subb32(t[i], 0, bb, bb);
+    }
+    return r;
   }
   ELL_HD static El neg(const El& a) { return sub(zero(), a); }
   ELL_HD static El dbl(const El& a) { return add(a, a); }
@@ -354,14 +411,7 @@ struct Fp25519 {
     // fold carry*2^256 == carry*38, and bit 255 == 19, in one pass
     u32 top = u[7] >> 31;
     u[7] &= 0x7FFFFFFFu;
-    u32 add0 = carry * 38u + 19u * top;
-    u32 r[8];
-    c = 0;
-    r[0] = addc32(u[0], add0, c, c);
-    ELL_UNROLL
-    for (int i = 1; i < 8; i++) r[i] = addc32(u[i], 0, c, c);
-    // r < 2^255 + 2^12: at most one more bit-255 fold, then one subtract
-    return from_plain(r);
+    return finish(u, carry * 38u + 19u * top);  // u < 2^255, add0 < 2^11
   }
   ELL_HD static El mul(const El& a, const El& b) {
     u32 t[16];

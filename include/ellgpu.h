@@ -184,7 +184,11 @@ int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n);
  * multiply-accumulates (v_mad_u64_u32) per lane on `blocks` x 256 lanes and
  * returns the elapsed milliseconds measured with HIP events.  kind: 0 =
  * v_mad_u64_u32, 1 = v_mul_lo_u32 + v_mul_hi_u32 pair, 2 = v_mad_u32_u24,
- * 3 = v_add_co/addc pair.  Used by bench.py to set the VALU peak. */
+ * 3 = v_add_co/addc pair.  Used by bench.py to set the VALU peak.
+ * kind 10..15: secp256k1 field-layer probes, one wavefront per block of 64 lanes, `iters`
+ * dependent operations per lane (blocks = 1024 * w puts w waves on every SIMD): 10 field mul,
+ * 11 field sqr, 12 two interleaved mul chains, 13 add + sub, 14 Jacobian doubling,
+ * 15 mixed addition; ops_out = lane-operations. */
 int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iters, double* ms_out,
                       double* ops_out);
 

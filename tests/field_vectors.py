@@ -1,0 +1,105 @@
+"""Directed operand pairs for the rarely taken branches of the special-form fields
+(FpK256 = field 0, Fp25519 = field 1 of the field-op probes): carry / borrow ripples that need a
+limb to be exactly 2^32 - 1 or 0, and values that land in [p, 2^256) before the last
+subtraction.  Random operands reach these with probability ~2^-31, so they are constructed.
+Python mirrors of the two reduce_wide routines assert that the multiply vectors really enter
+the branch."""
+
+M = 1 << 256
+P_K256 = M - (1 << 32) - 977
+P_25519 = (1 << 255) - 19
+
+
+def k256_mul_trace(a, b):
+    """mirror of FpK256::reduce_wide's intermediates -> (carry out of limb 2, u[7])"""
+    N = a * b
+    lo, hi = N % M, N // M
+    delta = (1 << 32) + 977
+    u = lo + hi * delta                                # 10 limbs
+    T, ulow = u >> 256, u % M
+    c = ((ulow % (1 << 96)) + T * delta) >> 96
+    return c, (ulow >> 224) & 0xFFFFFFFF
+
+
+def f25519_mul_trace(a, b):
+    """mirror of Fp25519::reduce_wide -> (carry out of limb 0 in finish, u[7] & 0x7fffffff)"""
+    N = a * b
+    lo, hi = N % M, N // M
+    u = lo + 38 * hi
+    carry, ul = u >> 256, u % M
+    top = ul >> 255
+    ul &= (1 << 255) - 1
+    add0 = carry * 38 + 19 * top
+    return ((ul & 0xFFFFFFFF) + add0) >> 32, (ul >> 224) & 0x7FFFFFFF
+
+
+def rare_vectors():
+    """-> list of (field, op, a, b, expected); op: 0 add, 1 sub, 2 mul, 3 sqr (b ignored)"""
+    out = []
+
+    def put(field, p, op, a, b):
+        assert 0 <= a < p and 0 <= b < p, (field, op, hex(a), hex(b))
+        want = [(a + b) % p, (a - b) % p, a * b % p, a * a % p][op]
+        out.append((field, op, a, b, want))
+
+    # ---- secp256k1 field ----
+    p = P_K256
+    delta = M - p
+    for t in [(0xFFFFFFFF << 32) | (2 ** 32 - 977), (0xFFFFFFFF << 32) | 0xFFFFFFFF, (0xFFFFFFFE << 32) | 0xFFFFFFFF,
+              (2 ** 224 - 1), (2 ** 224 - 1) - 976, ((2 ** 192 - 1) << 32) | 0xFFFFFC2F, (1 << 64) - 977, (1 << 64) - 978]:
+        S = M + t                                      # a + b = 2^256 + t: the fold ripples out of limb 1
+        a = p - 1 - 12345
+        put(0, p, 0, a, S - a)
+        put(0, p, 0, S - a, a)
+    for S in (p, p + 1, M - 1, p - 1, M - 2 ** 224, M - 2 ** 224 - 1):   # carry-less sums around [p, 2^256)
+        put(0, p, 0, S // 2, S - S // 2)
+        put(0, p, 0, S - S // 2, S // 2)
+    for t in [delta + 1, delta + 2, (1 << 33) + 976, (1 << 33) + 977, (1 << 33) + 978, (1 << 64) + 5,
+              (1 << 224) + 976, (2 << 32) + 3, (1 << 64) + (1 << 32) + 976, (1 << 96) + (1 << 32) + 5]:
+        # a - b = t - 2^256 (borrow); t - delta then borrows out of limb 1 when limbs 0..1 of t are small
+        b = p - 1
+        put(0, p, 1, (t - M) + b, b)
+    for a, b in ((0, p - 1), (0, 1), (5, 5), (0, 0), (1, 2), (976, 977), (p - 1, p - 1)):
+        put(0, p, 1, a, b)
+    # mul: carry out of limb 2 in the second fold.  b = 2^255: N = a << 255, hi = a >> 1; choose
+    # x = a >> 1 with x*delta = -1-k (mod 2^96) and x large so that T >= 1
+    inv = pow(delta, -1, 1 << 96)
+    hits = 0
+    for k in range(40):
+        x = ((1 << 96) - 1 - k) * inv % (1 << 96) + ((0x7ACE << 238) | (k << 100))
+        a = 2 * x
+        if a >= p:
+            continue
+        hits += k256_mul_trace(a, 1 << 255)[0]
+        put(0, p, 2, a, 1 << 255)
+        put(0, p, 2, 1 << 255, a)
+    assert hits >= 5, hits
+    # u[7] = 2^32 - 1 and values in [p, 2^256) before the last subtraction
+    for a in (p - 1, p - 2, M - 2 ** 224 + 5, p - 2 ** 200):
+        assert k256_mul_trace(a, 1)[1] == 0xFFFFFFFF
+        put(0, p, 2, a, 1)
+        put(0, p, 3, a, 0)
+        put(0, p, 2, a, p - 1)
+    # ---- 2^255 - 19 ----
+    p = P_25519
+    for S in (p, p + 1, p + 18, (1 << 255) - 1, 1 << 255, (1 << 255) + 1, 2 * p - 2, (1 << 255) + (1 << 32) - 19,
+              (1 << 255) + (1 << 32) - 20, (1 << 255) + (1 << 64) - 19, p - 1):
+        put(1, p, 0, S // 2, S - S // 2)
+        put(1, p, 0, S - S // 2, S // 2)
+    for a, b in ((0, 1), (0, p - 1), (5, 6), (18, 19), (0, 19), (1 << 32, (1 << 32) + 1), (7, 7), (p - 1, 0),
+                 (20, (1 << 64) + 39), (3, 1 << 200), (0, 0), (1 << 32, (1 << 32) + 19), (1 << 64, (1 << 64) + 1)):
+        put(1, p, 1, a, b)
+    hits = 0
+    for k in range(64):
+        a = ((((1 << 31) - 1) << 224) | (0xFFFFFFFF - k)) % p    # low limb near 2^32, top limb large
+        for b in (2, 3, 1 << 31, (1 << 31) + 1, p - 1):
+            hits += f25519_mul_trace(a, b)[0]
+            put(1, p, 2, a, b)
+            put(1, p, 2, b, a)
+    assert hits >= 1, hits
+    for a in (p - 1, p - 2, (1 << 255) - 20, (1 << 254) + 1, 1 << 254):
+        put(1, p, 3, a, 0)
+        put(1, p, 2, a, 2)
+        put(1, p, 2, a, 1)
+    assert f25519_mul_trace(p - 1, 1)[1] == 0x7FFFFFFF
+    return out

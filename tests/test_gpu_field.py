@@ -78,3 +78,19 @@ def test_field_ops_gpu(ctx, field):
     got = _unpack(R)
     for i in range(m):
         assert got[i] == pow(nz[i], -1, p), (field, "inv", hex(nz[i]))
+
+
+def test_rare_branches_gpu(ctx):
+    """the directed vectors of tests/field_vectors.py through the device code (asm products)"""
+    import field_vectors
+    vecs = field_vectors.rare_vectors()
+    for field in (0, 1):
+        for op in (0, 1, 2, 3):
+            sel = [v for v in vecs if v[0] == field and v[1] == op]
+            A, B = _pack([v[2] for v in sel], 8), _pack([v[3] for v in sel], 8)
+            R = np.zeros((len(sel), 8), np.uint32)
+            assert ctx._lib.ellgpu_debug_field_op(ctx._ctx, field, op, len(sel), A.ctypes.data, B.ctypes.data,
+                                                  R.ctypes.data) == 0
+            got = _unpack(R)
+            for v, g in zip(sel, got):
+                assert g == v[4], (field, op, hex(v[2]), hex(v[3]), hex(g))

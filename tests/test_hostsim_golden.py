@@ -86,6 +86,18 @@ def test_field_ops(hs, field):
         assert _val(r) == pow(a % p, -1, p)
 
 
+def test_rare_branches_k256_25519(hs):
+    """Directed vectors for the carry-ripple / final-subtraction branches that random inputs
+    reach with probability ~2^-31 (FpK256 and Fp25519 add, sub, mul, sqr)."""
+    import field_vectors
+    vecs = field_vectors.rare_vectors()
+    assert len(vecs) > 400
+    for field, op, a, b, want in vecs:
+        r = (ctypes.c_uint32 * 8)()
+        assert hs.hs_field_op(field, op, _limbs(a, 8), _limbs(b, 8), r) == 0
+        assert _val(r) == want, (field, op, hex(a), hex(b))
+
+
 def test_p521_from_plain_overrange(hs):
     """The Mersenne fold must canonicalise any 17-limb input (decompress hands raw 66-byte
     values to from_plain): p -> 0, 2^521 -> 1, all-ones limbs, ..."""

@@ -19,3 +19,20 @@ for kind, name in names.items():
     out[name] = best / 1e12
     print("%-28s %.3f T inner-ops/s" % (name, best / 1e12))
 print(json.dumps(out))
+
+# secp256k1 field / group operations: SIMD time per wavefront-operation at 1..5 resident waves
+# per SIMD (1024 one-wave blocks = one wave per SIMD), in units of the v_mad_u64_u32 issue time
+mad_rate = out["v_mad_u64_u32"] * 1e12 / (1024 * 64)       # wave-mads per second per SIMD
+fnames = {10: "field mul", 11: "field sqr", 12: "2 interleaved muls", 13: "add+sub", 14: "jacobian dbl",
+          15: "mixed add"}
+table = {}
+for kind, name in fnames.items():
+    row = []
+    for w in (1, 2, 3, 4, 5, 6, 8):
+        ms, ops = ctx.probe_valu(kind, 1024 * w, 2000)
+        per_simd = ops / 64 / 1024                            # wave-operations each SIMD executed
+        t = ms * 1e-3 / per_simd                              # SIMD seconds per wave-operation
+        row.append(round(t * mad_rate, 1))
+    table[name] = row
+    print("%-20s SIMD time per op, in mad-issue units, at 1,2,3,4,5,6,8 waves/SIMD: %s" % (name, row))
+print(json.dumps(table))
