@@ -2,6 +2,8 @@
 // context creation, and the integer-VALU roofline probe.  The kernels themselves
 // are instantiated per (curve, operation) in inst.hip; all curve arithmetic is in
 // the headers; there is no vendor library and no CPU path behind this library.
+#include <type_traits>
+
 #include "engine_extern.h"
 
 namespace ell {
@@ -89,7 +91,14 @@ __global__ void k_field_op(int op, size_t n, const u32* a, const u32* b, u32* r)
     case 2: z = F::mul(x, y); break;
     case 3: z = F::sqr(x); break;
     case 4: z = F::inv(x); break;
-    default: z = F::neg(x); break;
+    case 5: z = F::neg(x); break;
+    case 6: z = F::template mul_pow2<1>(x); break;
+    case 7: z = F::template mul_pow2<2>(x); break;
+    case 8: z = F::template mul_pow2<3>(x); break;
+    default: z = x; break;
+  }
+  if constexpr (std::is_same<F, Fp25519>::value) {
+    if (op == 10) z = F::mul_u32(x, tb[0]);               // one-limb constant
   }
   F::to_plain(tr, z);
   for (int l = 0; l < F::L; l++) r[i * F::L + l] = tr[l];

@@ -56,7 +56,7 @@ struct EdWork {
     P r;
     r.a = F::add(p.b, p.a);
     r.b = F::sub(p.b, p.a);
-    r.c = F::dbl(p.c);
+    r.c = F::template mul_pow2<1>(p.c);
     r.d = F::mul(p.d, const_dd());
     return r;
   }
@@ -80,7 +80,7 @@ struct EdWork {
   ELL_HD static P dbl(const P& p) {
     El A = F::sqr(p.a);
     El B = F::sqr(p.b);
-    El Cc = F::dbl(F::sqr(p.c));
+    El Cc = F::template mul_pow2<1>(F::sqr(p.c));
     El D = F::neg(A);
     El E = F::sub(F::sub(F::sqr(F::add(p.a, p.b)), A), B);
     El G = F::add(D, B);

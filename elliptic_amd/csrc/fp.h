@@ -192,6 +192,35 @@ struct FpK256 {
   }
   ELL_HD static El neg(const El& a) { return sub(zero(), a); }
   ELL_HD static El dbl(const El& a) { return add(a, a); }
+  // 2^K * a (K = 1..3) as one shift: the K bits shifted out of limb 7 fold back in as
+  // top * delta on the two low limbs.  Eight independent funnel shifts and a two-limb carry
+  // chain instead of K eight-limb chains; the ripple and the final subtraction are rare as in add.
+  template <int K>
+  ELL_HD static El mul_pow2(const El& a) {
+    static_assert(K >= 1 && K <= 3, "small shifts only");
+    u32 lo[8];
+    u32 top = a.v[7] >> (32 - K);
+    lo[0] = a.v[0] << K;
+    ELL_UNROLL
+    for (int i = 1; i < 8; i++) lo[i] = (a.v[i] << K) | (a.v[i - 1] >> (32 - K));
+    El r;
+    u32 c = 0;
+    r.v[0] = addc32(lo[0], top * C0, c, c);
+    r.v[1] = addc32(lo[1], top, c, c);
+    ELL_UNROLL
+    for (int i = 2; i < 8; i++) r.v[i] = lo[i];
+    if (ELL_UNLIKELY(c != 0 || lo[7] == 0xFFFFFFFFu)) {
+      ELL_UNROLL
+      for (int i = 2; i < 8; i++) r.v[i] = addc32(lo[i], 0, c, c);
+      u32 p[8]; get_p(p);
+      u32 s[8];
+      u32 br = bn_sub<8>(s, r.v, p);
+      bool take = (c != 0) || (br == 0);
+      ELL_UNROLL
+      for (int i = 0; i < 8; i++) r.v[i] = take ? s[i] : r.v[i];
+    }
+    return r;
+  }
 
   // fold a 512-bit value t[0..16) to [0,p): 2^256 == 2^32 + 977 (mod p).
   // Written with explicit carry chains (addc32) so that gfx950 gets
@@ -387,6 +416,33 @@ struct Fp25519 {
   }
   ELL_HD static El neg(const El& a) { return sub(zero(), a); }
   ELL_HD static El dbl(const El& a) { return add(a, a); }
+  // a * k for a one-limb k < 2^24: an 8-step multiply-accumulate chain; the ninth limb and
+  // bit 255 fold back in through finish
+  ELL_HD static El mul_u32(const El& a, u32 k) {
+    u32 lo[8];
+    u64 acc = 0;
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) {
+      acc = (u64)a.v[i] * k + (acc >> 32);
+      lo[i] = (u32)acc;
+    }
+    u32 carry = (u32)(acc >> 32);                 // < 2^24
+    u32 top = lo[7] >> 31;
+    lo[7] &= 0x7FFFFFFFu;
+    return finish(lo, carry * 38u + 19u * top);
+  }
+  // 2^K * a (K = 1..3) as one shift: bits 255.. of a << K fold back in as 19 * top
+  template <int K>
+  ELL_HD static El mul_pow2(const El& a) {
+    static_assert(K >= 1 && K <= 3, "small shifts only");
+    u32 lo[8];
+    u32 top = a.v[7] >> (31 - K);
+    lo[0] = a.v[0] << K;
+    ELL_UNROLL
+    for (int i = 1; i < 8; i++) lo[i] = (a.v[i] << K) | (a.v[i - 1] >> (32 - K));
+    lo[7] &= 0x7FFFFFFFu;
+    return finish(lo, 19u * top);
+  }
 
   ELL_HD static El reduce_wide(const u32 (&t)[16]) {
     // v = 38*hi: eight independent 32x6-bit products; u = lo + v (9 limbs)
@@ -571,6 +627,14 @@ struct FpMont {
   }
   ELL_HD static El neg(const El& a) { return sub(zero(), a); }
   ELL_HD static El dbl(const El& a) { return add(a, a); }
+  // 2^K * a (K = 1..3): repeated doubling
+  template <int K>
+  ELL_HD static El mul_pow2(const El& a) {
+    El r = dbl(a);
+    ELL_UNROLL
+    for (int i = 1; i < K; i++) r = dbl(r);
+    return r;
+  }
 
   // Montgomery reduction of a 2L-limb value: t * R^-1 mod p, row by row with explicit
   // carry chains (L multiplies by the constant limbs of p + 2L add-with-carry per row).
@@ -762,6 +826,14 @@ struct FpSolinas {
   }
   ELL_HD static El neg(const El& a) { return sub(zero(), a); }
   ELL_HD static El dbl(const El& a) { return add(a, a); }
+  // 2^K * a (K = 1..3): repeated doubling
+  template <int K>
+  ELL_HD static El mul_pow2(const El& a) {
+    El r = dbl(a);
+    ELL_UNROLL
+    for (int i = 1; i < K; i++) r = dbl(r);
+    return r;
+  }
 
   ELL_HD static El reduce_wide(const u32 (&t)[2 * L]) {
     u32 r[L];
@@ -923,6 +995,14 @@ struct FpP521 {
   }
   ELL_HD static El neg(const El& a) { return sub(zero(), a); }
   ELL_HD static El dbl(const El& a) { return add(a, a); }
+  // 2^K * a (K = 1..3): repeated doubling
+  template <int K>
+  ELL_HD static El mul_pow2(const El& a) {
+    El r = dbl(a);
+    ELL_UNROLL
+    for (int i = 1; i < K; i++) r = dbl(r);
+    return r;
+  }
 
   // value < 2^1088 in 34 limbs -> [0, p)
   ELL_HD static El reduce_wide(const u32 (&t)[34]) {

@@ -29,13 +29,16 @@ struct MontWork {
     bn_select<8>(r.z.v, c, a.z.v, b.z.v);
     return r;
   }
-  ELL_HD static XZ dbl(const XZ& p, const El& a24) {
+  // a24 = (a + 2) / 4 = 121666 is a one-limb constant on curve25519: a 1 x 8 limb product
+  static_assert(C::a24[1] == 0 && C::a24[2] == 0 && C::a24[3] == 0 && C::a24[4] == 0 && C::a24[5] == 0 &&
+                C::a24[6] == 0 && C::a24[7] == 0, "a24 must fit one limb");
+  ELL_HD static XZ dbl(const XZ& p) {
     El aa = F::sqr(F::add(p.x, p.z));
     El bb = F::sqr(F::sub(p.x, p.z));
     El c = F::sub(aa, bb);
     XZ r;
     r.x = F::mul(aa, bb);
-    r.z = F::mul(c, F::add(bb, F::mul(a24, c)));
+    r.z = F::mul(c, F::add(bb, F::mul_u32(c, C::a24[0])));
     return r;
   }
   // p + q given their difference (dx : 1)
@@ -54,9 +57,6 @@ struct MontWork {
     load_be<8>(k, ks + i * 32, 32);
     load_be<8>(t, xs + i * 32, 32);
     El x = F::from_plain(t);
-    El a24;
-    ELL_UNROLL
-    for (int l = 0; l < 8; l++) a24.v[l] = C::a24[l];
     XZ a, b;
     a.x = x; a.z = F::one();                      // (N/2)*Q + Q
     b.x = F::one(); b.z = F::zero();              // (N/2)*Q
@@ -67,7 +67,7 @@ struct MontWork {
       for (int l = 7; l > 0; l--) k[l] = (k[l] << 1) | (k[l - 1] >> 31);
       k[0] <<= 1;
       XZ s = diffadd(a, b, x);
-      XZ d = dbl(sel(bit, a, b), a24);
+      XZ d = dbl(sel(bit, a, b));
       a = sel(bit, d, s);
       b = sel(bit, s, d);
     }

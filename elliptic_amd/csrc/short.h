@@ -71,12 +71,12 @@ struct ShortOps {
       El c = F::sqr(b);
       El t = F::sqr(F::add(p.X, b));
       t = F::sub(F::sub(t, a), c);
-      El d = F::dbl(t);
-      El e = F::add(F::dbl(a), a);
+      El d = F::template mul_pow2<1>(t);
+      El e = F::add(F::template mul_pow2<1>(a), a);
       El f = F::sqr(e);
-      r.X = F::sub(f, F::dbl(d));
-      El c8 = F::dbl(F::dbl(F::dbl(c)));
-      r.Z = F::dbl(F::mul(p.Y, p.Z));
+      r.X = F::sub(f, F::template mul_pow2<1>(d));
+      El c8 = F::template mul_pow2<3>(c);
+      r.Z = F::template mul_pow2<1>(F::mul(p.Y, p.Z));
       r.Y = F::sub(F::mul(e, F::sub(d, r.X)), c8);
     } else {
       // dbl-2001-b, a = -3: 3M + 5S
@@ -84,13 +84,13 @@ struct ShortOps {
       El gamma = F::sqr(p.Y);
       El beta = F::mul(p.X, gamma);
       El t = F::mul(F::sub(p.X, delta), F::add(p.X, delta));
-      El alpha = F::add(F::dbl(t), t);
-      El beta4 = F::dbl(F::dbl(beta));
-      r.X = F::sub(F::sqr(alpha), F::dbl(beta4));
+      El alpha = F::add(F::template mul_pow2<1>(t), t);
+      El beta4 = F::template mul_pow2<2>(beta);
+      r.X = F::sub(F::sqr(alpha), F::template mul_pow2<1>(beta4));
       El yz = F::sqr(F::add(p.Y, p.Z));
       r.Z = F::sub(F::sub(yz, gamma), delta);
       El g2 = F::sqr(gamma);
-      El g8 = F::dbl(F::dbl(F::dbl(g2)));
+      El g8 = F::template mul_pow2<3>(g2);
       r.Y = F::sub(F::mul(alpha, F::sub(beta4, r.X)), g8);
     }
     return r;
@@ -107,7 +107,7 @@ struct ShortOps {
     El hhh = F::mul(h, hh);
     El v = F::mul(p.X, hh);
     J r;
-    r.X = F::sub(F::sub(F::sqr(rr), hhh), F::dbl(v));
+    r.X = F::sub(F::sub(F::sqr(rr), hhh), F::template mul_pow2<1>(v));
     r.Y = F::sub(F::mul(rr, F::sub(v, r.X)), F::mul(p.Y, hhh));
     r.Z = F::mul(p.Z, h);          // h == 0, rr != 0  ->  Z3 = 0: infinity
     bool pinf = F::is_zero(p.Z);
@@ -129,7 +129,7 @@ struct ShortOps {
     El hhh = F::mul(h, hh);
     El v = F::mul(p.X, hh);
     J r;
-    r.X = F::sub(F::sub(F::sqr(rr), hhh), F::dbl(v));
+    r.X = F::sub(F::sub(F::sqr(rr), hhh), F::template mul_pow2<1>(v));
     r.Y = F::sub(F::mul(rr, F::sub(v, r.X)), F::mul(p.Y, hhh));
     r.Z = F::mul(p.Z, h);
     return r;
@@ -149,7 +149,7 @@ struct ShortOps {
     El hhh = F::mul(h, hh);
     El v = F::mul(u1, hh);
     J r;
-    r.X = F::sub(F::sub(F::sqr(rr), hhh), F::dbl(v));
+    r.X = F::sub(F::sub(F::sqr(rr), hhh), F::template mul_pow2<1>(v));
     r.Y = F::sub(F::mul(rr, F::sub(v, r.X)), F::mul(s1, hhh));
     r.Z = F::mul(F::mul(p.Z, q.Z), h);
     bool pinf = F::is_zero(p.Z);

@@ -195,7 +195,9 @@ int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iters, double* 
 /* White-box probe for the GPU unit tests of the field layer: r[i] = a[i] <op> b[i] in one of
  * the engine's fields (n items, `L` 32-bit little-endian limbs each, host pointers).
  * field: 0 secp256k1 p, 1 2^255-19, 10+c / 20+c base / order field of short curve c in
- * Montgomery form (26 = ed25519 order); op: 0 add 1 sub 2 mul 3 sqr 4 inv 5 neg. */
+ * Montgomery form (26 = ed25519 order); op: 0 add 1 sub 2 mul 3 sqr 4 inv 5 neg, 6 / 7 / 8
+ * multiply by 2 / 4 / 8, 9 identity (reduce the input), 10 (field 1 only) multiply by the
+ * one-limb constant b[0]. */
 int ellgpu_debug_field_op(ellgpu_ctx* ctx, int field, int op, size_t n, const uint32_t* a,
                           const uint32_t* b, uint32_t* r);
 

@@ -103,3 +103,43 @@ def rare_vectors():
         put(1, p, 2, a, 1)
     assert f25519_mul_trace(p - 1, 1)[1] == 0x7FFFFFFF
     return out
+
+
+def shift_vectors():
+    """-> list of (field, op, a, b, expected) for mul_pow2 (op 6/7/8 = x2/x4/x8) and, on field 1,
+    mul_u32 (op 10, b = the one-limb constant): operands whose shifted limbs are all ones or
+    whose folded top bits carry out of the low limbs."""
+    import random
+    rnd = random.Random(99)
+    out = []
+    for field, p in ((0, P_K256), (1, P_25519)):
+        bits = 256 if field == 0 else 255
+        for K in (1, 2, 3):
+            cands = [0, 1, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, p >> K, (p >> K) + 1, (p >> K) - 1,
+                     (1 << (bits - K)) - 1, 1 << (bits - K), (1 << (bits - K)) + 1]
+            for top in range(1 << K):
+                for lo in [(1 << bits) - (1 << K),                         # all ones after the shift
+                           ((1 << 64) - 1) & ~((1 << K) - 1),              # limbs 0..1 all ones
+                           (((1 << 32) - 1) << 32) | ((1 << 32) - (1 << K)),
+                           (((1 << 32) - 1) << 32) | ((1 << 32) - 977 * top - (1 << K)) % (1 << 32) & ~((1 << K) - 1),
+                           (1 << 32) - (1 << K), ((1 << 32) - 19 * top) & ~((1 << K) - 1) & 0xFFFFFFFF,
+                           ((1 << bits) - (1 << 224)) & ~((1 << K) - 1),   # top limb all ones
+                           rnd.getrandbits(bits) & ~((1 << K) - 1)]:
+                    a = (top << (bits - K)) | (lo >> K)
+                    cands.append(a % p)
+            cands += [rnd.randrange(p) for _ in range(50)]
+            for a in cands:
+                out.append((field, 5 + K, a, 0, (a << K) % p))
+    p = P_25519
+    k = 121666
+    half = pow(k // 2, -1, 1 << 31)
+    for j in range(24):
+        a0 = ((1 << 31) - 1 - j) * half % (1 << 31)          # a0 * k = 2^32 - 2 - 2j (mod 2^32)
+        for hi in (0, 1, (1 << 223) - 1, rnd.getrandbits(222), (1 << 222) + 12345):
+            a = ((hi << 32) | a0) % p
+            out.append((1, 10, a, k, a * k % p))
+    for a in [0, 1, p - 1, p - 2, (1 << 255) - 20, (p - 1) // 2, ((1 << 255) - 19) // k, ((1 << 255) - 19) // k + 1,
+              (1 << 254) - 1] + [rnd.randrange(p) for _ in range(60)]:
+        for kk in (k, 1, 2, (1 << 20) - 1, 38):
+            out.append((1, 10, a, kk, a * kk % p))
+    return out

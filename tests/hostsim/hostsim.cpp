@@ -80,6 +80,9 @@ static void field_op(int op, const u32* a, const u32* b, u32* r) {
     case 3: z = F::sqr(x); break;
     case 4: z = F::inv(x); break;
     case 5: z = F::neg(x); break;
+    case 6: z = F::template mul_pow2<1>(x); break;
+    case 7: z = F::template mul_pow2<2>(x); break;
+    case 8: z = F::template mul_pow2<3>(x); break;
     default: z = x;
   }
   F::to_plain(tr, z);
@@ -100,7 +103,16 @@ int hs_field_limbs(int field) {
 int hs_field_op(int field, int op, const u32* a, const u32* b, u32* r) {
   switch (field) {
     case 0: field_op<FpK256>(op, a, b, r); break;
-    case 1: field_op<Fp25519>(op, a, b, r); break;
+    case 1:
+      if (op == 10) {                      // mul_u32 by the one-limb constant b[0]
+        u32 ta[8];
+        for (int i = 0; i < 8; i++) ta[i] = a[i];
+        Fp25519::El z = Fp25519::mul_u32(Fp25519::from_plain(ta), b[0]);
+        for (int i = 0; i < 8; i++) r[i] = z.v[i];
+      } else {
+        field_op<Fp25519>(op, a, b, r);
+      }
+      break;
     case 10: field_op<FpMont<consts::SECP256K1_P>>(op, a, b, r); break;
     case 11: field_op<CvP192::F>(op, a, b, r); break;
     case 12: field_op<CvP224::F>(op, a, b, r); break;

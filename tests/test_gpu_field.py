@@ -83,10 +83,12 @@ def test_field_ops_gpu(ctx, field):
 def test_rare_branches_gpu(ctx):
     """the directed vectors of tests/field_vectors.py through the device code (asm products)"""
     import field_vectors
-    vecs = field_vectors.rare_vectors()
+    vecs = field_vectors.rare_vectors() + field_vectors.shift_vectors()
     for field in (0, 1):
-        for op in (0, 1, 2, 3):
+        for op in (0, 1, 2, 3, 6, 7, 8, 10):
             sel = [v for v in vecs if v[0] == field and v[1] == op]
+            if not sel:
+                continue
             A, B = _pack([v[2] for v in sel], 8), _pack([v[3] for v in sel], 8)
             R = np.zeros((len(sel), 8), np.uint32)
             assert ctx._lib.ellgpu_debug_field_op(ctx._ctx, field, op, len(sel), A.ctypes.data, B.ctypes.data,

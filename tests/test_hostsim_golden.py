@@ -90,8 +90,8 @@ def test_rare_branches_k256_25519(hs):
     """Directed vectors for the carry-ripple / final-subtraction branches that random inputs
     reach with probability ~2^-31 (FpK256 and Fp25519 add, sub, mul, sqr)."""
     import field_vectors
-    vecs = field_vectors.rare_vectors()
-    assert len(vecs) > 400
+    vecs = field_vectors.rare_vectors() + field_vectors.shift_vectors()
+    assert len(vecs) > 1500
     for field, op, a, b, want in vecs:
         r = (ctypes.c_uint32 * 8)()
         assert hs.hs_field_op(field, op, _limbs(a, 8), _limbs(b, 8), r) == 0
