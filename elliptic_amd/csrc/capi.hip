@@ -69,7 +69,23 @@ __global__ void __launch_bounds__(64) k_probe_field(u32* out, int iters, u32 see
     else if (KIND == 12) { x = F::mul(x, y); z = F::mul(z, y); }
     else if (KIND == 13) { x = F::add(x, y); x = F::sub(x, z); }
     else if (KIND == 14) p = G::dbl(p);
-    else p = G::add_mixed(p, q);
+    else if (KIND == 15) p = G::add_mixed(p, q);
+    else if (KIND == 16) {                       // wide product only (no reduction)
+      u32 t[16];
+      fe_mul_wide<8>(t, x.v, y.v);
+#pragma unroll
+      for (int i = 0; i < 8; i++) x.v[i] = t[i] ^ t[i + 8];
+    } else if (KIND == 17) {                     // wide square only
+      u32 t[16];
+      fe_sqr_wide<8>(t, x.v);
+#pragma unroll
+      for (int i = 0; i < 8; i++) x.v[i] = t[i] ^ t[i + 8];
+    } else {                                     // reduction only
+      u32 t[16];
+#pragma unroll
+      for (int i = 0; i < 8; i++) { t[i] = x.v[i]; t[i + 8] = y.v[i]; }
+      x = F::reduce_wide(t);
+    }
   }
   u32 acc = 0;
 #pragma unroll
@@ -179,6 +195,9 @@ extern "C" int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iter
       case 13: hipLaunchKernelGGL(ell::k_probe_field<13>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       case 14: hipLaunchKernelGGL(ell::k_probe_field<14>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       case 15: hipLaunchKernelGGL(ell::k_probe_field<15>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 16: hipLaunchKernelGGL(ell::k_probe_field<16>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 17: hipLaunchKernelGGL(ell::k_probe_field<17>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 18: hipLaunchKernelGGL(ell::k_probe_field<18>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       default: bk.free_(out); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
                return set_err(ELLGPU_E_ARG, "unknown probe kind");
     }

@@ -188,7 +188,8 @@ int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n);
  * kind 10..15: secp256k1 field-layer probes, one wavefront per block of 64 lanes, `iters`
  * dependent operations per lane (blocks = 1024 * w puts w waves on every SIMD): 10 field mul,
  * 11 field sqr, 12 two interleaved mul chains, 13 add + sub, 14 Jacobian doubling,
- * 15 mixed addition; ops_out = lane-operations. */
+ * 15 mixed addition, 16 wide product only, 17 wide square only, 18 reduction only;
+ * ops_out = lane-operations. */
 int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iters, double* ms_out,
                       double* ops_out);
 

@@ -24,7 +24,7 @@ print(json.dumps(out))
 # per SIMD (1024 one-wave blocks = one wave per SIMD), in units of the v_mad_u64_u32 issue time
 mad_rate = out["v_mad_u64_u32"] * 1e12 / (1024 * 64)       # wave-mads per second per SIMD
 fnames = {10: "field mul", 11: "field sqr", 12: "2 interleaved muls", 13: "add+sub", 14: "jacobian dbl",
-          15: "mixed add"}
+          15: "mixed add", 16: "wide product only", 17: "wide square only", 18: "reduction only"}
 table = {}
 for kind, name in fnames.items():
     row = []
