@@ -150,6 +150,7 @@ struct FnEdDecompress {
 struct FnEddsaVerify {
   static constexpr const char* NAME = "eddsa_verify";
   static constexpr int DS_PER_LANE = EdWork::NWIN;
+  static constexpr int MIN_WAVES = 3;          // <= 168 VGPRs (unconstrained it takes 170: 2 waves/SIMD)
   size_t n; const u8* msgs; const u64* off; size_t msg_len; const u8* sigs; const u8* pubs;
   const EdWork::P* comb; EdWork::P* tbl; u8* ok; u8* err;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {

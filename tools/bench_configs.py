@@ -66,6 +66,50 @@ def main():
         timed("%s fixed-base G*k" % curve, n, lambda: ctx.mul_fixed_dev(curve, dd, pts, inf))
         timed("%s variable-base P*k" % curve, n, lambda: ctx.mul_var_dev(curve, dk, pts, out, inf))
         timed("%s k1*G + k2*P" % curve, n, lambda: ctx.mul_add2_dev(curve, dd, None, dk, pts, out, inf))
+        if curve == "secp256k1":
+            # ECDSA sign for supplied nonces (hash = k bytes, priv = d, nonce = k ^ d: all < 2^256, a few
+            # percent >= n are flagged per item), key decompression of the x coordinates just produced
+            NB = elliptic_amd.ORDER_BYTES[curve]
+            nonce = torch.bitwise_xor(dk, dd)
+            r_o = torch.zeros((n, NB), dtype=torch.uint8, device=dev)
+            s_o = torch.zeros((n, NB), dtype=torch.uint8, device=dev)
+            rec = torch.zeros(n, dtype=torch.uint8, device=dev)
+            ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+            timed("%s ECDSA sign (nonces supplied)" % curve, n,
+                  lambda: ctx.ecdsa_sign_dev(curve, dk, dd, nonce, r_o, s_o, rec, ok, canonical=True))
+            xs = pts[:, :B].contiguous()
+            odd = (pts[:, 2 * B - 1] & 1).contiguous()
+            timed("%s key decompression (pointFromX)" % curve, n, lambda: ctx.decompress_dev(curve, xs, odd, out, ok))
+            assert torch.equal(out, pts) and bool(ok.all())
+        if curve == "ed25519":
+            # EdDSA verify on valid signatures (A = aG, R = rG, S = r + h a; built with the fixed-base
+            # kernel + hashlib), 48-byte messages
+            from oracle import ec_oracle as O
+            N = O.get_curve("ed25519").n
+            m, mlen = 1 << 18, 48
+            raw = rnd("cfg:eddsa", m, 64 + mlen)
+            av = [int.from_bytes(raw[i, :32].tobytes(), "little") % N for i in range(m)]
+            rv = [int.from_bytes(raw[i, 32:64].tobytes(), "little") % N for i in range(m)]
+            msgs = np.ascontiguousarray(raw[:, 64:])
+            A, _ = ctx.mul_fixed("ed25519", elliptic_amd.ints_to_be(av, 32))
+            R, _ = ctx.mul_fixed("ed25519", elliptic_amd.ints_to_be(rv, 32))
+
+            def enc(P):
+                y = P[:, 32:][:, ::-1].copy()
+                y[:, 31] |= ((P[:, 31] & 1) << 7).astype(np.uint8)
+                return y
+            Ae, Re = enc(A), enc(R)
+            sig = np.zeros((m, 64), np.uint8)
+            sig[:, :32] = Re
+            for i in range(m):
+                h = int.from_bytes(hashlib.sha512(Re[i].tobytes() + Ae[i].tobytes() + msgs[i].tobytes()).digest(),
+                                   "little") % N
+                sig[i, 32:] = np.frombuffer(((rv[i] + h * av[i]) % N).to_bytes(32, "little"), np.uint8)
+            # the 2^18 distinct signatures tiled four times: 2^20 items, as in the other rows
+            dm, ds, dp = [torch.from_numpy(x).to(dev).repeat(4, 1).contiguous() for x in (msgs, sig, Ae)]
+            ok = torch.zeros(4 * m, dtype=torch.uint8, device=dev)
+            timed("ed25519 EdDSA verify (48-byte messages)", 4 * m, lambda: ctx.eddsa_verify_dev(dm, mlen, ds, dp, ok))
+            assert bool(ok.all())
     if only and "curve25519" not in only:
         return
     n = 1 << 20

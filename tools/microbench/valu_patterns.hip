@@ -79,6 +79,65 @@ __global__ void __launch_bounds__(64) k(u32* out, int iters, u32 seed) {
           "v_addc_co_u32 %6, vcc, %8, %6, vcc\n s_nop 1\n v_addc_co_u32 %7, vcc, %8, %7, vcc\n s_nop 1\n")
           : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7)
           : "v"(a) : "vcc");
+    } else if (P == 8) {   // single accumulator: every mad depends on the previous one, addc two slots behind
+      asm volatile(REP4(
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n"
+          "v_addc_co_u32_e64 %4, s[28:29], 0, %4, s[22:23]\n"
+          "v_mad_u64_u32 %0, s[22:23], %9, %8, %0\n"
+          "v_addc_co_u32_e64 %4, s[28:29], 0, %4, s[20:21]\n"
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n"
+          "v_addc_co_u32_e64 %4, s[28:29], 0, %4, s[22:23]\n"
+          "v_mad_u64_u32 %0, s[22:23], %9, %8, %0\n"
+          "v_addc_co_u32_e64 %4, s[28:29], 0, %4, s[20:21]\n")
+          : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7)
+          : "v"(a), "v"(b) : "s20", "s21", "s22", "s23", "s28", "s29");
+    } else if (P == 9) {   // 8 independent moves
+      asm volatile(REP4(
+          "v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n"
+          "v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n")
+          : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7)
+          : "v"(a));
+    } else if (P == 10) {  // 8 independent funnel shifts
+      asm volatile(REP4(
+          "v_alignbit_b32 %0, %8, %0, 3\n v_alignbit_b32 %1, %8, %1, 3\n v_alignbit_b32 %2, %8, %2, 3\n"
+          "v_alignbit_b32 %3, %8, %3, 3\n v_alignbit_b32 %4, %8, %4, 3\n v_alignbit_b32 %5, %8, %5, 3\n"
+          "v_alignbit_b32 %6, %8, %6, 3\n v_alignbit_b32 %7, %8, %7, 3\n")
+          : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7)
+          : "v"(a));
+    } else if (P == 11) {  // 8 independent selects on an SGPR-pair mask
+      asm volatile(REP4(
+          "v_cndmask_b32_e64 %0, %0, %8, s[22:23]\n v_cndmask_b32_e64 %1, %1, %8, s[22:23]\n"
+          "v_cndmask_b32_e64 %2, %2, %8, s[22:23]\n v_cndmask_b32_e64 %3, %3, %8, s[22:23]\n"
+          "v_cndmask_b32_e64 %4, %4, %8, s[22:23]\n v_cndmask_b32_e64 %5, %5, %8, s[22:23]\n"
+          "v_cndmask_b32_e64 %6, %6, %8, s[22:23]\n v_cndmask_b32_e64 %7, %7, %8, s[22:23]\n")
+          : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7)
+          : "v"(a) : "s22", "s23");
+    } else if (P == 12) {  // 8 independent selects on VCC (e32 encoding)
+      asm volatile(REP4(
+          "v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n"
+          "v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+          "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n"
+          "v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n")
+          : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7)
+          : "v"(a));
+    } else if (P == 13) {  // 8 independent add-with-carry-out only (v_add_co, VCC written, never read)
+      asm volatile(REP4(
+          "v_add_co_u32 %0, vcc, %8, %0\n v_add_co_u32 %1, vcc, %8, %1\n v_add_co_u32 %2, vcc, %8, %2\n"
+          "v_add_co_u32 %3, vcc, %8, %3\n v_add_co_u32 %4, vcc, %8, %4\n v_add_co_u32 %5, vcc, %8, %5\n"
+          "v_add_co_u32 %6, vcc, %8, %6\n v_add_co_u32 %7, vcc, %8, %7\n")
+          : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7)
+          : "v"(a) : "vcc");
+    } else if (P == 14) {  // 8 independent 64-bit adds without carry flags
+      asm volatile(REP4(
+          "v_lshl_add_u64 %0, %0, 0, %1\n v_lshl_add_u64 %1, %1, 0, %2\n v_lshl_add_u64 %2, %2, 0, %3\n"
+          "v_lshl_add_u64 %3, %3, 0, %4\n v_lshl_add_u64 %4, %4, 0, %5\n v_lshl_add_u64 %5, %5, 0, %6\n"
+          "v_lshl_add_u64 %6, %6, 0, %7\n v_lshl_add_u64 %7, %7, 0, %0\n")
+          : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7));
+    } else if (P == 15) {  // 8 independent 64-bit right shifts
+      asm volatile(REP4(
+          "v_lshrrev_b64 %0, 3, %0\n v_lshrrev_b64 %1, 3, %1\n v_lshrrev_b64 %2, 3, %2\n v_lshrrev_b64 %3, 3, %3\n"
+          "v_lshrrev_b64 %4, 3, %4\n v_lshrrev_b64 %5, 3, %5\n v_lshrrev_b64 %6, 3, %6\n v_lshrrev_b64 %7, 3, %7\n")
+          : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7));
     } else if (P == 7) {   // 8 independent mads whose 64-bit accumulators sit in the same VGPR bank pattern as a, b
       asm volatile(REP4(
           "v_mad_u64_u32 %0, s[20:21], %8, %9, 0\n v_mad_u64_u32 %1, s[20:21], %8, %9, 0\n"
@@ -112,13 +171,15 @@ int main() {
   u32* out;
   hipMalloc(&out, 1024 * 16 * 64 * 4);
   const int iters = 20000;
-  const int ninstr[8] = {0, 32, 32, 32, 32, 64, 32, 32};   // VALU instructions per loop iteration
-  const char* name[8] = {"", "mad vgpr*vgpr+acc", "mad vgpr*sgpr+acc", "v_add_u32", "v_addc e64 (sgpr carry)",
-                         "product pattern (mad+addc)", "vcc chain + s_nop 1", "mad vgpr*vgpr+0"};
+  const int ninstr[16] = {0, 32, 32, 32, 32, 64, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32};   // VALU instructions per loop iteration
+  const char* name[16] = {"", "mad vgpr*vgpr+acc", "mad vgpr*sgpr+acc", "v_add_u32", "v_addc e64 (sgpr carry)",
+                          "product pattern (mad+addc)", "vcc chain + s_nop 1", "mad vgpr*vgpr+0",
+                          "single-chain mad+addc", "v_mov_b32", "v_alignbit_b32", "v_cndmask e64 (sgpr mask)",
+                          "v_cndmask e32 (vcc)", "v_add_co (carry out only)", "v_lshl_add_u64", "v_lshrrev_b64"};
   int dev_clock_khz = 0;
   hipDeviceGetAttribute(&dev_clock_khz, hipDeviceAttributeClockRate, 0);
   printf("clock attribute %d kHz\n", dev_clock_khz);
-  for (int p = 1; p <= 7; p++) {
+  for (int p = 1; p <= 15; p++) {
     printf("%-30s ns per wave-instruction per SIMD at 1,2,3,4,8 waves:", name[p]);
     for (int w : {1, 2, 3, 4, 8}) {
       double ms = 0;
@@ -130,6 +191,14 @@ int main() {
         case 5: ms = run<5>(w, iters, out); break;
         case 6: ms = run<6>(w, iters, out); break;
         case 7: ms = run<7>(w, iters, out); break;
+        case 8: ms = run<8>(w, iters, out); break;
+        case 9: ms = run<9>(w, iters, out); break;
+        case 10: ms = run<10>(w, iters, out); break;
+        case 11: ms = run<11>(w, iters, out); break;
+        case 12: ms = run<12>(w, iters, out); break;
+        case 13: ms = run<13>(w, iters, out); break;
+        case 14: ms = run<14>(w, iters, out); break;
+        case 15: ms = run<15>(w, iters, out); break;
       }
       double per = ms * 1e6 / ((double)iters * ninstr[p] * w);   // ns of SIMD time per instruction
       printf(" %.3f", per);
