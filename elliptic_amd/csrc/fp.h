@@ -38,9 +38,21 @@ struct Fe {
 // Wide product / square of L-limb integers.  Device code uses the generated
 // v_mad_u64_u32 + carry-out blocks of mul_asm.h; host passes (hipcc's host side
 // and the CPU unit-test build) use the portable operand-scanning code.
+// ELL_MUL_CHAIN = 1: single-accumulator-chain blocks (one column per asm statement, the
+// compiler assembles the next column's (X.hi, E) pair); 0: two-column blocks + carry combines.
+#ifndef ELL_MUL_CHAIN
+#define ELL_MUL_CHAIN 1
+#endif
 template <int L>
 ELL_HD void fe_mul_wide(u32 (&r)[2 * L], const u32 (&a)[L], const u32 (&b)[L]) {
-#if defined(ELL_HAVE_MUL_ASM) && !defined(ELL_NO_ASM_MUL)
+#if defined(ELL_HAVE_MUL_ASM) && !defined(ELL_NO_ASM_MUL) && ELL_MUL_CHAIN
+  if constexpr (L == 6) masm::mulc_wide_6(r, a, b);
+  else if constexpr (L == 7) masm::mulc_wide_7(r, a, b);
+  else if constexpr (L == 8) masm::mulc_wide_8(r, a, b);
+  else if constexpr (L == 12) masm::mulc_wide_12(r, a, b);
+  else if constexpr (L == 17) masm::mulc_wide_17(r, a, b);
+  else bn_mul_wide<L, L>(r, a, b);
+#elif defined(ELL_HAVE_MUL_ASM) && !defined(ELL_NO_ASM_MUL)
   if constexpr (L == 6) masm::mul_wide_6(r, a, b);
   else if constexpr (L == 7) masm::mul_wide_7(r, a, b);
   else if constexpr (L == 8) masm::mul_wide_8(r, a, b);
@@ -55,12 +67,21 @@ template <int L>
 ELL_HD void fe_sqr_wide(u32 (&r)[2 * L], const u32 (&a)[L]) {
 #if defined(ELL_HAVE_MUL_ASM) && !defined(ELL_NO_ASM_MUL)
   u32 off[2 * L];
+#if ELL_MUL_CHAIN
+  if constexpr (L == 6) masm::sqrc_offdiag_6(off, a);
+  else if constexpr (L == 7) masm::sqrc_offdiag_7(off, a);
+  else if constexpr (L == 8) masm::sqrc_offdiag_8(off, a);
+  else if constexpr (L == 12) masm::sqrc_offdiag_12(off, a);
+  else if constexpr (L == 17) masm::sqrc_offdiag_17(off, a);
+  else { bn_sqr_wide<L>(r, a); return; }
+#else
   if constexpr (L == 6) masm::sqr_offdiag_6(off, a);
   else if constexpr (L == 7) masm::sqr_offdiag_7(off, a);
   else if constexpr (L == 8) masm::sqr_offdiag_8(off, a);
   else if constexpr (L == 12) masm::sqr_offdiag_12(off, a);
   else if constexpr (L == 17) masm::sqr_offdiag_17(off, a);
   else { bn_sqr_wide<L>(r, a); return; }
+#endif
   // r = 2*off + sum_i a_i^2 2^(64 i): the squares sit in disjoint 64-bit slots
   u32 c = 0;
   ELL_UNROLL

@@ -256,6 +256,157 @@ def gen_sqr_off(L):
     return "".join(out) + fn
 
 
+# --------------------------------------------------------------------------------------------
+# Single-chain variant: one asm statement per column (or per <= CHAIN_CH products of a column),
+# ONE 64-bit accumulator X + 32-bit extension E.  The next column starts from
+# Xin = (X.hi, E): the pair is assembled by the compiler between the statements (one v_mov),
+# which replaces the three carry-consuming adds of the two-column combine.  On gfx950 every
+# carry-consuming instruction issues at the cost of a v_mad_u64_u32, a plain v_mov at ~0.6 of it.
+# --------------------------------------------------------------------------------------------
+CHAIN_CH = 10       # products per statement (30-operand limit)
+
+
+def chain_stmt(name, prods, has_xin, has_ein, may_carry_first, need_e, square=False):
+    """one statement: X = Xin + sum(products), E = Ein + carries.
+       has_xin/has_ein: incoming values; may_carry_first: the first mad may overflow
+       need_e: the statement has to produce E at all"""
+    # schedule: mads in order; each carrying mad's addc issued >= MIN_DIST positions later
+    seq = []
+    pend = []
+    free = list(range(NSREG))
+    q = list(prods)
+    first = True
+    while q or pend:
+        pos = len(seq)
+        # multiplies first while a carry register is free (puts distance between a carry and
+        # its consumer), then the oldest pending carry, then a wait state
+        if q:
+            carry = need_e and (may_carry_first or not first)
+            if not carry:
+                i, j = q.pop(0)
+                seq.append(("madnc", i, j))
+                first = False
+                continue
+            if free:
+                i, j = q.pop(0)
+                sr = free.pop(0)
+                seq.append(("mad", i, j, sr))
+                pend.append((pos, sr))
+                first = False
+                continue
+        if pend and pos - pend[0][0] >= MIN_DIST:
+            _, sr = pend.pop(0)
+            seq.append(("addc", sr))
+            free.append(sr)
+            continue
+        seq.append(("nop",))
+    used_a = sorted({i for (i, j) in prods})
+    used_b = sorted({j for (i, j) in prods})
+    if square:
+        used_a = sorted(set(used_a) | set(used_b))
+        used_b = []
+    lines = []
+    x_touched = False
+    e_touched = False
+    for ins in seq:
+        if ins[0] == "nop":
+            lines.append("s_nop 0")
+            continue
+        if ins[0] in ("mad", "madnc"):
+            i, j = ins[1], ins[2]
+            bj = ("%%[a%d]" % j) if square else ("%%[b%d]" % j)
+            src = "%[X]" if x_touched else ("%[Xi]" if has_xin else "0")
+            sr = "%%[s%d]" % ins[3] if ins[0] == "mad" else "%[sd]"
+            lines.append("v_mad_u64_u32 %%[X], %s, %%[a%d], %s, %s" % (sr, i, bj, src))
+            x_touched = True
+        else:
+            src = "%[E]" if e_touched else ("%[Ei]" if has_ein else "0")
+            lines.append("v_addc_co_u32_e64 %%[E], %%[sd], 0, %s, %%[s%d]" % (src, ins[1]))
+            e_touched = True
+    if need_e and not e_touched:
+        lines.append("v_mov_b32 %%[E], %s" % ("%[Ei]" if has_ein else "0"))
+    body = "\\n\\t".join(lines)
+    args = ["u64& X"] + (["u32& E"] if need_e else [])
+    args += ["u32 a%d" % i for i in used_a] + ["u32 b%d" % j for j in used_b]
+    outs = ['[X] "=&v"(Xo)'] + (['[E] "=&v"(Eo)'] if need_e else [])
+    outs += ['[s%d] "=&s"(s%d)' % (k, k) for k in range(NSREG)] + ['[sd] "=&s"(sd)']
+    ins_ = []
+    if has_xin:
+        ins_.append('[Xi] "v"(X)')
+    if has_ein:
+        ins_.append('[Ei] "v"(E)')
+    ins_ += ['[a%d] "v"(a%d)' % (i, i) for i in used_a] + ['[b%d] "v"(b%d)' % (j, j) for j in used_b]
+    code = "ELL_DEVASM void %s(%s) {\n" % (name, ", ".join(args))
+    code += "  u64 %s, sd, Xo;\n" % ", ".join("s%d" % k for k in range(NSREG))
+    if need_e:
+        code += "  u32 Eo;\n"
+    code += '  asm("%s"\n      : %s\n      : %s\n      : );\n' % (body, ", ".join(outs), ", ".join(ins_) if ins_ else "")
+    code += "  X = Xo;" + (" E = Eo;" if need_e else "") + "\n"
+    code += "  (void)sd;" + "".join(" (void)s%d;" % k for k in range(NSREG)) + "\n}\n\n"
+    st = (sum(1 for x in seq if x[0] in ("mad", "madnc")), sum(1 for x in seq if x[0] == "addc"),
+          sum(1 for x in seq if x[0] == "nop"))
+    return code, used_a, used_b, st
+
+
+def gen_chain(L, square):
+    """single-chain wide product (square=False) or off-diagonal half of the square"""
+    out = []
+    stats = [0, 0, 0]
+    base = ("sqrc%d" if square else "mulc%d") % L
+    cols = []
+    for k in range(0, 2 * L - 1):
+        pr = [(i, k - i) for i in range(L) if 0 <= k - i < L and (not square or i < k - i)]
+        cols.append(pr)
+    nz = [k for k in range(len(cols)) if cols[k]]
+    first_col, last_col = nz[0], nz[-1]
+    fn_name = ("sqrc_offdiag_%d" if square else "mulc_wide_%d") % L
+    if square:
+        fn = "// r[0..%d) = sum_{i<j} a_i*a_j*2^(32(i+j)), single accumulator chain\n" % (2 * L)
+        fn += "ELL_DEVASM void %s(u32 (&r)[%d], const u32 (&a)[%d]) {\n" % (fn_name, 2 * L, L)
+    else:
+        fn = "// r[0..%d) = a * b, single accumulator chain\n" % (2 * L)
+        fn += "ELL_DEVASM void %s(u32 (&r)[%d], const u32 (&a)[%d], const u32 (&b)[%d]) {\n" % (fn_name, 2 * L, L, L)
+    fn += "  u64 X = 0; u32 E = 0;\n"
+    for k in range(first_col):
+        fn += "  r[%d] = 0;\n" % k
+    e_prev_zero = True          # E of the previous column is known to be zero
+    for k in range(first_col, last_col + 1):
+        pr = cols[k]
+        is_first = k == first_col
+        is_last = k == last_col
+        # the last column's sum cannot overflow 64 bits (the whole value fits 2L limbs); a single
+        # product on top of Xin < 2^32 cannot either
+        need_e = not is_last and not (len(pr) == 1 and e_prev_zero)
+        chunks = [pr[c:c + CHAIN_CH] for c in range(0, len(pr), CHAIN_CH)]
+        for ci, ch in enumerate(chunks):
+            name = "%s_%d_%d" % (base, k, ci)
+            has_xin = (not is_first) or ci > 0
+            has_ein = ci > 0 and need_e
+            # first mad of the column: Xin = (X.hi, E_prev) < 2^32 when E_prev == 0 -> cannot overflow
+            may_carry_first = (ci > 0) or (not e_prev_zero)
+            code, ua, ub, st = chain_stmt(name, ch, has_xin, has_ein, may_carry_first, need_e, square)
+            out.append(code)
+            for t in range(3):
+                stats[t] += st[t]
+            call_args = ["X"] + (["E"] if need_e else [])
+            call_args += ["a[%d]" % i for i in ua] + ["b[%d]" % j for j in ub]
+            fn += "  %s(%s);\n" % (name, ", ".join(call_args))
+        fn += "  r[%d] = (u32)X;\n" % k
+        if not is_last:
+            if need_e:
+                fn += "  X = ((u64)E << 32) | (X >> 32);\n"
+                e_prev_zero = False
+            else:
+                fn += "  X = X >> 32;\n"
+        else:
+            fn += "  r[%d] = (u32)(X >> 32);\n" % (k + 1)
+    for k in range(last_col + 2, 2 * L):
+        fn += "  r[%d] = 0;\n" % k
+    fn += "}\n"
+    fn = fn.replace("single accumulator chain", "single accumulator chain (%d v_mad_u64_u32, %d v_addc, %d s_nop)" % tuple(stats))
+    return "".join(out) + fn + "\n"
+
+
 def main():
     hdr = ('// GENERATED by tools/gen_mul_asm.py -- do not edit.\n'
            '// gfx950 inline-asm multiply-accumulate blocks (v_mad_u64_u32 with carry-out into an\n'
@@ -270,6 +421,8 @@ def main():
     for L in (6, 7, 8, 12, 17):
         body += gen_mul(L)
         body += gen_sqr_off(L)
+        body += gen_chain(L, False)
+        body += gen_chain(L, True)
     tail = "}  // namespace masm\n}  // namespace ell\n#endif  // __HIP_DEVICE_COMPILE__\n"
     with open(DST, "w") as f:
         f.write(hdr + body + tail)
