@@ -34,6 +34,7 @@ struct FnMulVar {
   static constexpr const char* NAME = "mul_var";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
+  static constexpr int MIN_WAVES = W::L <= 8 ? 4 : 1;       // <= 128 VGPRs for 256-bit curves: +2..4 % despite ~50 B of spills
   size_t n; const u8* k; const u8* xy; typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) W::mul_var(i, n, k, xy, tbl, ds, jac);
