@@ -246,7 +246,32 @@ struct FpK256 {
   // fold a 512-bit value t[0..16) to [0,p): 2^256 == 2^32 + 977 (mod p).
   // Written with explicit carry chains (addc32) so that gfx950 gets
   // v_add_co/v_addc instead of 64-bit add + move pairs.
+#if defined(ELL_HAVE_MUL_ASM) && !defined(ELL_NO_ASM_MUL)
+  // Device form of the first fold: x_i = hi_i * 977 + (lo_i + hi_i * 2^32) is ONE multiply-add
+  // per limb -- the 64-bit addend pair (lo_i, hi_i) carries both lo and the hi << 32 term --
+  // and u = sum x_i 2^(32 i) is one carry chain.  x_i overflows 64 bits only when
+  // hi_i >= 2^32 - 977; the multiply-adds' carry-out masks are OR-ed on the scalar unit and a
+  // wave that sees one (probability ~1e-4 per multiply) redoes the fold the generic way.
   ELL_HD static El reduce_wide(const u32 (&t)[16]) {
+    u64 x[8];
+    u64 m0 = masm::fold4(x[0], x[1], x[2], x[3], ((u64)t[8] << 32) | t[0], ((u64)t[9] << 32) | t[1],
+                         ((u64)t[10] << 32) | t[2], ((u64)t[11] << 32) | t[3], t[8], t[9], t[10], t[11], C0);
+    u64 m1 = masm::fold4(x[4], x[5], x[6], x[7], ((u64)t[12] << 32) | t[4], ((u64)t[13] << 32) | t[5],
+                         ((u64)t[14] << 32) | t[6], ((u64)t[15] << 32) | t[7], t[12], t[13], t[14], t[15], C0);
+    if (ELL_UNLIKELY((m0 | m1) != 0)) return reduce_wide_generic(t);
+    u32 u[10];
+    u32 c = 0;
+    u[0] = (u32)x[0];
+    ELL_UNROLL
+    for (int i = 1; i < 8; i++) u[i] = addc32((u32)x[i], (u32)(x[i - 1] >> 32), c, c);
+    u[8] = addc32((u32)(x[7] >> 32), 0, c, c);
+    u[9] = c;
+    return fold_top(u);
+  }
+#else
+  ELL_HD static El reduce_wide(const u32 (&t)[16]) { return reduce_wide_generic(t); }
+#endif
+  ELL_HD static El reduce_wide_generic(const u32 (&t)[16]) {
     // v = hi * 977: eight independent 32x10-bit products
     u32 pl[8], ph[8];
     ELL_UNROLL
@@ -273,7 +298,11 @@ struct FpK256 {
     for (int i = 0; i < 8; i++) u[i] = addc32(t[i], w[i], c, c);
     u[8] = addc32(w[8], 0, c, c);
     u[9] = w[9] + c;
-    // second fold: r = u[0..8) + T*977 + (T << 32)
+    return fold_top(u);
+  }
+  // second fold: r = u[0..8) + T*977 + (T << 32) for T = u[8] + u[9]*2^32 < 2^34, canonicalised
+  ELL_HD static El fold_top(const u32 (&u)[10]) {
+    u32 c;
     u64 q = (u64)u[8] * C0;
     u32 t0 = (u32)q;
     u32 t1 = (u32)(q >> 32) + u[9] * C0;       // < 2^10 + 2^12

@@ -407,6 +407,30 @@ def gen_chain(L, square):
     return "".join(out) + fn + "\n"
 
 
+def gen_fold4():
+    """x_i = h_i * k + P_i for four (h, P) pairs, P a 64-bit addend; returns the OR of the four
+    carry-out masks (non-zero when any lane overflowed 64 bits in any of them)"""
+    body = "\\n\\t".join(
+        ["v_mad_u64_u32 %%[x%d], %%[c%d], %%[h%d], %%[k], %%[P%d]" % (i, i, i, i) for i in range(4)] +
+        ["s_nop 1",
+         "s_or_b64 %[m], %[c0], %[c1]",
+         "s_or_b64 %[c2], %[c2], %[c3]",
+         "s_or_b64 %[m], %[m], %[c2]"])
+    code = "// x_i = h_i * k + P_i (i = 0..3); returns the OR of the carry-out lane masks\n"
+    code += "ELL_DEVASM u64 fold4(u64& x0, u64& x1, u64& x2, u64& x3, u64 P0, u64 P1, u64 P2, u64 P3,\n"
+    code += "                     u32 h0, u32 h1, u32 h2, u32 h3, u32 k) {\n"
+    code += "  u64 c0, c1, c2, c3, m, o0, o1, o2, o3;\n"
+    code += '  asm("%s"\n' % body
+    code += '      : [x0] "=&v"(o0), [x1] "=&v"(o1), [x2] "=&v"(o2), [x3] "=&v"(o3), [m] "=&s"(m),\n'
+    code += '        [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3)\n'
+    code += '      : [P0] "v"(P0), [P1] "v"(P1), [P2] "v"(P2), [P3] "v"(P3),\n'
+    code += '        [h0] "v"(h0), [h1] "v"(h1), [h2] "v"(h2), [h3] "v"(h3), [k] "s"(k)\n'
+    code += '      : "scc");\n'
+    code += "  x0 = o0; x1 = o1; x2 = o2; x3 = o3;\n"
+    code += "  (void)c0; (void)c1; (void)c2; (void)c3;\n  return m;\n}\n\n"
+    return code
+
+
 def main():
     hdr = ('// GENERATED by tools/gen_mul_asm.py -- do not edit.\n'
            '// gfx950 inline-asm multiply-accumulate blocks (v_mad_u64_u32 with carry-out into an\n'
@@ -423,6 +447,7 @@ def main():
         body += gen_sqr_off(L)
         body += gen_chain(L, False)
         body += gen_chain(L, True)
+    body += gen_fold4()
     tail = "}  // namespace masm\n}  // namespace ell\n#endif  // __HIP_DEVICE_COMPILE__\n"
     with open(DST, "w") as f:
         f.write(hdr + body + tail)
