@@ -494,7 +494,38 @@ struct Fp25519 {
     return finish(lo, 19u * top);
   }
 
+#if defined(ELL_HAVE_MUL_ASM) && !defined(ELL_NO_ASM_MUL)
+  // Device form: the even high limbs fold as x_j = 38 * hi_2j + (lo_2j, lo_2j+1) -- the four
+  // 64-bit addend pairs tile the low half exactly -- and the odd ones as y_j = 38 * hi_2j+1,
+  // which land on disjoint limbs (2j+1, 2j+2); u = E + O is then one carry chain.  x_j can
+  // overflow 64 bits (probability ~2^-27 per limb): the OR of the carry-out masks sends the
+  // wave to the generic fold.
   ELL_HD static El reduce_wide(const u32 (&t)[16]) {
+    u64 x[4];
+    u64 m = masm::fold4(x[0], x[1], x[2], x[3], ((u64)t[1] << 32) | t[0], ((u64)t[3] << 32) | t[2],
+                        ((u64)t[5] << 32) | t[4], ((u64)t[7] << 32) | t[6], t[8], t[10], t[12], t[14], 38u);
+    if (ELL_UNLIKELY(m != 0)) return reduce_wide_generic(t);
+    u64 y[4];
+    ELL_UNROLL
+    for (int j = 0; j < 4; j++) y[j] = (u64)t[9 + 2 * j] * 38u;
+    u32 u[8];
+    u32 c = 0;
+    u[0] = (u32)x[0];
+    u[1] = addc32((u32)(x[0] >> 32), (u32)y[0], c, c);
+    ELL_UNROLL
+    for (int j = 1; j < 4; j++) {
+      u[2 * j] = addc32((u32)x[j], (u32)(y[j - 1] >> 32), c, c);
+      u[2 * j + 1] = addc32((u32)(x[j] >> 32), (u32)y[j], c, c);
+    }
+    u32 carry = (u32)(y[3] >> 32) + c;          // < 2^7
+    u32 top = u[7] >> 31;
+    u[7] &= 0x7FFFFFFFu;
+    return finish(u, carry * 38u + 19u * top);
+  }
+#else
+  ELL_HD static El reduce_wide(const u32 (&t)[16]) { return reduce_wide_generic(t); }
+#endif
+  ELL_HD static El reduce_wide_generic(const u32 (&t)[16]) {
     // v = 38*hi: eight independent 32x6-bit products; u = lo + v (9 limbs)
     u32 pl[8], ph[8];
     ELL_UNROLL

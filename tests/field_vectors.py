@@ -33,6 +33,94 @@ def f25519_mul_trace(a, b):
     return ((ul & 0xFFFFFFFF) + add0) >> 32, (ul >> 224) & 0x7FFFFFFF
 
 
+def k256_fold_overflow(a, b):
+    """mirror of the device FpK256::reduce_wide: does any x_i = hi_i*977 + lo_i + hi_i*2^32
+    overflow 64 bits (the wave then takes the generic fold)?"""
+    N = a * b
+    for i in range(8):
+        lo = (N >> (32 * i)) & 0xFFFFFFFF
+        hi = (N >> (32 * (8 + i))) & 0xFFFFFFFF
+        if hi * 977 + lo + (hi << 32) >= 1 << 64:
+            return True
+    return False
+
+
+def fold_vectors():
+    """-> (field 0, op 2) vectors around the overflow boundary of the device fold: high product
+    limbs in [2^32 - 980, 2^32), both overflowing and not, mixed so that lanes of one wave
+    disagree"""
+    import random
+    rnd = random.Random(2024)
+    p = P_K256
+    out = []
+    n_over = n_not = 0
+    for trial in range(4000):
+        j = rnd.randrange(1, 8)
+        a = rnd.getrandbits(256)
+        # force one limb of a (it becomes a high limb of a * 2^(32 j)(+1)) to the boundary region
+        pos = rnd.randrange(8 - j, 8)
+        limb = 0xFFFFFFFF - rnd.randrange(0, 985)
+        a = (a & ~(0xFFFFFFFF << (32 * pos))) | (limb << (32 * pos))
+        a %= p
+        b = ((1 << (32 * j)) + rnd.choice([0, 1, 1, 0xFFFFFFFF, 977, rnd.getrandbits(32)])) % p
+        over = k256_fold_overflow(a, b)
+        if over and n_over < 150:
+            n_over += 1
+        elif not over and n_not < 150:
+            n_not += 1
+        else:
+            continue
+        out.append((0, 2, a, b, a * b % p))
+        if n_over >= 150 and n_not >= 150:
+            break
+    assert n_over >= 50 and n_not >= 50, (n_over, n_not)
+    rnd.shuffle(out)
+    return out
+
+
+def f25519_fold_overflow(a, b):
+    """mirror of the device Fp25519::reduce_wide: does 38*hi_2j + (lo_2j, lo_2j+1) overflow?"""
+    N = a * b
+    for j in range(4):
+        lo = (N >> (64 * j)) & ((1 << 64) - 1)
+        hi = (N >> (32 * (8 + 2 * j))) & 0xFFFFFFFF
+        if 38 * hi + lo >= 1 << 64:
+            return True
+    return False
+
+
+def fold25519_vectors():
+    """(field 1, op 2) vectors on both sides of the device fold's overflow boundary: a low
+    64-bit pair within 38 * 2^32 of 2^64"""
+    import random
+    rnd = random.Random(777)
+    p = P_25519
+    out = []
+    n_over = n_not = 0
+    for trial in range(20000):
+        # N = a * b with b = 2^(64 j) + small: low pairs of N are pairs of a
+        j = rnd.randrange(0, 3)
+        a = rnd.getrandbits(255)
+        pos = rnd.randrange(0, 4 - j)
+        pair = (1 << 64) - 1 - rnd.randrange(0, 40 << 32)
+        a = (a & ~(((1 << 64) - 1) << (64 * pos))) | (pair << (64 * pos))
+        a %= p
+        b = ((1 << (64 * j)) + (rnd.getrandbits(30) << 64 * 3)) % p if j else (1 + (rnd.getrandbits(60) << 190)) % p
+        over = f25519_fold_overflow(a, b)
+        if over and n_over < 120:
+            n_over += 1
+        elif not over and n_not < 120:
+            n_not += 1
+        else:
+            continue
+        out.append((1, 2, a, b, a * b % p))
+        if n_over >= 120 and n_not >= 120:
+            break
+    assert n_over >= 30 and n_not >= 30, (n_over, n_not)
+    rnd.shuffle(out)
+    return out
+
+
 def rare_vectors():
     """-> list of (field, op, a, b, expected); op: 0 add, 1 sub, 2 mul, 3 sqr (b ignored)"""
     out = []

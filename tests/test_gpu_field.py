@@ -83,7 +83,7 @@ def test_field_ops_gpu(ctx, field):
 def test_rare_branches_gpu(ctx):
     """the directed vectors of tests/field_vectors.py through the device code (asm products)"""
     import field_vectors
-    vecs = field_vectors.rare_vectors() + field_vectors.shift_vectors()
+    vecs = field_vectors.rare_vectors() + field_vectors.shift_vectors() + field_vectors.fold_vectors() + field_vectors.fold25519_vectors()
     for field in (0, 1):
         for op in (0, 1, 2, 3, 6, 7, 8, 10):
             sel = [v for v in vecs if v[0] == field and v[1] == op]

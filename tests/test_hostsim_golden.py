@@ -90,7 +90,7 @@ def test_rare_branches_k256_25519(hs):
     """Directed vectors for the carry-ripple / final-subtraction branches that random inputs
     reach with probability ~2^-31 (FpK256 and Fp25519 add, sub, mul, sqr)."""
     import field_vectors
-    vecs = field_vectors.rare_vectors() + field_vectors.shift_vectors()
+    vecs = field_vectors.rare_vectors() + field_vectors.shift_vectors() + field_vectors.fold_vectors() + field_vectors.fold25519_vectors()
     assert len(vecs) > 1500
     for field, op, a, b, want in vecs:
         r = (ctypes.c_uint32 * 8)()
