@@ -110,10 +110,14 @@ struct ShortOps {
     r.X = F::sub(F::sub(F::sqr(rr), hhh), F::template mul_pow2<1>(v));
     r.Y = F::sub(F::mul(rr, F::sub(v, r.X)), F::mul(p.Y, hhh));
     r.Z = F::mul(p.Z, h);          // h == 0, rr != 0  ->  Z3 = 0: infinity
-    bool pinf = F::is_zero(p.Z);
-    bool same = F::is_zero(h) && F::is_zero(rr) && !pinf;
-    if (ELL_UNLIKELY(same && do_add)) r = dbl(from_affine(q));   // P == Q
-    r = select(pinf, from_affine(q), r);                         // O + Q = Q
+    // Every exceptional input (P = O, P = Q, P = -Q) gives Z3 = Z1 * h = 0: one zero test on
+    // the common path, the case analysis behind a branch that is almost never taken.
+    if (ELL_UNLIKELY(F::is_zero(r.Z))) {
+      bool pinf = F::is_zero(p.Z);
+      bool same = F::is_zero(h) && F::is_zero(rr) && !pinf;
+      if (same) r = dbl(from_affine(q));                         // P == Q
+      r = select(pinf, from_affine(q), r);                       // O + Q = Q  (P == -Q keeps Z3 = 0)
+    }
     return select(do_add, r, p);
   }
 
@@ -152,12 +156,15 @@ struct ShortOps {
     r.X = F::sub(F::sub(F::sqr(rr), hhh), F::template mul_pow2<1>(v));
     r.Y = F::sub(F::mul(rr, F::sub(v, r.X)), F::mul(s1, hhh));
     r.Z = F::mul(F::mul(p.Z, q.Z), h);
-    bool pinf = F::is_zero(p.Z);
-    bool qinf = F::is_zero(q.Z);
-    bool same = F::is_zero(h) && F::is_zero(rr) && !pinf && !qinf;
-    if (ELL_UNLIKELY(same && do_add)) r = dbl(p);                // P == Q
-    r = select(pinf, q, r);                                      // O + Q = Q
-    r = select(qinf, p, r);                                      // P + O = P
+    // P = O, Q = O, P = Q and P = -Q all give Z3 = Z1 * Z2 * h = 0
+    if (ELL_UNLIKELY(F::is_zero(r.Z))) {
+      bool pinf = F::is_zero(p.Z);
+      bool qinf = F::is_zero(q.Z);
+      bool same = F::is_zero(h) && F::is_zero(rr) && !pinf && !qinf;
+      if (same) r = dbl(p);                                      // P == Q
+      r = select(pinf, q, r);                                    // O + Q = Q
+      r = select(qinf, p, r);                                    // P + O = P
+    }
     return select(do_add, r, p);
   }
 };
