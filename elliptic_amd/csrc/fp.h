@@ -22,6 +22,7 @@
 #include "common.h"
 #include "curve_consts.h"
 #include "mul_asm.h"
+#include "safegcd.h"
 
 // field multiplies of moduli with at least this many limbs are real function calls
 #ifndef ELL_MONT_CALL_MINL
@@ -345,25 +346,11 @@ struct FpK256 {
     for (int i = 0; i < n; i++) a = sqr(a);
     return a;
   }
-  // a^(p-2): addition chain over the run structure of p-2
-  // (223 ones, 0, 22 ones, 0000, 1, 0, 11, 0, 1)  -- 255 S + 15 M
+  // a^-1 (0 for 0): Bernstein-Yang division steps, safegcd.h
   static ELL_HD_NOINLINE El inv(const El& a) {
-    El x2 = mul(sqr(a), a);
-    El x3 = mul(sqr(x2), a);
-    El x6 = mul(sqr_n(x3, 3), x3);
-    El x9 = mul(sqr_n(x6, 3), x3);
-    El x11 = mul(sqr_n(x9, 2), x2);
-    El x22 = mul(sqr_n(x11, 11), x11);
-    El x44 = mul(sqr_n(x22, 22), x22);
-    El x88 = mul(sqr_n(x44, 44), x44);
-    El x176 = mul(sqr_n(x88, 88), x88);
-    El x220 = mul(sqr_n(x176, 44), x44);
-    El x223 = mul(sqr_n(x220, 3), x3);
-    El t = mul(sqr_n(x223, 23), x22);
-    t = mul(sqr_n(t, 5), a);
-    t = mul(sqr_n(t, 3), x2);
-    t = mul(sqr_n(t, 2), a);
-    return t;
+    El r;
+    SafeGcd<consts::SECP256K1_P>::inv(r.v, a.v);
+    return r;
   }
   // a^((p+1)/4): a square root of a when a is a square (p = 3 mod 4).  The exponent is
   // 223 ones, 0, 22 ones, 0000, 11, 00 in binary -- 253 S + 13 M.  (bn.js Red#sqrt,
@@ -565,20 +552,11 @@ struct Fp25519 {
     for (int i = 0; i < n; i++) a = sqr(a);
     return a;
   }
-  // a^(p-2) = a^(2^255 - 21): the classic 254 S + 11 M chain
+  // z^-1 (0 for 0): Bernstein-Yang division steps, safegcd.h
   static ELL_HD_NOINLINE El inv(const El& z) {
-    El z2 = sqr(z);
-    El z9 = mul(sqr_n(z2, 2), z);
-    El z11 = mul(z9, z2);
-    El z2_5_0 = mul(sqr(z11), z9);
-    El z2_10_0 = mul(sqr_n(z2_5_0, 5), z2_5_0);
-    El z2_20_0 = mul(sqr_n(z2_10_0, 10), z2_10_0);
-    El z2_40_0 = mul(sqr_n(z2_20_0, 20), z2_20_0);
-    El z2_50_0 = mul(sqr_n(z2_40_0, 10), z2_10_0);
-    El z2_100_0 = mul(sqr_n(z2_50_0, 50), z2_50_0);
-    El z2_200_0 = mul(sqr_n(z2_100_0, 100), z2_100_0);
-    El z2_250_0 = mul(sqr_n(z2_200_0, 50), z2_50_0);
-    return mul(sqr_n(z2_250_0, 5), z11);
+    El r;
+    SafeGcd<consts::P25519_P>::inv(r.v, z.v);
+    return r;
   }
   // z^((p-5)/8) = z^(2^252 - 3): the building block of the square root of a ratio
   static ELL_HD_NOINLINE El pow22523(const El& z) {
@@ -861,8 +839,15 @@ struct FpMont {
   // a^((p+1)/4): square root for p = 3 (mod 4) (bn.js Red#sqrt takes the same power)
   static constexpr bool HAS_SQRT = P::P3MOD4;
   static ELL_HD_NOINLINE El sqrt(const El& a) { return pow_const_window<FpMont<P>, L>(a, P::pp1d4); }
-  // a^(p-2) (amortised over a whole batch by Montgomery's trick, see normalize)
-  static ELL_HD_NOINLINE El inv(const El& a) { return pow_const_window<FpMont<P>, L>(a, P::pm2); }
+  // (aR)^-1 by division steps (safegcd.h) is a^-1 R^-1; one Montgomery multiply by R^3 gives
+  // a^-1 R.  (Amortised over a whole batch by Montgomery's trick, see normalize.)
+  static ELL_HD_NOINLINE El inv(const El& a) {
+    El y, r3;
+    SafeGcd<P>::inv(y.v, a.v);
+    ELL_UNROLL
+    for (int i = 0; i < L; i++) r3.v[i] = P::r3[i];
+    return mul(y, r3);
+  }
 };
 
 // --------------------------------------------------------------------------
@@ -987,7 +972,11 @@ struct FpSolinas {
     for (int i = 0; i < n; i++) a = sqr(a);
     return a;
   }
-  static ELL_HD_NOINLINE El inv(const El& a) { return pow_const_window<FpSolinas<R>, L>(a, MP::pm2); }
+  static ELL_HD_NOINLINE El inv(const El& a) {
+    El r;
+    SafeGcd<MP>::inv(r.v, a.v);
+    return r;
+  }
   static ELL_HD_NOINLINE El sqrt(const El& a) { return pow_const_window<FpSolinas<R>, L>(a, MP::pp1d4); }
 };
 
@@ -1147,22 +1136,10 @@ struct FpP521 {
     for (int i = 0; i < n; i++) a = sqr(a);
     return a;
   }
-  // a^(2^521 - 3) = (a^(2^519 - 1))^4 * a, with f(k) = a^(2^k - 1): f(2k) = f(k)^(2^k) f(k)
   static ELL_HD_NOINLINE El inv(const El& a) {
-    El f1 = a;
-    El f2 = mul(sqr(f1), f1);
-    El f3 = mul(sqr(f2), a);
-    El f4 = mul(sqr_n(f2, 2), f2);
-    El f7 = mul(sqr_n(f4, 3), f3);
-    El f8 = mul(sqr_n(f4, 4), f4);
-    El f16 = mul(sqr_n(f8, 8), f8);
-    El f32 = mul(sqr_n(f16, 16), f16);
-    El f64 = mul(sqr_n(f32, 32), f32);
-    El f128 = mul(sqr_n(f64, 64), f64);
-    El f256 = mul(sqr_n(f128, 128), f128);
-    El f512 = mul(sqr_n(f256, 256), f256);
-    El f519 = mul(sqr_n(f512, 7), f7);
-    return mul(sqr_n(f519, 2), a);
+    El r;
+    SafeGcd<consts::P521_P>::inv(r.v, a.v);
+    return r;
   }
   // (p + 1) / 4 = 2^519: the square root is 519 squarings
   static ELL_HD_NOINLINE El sqrt(const El& a) { return sqr_n(a, 519); }

@@ -70,14 +70,18 @@ def test_field_ops_gpu(ctx, field):
         got = _unpack(R)
         for i in range(n):
             assert got[i] == fn(a[i], b[i]), (field, op, hex(a[i]), hex(b[i]), hex(got[i]))
-    m = 64
+    # inversion (division steps, csrc/safegcd.h): edge values, powers of two, long zero runs, random
+    inv_in = [0, 1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << 30, (1 << 30) - 1, (1 << 60) + 1, p >> 1]
+    inv_in += [(1 << k) % p for k in range(1, p.bit_length(), 29)]
+    inv_in += [((rnd.randrange(p) >> k) << k) % p for k in (1, 17, 30, 31, 61, 90)]
+    inv_in += a[:400]
+    m = len(inv_in)
     R = np.zeros((m, L), np.uint32)
-    nz = [x if x else 1 for x in a[:m]]
-    A2 = _pack(nz, L)
+    A2 = _pack(inv_in, L)
     assert ctx._lib.ellgpu_debug_field_op(ctx._ctx, field, 4, m, A2.ctypes.data, A2.ctypes.data, R.ctypes.data) == 0
     got = _unpack(R)
     for i in range(m):
-        assert got[i] == pow(nz[i], -1, p), (field, "inv", hex(nz[i]))
+        assert got[i] == (pow(inv_in[i], -1, p) if inv_in[i] else 0), (field, "inv", hex(inv_in[i]))
 
 
 def test_rare_branches_gpu(ctx):

@@ -86,6 +86,28 @@ def test_field_ops(hs, field):
         assert _val(r) == pow(a % p, -1, p)
 
 
+def _inv_values(p, rnd, count):
+    vals = [0, 1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << 30, (1 << 30) - 1, (1 << 60) + 1,
+            1 << (p.bit_length() - 1), (1 << (p.bit_length() - 1)) - 1, p >> 1, 0x3FFFFFFF << 30]
+    vals += [(1 << k) % p for k in range(1, p.bit_length(), 29)]
+    vals += [(rnd.randrange(p) >> k) << k for k in (1, 17, 30, 31, 61, 90)]       # long runs of even steps
+    vals += [rnd.randrange(p) for _ in range(count)]
+    return [v % p for v in vals]
+
+
+@pytest.mark.parametrize("field", sorted(FIELDS))
+def test_field_inversion(hs, field):
+    """division-step inversion (csrc/safegcd.h) in every field: edge values, powers of two,
+    operands with long zero runs, random; inv(0) = 0 as bn.js `invm` callers expect"""
+    p = FIELDS[field]
+    L = hs.hs_field_limbs(field)
+    rnd = random.Random(31337 + field)
+    for a in _inv_values(p, rnd, 150):
+        r = (ctypes.c_uint32 * L)()
+        assert hs.hs_field_op(field, 4, _limbs(a, L), _limbs(0, L), r) == 0
+        assert _val(r) == (pow(a, -1, p) if a else 0), (field, hex(a))
+
+
 def test_rare_branches_k256_25519(hs):
     """Directed vectors for the carry-ripple / final-subtraction branches that random inputs
     reach with probability ~2^-31 (FpK256 and Fp25519 add, sub, mul, sqr)."""
