@@ -22,6 +22,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libellgpu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+FLAGS += os.environ.get("ELLGPU_CXXFLAGS", "").split()      # developer experiments (-DELL_...=...)
 
 CURVES = ["CvP521", "CvP384", "CvP256", "CvSecp256k1", "CvP224", "CvP192"]   # slowest first
 GROUPS = [4, 2, 3, 0, 1, 5]
