@@ -77,6 +77,9 @@ struct EdWork {
     r.d = fe_select<F>(c, x.d, y.d);
     return r;
   }
+  // WT = false: the T coordinate of the result is not produced (only an addition reads it, so
+  // a doubling followed by a doubling leaves it out: 3M + 4S)
+  template <bool WT = true>
   ELL_HD static P dbl(const P& p) {
     El A = F::sqr(p.a);
     El B = F::sqr(p.b);
@@ -89,12 +92,14 @@ struct EdWork {
     P r;
     r.a = F::mul(E, Ff);
     r.b = F::mul(G, H);
-    r.d = F::mul(E, H);
+    if (WT) r.d = F::mul(E, H);
+    else r.d = p.d;
     r.c = F::mul(Ff, G);
     return r;
   }
-  // p (extended) + q (cached); !do_add returns p
-  ELL_HD static P add(const P& p, const P& q, bool do_add = true) {
+  // p (extended) + q (cached); !do_add returns p.  with_t = false: T of the sum is not produced
+  // (the next operation is a doubling)
+  ELL_HD static P add(const P& p, const P& q, bool do_add = true, bool with_t = true) {
     El A = F::mul(F::sub(p.b, p.a), q.b);
     El B = F::mul(F::add(p.b, p.a), q.a);
     El Cc = F::mul(p.d, q.d);
@@ -106,7 +111,8 @@ struct EdWork {
     P r;
     r.a = F::mul(E, Ff);
     r.b = F::mul(G, H);
-    r.d = F::mul(E, H);
+    r.d = p.d;
+    if (with_t) r.d = F::mul(E, H);               // wave-uniform condition
     r.c = F::mul(Ff, G);
     return select(do_add, r, p);
   }
@@ -152,15 +158,18 @@ struct EdWork {
     for (int w = NWIN - 1; w >= 0; w--) {
       if (w != NWIN - 1) {
         ELL_NOUNROLL
-        for (int j = 0; j < 4; j++) acc = dbl(acc);
+        for (int j = 0; j < 3; j++) acc = dbl<false>(acc);
+        acc = dbl<true>(acc);                      // the addition below reads T
       }
-      ELL_NOUNROLL
+      ELL_UNROLL
       for (int s = 0; s < NS; s++) {
         int d = ds.get(w * NS + s);
         int ad = d < 0 ? -d : d;
         int e = ad ? ad - 1 : 0;
         P q = cached_cneg(tbl[s * 8 + e], d < 0);
-        acc = add(acc, q, ad != 0);
+        // T of the sum is read by the next addition of this window, or by the caller after the
+        // last window; four doublings follow otherwise
+        acc = add(acc, q, ad != 0, s + 1 < NS || w == 0);
       }
     }
     return acc;
