@@ -169,6 +169,7 @@ struct FnEddsaVerify {
 struct FnEdMulVar {
   static constexpr const char* NAME = "ed_mul_var";
   static constexpr int DS_PER_LANE = EdWork::NWIN;
+  static constexpr int MIN_WAVES = 4;          // <= 128 VGPRs
   size_t n; const u8* k; const u8* xy; EdWork::P* tbl; u32* ext;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) EdWork::mul_var(i, n, k, xy, tbl, ds, ext);
