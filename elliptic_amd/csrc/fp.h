@@ -1,13 +1,16 @@
 // ellgpu -- prime-field arithmetic, one field element per lane, limbs in VGPRs.
 //
-// Three field families, all exposing the same static interface (L, El, add,
-// sub, neg, dbl, mul, sqr, inv, is_zero, eq, from_plain, to_plain, one, zero):
+// Field families, all exposing the same static interface (L, El, add, sub, neg, dbl,
+// mul_pow2, mul, sqr, inv, is_zero, eq, from_plain, to_plain, one, zero):
 //
 //   FpK256      p = 2^256 - 2^32 - 977 (secp256k1): plain residues, the
 //               512-bit product is folded with 2^256 == 2^32 + 977.
 //   Fp25519     p = 2^255 - 19: plain residues, folded with 2^256 == 38.
-//   FpMont<P>   any odd modulus (NIST primes, and every group order n):
-//               Montgomery residues (x*R mod p, R = 2^(32L)), CIOS multiply.
+//   FpSolinas   p256 / p384: plain residues, FIPS 186-4 D.2 word sums.
+//   FpP521      p = 2^521 - 1: plain residues, Mersenne fold.
+//   FpMont<P>   any odd modulus (p192, p224, and every group order n):
+//               Montgomery residues (x*R mod p, R = 2^(32L)); wide product + row-wise REDC
+//               on the device, CIOS in the host test build.
 //
 // They replace bn.js `Red`+`K256` / `Red`+`P25519` / `Mont` contexts
 // (reference: dist/elliptic.js:6888-7381) -- internal representation is ours;
