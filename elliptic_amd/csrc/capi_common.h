@@ -153,6 +153,20 @@ int ellgpu_eddsa_verify_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, cons
                                                 out_ok, out_err));
 }
 
+int ellgpu_eddsa_sign(ellgpu_ctx* ctx, size_t n, const uint8_t* secrets, const uint8_t* msgs,
+                      const uint64_t* msg_off, size_t msg_len, uint8_t* out_sig, uint8_t* out_pub) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->eddsa_sign_host(n, secrets, msgs, (const ell::u64*)msg_off, msg_len, out_sig,
+                                               out_pub));
+}
+int ellgpu_eddsa_sign_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* secrets, const uint8_t* msgs,
+                          const uint64_t* msg_off, size_t msg_len, uint8_t* out_sig, uint8_t* out_pub,
+                          void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->eddsa_sign_dev(n, secrets, msgs, (const ell::u64*)msg_off, msg_len, out_sig,
+                                              out_pub));
+}
+
 int ellgpu_mul_fixed_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, uint8_t* out_xy,
                          uint8_t* out_inf, void* stream) {
   ELL_ENTER(ctx, stream);

@@ -289,21 +289,10 @@ struct EdWork {
   // :65-70, little-endian), accept iff R + h*A == S*G.  ok = 0/1; err = 1 where the
   // reference throws (R or A does not decode to a curve point) -- only evaluated when S < n,
   // as in the reference.  sig = R || S and pub = A in their 32-byte wire encodings.
-  ELL_HD static void eddsa_verify(size_t i, const u8* msg, u64 msg_len, const u8* sig,
-                                  const u8* pub, const P* comb, P* tbl_all, const DigitStore& ds,
-                                  u8* out_ok, u8* out_err) {
+  // hashInt (eddsa/index.js:65-70): a 64-byte digest read little-endian, mod n -> plain limbs.
+  // h = (hi * 2^256 + lo) mod n: the Montgomery image of hi IS hi * 2^256 mod n.
+  ELL_HD static void hash_int(u32 (&h)[8], const u8 (&digest)[64]) {
     typedef FpMont<consts::ED25519_N> Fn;
-    u32 S[8], nn[8];
-    ELL_UNROLL
-    for (int l = 0; l < 8; l++) {
-      const u8* q = sig + 32 + 4 * l;
-      S[l] = (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16) | ((u32)q[3] << 24);
-      nn[l] = C::n[l];
-    }
-    bool s_ok = !bn_geq<8>(S, nn);
-    u8 digest[64];
-    Sha512::hash3(digest, sig, 32, pub, 32, msg, msg_len);
-    // h = (hi * 2^256 + lo) mod n: the Montgomery image of hi IS hi * 2^256 mod n
     u32 lo[8], hi[8];
     ELL_UNROLL
     for (int l = 0; l < 8; l++) {
@@ -318,8 +307,84 @@ struct EdWork {
     Fn::El lom;
     bn_copy<8>(lom.v, lor);
     Fn::El hsum = Fn::add(hm, lom);
-    u32 h[8];
     bn_copy<8>(h, hsum.v);
+  }
+
+  // ---- EdDSA sign (eddsa/index.js:32-50 with KeyPair.fromSecret, eddsa/key.js:42-75) ----
+  // stage 1: hash = SHA-512(secret); a = the clamped first half (key.js:51-62), prefix = the
+  // second half; r = hashInt(prefix || M).  Both scalars go out as 32-byte big-endian inputs
+  // of the fixed-base kernel: scal[i] = a, scal[n + i] = r.
+  ELL_HD static void sign_pre(size_t i, size_t n, const u8* secret, const u8* msg, u64 msg_len, u8* scal) {
+    u8 hsh[64];
+    Sha512::hash3(hsh, secret, 32, nullptr, 0, nullptr, 0);
+    hsh[0] &= 248;
+    hsh[31] &= 127;
+    hsh[31] |= 64;
+    ELL_UNROLL
+    for (int j = 0; j < 32; j++) scal[i * 32 + j] = hsh[31 - j];
+    u8 digest[64];
+    Sha512::hash3(digest, hsh + 32, 32, msg, msg_len, nullptr, 0);
+    u32 r[8];
+    hash_int(r, digest);
+    store_be<8>(scal + (n + i) * 32, r, 32);
+  }
+  // encodePoint (eddsa/index.js:94-98) of an affine point given as x || y big-endian
+  ELL_HD static void encode_affine(u8 (&enc)[32], const u8* xy) {
+    ELL_UNROLL
+    for (int j = 0; j < 32; j++) enc[j] = xy[32 + 31 - j];
+    enc[31] |= (u8)((xy[31] & 1) << 7);
+  }
+  // stage 3: A = a G and R = r G arrive as affine points; h = hashInt(Renc || Aenc || M),
+  // S = (r + h a) mod n; sig = Renc || S (little-endian), pub = Aenc
+  ELL_HD static void sign_post(size_t i, size_t n, const u8* msg, u64 msg_len, const u8* scal,
+                               const u8* xy, u8* sig, u8* pub) {
+    typedef FpMont<consts::ED25519_N> Fn;
+    u8 aenc[32], renc[32];
+    encode_affine(aenc, xy + i * 64);
+    encode_affine(renc, xy + (n + i) * 64);
+    u8 digest[64];
+    Sha512::hash3(digest, renc, 32, aenc, 32, msg, msg_len);
+    u32 h[8], a[8], r[8];
+    hash_int(h, digest);
+    load_be<8>(a, scal + i * 32, 32);
+    load_be<8>(r, scal + (n + i) * 32, 32);
+    u32 ha[8];
+    Fn::to_plain(ha, Fn::mul(Fn::from_plain(h), Fn::from_plain(a)));
+    Fn::El x, y;
+    bn_copy<8>(x.v, ha);
+    bn_copy<8>(y.v, r);
+    Fn::El S = Fn::add(x, y);                     // both canonical residues: plain modular add
+    ELL_UNROLL
+    for (int j = 0; j < 32; j++) sig[i * 64 + j] = renc[j];
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++) {
+      sig[i * 64 + 32 + 4 * l] = (u8)S.v[l];
+      sig[i * 64 + 32 + 4 * l + 1] = (u8)(S.v[l] >> 8);
+      sig[i * 64 + 32 + 4 * l + 2] = (u8)(S.v[l] >> 16);
+      sig[i * 64 + 32 + 4 * l + 3] = (u8)(S.v[l] >> 24);
+    }
+    if (pub) {
+      ELL_UNROLL
+      for (int j = 0; j < 32; j++) pub[i * 32 + j] = aenc[j];
+    }
+  }
+
+  ELL_HD static void eddsa_verify(size_t i, const u8* msg, u64 msg_len, const u8* sig,
+                                  const u8* pub, const P* comb, P* tbl_all, const DigitStore& ds,
+                                  u8* out_ok, u8* out_err) {
+    typedef FpMont<consts::ED25519_N> Fn;
+    u32 S[8], nn[8];
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++) {
+      const u8* q = sig + 32 + 4 * l;
+      S[l] = (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16) | ((u32)q[3] << 24);
+      nn[l] = C::n[l];
+    }
+    bool s_ok = !bn_geq<8>(S, nn);
+    u8 digest[64];
+    Sha512::hash3(digest, sig, 32, pub, 32, msg, msg_len);
+    u32 h[8];
+    hash_int(h, digest);
 
     P A, R;
     bool a_ok = decode_point(A, pub);

@@ -166,6 +166,29 @@ struct FnEddsaVerify {
 };
 
 // Edwards / Montgomery functors
+struct FnEddsaSignPre {
+  static constexpr const char* NAME = "eddsa_sign_pre";
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* secrets; const u8* msgs; const u64* off; size_t msg_len; u8* scal;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i >= n) return;
+    const u8* m = off ? msgs + off[i] : msgs + i * msg_len;
+    u64 len = off ? off[i + 1] - off[i] : (u64)msg_len;
+    EdWork::sign_pre(i, n, secrets + i * 32, m, len, scal);
+  }
+};
+struct FnEddsaSignPost {
+  static constexpr const char* NAME = "eddsa_sign_post";
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* msgs; const u64* off; size_t msg_len; const u8* scal; const u8* xy;
+  u8* sig; u8* pub;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i >= n) return;
+    const u8* m = off ? msgs + off[i] : msgs + i * msg_len;
+    u64 len = off ? off[i + 1] - off[i] : (u64)msg_len;
+    EdWork::sign_post(i, n, m, len, scal, xy, sig, pub);
+  }
+};
 struct FnEdMulVar {
   static constexpr const char* NAME = "ed_mul_var";
   static constexpr int DS_PER_LANE = EdWork::NWIN;
@@ -330,6 +353,9 @@ class Engine {
   template <int U = 0>
   int eddsa_chunk(size_t n, size_t o, const u8* msgs, const u64* off, size_t msg_len, const u8* sigs,
                   const u8* pubs, u8* ok, u8* err);
+  template <int U = 0>
+  int eddsa_sign_chunk(size_t n, size_t o, const u8* secrets, const u8* msgs, const u64* off,
+                       size_t msg_len, u8* sig, u8* pub);
 
   // ---- dispatch over curves (device pointers) --------------------------------
 #if defined(ELL_ONLY_CURVE)
@@ -552,6 +578,39 @@ class Engine {
     if (rc) return rc;
     bk.d2h(ok, dok, n);
     if (err) bk.d2h(err, derr, n);
+    return bk.sync();
+  }
+
+  // EdDSA (ed25519) sign from 32-byte secrets: EDDSA#sign with KeyPair.fromSecret.  Messages as
+  // for eddsa_verify_dev; pub (n x 32, the encoded public keys) may be null.
+  int eddsa_sign_dev(size_t n, const u8* secrets, const u8* msgs, const u64* off, size_t msg_len,
+                     u8* sig, u8* pub) {
+    if (n && (!secrets || !sig || (!msgs && (off || msg_len)))) return fail(E_ARG, "null pointer");
+    int rc = prepare_curve(CURVE_ED25519);
+    if (rc) return rc;
+    const size_t step = CHUNK / 2;                 // two fixed-base multiplications per item
+    for (size_t o = 0; o < n; o += step) {
+      size_t m = n - o < step ? n - o : step;
+      rc = eddsa_sign_chunk(m, o, secrets, msgs, off, msg_len, sig, pub);
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+  int eddsa_sign_host(size_t n, const u8* secrets, const u8* msgs, const u64* off, size_t msg_len,
+                      u8* sig, u8* pub) {
+    if (n && (!secrets || !sig)) return fail(E_ARG, "null pointer");
+    size_t total = off ? (size_t)off[n] : n * msg_len;
+    if (total && !msgs) return fail(E_ARG, "null message pointer");
+    u8* dm = put(G_IN0, msgs ? msgs : (const u8*)"", total);
+    u64* doff = off ? (u64*)put(G_IN1, off, (n + 1) * sizeof(u64)) : nullptr;
+    u8* dsec = put(G_IN2, secrets, n * 32);
+    u8* dsig = out_buf(G_OUT0, n * 64);
+    u8* dpub = out_buf(G_OUT1, n * 32);
+    if (!dm || !dsec || !dsig || !dpub || (off && !doff)) return fail(E_NOMEM, "staging allocation failed");
+    int rc = eddsa_sign_dev(n, dsec, dm, doff, msg_len, dsig, dpub);
+    if (rc) return rc;
+    bk.d2h(sig, dsig, n * 64);
+    if (pub) bk.d2h(pub, dpub, n * 32);
     return bk.sync();
   }
 
@@ -1007,6 +1066,25 @@ int Engine<BK>::eddsa_chunk(size_t n, size_t o, const u8* msgs, const u64* off, 
                   sigs + o * 64, pubs + o * 32, (const EdWork::P*)comb_[CURVE_ED25519], tbl,
                   ok + o, err ? err + o : nullptr};
   bk.launch(f, n);
+  return E_OK;
+}
+
+template <class BK>
+template <int U>
+int Engine<BK>::eddsa_sign_chunk(size_t n, size_t o, const u8* secrets, const u8* msgs, const u64* off,
+                                 size_t msg_len, u8* sig, u8* pub) {
+  u8* scal = (u8*)scratch(S_U12, 2 * n * 32);                     // a and r, big-endian
+  u8* xy = (u8*)scratch(S_TBL, 2 * n * 64);                       // A = a G and R = r G, affine
+  u8* inf = (u8*)scratch(S_VALID, 2 * n);
+  if (!scal || !xy || !inf) return fail(E_NOMEM, "scratch allocation failed");
+  const u8* m0 = off ? msgs : msgs + o * msg_len;
+  const u64* off0 = off ? off + o : nullptr;
+  FnEddsaSignPre f1{n, secrets + o * 32, m0, off0, msg_len, scal};
+  bk.launch(f1, n);
+  int rc = ed_mul_fixed_chunk(2 * n, scal, xy, inf);
+  if (rc) return rc;
+  FnEddsaSignPost f2{n, m0, off0, msg_len, scal, xy, sig + o * 64, pub ? pub + o * 32 : nullptr};
+  bk.launch(f2, n);
   return E_OK;
 }
 

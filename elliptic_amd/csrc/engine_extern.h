@@ -36,6 +36,9 @@ namespace ell {
 #define ELL_DECL_ED3(KW)                                                                          \
   KW template int Engine<HipBackend>::eddsa_chunk<0>(size_t, size_t, const u8*, const u64*, size_t, \
                                                      const u8*, const u8*, u8*, u8*);
+#define ELL_DECL_ED4(KW)                                                                          \
+  KW template int Engine<HipBackend>::eddsa_sign_chunk<0>(size_t, size_t, const u8*, const u8*,   \
+                                                          const u64*, size_t, u8*, u8*);
 
 #define ELL_DECL_ED0(KW)                                                                          \
   KW template int Engine<HipBackend>::ensure_ed_comb<0>();                                        \
@@ -60,5 +63,6 @@ ELL_DECL_ED1(extern)
 ELL_DECL_X(extern)
 ELL_DECL_ED2(extern)
 ELL_DECL_ED3(extern)
+ELL_DECL_ED4(extern)
 
 }  // namespace ell

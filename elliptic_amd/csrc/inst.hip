@@ -21,6 +21,8 @@ ELL_DECL_G5(ELL_NOKW, ELL_INST_CURVE)
 ELL_DECL_ED2(ELL_NOKW)
 #elif ELL_INST_GROUP == 14
 ELL_DECL_ED3(ELL_NOKW)
+#elif ELL_INST_GROUP == 15
+ELL_DECL_ED4(ELL_NOKW)
 #elif ELL_INST_GROUP == 10
 ELL_DECL_ED0(ELL_NOKW)
 #elif ELL_INST_GROUP == 11

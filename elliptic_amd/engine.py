@@ -208,6 +208,33 @@ class Context:
                                                   err.ctypes.data))
         return ok, err
 
+    def eddsa_sign(self, msgs, secrets):
+        """ed25519 EdDSA sign from 32-byte secrets (EDDSA#sign with keyFromSecret).  msgs as for
+        eddsa_verify.  -> (sig (n, 64), pub (n, 32)) uint8 arrays"""
+        secrets = _u8(secrets, (-1, 32))
+        n = secrets.shape[0]
+        sig = np.zeros((n, 64), np.uint8)
+        pub = np.zeros((n, 32), np.uint8)
+        if isinstance(msgs, np.ndarray) and msgs.ndim == 2:
+            m = np.ascontiguousarray(msgs, np.uint8)
+            off_p, mlen = None, m.shape[1]
+            if m.size == 0:
+                m = np.zeros(1, np.uint8)
+        else:
+            off = np.zeros(n + 1, np.uint64)
+            off[1:] = np.cumsum([len(x) for x in msgs])
+            m = np.frombuffer(b"".join(bytes(x) for x in msgs) or b"\0", dtype=np.uint8)
+            off_p, mlen = off.ctypes.data, 0
+        self._check(self._lib.ellgpu_eddsa_sign(self._ctx, n, secrets.ctypes.data, m.ctypes.data, off_p, mlen,
+                                                sig.ctypes.data, pub.ctypes.data))
+        return sig, pub
+
+    def eddsa_sign_dev(self, secrets, msgs, msg_len, out_sig, out_pub=None, msg_off=None):
+        n = secrets.shape[0]
+        self._check(self._lib.ellgpu_eddsa_sign_dev(
+            self._ctx, n, secrets.data_ptr(), msgs.data_ptr(), None if msg_off is None else msg_off.data_ptr(),
+            int(msg_len), out_sig.data_ptr(), None if out_pub is None else out_pub.data_ptr(), self._stream()))
+
     def eddsa_verify_dev(self, msgs, msg_len, sigs, pubs, out_ok, out_err=None, msg_off=None):
         n = sigs.shape[0]
         self._check(self._lib.ellgpu_eddsa_verify_dev(

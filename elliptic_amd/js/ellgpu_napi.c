@@ -22,6 +22,7 @@
  *           ecdsaSign(ctx, curve, hash, hashLen, msgBits, priv, nonces, canonical)
  *             -> {r, s, recid, ok}
  *           eddsaVerify(ctx, msgs, offsets|null, msgLen, sigs, pubs) -> {ok, err}
+ *           eddsaSign(ctx, msgs, offsets|null, msgLen, secrets) -> {sig, pub}
  *             offsets: Buffer of n+1 little-endian uint64 byte offsets into msgs
  *           callAsync(op, ctx, curve, hashLen, msgBits, b0, b1, b2, b3) -> Promise
  *             op 0 mulFixed(b0=k) 1 mulVar(k, xy) 2 mulAdd2(k1, p1|null, k2, p2)
@@ -61,6 +62,8 @@ static struct {
                     int, uint8_t*, uint8_t*, uint8_t*, uint8_t*);
   int (*eddsa_verify)(ellgpu_ctx*, size_t, const uint8_t*, const uint64_t*, size_t, const uint8_t*,
                       const uint8_t*, uint8_t*, uint8_t*);
+  int (*eddsa_sign)(ellgpu_ctx*, size_t, const uint8_t*, const uint8_t*, const uint64_t*, size_t,
+                    uint8_t*, uint8_t*);
 } L;
 
 #define THROW(env, msg) do { napi_throw_error((env), NULL, (msg)); return NULL; } while (0)
@@ -93,6 +96,7 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   SYM(mul_add2, "ellgpu_mul_add2"); SYM(ecdsa_verify, "ellgpu_ecdsa_verify"); SYM(x25519, "ellgpu_x25519_ladder");
   SYM(decompress, "ellgpu_decompress");
   SYM(eddsa_verify, "ellgpu_eddsa_verify");
+  SYM(eddsa_sign, "ellgpu_eddsa_sign");
   SYM(ecdsa_sign, "ellgpu_ecdsa_sign");
   L.h = h;
   napi_value t; CHECK(env, napi_get_boolean(env, 1, &t));
@@ -296,6 +300,30 @@ static napi_value fn_eddsa_verify(napi_env env, napi_callback_info info) {
   return mk_result(env, "ok", bok, "err", berr);
 }
 
+/* eddsaSign(ctx, msgs, offsets|null, msgLen, secrets) -> {sig: Buffer(n*64), pub: Buffer(n*32)} */
+static napi_value fn_eddsa_sign(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 5; napi_value argv[5];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  const uint8_t *m, *off, *sec; size_t lm, loff, lsec; int32_t mlen = 0;
+  if (!get_buf(env, argv[1], &m, &lm, 1) || !get_buf(env, argv[2], &off, &loff, 1) ||
+      !get_buf(env, argv[4], &sec, &lsec, 0)) return NULL;
+  napi_get_value_int32(env, argv[3], &mlen);
+  if (lsec % 32) THROW(env, "secrets must be n x 32 bytes");
+  size_t n = lsec / 32;
+  if (off) {
+    if (loff != (n + 1) * 8 || ((uintptr_t)off & 7)) THROW(env, "offsets must be an aligned Buffer of n+1 uint64");
+    if (((const uint64_t*)off)[n] > lm) THROW(env, "offsets exceed the message buffer");
+  } else if ((size_t)mlen * n > lm) THROW(env, "message buffer too short");
+  napi_value bsig, bpub; void *dsig, *dpub;
+  CHECK(env, napi_create_buffer(env, n * 64, &dsig, &bsig));
+  CHECK(env, napi_create_buffer(env, n * 32, &dpub, &bpub));
+  if (L.eddsa_sign(c, n, sec, m, (const uint64_t*)off, (size_t)mlen, (uint8_t*)dsig, (uint8_t*)dpub) != 0)
+    return lib_error(env);
+  return mk_result(env, "sig", bsig, "pub", bpub);
+}
+
 /* ---- asynchronous form: napi_async_work + Promise ---------------------------------- */
 typedef struct {
   napi_async_work work;
@@ -409,7 +437,7 @@ static napi_value init(napi_env env, napi_value exports) {
     {"deviceCount", fn_device_count}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
     {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519},
     {"callAsync", fn_call_async}, {"decompress", fn_decompress},
-    {"eddsaVerify", fn_eddsa_verify}, {"ecdsaSign", fn_sign},
+    {"eddsaVerify", fn_eddsa_verify}, {"eddsaSign", fn_eddsa_sign}, {"ecdsaSign", fn_sign},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

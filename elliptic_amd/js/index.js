@@ -109,6 +109,21 @@ Engine.prototype.eddsaVerifyBatch = function eddsaVerifyBatch(msgs, sigs, pubs) 
   return this.addon.eddsaVerify(this.ctx, Buffer.concat(msgs), off, 0, sigs, pubs);
 };
 
+// ed25519 EdDSA sign from 32-byte secrets (EDDSA#sign with keyFromSecret).  msgs: array of
+// Buffers; secrets: Buffer(n x 32).  -> { sig: Buffer(n x 64) of R||S, pub: Buffer(n x 32) }
+Engine.prototype.eddsaSignBatch = function eddsaSignBatch(msgs, secrets) {
+  var n = msgs.length;
+  var off = Buffer.alloc((n + 1) * 8);
+  var pos = 0;
+  for (var i = 0; i < n; i++) {
+    off.writeUInt32LE(pos >>> 0, i * 8); off.writeUInt32LE(Math.floor(pos / 4294967296), i * 8 + 4);
+    pos += msgs[i].length;
+  }
+  off.writeUInt32LE(pos >>> 0, n * 8); off.writeUInt32LE(Math.floor(pos / 4294967296), n * 8 + 4);
+  this.stats.gpuCalls++; this.stats.gpuItems += n;
+  return this.addon.eddsaSign(this.ctx, Buffer.concat(msgs), off, 0, secrets);
+};
+
 // ---- asynchronous batch API: same arguments, returns a Promise; the work runs on a
 // libuv worker thread (napi_async_work), so the JS thread stays responsive during a large
 // batch.  A context processes one call at a time, so calls are chained.
@@ -310,6 +325,24 @@ function install(elliptic, options) {
     return r.ok[0] === 1;
   };
 
+  // EDDSA#sign (eddsa/index.js:32-50) for ed25519 and 32-byte secrets: both hashes, a*G, r*G and
+  // S = r + h*a in one call; other secrets (any length is legal for the reference) pass through.
+  orig.eddsaSign = eddsaProto.sign;
+  eddsaProto.sign = function sign(message, secret) {
+    var d = domain(this.curve);
+    try {
+      if (!d || d.name !== 'ed25519') throw null;
+      var m = Buffer.from(elliptic.utils.parseBytes(message));
+      var sec = Buffer.from(this.keyFromSecret(secret).secret());
+      if (sec.length !== 32) throw null;
+    } catch (e) {
+      eng.stats.passthrough++;
+      return orig.eddsaSign.apply(this, arguments);
+    }
+    var r = eng.eddsaSignBatch([m], sec);
+    return this.makeSignature(Array.prototype.slice.call(r.sig, 0, 64));
+  };
+
   // Montgomery x-only ladder (Point class is not exported: reach it as
   // eddsa/index.js:22 does, through an instance)
   var montProto = elliptic.curves.curve25519.curve.g.constructor.prototype;
@@ -332,6 +365,7 @@ function install(elliptic, options) {
     montProto.mul = orig.montMul;
     short.pointFromX = orig.pointFromX;
     eddsaProto.verify = orig.eddsaVerify;
+    eddsaProto.sign = orig.eddsaSign;
     edw.pointFromY = orig.pointFromY;
   };
 

@@ -107,6 +107,17 @@ function check(r, i, B, want, what) {
     checked++;
   });
 })();
+(function() {
+  var cs = JSON.parse(fs.readFileSync(path.join(GOLD, 'eddsa_sign_ed25519.json')));
+  var r = eng.eddsaSignBatch(cs.map(function(c) { return Buffer.from(c.msg, 'hex'); }),
+    Buffer.concat(cs.map(function(c) { return Buffer.from(c.secret, 'hex'); })));
+  cs.forEach(function(c, i) {
+    if (r.sig.slice(i * 64, i * 64 + 64).toString('hex') !== c.sig ||
+        r.pub.slice(i * 32, i * 32 + 32).toString('hex') !== c.pub)
+      throw new Error('eddsa sign mismatch at ' + i + ' (' + c.note + ')');
+    checked++;
+  });
+})();
 var lc = JSON.parse(fs.readFileSync(path.join(GOLD, 'mul_curve25519.json')));
 var rr = eng.x25519Batch(hexBuf(lc.map(function(c) { return c.k; }), 32), hexBuf(lc.map(function(c) { return c.px; }), 32));
 lc.forEach(function(c, i) {

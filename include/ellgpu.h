@@ -161,6 +161,18 @@ int ellgpu_eddsa_verify_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, cons
                             size_t msg_len, const uint8_t* sigs, const uint8_t* pubs,
                             uint8_t* out_ok, uint8_t* out_err, void* stream);
 
+/* EdDSA (ed25519) sign from 32-byte secrets: out_sig[i] = EDDSA#sign(msg_i, secret_i).toBytes()
+ * (R || S, 64 bytes), lib/elliptic/eddsa/index.js:32-50, with the key derivation of
+ * KeyPair.fromSecret (eddsa/key.js:42-75): hash = SHA-512(secret), a = the clamped first half,
+ * prefix = the second half, A = a*G, r = SHA-512(prefix || M) mod n, R = r*G,
+ * S = (r + SHA-512(R || A || M) * a) mod n.  Messages as for ellgpu_eddsa_verify.  out_pub (may be
+ * NULL): the encoded public keys A (n x 32 bytes, KeyPair#getPublic). */
+int ellgpu_eddsa_sign(ellgpu_ctx* ctx, size_t n, const uint8_t* secrets, const uint8_t* msgs,
+                      const uint64_t* msg_off, size_t msg_len, uint8_t* out_sig, uint8_t* out_pub);
+int ellgpu_eddsa_sign_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* secrets, const uint8_t* msgs,
+                          const uint64_t* msg_off, size_t msg_len, uint8_t* out_sig, uint8_t* out_pub,
+                          void* stream);
+
 /* ---- device-buffer entry points (inputs/outputs resident in HBM) -------- */
 int ellgpu_mul_fixed_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
                          uint8_t* out_xy, uint8_t* out_inf, void* stream);

@@ -891,6 +891,40 @@ def eddsa_verify(curve: "EdwardsCurve", msg: bytes, sig: bytes, pub: bytes) -> b
     return lhs.normalized() == SG.normalized()
 
 
+def ed_encode_point(P: "EdPoint") -> bytes:
+    """eddsa/index.js:94-98 EDDSA#encodePoint: y little-endian, top bit = parity of x"""
+    x, y = P.normalized()
+    enc = bytearray(y.to_bytes(32, "little"))
+    enc[31] |= 0x80 if x & 1 else 0
+    return bytes(enc)
+
+
+def eddsa_keypair(curve: "EdwardsCurve", secret: bytes) -> Tuple[int, bytes, bytes]:
+    """eddsa/key.js:42-75 KeyPair from a secret: hash = SHA-512(secret); the first 32 bytes,
+    clamped (:51-62), are the private scalar a (little-endian, :65-67); the rest is the message
+    prefix (:73-75); the public key is encodePoint(G * a) (:42-49).  -> (a, prefix, pub)"""
+    import hashlib
+    h = hashlib.sha512(secret).digest()
+    a = bytearray(h[:32])
+    a[0] &= 248
+    a[31] &= 127
+    a[31] |= 64
+    a_int = int.from_bytes(bytes(a), "little")
+    return a_int, h[32:], ed_encode_point(curve.g.mul(a_int))
+
+
+def eddsa_sign(curve: "EdwardsCurve", msg: bytes, secret: bytes) -> Tuple[bytes, bytes]:
+    """eddsa/index.js:32-50 EDDSA#sign: r = H(prefix || M) mod n, R = G * r,
+    S = (r + H(R || A || M) * a) mod n.  -> (signature R || S, public key A)"""
+    import hashlib
+    a, prefix, pub = eddsa_keypair(curve, secret)
+    r = int.from_bytes(hashlib.sha512(prefix + msg).digest(), "little") % curve.n
+    Renc = ed_encode_point(curve.g.mul(r))
+    h = int.from_bytes(hashlib.sha512(Renc + pub + msg).digest(), "little") % curve.n
+    S = (r + h * a) % curve.n
+    return Renc + S.to_bytes(32, "little"), pub
+
+
 def _sqrt_mod(a: int, p: int) -> Optional[int]:
     """bn.js Red.sqrt (dist/elliptic.js:7180-7230): p%4==3 -> pow; else
     Tonelli-Shanks.  Returns the root bn.js returns (either root is accepted by

@@ -150,6 +150,30 @@ def check_eddsa_golden(ctx):
     return len(cases)
 
 
+def check_eddsa_sign_golden(ctx):
+    """EDDSA#sign / keyFromSecret goldens: sign.input vectors + seeded block-boundary lengths;
+    the signatures must also verify"""
+    from golden_util import load
+    cases = load("eddsa_sign_ed25519.json")
+    msgs = [bytes.fromhex(c["msg"]) for c in cases]
+    sec = np.frombuffer(b"".join(bytes.fromhex(c["secret"]) for c in cases), np.uint8).reshape(-1, 32)
+    sig, pub = ctx.eddsa_sign(msgs, sec)
+    for i, c in enumerate(cases):
+        assert sig[i].tobytes().hex() == c["sig"], c["note"]
+        assert pub[i].tobytes().hex() == c["pub"], c["note"]
+    ok, err = ctx.eddsa_verify(msgs, sig, pub)
+    assert ok.all() and not err.any()
+    # uniform-length form
+    from collections import Counter
+    L = Counter(len(m) for m in msgs).most_common(1)[0][0]
+    idx = [i for i, m in enumerate(msgs) if len(m) == L]
+    if len(idx) > 1:
+        arr = np.frombuffer(b"".join(msgs[i] for i in idx), np.uint8).reshape(len(idx), L)
+        sig2, pub2 = ctx.eddsa_sign(arr, sec[idx])
+        assert np.array_equal(sig2, sig[idx]) and np.array_equal(pub2, pub[idx])
+    return len(cases)
+
+
 def check_sign_golden(ctx, curve):
     """EC#sign with supplied nonces: (hash, d, k) -> (r, s, recoveryParam) or 'next nonce'"""
     from golden_util import load

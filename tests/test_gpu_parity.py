@@ -58,6 +58,10 @@ def test_decompress_roundtrip_full_size(ctx):
     assert np.array_equal(ctx.ecdsa_verify("secp256k1", h, r, s, out), expect)
 
 
+def test_eddsa_sign_golden(ctx):
+    assert PC.check_eddsa_sign_golden(ctx) > 100
+
+
 def test_eddsa_verify_golden(ctx):
     assert PC.check_eddsa_golden(ctx) > 200
 

@@ -200,6 +200,10 @@ def test_sign_golden(ctx, curve):
     assert PC.check_sign_golden(ctx, curve) >= 12
 
 
+def test_eddsa_sign_golden(ctx):
+    assert PC.check_eddsa_sign_golden(ctx) > 100
+
+
 def test_eddsa_verify_golden(ctx):
     assert PC.check_eddsa_golden(ctx) > 200
 

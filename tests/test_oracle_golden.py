@@ -155,6 +155,17 @@ def test_eddsa_verify_matches_reference():
     assert seen[True] > 50 and seen[False] > 30 and seen["throws"] > 3
 
 
+def test_eddsa_sign_matches_reference():
+    """EDDSA#sign / keyFromSecret on the official sign.input vectors and seeded
+    (secret, message) pairs with block-boundary message lengths"""
+    cur = O.get_curve("ed25519")
+    cases = load("eddsa_sign_ed25519.json")
+    assert len(cases) > 100
+    for c in cases[::3]:                                  # pure-Python ladders: a third is enough here
+        sig, pub = O.eddsa_sign(cur, bytes.fromhex(c["msg"]), bytes.fromhex(c["secret"]))
+        assert sig.hex() == c["sig"] and pub.hex() == c["pub"], c["note"]
+
+
 @pytest.mark.parametrize("name", O.SHORT_CURVES)
 def test_ecdsa_sign_matches_reference(name):
     cur = O.get_curve(name)

@@ -406,6 +406,46 @@ function genEddsa() {
   return cases;
 }
 
+// ------------------------------------------------------ eddsa_sign_ed25519.json
+// EDDSA#sign (eddsa/index.js:32-50) with KeyPair.fromSecret (eddsa/key.js:42-75): a pure
+// function (secret, message) -> (signature, public key).  The official sign.input vectors
+// (secret, pub, msg, sig) plus seeded secrets with message lengths around the SHA-512 block
+// boundaries of both hashes (prefix||M: 32 + len, R||A||M: 64 + len; padding flips at
+// 112 mod 128).
+function genEddsaSign() {
+  var ed = new elliptic.eddsa('ed25519');
+  var rng = new Prng('ellgpu-golden-v1:eddsa-sign');
+  var lines = fs.readFileSync(path.join(ref.root, 'test', 'fixtures', 'sign.input'), 'utf8')
+    .split('\n').filter(function(l) { return l.length; });
+  var cases = [];
+  function rec(secretHex, msgHex, note) {
+    var key = ed.keyFromSecret(secretHex);
+    var msg = msgHex.length ? Buffer.from(msgHex, 'hex').toJSON().data : [];
+    var sig = key.sign(msg).toHex().toLowerCase();
+    cases.push({ secret: secretHex, msg: msgHex, sig: sig,
+      pub: Buffer.from(key.getPublic()).toString('hex'), note: note });
+  }
+  var picks = [];
+  for (var i = 0; i < 64; i++) picks.push(i);
+  [100, 127, 128, 129, 255, 256, 511, 512, 1000, 1023].forEach(function(i) { picks.push(i); });
+  picks.forEach(function(i) {
+    var f = lines[i].split(':');
+    rec(f[0].slice(0, 64), f[2], 'sign.input line ' + i);
+    var last = cases[cases.length - 1];
+    if (last.sig !== f[3].slice(0, 128) || last.pub !== f[1])
+      throw new Error('reference disagrees with sign.input line ' + i);
+  });
+  [0, 1, 2, 31, 32, 46, 47, 48, 49, 63, 64, 78, 79, 80, 81, 95, 96, 111, 112, 113, 127, 128, 129,
+    174, 175, 176, 177, 191, 192, 207, 208, 209, 255, 256, 257, 300, 511, 640].forEach(function(len) {
+    rec(rng.bytes(32).toString('hex'), rng.bytes(len).toString('hex'), 'seeded, ' + len + '-byte message');
+  });
+  // secrets whose hash has extreme clamped bytes are as good as random; a few fixed patterns
+  ['00', 'ff', '80', '01'].forEach(function(b) {
+    rec(new Array(33).join(b), rng.bytes(40).toString('hex'), 'secret of 32 x 0x' + b);
+  });
+  return cases;
+}
+
 // ------------------------------------------------------------- sign_<curve>.json
 // EC#sign (ec/index.js:110-186) with the nonce supplied through options.k, so that
 // (hash, d, k) -> (r, s, recoveryParam) is a pure function; rejected nonces (k <= 1,
@@ -583,6 +623,7 @@ SHORT.forEach(function(name) {
   write('decompress_' + name + '.json', genDecompress(name));
 });
 write('eddsa_verify_ed25519.json', genEddsa());
+write('eddsa_sign_ed25519.json', genEddsaSign());
 write('mul_ed25519.json', genEdwardsMul());
 write('mul_curve25519.json', genMontMul());
 var c = captureFromReferenceTests();
