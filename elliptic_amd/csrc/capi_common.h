@@ -153,6 +153,19 @@ int ellgpu_eddsa_verify_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, cons
                                                 out_ok, out_err));
 }
 
+int ellgpu_ecdsa_recover(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                         const uint8_t* r, const uint8_t* s, const uint8_t* recid, uint8_t* out_xy,
+                         uint8_t* out_status) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->ecdsa_recover_host(curve, n, hash, hash_len, r, s, recid, out_xy, out_status));
+}
+int ellgpu_ecdsa_recover_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                             const uint8_t* r, const uint8_t* s, const uint8_t* recid, uint8_t* out_xy,
+                             uint8_t* out_status, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->ecdsa_recover_dev(curve, n, hash, hash_len, r, s, recid, out_xy, out_status));
+}
+
 int ellgpu_eddsa_sign(ellgpu_ctx* ctx, size_t n, const uint8_t* secrets, const uint8_t* msgs,
                       const uint64_t* msg_off, size_t msg_len, uint8_t* out_sig, uint8_t* out_pub) {
   ELL_ENTER(ctx, nullptr);

@@ -133,6 +133,27 @@ struct FnSignFinish {
   }
 };
 template <class CV>
+struct FnRecoverPrep {
+  static constexpr const char* NAME = "recover_prep";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t T, n; int K; const u8* hash; int hash_len; const u8* r; const u8* s; const u8* recid;
+  u32* pre; u8* xs; u8* odd; u8* s1; u8* s2; u8* status;
+  ELL_HD void operator()(size_t t, const DigitStore&) const {
+    if (t < T) W::recover_prep(t, T, n, K, hash, hash_len, r, s, recid, pre, xs, odd, s1, s2, status);
+  }
+};
+template <class CV>
+struct FnRecoverFinish {
+  static constexpr const char* NAME = "recover_finish";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* dec_ok; const u8* inf; u8* out_xy; u8* status;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::recover_finish(i, dec_ok, inf, out_xy, status);
+  }
+};
+template <class CV>
 struct FnDecompress {
   static constexpr const char* NAME = "decompress";
   typedef Work<CV> W;
@@ -348,6 +369,9 @@ class Engine {
   template <class CV>
   int sign_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* priv, const u8* nonces,
                  int canonical, u8* out_r, u8* out_s, u8* out_recid, u8* out_ok);
+  template <class CV>
+  int recover_chunk(size_t n, const u8* hash, int hash_len, const u8* r, const u8* s, const u8* recid,
+                    u8* out_xy, u8* out_status);
   template <int U = 0>
   int ed_decompress_chunk(size_t n, const u8* y, const u8* odd, u8* out_xy, u8* out_ok);
   template <int U = 0>
@@ -545,6 +569,49 @@ class Engine {
     bk.d2h(out_s, dsg, n * NB);
     bk.d2h(out_recid, drec, n);
     bk.d2h(out_ok, dok, n);
+    return bk.sync();
+  }
+
+  // EC#recoverPubKey (ec/index.js:231-259) over a batch: status 0 point / 1 infinity /
+  // 2 the reference throws / 3 outside the engine's domain (r = 0 or r >= n)
+  int ecdsa_recover_dev(int curve, size_t n, const u8* hash, int hash_len, const u8* r, const u8* s,
+                        const u8* recid, u8* out_xy, u8* out_status) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (curve >= CURVE_ED25519)
+      return fail(E_UNSUPPORTED, "public-key recovery is an ECDSA (short Weierstrass) operation");
+    if (n && (!hash || !r || !s || !recid || !out_xy || !out_status)) return fail(E_ARG, "null pointer");
+    int ln = (ci->order_bits + 31) / 32;
+    if (hash_len <= 0 || hash_len > 8 * ln) return fail(E_ARG, "hash_len must be 1 .. twice the order width");
+    int rc = prepare_curve(curve);
+    if (rc) return rc;
+    const size_t B = ci->field_bytes, NB = ci->order_bytes;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      ELL_SHORT_DISPATCH(curve, rc = recover_chunk<CV>(m, hash + o * hash_len, hash_len, r + o * NB, s + o * NB,
+                                                       recid + o, out_xy + o * 2 * B, out_status + o));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+  int ecdsa_recover_host(int curve, size_t n, const u8* hash, int hash_len, const u8* r, const u8* s,
+                         const u8* recid, u8* out_xy, u8* out_status) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (n && (!hash || !r || !s || !recid || !out_xy || !out_status)) return fail(E_ARG, "null pointer");
+    if (hash_len <= 0) return fail(E_ARG, "bad hash_len");
+    const size_t B = ci->field_bytes, NB = ci->order_bytes;
+    u8* dh = put(G_IN0, hash, n * (size_t)hash_len);
+    u8* dr = put(G_IN1, r, n * NB);
+    u8* dsg = put(G_IN2, s, n * NB);
+    u8* dj = put(G_IN3, recid, n);
+    u8* dxy = out_buf(G_OUT0, n * 2 * B);
+    u8* dst = out_buf(G_OUT1, n);
+    if (!dh || !dr || !dsg || !dj || !dxy || !dst) return fail(E_NOMEM, "staging allocation failed");
+    int rc = ecdsa_recover_dev(curve, n, dh, hash_len, dr, dsg, dj, dxy, dst);
+    if (rc) return rc;
+    bk.d2h(out_xy, dxy, n * 2 * B);
+    bk.d2h(out_status, dst, n);
     return bk.sync();
   }
 
@@ -1048,6 +1115,41 @@ int Engine<BK>::decompress_chunk(size_t n, const u8* x, const u8* odd, u8* out_x
     return E_OK;
   }
 }
+template <class BK>
+template <class CV>
+int Engine<BK>::recover_chunk(size_t n, const u8* hash, int hash_len, const u8* r, const u8* s,
+                              const u8* recid, u8* out_xy, u8* out_status) {
+  if constexpr (!CV::F::HAS_SQRT) {
+    return fail(E_UNSUPPORTED, "public-key recovery needs point decompression: p = 3 (mod 4) (not p224)");
+  } else {
+    typedef Work<CV> W;
+    const size_t B = W::BYTES, NB = W::NBYTES;
+    // scalars, the x-coordinates and the decompressed points R live across the ladder kernels,
+    // which use S_TBL / S_JAC / S_PRE only
+    u8* buf = (u8*)scratch(S_U12, n * (2 * NB + 3 * B));
+    u8* flags = (u8*)scratch(S_VALID, 3 * n);
+    u32* pre = (u32*)scratch(S_PRE, n * W::LN * 4);
+    if (!buf || !flags || !pre) return fail(E_NOMEM, "scratch allocation failed");
+    u8* s1 = buf;
+    u8* s2 = s1 + n * NB;
+    u8* xs = s2 + n * NB;
+    u8* rxy = xs + n * B;
+    u8* odd = flags;
+    u8* dec_ok = flags + n;
+    u8* inf = flags + 2 * n;
+    size_t T = (n + INV_BATCH_N - 1) / INV_BATCH_N;
+    FnRecoverPrep<CV> f1{T, n, INV_BATCH_N, hash, hash_len, r, s, recid, pre, xs, odd, s1, s2, out_status};
+    bk.launch(f1, T);
+    int rc = decompress_chunk<CV>(n, xs, odd, rxy, dec_ok);
+    if (rc) return rc;
+    rc = mul_add_g_chunk<CV>(n, s1, s2, rxy, out_xy, inf);         // s1 * G + s2 * R
+    if (rc) return rc;
+    FnRecoverFinish<CV> f2{n, dec_ok, inf, out_xy, out_status};
+    bk.launch(f2, n);
+    return E_OK;
+  }
+}
+
 template <class BK>
 template <int U>
 int Engine<BK>::ed_decompress_chunk(size_t n, const u8* y, const u8* odd, u8* out_xy, u8* out_ok) {

@@ -368,6 +368,101 @@ struct Work {
     }
   }
 
+  // ---- public-key recovery (ec/index.js:231-259 EC#recoverPubKey) ----------------------
+  // Q = r^-1 (s R - e G) with R = pointFromX(r + (j >> 1) n, j & 1); e = new BN(msg) is NOT
+  // truncated there, only reduced by the arithmetic mod n.
+  // Pass 1 (thread t handles items t, t+T, ...: one inversion per K items): checks, the
+  // x-coordinate and parity for the decompression kernel, s1 = -e/r and s2 = s/r for the
+  // double-scalar kernel.  status: 0 so far fine, 2 the reference throws (second candidate
+  // with r >= p mod n, j > 3), 3 outside the engine's domain (r = 0 or r >= n: the reference
+  // goes through BN#invm of an unreduced value there; callers hand those to the reference).
+  enum { RECOVER_POINT = 0, RECOVER_INF = 1, RECOVER_THROWS = 2, RECOVER_DOMAIN = 3 };
+  // a big-endian byte string of up to 8 LN bytes -> its value mod n, in Montgomery form
+  ELL_HD static Nl bytes_mod_n(const u8* h, int len) {
+    u32 t[2 * LN];
+    load_be<2 * LN>(t, h, len);
+    u32 lo[LN], hi[LN];
+    ELL_UNROLL
+    for (int i = 0; i < LN; i++) { lo[i] = t[i]; hi[i] = t[LN + i]; }
+    // hi * 2^(32 LN) + lo: from_plain(hi) = hi * R as a residue, read as a plain value
+    Nl him = Fn::from_plain(hi);
+    return Fn::add(Fn::from_plain(lo), Fn::from_plain(him.v));
+  }
+  ELL_HD static void recover_prep(size_t t, size_t T, size_t n, int K, const u8* hash, int hash_len,
+                                  const u8* rs, const u8* ss, const u8* recid, u32* pre, u8* xs,
+                                  u8* odd, u8* s1b, u8* s2b, u8* status) {
+    static_assert(L == LN, "the presets' fields and orders have the same limb count");
+    u32 nn[LN], pmn[LN];
+    {
+      u32 pp[L];
+      F::get_p(pp);
+      ELL_UNROLL
+      for (int i = 0; i < LN; i++) nn[i] = C::n[i];
+      bn_sub<LN>(pmn, pp, nn);                   // p mod n = p - n  (n < p < 2n for every preset)
+    }
+    Nl acc = Fn::one();
+    ELL_NOUNROLL
+    for (int j = 0; j < K; j++) {
+      size_t i = t + (size_t)j * T;
+      if (i >= n) break;
+      u32 r[LN];
+      load_be<LN>(r, rs + i * NBYTES, NBYTES);
+      u32 jj = recid[i];
+      bool second = (jj >> 1) != 0;
+      int st = RECOVER_POINT;
+      if (!scalar_in_range(r)) st = RECOVER_DOMAIN;
+      else if (jj > 3 || (second && bn_geq<LN>(r, pmn))) st = RECOVER_THROWS;
+      status[i] = (u8)st;
+      u32 x[LN], rn[LN];
+      bn_add<LN>(rn, r, nn);                     // r + n < p when the second candidate exists
+      bn_select<LN>(x, second && st == RECOVER_POINT, rn, r);
+      store_be<LN>(xs + i * BYTES, x, BYTES);
+      odd[i] = (u8)(jj & 1);
+      Nl rm = fe_select<Fn>(st == RECOVER_POINT, Fn::from_plain(r), Fn::one());
+      ELL_UNROLL
+      for (int l = 0; l < LN; l++) pre[(size_t)l * n + i] = acc.v[l];
+      acc = Fn::mul(acc, rm);
+    }
+    Nl inv = Fn::inv(acc);
+    ELL_NOUNROLL
+    for (int j = K - 1; j >= 0; j--) {
+      size_t i = t + (size_t)j * T;
+      if (i >= n) continue;
+      u32 r[LN], s[LN];
+      load_be<LN>(r, rs + i * NBYTES, NBYTES);
+      load_be<LN>(s, ss + i * NBYTES, NBYTES);
+      bool ok = status[i] == RECOVER_POINT;
+      Nl rm = fe_select<Fn>(ok, Fn::from_plain(r), Fn::one());
+      Nl pr;
+      ELL_UNROLL
+      for (int l = 0; l < LN; l++) pr.v[l] = pre[(size_t)l * n + i];
+      Nl rinv = Fn::mul(inv, pr);
+      inv = Fn::mul(inv, rm);
+      Nl e = bytes_mod_n(hash + i * (size_t)hash_len, hash_len);
+      Nl s1 = Fn::neg(Fn::mul(e, rinv));
+      Nl s2 = Fn::mul(Fn::from_plain(s), rinv);
+      u32 p1[LN], p2[LN];
+      Fn::to_plain(p1, s1);
+      Fn::to_plain(p2, s2);
+      ELL_UNROLL
+      for (int l = 0; l < LN; l++) { p1[l] = ok ? p1[l] : 0u; p2[l] = ok ? p2[l] : 0u; }
+      store_be<LN>(s1b + i * NBYTES, p1, NBYTES);
+      store_be<LN>(s2b + i * NBYTES, p2, NBYTES);
+    }
+  }
+  // Pass 4: fold the decompression result and the infinity flag into the status; no point is
+  // reported for items whose status is not RECOVER_POINT
+  ELL_HD static void recover_finish(size_t i, const u8* dec_ok, const u8* inf, u8* out_xy, u8* status) {
+    int st = status[i];
+    if (st == RECOVER_POINT && !dec_ok[i]) st = RECOVER_THROWS;          // 'invalid point'
+    else if (st == RECOVER_POINT && inf[i]) st = RECOVER_INF;
+    status[i] = (u8)st;
+    if (st != RECOVER_POINT) {
+      ELL_NOUNROLL
+      for (int b = 0; b < 2 * BYTES; b++) out_xy[i * 2 * BYTES + b] = 0;
+    }
+  }
+
   // ---- ECDSA sign for supplied nonces (ec/index.js:110-186, one pass of its loop) ----
   // nonce K (NBYTES big-endian, as HmacDRBG#generate returns it) -> k = _truncateToN(K, true):
   // K reaches it as a BN, so the shift is 8*byteLength(value) - n.bitLength() when positive

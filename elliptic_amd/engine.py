@@ -208,6 +208,28 @@ class Context:
                                                   err.ctypes.data))
         return ok, err
 
+    def ecdsa_recover(self, curve, hashes, r, s, recid):
+        """EC#recoverPubKey per item -> (xy (n, 2B), status (n,)): 0 point, 1 infinity,
+        2 the reference throws, 3 outside the engine's domain (r = 0 or r >= n)"""
+        B, NB = FIELD_BYTES[curve], ORDER_BYTES[curve]
+        hashes = _u8(hashes)
+        n, hash_len = hashes.shape
+        r = _u8(r, (n, NB))
+        s = _u8(s, (n, NB))
+        recid = _u8(recid, (n,))
+        xy = np.zeros((n, 2 * B), np.uint8)
+        st = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_ecdsa_recover(self._ctx, self._cid(curve), n, hashes.ctypes.data, hash_len,
+                                                   r.ctypes.data, s.ctypes.data, recid.ctypes.data,
+                                                   xy.ctypes.data, st.ctypes.data))
+        return xy, st
+
+    def ecdsa_recover_dev(self, curve, hashes, r, s, recid, out_xy, out_status):
+        n, hash_len = hashes.shape
+        self._check(self._lib.ellgpu_ecdsa_recover_dev(self._ctx, self._cid(curve), n, hashes.data_ptr(), hash_len,
+                                                       r.data_ptr(), s.data_ptr(), recid.data_ptr(),
+                                                       out_xy.data_ptr(), out_status.data_ptr(), self._stream()))
+
     def eddsa_sign(self, msgs, secrets):
         """ed25519 EdDSA sign from 32-byte secrets (EDDSA#sign with keyFromSecret).  msgs as for
         eddsa_verify.  -> (sig (n, 64), pub (n, 32)) uint8 arrays"""

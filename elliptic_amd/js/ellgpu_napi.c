@@ -23,6 +23,7 @@
  *             -> {r, s, recid, ok}
  *           eddsaVerify(ctx, msgs, offsets|null, msgLen, sigs, pubs) -> {ok, err}
  *           eddsaSign(ctx, msgs, offsets|null, msgLen, secrets) -> {sig, pub}
+ *           ecdsaRecover(ctx, curve, hash, hashLen, r, s, recid) -> {xy, status}
  *             offsets: Buffer of n+1 little-endian uint64 byte offsets into msgs
  *           callAsync(op, ctx, curve, hashLen, msgBits, b0, b1, b2, b3) -> Promise
  *             op 0 mulFixed(b0=k) 1 mulVar(k, xy) 2 mulAdd2(k1, p1|null, k2, p2)
@@ -64,6 +65,8 @@ static struct {
                       const uint8_t*, uint8_t*, uint8_t*);
   int (*eddsa_sign)(ellgpu_ctx*, size_t, const uint8_t*, const uint8_t*, const uint64_t*, size_t,
                     uint8_t*, uint8_t*);
+  int (*ecdsa_recover)(ellgpu_ctx*, int, size_t, const uint8_t*, int, const uint8_t*, const uint8_t*,
+                       const uint8_t*, uint8_t*, uint8_t*);
 } L;
 
 #define THROW(env, msg) do { napi_throw_error((env), NULL, (msg)); return NULL; } while (0)
@@ -97,6 +100,7 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   SYM(decompress, "ellgpu_decompress");
   SYM(eddsa_verify, "ellgpu_eddsa_verify");
   SYM(eddsa_sign, "ellgpu_eddsa_sign");
+  SYM(ecdsa_recover, "ellgpu_ecdsa_recover");
   SYM(ecdsa_sign, "ellgpu_ecdsa_sign");
   L.h = h;
   napi_value t; CHECK(env, napi_get_boolean(env, 1, &t));
@@ -277,6 +281,30 @@ static napi_value fn_sign(napi_env env, napi_callback_info info) {
   return o;
 }
 
+/* ecdsaRecover(ctx, curve, hash, hashLen, r, s, recid) -> {xy: Buffer(n*2B), status: Buffer(n)} */
+static napi_value fn_recover(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 7; napi_value argv[7];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  int32_t curve, hl;
+  if (napi_get_value_int32(env, argv[1], &curve) != napi_ok || napi_get_value_int32(env, argv[3], &hl) != napi_ok)
+    THROW(env, "ecdsaRecover(ctx, curve, hash, hashLen, r, s, recid)");
+  int B = L.field_bytes(curve), NB = L.order_bytes(curve);
+  if (B <= 0 || NB <= 0 || hl <= 0) THROW(env, "bad curve / hashLen");
+  const uint8_t *h, *r, *sg, *j; size_t lh, lr, ls, lj;
+  if (!get_buf(env, argv[2], &h, &lh, 0) || !get_buf(env, argv[4], &r, &lr, 0) ||
+      !get_buf(env, argv[5], &sg, &ls, 0) || !get_buf(env, argv[6], &j, &lj, 0)) return NULL;
+  if (lh % (size_t)hl) THROW(env, "hash buffer length is not a multiple of hashLen");
+  size_t n = lh / (size_t)hl;
+  if (lr != n * (size_t)NB || ls != lr || lj != n) THROW(env, "buffer length mismatch");
+  napi_value bxy, bst; void *dxy, *dst;
+  CHECK(env, napi_create_buffer(env, n * 2 * (size_t)B, &dxy, &bxy));
+  CHECK(env, napi_create_buffer(env, n, &dst, &bst));
+  if (L.ecdsa_recover(c, curve, n, h, hl, r, sg, j, (uint8_t*)dxy, (uint8_t*)dst) != 0) return lib_error(env);
+  return mk_result(env, "xy", bxy, "status", bst);
+}
+
 static napi_value fn_eddsa_verify(napi_env env, napi_callback_info info) {
   if (!need_lib(env)) return NULL;
   size_t argc = 6; napi_value argv[6];
@@ -437,7 +465,7 @@ static napi_value init(napi_env env, napi_value exports) {
     {"deviceCount", fn_device_count}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
     {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519},
     {"callAsync", fn_call_async}, {"decompress", fn_decompress},
-    {"eddsaVerify", fn_eddsa_verify}, {"eddsaSign", fn_eddsa_sign}, {"ecdsaSign", fn_sign},
+    {"eddsaVerify", fn_eddsa_verify}, {"eddsaSign", fn_eddsa_sign}, {"ecdsaSign", fn_sign}, {"ecdsaRecover", fn_recover},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

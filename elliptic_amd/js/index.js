@@ -93,6 +93,15 @@ Engine.prototype.ecdsaSignBatch = function ecdsaSignBatch(curve, o) {
     !!o.canonical);
 };
 
+// EC#recoverPubKey per item (ec/index.js:231-259).  o = { hashes, hashLen, r, s: Buffer(n x NB),
+// recid: Buffer(n) } -> { xy: Buffer(n x 2B), status: Buffer(n) }  (0 point, 1 infinity,
+// 2 the reference throws, 3 outside the engine's domain: r = 0 or r >= n)
+Engine.prototype.ecdsaRecoverBatch = function ecdsaRecoverBatch(curve, o) {
+  var id = this._id(curve);
+  this.stats.gpuCalls++; this.stats.gpuItems += o.recid.length;
+  return this.addon.ecdsaRecover(this.ctx, id, o.hashes, o.hashLen, o.r, o.s, o.recid);
+};
+
 // ed25519 EdDSA verify.  msgs: array of Buffers (any lengths); sigs: Buffer(n x 64) of R||S;
 // pubs: Buffer(n x 32).  -> { ok: Buffer(n), err: Buffer(n) }  (err = 1 where the
 // reference throws: R or A is not a curve point)
@@ -272,7 +281,9 @@ function install(elliptic, options) {
   };
 
   // point decompression: ShortCurve#pointFromX (short.js:187-204) and
-  // EdwardsCurve#pointFromY (edwards.js:71-97); same 'invalid point' error
+  // EdwardsCurve#pointFromY (edwards.js:71-97).  An input with no point is handed to the
+  // reference's own method, so the caller sees exactly the reference's exception ('invalid
+  // point', or 'Assertion failed' out of bn.js's Tonelli-Shanks loop for 2^255 - 19)
   orig.pointFromX = short.pointFromX;
   short.pointFromX = function pointFromX(x, odd) {
     var d = domain(this);
@@ -283,7 +294,7 @@ function install(elliptic, options) {
       return orig.pointFromX.apply(this, arguments);
     }
     var r = eng.decompressBatch(d.id, Buffer.from(xb.toArray('be', d.B)), Buffer.from([odd ? 1 : 0]));
-    if (!r.ok[0]) throw new Error('invalid point');
+    if (!r.ok[0]) return orig.pointFromX.apply(this, arguments);      // throws as the reference does
     return this.point(new BN(r.xy.slice(0, d.B)), new BN(r.xy.slice(d.B, 2 * d.B)));
   };
   var edw = elliptic.curve.edwards.prototype;
@@ -297,13 +308,46 @@ function install(elliptic, options) {
       return orig.pointFromY.apply(this, arguments);
     }
     var r = eng.decompressBatch(d.id, Buffer.from(yb.toArray('be', d.B)), Buffer.from([odd ? 1 : 0]));
-    if (!r.ok[0]) throw new Error('invalid point');
+    if (!r.ok[0]) return orig.pointFromY.apply(this, arguments);      // throws as the reference does
     return this.point(new BN(r.xy.slice(0, d.B)), new BN(r.xy.slice(d.B, 2 * d.B)));
   };
 
+  // EC#recoverPubKey (ec/index.js:231-259): decompression of R, r^-1, both scalars and
+  // s1*G + s2*R in one call.  Anything the engine does not take (p224, toy curves, r outside
+  // [1, n), digests longer than twice the order, non-byte messages) and every case where the
+  // reference throws is run by the reference's own method, so results and exceptions are its own.
+  var ecProto = elliptic.ec.prototype;
+  orig.recoverPubKey = ecProto.recoverPubKey;
+  ecProto.recoverPubKey = function recoverPubKey(msg, signature, j, enc) {
+    var d = domain(this.curve);
+    var e, r, s, NB;
+    try {
+      if (!d || d.name === 'p224' || (3 & j) !== j) throw null;
+      // the reference's Signature class is not exported; {r, s} objects (which include its own
+      // instances) are decoded as it does (signature.js:20-21), DER input goes to the reference
+      if (!signature || signature.r === undefined || signature.s === undefined) throw null;
+      r = new BN(signature.r, 16);
+      s = new BN(signature.s, 16);
+      e = new BN(msg);
+      NB = this.n.byteLength();
+      if (e.isNeg() || r.isNeg() || s.isNeg() || r.byteLength() > NB || s.byteLength() > NB ||
+          e.byteLength() > 2 * NB) throw null;
+    } catch (x) {
+      eng.stats.passthrough++;
+      return orig.recoverPubKey.apply(this, arguments);
+    }
+    var hl = Math.max(e.byteLength(), 1);
+    var res = eng.ecdsaRecoverBatch(d.id, { hashes: Buffer.from(e.toArray('be', hl)), hashLen: hl,
+      r: Buffer.from(r.toArray('be', NB)), s: Buffer.from(s.toArray('be', NB)), recid: Buffer.from([j]) });
+    // status 2 / 3: the reference throws, or inverts an unreduced r -- let it
+    if (res.status[0] >= 2) return orig.recoverPubKey.apply(this, arguments);
+    if (res.status[0] === 1) return this.curve.point(null, null);
+    return this.curve.point(new BN(res.xy.slice(0, d.B)), new BN(res.xy.slice(d.B, 2 * d.B)));
+  };
+
   // EDDSA#verify (eddsa/index.js:52-63) for ed25519: one launch does SHA-512, both point
-  // decodings, S*G, h*A and the comparison.  Same results: false for S >= n, an Error where
-  // the reference throws on an undecodable R or A.
+  // decodings, S*G, h*A and the comparison.  Same results: false for S >= n; where the
+  // reference throws (an undecodable R or A) its own method is run to throw the same Error.
   var eddsaProto = elliptic.eddsa.prototype;
   orig.eddsaVerify = eddsaProto.verify;
   eddsaProto.verify = function verify(message, sig, pub) {
@@ -321,7 +365,7 @@ function install(elliptic, options) {
       return orig.eddsaVerify.apply(this, arguments);
     }
     var r = eng.eddsaVerifyBatch([m], sb, pb);
-    if (r.err[0]) throw new Error('invalid point');
+    if (r.err[0]) return orig.eddsaVerify.apply(this, arguments);      // throws as the reference does
     return r.ok[0] === 1;
   };
 
@@ -366,6 +410,7 @@ function install(elliptic, options) {
     short.pointFromX = orig.pointFromX;
     eddsaProto.verify = orig.eddsaVerify;
     eddsaProto.sign = orig.eddsaSign;
+    ecProto.recoverPubKey = orig.recoverPubKey;
     edw.pointFromY = orig.pointFromY;
   };
 

@@ -107,6 +107,26 @@ function check(r, i, B, want, what) {
     checked++;
   });
 })();
+['secp256k1', 'p256', 'p384'].forEach(function(name) {
+  var cs = JSON.parse(fs.readFileSync(path.join(GOLD, 'recover_' + name + '.json')));
+  var NB = cs[0].r.length / 2;
+  var byLen = {};
+  cs.forEach(function(c) { (byLen[c.z.length / 2] = byLen[c.z.length / 2] || []).push(c); });
+  Object.keys(byLen).forEach(function(len) {
+    var g = byLen[len];
+    var r = eng.ecdsaRecoverBatch(name, { hashes: hexBuf(g.map(function(c) { return c.z; }), +len), hashLen: +len,
+      r: hexBuf(g.map(function(c) { return c.r; }), NB), s: hexBuf(g.map(function(c) { return c.s; }), NB),
+      recid: Buffer.from(g.map(function(c) { return c.j; })) });
+    var B2 = r.xy.length / g.length;
+    g.forEach(function(c, i) {
+      var st = r.status[i];
+      var good = c.throws ? st === 2 : (c.q.inf ? st === 1 :
+        (st === 0 && r.xy.slice(i * B2, (i + 1) * B2).toString('hex') === c.q.x + c.q.y));
+      if (!good) throw new Error('recover mismatch: ' + name + ' ' + c.note);
+      checked++;
+    });
+  });
+});
 (function() {
   var cs = JSON.parse(fs.readFileSync(path.join(GOLD, 'eddsa_sign_ed25519.json')));
   var r = eng.eddsaSignBatch(cs.map(function(c) { return Buffer.from(c.msg, 'hex'); }),

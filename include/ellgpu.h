@@ -161,6 +161,24 @@ int ellgpu_eddsa_verify_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, cons
                             size_t msg_len, const uint8_t* sigs, const uint8_t* pubs,
                             uint8_t* out_ok, uint8_t* out_err, void* stream);
 
+/* ECDSA public-key recovery: out_xy[i] = EC#recoverPubKey(hash_i, {r_i, s_i}, recid_i),
+ * lib/elliptic/ec/index.js:231-259 -- Q = r^-1 (s R - e G) with R = pointFromX(r + (j >> 1) n,
+ * j & 1) (short.js:187-204) and e = new BN(hash) (NOT truncated by that method, only reduced
+ * mod n; hash_len bytes per item, at most twice the order width).  out_status[i]:
+ *   0  Q is a finite point, written to out_xy (x || y)
+ *   1  Q is the point at infinity
+ *   2  the reference throws: 'Unable to find sencond key candinate' (j & 2 with r >= p mod n),
+ *      'invalid point' (no point with that x), or j > 3
+ *   3  outside the engine's domain (r = 0 or r >= n, where the reference inverts an unreduced
+ *      BN): hand the item to the reference
+ * out_xy is zeroed where the status is not 0.  Not available for p224 (p = 1 mod 4). */
+int ellgpu_ecdsa_recover(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                         const uint8_t* r, const uint8_t* s, const uint8_t* recid, uint8_t* out_xy,
+                         uint8_t* out_status);
+int ellgpu_ecdsa_recover_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                             const uint8_t* r, const uint8_t* s, const uint8_t* recid, uint8_t* out_xy,
+                             uint8_t* out_status, void* stream);
+
 /* EdDSA (ed25519) sign from 32-byte secrets: out_sig[i] = EDDSA#sign(msg_i, secret_i).toBytes()
  * (R || S, 64 bytes), lib/elliptic/eddsa/index.js:32-50, with the key derivation of
  * KeyPair.fromSecret (eddsa/key.js:42-75): hash = SHA-512(secret), a = the clamped first half,

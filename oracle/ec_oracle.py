@@ -620,6 +620,25 @@ def ecdsa_verify(curve: ShortCurve, msg: int, msg_bytes: int, r: int, s: int,
     return curve.j_eq_x_to_p(jp, r)
 
 
+def ecdsa_recover(curve: ShortCurve, e: int, r: int, s: int, j: int) -> ShortPoint:
+    """ec/index.js:231-259 EC#recoverPubKey: Q = r^-1 (s R - e G), R = the point with
+    x = r (+ n when j & 2) and y-parity j & 1.  e = new BN(msg) is used as it is (no
+    _truncateToN here), only reduced by the arithmetic mod n.  Raises ValueError with the
+    reference's message where it throws."""
+    if (3 & j) != j:
+        raise ValueError("The recovery param is more than two bits")
+    n = curve.n
+    is_y_odd = j & 1
+    is_second = j >> 1
+    if r >= curve.p % n and is_second:
+        raise ValueError("Unable to find sencond key candinate")
+    R = curve.point_from_x(r + n if is_second else r, bool(is_y_odd))       # 'invalid point'
+    rinv = pow(r, -1, n)
+    s1 = (n - e) * rinv % n
+    s2 = s * rinv % n
+    return curve.g.mul_add(s1, R, s2)
+
+
 def ecdsa_sign(curve: ShortCurve, msg: int, msg_bytes: int, d: int, k_bytes: bytes, canonical=False,
                msg_bit_length=None):
     """ec/index.js:110-186 EC#sign for ONE supplied nonce (options.k(0)): returns
@@ -936,7 +955,9 @@ def _sqrt_mod(a: int, p: int) -> Optional[int]:
         r = pow(a, (p + 1) // 4, p)
         return r if r * r % p == a else None
     if pow(a, (p - 1) // 2, p) != 1:
-        return None
+        # a non-residue never reaches t^(2^i) == 1 with i < m in bn.js's Tonelli-Shanks loop:
+        # `assert(i < m)` (dist/elliptic.js:7216) fails, the caller sees Error('Assertion failed')
+        raise ValueError("Assertion failed")
     q, s = p - 1, 0
     while q % 2 == 0:
         q //= 2

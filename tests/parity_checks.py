@@ -150,6 +150,40 @@ def check_eddsa_golden(ctx):
     return len(cases)
 
 
+def check_recover_golden(ctx, curve):
+    """EC#recoverPubKey goldens: points, infinity, and status 2 exactly where the reference
+    throws ('invalid point' / 'Unable to find sencond key candinate')"""
+    from golden_util import load
+    B, NB = FIELD_BYTES[curve], ORDER_BYTES[curve]
+    groups = {}
+    for c in load("recover_%s.json" % curve):
+        groups.setdefault(len(c["z"]) // 2, []).append(c)
+    total = 0
+    for zlen, cs in sorted(groups.items()):
+        z = np.frombuffer(b"".join(bytes.fromhex(c["z"]) for c in cs), np.uint8).reshape(-1, zlen)
+        r = np.frombuffer(b"".join(bytes.fromhex(c["r"]) for c in cs), np.uint8).reshape(-1, NB)
+        s = np.frombuffer(b"".join(bytes.fromhex(c["s"]) for c in cs), np.uint8).reshape(-1, NB)
+        j = np.array([c["j"] for c in cs], np.uint8)
+        xy, st = ctx.ecdsa_recover(curve, z, r, s, j)
+        for i, c in enumerate(cs):
+            if "throws" in c:
+                assert st[i] == 2 and not xy[i].any(), c
+            elif c["q"].get("inf"):
+                assert st[i] == 1, c
+            else:
+                assert st[i] == 0, c
+                assert xy[i].tobytes().hex() == c["q"]["x"] + c["q"]["y"], c
+            total += 1
+    # outside the domain: r = 0 and r = n are reported, not computed
+    n_int = int.from_bytes(bytes.fromhex(load("curves.json")[curve]["n"].rjust(2 * NB, "0")), "big")
+    z = np.zeros((2, 32), np.uint8)
+    r = ints_to_be([0, n_int], NB)
+    s = ints_to_be([5, 5], NB)
+    xy, st = ctx.ecdsa_recover(curve, z, r, s, np.array([0, 1], np.uint8))
+    assert list(st) == [3, 3] and not xy.any()
+    return total
+
+
 def check_eddsa_sign_golden(ctx):
     """EDDSA#sign / keyFromSecret goldens: sign.input vectors + seeded block-boundary lengths;
     the signatures must also verify"""

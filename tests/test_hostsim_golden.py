@@ -200,6 +200,18 @@ def test_sign_golden(ctx, curve):
     assert PC.check_sign_golden(ctx, curve) >= 12
 
 
+@pytest.mark.parametrize("curve", ["secp256k1", "p192", "p256", "p384", "p521"])
+def test_recover_golden(ctx, curve):
+    assert PC.check_recover_golden(ctx, curve) >= 30
+
+
+def test_recover_unsupported(ctx):
+    with pytest.raises(elliptic_amd.EllgpuError) as e:
+        ctx.ecdsa_recover("p224", np.zeros((1, 28), np.uint8), np.ones((1, 28), np.uint8), np.ones((1, 28), np.uint8),
+                          np.zeros(1, np.uint8))
+    assert e.value.code == -5
+
+
 def test_eddsa_sign_golden(ctx):
     assert PC.check_eddsa_sign_golden(ctx) > 100
 

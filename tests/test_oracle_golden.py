@@ -147,12 +147,35 @@ def test_eddsa_verify_matches_reference():
     for c in load("eddsa_verify_ed25519.json"):
         try:
             got = O.eddsa_verify(cur, bytes.fromhex(c["msg"]), bytes.fromhex(c["sig"]), bytes.fromhex(c["pub"]))
-        except ValueError:
-            got = "throws"
-        want = "throws" if "throws" in c else c["ok"]
+        except ValueError as ex:
+            got = "throws: " + str(ex)               # the message too ('Assertion failed' from bn.js sqrt)
+        want = "throws: " + c["throws"] if "throws" in c else c["ok"]
         assert got == want, c
-        seen[want] += 1
+        seen["throws" if "throws" in c else want] += 1
     assert seen[True] > 50 and seen[False] > 30 and seen["throws"] > 3
+
+
+@pytest.mark.parametrize("name", O.SHORT_CURVES)
+def test_ecdsa_recover_matches_reference(name):
+    """EC#recoverPubKey: real signatures with every j, random (r, s), second candidates,
+    e = 0 / n / n + 1, long digests; points, infinity and both thrown messages"""
+    cur = O.get_curve(name)
+    seen = {"pt": 0, "throws": 0}
+    for c in load("recover_%s.json" % name):
+        try:
+            q = O.ecdsa_recover(cur, I(c["z"]), I(c["r"]), I(c["s"]), c["j"])
+            got = {"inf": True} if q.inf else {"x": q.x, "y": q.y}
+        except ValueError as ex:
+            got = {"throws": str(ex)}
+        if "throws" in c:
+            assert got == {"throws": c["throws"]}, c
+            seen["throws"] += 1
+        elif c["q"].get("inf"):
+            assert got == {"inf": True}, c
+        else:
+            assert got == {"x": I(c["q"]["x"]), "y": I(c["q"]["y"])}, c
+            seen["pt"] += 1
+    assert seen["pt"] > 8 and seen["throws"] > 5
 
 
 def test_eddsa_sign_matches_reference():

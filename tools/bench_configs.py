@@ -77,6 +77,14 @@ def main():
             ok = torch.zeros(n, dtype=torch.uint8, device=dev)
             timed("%s ECDSA sign (nonces supplied)" % curve, n,
                   lambda: ctx.ecdsa_sign_dev(curve, dk, dd, nonce, r_o, s_o, rec, ok, canonical=True))
+            # public-key recovery from those signatures (decompress R, r^-1, s1*G + s2*R): must
+            # give back d*G wherever the signing pass accepted the nonce
+            q_o = torch.zeros((n, 2 * B), dtype=torch.uint8, device=dev)
+            st = torch.zeros(n, dtype=torch.uint8, device=dev)
+            timed("%s ECDSA public-key recovery" % curve, n,
+                  lambda: ctx.ecdsa_recover_dev(curve, dk, r_o, s_o, rec, q_o, st))
+            good = ok.bool()
+            assert bool((st[good] == 0).all()) and torch.equal(q_o[good], pts[good])
             xs = pts[:, :B].contiguous()
             odd = (pts[:, 2 * B - 1] & 1).contiguous()
             timed("%s key decompression (pointFromX)" % curve, n, lambda: ctx.decompress_dev(curve, xs, odd, out, ok))
@@ -109,6 +117,14 @@ def main():
             dm, ds, dp = [torch.from_numpy(x).to(dev).repeat(4, 1).contiguous() for x in (msgs, sig, Ae)]
             ok = torch.zeros(4 * m, dtype=torch.uint8, device=dev)
             timed("ed25519 EdDSA verify (48-byte messages)", 4 * m, lambda: ctx.eddsa_verify_dev(dm, mlen, ds, dp, ok))
+            assert bool(ok.all())
+            # EdDSA sign from 32-byte secrets (two hashes of the message, a*G, r*G, S), then verified
+            sec = torch.from_numpy(rnd("cfg:eddsa:secret", 4 * m, 32)).to(dev)
+            sg = torch.zeros((4 * m, 64), dtype=torch.uint8, device=dev)
+            pk = torch.zeros((4 * m, 32), dtype=torch.uint8, device=dev)
+            timed("ed25519 EdDSA sign (48-byte messages)", 4 * m, lambda: ctx.eddsa_sign_dev(sec, dm, mlen, sg, pk))
+            ctx.eddsa_verify_dev(dm, mlen, sg, pk, ok)
+            torch.cuda.synchronize()
             assert bool(ok.all())
     if only and "curve25519" not in only:
         return

@@ -406,6 +406,61 @@ function genEddsa() {
   return cases;
 }
 
+// ------------------------------------------------------------ recover_<curve>.json
+// EC#recoverPubKey (ec/index.js:231-259): (e, r, s, j) -> Q = r^-1 (s R - e G) with R the point
+// of x-coordinate r (+ n when j & 2) and y-parity j & 1.  Real signatures with all four j,
+// random (r, s), small r (the second candidate exists only for r < p - n), digests longer
+// than n (e is NOT truncated here, only reduced).  Result: point, inf, or the message thrown.
+function genRecover(name) {
+  var pc = elliptic.curves[name];
+  var ec = new elliptic.ec(pc);
+  var c = pc.curve;
+  var NB = c.n.byteLength();
+  var rng = new Prng('ellgpu-golden-v1:recover:' + name);
+  var cases = [];
+  function one(z, r, s, j, note) {
+    var o = { z: Buffer.from(z).toString('hex'), r: hex(r, NB), s: hex(s, NB), j: j, note: note };
+    try {
+      var Q = ec.recoverPubKey(z, { r: hex(r, NB), s: hex(s, NB) }, j);
+      o.q = affine(c, Q);
+    } catch (e) {
+      o.throws = e.message;
+    }
+    cases.push(o);
+  }
+  var N = Math.ceil(COUNTS[name] / 3);
+  for (var i = 0; i < N; i++) {
+    var zlen = [32, 32, NB, 20, 48][i % 5];
+    if (zlen > 2 * NB) zlen = NB;
+    var z = rng.bytes(zlen);
+    var key = ec.keyFromPrivate(hex(rng.below(c.n.subn(1)).addn(1), NB), 'hex');
+    var sig = ec.sign(z, key, { canonical: (i & 1) === 1 });
+    for (var j = 0; j < 4; j++) one(z, sig.r, sig.s, j, j === sig.recoveryParam ? 'signature, its own j' : 'signature, other j');
+    var last = cases[cases.length - 4 + sig.recoveryParam];
+    // note: EC#sign truncates the digest (_truncateToN), recoverPubKey does not: they only agree
+    // when the digest is not longer than n
+    if (zlen * 8 <= c.n.bitLength() && (!last.q || last.q.x !== hex(key.getPublic().getX(), flen(c))))
+      throw new Error('reference recoverPubKey disagrees with the signing key');
+  }
+  for (i = 0; i < N; i++) {
+    one(rng.bytes(32), rng.below(c.n.subn(1)).addn(1), rng.below(c.n.subn(1)).addn(1), i & 3, 'random r, s');
+  }
+  // small r: the second candidate r + n is below p
+  var pmn = c.p.umod(c.n);
+  for (i = 0; i < 12; i++) {
+    var rs = rng.below(pmn.subn(1)).addn(1);
+    one(rng.bytes(32), rs, rng.below(c.n.subn(1)).addn(1), 2 + (i & 1), 'r < p mod n, second candidate');
+  }
+  one(rng.bytes(32), pmn, new BN(5), 2, 'r = p mod n, second candidate');
+  one(rng.bytes(32), pmn.subn(1), new BN(5), 3, 'r = p mod n - 1, second candidate');
+  one(Buffer.alloc(32), new BN(7), new BN(9), 0, 'e = 0');
+  one(Buffer.from(c.n.toArray('be', NB)), new BN(7), new BN(9), 1, 'e = n');
+  one(Buffer.from(c.n.addn(1).toArray('be', NB)), c.n.subn(1), c.n.subn(1), 1, 'e = n + 1, r = s = n - 1');
+  one(rng.bytes(2 * NB > 64 ? 64 : 2 * NB), rng.below(c.n.subn(1)).addn(1), new BN(3), 0, 'long digest');
+  one(rng.bytes(32), new BN(1), new BN(1), 0, 'r = s = 1');
+  return cases;
+}
+
 // ------------------------------------------------------ eddsa_sign_ed25519.json
 // EDDSA#sign (eddsa/index.js:32-50) with KeyPair.fromSecret (eddsa/key.js:42-75): a pure
 // function (secret, message) -> (signature, public key).  The official sign.input vectors
@@ -618,6 +673,7 @@ SHORT.forEach(function(name) {
   write('mul_' + name + '.json', genShortMul(name));
   write('verify_' + name + '.json', genVerify(name));
   write('sign_' + name + '.json', genSign(name));
+  write('recover_' + name + '.json', genRecover(name));
 });
 ['secp256k1', 'p192', 'p256', 'p384', 'p521', 'ed25519'].forEach(function(name) {
   write('decompress_' + name + '.json', genDecompress(name));
