@@ -44,6 +44,23 @@ def test_reference_suite_passes_with_install_patch():
 
 
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_patched_api_matches_goldens_including_exception_messages():
+    """recoverPubKey / EDDSA sign / EDDSA verify / pointFromX / pointFromY through install():
+    the results and the message of every thrown Error equal what the unpatched reference
+    produced when the golden files were generated"""
+    if not os.path.exists("/root/reference/dist/elliptic.js"):
+        pytest.skip("reference checkout not present (GPU box)")
+    _addon()
+    from hostsim.build import build as build_hostsim
+    env = dict(os.environ, ELLGPU_LIB=build_hostsim())
+    p = subprocess.run(["node", os.path.join(ROOT, "tools", "check_patched_results.js")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["checked"] > 1000 and res["thrown"] > 300
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
 def test_js_batch_api_hostsim():
     _addon()
     from hostsim.build import build as build_hostsim
