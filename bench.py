@@ -128,6 +128,46 @@ def traffic_from_profiles():
                     "~4.2 KiB gathered per verify), see DESIGN.md section 3"}
 
 
+def issue_from_profiles(kernel_ms, n):
+    """Instruction-issue accounting of ecdsa_main from the newest committed rocprofv3 PMC
+    summaries (profiles/*pmc_sq_a*.txt: SQ_INSTS_VALU; *pmc_sq_b*.txt: SQ_INSTS_VALU_INT64 /
+    _INT32), priced at the issue times measured by tools/microbench/valu_patterns.hip
+    (profiles/*valu_patterns.log: 4.5 cycles per wavefront for v_mad_u64_u32, 4.2 for every
+    carry-consuming / VOP3 integer op, 2.5 for plain VOP1/VOP2 ops).  `frac` = issue cycles the
+    instruction mix needs / cycles the kernel took per SIMD: the honest utilisation figure for a
+    kernel in which a carry costs as much as a multiply."""
+    import glob
+    import re
+
+    def counter(pattern, name):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        if not files:
+            return None, None
+        txt = open(files[-1]).read()
+        m = re.search(r"FnEcdsaMain<CvSecp256k1>>\s+" + name + r"\s+(\d+)\s+n=(\d+)", txt)
+        c = re.search(r"FnEcdsaMain<CvSecp256k1>>\s+(\d+)\s+\d+\s+\d+\s+[\d.]+", txt)   # kernel-stats row: calls
+        if not m or not c:
+            return None, None
+        return int(m.group(1)) / int(c.group(1)), os.path.relpath(files[-1], ROOT)
+
+    valu, src_a = counter("*pmc_sq_a*.txt", "SQ_INSTS_VALU")
+    i64, src_b = counter("*pmc_sq_b*.txt", "SQ_INSTS_VALU_INT64")
+    i32, _ = counter("*pmc_sq_b*.txt", "SQ_INSTS_VALU_INT32")
+    if not valu or not i64 or not i32:
+        return None
+    waves = (1 << 20) / 64.0                      # the profiled launches are 2^20-tuple launches
+    valu, i64, i32 = valu / waves, i64 / waves, i32 / waves
+    other = max(valu - i64 - i32, 0.0)
+    need = 4.5 * i64 + 4.2 * i32 + 2.5 * other    # issue cycles per wavefront
+    simds = 256 * 4
+    clock_khz = 2.4e6
+    have = kernel_ms * clock_khz / ((n / 64.0) / simds)
+    return {"valu_insts_per_unit": valu, "mad_u64_per_unit": i64, "carry_int32_per_unit": i32,
+            "other_per_unit": other, "issue_cycles_per_wave": need, "elapsed_cycles_per_wave_slot": have,
+            "frac": need / have if have else None, "clock_ghz": 2.4,
+            "sources": [src_a, src_b, "profiles/r01_valu_patterns.log"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,6 +286,7 @@ def main():
                 "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach_gbs / HBM_PEAK_GBS, "alg_bytes_per_unit": BYTES_PER_VERIFY},
                 "traffic": traffic_from_profiles() if n == 1 << 20 else None,
+                "issue": issue_from_profiles(k_ms, n) if n == 1 << 20 else None,
             },
         }
         if world == 1 and not args.no_cpu:
