@@ -23,6 +23,17 @@ def main(path):
     for name, calls, total, avg, pct in cur.execute(
             "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc"):
         print("%-60s %6d %14d %14.0f %7.2f" % (short(name), calls, total, avg, pct))
+    # per-dispatch durations in launch order: the first launches of a kernel (cold code / clocks,
+    # bench.py's untimed warm-up steps) are slower than the steady state its HIP events time
+    print("\n## durations per dispatch, launch order (ms)")
+    per = {}
+    for name, dur in cur.execute("select name,duration from kernels order by start"):
+        per.setdefault(short(name), []).append(dur / 1e6)
+    for name, ds in per.items():
+        if len(ds) > 1 and max(ds) > 0.05:
+            tail = ds[len(ds) // 2:]
+            print("%-60s %s   | mean of the last %d: %.3f" % (name, " ".join("%.3f" % d for d in ds[:12]),
+                                                            len(tail), sum(tail) / len(tail)))
     print("\n## dispatches (grid, workgroup, VGPR/AGPR/SGPR, LDS, scratch)")
     seen = set()
     for row in cur.execute("select name,grid_x,workgroup_x,vgpr_count,accum_vgpr_count,sgpr_count,lds_size,scratch_size,duration from kernels order by start"):
