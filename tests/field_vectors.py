@@ -231,3 +231,56 @@ def shift_vectors():
         for kk in (k, 1, 2, (1 << 20) - 1, 38):
             out.append((1, 10, a, kk, a * kk % p))
     return out
+
+
+# ---- FpSolinas (p256 = field 13, p384 = field 14): the lazy-accumulator fold ----------------
+SOL_FIELDS = {
+    13: (2 ** 256 - 2 ** 224 + 2 ** 192 + 2 ** 96 - 1, 8, [(7, 1), (6, -1), (3, -1), (0, 1)]),
+    14: (2 ** 384 - 2 ** 128 - 2 ** 96 + 2 ** 32 - 1, 12, [(4, 1), (3, 1), (1, -1), (0, 1)]),
+}
+
+
+def solinas_trace(a, b, field):
+    """mirror of FpSolinas::reduce_wide -> (c2 after the second fold pass, top word, carry c)"""
+    p, L, fold = SOL_FIELDS[field]
+    N = a * b
+    A = [(N >> (32 * k)) & 0xFFFFFFFF for k in range(2 * L)]
+    for k in range(2 * L - 1, L - 1, -1):
+        v = A[k]
+        for pos, sg in fold:
+            A[k - L + pos] += sg * v
+    r, c = [], 0
+    for k in range(L):
+        t = A[k] + c
+        r.append(t & 0xFFFFFFFF)
+        c = t >> 32
+    c2 = 0
+    for k in range(fold[0][0] + 1):
+        e = sum(sg * c for pos, sg in fold if pos == k)
+        t = r[k] + e + c2
+        r[k] = t & 0xFFFFFFFF
+        c2 = t >> 32
+    return c2, r[L - 1], c
+
+
+def solinas_vectors():
+    """(field, op 2, a, b, a*b mod p) for operand pairs found by a seeded structured search
+    (tests/solinas_rare_operands.json) that enter the rare branch of the fold: a carry out of
+    the second pass, or a top word of 2^32 - 1"""
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "solinas_rare_operands.json")))
+    out = []
+    for field in (13, 14):
+        p = SOL_FIELDS[field][0]
+        n_c2 = n_top = 0
+        for ah, bh in d[str(field)]:
+            a, b = int(ah, 16), int(bh, 16)
+            c2, top, _ = solinas_trace(a, b, field)
+            n_c2 += c2 != 0
+            n_top += top == 0xFFFFFFFF
+            out.append((field, 2, a, b, a * b % p))
+            out.append((field, 2, b, a, a * b % p))
+            out.append((field, 3, a, 0, a * a % p))
+        assert n_c2 >= 5 and n_top >= 10, (field, n_c2, n_top)
+    return out

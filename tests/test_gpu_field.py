@@ -100,3 +100,17 @@ def test_rare_branches_gpu(ctx):
             got = _unpack(R)
             for v, g in zip(sel, got):
                 assert g == v[4], (field, op, hex(v[2]), hex(v[3]), hex(g))
+
+
+def test_rare_branches_solinas_gpu(ctx):
+    import field_vectors
+    vecs = field_vectors.solinas_vectors()
+    for field, L in ((13, 8), (14, 12)):
+        for op in (2, 3):
+            sel = [v for v in vecs if v[0] == field and v[1] == op]
+            A, B = _pack([v[2] for v in sel], L), _pack([v[3] for v in sel], L)
+            R = np.zeros((len(sel), L), np.uint32)
+            assert ctx._lib.ellgpu_debug_field_op(ctx._ctx, field, op, len(sel), A.ctypes.data, B.ctypes.data,
+                                                  R.ctypes.data) == 0
+            for v, g in zip(sel, _unpack(R)):
+                assert g == v[4], (field, op, hex(v[2]), hex(v[3]), hex(g))

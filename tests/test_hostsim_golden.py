@@ -120,6 +120,18 @@ def test_rare_branches_k256_25519(hs):
         assert _val(r) == want, (field, op, hex(a), hex(b))
 
 
+def test_rare_branches_solinas(hs):
+    """operands that drive the p256 / p384 lazy-accumulator fold into its rare branch"""
+    import field_vectors
+    vecs = field_vectors.solinas_vectors()
+    assert len(vecs) > 150
+    for field, op, a, b, want in vecs:
+        L = 8 if field == 13 else 12
+        r = (ctypes.c_uint32 * L)()
+        assert hs.hs_field_op(field, op, _limbs(a, L), _limbs(b, L), r) == 0
+        assert _val(r) == want, (field, op, hex(a), hex(b))
+
+
 def test_p521_from_plain_overrange(hs):
     """The Mersenne fold must canonicalise any 17-limb input (decompress hands raw 66-byte
     values to from_plain): p -> 0, 2^521 -> 1, all-ones limbs, ..."""
