@@ -171,8 +171,8 @@ def issue_from_profiles(kernel_ms, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1 << 20, help="tuples per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (self-test of the N>1 flow)")
