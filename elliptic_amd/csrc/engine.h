@@ -58,6 +58,7 @@ struct FnMulAddG {
   static constexpr const char* NAME = "mul_add_g";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
+  static constexpr int MIN_WAVES = W::L == 12 ? 2 : 1;      // p384: 2 waves/SIMD (<= 256 registers) beats a spill-free single wave
   size_t n; const u8* k1; const u8* k2; const u8* xy2; const typename W::A* comb;
   typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
@@ -100,7 +101,7 @@ template <class CV>
 struct FnEcdsaMain {
   static constexpr const char* NAME = "ecdsa_main";
   typedef Work<CV> W;
-  static constexpr int MIN_WAVES = W::L <= 8 ? ELL_ECDSA_MIN_WAVES : 1;      // <= 168 VGPRs for 256-bit curves
+  static constexpr int MIN_WAVES = W::L <= 8 ? ELL_ECDSA_MIN_WAVES : (W::L == 12 ? 2 : 1);   // <= 168 VGPRs for 256-bit curves, <= 256 for p384
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
   size_t n; const u32* u12; const u8* valid; const u8* r; const u8* pub;
   const typename W::A* comb; typename W::VT* tbl; u8* ok;
@@ -964,7 +965,7 @@ int Engine<BK>::mul_add2_chunk(size_t n, const u8* k1, const u8* xy1, const u8* 
                    u8* out_xy, u8* out_inf) {
   typedef Work<CV> W;
   u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
-  typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * 2 * W::TBL1 * sizeof(typename W::J));
+  typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * 2 * W::TBLJ * sizeof(typename W::J));
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
   FnMulAdd2<CV> f{n, k1, xy1, k2, xy2, tbl, jac};
   bk.launch(f, n);

@@ -112,13 +112,15 @@ struct Ladder {
     }
   }
 
-  // Effective-affine table of the odd multiples {1,3,...,15}*P (a = 0 curves only):
+  // Effective-affine table of the odd multiples {1,3,...,15}*P:
   // with d = 2P = (Xd, Yd, Zd), the map (x, y) -> (x Zd^2, y Zd^3) sends the curve to an
-  // isomorphic one (same a = 0 formulas) on which d is AFFINE, so each next odd multiple is
+  // isomorphic one (a' = a Zd^4; additions do not involve a) on which d is AFFINE, so each next odd multiple is
   // one mixed add; rescaling every entry to the last entry's Z then makes the whole table
   // affine on a second isomorphic curve.  The ladder runs there with 8M+3S mixed adds
   // (instead of 12M+4S) and its result is mapped back by one multiplication of Z by
-  // zg = Z_last * Zd.   tbl[0..8) = table, tbl[8..16) is used as scratch for the ratios.
+  // zg = Z_last * Zd -- when a = 0, whose doubling formula holds on every isomorphic curve;
+  // for a = -3 the caller maps the TABLE back to the true curve with zg^-1 instead
+  // (Work::var_ladder).   tbl[0..8) = table, tbl[8..16) is used as scratch for the ratios.
   ELL_HD static void build_table_odd8(A* tbl, const A& p, El& zg) {
     J d = G::dbl(G::from_affine(p));
     El zd2 = F::sqr(d.Z);

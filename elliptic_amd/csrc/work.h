@@ -47,10 +47,11 @@ struct Work {
   static constexpr int NNIB = ENDO ? 33 : 2 * BYTES;
   static constexpr bool TOP = !ENDO;
   static constexpr int NWIN = NNIB + (TOP ? 1 : 0);
-  static constexpr int TBL1 = 8 * NSV;                     // table entries per (k, P)
-  // element type of the variable-base window table: affine on the effective-affine curve
-  // for secp256k1 (ladder.h build_table_odd8), Jacobian otherwise
-  typedef typename std::conditional<ENDO, A, J>::type VT;
+  // variable-base window table: 8 affine odd multiples per digit string (16 entries per item:
+  // P and lambda*P for secp256k1; the second half is build_table_odd8's scratch otherwise)
+  static constexpr int TBL1 = 16;
+  typedef A VT;
+  static constexpr int TBLJ = 8 * NSV;                     // mul_add2: Jacobian entries per (k, P)
   // fixed-base comb: COMB_BITS-bit unsigned windows, table of d * 2^(COMB_BITS*w) * G.
   // 16-bit windows for the 256-bit curves (16 adds per k*G, 67 MB table that lives in
   // MALL/HBM and is gathered 64 B at a time); 8-bit windows otherwise.
@@ -97,7 +98,7 @@ struct Work {
 
   // ---- variable base -----------------------------------------------------
   // Recode k and build the window table(s) of P into digit slots
-  // [s0, s0+NSV) of an NS-string store and table entries tbl[0 .. TBL1).
+  // [s0, s0+NSV) of an NS-string store and table entries tbl[0 .. TBLJ).
   ELL_HD static void prepare_var(const u32 (&k)[L], const A& p, const DigitStore& ds, int s0,
                                  int NS, J* tbl, u32& negmask) {
     LD::build_table8(tbl, p);
@@ -126,7 +127,7 @@ struct Work {
 
   // k*P for one (k, P), result in true Jacobian coordinates.  secp256k1: GLV split, odd
   // signed digits, effective-affine tables of P and lambda*P (mixed adds only); other
-  // curves: signed 4-bit windows over a Jacobian table.
+  // curves: odd signed digits over an affine table of the odd multiples.
   ELL_HD static J var_ladder(const u32 (&k)[L], const A& p, VT* tbl, const DigitStore& ds) {
     if constexpr (ENDO) {
       u32 k1[5], k2[5];
@@ -154,10 +155,36 @@ struct Work {
       J r = LD::template run_odd_w4<2, NNIB>(ds, tbl, negmask, evenmask);
       r.Z = F::mul(r.Z, zg);
       return r;
-    } else {
+    } else if constexpr (L > 12) {
+      // p521: measured faster with the plain signed-window ladder over a Jacobian table (the
+      // 16 affine slots hold its 8 Jacobian entries)
+      static_assert(16 * sizeof(A) >= 8 * sizeof(J), "table slot too small");
       u32 negmask = 0;
-      prepare_var(k, p, ds, 0, NSV, tbl, negmask);
-      return LD::template run_w4<NSV, NWIN>(ds, tbl, negmask);
+      prepare_var(k, p, ds, 0, NSV, (J*)tbl, negmask);
+      return LD::template run_w4<NSV, NWIN>(ds, (const J*)tbl, negmask);
+    } else {
+      // no endomorphism: the same odd-digit ladder over the full-width scalar.  The table is
+      // built on the isomorphic curves (additions do not involve a) and mapped back to the
+      // true curve -- whose a = -3 doubling the ladder needs -- by one division-step inversion
+      // of the common factor zg: x = x' zg^-2, y = y' zg^-3.  Mixed additions throughout.
+      u32 kk[L];
+      bn_copy<L>(kk, k);
+      u32 evenmask = (k[0] & 1u) ? 0u : 1u;
+      kk[0] |= 1u;                                  // k even -> k + 1, P subtracted at the end
+      recode_odd_w4<L, NWIN>(kk, ds, 0, 1);
+      El zg;
+      LD::build_table_odd8(tbl, p, zg);
+      El zi = F::inv(zg);
+      El zi2 = F::sqr(zi);
+      El zi3 = F::mul(zi2, zi);
+      ELL_NOUNROLL
+      for (int e = 0; e < 8; e++) {
+        A t = tbl[e];
+        t.x = F::mul(t.x, zi2);
+        t.y = F::mul(t.y, zi3);
+        tbl[e] = t;
+      }
+      return LD::template run_odd_w4<1, NWIN>(ds, tbl, 0u, evenmask);
     }
   }
 
@@ -181,10 +208,10 @@ struct Work {
     load_be<L>(k2, k2s + i * BYTES, BYTES);
     A p1 = load_affine(xy1, i);
     A p2 = load_affine(xy2, i);
-    J* tbl = tbl_all + i * 2 * TBL1;
+    J* tbl = tbl_all + i * 2 * TBLJ;
     u32 negmask = 0;
     prepare_var(k1, p1, ds, 0, 2 * NSV, tbl, negmask);
-    prepare_var(k2, p2, ds, NSV, 2 * NSV, tbl + TBL1, negmask);
+    prepare_var(k2, p2, ds, NSV, 2 * NSV, tbl + TBLJ, negmask);
     J r = LD::template run_w4<2 * NSV, NWIN>(ds, tbl, negmask);
     store_jac(jac, n, i, r);
   }
