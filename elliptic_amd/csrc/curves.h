@@ -29,9 +29,8 @@ struct CvSecp256k1 {
   static constexpr int ID = CURVE_SECP256K1;
 };
 
-// NIST curves (a = -3): FIELD is the base-field arithmetic -- Solinas reduction for p256 /
-// p384, the Mersenne fold for p521, generic Montgomery for p192 / p224; the order field is
-// always Montgomery.
+// NIST curves (a = -3): FIELD is the base-field arithmetic -- the generalised-Mersenne fold for
+// p192 / p224 / p256 / p384, the Mersenne fold for p521; the order field is always Montgomery.
 template <class FIELD, class CN, class CC, int ID_>
 struct CvNist {
   typedef FIELD F;
@@ -42,8 +41,8 @@ struct CvNist {
   static constexpr int ID = ID_;
 };
 
-typedef CvNist<FpMont<consts::P192_P>, consts::P192_N, consts::P192_C, CURVE_P192> CvP192;
-typedef CvNist<FpMont<consts::P224_P>, consts::P224_N, consts::P224_C, CURVE_P224> CvP224;
+typedef CvNist<FpSolinas<SolP192>, consts::P192_N, consts::P192_C, CURVE_P192> CvP192;
+typedef CvNist<FpSolinas<SolP224>, consts::P224_N, consts::P224_C, CURVE_P224> CvP224;
 typedef CvNist<FpSolinas<SolP256>, consts::P256_N, consts::P256_C, CURVE_P256> CvP256;
 typedef CvNist<FpSolinas<SolP384>, consts::P384_N, consts::P384_C, CURVE_P384> CvP384;
 typedef CvNist<FpP521, consts::P521_N, consts::P521_C, CURVE_P521> CvP521;

@@ -854,12 +854,11 @@ struct FpMont {
 };
 
 // --------------------------------------------------------------------------
-// NIST primes with Solinas (generalised-Mersenne) reduction: plain residues, the 2L-word
-// product is folded by the word-level sums of FIPS 186-4 D.2 -- additions only, no
-// multiplies (a Montgomery reduction spends another L^2 multiplies here).
-// R supplies: MP (Montgomery-style constant struct with p, pm2, pp1d4), the term table
-//   NPOS, NNEG, pos[NPOS][L], neg[NNEG][L]  (source word index, -1 = zero word; a vector
-//   listed twice is added twice), and mul_delta(d, out) = d * (2^(32L) - p) for small d.
+// NIST primes of generalised-Mersenne (Solinas) form: plain residues, the 2L-word product is
+// folded with the rule B^L == +-B^j ... that the prime's shape gives (additions only, no
+// multiplies; a Montgomery reduction spends another L^2 multiplies here).
+// R supplies: MP (constant struct with p, pm2, pp1d4, the inversion constants) and the rule
+//   NFOLD, fold_pos[NFOLD] (highest first), fold_sign[NFOLD].
 // --------------------------------------------------------------------------
 template <class R>
 struct FpSolinas {
@@ -911,8 +910,7 @@ struct FpSolinas {
   // One carry propagation brings them back to L words plus a small signed carry, which is
   // folded the same way into the lowest max(pos)+1 words; a ripple beyond those and the final
   // range correction are rare (they need a word equal to 0 / 2^32-1) and share one branch.
-  // Same value as the FIPS 186-4 D.2 word sums (reduce_wide_wordsum, kept for reference and
-  // used by the unit tests as a cross-check), ~45 % fewer carry-class instructions.
+  // Same value as the FIPS 186-4 D.2 word sums, ~45 % fewer carry-class instructions.
   ELL_HD static El reduce_wide(const u32 (&t)[2 * L]) {
     i64 A[2 * L];
     ELL_UNROLL
@@ -970,52 +968,6 @@ struct FpSolinas {
     bn_copy<L>(out.v, r);
     return out;
   }
-  ELL_HD static El reduce_wide_wordsum(const u32 (&t)[2 * L]) {
-    u32 r[L];
-    ELL_UNROLL
-    for (int i = 0; i < L; i++) r[i] = t[i];
-    int top = 0;                                   // value = top * 2^(32L) + r
-    ELL_UNROLL
-    for (int k = 0; k < R::NPOS; k++) {
-      u32 c = 0;
-      ELL_UNROLL
-      for (int i = 0; i < L; i++) {
-        const int w = R::pos[k][i];
-        r[i] = addc32(r[i], w >= 0 ? t[w >= 0 ? w : 0] : 0u, c, c);
-      }
-      top += (int)c;
-    }
-    ELL_UNROLL
-    for (int k = 0; k < R::NNEG; k++) {
-      u32 b = 0;
-      ELL_UNROLL
-      for (int i = 0; i < L; i++) {
-        const int w = R::neg[k][i];
-        r[i] = subb32(r[i], w >= 0 ? t[w >= 0 ? w : 0] : 0u, b, b);
-      }
-      top -= (int)b;
-    }
-    // 2^(32L) == delta (mod p): V' = r + top*delta lies in (-p, 2p)
-    bool negt = top < 0;
-    u32 d = (u32)(negt ? -top : top);
-    u32 dd[L];
-    R::mul_delta(d, dd);
-    u32 mask = negt ? 0xFFFFFFFFu : 0u;
-    u32 c = negt ? 1u : 0u;
-    ELL_UNROLL
-    for (int i = 0; i < L; i++) r[i] = addc32(r[i], dd[i] ^ mask, c, c);
-    // add case: c = overflow beyond 2^(32L);  subtract case: c == 0 means the result is negative
-    u32 p[L]; get_p(p);
-    u32 sm[L], sp[L];
-    u32 bs = bn_sub<L>(sm, r, p);
-    bn_add<L>(sp, r, p);
-    bool is_neg = negt && (c == 0);
-    bool over = (!negt && c != 0) || (bs == 0);
-    El out;
-    ELL_UNROLL
-    for (int i = 0; i < L; i++) out.v[i] = is_neg ? sp[i] : (over ? sm[i] : r[i]);
-    return out;
-  }
   ELL_HD static El mul_inline(const El& a, const El& b) {
     u32 t[2 * L];
     fe_mul_wide<L>(t, a.v, b.v);
@@ -1049,66 +1001,31 @@ struct FpSolinas {
   static ELL_HD_NOINLINE El sqrt(const El& a) { return pow_const_window<FpSolinas<R>, L>(a, MP::pp1d4); }
 };
 
-// p256 = 2^256 - 2^224 + 2^192 + 2^96 - 1  (FIPS 186-4 D.2.3):
-//   r = T + 2 S1 + 2 S2 + S3 + S4 - D1 - D2 - D3 - D4, words listed least significant first
-struct SolP256 {
+// fold rules B^L == sum_f fold_sign[f] * B^fold_pos[f]  (B = 2^32), positions listed highest first;
+// every one of these primes has 2^32 - 1 as its top word (FpSolinas's rare-branch test)
+struct SolP192 {                       // p192 = 2^192 - 2^64 - 1:            B^6 == B^2 + 1
+  typedef consts::P192_P MP;
+  static constexpr int NFOLD = 2;
+  static constexpr int fold_pos[2] = {2, 0};
+  static constexpr int fold_sign[2] = {1, 1};
+};
+struct SolP224 {                       // p224 = 2^224 - 2^96 + 1:            B^7 == B^3 - 1
+  typedef consts::P224_P MP;
+  static constexpr int NFOLD = 2;
+  static constexpr int fold_pos[2] = {3, 0};
+  static constexpr int fold_sign[2] = {1, -1};
+};
+struct SolP256 {                       // p256 = 2^256 - 2^224 + 2^192 + 2^96 - 1:   B^8 == B^7 - B^6 - B^3 + 1
   typedef consts::P256_P MP;
-  static constexpr int NPOS = 6, NNEG = 4;
-  static constexpr signed char pos[6][8] = {
-      {-1, -1, -1, 11, 12, 13, 14, 15},   // S1
-      {-1, -1, -1, 11, 12, 13, 14, 15},   // S1 again
-      {-1, -1, -1, 12, 13, 14, 15, -1},   // S2
-      {-1, -1, -1, 12, 13, 14, 15, -1},   // S2 again
-      {8, 9, 10, -1, -1, -1, 14, 15},     // S3
-      {9, 10, 11, 13, 14, 15, 13, 8},     // S4
-  };
-  static constexpr signed char neg[4][8] = {
-      {11, 12, 13, -1, -1, -1, 8, 10},    // D1
-      {12, 13, 14, 15, -1, -1, 9, 11},    // D2
-      {13, 14, 15, 8, 9, 10, -1, 12},     // D3
-      {14, 15, -1, 9, 10, 11, -1, 13},    // D4
-  };
-  // B^8 == B^7 - B^6 - B^3 + 1
   static constexpr int NFOLD = 4;
   static constexpr int fold_pos[4] = {7, 6, 3, 0};
   static constexpr int fold_sign[4] = {1, -1, -1, 1};
-  // d * (2^224 - 2^192 - 2^96 + 1)
-  ELL_HD static void mul_delta(u32 d, u32 (&o)[8]) {
-    u32 x[8] = {d, 0, 0, 0, 0, 0, 0, d};
-    u32 y[8] = {0, 0, 0, d, 0, 0, d, 0};
-    bn_sub<8>(o, x, y);
-  }
 };
-
-// p384 = 2^384 - 2^128 - 2^96 + 2^32 - 1  (FIPS 186-4 D.2.4):
-//   r = T + 2 S1 + S2 + S3 + S4 + S5 + S6 - D1 - D2 - D3
-struct SolP384 {
+struct SolP384 {                       // p384 = 2^384 - 2^128 - 2^96 + 2^32 - 1:    B^12 == B^4 + B^3 - B + 1
   typedef consts::P384_P MP;
-  static constexpr int NPOS = 7, NNEG = 3;
-  static constexpr signed char pos[7][12] = {
-      {-1, -1, -1, -1, 21, 22, 23, -1, -1, -1, -1, -1},   // S1
-      {-1, -1, -1, -1, 21, 22, 23, -1, -1, -1, -1, -1},   // S1 again
-      {12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23},   // S2
-      {21, 22, 23, 12, 13, 14, 15, 16, 17, 18, 19, 20},   // S3
-      {-1, 23, -1, 20, 12, 13, 14, 15, 16, 17, 18, 19},   // S4
-      {-1, -1, -1, -1, 20, 21, 22, 23, -1, -1, -1, -1},   // S5
-      {20, -1, -1, 21, 22, 23, -1, -1, -1, -1, -1, -1},   // S6
-  };
-  static constexpr signed char neg[3][12] = {
-      {23, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22},   // D1
-      {-1, 20, 21, 22, 23, -1, -1, -1, -1, -1, -1, -1},   // D2
-      {-1, -1, -1, 23, 23, -1, -1, -1, -1, -1, -1, -1},   // D3
-  };
-  // B^12 == B^4 + B^3 - B + 1
   static constexpr int NFOLD = 4;
   static constexpr int fold_pos[4] = {4, 3, 1, 0};
   static constexpr int fold_sign[4] = {1, 1, -1, 1};
-  // d * (2^128 + 2^96 - 2^32 + 1)
-  ELL_HD static void mul_delta(u32 d, u32 (&o)[12]) {
-    u32 x[12] = {d, 0, 0, d, d, 0, 0, 0, 0, 0, 0, 0};
-    u32 y[12] = {0, d, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    bn_sub<12>(o, x, y);
-  }
 };
 
 // --------------------------------------------------------------------------

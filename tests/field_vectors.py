@@ -233,8 +233,10 @@ def shift_vectors():
     return out
 
 
-# ---- FpSolinas (p256 = field 13, p384 = field 14): the lazy-accumulator fold ----------------
+# ---- FpSolinas (p192 / p224 / p256 / p384 = fields 11..14): the lazy-accumulator fold ----------------
 SOL_FIELDS = {
+    11: (2 ** 192 - 2 ** 64 - 1, 6, [(2, 1), (0, 1)]),
+    12: (2 ** 224 - 2 ** 96 + 1, 7, [(3, 1), (0, -1)]),
     13: (2 ** 256 - 2 ** 224 + 2 ** 192 + 2 ** 96 - 1, 8, [(7, 1), (6, -1), (3, -1), (0, 1)]),
     14: (2 ** 384 - 2 ** 128 - 2 ** 96 + 2 ** 32 - 1, 12, [(4, 1), (3, 1), (1, -1), (0, 1)]),
 }
@@ -271,7 +273,7 @@ def solinas_vectors():
     import os
     d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "solinas_rare_operands.json")))
     out = []
-    for field in (13, 14):
+    for field in (11, 12, 13, 14):
         p = SOL_FIELDS[field][0]
         n_c2 = n_top = 0
         for ah, bh in d[str(field)]:

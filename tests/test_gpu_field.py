@@ -105,7 +105,7 @@ def test_rare_branches_gpu(ctx):
 def test_rare_branches_solinas_gpu(ctx):
     import field_vectors
     vecs = field_vectors.solinas_vectors()
-    for field, L in ((13, 8), (14, 12)):
+    for field, L in ((11, 6), (12, 7), (13, 8), (14, 12)):
         for op in (2, 3):
             sel = [v for v in vecs if v[0] == field and v[1] == op]
             A, B = _pack([v[2] for v in sel], L), _pack([v[3] for v in sel], L)
