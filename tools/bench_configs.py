@@ -66,7 +66,7 @@ def main():
         timed("%s fixed-base G*k" % curve, n, lambda: ctx.mul_fixed_dev(curve, dd, pts, inf))
         timed("%s variable-base P*k" % curve, n, lambda: ctx.mul_var_dev(curve, dk, pts, out, inf))
         timed("%s k1*G + k2*P" % curve, n, lambda: ctx.mul_add2_dev(curve, dd, None, dk, pts, out, inf))
-        if curve == "secp256k1":
+        if curve in ("secp256k1", "p192", "p224", "p256", "p384"):
             # ECDSA sign for supplied nonces (hash = k bytes, priv = d, nonce = k ^ d: all < 2^256, a few
             # percent >= n are flagged per item), key decompression of the x coordinates just produced
             NB = elliptic_amd.ORDER_BYTES[curve]
@@ -77,13 +77,20 @@ def main():
             ok = torch.zeros(n, dtype=torch.uint8, device=dev)
             timed("%s ECDSA sign (nonces supplied)" % curve, n,
                   lambda: ctx.ecdsa_sign_dev(curve, dk, dd, nonce, r_o, s_o, rec, ok, canonical=True))
+            good = ok.bool()
+            # ECDSA verify of those signatures against d*G (the bench.py headline is this row for
+            # secp256k1, with its own signature generator)
+            ok2 = torch.zeros(n, dtype=torch.uint8, device=dev)
+            timed("%s ECDSA verify" % curve, n, lambda: ctx.ecdsa_verify_dev(curve, dk, r_o, s_o, pts, ok2))
+            assert bool(ok2[good].bool().all())
+            if curve == "p224":
+                continue                      # no point decompression for p = 1 (mod 4)
             # public-key recovery from those signatures (decompress R, r^-1, s1*G + s2*R): must
             # give back d*G wherever the signing pass accepted the nonce
             q_o = torch.zeros((n, 2 * B), dtype=torch.uint8, device=dev)
             st = torch.zeros(n, dtype=torch.uint8, device=dev)
             timed("%s ECDSA public-key recovery" % curve, n,
                   lambda: ctx.ecdsa_recover_dev(curve, dk, r_o, s_o, rec, q_o, st))
-            good = ok.bool()
             assert bool((st[good] == 0).all()) and torch.equal(q_o[good], pts[good])
             xs = pts[:, :B].contiguous()
             odd = (pts[:, 2 * B - 1] & 1).contiguous()
