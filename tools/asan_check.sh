@@ -19,6 +19,10 @@ for c in ["secp256k1", "p224", "p521", "ed25519"]:
 print("x25519", PC.check_x25519_golden(ctx))
 for c in ["secp256k1", "p384", "p521"]:
     print(c, "verify", PC.check_verify_golden(ctx, c))
+for c in ["secp256k1", "p256", "p521"]:
+    print(c, "sign", PC.check_sign_golden(ctx, c), "recover", PC.check_recover_golden(ctx, c),
+          "decompress", PC.check_decompress_golden(ctx, c))
+print("eddsa verify", PC.check_eddsa_golden(ctx), "sign", PC.check_eddsa_sign_golden(ctx))
 ctx.close()
 print("ASAN/UBSAN run clean")
 PY
