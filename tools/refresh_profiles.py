@@ -16,6 +16,7 @@ MAP = {
     "valu_patterns.log": "valu_patterns.log",
     "configs.jsonl": "configs.jsonl",
     "host_path.jsonl": "host_path.jsonl",
+    "latency.jsonl": "latency.jsonl",
     "bench_under_rocprof.log": "bench_under_rocprof.log",
     "rocprof_stats.txt": "rocprof_kernel_stats.txt",
     "rocprof_fw.txt": "rocprof_pmc_fetch_write.txt",
