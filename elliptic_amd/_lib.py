@@ -35,6 +35,8 @@ _SIGS = {
     "ellgpu_ecdsa_sign_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, c_u8p, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
     "ellgpu_eddsa_verify": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, c_u8p, c_u8p, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p]),
     "ellgpu_eddsa_verify_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, c_u8p, c_u8p, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
+    "ellgpu_ecdsa_sign_det": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "ellgpu_ecdsa_sign_det_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
     "ellgpu_ecdsa_recover": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p]),
     "ellgpu_ecdsa_recover_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
     "ellgpu_eddsa_sign": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, ctypes.c_size_t, c_u8p, c_u8p]),

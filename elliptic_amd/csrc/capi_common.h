@@ -153,6 +153,21 @@ int ellgpu_eddsa_verify_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, cons
                                                 out_ok, out_err));
 }
 
+int ellgpu_ecdsa_sign_det(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                          int msg_bits, const uint8_t* priv, int canonical, uint8_t* out_r, uint8_t* out_s,
+                          uint8_t* out_recid, uint8_t* out_ok) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->ecdsa_sign_det_host(curve, n, hash, hash_len, msg_bits, priv, canonical, out_r,
+                                                   out_s, out_recid, out_ok));
+}
+int ellgpu_ecdsa_sign_det_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                              int msg_bits, const uint8_t* priv, int canonical, uint8_t* out_r,
+                              uint8_t* out_s, uint8_t* out_recid, uint8_t* out_ok, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->ecdsa_sign_det_dev(curve, n, hash, hash_len, msg_bits, priv, canonical, out_r,
+                                                  out_s, out_recid, out_ok));
+}
+
 int ellgpu_ecdsa_recover(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
                          const uint8_t* r, const uint8_t* s, const uint8_t* recid, uint8_t* out_xy,
                          uint8_t* out_status) {

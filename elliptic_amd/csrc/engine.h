@@ -134,6 +134,16 @@ struct FnSignFinish {
   }
 };
 template <class CV>
+struct FnDetNonce {
+  static constexpr const char* NAME = "det_nonce";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* hash; int hash_len; int shift; const u8* priv; u8* nonces;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::det_nonce(i, hash, hash_len, shift, priv, nonces);
+  }
+};
+template <class CV>
 struct FnRecoverPrep {
   static constexpr const char* NAME = "recover_prep";
   typedef Work<CV> W;
@@ -371,6 +381,9 @@ class Engine {
   int sign_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* priv, const u8* nonces,
                  int canonical, u8* out_r, u8* out_s, u8* out_recid, u8* out_ok);
   template <class CV>
+  int sign_det_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* priv, int canonical,
+                     u8* out_r, u8* out_s, u8* out_recid, u8* out_ok);
+  template <class CV>
   int recover_chunk(size_t n, const u8* hash, int hash_len, const u8* r, const u8* s, const u8* recid,
                     u8* out_xy, u8* out_status);
   template <int U = 0>
@@ -565,6 +578,57 @@ class Engine {
     u8* drec = dsg + n * NB;
     u8* dok = drec + n;
     int rc = ecdsa_sign_dev(curve, n, dh, hash_len, msg_bits, dd, dk, canonical, dr, dsg, drec, dok);
+    if (rc) return rc;
+    bk.d2h(out_r, dr, n * NB);
+    bk.d2h(out_s, dsg, n * NB);
+    bk.d2h(out_recid, drec, n);
+    bk.d2h(out_ok, dok, n);
+    return bk.sync();
+  }
+
+  // EC#sign with the reference's own nonce source (HmacDRBG, deterministic): nonces == nullptr
+  // in the calls below means "derive them"
+  int ecdsa_sign_det_dev(int curve, size_t n, const u8* hash, int hash_len, int msg_bits, const u8* priv,
+                         int canonical, u8* out_r, u8* out_s, u8* out_recid, u8* out_ok) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (curve >= CURVE_ED25519)
+      return fail(E_UNSUPPORTED, "ECDSA sign is implemented for the short Weierstrass presets");
+    if (n && (!hash || !priv || !out_r || !out_s || !out_recid || !out_ok)) return fail(E_ARG, "null pointer");
+    if (hash_len <= 0 || msg_bits < 0) return fail(E_ARG, "bad hash_len / msg_bits");
+    int bits = msg_bits ? msg_bits : hash_len * 8;
+    int shift = bits - ci->order_bits;
+    if (shift < 0) shift = 0;
+    int ln = (ci->order_bits + 31) / 32;
+    if (hash_len * 8 - shift > 32 * ln || hash_len - (shift >> 3) > 4 * (ln + 1))
+      return fail(E_ARG, "hash_len / msg_bits combination leaves more bits than the order width");
+    int rc = prepare_curve(curve);
+    if (rc) return rc;
+    const size_t NB = ci->order_bytes;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      ELL_SHORT_DISPATCH(curve, rc = sign_det_chunk<CV>(m, hash + o * hash_len, hash_len, shift, priv + o * NB,
+                                                        canonical, out_r + o * NB, out_s + o * NB,
+                                                        out_recid + o, out_ok + o));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+  int ecdsa_sign_det_host(int curve, size_t n, const u8* hash, int hash_len, int msg_bits, const u8* priv,
+                          int canonical, u8* out_r, u8* out_s, u8* out_recid, u8* out_ok) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (n && (!hash || !priv || !out_r || !out_s || !out_recid || !out_ok)) return fail(E_ARG, "null pointer");
+    if (hash_len <= 0) return fail(E_ARG, "bad hash_len");
+    const size_t NB = ci->order_bytes;
+    u8* dh = put(G_IN0, hash, n * (size_t)hash_len);
+    u8* dd = put(G_IN1, priv, n * NB);
+    u8* dr = out_buf(G_OUT0, n * NB);
+    u8* dsg = out_buf(G_OUT1, n * NB);
+    u8* drec = out_buf(G_IN3, n);
+    u8* dok = out_buf(G_IN4, n);
+    if (!dh || !dd || !dr || !dsg || !drec || !dok) return fail(E_NOMEM, "staging allocation failed");
+    int rc = ecdsa_sign_det_dev(curve, n, dh, hash_len, msg_bits, dd, canonical, dr, dsg, drec, dok);
     if (rc) return rc;
     bk.d2h(out_r, dr, n * NB);
     bk.d2h(out_s, dsg, n * NB);
@@ -1116,6 +1180,18 @@ int Engine<BK>::decompress_chunk(size_t n, const u8* x, const u8* odd, u8* out_x
     return E_OK;
   }
 }
+template <class BK>
+template <class CV>
+int Engine<BK>::sign_det_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* priv,
+                               int canonical, u8* out_r, u8* out_s, u8* out_recid, u8* out_ok) {
+  typedef Work<CV> W;
+  u8* nonces = (u8*)scratch(S_TBL, n * W::NBYTES);        // the sign pipeline uses S_JAC / S_U12 / S_PRE
+  if (!nonces) return fail(E_NOMEM, "scratch allocation failed");
+  FnDetNonce<CV> f{n, hash, hash_len, shift, priv, nonces};
+  bk.launch(f, n);
+  return sign_chunk<CV>(n, hash, hash_len, shift, priv, nonces, canonical, out_r, out_s, out_recid, out_ok);
+}
+
 template <class BK>
 template <class CV>
 int Engine<BK>::recover_chunk(size_t n, const u8* hash, int hash_len, const u8* r, const u8* s,

@@ -32,7 +32,9 @@ namespace ell {
   KW template int Engine<HipBackend>::sign_chunk<CV>(size_t, const u8*, int, int, const u8*,       \
                                                      const u8*, int, u8*, u8*, u8*, u8*);           \
   KW template int Engine<HipBackend>::recover_chunk<CV>(size_t, const u8*, int, const u8*,         \
-                                                        const u8*, const u8*, u8*, u8*);
+                                                        const u8*, const u8*, u8*, u8*);           \
+  KW template int Engine<HipBackend>::sign_det_chunk<CV>(size_t, const u8*, int, int, const u8*,   \
+                                                         int, u8*, u8*, u8*, u8*);
 #define ELL_DECL_ED2(KW) \
   KW template int Engine<HipBackend>::ed_decompress_chunk<0>(size_t, const u8*, const u8*, u8*, u8*);
 #define ELL_DECL_ED3(KW)                                                                          \

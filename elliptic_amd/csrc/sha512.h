@@ -1,14 +1,18 @@
-// ellgpu -- SHA-512 of a three-part message (R || A || M) per lane, for EdDSA's
-// hashInt (lib/elliptic/eddsa/index.js:65-70; hash.js sha512 is FIPS 180-4).
-// Hashing is ~1 % of an EdDSA verification, so this is a plain byte-wise implementation:
-// one lane = one message, blocks assembled from byte loads.
+// ellgpu -- SHA-512 / SHA-384 of a three-part message per lane: EdDSA's hashInt
+// (lib/elliptic/eddsa/index.js:65-70) and the HMAC-DRBG of EC#sign on p384 / p521
+// (hash.js sha512 / sha384 are FIPS 180-4).  Hashing is ~1 % of an EdDSA verification, so this
+// is a plain byte-wise implementation: one lane = one message, blocks assembled from byte loads.
 #pragma once
 
 #include "common.h"
 
 namespace ell {
 
-struct Sha512 {
+// OUT = 64: SHA-512; OUT = 48: SHA-384 (other initial state, truncated output)
+template <int OUT_>
+struct Sha2Wide {
+  static constexpr int OUT = OUT_;
+  static constexpr int BLOCK = 128;
   ELL_HD static u64 K(int i) {
     const u64 k[80] = {
         0x428a2f98d728ae22ULL, 0x7137449123ef65cdULL, 0xb5c0fbcfec4d3b2fULL, 0xe9b5dba58189dbbcULL,
@@ -49,12 +53,23 @@ struct Sha512 {
     return 0u;
   }
 
-  // digest[0..64) = SHA-512(p0 || p1 || p2)
-  ELL_HD static void hash3(u8 (&digest)[64], const u8* p0, u64 l0, const u8* p1, u64 l1,
+  // digest[0..OUT) = SHA-512 / SHA-384 (p0 || p1 || p2)
+  ELL_HD static void hash3(u8 (&digest)[OUT], const u8* p0, u64 l0, const u8* p1, u64 l1,
                            const u8* p2, u64 l2) {
-    u64 h[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
-                0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL,
-                0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+    u64 h[8];
+    if (OUT == 64) {
+      const u64 iv[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
+                         0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL,
+                         0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+      ELL_UNROLL
+      for (int i = 0; i < 8; i++) h[i] = iv[i];
+    } else {
+      const u64 iv[8] = {0xcbbb9d5dc1059ed8ULL, 0x629a292a367cd507ULL, 0x9159015a3070dd17ULL,
+                         0x152fecd8f70e5939ULL, 0x67332667ffc00b31ULL, 0x8eb44a8768581511ULL,
+                         0xdb0c2e0d64f98fa7ULL, 0x47b5481dbefa4fa4ULL};
+      ELL_UNROLL
+      for (int i = 0; i < 8; i++) h[i] = iv[i];
+    }
     const u64 total = l0 + l1 + l2;
     const u64 padded = ((total + 1 + 16 + 127) / 128) * 128;
     ELL_NOUNROLL
@@ -95,10 +110,12 @@ struct Sha512 {
       h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
     }
     ELL_UNROLL
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < OUT / 8; i++)
       ELL_UNROLL
       for (int b = 0; b < 8; b++) digest[8 * i + b] = (u8)(h[i] >> (56 - 8 * b));
   }
 };
+typedef Sha2Wide<64> Sha512;
+typedef Sha2Wide<48> Sha384;
 
 }  // namespace ell

@@ -16,6 +16,10 @@
 #include <type_traits>
 
 #include "ladder.h"
+#include "hmac_drbg.h"
+#include "hmac_drbg256.h"
+#include "sha256.h"
+#include "sha512.h"
 
 // comb window width for the 256-bit curves (the CPU unit-test build of these headers
 // overrides it with 8 so that it does not have to generate 2^20-entry tables on the host)
@@ -487,6 +491,65 @@ struct Work {
     if (st != RECOVER_POINT) {
       ELL_NOUNROLL
       for (int b = 0; b < 2 * BYTES; b++) out_xy[i * 2 * BYTES + b] = 0;
+    }
+  }
+
+  // ---- EC#sign's own nonces (ec/index.js:136-158): HmacDRBG over the curve's hash
+  // (curves.js `hash:`), entropy = the private key, nonce = the truncated message, both
+  // n.byteLength() bytes; drbg.generate(n.byteLength()) is repeated while the candidate,
+  // truncated like a digest (_truncateToN(k, true)), is <= 1 or >= n - 1.  Writes the accepted
+  // candidate bytes (what the supplied-nonce pipeline below takes), zeros if none was accepted
+  // within 16 draws (never in practice; the item is then reported as not signed).
+  typedef typename std::conditional<CV::ID == CURVE_P384, Sha384,
+          typename std::conditional<CV::ID == CURVE_P521, Sha512, Sha256>::type>::type SignHash;
+  ELL_HD static void det_nonce(size_t i, const u8* hash, int hash_len, int shift, const u8* priv,
+                               u8* nonce_out) {
+    u32 e[LN], nn[LN], nm1[LN], one1[LN];
+    load_hash(e, hash + i * (size_t)hash_len, hash_len, shift);
+    ELL_UNROLL
+    for (int l = 0; l < LN; l++) { nn[l] = C::n[l]; one1[l] = l == 0 ? 1u : 0u; }
+    bn_sub<LN>(nm1, nn, one1);
+    {
+      u32 t[LN];
+      u32 br = bn_sub<LN>(t, e, nn);               // msg >= n -> msg - n (:106-107)
+      bn_select<LN>(e, br == 0, t, e);
+    }
+    if constexpr (std::is_same<SignHash, Sha256>::value && NBYTES % 4 == 0 && NBYTES <= 32) {
+      // word-oriented generator: n.byteLength() is a whole number of words, one V per draw
+      constexpr int NW = NBYTES / 4;
+      u32 d[LN], seed[2 * NW];
+      load_be<LN>(d, priv + i * NBYTES, NBYTES);
+      ELL_UNROLL
+      for (int w = 0; w < NW; w++) { seed[w] = d[NW - 1 - w]; seed[NW + w] = e[NW - 1 - w]; }
+      HmacDrbg256<2 * NW> g;
+      g.init(seed);
+      u32 v[8], k[LN];
+      bool done = false;
+      ELL_NOUNROLL
+      for (int it = 0; it < 16 && !done; it++) {
+        g.generate(v);
+        ELL_UNROLL
+        for (int w = 0; w < LN; w++) k[w] = w < NW ? v[NW - 1 - w] : 0u;      // no shift: 8 NBYTES == bit length of n
+        done = !bn_is_zero<LN>(k) && !bn_eq<LN>(k, one1) && !bn_geq<LN>(k, nm1);
+      }
+      ELL_UNROLL
+      for (int w = 0; w < LN; w++) k[w] = done ? k[w] : 0u;
+      store_be<LN>(nonce_out + i * NBYTES, k, NBYTES);
+    } else {
+      u8 eb[NBYTES], kb[NBYTES];
+      store_be<LN>(eb, e, NBYTES);
+      HmacDrbg<SignHash> g;
+      g.init(priv + i * NBYTES, NBYTES, eb, NBYTES);
+      bool done = false;
+      ELL_NOUNROLL
+      for (int it = 0; it < 16 && !done; it++) {
+        g.generate(kb, NBYTES);
+        u32 k[LN];
+        load_nonce(k, kb);
+        done = !bn_is_zero<LN>(k) && !bn_eq<LN>(k, one1) && !bn_geq<LN>(k, nm1);
+      }
+      ELL_NOUNROLL
+      for (int b = 0; b < NBYTES; b++) nonce_out[i * NBYTES + b] = done ? kb[b] : (u8)0;
     }
   }
 

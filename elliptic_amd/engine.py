@@ -208,6 +208,29 @@ class Context:
                                                   err.ctypes.data))
         return ok, err
 
+    def ecdsa_sign_det(self, curve, hashes, priv, canonical=False, msg_bits=0):
+        """EC#sign with the reference's own (HmacDRBG, deterministic) nonces -> (r, s, recid, ok)"""
+        NB = ORDER_BYTES[curve]
+        hashes = _u8(hashes)
+        n, hash_len = hashes.shape
+        priv = _u8(priv, (n, NB))
+        r = np.zeros((n, NB), np.uint8)
+        s = np.zeros((n, NB), np.uint8)
+        rec = np.zeros(n, np.uint8)
+        ok = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_ecdsa_sign_det(self._ctx, self._cid(curve), n, hashes.ctypes.data, hash_len,
+                                                    int(msg_bits), priv.ctypes.data, 1 if canonical else 0,
+                                                    r.ctypes.data, s.ctypes.data, rec.ctypes.data, ok.ctypes.data))
+        return r, s, rec, ok
+
+    def ecdsa_sign_det_dev(self, curve, hashes, priv, out_r, out_s, out_recid, out_ok, canonical=False,
+                           msg_bits=0):
+        n, hash_len = hashes.shape
+        self._check(self._lib.ellgpu_ecdsa_sign_det_dev(self._ctx, self._cid(curve), n, hashes.data_ptr(), hash_len,
+                                                        int(msg_bits), priv.data_ptr(), 1 if canonical else 0,
+                                                        out_r.data_ptr(), out_s.data_ptr(), out_recid.data_ptr(),
+                                                        out_ok.data_ptr(), self._stream()))
+
     def ecdsa_recover(self, curve, hashes, r, s, recid):
         """EC#recoverPubKey per item -> (xy (n, 2B), status (n,)): 0 point, 1 infinity,
         2 the reference throws, 3 outside the engine's domain (r = 0 or r >= n)"""

@@ -24,6 +24,7 @@
  *           eddsaVerify(ctx, msgs, offsets|null, msgLen, sigs, pubs) -> {ok, err}
  *           eddsaSign(ctx, msgs, offsets|null, msgLen, secrets) -> {sig, pub}
  *           ecdsaRecover(ctx, curve, hash, hashLen, r, s, recid) -> {xy, status}
+ *           ecdsaSignDet(ctx, curve, hash, hashLen, msgBits, priv, canonical) -> {r, s, recid, ok}
  *             offsets: Buffer of n+1 little-endian uint64 byte offsets into msgs
  *           callAsync(op, ctx, curve, hashLen, msgBits, b0, b1, b2, b3) -> Promise
  *             op 0 mulFixed(b0=k) 1 mulVar(k, xy) 2 mulAdd2(k1, p1|null, k2, p2)
@@ -67,6 +68,8 @@ static struct {
                     uint8_t*, uint8_t*);
   int (*ecdsa_recover)(ellgpu_ctx*, int, size_t, const uint8_t*, int, const uint8_t*, const uint8_t*,
                        const uint8_t*, uint8_t*, uint8_t*);
+  int (*ecdsa_sign_det)(ellgpu_ctx*, int, size_t, const uint8_t*, int, int, const uint8_t*, int,
+                        uint8_t*, uint8_t*, uint8_t*, uint8_t*);
 } L;
 
 #define THROW(env, msg) do { napi_throw_error((env), NULL, (msg)); return NULL; } while (0)
@@ -101,6 +104,7 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   SYM(eddsa_verify, "ellgpu_eddsa_verify");
   SYM(eddsa_sign, "ellgpu_eddsa_sign");
   SYM(ecdsa_recover, "ellgpu_ecdsa_recover");
+  SYM(ecdsa_sign_det, "ellgpu_ecdsa_sign_det");
   SYM(ecdsa_sign, "ellgpu_ecdsa_sign");
   L.h = h;
   napi_value t; CHECK(env, napi_get_boolean(env, 1, &t));
@@ -272,6 +276,38 @@ static napi_value fn_sign(napi_env env, napi_callback_info info) {
   CHECK(env, napi_create_buffer(env, n, &drec, &brec));
   CHECK(env, napi_create_buffer(env, n, &dok, &bok));
   if (L.ecdsa_sign(c, curve, n, h, hl, mb, d, k, canon ? 1 : 0, (uint8_t*)dr, (uint8_t*)dsg, (uint8_t*)drec, (uint8_t*)dok) != 0)
+    return lib_error(env);
+  CHECK(env, napi_create_object(env, &o));
+  CHECK(env, napi_set_named_property(env, o, "r", br));
+  CHECK(env, napi_set_named_property(env, o, "s", bs));
+  CHECK(env, napi_set_named_property(env, o, "recid", brec));
+  CHECK(env, napi_set_named_property(env, o, "ok", bok));
+  return o;
+}
+
+/* ecdsaSignDet(ctx, curve, hash, hashLen, msgBits, priv, canonical) -> {r, s, recid, ok} */
+static napi_value fn_sign_det(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 7; napi_value argv[7];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  int32_t curve, hl, mb; bool canon = 0;
+  if (napi_get_value_int32(env, argv[1], &curve) != napi_ok || napi_get_value_int32(env, argv[3], &hl) != napi_ok ||
+      napi_get_value_int32(env, argv[4], &mb) != napi_ok) THROW(env, "ecdsaSignDet(ctx, curve, hash, hashLen, msgBits, priv, canonical)");
+  napi_get_value_bool(env, argv[6], &canon);
+  int NB = L.order_bytes(curve);
+  if (NB <= 0 || hl <= 0) THROW(env, "bad curve / hashLen");
+  const uint8_t *h, *d; size_t lh, ld;
+  if (!get_buf(env, argv[2], &h, &lh, 0) || !get_buf(env, argv[5], &d, &ld, 0)) return NULL;
+  if (lh % (size_t)hl) THROW(env, "hash buffer length is not a multiple of hashLen");
+  size_t n = lh / (size_t)hl;
+  if (ld != n * (size_t)NB) THROW(env, "buffer length mismatch");
+  napi_value br, bs, brec, bok, o; void *dr, *dsg, *drec, *dok;
+  CHECK(env, napi_create_buffer(env, n * (size_t)NB, &dr, &br));
+  CHECK(env, napi_create_buffer(env, n * (size_t)NB, &dsg, &bs));
+  CHECK(env, napi_create_buffer(env, n, &drec, &brec));
+  CHECK(env, napi_create_buffer(env, n, &dok, &bok));
+  if (L.ecdsa_sign_det(c, curve, n, h, hl, mb, d, canon ? 1 : 0, (uint8_t*)dr, (uint8_t*)dsg, (uint8_t*)drec, (uint8_t*)dok) != 0)
     return lib_error(env);
   CHECK(env, napi_create_object(env, &o));
   CHECK(env, napi_set_named_property(env, o, "r", br));
@@ -465,7 +501,7 @@ static napi_value init(napi_env env, napi_value exports) {
     {"deviceCount", fn_device_count}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
     {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519},
     {"callAsync", fn_call_async}, {"decompress", fn_decompress},
-    {"eddsaVerify", fn_eddsa_verify}, {"eddsaSign", fn_eddsa_sign}, {"ecdsaSign", fn_sign}, {"ecdsaRecover", fn_recover},
+    {"eddsaVerify", fn_eddsa_verify}, {"eddsaSign", fn_eddsa_sign}, {"ecdsaSign", fn_sign}, {"ecdsaRecover", fn_recover}, {"ecdsaSignDet", fn_sign_det},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

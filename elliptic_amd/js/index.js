@@ -93,6 +93,14 @@ Engine.prototype.ecdsaSignBatch = function ecdsaSignBatch(curve, o) {
     !!o.canonical);
 };
 
+// EC#sign with the reference's own deterministic nonces (HmacDRBG; ec/index.js:110-186).
+// o = { hashes, hashLen, msgBits, priv: Buffer(n x NB), canonical } -> { r, s, recid, ok }
+Engine.prototype.ecdsaSignDetBatch = function ecdsaSignDetBatch(curve, o) {
+  var id = this._id(curve);
+  this.stats.gpuCalls++; this.stats.gpuItems += o.hashes.length / o.hashLen;
+  return this.addon.ecdsaSignDet(this.ctx, id, o.hashes, o.hashLen, o.msgBits | 0, o.priv, !!o.canonical);
+};
+
 // EC#recoverPubKey per item (ec/index.js:231-259).  o = { hashes, hashLen, r, s: Buffer(n x NB),
 // recid: Buffer(n) } -> { xy: Buffer(n x 2B), status: Buffer(n) }  (0 point, 1 infinity,
 // 2 the reference throws, 3 outside the engine's domain: r = 0 or r >= n)
@@ -317,6 +325,37 @@ function install(elliptic, options) {
   // [1, n), digests longer than twice the order, non-byte messages) and every case where the
   // reference throws is run by the reference's own method, so results and exceptions are its own.
   var ecProto = elliptic.ec.prototype;
+  // EC#sign (ec/index.js:110-186) with its default nonce source: the HmacDRBG draws, k*G, and
+  // s = k^-1 (z + r d) in one call.  Byte-array digests only (the reference also takes hex
+  // strings, numbers and BNs with their own length rules -- those, options.k / options.pers,
+  // and anything the engine refuses go to the reference).
+  var SigCtor = null;
+  orig.sign = ecProto.sign;
+  ecProto.sign = function sign(msg, key, enc, options) {
+    if (typeof enc === 'object') { options = enc; enc = null; }
+    if (!options) options = {};
+    var d = domain(this.curve);
+    var res = null;
+    try {
+      if (!d || options.k || options.pers !== undefined || typeof msg !== 'object' || BN.isBN(msg) ||
+          !msg || typeof msg.length !== 'number' || msg.length === 0) throw null;
+      // new EC({ curve, hash }) may carry another DRBG hash than the preset's (ec/index.js:31)
+      if (this.hash !== elliptic.curves[d.name].hash) throw null;
+      for (var i = 0; i < msg.length; i++) if ((msg[i] & 255) !== msg[i]) throw null;
+      var priv = this.keyFromPrivate(key, enc).getPrivate();
+      var NB = this.n.byteLength();
+      if (priv.isNeg() || priv.byteLength() > NB) throw null;
+      res = eng.ecdsaSignDetBatch(d.id, { hashes: Buffer.from(msg), hashLen: msg.length,
+        msgBits: typeof options.msgBitLength === 'number' ? options.msgBitLength : 0,
+        priv: Buffer.from(priv.toArray('be', NB)), canonical: !!options.canonical });
+      if (!res.ok[0]) throw null;
+    } catch (e) {
+      eng.stats.passthrough++;
+      return orig.sign.apply(this, arguments);
+    }
+    if (!SigCtor) SigCtor = orig.sign.call(new elliptic.ec('p192'), [ 1 ], '01', 'hex').constructor;
+    return new SigCtor({ r: new BN(res.r), s: new BN(res.s), recoveryParam: res.recid[0] });
+  };
   orig.recoverPubKey = ecProto.recoverPubKey;
   ecProto.recoverPubKey = function recoverPubKey(msg, signature, j, enc) {
     var d = domain(this.curve);
@@ -411,6 +450,7 @@ function install(elliptic, options) {
     eddsaProto.verify = orig.eddsaVerify;
     eddsaProto.sign = orig.eddsaSign;
     ecProto.recoverPubKey = orig.recoverPubKey;
+    ecProto.sign = orig.sign;
     edw.pointFromY = orig.pointFromY;
   };
 

@@ -107,6 +107,17 @@ function check(r, i, B, want, what) {
     checked++;
   });
 })();
+['secp256k1', 'p256', 'p384', 'p521'].forEach(function(name) {
+  var cs = JSON.parse(fs.readFileSync(path.join(GOLD, 'signdet_' + name + '.json')));
+  var NB = cs[0].d.length / 2;
+  cs.forEach(function(c) {
+    var r = eng.ecdsaSignDetBatch(name, { hashes: Buffer.from(c.z, 'hex'), hashLen: c.z.length / 2,
+      priv: hexBuf([c.d], NB), canonical: c.canonical });
+    if (!r.ok[0] || r.r.toString('hex') !== c.r || r.s.toString('hex') !== c.s || r.recid[0] !== c.recid)
+      throw new Error('deterministic sign mismatch: ' + name + ' ' + c.note);
+    checked++;
+  });
+});
 ['secp256k1', 'p256', 'p384'].forEach(function(name) {
   var cs = JSON.parse(fs.readFileSync(path.join(GOLD, 'recover_' + name + '.json')));
   var NB = cs[0].r.length / 2;

@@ -161,6 +161,21 @@ int ellgpu_eddsa_verify_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, cons
                             size_t msg_len, const uint8_t* sigs, const uint8_t* pubs,
                             uint8_t* out_ok, uint8_t* out_err, void* stream);
 
+/* EC#sign with its own nonces -- deterministic signatures, lib/elliptic/ec/index.js:110-186:
+ * HmacDRBG (hmac-drbg 1.0.1) over the curve's hash (SHA-256; SHA-384 for p384, SHA-512 for p521;
+ * lib/elliptic/curves.js `hash:`), entropy = the private key, nonce = the truncated message,
+ * candidates drawn until one is accepted (:151-158); no personalisation string (options.pers).
+ * Arguments and outputs as ellgpu_ecdsa_sign without `nonces`; priv must be the
+ * n.byteLength()-byte big-endian encoding the reference feeds to the DRBG.  out_ok[i] = 0 only
+ * in the (never observed) case that the reference would go on to a further candidate because
+ * r or s came out zero. */
+int ellgpu_ecdsa_sign_det(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                          int msg_bits, const uint8_t* priv, int canonical, uint8_t* out_r, uint8_t* out_s,
+                          uint8_t* out_recid, uint8_t* out_ok);
+int ellgpu_ecdsa_sign_det_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                              int msg_bits, const uint8_t* priv, int canonical, uint8_t* out_r,
+                              uint8_t* out_s, uint8_t* out_recid, uint8_t* out_ok, void* stream);
+
 /* ECDSA public-key recovery: out_xy[i] = EC#recoverPubKey(hash_i, {r_i, s_i}, recid_i),
  * lib/elliptic/ec/index.js:231-259 -- Q = r^-1 (s R - e G) with R = pointFromX(r + (j >> 1) n,
  * j & 1) (short.js:187-204) and e = new BN(hash) (NOT truncated by that method, only reduced

@@ -620,6 +620,60 @@ def ecdsa_verify(curve: ShortCurve, msg: int, msg_bytes: int, r: int, s: int,
     return curve.j_eq_x_to_p(jp, r)
 
 
+CURVE_HASH = {"secp256k1": "sha256", "p192": "sha256", "p224": "sha256", "p256": "sha256",
+              "p384": "sha384", "p521": "sha512"}        # lib/elliptic/curves.js: `hash:` of each preset
+
+
+class HmacDrbg:
+    """hmac-drbg 1.0.1 lib/hmac-drbg.js (the reference's dependency, pinned in
+    package-lock.json): HMAC_DRBG of NIST SP 800-90A without prediction resistance, as
+    EC#sign instantiates it (entropy = private key, nonce = truncated message, no
+    personalisation string)."""
+
+    def __init__(self, hash_name: str, entropy: bytes, nonce: bytes):
+        import hashlib
+        import hmac
+        self._new = lambda key: hmac.new(key, digestmod=getattr(hashlib, hash_name))
+        out = getattr(hashlib, hash_name)().digest_size
+        self.K = b"\x00" * out                     # _init :37-48
+        self.V = b"\x01" * out
+        self._update(entropy + nonce)
+
+    def _hmac(self, *parts) -> bytes:
+        h = self._new(self.K)
+        for p in parts:
+            h.update(p)
+        return h.digest()
+
+    def _update(self, seed: bytes = b""):            # :54-69
+        self.K = self._hmac(self.V, b"\x00", seed)
+        self.V = self._hmac(self.V)
+        if not seed:
+            return
+        self.K = self._hmac(self.V, b"\x01", seed)
+        self.V = self._hmac(self.V)
+
+    def generate(self, n: int) -> bytes:             # :91-113
+        temp = b""
+        while len(temp) < n:
+            self.V = self._hmac(self.V)
+            temp += self.V
+        self._update()
+        return temp[:n]
+
+
+def ecdsa_sign_det(curve: ShortCurve, name: str, msg: int, msg_bytes: int, d: int, canonical=False):
+    """ec/index.js:110-186 EC#sign with its own nonce source: the loop over
+    drbg.generate(n.byteLength()) until a nonce is accepted.  -> (r, s, recoveryParam)"""
+    nb = (curve.n.bit_length() + 7) // 8
+    e = truncate_to_n(curve, msg, msg_bytes, False)
+    drbg = HmacDrbg(CURVE_HASH[name], d.to_bytes(nb, "big"), e.to_bytes(nb, "big"))
+    while True:
+        res = ecdsa_sign(curve, msg, msg_bytes, d, drbg.generate(nb), canonical)
+        if res is not None:
+            return res
+
+
 def ecdsa_recover(curve: ShortCurve, e: int, r: int, s: int, j: int) -> ShortPoint:
     """ec/index.js:231-259 EC#recoverPubKey: Q = r^-1 (s R - e G), R = the point with
     x = r (+ n when j & 2) and y-parity j & 1.  e = new BN(msg) is used as it is (no

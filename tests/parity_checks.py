@@ -150,6 +150,25 @@ def check_eddsa_golden(ctx):
     return len(cases)
 
 
+def check_signdet_golden(ctx, curve):
+    """EC#sign with the reference's own HmacDRBG nonces: (z, d, canonical) -> (r, s, recoveryParam)"""
+    from golden_util import load
+    NB = ORDER_BYTES[curve]
+    groups = {}
+    for c in load("signdet_%s.json" % curve):
+        groups.setdefault((len(c["z"]) // 2, c["canonical"]), []).append(c)
+    total = 0
+    for (zlen, canonical), cs in sorted(groups.items()):
+        z = np.frombuffer(b"".join(bytes.fromhex(c["z"]) for c in cs), np.uint8).reshape(-1, zlen)
+        d = np.frombuffer(b"".join(bytes.fromhex(c["d"]) for c in cs), np.uint8).reshape(-1, NB)
+        r, s, rec, ok = ctx.ecdsa_sign_det(curve, z, d, canonical=canonical)
+        for i, c in enumerate(cs):
+            assert ok[i] == 1, c["note"]
+            assert (r[i].tobytes().hex(), s[i].tobytes().hex(), int(rec[i])) == (c["r"], c["s"], c["recid"]), c["note"]
+            total += 1
+    return total
+
+
 def check_recover_golden(ctx, curve):
     """EC#recoverPubKey goldens: points, infinity, and status 2 exactly where the reference
     throws ('invalid point' / 'Unable to find sencond key candinate')"""

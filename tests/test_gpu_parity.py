@@ -58,6 +58,11 @@ def test_decompress_roundtrip_full_size(ctx):
     assert np.array_equal(ctx.ecdsa_verify("secp256k1", h, r, s, out), expect)
 
 
+@pytest.mark.parametrize("curve", O.SHORT_CURVES)
+def test_sign_deterministic_golden(ctx, curve):
+    assert PC.check_signdet_golden(ctx, curve) >= 10
+
+
 @pytest.mark.parametrize("curve", ["secp256k1", "p192", "p256", "p384", "p521"])
 def test_recover_golden(ctx, curve):
     assert PC.check_recover_golden(ctx, curve) >= 30

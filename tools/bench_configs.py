@@ -77,6 +77,11 @@ def main():
             ok = torch.zeros(n, dtype=torch.uint8, device=dev)
             timed("%s ECDSA sign (nonces supplied)" % curve, n,
                   lambda: ctx.ecdsa_sign_dev(curve, dk, dd, nonce, r_o, s_o, rec, ok, canonical=True))
+            ok_d = torch.zeros(n, dtype=torch.uint8, device=dev)
+            timed("%s ECDSA sign (deterministic nonces, HMAC-DRBG on the device)" % curve, n,
+                  lambda: ctx.ecdsa_sign_det_dev(curve, dk, dd, r_o, s_o, rec, ok_d, canonical=True))
+            assert bool(ok_d.all())
+            ok.copy_(ok_d)
             good = ok.bool()
             # ECDSA verify of those signatures against d*G (the bench.py headline is this row for
             # secp256k1, with its own signature generator)

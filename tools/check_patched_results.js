@@ -37,6 +37,20 @@ function expectThrow(fn, msg, what) {
   });
 });
 
+['secp256k1', 'p192', 'p224', 'p256', 'p384', 'p521'].forEach(function(name) {
+  var ec = new elliptic.ec(name);
+  var NB = ec.n.byteLength();
+  load('signdet_' + name + '.json').forEach(function(c) {
+    var sig = ec.sign(Buffer.from(c.z, 'hex').toJSON().data, c.d, 'hex', { canonical: c.canonical });
+    if (sig.r.toString(16, 2 * NB) !== c.r || sig.s.toString(16, 2 * NB) !== c.s || sig.recoveryParam !== c.recid)
+      throw new Error('sign mismatch: ' + name + ' ' + c.note);
+    // the result must behave like the reference's Signature (DER round trip, verify)
+    if (!ec.verify(Buffer.from(c.z, 'hex').toJSON().data, sig.toDER('hex'), ec.keyFromPrivate(c.d, 'hex')))
+      throw new Error('signature does not verify: ' + name + ' ' + c.note);
+    checked++;
+  });
+});
+
 var ed = new elliptic.eddsa('ed25519');
 load('eddsa_sign_ed25519.json').forEach(function(c) {
   var msg = c.msg.length ? Buffer.from(c.msg, 'hex').toJSON().data : [];

@@ -406,6 +406,37 @@ function genEddsa() {
   return cases;
 }
 
+// ------------------------------------------------------------ signdet_<curve>.json
+// EC#sign (ec/index.js:110-186) with its own nonces: HmacDRBG (hmac-drbg 1.0.1) over the
+// curve's hash, entropy = the private key, nonce = the truncated message, both n.byteLength()
+// bytes -- i.e. deterministic signatures.  (z, d, canonical) -> (r, s, recoveryParam).
+function genSignDet(name) {
+  var pc = elliptic.curves[name];
+  var ec = new elliptic.ec(pc);
+  var c = pc.curve;
+  var NB = c.n.byteLength();
+  var rng = new Prng('ellgpu-golden-v1:signdet:' + name);
+  var cases = [];
+  function one(z, d, canonical, note) {
+    var sig = ec.sign(z, ec.keyFromPrivate(hex(d, NB), 'hex'), { canonical: canonical });
+    cases.push({ z: Buffer.from(z).toString('hex'), d: hex(d, NB), canonical: canonical,
+      r: hex(sig.r, NB), s: hex(sig.s, NB), recid: sig.recoveryParam, note: note });
+  }
+  var N = Math.ceil(COUNTS[name] / 2);
+  for (var i = 0; i < N; i++) {
+    var zlen = [32, NB, 20, 48, 64, 32][i % 6];
+    one(rng.bytes(zlen), rng.below(c.n.subn(1)).addn(1), (i & 1) === 1, 'seeded, ' + zlen + '-byte digest');
+  }
+  var d0 = rng.below(c.n.subn(1)).addn(1);
+  one(Buffer.alloc(32), d0, true, 'digest 0');
+  one(Buffer.alloc(NB, 0xff), d0, false, 'digest ff..ff');
+  one(Buffer.from(c.n.toArray('be', NB)), d0, true, 'digest = n');
+  one(Buffer.from(c.n.subn(1).toArray('be', NB)), d0, false, 'digest = n - 1');
+  one(rng.bytes(32), new BN(1), true, 'd = 1');
+  one(rng.bytes(32), c.n.subn(1), false, 'd = n - 1');
+  return cases;
+}
+
 // ------------------------------------------------------------ recover_<curve>.json
 // EC#recoverPubKey (ec/index.js:231-259): (e, r, s, j) -> Q = r^-1 (s R - e G) with R the point
 // of x-coordinate r (+ n when j & 2) and y-parity j & 1.  Real signatures with all four j,
@@ -674,6 +705,7 @@ SHORT.forEach(function(name) {
   write('verify_' + name + '.json', genVerify(name));
   write('sign_' + name + '.json', genSign(name));
   write('recover_' + name + '.json', genRecover(name));
+  write('signdet_' + name + '.json', genSignDet(name));
 });
 ['secp256k1', 'p192', 'p256', 'p384', 'p521', 'ed25519'].forEach(function(name) {
   write('decompress_' + name + '.json', genDecompress(name));
