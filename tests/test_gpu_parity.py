@@ -279,3 +279,24 @@ def test_full_size_group_properties(ctx):
     sums = [(x + y) % N for x, y in zip(be_to_ints(a[:m]), be_to_ints(b[:m]))]
     S2, _ = ctx.mul_fixed("secp256k1", ints_to_be(sums, 32))
     assert np.array_equal(S, S2)
+
+
+def test_chunk_boundary(ctx):
+    """batches larger than the engine's 2^21-item launch chunk: the items either side of the
+    cut must equal what separate calls give (fixed base, variable base and verify)"""
+    n = (1 << 21) + 777
+    raw = np.frombuffer(hashlib.shake_256(b"gpu-chunk").digest(n * 32), dtype=np.uint8).reshape(n, 32)
+    xy, inf = ctx.mul_fixed("secp256k1", raw)
+    lo, hi = (1 << 21) - 300, (1 << 21) + 300
+    xy2, inf2 = ctx.mul_fixed("secp256k1", raw[lo:hi])
+    assert np.array_equal(xy[lo:hi], xy2) and np.array_equal(inf[lo:hi], inf2)
+    xy3, inf3 = ctx.mul_fixed("secp256k1", raw[-50:])
+    assert np.array_equal(xy[-50:], xy3) and not inf.any()
+    k = np.roll(raw, 1, axis=0)
+    out, oinf = ctx.mul_var("secp256k1", k, xy)
+    out2, oinf2 = ctx.mul_var("secp256k1", k[lo:hi], xy[lo:hi])
+    assert np.array_equal(out[lo:hi], out2) and np.array_equal(oinf[lo:hi], oinf2)
+    cur = O.get_curve("secp256k1")
+    for i in (0, (1 << 21) - 1, 1 << 21, n - 1):
+        w = cur.g.mul(int.from_bytes(raw[i].tobytes(), "big")).mul(int.from_bytes(k[i].tobytes(), "big"))
+        assert (int.from_bytes(out[i, :32].tobytes(), "big"), int.from_bytes(out[i, 32:].tobytes(), "big")) == (w.x, w.y)
