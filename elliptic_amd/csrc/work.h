@@ -18,6 +18,7 @@
 #include "ladder.h"
 #include "hmac_drbg.h"
 #include "hmac_drbg256.h"
+#include "hmac_drbg512.h"
 #include "sha256.h"
 #include "sha512.h"
 
@@ -530,6 +531,31 @@ struct Work {
         g.generate(v);
         ELL_UNROLL
         for (int w = 0; w < LN; w++) k[w] = w < NW ? v[NW - 1 - w] : 0u;      // no shift: 8 NBYTES == bit length of n
+        done = !bn_is_zero<LN>(k) && !bn_eq<LN>(k, one1) && !bn_geq<LN>(k, nm1);
+      }
+      ELL_UNROLL
+      for (int w = 0; w < LN; w++) k[w] = done ? k[w] : 0u;
+      store_be<LN>(nonce_out + i * NBYTES, k, NBYTES);
+    } else if constexpr (std::is_same<SignHash, Sha384>::value && NBYTES == 48) {
+      // p384: the same with 64-bit words (SHA-384: 6-word K / V, one V per 48-byte draw)
+      u32 d[LN];
+      load_be<LN>(d, priv + i * NBYTES, NBYTES);
+      u64 seed[12];
+      ELL_UNROLL
+      for (int w = 0; w < 6; w++) {
+        seed[w] = ((u64)d[11 - 2 * w] << 32) | d[10 - 2 * w];
+        seed[6 + w] = ((u64)e[11 - 2 * w] << 32) | e[10 - 2 * w];
+      }
+      HmacDrbg512<6, 12> g;
+      g.init(seed);
+      u64 v[6];
+      u32 k[LN];
+      bool done = false;
+      ELL_NOUNROLL
+      for (int it = 0; it < 16 && !done; it++) {
+        g.generate(v);
+        ELL_UNROLL
+        for (int w = 0; w < 6; w++) { k[11 - 2 * w] = (u32)(v[w] >> 32); k[10 - 2 * w] = (u32)v[w]; }
         done = !bn_is_zero<LN>(k) && !bn_eq<LN>(k, one1) && !bn_geq<LN>(k, nm1);
       }
       ELL_UNROLL
