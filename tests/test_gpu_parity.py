@@ -217,6 +217,17 @@ def test_ragged_and_empty_batches(ctx):
             assert _xy(out, i, 32) == (w.x, w.y)
 
 
+def test_empty_batches_newer_entry_points(ctx):
+    z = np.zeros((0, 32), np.uint8)
+    e32 = np.zeros((0, 32), np.uint8)
+    assert ctx.ecdsa_sign("secp256k1", z, e32, e32)[0].shape == (0, 32)
+    assert ctx.ecdsa_sign_det("secp256k1", z, e32)[0].shape == (0, 32)
+    assert ctx.ecdsa_recover("secp256k1", z, e32, e32, np.zeros(0, np.uint8))[0].shape == (0, 64)
+    assert ctx.decompress("secp256k1", e32, np.zeros(0, np.uint8))[0].shape == (0, 64)
+    assert ctx.eddsa_sign([], np.zeros((0, 32), np.uint8))[0].shape == (0, 64)
+    assert ctx.eddsa_verify([], np.zeros((0, 64), np.uint8), np.zeros((0, 32), np.uint8))[0].shape == (0,)
+
+
 def _make_sigs(ctx, n, seed):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench

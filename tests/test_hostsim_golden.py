@@ -279,6 +279,24 @@ def test_host_pipeline_chunks(ctx, n):
     assert want[1::3].all() and not want[::3].any()
 
 
+def test_empty_batches_newer_entry_points(ctx):
+    """n = 0 through sign (both nonce sources), recover, decompress, EdDSA sign / verify"""
+    z = np.zeros((0, 32), np.uint8)
+    e32 = np.zeros((0, 32), np.uint8)
+    r, s_, rec, ok = ctx.ecdsa_sign("secp256k1", z, e32, e32)
+    assert r.shape == (0, 32) and ok.shape == (0,)
+    r, s_, rec, ok = ctx.ecdsa_sign_det("secp256k1", z, e32)
+    assert r.shape == (0, 32) and ok.shape == (0,)
+    xy, st = ctx.ecdsa_recover("secp256k1", z, e32, e32, np.zeros(0, np.uint8))
+    assert xy.shape == (0, 64) and st.shape == (0,)
+    xy, ok = ctx.decompress("secp256k1", e32, np.zeros(0, np.uint8))
+    assert xy.shape == (0, 64)
+    sig, pub = ctx.eddsa_sign([], np.zeros((0, 32), np.uint8))
+    assert sig.shape == (0, 64) and pub.shape == (0, 32)
+    ok, err = ctx.eddsa_verify([], np.zeros((0, 64), np.uint8), np.zeros((0, 32), np.uint8))
+    assert ok.shape == (0,)
+
+
 def test_error_paths(ctx, hs):
     with pytest.raises(elliptic_amd.EllgpuError):
         ctx.mul_fixed("curve25519", np.zeros((1, 32), np.uint8))
