@@ -279,6 +279,43 @@ def test_host_pipeline_chunks(ctx, n):
     assert want[1::3].all() and not want[::3].any()
 
 
+@pytest.mark.parametrize("curve", O.SHORT_CURVES)
+def test_random_ladders_vs_c_oracle(ctx, curve):
+    """seeded random and edge scalars through mul_var / mul_fixed / mul_add2 against the C port of
+    the reference's ladder (a second, independent check of the odd-digit / affine-table paths)"""
+    from oracle import c_oracle
+    B = elliptic_amd.FIELD_BYTES[curve]
+    cur = O.get_curve(curve, False)
+    n_int = int(cur.n)
+    rnd = np.random.default_rng(2025 + B)
+    m = 40
+    d = rnd.integers(0, 256, (m, B), dtype=np.uint8)
+    k = rnd.integers(0, 256, (m, B), dtype=np.uint8)
+    k2 = rnd.integers(0, 256, (m, B), dtype=np.uint8)
+    if curve == "p521":
+        d[:, 0] &= 1
+        k[:, 0] &= 1
+        k2[:, 0] &= 1
+    edge = [0, 1, 2, 3, 15, 16, 17, n_int - 1, n_int, n_int + 1, (1 << (8 * B - (7 if curve == "p521" else 0))) - 1,
+            n_int - 2, (n_int + 1) // 2, 1 << 4, (1 << 64) - 1, 1 << 128]
+    for i, v in enumerate(edge):
+        k[i] = np.frombuffer(int(v).to_bytes(B, "big"), np.uint8)
+    pts, inf = c_oracle.mul(curve, d)
+    assert not inf.any()
+    want = c_oracle.mul(curve, k, pts)
+    got = ctx.mul_var(curve, k, pts)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+    want = c_oracle.mul(curve, k)
+    got = ctx.mul_fixed(curve, k)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+    want = c_oracle.mul_add(curve, k, None, k2, pts)
+    got = ctx.mul_add2(curve, k, None, k2, pts)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+    want = c_oracle.mul_add(curve, k, pts[::-1].copy(), k2, pts)
+    got = ctx.mul_add2(curve, k, pts[::-1].copy(), k2, pts)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+
+
 def test_empty_batches_newer_entry_points(ctx):
     """n = 0 through sign (both nonce sources), recover, decompress, EdDSA sign / verify"""
     z = np.zeros((0, 32), np.uint8)
