@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Randomised differential soak on the GPU box: large seeded batches of every ladder-shaped
+entry point on every short curve against the C port of the reference's algorithm
+(oracle/ec_oracle.c, run on host threads), item by item.  Checker use of oracle/ only.
+
+    python tests/soak.py [--seconds 120] [--seed 1]
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import elliptic_amd
+from oracle import c_oracle
+
+CURVES = ["secp256k1", "p192", "p224", "p256", "p384", "p521"]
+
+
+def rnd(seed, n, w):
+    return np.frombuffer(hashlib.shake_256(seed.encode()).digest(n * w), dtype=np.uint8).reshape(n, w).copy()
+
+
+def par(fn, n, threads, *arrays):
+    """run fn(slice...) over `threads` slices, concatenate the tuple results"""
+    cuts = [n * t // threads for t in range(threads + 1)]
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda t: fn(*[a[cuts[t]:cuts[t + 1]] if a is not None else None for a in arrays]),
+                            range(threads)))
+    return tuple(np.concatenate([p[j] for p in parts]) for j in range(len(parts[0])))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    ctx = elliptic_amd.Context(0)
+    threads = max(1, min(32, len(os.sched_getaffinity(0))))
+    t_end = time.time() + a.seconds
+    rounds = 0
+    checked = 0
+    while time.time() < t_end:
+        for curve in CURVES:
+            B = elliptic_amd.FIELD_BYTES[curve]
+            n = {"p384": 3000, "p521": 1200}.get(curve, 8000)
+            tag = "soak:%d:%d:%s" % (a.seed, rounds, curve)
+            d, k, k2 = rnd(tag + ":d", n, B), rnd(tag + ":k", n, B), rnd(tag + ":k2", n, B)
+            if curve == "p521":
+                for x in (d, k, k2):
+                    x[:, 0] &= 1
+            # sprinkle small / structured scalars
+            k[::97] = 0
+            k[1::97, :B - 1] = 0
+            k2[2::97, : B // 2] = 0xFF
+            pts, inf = par(lambda dd: c_oracle.mul(curve, dd), n, threads, d)
+            assert not inf.any()
+            got = ctx.mul_fixed(curve, d)
+            assert np.array_equal(got[0], pts) and not got[1].any(), (curve, "mul_fixed")
+            want = par(lambda kk, pp: c_oracle.mul(curve, kk, pp), n, threads, k, pts)
+            got = ctx.mul_var(curve, k, pts)
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]), (curve, "mul_var")
+            want = par(lambda a1, a2, pp: c_oracle.mul_add(curve, a1, None, a2, pp), n, threads, k, k2, pts)
+            got = ctx.mul_add2(curve, k, None, k2, pts)
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]), (curve, "mul_add_g")
+            p1 = np.roll(pts, 1, axis=0)
+            want = par(lambda a1, q1, a2, pp: c_oracle.mul_add(curve, a1, q1, a2, pp), n, threads, k, p1, k2, pts)
+            got = ctx.mul_add2(curve, k, p1, k2, pts)
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]), (curve, "mul_add2")
+            # sign with the device's deterministic nonces, verify on both sides, corrupt, verify again
+            NB = elliptic_amd.ORDER_BYTES[curve]
+            z = rnd(tag + ":z", n, min(NB, 32) if curve != "p521" else 64)
+            r, s, rec, ok = ctx.ecdsa_sign_det(curve, z, d[:, :NB] if NB == B else d)
+            assert ok.all(), (curve, "sign_det")
+            z[::5, 0] ^= 1
+            s[1::5, NB - 1] ^= 2
+            want = c_oracle.verify(curve, z, r, s, pts, threads=threads)
+            got = ctx.ecdsa_verify(curve, z, r, s, pts)
+            assert np.array_equal(got, want), (curve, "verify")
+            assert want[2::5].all() and not want[::5].any()
+            checked += 6 * n
+        rounds += 1
+    print(json.dumps({"ok": True, "rounds": rounds, "items_checked": checked, "threads": threads}))
+
+
+if __name__ == "__main__":
+    main()
