@@ -82,12 +82,17 @@ class Context:
         self._check(self._lib.ellgpu_ctx_reserve(self._ctx, self._cid(curve), int(n)))
 
     # ---- host buffers -------------------------------------------------------
-    def mul_fixed(self, curve, k):
+    def mul_fixed(self, curve, k, out=None):
+        """out: optional (xy, inf) uint8 arrays to write into (see mul_var)"""
         B = FIELD_BYTES[curve]
         k = _u8(k, (-1, B))
         n = k.shape[0]
-        out = np.zeros((n, 2 * B), np.uint8)
-        inf = np.zeros(n, np.uint8)
+        if out is None:
+            out, inf = np.zeros((n, 2 * B), np.uint8), np.zeros(n, np.uint8)
+        else:
+            out, inf = out
+            assert out.dtype == np.uint8 and out.shape == (n, 2 * B) and out.flags.c_contiguous
+            assert inf.dtype == np.uint8 and inf.shape == (n,) and inf.flags.c_contiguous
         self._check(self._lib.ellgpu_mul_fixed(self._ctx, self._cid(curve), n, k.ctypes.data,
                                                out.ctypes.data, inf.ctypes.data))
         return out, inf

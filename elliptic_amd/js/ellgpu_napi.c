@@ -41,6 +41,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 typedef struct ellgpu_ctx ellgpu_ctx;
 static struct {
@@ -138,6 +139,53 @@ static int get_buf(napi_env env, napi_value v, const uint8_t** p, size_t* len, i
   void* d; if (napi_get_buffer_info(env, v, &d, len) != napi_ok) { napi_throw_error(env, NULL, "ellgpu: bad Buffer"); return 0; }
   *p = (const uint8_t*)d; return 1;
 }
+/* ---- result buffers -------------------------------------------------------------------
+ * A fresh n x 64-byte Buffer costs more to fault in (first touch, ~6 ms per 64 MB, whoever
+ * touches it) than the GPU needs to fill it.  Large result Buffers are therefore external
+ * Buffers over blocks that return to a free list when V8 collects them: after the first call of
+ * a given size the memory has been touched already.  The blocks are 2 MiB-aligned and advised
+ * as huge pages (the copy engine moves device data into huge-page-backed memory ~3x faster
+ * than into 4 KiB pages here; numpy does the same for its large arrays).  Callers that keep
+ * their own result Buffers pass them in (mulFixed / mulVar / mulAdd2: trailing xy, inf
+ * arguments) and skip all of this.  Everything here runs on the JS thread. */
+typedef struct pool_blk { void* p; size_t cap; struct pool_blk* next; } pool_blk;
+static pool_blk* g_pool = NULL;
+static size_t g_pool_bytes = 0;
+#define POOL_MIN_BYTES ((size_t)256 * 1024)
+#define POOL_MAX_BYTES ((size_t)1 << 31)
+static void pool_release(napi_env env, void* data, void* hint) {
+  (void)data;
+  pool_blk* b = (pool_blk*)hint;
+  int64_t adj;
+  napi_adjust_external_memory(env, -(int64_t)b->cap, &adj);
+  if (g_pool_bytes + b->cap > POOL_MAX_BYTES) { free(b->p); free(b); return; }
+  b->next = g_pool; g_pool = b; g_pool_bytes += b->cap;
+}
+static napi_status result_buffer(napi_env env, size_t size, void** data, napi_value* out) {
+  if (size < POOL_MIN_BYTES) return napi_create_buffer(env, size, data, out);
+  pool_blk **pp = &g_pool, **best = NULL;
+  for (; *pp; pp = &(*pp)->next)                         /* best fit, at most 2x the request */
+    if ((*pp)->cap >= size && (*pp)->cap <= 2 * size && (!best || (*pp)->cap < (*best)->cap)) best = pp;
+  pool_blk* b;
+  if (best) {
+    b = *best; *best = b->next; g_pool_bytes -= b->cap;
+  } else {
+    b = (pool_blk*)malloc(sizeof *b);
+    if (!b) return napi_generic_failure;
+    b->cap = (size + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    if (posix_memalign(&b->p, (size_t)2 << 20, b->cap) != 0) { free(b); return napi_generic_failure; }
+    madvise(b->p, b->cap, MADV_HUGEPAGE);                /* as numpy does for large arrays */
+    memset(b->p, 0, b->cap);                             /* first touch here, once per block */
+  }
+  b->next = NULL;
+  *data = b->p;
+  napi_status st = napi_create_external_buffer(env, size, b->p, pool_release, b, out);
+  if (st != napi_ok) { free(b->p); free(b); return st; }
+  int64_t adj;                                           /* let V8 see the memory behind the Buffer */
+  napi_adjust_external_memory(env, (int64_t)b->cap, &adj);
+  return st;
+}
+
 static napi_value mk_result(napi_env env, const char* k1, napi_value a, const char* k2, napi_value b) {
   napi_value o; CHECK(env, napi_create_object(env, &o));
   CHECK(env, napi_set_named_property(env, o, k1, a));
@@ -171,7 +219,7 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info) {
 /* mulFixed / mulVar / mulAdd2 share the output shape */
 static napi_value mul_common(napi_env env, napi_callback_info info, int kind) {
   if (!need_lib(env)) return NULL;
-  size_t argc = 6; napi_value argv[6];
+  size_t argc = 8; napi_value argv[8];
   CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
   int32_t curve; if (napi_get_value_int32(env, argv[1], &curve) != napi_ok) THROW(env, "curve id expected");
@@ -188,8 +236,24 @@ static napi_value mul_common(napi_env env, napi_callback_info info, int kind) {
     if ((p1 && lp1 != n * 2 * (size_t)B) || l2 != l1 || lp2 != n * 2 * (size_t)B) THROW(env, "buffer length mismatch");
   }
   napi_value bxy, binf; void *dxy, *dinf;
-  CHECK(env, napi_create_buffer(env, n * 2 * (size_t)B, &dxy, &bxy));
-  CHECK(env, napi_create_buffer(env, n, &dinf, &binf));
+  /* optional trailing (xy, inf) result Buffers supplied by the caller */
+  size_t oi = kind == 0 ? 3 : kind == 1 ? 4 : 6;
+  bool own = false;
+  if (argc >= oi + 2) {
+    bool is0 = false, is1 = false;
+    napi_is_buffer(env, argv[oi], &is0); napi_is_buffer(env, argv[oi + 1], &is1);
+    own = is0 && is1;
+  }
+  if (own) {
+    size_t lx, li;
+    CHECK(env, napi_get_buffer_info(env, argv[oi], &dxy, &lx));
+    CHECK(env, napi_get_buffer_info(env, argv[oi + 1], &dinf, &li));
+    if (lx != n * 2 * (size_t)B || li != n) THROW(env, "result buffer length mismatch");
+    bxy = argv[oi]; binf = argv[oi + 1];
+  } else {
+    CHECK(env, result_buffer(env, n * 2 * (size_t)B, &dxy, &bxy));
+    CHECK(env, result_buffer(env, n, &dinf, &binf));
+  }
   int rc = kind == 0 ? L.mul_fixed(c, curve, n, k1, (uint8_t*)dxy, (uint8_t*)dinf)
          : kind == 1 ? L.mul_var(c, curve, n, k1, p1, (uint8_t*)dxy, (uint8_t*)dinf)
                      : L.mul_add2(c, curve, n, k1, p1, k2, p2, (uint8_t*)dxy, (uint8_t*)dinf);
@@ -216,7 +280,7 @@ static napi_value fn_verify(napi_env env, napi_callback_info info) {
   if (lh % (size_t)hl) THROW(env, "hash buffer length is not a multiple of hashLen");
   size_t n = lh / (size_t)hl;
   if (lr != n * (size_t)NB || ls != n * (size_t)NB || lq != n * 2 * (size_t)B) THROW(env, "buffer length mismatch");
-  napi_value bok; void* dok; CHECK(env, napi_create_buffer(env, n, &dok, &bok));
+  napi_value bok; void* dok; CHECK(env, result_buffer(env, n, &dok, &bok));
   if (L.ecdsa_verify(c, curve, n, h, hl, mb, r, s, q, (uint8_t*)dok) != 0) return lib_error(env);
   return bok;
 }
@@ -230,8 +294,8 @@ static napi_value fn_x25519(napi_env env, napi_callback_info info) {
   if (lk % 32 || lx != lk) THROW(env, "buffer length mismatch");
   size_t n = lk / 32;
   napi_value bx, binf; void *dx, *dinf;
-  CHECK(env, napi_create_buffer(env, n * 32, &dx, &bx));
-  CHECK(env, napi_create_buffer(env, n, &dinf, &binf));
+  CHECK(env, result_buffer(env, n * 32, &dx, &bx));
+  CHECK(env, result_buffer(env, n, &dinf, &binf));
   if (L.x25519(c, n, k, x, (uint8_t*)dx, (uint8_t*)dinf) != 0) return lib_error(env);
   return mk_result(env, "x", bx, "inf", binf);
 }
@@ -248,8 +312,8 @@ static napi_value fn_decompress(napi_env env, napi_callback_info info) {
   if (lv % (size_t)B || lo != lv / (size_t)B) THROW(env, "buffer length mismatch");
   size_t n = lo;
   napi_value bxy, bok; void *dxy, *dok;
-  CHECK(env, napi_create_buffer(env, n * 2 * (size_t)B, &dxy, &bxy));
-  CHECK(env, napi_create_buffer(env, n, &dok, &bok));
+  CHECK(env, result_buffer(env, n * 2 * (size_t)B, &dxy, &bxy));
+  CHECK(env, result_buffer(env, n, &dok, &bok));
   if (L.decompress(c, curve, n, v, odd, (uint8_t*)dxy, (uint8_t*)dok) != 0) return lib_error(env);
   return mk_result(env, "xy", bxy, "ok", bok);
 }
@@ -271,10 +335,10 @@ static napi_value fn_sign(napi_env env, napi_callback_info info) {
   size_t n = lh / (size_t)hl;
   if (ld != n * (size_t)NB || lk != ld) THROW(env, "buffer length mismatch");
   napi_value br, bs, brec, bok, o; void *dr, *dsg, *drec, *dok;
-  CHECK(env, napi_create_buffer(env, n * (size_t)NB, &dr, &br));
-  CHECK(env, napi_create_buffer(env, n * (size_t)NB, &dsg, &bs));
-  CHECK(env, napi_create_buffer(env, n, &drec, &brec));
-  CHECK(env, napi_create_buffer(env, n, &dok, &bok));
+  CHECK(env, result_buffer(env, n * (size_t)NB, &dr, &br));
+  CHECK(env, result_buffer(env, n * (size_t)NB, &dsg, &bs));
+  CHECK(env, result_buffer(env, n, &drec, &brec));
+  CHECK(env, result_buffer(env, n, &dok, &bok));
   if (L.ecdsa_sign(c, curve, n, h, hl, mb, d, k, canon ? 1 : 0, (uint8_t*)dr, (uint8_t*)dsg, (uint8_t*)drec, (uint8_t*)dok) != 0)
     return lib_error(env);
   CHECK(env, napi_create_object(env, &o));
@@ -303,10 +367,10 @@ static napi_value fn_sign_det(napi_env env, napi_callback_info info) {
   size_t n = lh / (size_t)hl;
   if (ld != n * (size_t)NB) THROW(env, "buffer length mismatch");
   napi_value br, bs, brec, bok, o; void *dr, *dsg, *drec, *dok;
-  CHECK(env, napi_create_buffer(env, n * (size_t)NB, &dr, &br));
-  CHECK(env, napi_create_buffer(env, n * (size_t)NB, &dsg, &bs));
-  CHECK(env, napi_create_buffer(env, n, &drec, &brec));
-  CHECK(env, napi_create_buffer(env, n, &dok, &bok));
+  CHECK(env, result_buffer(env, n * (size_t)NB, &dr, &br));
+  CHECK(env, result_buffer(env, n * (size_t)NB, &dsg, &bs));
+  CHECK(env, result_buffer(env, n, &drec, &brec));
+  CHECK(env, result_buffer(env, n, &dok, &bok));
   if (L.ecdsa_sign_det(c, curve, n, h, hl, mb, d, canon ? 1 : 0, (uint8_t*)dr, (uint8_t*)dsg, (uint8_t*)drec, (uint8_t*)dok) != 0)
     return lib_error(env);
   CHECK(env, napi_create_object(env, &o));
@@ -335,8 +399,8 @@ static napi_value fn_recover(napi_env env, napi_callback_info info) {
   size_t n = lh / (size_t)hl;
   if (lr != n * (size_t)NB || ls != lr || lj != n) THROW(env, "buffer length mismatch");
   napi_value bxy, bst; void *dxy, *dst;
-  CHECK(env, napi_create_buffer(env, n * 2 * (size_t)B, &dxy, &bxy));
-  CHECK(env, napi_create_buffer(env, n, &dst, &bst));
+  CHECK(env, result_buffer(env, n * 2 * (size_t)B, &dxy, &bxy));
+  CHECK(env, result_buffer(env, n, &dst, &bst));
   if (L.ecdsa_recover(c, curve, n, h, hl, r, sg, j, (uint8_t*)dxy, (uint8_t*)dst) != 0) return lib_error(env);
   return mk_result(env, "xy", bxy, "status", bst);
 }
@@ -357,8 +421,8 @@ static napi_value fn_eddsa_verify(napi_env env, napi_callback_info info) {
     if (((const uint64_t*)off)[n] > lm) THROW(env, "offsets exceed the message buffer");
   } else if ((size_t)mlen * n > lm) THROW(env, "message buffer too short");
   napi_value bok, berr; void *dok, *derr;
-  CHECK(env, napi_create_buffer(env, n, &dok, &bok));
-  CHECK(env, napi_create_buffer(env, n, &derr, &berr));
+  CHECK(env, result_buffer(env, n, &dok, &bok));
+  CHECK(env, result_buffer(env, n, &derr, &berr));
   if (L.eddsa_verify(c, n, m, (const uint64_t*)off, (size_t)mlen, sg, pk, (uint8_t*)dok, (uint8_t*)derr) != 0)
     return lib_error(env);
   return mk_result(env, "ok", bok, "err", berr);
@@ -381,8 +445,8 @@ static napi_value fn_eddsa_sign(napi_env env, napi_callback_info info) {
     if (((const uint64_t*)off)[n] > lm) THROW(env, "offsets exceed the message buffer");
   } else if ((size_t)mlen * n > lm) THROW(env, "message buffer too short");
   napi_value bsig, bpub; void *dsig, *dpub;
-  CHECK(env, napi_create_buffer(env, n * 64, &dsig, &bsig));
-  CHECK(env, napi_create_buffer(env, n * 32, &dpub, &bpub));
+  CHECK(env, result_buffer(env, n * 64, &dsig, &bsig));
+  CHECK(env, result_buffer(env, n * 32, &dpub, &bpub));
   if (L.eddsa_sign(c, n, sec, m, (const uint64_t*)off, (size_t)mlen, (uint8_t*)dsig, (uint8_t*)dpub) != 0)
     return lib_error(env);
   return mk_result(env, "sig", bsig, "pub", bpub);

@@ -46,11 +46,15 @@ Engine.prototype._id = function _id(curve) {
 
 // ---- batch API on flat Buffers (fixed-width big-endian, item-major) ----------
 // scalars: n x B bytes; points: n x 2B bytes (x||y) or null for the generator.
-// -> { xy: Buffer(n x 2B), inf: Buffer(n) }
-Engine.prototype.mulBatch = function mulBatch(curve, scalars, points) {
+// -> { xy: Buffer(n x 2B), inf: Buffer(n) }.  out (optional): { xy, inf } Buffers of those sizes to
+// write into -- a caller that keeps its result Buffers spares every call their allocation.
+Engine.prototype.mulBatch = function mulBatch(curve, scalars, points, out) {
   var id = this._id(curve);
   var n = scalars.length / this.addon.fieldBytes(id);
   this.stats.gpuCalls++; this.stats.gpuItems += n;
+  if (out)
+    return points ? this.addon.mulVar(this.ctx, id, scalars, points, out.xy, out.inf) :
+      this.addon.mulFixed(this.ctx, id, scalars, out.xy, out.inf);
   return points ? this.addon.mulVar(this.ctx, id, scalars, points) :
     this.addon.mulFixed(this.ctx, id, scalars);
 };

@@ -45,6 +45,11 @@ def main():
     timed("secp256k1 mul_var, host buffers (H2D 96 B + D2H 65 B per item)",
           lambda: ctx.mul_var("secp256k1", hr, hq),
           lambda o: np.array_equal(o[0], xy0) and np.array_equal(o[1], inf0))
+    fx0, fi0 = ctx.mul_fixed("secp256k1", hr)
+    fb = (np.zeros_like(fx0), np.zeros_like(fi0))
+    timed("secp256k1 mul_fixed, host buffers (H2D 32 B + D2H 65 B per item), result buffers reused",
+          lambda: ctx.mul_fixed("secp256k1", hr, out=fb),
+          lambda o: np.array_equal(o[0], fx0) and np.array_equal(o[1], fi0))
     bufs = (np.zeros_like(xy0), np.zeros_like(inf0))
     timed("secp256k1 mul_var, host buffers, result buffers reused",
           lambda: ctx.mul_var("secp256k1", hr, hq, out=bufs),
