@@ -149,6 +149,7 @@ static int ell_backend_create(int device, ell::HipBackend* bk, std::string* err)
   if (hipStreamCreateWithFlags(&bk->own, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; return ell::E_HIP; }
   bk->cur = bk->own;
   if (hipStreamCreateWithFlags(&bk->copy, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&bk->copy_out, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&bk->own2, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; return ell::E_HIP; }
   for (int i = 0; i < ell::HipBackend::RING; i++)
     if (hipEventCreateWithFlags(&bk->ring[i], hipEventDisableTiming) != hipSuccess) { *err = "hipEventCreate failed"; return ell::E_HIP; }
@@ -159,6 +160,8 @@ static void ell_backend_destroy(ell::HipBackend* bk) {
   if (bk->own) (void)hipStreamDestroy(bk->own);
   bk->own = nullptr;
   if (bk->copy) (void)hipStreamDestroy(bk->copy);
+  if (bk->copy_out) (void)hipStreamDestroy(bk->copy_out);
+  bk->copy_out = nullptr;
   if (bk->own2) (void)hipStreamDestroy(bk->own2);
   bk->copy = bk->own2 = nullptr;
   for (int i = 0; i < ell::HipBackend::RING; i++)

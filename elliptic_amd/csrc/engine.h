@@ -569,21 +569,21 @@ class Engine {
       return fail(E_ARG, "null pointer");
     if (hash_len <= 0) return fail(E_ARG, "bad hash_len");
     size_t NB = ci->order_bytes;
-    u8* dh = put(G_IN0, hash, n * (size_t)hash_len);
-    u8* dd = put(G_IN1, priv, n * NB);
-    u8* dk = put(G_IN2, nonces, n * NB);
+    const size_t HL = (size_t)hash_len;
+    u8* dh = out_buf(G_IN0, n * HL);
+    u8* dd = out_buf(G_IN1, n * NB);
+    u8* dk = out_buf(G_IN2, n * NB);
     u8* dr = out_buf(G_OUT0, n * NB * 2 + 2 * n);
     if (!dh || !dd || !dk || !dr) return fail(E_NOMEM, "staging allocation failed");
     u8* dsg = dr + n * NB;
     u8* drec = dsg + n * NB;
     u8* dok = drec + n;
-    int rc = ecdsa_sign_dev(curve, n, dh, hash_len, msg_bits, dd, dk, canonical, dr, dsg, drec, dok);
-    if (rc) return rc;
-    bk.d2h(out_r, dr, n * NB);
-    bk.d2h(out_s, dsg, n * NB);
-    bk.d2h(out_recid, drec, n);
-    bk.d2h(out_ok, dok, n);
-    return bk.sync();
+    HostIn ins[3] = {{dh, hash, HL}, {dd, priv, NB}, {dk, nonces, NB}};
+    HostOut outs[4] = {{out_r, dr, NB}, {out_s, dsg, NB}, {out_recid, drec, 1}, {out_ok, dok, 1}};
+    return pipelined(n, ins, 3, outs, 4, [&](size_t o, size_t m) {
+      return ecdsa_sign_dev(curve, m, dh + o * HL, hash_len, msg_bits, dd + o * NB, dk + o * NB, canonical,
+                            dr + o * NB, dsg + o * NB, drec + o, dok + o);
+    });
   }
 
   // EC#sign with the reference's own nonce source (HmacDRBG, deterministic): nonces == nullptr
@@ -621,20 +621,20 @@ class Engine {
     if (n && (!hash || !priv || !out_r || !out_s || !out_recid || !out_ok)) return fail(E_ARG, "null pointer");
     if (hash_len <= 0) return fail(E_ARG, "bad hash_len");
     const size_t NB = ci->order_bytes;
-    u8* dh = put(G_IN0, hash, n * (size_t)hash_len);
-    u8* dd = put(G_IN1, priv, n * NB);
+    const size_t HL = (size_t)hash_len;
+    u8* dh = out_buf(G_IN0, n * HL);
+    u8* dd = out_buf(G_IN1, n * NB);
     u8* dr = out_buf(G_OUT0, n * NB);
     u8* dsg = out_buf(G_OUT1, n * NB);
     u8* drec = out_buf(G_IN3, n);
     u8* dok = out_buf(G_IN4, n);
     if (!dh || !dd || !dr || !dsg || !drec || !dok) return fail(E_NOMEM, "staging allocation failed");
-    int rc = ecdsa_sign_det_dev(curve, n, dh, hash_len, msg_bits, dd, canonical, dr, dsg, drec, dok);
-    if (rc) return rc;
-    bk.d2h(out_r, dr, n * NB);
-    bk.d2h(out_s, dsg, n * NB);
-    bk.d2h(out_recid, drec, n);
-    bk.d2h(out_ok, dok, n);
-    return bk.sync();
+    HostIn ins[2] = {{dh, hash, HL}, {dd, priv, NB}};
+    HostOut outs[4] = {{out_r, dr, NB}, {out_s, dsg, NB}, {out_recid, drec, 1}, {out_ok, dok, 1}};
+    return pipelined(n, ins, 2, outs, 4, [&](size_t o, size_t m) {
+      return ecdsa_sign_det_dev(curve, m, dh + o * HL, hash_len, msg_bits, dd + o * NB, canonical,
+                                dr + o * NB, dsg + o * NB, drec + o, dok + o);
+    });
   }
 
   // EC#recoverPubKey (ec/index.js:231-259) over a batch: status 0 point / 1 infinity /
@@ -666,18 +666,20 @@ class Engine {
     if (n && (!hash || !r || !s || !recid || !out_xy || !out_status)) return fail(E_ARG, "null pointer");
     if (hash_len <= 0) return fail(E_ARG, "bad hash_len");
     const size_t B = ci->field_bytes, NB = ci->order_bytes;
-    u8* dh = put(G_IN0, hash, n * (size_t)hash_len);
-    u8* dr = put(G_IN1, r, n * NB);
-    u8* dsg = put(G_IN2, s, n * NB);
-    u8* dj = put(G_IN3, recid, n);
+    const size_t HL = (size_t)hash_len;
+    u8* dh = out_buf(G_IN0, n * HL);
+    u8* dr = out_buf(G_IN1, n * NB);
+    u8* dsg = out_buf(G_IN2, n * NB);
+    u8* dj = out_buf(G_IN3, n);
     u8* dxy = out_buf(G_OUT0, n * 2 * B);
     u8* dst = out_buf(G_OUT1, n);
     if (!dh || !dr || !dsg || !dj || !dxy || !dst) return fail(E_NOMEM, "staging allocation failed");
-    int rc = ecdsa_recover_dev(curve, n, dh, hash_len, dr, dsg, dj, dxy, dst);
-    if (rc) return rc;
-    bk.d2h(out_xy, dxy, n * 2 * B);
-    bk.d2h(out_status, dst, n);
-    return bk.sync();
+    HostIn ins[4] = {{dh, hash, HL}, {dr, r, NB}, {dsg, s, NB}, {dj, recid, 1}};
+    HostOut outs[2] = {{out_xy, dxy, 2 * B}, {out_status, dst, 1}};
+    return pipelined(n, ins, 4, outs, 2, [&](size_t o, size_t m) {
+      return ecdsa_recover_dev(curve, m, dh + o * HL, hash_len, dr + o * NB, dsg + o * NB, dj + o,
+                               dxy + o * 2 * B, dst + o);
+    });
   }
 
   // EdDSA (ed25519) verify.  msgs: concatenated message bytes; off (n+1 offsets, device
@@ -767,16 +769,16 @@ class Engine {
     if (!ci) return fail(E_ARG, "unknown curve id");
     if (n && (!v || !odd || !out_xy || !out_ok)) return fail(E_ARG, "null pointer");
     size_t B = ci->field_bytes;
-    u8* dv = put(G_IN0, v, n * B);
-    u8* dodd = put(G_IN1, odd, n);
+    u8* dv = out_buf(G_IN0, n * B);
+    u8* dodd = out_buf(G_IN1, n);
     u8* dxy = out_buf(G_OUT0, n * 2 * B);
     u8* dok = out_buf(G_OUT1, n);
     if (!dv || !dodd || !dxy || !dok) return fail(E_NOMEM, "staging allocation failed");
-    int rc = decompress_dev(curve, n, dv, dodd, dxy, dok);
-    if (rc) return rc;
-    bk.d2h(out_xy, dxy, n * 2 * B);
-    bk.d2h(out_ok, dok, n);
-    return bk.sync();
+    HostIn ins[2] = {{dv, v, B}, {dodd, odd, 1}};
+    HostOut outs[2] = {{out_xy, dxy, 2 * B}, {out_ok, dok, 1}};
+    return pipelined(n, ins, 2, outs, 2, [&](size_t o, size_t m) {
+      return decompress_dev(curve, m, dv + o * B, dodd + o, dxy + o * 2 * B, dok + o);
+    });
   }
 
   // ---- host-buffer wrappers: stage through device buffers --------------------
@@ -837,15 +839,15 @@ class Engine {
     if (!ci) return fail(E_ARG, "unknown curve id");
     if (n && (!k || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
     size_t B = ci->field_bytes;
-    u8* dk = put(G_IN0, k, n * B);
+    u8* dk = out_buf(G_IN0, n * B);
     u8* dxy = out_buf(G_OUT0, n * 2 * B);
     u8* dinf = out_buf(G_OUT1, n);
     if (!dk || !dxy || !dinf) return fail(E_NOMEM, "staging allocation failed");
-    int rc = mul_fixed_dev(curve, n, dk, dxy, dinf);
-    if (rc) return rc;
-    bk.d2h(out_xy, dxy, n * 2 * B);
-    bk.d2h(out_inf, dinf, n);
-    return bk.sync();
+    HostIn ins[1] = {{dk, k, B}};
+    HostOut outs[2] = {{out_xy, dxy, 2 * B}, {out_inf, dinf, 1}};
+    return pipelined(n, ins, 1, outs, 2, [&](size_t o, size_t m) {
+      return mul_fixed_dev(curve, m, dk + o * B, dxy + o * 2 * B, dinf + o);
+    });
   }
   int mul_var_host(int curve, size_t n, const u8* k, const u8* xy, u8* out_xy, u8* out_inf) {
     const CurveInfo* ci = curve_info(curve);

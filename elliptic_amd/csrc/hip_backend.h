@@ -43,7 +43,8 @@ struct HipBackend {
   hipStream_t own = nullptr;       // the context's stream
   hipStream_t cur = nullptr;       // stream used by the current call
   hipStream_t own2 = nullptr;      // second compute lane of the host-buffer entry points
-  hipStream_t copy = nullptr;      // H2D / D2H of the host-buffer entry points
+  hipStream_t copy = nullptr;      // H2D of the host-buffer entry points
+  hipStream_t copy_out = nullptr;  // D2H of the host-buffer entry points
   static constexpr int RING = 8;
   hipEvent_t ring[RING] = {};      // cross-stream dependencies (reused round-robin)
   unsigned ring_i = 0;
@@ -82,8 +83,8 @@ struct HipBackend {
   void h2d_copy(void* d, const void* h, size_t bytes) {
     if (bytes) note(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, copy));
   }
-  void d2h_copy(void* h, const void* d, size_t bytes) {
-    if (bytes) note(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, copy));
+  void d2h_copy(void* h, const void* d, size_t bytes) {       // its own stream: PCIe is full duplex
+    if (bytes) note(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, copy_out));
   }
   // the compute stream waits for every copy queued so far
   void copies_before_compute() {
@@ -97,12 +98,13 @@ struct HipBackend {
     note(hipEventRecord(ring[i], cur));
     return i;
   }
-  void copy_after(int ev) { note(hipStreamWaitEvent(copy, ring[ev], 0)); }
+  void copy_after(int ev) { note(hipStreamWaitEvent(copy_out, ring[ev], 0)); }
   // compute lane 0 = the context's stream, lane 1 = a second stream for alternate chunks
   void select_lane(int lane) { cur = lane ? own2 : own; }
   // wait for the copy stream and both lanes
   int sync_lanes() {
     note(hipStreamSynchronize(copy));
+    note(hipStreamSynchronize(copy_out));
     note(hipStreamSynchronize(own2));
     note(hipStreamSynchronize(own));
     return last ? E_HIP : E_OK;
