@@ -30,6 +30,12 @@ _SIGS = {
     "ellgpu_ecdsa_verify": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p]),
     "ellgpu_x25519_ladder": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p]),
     "ellgpu_decompress": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "ellgpu_decode_points": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_size_t, c_u8p, c_u8p]),
+    "ellgpu_decode_points_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_size_t, c_u8p, c_u8p, ctypes.c_void_p]),
+    "ellgpu_encode_points": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, c_u8p]),
+    "ellgpu_encode_points_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, c_u8p, ctypes.c_void_p]),
+    "ellgpu_validate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, ctypes.c_int, c_u8p]),
+    "ellgpu_validate_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, ctypes.c_int, c_u8p, ctypes.c_void_p]),
     "ellgpu_decompress_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
     "ellgpu_ecdsa_sign": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, c_u8p, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p]),
     "ellgpu_ecdsa_sign_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, c_u8p, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),

@@ -122,6 +122,38 @@ int ellgpu_decompress_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v
   return finish(ctx, ctx->eng->decompress_dev(curve, n, v, odd, out_xy, out_ok));
 }
 
+// point codecs and key validation (decodePoint / encode / KeyPair#validate)
+int ellgpu_decode_points(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* enc, size_t enc_len,
+                         uint8_t* out_xy, uint8_t* out_status) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->decode_points_host(curve, n, enc, enc_len, out_xy, out_status));
+}
+int ellgpu_decode_points_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* enc, size_t enc_len,
+                             uint8_t* out_xy, uint8_t* out_status, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->decode_points_dev(curve, n, enc, enc_len, out_xy, out_status));
+}
+int ellgpu_encode_points(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, int compact,
+                         uint8_t* out_enc) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->encode_points_host(curve, n, xy, compact, out_enc));
+}
+int ellgpu_encode_points_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, int compact,
+                             uint8_t* out_enc, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->encode_points_dev(curve, n, xy, compact, out_enc));
+}
+int ellgpu_validate(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, const uint8_t* inf,
+                    int check_order, uint8_t* out_status) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->validate_host(curve, n, xy, inf, check_order, out_status));
+}
+int ellgpu_validate_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, const uint8_t* inf,
+                        int check_order, uint8_t* out_status, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->validate_dev(curve, n, xy, inf, check_order, out_status));
+}
+
 int ellgpu_ecdsa_sign(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len, int msg_bits,
                       const uint8_t* priv, const uint8_t* nonces, int canonical, uint8_t* out_r,
                       uint8_t* out_s, uint8_t* out_recid, uint8_t* out_ok) {

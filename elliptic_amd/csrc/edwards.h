@@ -285,6 +285,48 @@ struct EdWork {
     return ok;
   }
 
+  // ---- batch codecs / validation ---------------------------------------------------
+  // EDDSA#decodePoint (eddsa/index.js:99-109): status 0 = point, 2 = 'invalid point'
+  ELL_HD static void decode_points(size_t i, const u8* enc, u8* out_xy, u8* status) {
+    P pt;
+    bool ok = decode_point(pt, enc + i * 32);
+    if (!ok) { pt.a = F::zero(); pt.b = F::zero(); }
+    store_be<8>(out_xy + i * 64, pt.a.v, 32);
+    store_be<8>(out_xy + i * 64 + 32, pt.b.v, 32);
+    status[i] = ok ? 0 : 2;
+  }
+  // EDDSA#encodePoint (eddsa/index.js:94-98) of affine x || y (big-endian, reduced mod p)
+  ELL_HD static void encode_points(size_t i, const u8* xy, u8* out) {
+    El x = load_fe(xy + i * 64), y = load_fe(xy + i * 64 + 32);
+    u8 can[64];
+    store_be<8>(can, x.v, 32);
+    store_be<8>(can + 32, y.v, 32);
+    u8 enc[32];
+    encode_affine(enc, can);
+    ELL_UNROLL
+    for (int j = 0; j < 32; j++) out[i * 32 + j] = enc[j];
+  }
+  // EdwardsCurve#validate (edwards.js:99-112) of an affine point: a x^2 + y^2 == 1 + d x^2 y^2
+  // (a = -1, c = 1).  status 0 = on the curve, 2 = not a point, 1 = flagged as the identity by
+  // the caller (`inf`, for symmetry with the short curves' KeyPair#validate).
+  ELL_HD static void validate_point(size_t i, const u8* xy, const u8* inf, u8* status) {
+    if (inf && inf[i]) { status[i] = 1; return; }
+    El x = load_fe(xy + i * 64), y = load_fe(xy + i * 64 + 32);
+    El d;
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++) d.v[l] = C::d[l];
+    El x2 = F::sqr(x), y2 = F::sqr(y);
+    El lhs = F::sub(y2, x2);
+    El rhs = F::add(F::one(), F::mul(F::mul(d, x2), y2));
+    status[i] = F::eq(lhs, rhs) ? 0 : 2;
+  }
+  ELL_HD static void fill_order(size_t i, u8* scal) {
+    typedef FpMont<consts::ED25519_N> Fn;
+    u32 nn[8];
+    Fn::get_p(nn);
+    store_be<8>(scal + i * 32, nn, 32);
+  }
+
   // EDDSA#verify (eddsa/index.js:52-63): S < n, h = SHA-512(R || A || M) mod n (hashInt
   // :65-70, little-endian), accept iff R + h*A == S*G.  ok = 0/1; err = 1 where the
   // reference throws (R or A does not decode to a curve point) -- only evaluated when S < n,

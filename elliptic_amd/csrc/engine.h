@@ -183,6 +183,76 @@ struct FnEdDecompress {
   }
 };
 
+template <class CV>
+struct FnDecodePoint {
+  static constexpr const char* NAME = "decode_point";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* enc; size_t len; u8* out_xy; u8* status;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::decode_point(i, enc, len, out_xy, status);
+  }
+};
+template <class CV>
+struct FnEncodePoint {
+  static constexpr const char* NAME = "encode_point";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* xy; int compact; u8* out;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::encode_point(i, xy, compact, out);
+  }
+};
+template <class CV>
+struct FnValidatePoint {
+  static constexpr const char* NAME = "validate_point";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* xy; const u8* inf; u8* status; u8* scal;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) {
+      W::validate_point(i, xy, inf, status);
+      if (scal) W::fill_order(i, scal);
+    }
+  }
+};
+struct FnEdDecodePoint {
+  static constexpr const char* NAME = "ed_decode_point";
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* enc; u8* out_xy; u8* status;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) EdWork::decode_points(i, enc, out_xy, status);
+  }
+};
+struct FnEdEncodePoint {
+  static constexpr const char* NAME = "ed_encode_point";
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* xy; u8* out;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) EdWork::encode_points(i, xy, out);
+  }
+};
+struct FnEdValidatePoint {
+  static constexpr const char* NAME = "ed_validate_point";
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* xy; const u8* inf; u8* status; u8* scal;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) {
+      EdWork::validate_point(i, xy, inf, status);
+      if (scal) EdWork::fill_order(i, scal);
+    }
+  }
+};
+// third test of KeyPair#validate: status 0 stays 0 only when n * P came out as infinity
+struct FnOrderStatus {
+  static constexpr const char* NAME = "order_status";
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* mul_inf; u8* status;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n && status[i] == 0 && !mul_inf[i]) status[i] = 3;
+  }
+};
+
 struct FnEddsaVerify {
   static constexpr const char* NAME = "eddsa_verify";
   static constexpr int DS_PER_LANE = EdWork::NWIN;
@@ -378,6 +448,8 @@ class Engine {
   template <class CV>
   int decompress_chunk(size_t n, const u8* x, const u8* odd, u8* out_xy, u8* out_ok);
   template <class CV>
+  int codec_chunk(int op, size_t n, const u8* in, size_t len, int flag, const u8* inf, u8* out, u8* status);
+  template <class CV>
   int sign_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* priv, const u8* nonces,
                  int canonical, u8* out_r, u8* out_s, u8* out_recid, u8* out_ok);
   template <class CV>
@@ -388,6 +460,8 @@ class Engine {
                     u8* out_xy, u8* out_status);
   template <int U = 0>
   int ed_decompress_chunk(size_t n, const u8* y, const u8* odd, u8* out_xy, u8* out_ok);
+  template <int U = 0>
+  int ed_codec_chunk(int op, size_t n, const u8* in, int flag, const u8* inf, u8* out, u8* status);
   template <int U = 0>
   int eddsa_chunk(size_t n, size_t o, const u8* msgs, const u64* off, size_t msg_len, const u8* sigs,
                   const u8* pubs, u8* ok, u8* err);
@@ -778,6 +852,119 @@ class Engine {
     HostOut outs[2] = {{out_xy, dxy, 2 * B}, {out_ok, dok, 1}};
     return pipelined(n, ins, 2, outs, 2, [&](size_t o, size_t m) {
       return decompress_dev(curve, m, dv + o * B, dodd + o, dxy + o * 2 * B, dok + o);
+    });
+  }
+
+  // ---- SEC1 / EdDSA point codecs and key validation --------------------------------
+  enum { OP_DECODE = 0, OP_ENCODE = 1, OP_VALIDATE = 2 };
+  // decodePoint (base.js:270-293; eddsa/index.js:99-109): n encodings of enc_len bytes each
+  int decode_points_dev(int curve, size_t n, const u8* enc, size_t enc_len, u8* out_xy, u8* out_status) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (curve == CURVE_CURVE25519) return fail(E_UNSUPPORTED, "curve25519 points are x-only");
+    if (n && (!enc || !out_xy || !out_status)) return fail(E_ARG, "null pointer");
+    const size_t B = ci->field_bytes;
+    if (curve == CURVE_ED25519 && enc_len != 32) return fail(E_ARG, "ed25519 encodings are 32 bytes");
+    if (curve == CURVE_P224 && enc_len == 1 + B)
+      return fail(E_UNSUPPORTED, "point decompression needs p = 3 (mod 4) (not p224)");
+    if (enc_len == 0) return fail(E_ARG, "enc_len must be positive");
+    int rc = E_OK;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      if (curve == CURVE_ED25519)
+        rc = ed_codec_chunk(OP_DECODE, m, enc + o * enc_len, 0, nullptr, out_xy + o * 2 * B, out_status + o);
+      else
+        ELL_SHORT_DISPATCH(curve, rc = codec_chunk<CV>(OP_DECODE, m, enc + o * enc_len, enc_len, 0, nullptr,
+                                                       out_xy + o * 2 * B, out_status + o));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+  static size_t encoded_len(int curve, size_t B, int compact) {
+    return curve == CURVE_ED25519 ? 32 : (compact ? 1 + B : 1 + 2 * B);
+  }
+  // BasePoint#encode (base.js:295-311) / EDDSA#encodePoint (eddsa/index.js:94-98)
+  int encode_points_dev(int curve, size_t n, const u8* xy, int compact, u8* out_enc) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (curve == CURVE_CURVE25519) return fail(E_UNSUPPORTED, "curve25519 points are x-only");
+    if (n && (!xy || !out_enc)) return fail(E_ARG, "null pointer");
+    const size_t B = ci->field_bytes, EL = encoded_len(curve, B, compact);
+    int rc = E_OK;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      if (curve == CURVE_ED25519)
+        rc = ed_codec_chunk(OP_ENCODE, m, xy + o * 2 * B, 0, nullptr, out_enc + o * EL, nullptr);
+      else
+        ELL_SHORT_DISPATCH(curve, rc = codec_chunk<CV>(OP_ENCODE, m, xy + o * 2 * B, 0, compact, nullptr,
+                                                       out_enc + o * EL, nullptr));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+  // KeyPair#validate (ec/key.js:41-52): 0 ok, 1 'Invalid public key' (inf[i] set), 2 'Public key
+  // is not a point', 3 'Public key * N != O' (only tested when check_order)
+  int validate_dev(int curve, size_t n, const u8* xy, const u8* inf, int check_order, u8* out_status) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (curve == CURVE_CURVE25519) return fail(E_UNSUPPORTED, "curve25519 points are x-only");
+    if (n && (!xy || !out_status)) return fail(E_ARG, "null pointer");
+    const size_t B = ci->field_bytes;
+    int rc = E_OK;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      const u8* fi = inf ? inf + o : nullptr;
+      if (curve == CURVE_ED25519)
+        rc = ed_codec_chunk(OP_VALIDATE, m, xy + o * 2 * B, check_order, fi, nullptr, out_status + o);
+      else
+        ELL_SHORT_DISPATCH(curve, rc = codec_chunk<CV>(OP_VALIDATE, m, xy + o * 2 * B, 0, check_order, fi,
+                                                       nullptr, out_status + o));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+  int decode_points_host(int curve, size_t n, const u8* enc, size_t enc_len, u8* out_xy, u8* out_status) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (n && (!enc || !out_xy || !out_status)) return fail(E_ARG, "null pointer");
+    const size_t B = ci->field_bytes;
+    u8* de = out_buf(G_IN0, n * enc_len);
+    u8* dxy = out_buf(G_OUT0, n * 2 * B);
+    u8* dst = out_buf(G_OUT1, n);
+    if (!de || !dxy || !dst) return fail(E_NOMEM, "staging allocation failed");
+    HostIn ins[1] = {{de, enc, enc_len}};
+    HostOut outs[2] = {{out_xy, dxy, 2 * B}, {out_status, dst, 1}};
+    return pipelined(n, ins, 1, outs, 2, [&](size_t o, size_t m) {
+      return decode_points_dev(curve, m, de + o * enc_len, enc_len, dxy + o * 2 * B, dst + o);
+    });
+  }
+  int encode_points_host(int curve, size_t n, const u8* xy, int compact, u8* out_enc) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (n && (!xy || !out_enc)) return fail(E_ARG, "null pointer");
+    const size_t B = ci->field_bytes, EL = encoded_len(curve, B, compact);
+    u8* dxy = out_buf(G_IN0, n * 2 * B);
+    u8* de = out_buf(G_OUT0, n * EL);
+    if (!dxy || !de) return fail(E_NOMEM, "staging allocation failed");
+    HostIn ins[1] = {{dxy, xy, 2 * B}};
+    HostOut outs[1] = {{out_enc, de, EL}};
+    return pipelined(n, ins, 1, outs, 1, [&](size_t o, size_t m) {
+      return encode_points_dev(curve, m, dxy + o * 2 * B, compact, de + o * EL);
+    });
+  }
+  int validate_host(int curve, size_t n, const u8* xy, const u8* inf, int check_order, u8* out_status) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (n && (!xy || !out_status)) return fail(E_ARG, "null pointer");
+    const size_t B = ci->field_bytes;
+    u8* dxy = out_buf(G_IN0, n * 2 * B);
+    u8* dinf = inf ? out_buf(G_IN1, n) : nullptr;
+    u8* dst = out_buf(G_OUT0, n);
+    if (!dxy || !dst || (inf && !dinf)) return fail(E_NOMEM, "staging allocation failed");
+    HostIn ins[2] = {{dxy, xy, 2 * B}, {dinf, inf, 1}};
+    HostOut outs[1] = {{out_status, dst, 1}};
+    return pipelined(n, ins, inf ? 2 : 1, outs, 1, [&](size_t o, size_t m) {
+      return validate_dev(curve, m, dxy + o * 2 * B, dinf ? dinf + o : nullptr, check_order, dst + o);
     });
   }
 
@@ -1184,6 +1371,38 @@ int Engine<BK>::decompress_chunk(size_t n, const u8* x, const u8* odd, u8* out_x
 }
 template <class BK>
 template <class CV>
+int Engine<BK>::codec_chunk(int op, size_t n, const u8* in, size_t len, int flag, const u8* inf, u8* out,
+                            u8* status) {
+  typedef Work<CV> W;
+  if (op == OP_DECODE) {
+    FnDecodePoint<CV> f{n, in, len, out, status};
+    bk.launch(f, n);
+    return E_OK;
+  }
+  if (op == OP_ENCODE) {
+    FnEncodePoint<CV> f{n, in, flag, out};
+    bk.launch(f, n);
+    return E_OK;
+  }
+  // validate: curve equation, then (flag) n * P == O through the variable-base ladder
+  u8* tmp = nullptr;
+  if (flag) {
+    tmp = (u8*)scratch(S_U12, n * (3 * (size_t)W::BYTES + 1));
+    if (!tmp) return fail(E_NOMEM, "scratch allocation failed");
+  }
+  FnValidatePoint<CV> f{n, in, inf, status, tmp};
+  bk.launch(f, n);
+  if (!flag) return E_OK;
+  u8* mxy = tmp + n * W::BYTES;
+  u8* minf = mxy + n * 2 * W::BYTES;
+  int rc = mul_var_chunk<CV>(n, tmp, in, mxy, minf, nullptr);
+  if (rc) return rc;
+  FnOrderStatus g{n, minf, status};
+  bk.launch(g, n);
+  return E_OK;
+}
+template <class BK>
+template <class CV>
 int Engine<BK>::sign_det_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* priv,
                                int canonical, u8* out_r, u8* out_s, u8* out_recid, u8* out_ok) {
   typedef Work<CV> W;
@@ -1234,6 +1453,36 @@ template <int U>
 int Engine<BK>::ed_decompress_chunk(size_t n, const u8* y, const u8* odd, u8* out_xy, u8* out_ok) {
   FnEdDecompress f{n, y, odd, out_xy, out_ok};
   bk.launch(f, n);
+  return E_OK;
+}
+
+template <class BK>
+template <int U>
+int Engine<BK>::ed_codec_chunk(int op, size_t n, const u8* in, int flag, const u8* inf, u8* out, u8* status) {
+  if (op == OP_DECODE) {
+    FnEdDecodePoint f{n, in, out, status};
+    bk.launch(f, n);
+    return E_OK;
+  }
+  if (op == OP_ENCODE) {
+    FnEdEncodePoint f{n, in, out};
+    bk.launch(f, n);
+    return E_OK;
+  }
+  u8* tmp = nullptr;
+  if (flag) {
+    tmp = (u8*)scratch(S_U12, n * (3 * 32 + 1));
+    if (!tmp) return fail(E_NOMEM, "scratch allocation failed");
+  }
+  FnEdValidatePoint f{n, in, inf, status, tmp};
+  bk.launch(f, n);
+  if (!flag) return E_OK;
+  u8* mxy = tmp + n * 32;
+  u8* minf = mxy + n * 64;
+  int rc = ed_mul_var_chunk(n, tmp, in, mxy, minf, nullptr);
+  if (rc) return rc;
+  FnOrderStatus g{n, minf, status};
+  bk.launch(g, n);
   return E_OK;
 }
 

@@ -250,33 +250,97 @@ struct Work {
   }
 
   // ---- point decompression (ShortCurve#pointFromX, short.js:187-204) --------------
-  // y = sqrt(x^3 + a x + b) with the requested parity; ok = 0 ('invalid point') when x is
-  // not the abscissa of a curve point.  One exponentiation per item.
-  ELL_HD static void decompress(size_t i, const u8* xs, const u8* odd, u8* out_xy, u8* out_ok) {
-    El x = load_fe(xs + i * BYTES);
+  // rhs = x^3 + a x + b  (ShortCurve#validate short.js:205-216 and pointFromX share it)
+  ELL_HD static El curve_rhs(const El& x) {
     u32 bp[L];
     ELL_UNROLL
     for (int l = 0; l < L; l++) bp[l] = C::b_plain[l];
     El b = F::from_plain(bp);
     El x2 = F::sqr(x);
-    El rhs;
-    if (CV::A_KIND == 0) rhs = F::add(F::mul(x2, x), b);
-    else {
-      El three = F::add(F::one(), F::dbl(F::one()));
-      rhs = F::add(F::mul(F::sub(x2, three), x), b);          // x^3 - 3x + b
-    }
-    El y = F::sqrt(rhs);
+    if (CV::A_KIND == 0) return F::add(F::mul(x2, x), b);
+    El three = F::add(F::one(), F::dbl(F::one()));
+    return F::add(F::mul(F::sub(x2, three), x), b);            // x^3 - 3x + b
+  }
+  // y = sqrt(x^3 + a x + b) with the requested parity; false ('invalid point') when x is
+  // not the abscissa of a curve point.  One exponentiation.
+  ELL_HD static bool lift_x(El& y, const El& x, bool want_odd) {
+    El rhs = curve_rhs(x);
+    y = F::sqrt(rhs);
     bool ok = F::eq(F::sqr(y), rhs);
     u32 yp[L];
     F::to_plain(yp, y);
-    bool want_odd = odd[i] != 0;
     bool is_odd = (yp[0] & 1u) != 0;
     El yn = F::neg(y);
     y = fe_select<F>(is_odd != want_odd, yn, y);
+    return ok;
+  }
+  ELL_HD static void decompress(size_t i, const u8* xs, const u8* odd, u8* out_xy, u8* out_ok) {
+    El x = load_fe(xs + i * BYTES);
+    El y;
+    bool ok = lift_x(y, x, odd[i] != 0);
     if (!ok) { x = F::zero(); y = F::zero(); }
     store_fe(out_xy + i * 2 * BYTES, x);
     store_fe(out_xy + i * 2 * BYTES + BYTES, y);
     out_ok[i] = ok ? 1 : 0;
+  }
+
+  // ---- SEC1 codecs --------------------------------------------------------------
+  // BaseCurve#decodePoint (base.js:270-293) of n encodings of `len` bytes each.  status:
+  // 0 = point, 1 = 'Unknown point format' (prefix / length), 2 = 'invalid point' (compressed x
+  // without a y), 3 = 'Assertion failed' (hybrid 06/07 prefix contradicting y's last bit).
+  // Like the reference, an uncompressed encoding is NOT checked against the curve equation and
+  // its coordinates are reduced mod p (Point's toRed, short.js:261-264).
+  enum { DECODE_OK = 0, DECODE_FORMAT = 1, DECODE_INVALID = 2, DECODE_ASSERT = 3 };
+  ELL_HD static void decode_point(size_t i, const u8* enc, size_t len, u8* out_xy, u8* status) {
+    const u8* e = enc + i * len;
+    const u32 tag = len ? e[0] : 0u;
+    El x = F::zero(), y = F::zero();
+    u32 st = DECODE_FORMAT;
+    if ((tag == 4 || tag == 6 || tag == 7) && len == 1 + 2 * (size_t)BYTES) {
+      const u32 last = e[len - 1] & 1u;
+      if ((tag == 6 && last != 0) || (tag == 7 && last != 1)) st = DECODE_ASSERT;
+      else {
+        x = load_fe(e + 1);
+        y = load_fe(e + 1 + BYTES);
+        st = DECODE_OK;
+      }
+    } else if ((tag == 2 || tag == 3) && len == 1 + (size_t)BYTES) {
+      if constexpr (F::HAS_SQRT) {
+        x = load_fe(e + 1);
+        st = lift_x(y, x, tag == 3) ? DECODE_OK : DECODE_INVALID;
+        if (st != DECODE_OK) { x = F::zero(); y = F::zero(); }
+      }
+    }
+    store_fe(out_xy + i * 2 * BYTES, x);
+    store_fe(out_xy + i * 2 * BYTES + BYTES, y);
+    status[i] = (u8)st;
+  }
+  // BasePoint#_encode (base.js:299-307): 02/03 || x  or  04 || x || y, coordinates reduced
+  ELL_HD static void encode_point(size_t i, const u8* xy, int compact, u8* out) {
+    A a = load_affine(xy, i);
+    const size_t len = compact ? 1 + (size_t)BYTES : 1 + 2 * (size_t)BYTES;
+    u8* o = out + i * len;
+    u32 yp[L];
+    F::to_plain(yp, a.y);
+    o[0] = compact ? (u8)(2u + (yp[0] & 1u)) : (u8)4;
+    store_fe(o + 1, a.x);
+    if (!compact) store_fe(o + 1 + BYTES, a.y);
+  }
+  // KeyPair#validate (ec/key.js:41-52), first two tests: 1 = 'Invalid public key' (infinity),
+  // 2 = 'Public key is not a point' (ShortCurve#validate short.js:205-216), else 0
+  enum { VALIDATE_OK = 0, VALIDATE_INF = 1, VALIDATE_NOT_POINT = 2, VALIDATE_ORDER = 3 };
+  ELL_HD static void validate_point(size_t i, const u8* xy, const u8* inf, u8* status) {
+    if (inf && inf[i]) { status[i] = VALIDATE_INF; return; }
+    A a = load_affine(xy, i);
+    status[i] = F::eq(F::sqr(a.y), curve_rhs(a.x)) ? VALIDATE_OK : VALIDATE_NOT_POINT;
+  }
+  // the group order as a scalar for item i (third test: pub.mul(n).isInfinity())
+  ELL_HD static void fill_order(size_t i, u8* scal) {
+    u32 nq[LN], nn[L];
+    Fn::get_p(nq);
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) nn[l] = l < LN ? nq[l] : 0u;
+    store_be<L>(scal + i * BYTES, nn, BYTES);
   }
 
   // ---- Jacobian -> affine with Montgomery's trick ------------------------------

@@ -166,6 +166,64 @@ class Context:
                                                     odd.data_ptr(), out_xy.data_ptr(),
                                                     out_ok.data_ptr(), self._stream()))
 
+    def decode_points(self, curve, enc):
+        """decodePoint per row of `enc` (n, enc_len) -> (xy, status); status 0 point,
+        1 'Unknown point format', 2 'invalid point', 3 'Assertion failed' (hybrid parity)"""
+        B = FIELD_BYTES[curve]
+        enc = _u8(enc)
+        if enc.ndim != 2:
+            raise ValueError("enc must be (n, enc_len)")
+        n, enc_len = enc.shape
+        out = np.zeros((n, 2 * B), np.uint8)
+        st = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_decode_points(self._ctx, self._cid(curve), n, enc.ctypes.data,
+                                                   enc_len, out.ctypes.data, st.ctypes.data))
+        return out, st
+
+    def decode_points_dev(self, curve, enc, out_xy, out_status):
+        n, enc_len = enc.shape
+        self._check(self._lib.ellgpu_decode_points_dev(self._ctx, self._cid(curve), n, enc.data_ptr(),
+                                                       enc_len, out_xy.data_ptr(),
+                                                       out_status.data_ptr(), self._stream()))
+
+    def encode_points(self, curve, xy, compact=False):
+        """BasePoint#encode / EDDSA#encodePoint per affine point -> (n, enc_len) bytes"""
+        B = FIELD_BYTES[curve]
+        xy = _u8(xy, (-1, 2 * B))
+        n = xy.shape[0]
+        enc_len = 32 if curve == "ed25519" else (1 + B if compact else 1 + 2 * B)
+        out = np.zeros((n, enc_len), np.uint8)
+        self._check(self._lib.ellgpu_encode_points(self._ctx, self._cid(curve), n, xy.ctypes.data,
+                                                   1 if compact else 0, out.ctypes.data))
+        return out
+
+    def encode_points_dev(self, curve, xy, compact, out_enc):
+        n = xy.shape[0]
+        self._check(self._lib.ellgpu_encode_points_dev(self._ctx, self._cid(curve), n, xy.data_ptr(),
+                                                       1 if compact else 0, out_enc.data_ptr(),
+                                                       self._stream()))
+
+    def validate(self, curve, xy, inf=None, check_order=True):
+        """KeyPair#validate per item -> status (0 ok, 1 'Invalid public key', 2 'Public key is
+        not a point', 3 'Public key * N != O')"""
+        B = FIELD_BYTES[curve]
+        xy = _u8(xy, (-1, 2 * B))
+        n = xy.shape[0]
+        if inf is not None:
+            inf = _u8(inf, (n,))
+        st = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_validate(self._ctx, self._cid(curve), n, xy.ctypes.data,
+                                              inf.ctypes.data if inf is not None else None,
+                                              1 if check_order else 0, st.ctypes.data))
+        return st
+
+    def validate_dev(self, curve, xy, inf, check_order, out_status):
+        n = xy.shape[0]
+        self._check(self._lib.ellgpu_validate_dev(self._ctx, self._cid(curve), n, xy.data_ptr(),
+                                                  inf.data_ptr() if inf is not None else None,
+                                                  1 if check_order else 0, out_status.data_ptr(),
+                                                  self._stream()))
+
     def ecdsa_sign(self, curve, hashes, priv, nonces, canonical=False, msg_bits=0):
         """one pass of EC#sign per item for supplied nonces -> (r, s, recid, ok)"""
         NB = ORDER_BYTES[curve]

@@ -25,6 +25,9 @@
  *           eddsaSign(ctx, msgs, offsets|null, msgLen, secrets) -> {sig, pub}
  *           ecdsaRecover(ctx, curve, hash, hashLen, r, s, recid) -> {xy, status}
  *           ecdsaSignDet(ctx, curve, hash, hashLen, msgBits, priv, canonical) -> {r, s, recid, ok}
+ *           decodePoints(ctx, curve, enc, encLen) -> {xy, status}
+ *           encodePoints(ctx, curve, xy, compact) -> Buffer
+ *           validate(ctx, curve, xy, inf|null, checkOrder) -> Buffer (status bytes)
  *             offsets: Buffer of n+1 little-endian uint64 byte offsets into msgs
  *           callAsync(op, ctx, curve, hashLen, msgBits, b0, b1, b2, b3) -> Promise
  *             op 0 mulFixed(b0=k) 1 mulVar(k, xy) 2 mulAdd2(k1, p1|null, k2, p2)
@@ -71,6 +74,9 @@ static struct {
                        const uint8_t*, uint8_t*, uint8_t*);
   int (*ecdsa_sign_det)(ellgpu_ctx*, int, size_t, const uint8_t*, int, int, const uint8_t*, int,
                         uint8_t*, uint8_t*, uint8_t*, uint8_t*);
+  int (*decode_points)(ellgpu_ctx*, int, size_t, const uint8_t*, size_t, uint8_t*, uint8_t*);
+  int (*encode_points)(ellgpu_ctx*, int, size_t, const uint8_t*, int, uint8_t*);
+  int (*validate)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, int, uint8_t*);
 } L;
 
 #define THROW(env, msg) do { napi_throw_error((env), NULL, (msg)); return NULL; } while (0)
@@ -107,6 +113,9 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   SYM(ecdsa_recover, "ellgpu_ecdsa_recover");
   SYM(ecdsa_sign_det, "ellgpu_ecdsa_sign_det");
   SYM(ecdsa_sign, "ellgpu_ecdsa_sign");
+  SYM(decode_points, "ellgpu_decode_points");
+  SYM(encode_points, "ellgpu_encode_points");
+  SYM(validate, "ellgpu_validate");
   L.h = h;
   napi_value t; CHECK(env, napi_get_boolean(env, 1, &t));
   return t;
@@ -405,6 +414,68 @@ static napi_value fn_recover(napi_env env, napi_callback_info info) {
   return mk_result(env, "xy", bxy, "status", bst);
 }
 
+static napi_value fn_decode_points(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 4; napi_value argv[4];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  int32_t curve, el;
+  if (napi_get_value_int32(env, argv[1], &curve) != napi_ok || napi_get_value_int32(env, argv[3], &el) != napi_ok)
+    THROW(env, "decodePoints(ctx, curve, enc, encLen)");
+  int B = L.field_bytes(curve); if (B <= 0 || el <= 0) THROW(env, "bad curve / encLen");
+  const uint8_t* enc; size_t le;
+  if (!get_buf(env, argv[2], &enc, &le, 0)) return NULL;
+  if (le % (size_t)el) THROW(env, "enc buffer length is not a multiple of encLen");
+  size_t n = le / (size_t)el;
+  napi_value bxy, bst; void *dxy, *dst;
+  CHECK(env, result_buffer(env, n * 2 * (size_t)B, &dxy, &bxy));
+  CHECK(env, result_buffer(env, n, &dst, &bst));
+  if (L.decode_points(c, curve, n, enc, (size_t)el, (uint8_t*)dxy, (uint8_t*)dst) != 0) return lib_error(env);
+  return mk_result(env, "xy", bxy, "status", bst);
+}
+
+static napi_value fn_encode_points(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 4; napi_value argv[4];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  int32_t curve; bool compact = 0;
+  if (napi_get_value_int32(env, argv[1], &curve) != napi_ok || napi_get_value_bool(env, argv[3], &compact) != napi_ok)
+    THROW(env, "encodePoints(ctx, curve, xy, compact)");
+  int B = L.field_bytes(curve); if (B <= 0) THROW(env, "unknown curve id");
+  const uint8_t* xy; size_t lx;
+  if (!get_buf(env, argv[2], &xy, &lx, 0)) return NULL;
+  if (lx % (2 * (size_t)B)) THROW(env, "xy buffer length is not a multiple of 2 * fieldBytes");
+  size_t n = lx / (2 * (size_t)B);
+  /* the library's rule for the encoded length: SEC1 for the short curves, 32 bytes for ed25519 */
+  size_t el = compact ? 1 + (size_t)B : 1 + 2 * (size_t)B;
+  if (L.curve_id("ed25519") == curve) el = 32;
+  napi_value be; void* de;
+  CHECK(env, result_buffer(env, n * el, &de, &be));
+  if (L.encode_points(c, curve, n, xy, compact ? 1 : 0, (uint8_t*)de) != 0) return lib_error(env);
+  return be;
+}
+
+static napi_value fn_validate(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 5; napi_value argv[5];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  int32_t curve; bool order = 1;
+  if (napi_get_value_int32(env, argv[1], &curve) != napi_ok || napi_get_value_bool(env, argv[4], &order) != napi_ok)
+    THROW(env, "validate(ctx, curve, xy, inf|null, checkOrder)");
+  int B = L.field_bytes(curve); if (B <= 0) THROW(env, "unknown curve id");
+  const uint8_t *xy, *inf; size_t lx, li;
+  if (!get_buf(env, argv[2], &xy, &lx, 0) || !get_buf(env, argv[3], &inf, &li, 1)) return NULL;
+  if (lx % (2 * (size_t)B)) THROW(env, "xy buffer length is not a multiple of 2 * fieldBytes");
+  size_t n = lx / (2 * (size_t)B);
+  if (inf && li != n) THROW(env, "buffer length mismatch");
+  napi_value bst; void* dst;
+  CHECK(env, result_buffer(env, n, &dst, &bst));
+  if (L.validate(c, curve, n, xy, inf, order ? 1 : 0, (uint8_t*)dst) != 0) return lib_error(env);
+  return bst;
+}
+
 static napi_value fn_eddsa_verify(napi_env env, napi_callback_info info) {
   if (!need_lib(env)) return NULL;
   size_t argc = 6; napi_value argv[6];
@@ -566,6 +637,7 @@ static napi_value init(napi_env env, napi_value exports) {
     {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519},
     {"callAsync", fn_call_async}, {"decompress", fn_decompress},
     {"eddsaVerify", fn_eddsa_verify}, {"eddsaSign", fn_eddsa_sign}, {"ecdsaSign", fn_sign}, {"ecdsaRecover", fn_recover}, {"ecdsaSignDet", fn_sign_det},
+    {"decodePoints", fn_decode_points}, {"encodePoints", fn_encode_points}, {"validate", fn_validate},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

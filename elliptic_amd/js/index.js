@@ -114,6 +114,34 @@ Engine.prototype.ecdsaRecoverBatch = function ecdsaRecoverBatch(curve, o) {
   return this.addon.ecdsaRecover(this.ctx, id, o.hashes, o.hashLen, o.r, o.s, o.recid);
 };
 
+// Point codecs and key validation on flat Buffers.
+// decodePointBatch: enc = Buffer(n x encLen) of SEC1 encodings (02/03||x, 04/06/07||x||y) or, for
+// ed25519, 32-byte EDDSA encodings -> { xy: Buffer(n x 2B), status: Buffer(n) }; status 0 point,
+// 1 'Unknown point format', 2 'invalid point', 3 'Assertion failed' (hybrid prefix vs. y parity):
+// the exception BaseCurve#decodePoint / EDDSA#decodePoint throws for that item.
+Engine.prototype.decodePointBatch = function decodePointBatch(curve, enc, encLen) {
+  var id = this._id(curve);
+  this.stats.gpuCalls++; this.stats.gpuItems += enc.length / encLen;
+  return this.addon.decodePoints(this.ctx, id, enc, encLen);
+};
+// encodePointBatch: xy = Buffer(n x 2B) -> Buffer(n x encLen) as BasePoint#encode(enc, compact)
+// (EDDSA#encodePoint for ed25519, 32 bytes each)
+Engine.prototype.encodePointBatch = function encodePointBatch(curve, xy, compact) {
+  var id = this._id(curve);
+  this.stats.gpuCalls++;
+  return this.addon.encodePoints(this.ctx, id, xy, !!compact);
+};
+// validateBatch: KeyPair#validate per point -> Buffer(n) of 0 ok / 1 'Invalid public key'
+// (o.inf[i] set) / 2 'Public key is not a point' / 3 'Public key * N != O' (skipped when
+// o.checkOrder === false)
+Engine.VALIDATE_REASON = [null, 'Invalid public key', 'Public key is not a point', 'Public key * N != O'];
+Engine.prototype.validateBatch = function validateBatch(curve, xy, o) {
+  var id = this._id(curve);
+  o = o || {};
+  this.stats.gpuCalls++;
+  return this.addon.validate(this.ctx, id, xy, o.inf || null, o.checkOrder !== false);
+};
+
 // ed25519 EdDSA verify.  msgs: array of Buffers (any lengths); sigs: Buffer(n x 64) of R||S;
 // pubs: Buffer(n x 32).  -> { ok: Buffer(n), err: Buffer(n) }  (err = 1 where the
 // reference throws: R or A is not a curve point)

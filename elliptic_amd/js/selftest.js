@@ -149,6 +149,41 @@ function check(r, i, B, want, what) {
     checked++;
   });
 })();
+['secp256k1', 'p256', 'p521', 'ed25519'].forEach(function(name) {
+  var g = JSON.parse(fs.readFileSync(path.join(GOLD, 'codec_' + name + '.json')));
+  var ST = { 'Unknown point format': 1, 'invalid point': 2, 'Assertion failed': 3 };
+  var byLen = {};
+  g.decode.forEach(function(c) { (byLen[c.enc.length / 2] = byLen[c.enc.length / 2] || []).push(c); });
+  Object.keys(byLen).forEach(function(len) {
+    var cs = byLen[len];
+    var r = eng.decodePointBatch(name, Buffer.from(cs.map(function(c) { return c.enc; }).join(''), 'hex'), +len);
+    var B2 = r.xy.length / cs.length;
+    cs.forEach(function(c, i) {
+      var want = c.r.throws ? (name === 'ed25519' ? 2 : ST[c.r.throws]) : 0;
+      if (r.status[i] !== want ||
+          (!want && r.xy.slice(i * B2, (i + 1) * B2).toString('hex') !== c.r.x + c.r.y))
+        throw new Error('decodePoint mismatch: ' + name + ' ' + c.enc);
+      checked++;
+    });
+  });
+  var xy = Buffer.from(g.encode.map(function(c) { return c.x + c.y; }).join(''), 'hex');
+  var comp = eng.encodePointBatch(name, xy, true).toString('hex');
+  if (comp !== g.encode.map(function(c) { return c.compact; }).join('')) throw new Error('encode(compact) mismatch: ' + name);
+  if (name !== 'ed25519') {
+    var full = eng.encodePointBatch(name, xy, false).toString('hex');
+    if (full !== g.encode.map(function(c) { return c.full; }).join('')) throw new Error('encode mismatch: ' + name);
+  }
+  checked += g.encode.length;
+  var B = g.encode[0].x.length / 2;
+  var vs = g.validate.filter(function(c) { return c.x.length === 2 * B && c.y.length === 2 * B; });
+  var st = eng.validateBatch(name, Buffer.from(vs.map(function(c) { return c.x + c.y; }).join(''), 'hex'));
+  vs.forEach(function(c, i) {
+    var want = name === 'ed25519' ? (c.on_curve ? (c.order_ok ? 0 : 3) : 2)
+      : ellgpu.Engine.VALIDATE_REASON.indexOf(c.reason);
+    if (st[i] !== want) throw new Error('validate mismatch: ' + name + ' ' + c.x);
+    checked++;
+  });
+});
 var lc = JSON.parse(fs.readFileSync(path.join(GOLD, 'mul_curve25519.json')));
 var rr = eng.x25519Batch(hexBuf(lc.map(function(c) { return c.k; }), 32), hexBuf(lc.map(function(c) { return c.px; }), 32));
 lc.forEach(function(c, i) {

@@ -131,6 +131,40 @@ int ellgpu_decompress(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, co
 int ellgpu_decompress_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, const uint8_t* odd,
                           uint8_t* out_xy, uint8_t* out_ok, void* stream);
 
+/* Point codecs ("SEC1 & ed25519 codecs").
+ * ellgpu_decode_points: n encodings of enc_len bytes each -> affine x||y (big-endian, reduced
+ * mod p) + a status byte per item.
+ *   short curves: BaseCurve#decodePoint (lib/elliptic/curve/base.js:270-293).  enc_len = 1+2B
+ *     with prefix 04 / 06 / 07 (uncompressed, hybrid), or 1+B with prefix 02 / 03 (compressed,
+ *     -> pointFromX).  status 0 = point; 1 = 'Unknown point format' (prefix does not fit
+ *     enc_len); 2 = 'invalid point' (no y for that x); 3 = 'Assertion failed' (hybrid prefix
+ *     contradicts y's last bit, base.js:279-282).  As in the reference an uncompressed point
+ *     is NOT checked against the curve equation -- that is ellgpu_validate.  Compressed
+ *     encodings on p224 return ELLGPU_E_UNSUPPORTED (see ellgpu_decompress).
+ *   ed25519: EDDSA#decodePoint (lib/elliptic/eddsa/index.js:99-109), enc_len = 32: little-endian
+ *     y with x's parity in the top bit.  status 0 / 2.
+ * ellgpu_encode_points: affine x||y -> BasePoint#encode (base.js:295-311): compact = 0 gives
+ *   04||x||y (1+2B bytes per item), compact != 0 gives 02/03||x (1+B bytes); ed25519:
+ *   EDDSA#encodePoint (eddsa/index.js:94-98), 32 bytes per item, `compact` ignored.  The point
+ *   at infinity has no encoding (the reference throws); callers filter on their inf flags.
+ * ellgpu_validate: KeyPair#validate (lib/elliptic/ec/key.js:41-52) per item.  status 0 =
+ *   {result: true}; 1 = 'Invalid public key' (inf[i] != 0; inf may be NULL); 2 = 'Public key is
+ *   not a point' (ShortCurve#validate short.js:205-216 / EdwardsCurve#validate
+ *   edwards.js:99-112); 3 = 'Public key * N != O' (only evaluated when check_order != 0: one
+ *   variable-base n*P per item through the same ladder as ellgpu_mul_var). */
+int ellgpu_decode_points(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* enc, size_t enc_len,
+                         uint8_t* out_xy, uint8_t* out_status);
+int ellgpu_decode_points_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* enc, size_t enc_len,
+                             uint8_t* out_xy, uint8_t* out_status, void* stream);
+int ellgpu_encode_points(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, int compact,
+                         uint8_t* out_enc);
+int ellgpu_encode_points_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, int compact,
+                             uint8_t* out_enc, void* stream);
+int ellgpu_validate(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, const uint8_t* inf,
+                    int check_order, uint8_t* out_status);
+int ellgpu_validate_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, const uint8_t* inf,
+                        int check_order, uint8_t* out_status, void* stream);
+
 /* ECDSA sign for caller-supplied nonces: one pass of EC#sign's loop per item
  * (lib/elliptic/ec/index.js:153-185): k = _truncateToN(nonce, true), R = k*G (fixed-base comb),
  * r = R.x mod n, s = k^-1 (z + r d) mod n (k^-1 batched), recoveryParam (:174-175), and with

@@ -693,6 +693,45 @@ def ecdsa_recover(curve: ShortCurve, e: int, r: int, s: int, j: int) -> ShortPoi
     return curve.g.mul_add(s1, R, s2)
 
 
+def decode_point(curve: ShortCurve, data: bytes) -> ShortPoint:
+    """base.js:270-293 BaseCurve#decodePoint.  Raises ValueError with the reference's message:
+    'Unknown point format', 'Assertion failed' (hybrid prefix vs. y's last bit), 'invalid point'
+    (pointFromX).  Uncompressed coordinates are reduced mod p (short.js:261-264) and NOT checked
+    against the curve equation."""
+    ln = (curve.p.bit_length() + 7) // 8
+    b = bytes(data)
+    if len(b) and b[0] in (4, 6, 7) and len(b) - 1 == 2 * ln:
+        if b[0] == 6 and b[-1] % 2 != 0:
+            raise ValueError("Assertion failed")
+        if b[0] == 7 and b[-1] % 2 != 1:
+            raise ValueError("Assertion failed")
+        return curve.point(int.from_bytes(b[1:1 + ln], "big") % curve.p,
+                           int.from_bytes(b[1 + ln:], "big") % curve.p)
+    if len(b) and b[0] in (2, 3) and len(b) - 1 == ln:
+        return curve.point_from_x(int.from_bytes(b[1:], "big"), b[0] == 3)
+    raise ValueError("Unknown point format")
+
+
+def encode_point(curve: ShortCurve, pt: ShortPoint, compact: bool) -> bytes:
+    """base.js:299-311 BasePoint#_encode"""
+    ln = (curve.p.bit_length() + 7) // 8
+    x = (pt.x % curve.p).to_bytes(ln, "big")
+    if compact:
+        return bytes([3 if (pt.y % curve.p) & 1 else 2]) + x
+    return b"\x04" + x + (pt.y % curve.p).to_bytes(ln, "big")
+
+
+def key_validate(curve: ShortCurve, pt: ShortPoint) -> Tuple[bool, Optional[str]]:
+    """ec/key.js:41-52 KeyPair#validate -> (result, reason)"""
+    if pt.inf:
+        return False, "Invalid public key"
+    if not curve.validate(pt):
+        return False, "Public key is not a point"
+    if not pt.mul(curve.n).inf:
+        return False, "Public key * N != O"
+    return True, None
+
+
 def ecdsa_sign(curve: ShortCurve, msg: int, msg_bytes: int, d: int, k_bytes: bytes, canonical=False,
                msg_bit_length=None):
     """ec/index.js:110-186 EC#sign for ONE supplied nonce (options.k(0)): returns
@@ -946,6 +985,13 @@ def ed_decode_point(curve: "EdwardsCurve", data: bytes) -> EdPoint:
     odd = (b[-1] & 0x80) != 0
     b[-1] &= 0x7F
     return curve.point_from_y(int.from_bytes(bytes(b), "little"), odd)
+
+
+def ed_validate(curve: "EdwardsCurve", x: int, y: int) -> bool:
+    """edwards.js:99-112 EdwardsCurve#validate of an affine point (c = 1)"""
+    p = curve.p
+    x2, y2 = x * x % p, y * y % p
+    return (x2 * curve.a + y2 - (1 + curve.d * x2 % p * y2)) % p == 0
 
 
 def eddsa_verify(curve: "EdwardsCurve", msg: bytes, sig: bytes, pub: bytes) -> bool:

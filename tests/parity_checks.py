@@ -203,6 +203,74 @@ def check_recover_golden(ctx, curve):
     return total
 
 
+DECODE_STATUS = {"Unknown point format": 1, "invalid point": 2, "Assertion failed": 3}
+VALIDATE_STATUS = {None: 0, "Invalid public key": 1, "Public key is not a point": 2,
+                   "Public key * N != O": 3}
+
+
+def check_codec_golden(ctx, curve):
+    """decodePoint / encode / KeyPair#validate goldens (tools/gen_golden.js genCodec): the status
+    byte names the exception the reference throws, results are byte-identical"""
+    from golden_util import load
+    B = FIELD_BYTES[curve]
+    g = load("codec_%s.json" % curve)
+    total = 0
+    groups = {}
+    for c in g["decode"]:
+        groups.setdefault(len(c["enc"]) // 2, []).append(c)
+    for ln, cs in sorted(groups.items()):
+        if curve == "p224" and ln == 1 + B:
+            # compressed p224 stays in JavaScript (p = 1 mod 4): the library says so, loudly
+            enc = np.frombuffer(b"".join(bytes.fromhex(c["enc"]) for c in cs), np.uint8).reshape(-1, ln)
+            try:
+                ctx.decode_points(curve, enc)
+            except Exception as e:                     # noqa: BLE001
+                assert "p224" in str(e)
+            else:
+                raise AssertionError("compressed p224 must be refused")
+            continue
+        enc = np.frombuffer(b"".join(bytes.fromhex(c["enc"]) for c in cs), np.uint8).reshape(-1, ln)
+        xy, st = ctx.decode_points(curve, enc)
+        for i, c in enumerate(cs):
+            if "throws" in c["r"]:
+                want = 2 if curve == "ed25519" else DECODE_STATUS[c["r"]["throws"]]
+                assert st[i] == want and not xy[i].any(), c
+            else:
+                assert st[i] == 0, c
+                assert xy[i].tobytes().hex() == c["r"]["x"] + c["r"]["y"], c
+            total += 1
+    xy = np.frombuffer(b"".join(bytes.fromhex(c["x"] + c["y"]) for c in g["encode"]), np.uint8).reshape(-1, 2 * B)
+    comp = ctx.encode_points(curve, xy, compact=True)
+    for i, c in enumerate(g["encode"]):
+        assert comp[i].tobytes().hex() == c["compact"], c
+    if curve != "ed25519":
+        full = ctx.encode_points(curve, xy, compact=False)
+        for i, c in enumerate(g["encode"]):
+            assert full[i].tobytes().hex() == c["full"], c
+    total += len(g["encode"])
+    # (a coordinate >= 2^(8B) -- keyFromPublic takes any integer -- has no fixed-width form)
+    vcases = [c for c in g["validate"] if len(c["x"]) == 2 * B and len(c["y"]) == 2 * B]
+    xy = np.frombuffer(b"".join(bytes.fromhex(c["x"] + c["y"]) for c in vcases), np.uint8).reshape(-1, 2 * B)
+    st_full = ctx.validate(curve, xy, check_order=True)
+    st_eq = ctx.validate(curve, xy, check_order=False)
+    for i, c in enumerate(vcases):
+        if curve == "ed25519":
+            want_eq = 0 if c["on_curve"] else 2
+            want_full = want_eq if (want_eq or c["order_ok"]) else 3
+        else:
+            want_full = VALIDATE_STATUS[c["reason"]]
+            assert (want_full == 0) == c["result"]
+            want_eq = want_full if want_full != 3 else 0
+        assert st_eq[i] == want_eq and st_full[i] == want_full, (c, st_eq[i], st_full[i])
+    total += len(vcases)
+    # the caller's infinity flags come back as 'Invalid public key'
+    inf = np.zeros(len(xy), np.uint8)
+    inf[::3] = 1
+    st = ctx.validate(curve, xy, inf=inf, check_order=False)
+    assert (st[::3] == 1).all() and (st[1::3] == st_eq[1::3]).all()
+    return total
+
+
 def check_eddsa_sign_golden(ctx):
     """EDDSA#sign / keyFromSecret goldens: sign.input vectors + seeded block-boundary lengths;
     the signatures must also verify"""

@@ -222,6 +222,11 @@ def test_recover_golden(ctx, curve):
     assert PC.check_recover_golden(ctx, curve) >= 30
 
 
+@pytest.mark.parametrize("curve", O.SHORT_CURVES + ["ed25519"])
+def test_codec_golden(ctx, curve):
+    assert PC.check_codec_golden(ctx, curve) >= 100
+
+
 def test_recover_unsupported(ctx):
     with pytest.raises(elliptic_amd.EllgpuError) as e:
         ctx.ecdsa_recover("p224", np.zeros((1, 28), np.uint8), np.ones((1, 28), np.uint8), np.ones((1, 28), np.uint8),

@@ -140,6 +140,47 @@ def test_decompress_matches_reference(name):
     assert n_inv > 3
 
 
+@pytest.mark.parametrize("name", O.SHORT_CURVES + ["ed25519"])
+def test_codec_matches_reference(name):
+    """decodePoint / encode / KeyPair#validate (base.js:270-311, ec/key.js:41-52,
+    eddsa/index.js:94-109, edwards.js:99-112), exception messages included"""
+    cur = O.get_curve(name)
+    g = load("codec_%s.json" % name)
+    thrown = 0
+    for c in g["decode"]:
+        try:
+            if name == "ed25519":
+                got = O.ed_decode_point(cur, bytes.fromhex(c["enc"])).normalized()
+            else:
+                pt = O.decode_point(cur, bytes.fromhex(c["enc"]))
+                got = (pt.x, pt.y)
+        except ValueError as ex:
+            got = str(ex)
+        want = c["r"]["throws"] if "throws" in c["r"] else (I(c["r"]["x"]), I(c["r"]["y"]))
+        assert got == want, (name, c)
+        thrown += "throws" in c["r"]
+    assert thrown > 3
+    for c in g["encode"]:
+        if name == "ed25519":
+            assert O.ed_encode_point(cur.point(I(c["x"]), I(c["y"]))).hex() == c["compact"]
+        else:
+            pt = cur.point(I(c["x"]), I(c["y"]))
+            assert O.encode_point(cur, pt, True).hex() == c["compact"]
+            assert O.encode_point(cur, pt, False).hex() == c["full"]
+    seen = set()
+    for c in g["validate"]:
+        if name == "ed25519":
+            assert O.ed_validate(cur, I(c["x"]), I(c["y"])) == c["on_curve"], c
+            if "order_ok" in c:
+                assert cur.point(I(c["x"]), I(c["y"])).mul(cur.n).is_infinity() == c["order_ok"], c
+                seen.add((c["on_curve"], c["order_ok"]))
+        else:
+            got = O.key_validate(cur, cur.point(I(c["x"]) % cur.p, I(c["y"]) % cur.p))
+            assert got == (c["result"], c["reason"]), c
+            seen.add(got)
+    assert len(seen) >= 2
+
+
 def test_eddsa_verify_matches_reference():
     """EDDSA#verify on the reference's own sign.input vectors + corrupted variants"""
     cur = O.get_curve("ed25519")

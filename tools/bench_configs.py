@@ -101,6 +101,19 @@ def main():
             odd = (pts[:, 2 * B - 1] & 1).contiguous()
             timed("%s key decompression (pointFromX)" % curve, n, lambda: ctx.decompress_dev(curve, xs, odd, out, ok))
             assert torch.equal(out, pts) and bool(ok.all())
+            if curve == "secp256k1":
+                # SEC1 codecs and KeyPair#validate: encode d*G compressed, decode it back, validate
+                # it (curve equation + n*P == O: one more variable-base ladder per key)
+                enc = torch.zeros((n, 1 + B), dtype=torch.uint8, device=dev)
+                timed("%s encode (compressed SEC1)" % curve, n, lambda: ctx.encode_points_dev(curve, pts, True, enc))
+                timed("%s decodePoint (compressed SEC1)" % curve, n, lambda: ctx.decode_points_dev(curve, enc, out, st))
+                assert torch.equal(out, pts) and bool((st == 0).all())
+                timed("%s KeyPair#validate (curve equation only)" % curve, n,
+                      lambda: ctx.validate_dev(curve, pts, None, False, st))
+                assert bool((st == 0).all())
+                timed("%s KeyPair#validate (with n*P == O)" % curve, n,
+                      lambda: ctx.validate_dev(curve, pts, None, True, st))
+                assert bool((st == 0).all())
         if curve == "ed25519":
             # EdDSA verify on valid signatures (A = aG, R = rG, S = r + h a; built with the fixed-base
             # kernel + hashlib), 48-byte messages

@@ -361,6 +361,109 @@ function genDecompress(name) {
   return cases;
 }
 
+// ------------------------------------------------------------ codec_<curve>.json
+// BaseCurve#decodePoint / BasePoint#encode (base.js:270-311), KeyPair#validate
+// (ec/key.js:41-52); for ed25519 EDDSA#decodePoint / encodePoint (eddsa/index.js:94-109),
+// EdwardsCurve#validate (edwards.js:99-112) and P.mul(n).isInfinity().
+function genCodec(name) {
+  var c = elliptic.curves[name].curve;
+  var L = flen(c);
+  var rng = new Prng('ellgpu-golden-v1:codec:' + name);
+  var N = Math.max(8, COUNTS[name] >> 1);
+  var out = { decode: [], encode: [], validate: [] };
+  function tohex(arr) { return Buffer.from(arr).toString('hex'); }
+  if (c.type === 'short') {
+    var ec = new elliptic.ec(name);
+    var dec = function(bytes) {
+      var o = { enc: tohex(bytes) };
+      try { o.r = affine(c, c.decodePoint(bytes)); } catch (e) { o.r = { throws: e.message }; }
+      out.decode.push(o);
+    };
+    var val = function(x, y) {
+      var o = { x: hex(x, L), y: hex(y, L) };
+      var v = ec.keyFromPublic({ x: o.x, y: o.y }).validate();
+      o.result = v.result; o.reason = v.reason;
+      out.validate.push(o);
+    };
+    for (var i = 0; i < N; i++) {
+      var P = c.g.mul(rng.below(c.n.subn(1)).addn(1));
+      var un = P.encode('array', false), co = P.encode('array', true);
+      out.encode.push({ x: hex(P.getX(), L), y: hex(P.getY(), L), compact: tohex(co), full: tohex(un) });
+      dec(un);
+      var odd = P.getY().isOdd();
+      dec([odd ? 7 : 6].concat(un.slice(1)));             // hybrid, consistent
+      dec([odd ? 6 : 7].concat(un.slice(1)));             // hybrid, contradicting -> assert
+      if (name !== 'p224') { dec(co); dec([co[0] ^ 1].concat(co.slice(1))); }
+      dec([[0, 1, 5, 8, 0xff][i % 5]].concat(un.slice(1)));     // unknown prefix, long form
+      dec([[0, 4, 6, 0x12][i % 4]].concat(co.slice(1)));       // long-form prefix on a short string
+      dec([[2, 3][i % 2]].concat(un.slice(1)));                 // short-form prefix on a long string
+      // not on the curve: decodePoint does not check, validate does
+      var bx = rng.below(c.p), by = rng.below(c.p);
+      dec([4].concat(bx.toArray('be', L), by.toArray('be', L)));
+      val(P.getX(), P.getY());
+      val(bx, by);
+      val(P.getX(), P.getY().addn(1).umod(c.p));
+      if (name !== 'p224') dec([2 + (i & 1)].concat(rng.below(c.p).toArray('be', L)));   // ~half invalid
+    }
+    // coordinates >= p are reduced by Point's toRed
+    if (c.p.bitLength() % 8 === 0 || name === 'p521') {
+      var big = new BN(1).ushln(L * 8).subn(1 + 5);
+      dec([4].concat(big.toArray('be', L), c.p.addn(3).toArray('be', L)));
+      if (name !== 'p224') { dec([2].concat(c.p.addn(1).toArray('be', L))); dec([3].concat(big.toArray('be', L))); }
+      val(c.g.getX().add(c.p), c.g.getY());
+    }
+    val(new BN(0), new BN(0));
+    val(c.g.getX(), c.g.getY());
+    val(c.g.getX(), c.p.sub(c.g.getY()));
+  } else {
+    var ed = new elliptic.eddsa(name);
+    var edec = function(bytes) {
+      var o = { enc: tohex(bytes) };
+      try {
+        var p = ed.decodePoint(bytes);
+        o.r = { x: hex(p.getX(), L), y: hex(p.getY(), L) };
+      } catch (e) { o.r = { throws: e.message }; }
+      out.decode.push(o);
+    };
+    var eval_ = function(p) {
+      var o = { x: hex(p.getX(), L), y: hex(p.getY(), L) };
+      o.on_curve = c.validate(c.point(o.x, o.y));
+      o.order_ok = c.point(o.x, o.y).mul(c.n).isInfinity();
+      out.validate.push(o);
+    };
+    // a point of order 8 (y from the well-known small-order encodings), via decodePoint
+    var t8 = ed.decodePoint('26e8958fc2b227b045c3f489f2ef98f0d5dfac05d3c63339b13802886d53fc05');
+    for (var j = 0; j < N; j++) {
+      var Q = c.g.mul(rng.below(c.n.subn(1)).addn(1));
+      var enc = ed.encodePoint(Q);
+      out.encode.push({ x: hex(Q.getX(), L), y: hex(Q.getY(), L), compact: tohex(enc) });
+      edec(enc);
+      edec(enc.slice(0, 31).concat(enc[31] ^ 0x80));
+      edec(Array.prototype.slice.call(rng.bytes(32)));                // ~half invalid
+      eval_(Q);
+      var M = Q.add(j & 1 ? t8 : t8.dbl());                          // mixed order: on curve, n*M != O
+      eval_(M);
+      out.validate.push({ x: hex(Q.getX(), L), y: hex(Q.getY().addn(1).umod(c.p), L), on_curve: false, order_ok: null });
+    }
+    eval_(t8); eval_(t8.dbl()); eval_(t8.dbl().dbl());
+    eval_(c.point(null, null, null));                                 // identity (0, 1)
+    ['0100000000000000000000000000000000000000000000000000000000000000',
+      '0100000000000000000000000000000000000000000000000000000000000080',
+      '0000000000000000000000000000000000000000000000000000000000000000',
+      'ecffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff7f',
+      'edffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff7f',
+      'eeffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff',
+      'ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff'].forEach(function(h) {
+      edec(Array.prototype.slice.call(Buffer.from(h, 'hex')));
+    });
+    // the third off-curve entry above was not produced by the reference's validate: fix that
+    out.validate.forEach(function(o) {
+      if (o.order_ok === null) { o.on_curve = c.validate(c.point(o.x, o.y)); delete o.order_ok; }
+    });
+  }
+  return out;
+}
+
 // ------------------------------------------------------ eddsa_verify_ed25519.json
 // EDDSA#verify (eddsa/index.js:52-63) on the official ed25519 sign.input vectors the
 // reference ships (test/fixtures/sign.input), plus corrupted / malformed variants.
@@ -709,6 +812,9 @@ SHORT.forEach(function(name) {
 });
 ['secp256k1', 'p192', 'p256', 'p384', 'p521', 'ed25519'].forEach(function(name) {
   write('decompress_' + name + '.json', genDecompress(name));
+});
+SHORT.concat(['ed25519']).forEach(function(name) {
+  write('codec_' + name + '.json', genCodec(name));
 });
 write('eddsa_verify_ed25519.json', genEddsa());
 write('eddsa_sign_ed25519.json', genEddsaSign());
