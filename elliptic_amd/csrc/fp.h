@@ -44,6 +44,18 @@ struct Fe {
 // and the CPU unit-test build) use the portable operand-scanning code.
 // ELL_MUL_CHAIN = 1: single-accumulator-chain blocks (one column per asm statement, the
 // compiler assembles the next column's (X.hi, E) pair); 0: two-column blocks + carry combines.
+// ELL_P521_INLINE = 1: the 17-limb multiply / square are inlined like the smaller fields'.  As
+// function calls their 34 + 17 operand words do not fit the 32 argument VGPRs, and everything
+// live across a call goes through the stack: 1.2-1.6 KB of scratch per lane and half the
+// throughput (3.6 M P*k/s against 6.8 M/s inlined, scratch 0).
+#ifndef ELL_P521_INLINE
+#define ELL_P521_INLINE 1
+#endif
+// ELL_P521_JTABLE = 1: p521 keeps the signed-window ladder over a Jacobian table; the odd-digit
+// affine-table ladder of the smaller curves measures slower there (4.8 M/s)
+#ifndef ELL_P521_JTABLE
+#define ELL_P521_JTABLE 1
+#endif
 #ifndef ELL_MUL_CHAIN
 #define ELL_MUL_CHAIN 1
 #endif
@@ -1123,8 +1135,13 @@ struct FpP521 {
   }
   static ELL_HD_NOINLINE El mul_call(El a, El b) { return mul_inline(a, b); }
   static ELL_HD_NOINLINE El sqr_call(El a) { return sqr_inline(a); }
+#if ELL_P521_INLINE
+  ELL_HD static El mul(const El& a, const El& b) { return mul_inline(a, b); }
+  ELL_HD static El sqr(const El& a) { return sqr_inline(a); }
+#else
   ELL_HD static El mul(const El& a, const El& b) { return mul_call(a, b); }
   ELL_HD static El sqr(const El& a) { return sqr_call(a); }
+#endif
   ELL_HD static El sqr_n(El a, int n) {
     ELL_NOUNROLL
     for (int i = 0; i < n; i++) a = sqr(a);

@@ -160,7 +160,7 @@ struct Work {
       J r = LD::template run_odd_w4<2, NNIB>(ds, tbl, negmask, evenmask);
       r.Z = F::mul(r.Z, zg);
       return r;
-    } else if constexpr (L > 12) {
+    } else if constexpr (L > 12 && ELL_P521_JTABLE) {
       // p521: measured faster with the plain signed-window ladder over a Jacobian table (the
       // 16 affine slots hold its 8 Jacobian entries)
       static_assert(16 * sizeof(A) >= 8 * sizeof(J), "table slot too small");
