@@ -14,6 +14,7 @@
 #include "curve_consts.h"
 #include "ladder.h"
 #include "sha512.h"
+#include "hmac_drbg512.h"
 
 #ifndef ELL_COMB_BITS_256
 #define ELL_COMB_BITS_256 16
@@ -333,16 +334,21 @@ struct EdWork {
   // as in the reference.  sig = R || S and pub = A in their 32-byte wire encodings.
   // hashInt (eddsa/index.js:65-70): a 64-byte digest read little-endian, mod n -> plain limbs.
   // h = (hi * 2^256 + lo) mod n: the Montgomery image of hi IS hi * 2^256 mod n.
-  ELL_HD static void hash_int(u32 (&h)[8], const u8 (&digest)[64]) {
+  // The digest arrives as SHA-512's eight big-endian 64-bit state words; little-endian limb 2k
+  // of the byte string is the byte-swapped high half of word k, limb 2k + 1 the low half.
+  ELL_HD static void digest_limbs(u32 (&lo)[8], u32 (&hi)[8], const u64 (&st)[8]) {
+    ELL_UNROLL
+    for (int k = 0; k < 4; k++) {
+      lo[2 * k] = __builtin_bswap32((u32)(st[k] >> 32));
+      lo[2 * k + 1] = __builtin_bswap32((u32)st[k]);
+      hi[2 * k] = __builtin_bswap32((u32)(st[4 + k] >> 32));
+      hi[2 * k + 1] = __builtin_bswap32((u32)st[4 + k]);
+    }
+  }
+  ELL_HD static void hash_int(u32 (&h)[8], const u64 (&st)[8]) {
     typedef FpMont<consts::ED25519_N> Fn;
     u32 lo[8], hi[8];
-    ELL_UNROLL
-    for (int l = 0; l < 8; l++) {
-      lo[l] = (u32)digest[4 * l] | ((u32)digest[4 * l + 1] << 8) | ((u32)digest[4 * l + 2] << 16) |
-              ((u32)digest[4 * l + 3] << 24);
-      hi[l] = (u32)digest[32 + 4 * l] | ((u32)digest[32 + 4 * l + 1] << 8) |
-              ((u32)digest[32 + 4 * l + 2] << 16) | ((u32)digest[32 + 4 * l + 3] << 24);
-    }
+    digest_limbs(lo, hi, st);
     Fn::El hm = Fn::from_plain(hi);
     u32 lor[8];
     Fn::to_plain(lor, Fn::from_plain(lo));
@@ -351,23 +357,38 @@ struct EdWork {
     Fn::El hsum = Fn::add(hm, lom);
     bn_copy<8>(h, hsum.v);
   }
+  // the four big-endian 64-bit words of a 32-byte string given as little-endian limbs
+  ELL_HD static void le_limbs_to_words(u64* w, const u32 (&t)[8]) {
+    ELL_UNROLL
+    for (int k = 0; k < 4; k++)
+      w[k] = ((u64)__builtin_bswap32(t[2 * k]) << 32) | (u64)__builtin_bswap32(t[2 * k + 1]);
+  }
+  // ... and of 32 bytes in memory
+  ELL_HD static void bytes_to_words(u64* w, const u8* p) {
+    ELL_UNROLL
+    for (int k = 0; k < 4; k++) {
+      u64 x;
+      __builtin_memcpy(&x, p + 8 * k, 8);
+      w[k] = __builtin_bswap64(x);
+    }
+  }
 
   // ---- EdDSA sign (eddsa/index.js:32-50 with KeyPair.fromSecret, eddsa/key.js:42-75) ----
   // stage 1: hash = SHA-512(secret); a = the clamped first half (key.js:51-62), prefix = the
   // second half; r = hashInt(prefix || M).  Both scalars go out as 32-byte big-endian inputs
   // of the fixed-base kernel: scal[i] = a, scal[n + i] = r.
   ELL_HD static void sign_pre(size_t i, size_t n, const u8* secret, const u8* msg, u64 msg_len, u8* scal) {
-    u8 hsh[64];
-    Sha512::hash3(hsh, secret, 32, nullptr, 0, nullptr, 0);
-    hsh[0] &= 248;
-    hsh[31] &= 127;
-    hsh[31] |= 64;
-    ELL_UNROLL
-    for (int j = 0; j < 32; j++) scal[i * 32 + j] = hsh[31 - j];
-    u8 digest[64];
-    Sha512::hash3(digest, hsh + 32, 32, msg, msg_len, nullptr, 0);
+    u64 hs[8];
+    sha512_prefixed<0>(hs, nullptr, secret, 32);
+    u32 a[8], pf[8];
+    digest_limbs(a, pf, hs);
+    a[0] &= ~7u;                                   // hash[0] &= 248
+    a[7] = (a[7] & 0x7FFFFFFFu) | 0x40000000u;     // hash[31] &= 127, |= 64
+    store_be<8>(scal + i * 32, a, 32);
+    u64 st[8];
+    sha512_prefixed<4>(st, hs + 4, msg, msg_len);
     u32 r[8];
-    hash_int(r, digest);
+    hash_int(r, st);
     store_be<8>(scal + (n + i) * 32, r, 32);
   }
   // encodePoint (eddsa/index.js:94-98) of an affine point given as x || y big-endian
@@ -381,13 +402,21 @@ struct EdWork {
   ELL_HD static void sign_post(size_t i, size_t n, const u8* msg, u64 msg_len, const u8* scal,
                                const u8* xy, u8* sig, u8* pub) {
     typedef FpMont<consts::ED25519_N> Fn;
-    u8 aenc[32], renc[32];
-    encode_affine(aenc, xy + i * 64);
-    encode_affine(renc, xy + (n + i) * 64);
-    u8 digest[64];
-    Sha512::hash3(digest, renc, 32, aenc, 32, msg, msg_len);
+    // encodePoint: y little-endian with x's parity in the top bit, as limbs
+    u32 ae[8], re[8], xa[8], xr[8];
+    load_be<8>(xa, xy + i * 64, 32);
+    load_be<8>(ae, xy + i * 64 + 32, 32);
+    load_be<8>(xr, xy + (n + i) * 64, 32);
+    load_be<8>(re, xy + (n + i) * 64 + 32, 32);
+    ae[7] |= (xa[0] & 1u) << 31;
+    re[7] |= (xr[0] & 1u) << 31;
+    u64 pre[8];
+    le_limbs_to_words(pre, re);
+    le_limbs_to_words(pre + 4, ae);
+    u64 st[8];
+    sha512_prefixed<8>(st, pre, msg, msg_len);
     u32 h[8], a[8], r[8];
-    hash_int(h, digest);
+    hash_int(h, st);
     load_be<8>(a, scal + i * 32, 32);
     load_be<8>(r, scal + (n + i) * 32, 32);
     u32 ha[8];
@@ -397,17 +426,13 @@ struct EdWork {
     bn_copy<8>(y.v, r);
     Fn::El S = Fn::add(x, y);                     // both canonical residues: plain modular add
     ELL_UNROLL
-    for (int j = 0; j < 32; j++) sig[i * 64 + j] = renc[j];
-    ELL_UNROLL
-    for (int l = 0; l < 8; l++) {
-      sig[i * 64 + 32 + 4 * l] = (u8)S.v[l];
-      sig[i * 64 + 32 + 4 * l + 1] = (u8)(S.v[l] >> 8);
-      sig[i * 64 + 32 + 4 * l + 2] = (u8)(S.v[l] >> 16);
-      sig[i * 64 + 32 + 4 * l + 3] = (u8)(S.v[l] >> 24);
+    for (int l = 0; l < 8; l++) {                  // little-endian limbs = the wire bytes
+      __builtin_memcpy(sig + i * 64 + 4 * l, &re[l], 4);
+      __builtin_memcpy(sig + i * 64 + 32 + 4 * l, &S.v[l], 4);
     }
     if (pub) {
       ELL_UNROLL
-      for (int j = 0; j < 32; j++) pub[i * 32 + j] = aenc[j];
+      for (int l = 0; l < 8; l++) __builtin_memcpy(pub + i * 32 + 4 * l, &ae[l], 4);
     }
   }
 
@@ -423,10 +448,12 @@ struct EdWork {
       nn[l] = C::n[l];
     }
     bool s_ok = !bn_geq<8>(S, nn);
-    u8 digest[64];
-    Sha512::hash3(digest, sig, 32, pub, 32, msg, msg_len);
+    u64 pre[8], st[8];
+    bytes_to_words(pre, sig);
+    bytes_to_words(pre + 4, pub);
+    sha512_prefixed<8>(st, pre, msg, msg_len);
     u32 h[8];
-    hash_int(h, digest);
+    hash_int(h, st);
 
     P A, R;
     bool a_ok = decode_point(A, pub);

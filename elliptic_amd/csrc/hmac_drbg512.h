@@ -60,6 +60,52 @@ struct Sha512W {
   }
 };
 
+// SHA-512 of  prefix (PW 64-bit big-endian words held in registers) || msg[0..len): EdDSA's
+// hashInt inputs (eddsa/index.js:65-70) are 0, 32 or 64 known bytes followed by the message.
+// The prefix words and every whole message word are assembled without byte loops (the message
+// is read with 8-byte loads + a byte swap); only the word holding the end of the message is put
+// together byte by byte.
+template <int PW>
+ELL_HD void sha512_prefixed(u64 (&st)[8], const u64* pre, const u8* msg, u64 len) {
+  typedef Sha512W<8> H;
+  static_assert(PW >= 0 && PW < 14, "prefix must leave room in the first block");
+  H::iv(st);
+  const u64 total = 8ull * PW + len;
+  const u64 nblk = (total + 1 + 16 + 127) / 128;
+  // message word starting at byte `off` of msg (may lie beyond its end: padding)
+  auto msg_word = [&](u64 off) -> u64 {
+    if (off + 8 <= len) {
+      u64 x;
+      __builtin_memcpy(&x, msg + off, 8);
+      return __builtin_bswap64(x);
+    }
+    u64 x = 0;
+    ELL_UNROLL
+    for (int b = 0; b < 8; b++) {
+      u64 j = off + b;
+      u64 v = j < len ? (u64)msg[j] : (j == len ? 0x80ull : 0ull);
+      x = (x << 8) | v;
+    }
+    return x;
+  };
+  ELL_NOUNROLL
+  for (u64 blk = 0; blk < nblk; blk++) {
+    u64 w[16];
+    const bool last = blk + 1 == nblk;
+    ELL_UNROLL
+    for (int t = 0; t < 16; t++) {
+      if (t < PW) {
+        // prefix words live in block 0 only
+        w[t] = blk == 0 ? pre[t] : msg_word(blk * 128 + 8 * t - 8ull * PW);
+      } else {
+        w[t] = msg_word(blk * 128 + 8 * t - 8ull * PW);
+      }
+    }
+    if (last) { w[14] = 0; w[15] = total * 8; }       // 128-bit length; messages are < 2^61 bytes
+    H::compress(st, w);
+  }
+}
+
 template <int OUTW, int SEEDW>
 struct HmacDrbg512 {
   typedef Sha512W<OUTW> H;
