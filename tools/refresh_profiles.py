@@ -17,6 +17,8 @@ MAP = {
     "configs.jsonl": "configs.jsonl",
     "host_path.jsonl": "host_path.jsonl",
     "latency.jsonl": "latency.jsonl",
+    "js_bench.jsonl": "js_bench.jsonl",
+    "js_selftest.log": "js_selftest.log",
     "bench_under_rocprof.log": "bench_under_rocprof.log",
     "rocprof_stats.txt": "rocprof_kernel_stats.txt",
     "rocprof_fw.txt": "rocprof_pmc_fetch_write.txt",

@@ -27,6 +27,8 @@ timeout 200 tools/microbench/_build/valu_patterns > $O/valu_patterns.log 2>&1
 timeout 600 python tools/bench_configs.py 2>/dev/null | grep '"config"' > $O/configs.jsonl
 timeout 300 python tools/bench_host_path.py --reps 8 2>/dev/null | grep '"config"' > $O/host_path.jsonl
 timeout 300 python tools/bench_latency.py 2>/dev/null | grep '^{' > $O/latency.jsonl
+timeout 120 node elliptic_amd/js/bench.js 2>/dev/null | grep '^{' > $O/js_bench.jsonl
+timeout 120 node elliptic_amd/js/selftest.js > $O/js_selftest.log 2>&1
 timeout 150 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o stats -- python bench.py > $O/bench_under_rocprof.log 2>&1
 # FETCH_SIZE and WRITE_SIZE do not fit one pass ("exceeds the capabilities of the hardware")
 timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fwa -o fwa -- python bench.py --steps 2 --warmup 1 > $O/pmc_fwa.log 2>&1
