@@ -36,6 +36,12 @@ _SIGS = {
     "ellgpu_encode_points_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, c_u8p, ctypes.c_void_p]),
     "ellgpu_validate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, ctypes.c_int, c_u8p]),
     "ellgpu_validate_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, ctypes.c_int, c_u8p, ctypes.c_void_p]),
+    "ellgpu_sig_from_der": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "ellgpu_sig_from_der_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
+    "ellgpu_sig_to_der": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, ctypes.c_size_t, c_u8p]),
+    "ellgpu_sig_to_der_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_void_p]),
+    "ellgpu_ecdsa_verify_wire": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, ctypes.c_size_t, c_u8p, c_u8p, ctypes.c_size_t, c_u8p, c_u8p]),
+    "ellgpu_ecdsa_verify_wire_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, ctypes.c_size_t, c_u8p, c_u8p, ctypes.c_size_t, c_u8p, c_u8p, ctypes.c_void_p]),
     "ellgpu_decompress_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
     "ellgpu_ecdsa_sign": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, c_u8p, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p]),
     "ellgpu_ecdsa_sign_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, c_u8p, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),

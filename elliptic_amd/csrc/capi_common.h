@@ -154,6 +154,44 @@ int ellgpu_validate_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy,
   return finish(ctx, ctx->eng->validate_dev(curve, n, xy, inf, check_order, out_status));
 }
 
+// signature DER codec and EC#verify on wire formats
+int ellgpu_sig_from_der(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* der, size_t stride,
+                        const uint32_t* der_len, uint8_t* out_r, uint8_t* out_s, uint8_t* out_status) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->sig_from_der_host(curve, n, der, stride, der_len, out_r, out_s, out_status));
+}
+int ellgpu_sig_from_der_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* der, size_t stride,
+                            const uint32_t* der_len, uint8_t* out_r, uint8_t* out_s, uint8_t* out_status,
+                            void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->sig_from_der_dev(curve, n, der, stride, der_len, out_r, out_s, out_status));
+}
+int ellgpu_sig_to_der(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* r, const uint8_t* s,
+                      uint8_t* out_der, size_t stride, uint32_t* out_len) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->sig_to_der_host(curve, n, r, s, out_der, stride, out_len));
+}
+int ellgpu_sig_to_der_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* r, const uint8_t* s,
+                          uint8_t* out_der, size_t stride, uint32_t* out_len, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->sig_to_der_dev(curve, n, r, s, out_der, stride, out_len));
+}
+int ellgpu_ecdsa_verify_wire(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                             int msg_bits, const uint8_t* der, size_t der_stride, const uint32_t* der_len,
+                             const uint8_t* pub_enc, size_t pub_len, uint8_t* out_ok, uint8_t* out_err) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->ecdsa_verify_wire_host(curve, n, hash, hash_len, msg_bits, der, der_stride,
+                                                      der_len, pub_enc, pub_len, out_ok, out_err));
+}
+int ellgpu_ecdsa_verify_wire_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                                 int msg_bits, const uint8_t* der, size_t der_stride,
+                                 const uint32_t* der_len, const uint8_t* pub_enc, size_t pub_len,
+                                 uint8_t* out_ok, uint8_t* out_err, void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->ecdsa_verify_wire_dev(curve, n, hash, hash_len, msg_bits, der, der_stride,
+                                                     der_len, pub_enc, pub_len, out_ok, out_err));
+}
+
 int ellgpu_ecdsa_sign(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len, int msg_bits,
                       const uint8_t* priv, const uint8_t* nonces, int canonical, uint8_t* out_r,
                       uint8_t* out_s, uint8_t* out_recid, uint8_t* out_ok) {

@@ -23,6 +23,9 @@
 #ifndef ELL_INV_BATCH
 #define ELL_INV_BATCH 16
 #endif
+#ifndef ELL_MULVAR_MIN_WAVES
+#define ELL_MULVAR_MIN_WAVES 4
+#endif
 #ifndef ELL_ECDSA_MIN_WAVES
 #define ELL_ECDSA_MIN_WAVES 3
 #endif
@@ -37,7 +40,7 @@ struct FnMulVar {
   static constexpr const char* NAME = "mul_var";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
-  static constexpr int MIN_WAVES = W::L <= 8 ? 4 : 1;       // <= 128 VGPRs for 256-bit curves: +2..4 % despite ~50 B of spills
+  static constexpr int MIN_WAVES = W::L <= 8 ? ELL_MULVAR_MIN_WAVES : 1;   // <= 128 VGPRs for 256-bit curves: +2..4 % despite ~50 B of spills
   size_t n; const u8* k; const u8* xy; typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) W::mul_var(i, n, k, xy, tbl, ds, jac);
@@ -214,6 +217,36 @@ struct FnValidatePoint {
       W::validate_point(i, xy, inf, status);
       if (scal) W::fill_order(i, scal);
     }
+  }
+};
+template <class CV>
+struct FnSigFromDer {
+  static constexpr const char* NAME = "sig_from_der";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* der; size_t stride; const u32* der_len; u8* r; u8* s; u8* status;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::sig_from_der(i, der, stride, der_len, r, s, status);
+  }
+};
+template <class CV>
+struct FnSigToDer {
+  static constexpr const char* NAME = "sig_to_der";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* r; const u8* s; u8* out; size_t stride; u32* out_len;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::sig_to_der(i, r, s, out, stride, out_len);
+  }
+};
+template <class CV>
+struct FnWireStatus {
+  static constexpr const char* NAME = "wire_status";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* key_st; const u8* sig_st; u8* ok; u8* err;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::wire_status(i, key_st, sig_st, ok, err);
   }
 };
 struct FnEdDecodePoint {
@@ -395,7 +428,7 @@ class Engine {
 
   // ---- scratch arena: a few grow-only device buffers ----------------------
   struct Buf { void* p = nullptr; size_t cap = 0; };
-  enum { S_TBL = 0, S_JAC, S_PRE, S_U12, S_VALID, S_COUNT };
+  enum { S_TBL = 0, S_JAC, S_PRE, S_U12, S_VALID, S_WIRE, S_COUNT };
   enum { G_IN0 = 0, G_IN1, G_IN2, G_IN3, G_IN4, G_OUT0, G_OUT1, G_COUNT };
 
   void* grow(Buf& b, size_t bytes) {
@@ -449,6 +482,8 @@ class Engine {
   int decompress_chunk(size_t n, const u8* x, const u8* odd, u8* out_xy, u8* out_ok);
   template <class CV>
   int codec_chunk(int op, size_t n, const u8* in, size_t len, int flag, const u8* inf, u8* out, u8* status);
+  template <class CV>
+  int der_chunk(int op, size_t n, const u8* a, const u8* b, size_t stride, u32* lens, u8* o1, u8* o2, u8* o3);
   template <class CV>
   int sign_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* priv, const u8* nonces,
                  int canonical, u8* out_r, u8* out_s, u8* out_recid, u8* out_ok);
@@ -968,6 +1003,140 @@ class Engine {
     });
   }
 
+  // ---- signature DER codec and EC#verify on wire formats ------------------------------
+  enum { OP_FROM_DER = 0, OP_TO_DER = 1, OP_WIRE_STATUS = 2 };
+  int check_short(int curve, const CurveInfo*& ci) {
+    ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (curve >= CURVE_ED25519) return fail(E_UNSUPPORTED, "ECDSA signatures belong to the short Weierstrass presets");
+    return E_OK;
+  }
+  // Signature#_importDER (ec/signature.js:83-147): der = n records of `stride` bytes, der_len[i] used
+  int sig_from_der_dev(int curve, size_t n, const u8* der, size_t stride, const u32* der_len,
+                       u8* out_r, u8* out_s, u8* out_status) {
+    const CurveInfo* ci;
+    int rc = check_short(curve, ci);
+    if (rc) return rc;
+    if (n && (!der || !der_len || !out_r || !out_s || !out_status)) return fail(E_ARG, "null pointer");
+    if (stride == 0) return fail(E_ARG, "stride must be positive");
+    const size_t NB = ci->order_bytes;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      ELL_SHORT_DISPATCH(curve, rc = der_chunk<CV>(OP_FROM_DER, m, der + o * stride, nullptr, stride,
+                                                   (u32*)der_len + o, out_r + o * NB, out_s + o * NB,
+                                                   out_status + o));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+  // Signature#toDER (ec/signature.js:149-176): out = n records of `stride` >= 2 NB + 9 bytes
+  int sig_to_der_dev(int curve, size_t n, const u8* r, const u8* s, u8* out_der, size_t stride, u32* out_len) {
+    const CurveInfo* ci;
+    int rc = check_short(curve, ci);
+    if (rc) return rc;
+    if (n && (!r || !s || !out_der || !out_len)) return fail(E_ARG, "null pointer");
+    const size_t NB = ci->order_bytes;
+    if (stride < 2 * NB + 9) return fail(E_ARG, "stride must be at least 2 * order_bytes + 9");
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      ELL_SHORT_DISPATCH(curve, rc = der_chunk<CV>(OP_TO_DER, m, r + o * NB, s + o * NB, stride, out_len + o,
+                                                   out_der + o * stride, nullptr, nullptr));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+  // EC#verify(msg, derSignature, encodedKey) (ec/index.js:188-229 with keyFromPublic ->
+  // decodePoint and new Signature(der)): decode, parse and verify on the device
+  int ecdsa_verify_wire_dev(int curve, size_t n, const u8* hash, int hash_len, int msg_bits,
+                            const u8* der, size_t der_stride, const u32* der_len, const u8* pub_enc,
+                            size_t pub_len, u8* ok, u8* err) {
+    const CurveInfo* ci;
+    int rc = check_short(curve, ci);
+    if (rc) return rc;
+    if (n && (!hash || !der || !der_len || !pub_enc || !ok)) return fail(E_ARG, "null pointer");
+    if (hash_len <= 0 || der_stride == 0 || pub_len == 0) return fail(E_ARG, "bad hash_len / stride / pub_len");
+    const size_t B = ci->field_bytes, NB = ci->order_bytes, HL = (size_t)hash_len;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      u8* tmp = (u8*)scratch(S_WIRE, m * (2 * NB + 2 * B + 2));
+      if (!tmp) return fail(E_NOMEM, "scratch allocation failed");
+      u8* r = tmp;
+      u8* s = r + m * NB;
+      u8* xy = s + m * NB;
+      u8* kst = xy + m * 2 * B;
+      u8* sst = kst + m;
+      rc = decode_points_dev(curve, m, pub_enc + o * pub_len, pub_len, xy, kst);
+      if (rc) return rc;
+      rc = sig_from_der_dev(curve, m, der + o * der_stride, der_stride, der_len + o, r, s, sst);
+      if (rc) return rc;
+      rc = ecdsa_verify_dev(curve, m, hash + o * HL, hash_len, msg_bits, r, s, xy, ok + o);
+      if (rc) return rc;
+      ELL_SHORT_DISPATCH(curve, rc = der_chunk<CV>(OP_WIRE_STATUS, m, kst, sst, 0, nullptr, ok + o,
+                                                   err ? err + o : nullptr, nullptr));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+  int sig_from_der_host(int curve, size_t n, const u8* der, size_t stride, const u32* der_len,
+                        u8* out_r, u8* out_s, u8* out_status) {
+    const CurveInfo* ci;
+    int rc = check_short(curve, ci);
+    if (rc) return rc;
+    if (n && (!der || !der_len || !out_r || !out_s || !out_status)) return fail(E_ARG, "null pointer");
+    const size_t NB = ci->order_bytes;
+    u8* dd = out_buf(G_IN0, n * stride);
+    u8* dl = out_buf(G_IN1, n * 4);
+    u8* dr = out_buf(G_OUT0, n * NB);
+    u8* ds = out_buf(G_OUT1, n * NB);
+    u8* dst = out_buf(G_IN2, n);
+    if (!dd || !dl || !dr || !ds || !dst) return fail(E_NOMEM, "staging allocation failed");
+    HostIn ins[2] = {{dd, der, stride}, {dl, (const u8*)der_len, 4}};
+    HostOut outs[3] = {{out_r, dr, NB}, {out_s, ds, NB}, {out_status, dst, 1}};
+    return pipelined(n, ins, 2, outs, 3, [&](size_t o, size_t m) {
+      return sig_from_der_dev(curve, m, dd + o * stride, stride, (const u32*)dl + o, dr + o * NB, ds + o * NB, dst + o);
+    });
+  }
+  int sig_to_der_host(int curve, size_t n, const u8* r, const u8* s, u8* out_der, size_t stride, u32* out_len) {
+    const CurveInfo* ci;
+    int rc = check_short(curve, ci);
+    if (rc) return rc;
+    if (n && (!r || !s || !out_der || !out_len)) return fail(E_ARG, "null pointer");
+    const size_t NB = ci->order_bytes;
+    u8* dr = out_buf(G_IN0, n * NB);
+    u8* ds = out_buf(G_IN1, n * NB);
+    u8* dd = out_buf(G_OUT0, n * stride);
+    u8* dl = out_buf(G_OUT1, n * 4);
+    if (!dr || !ds || !dd || !dl) return fail(E_NOMEM, "staging allocation failed");
+    HostIn ins[2] = {{dr, r, NB}, {ds, s, NB}};
+    HostOut outs[2] = {{out_der, dd, stride}, {(u8*)out_len, dl, 4}};
+    return pipelined(n, ins, 2, outs, 2, [&](size_t o, size_t m) {
+      return sig_to_der_dev(curve, m, dr + o * NB, ds + o * NB, dd + o * stride, stride, (u32*)dl + o);
+    });
+  }
+  int ecdsa_verify_wire_host(int curve, size_t n, const u8* hash, int hash_len, int msg_bits,
+                             const u8* der, size_t der_stride, const u32* der_len, const u8* pub_enc,
+                             size_t pub_len, u8* ok, u8* err) {
+    const CurveInfo* ci;
+    int rc = check_short(curve, ci);
+    if (rc) return rc;
+    if (n && (!hash || !der || !der_len || !pub_enc || !ok)) return fail(E_ARG, "null pointer");
+    if (hash_len <= 0) return fail(E_ARG, "bad hash_len");
+    const size_t HL = (size_t)hash_len;
+    u8* dh = out_buf(G_IN0, n * HL);
+    u8* dd = out_buf(G_IN1, n * der_stride);
+    u8* dl = out_buf(G_IN2, n * 4);
+    u8* dq = out_buf(G_IN3, n * pub_len);
+    u8* dok = out_buf(G_OUT0, n);
+    u8* derr = out_buf(G_OUT1, n);
+    if (!dh || !dd || !dl || !dq || !dok || !derr) return fail(E_NOMEM, "staging allocation failed");
+    HostIn ins[4] = {{dh, hash, HL}, {dd, der, der_stride}, {dl, (const u8*)der_len, 4}, {dq, pub_enc, pub_len}};
+    HostOut outs[2] = {{ok, dok, 1}, {err, derr, 1}};
+    return pipelined(n, ins, 4, outs, err ? 2 : 1, [&](size_t o, size_t m) {
+      return ecdsa_verify_wire_dev(curve, m, dh + o * HL, hash_len, msg_bits, dd + o * der_stride, der_stride,
+                                   (const u32*)dl + o, dq + o * pub_len, pub_len, dok + o, derr + o);
+    });
+  }
+
   // ---- host-buffer wrappers: stage through device buffers --------------------
   u8* put(int slot, const void* host, size_t bytes) {
     if (!host) return nullptr;
@@ -1399,6 +1568,22 @@ int Engine<BK>::codec_chunk(int op, size_t n, const u8* in, size_t len, int flag
   if (rc) return rc;
   FnOrderStatus g{n, minf, status};
   bk.launch(g, n);
+  return E_OK;
+}
+template <class BK>
+template <class CV>
+int Engine<BK>::der_chunk(int op, size_t n, const u8* a, const u8* b, size_t stride, u32* lens, u8* o1, u8* o2,
+                          u8* o3) {
+  if (op == OP_FROM_DER) {
+    FnSigFromDer<CV> f{n, a, stride, lens, o1, o2, o3};
+    bk.launch(f, n);
+  } else if (op == OP_TO_DER) {
+    FnSigToDer<CV> f{n, a, b, o1, stride, lens};
+    bk.launch(f, n);
+  } else {
+    FnWireStatus<CV> f{n, a, b, o1, o2};
+    bk.launch(f, n);
+  }
   return E_OK;
 }
 template <class BK>

@@ -31,6 +31,8 @@ namespace ell {
   KW template int Engine<HipBackend>::decompress_chunk<CV>(size_t, const u8*, const u8*, u8*, u8*); \
   KW template int Engine<HipBackend>::codec_chunk<CV>(int, size_t, const u8*, size_t, int,         \
                                                       const u8*, u8*, u8*);                         \
+  KW template int Engine<HipBackend>::der_chunk<CV>(int, size_t, const u8*, const u8*, size_t,     \
+                                                    u32*, u8*, u8*, u8*);                           \
   KW template int Engine<HipBackend>::sign_chunk<CV>(size_t, const u8*, int, int, const u8*,       \
                                                      const u8*, int, u8*, u8*, u8*, u8*);           \
   KW template int Engine<HipBackend>::recover_chunk<CV>(size_t, const u8*, int, const u8*,         \

@@ -326,6 +326,121 @@ struct Work {
     store_fe(o + 1, a.x);
     if (!compact) store_fe(o + 1 + BYTES, a.y);
   }
+  // ---- signature DER codec (lib/elliptic/ec/signature.js) ---------------------------
+  // getLength (signature.js:30-59).  false = the reference's `false`; a length byte read past
+  // the end (JavaScript `undefined`) also ends in `return false` at the caller's next test.
+  ELL_HD static bool der_length(const u8* d, u64 dl, u64& place, u64& out) {
+    if (place >= dl) return false;
+    u32 initial = d[place++];
+    if (!(initial & 0x80u)) { out = initial; return true; }
+    u32 oct = initial & 0xFu;
+    if (oct == 0 || oct > 4) return false;                    // indefinite length or overflow
+    if (place < dl && d[place] == 0) return false;
+    u64 val = 0, off = place;
+    ELL_NOUNROLL
+    for (u32 i = 0; i < oct; i++, off++) val = ((val << 8) | (off < dl ? (u64)d[off] : 0ull)) & 0xFFFFFFFFull;
+    if (val <= 0x7F) return false;                            // leading zeroes
+    place = off;
+    out = val;
+    return true;
+  }
+  // Signature#_importDER (signature.js:83-147) of d[0..dl).  status 0: r and s written as
+  // NBYTES-wide big-endian integers; 1: the reference's `return false` ("Signature without r
+  // or s" is thrown by the constructor); 2: well-formed, but r or s is wider than NBYTES (hence
+  // >= n: EC#verify answers false) -- r and s are zeroed for 1 and 2.
+  enum { DER_OK = 0, DER_MALFORMED = 1, DER_TOO_WIDE = 2 };
+  ELL_HD static u32 der_parse(const u8* d, u64 dl, u64& r0, u64& rn, u64& s0, u64& sn) {
+    u64 p = 0;
+    if (!(p < dl && d[p] == 0x30)) return DER_MALFORMED;
+    p++;
+    u64 len;
+    if (!der_length(d, dl, p, len)) return DER_MALFORMED;
+    if (len + p != dl) return DER_MALFORMED;
+    if (!(p < dl && d[p] == 0x02)) return DER_MALFORMED;
+    p++;
+    u64 rlen;
+    if (!der_length(d, dl, p, rlen)) return DER_MALFORMED;
+    if (p < dl && (d[p] & 0x80u)) return DER_MALFORMED;
+    r0 = p;
+    p += rlen;
+    if (!(p < dl && d[p] == 0x02)) return DER_MALFORMED;       // also: r lies inside the buffer
+    p++;
+    u64 slen;
+    if (!der_length(d, dl, p, slen)) return DER_MALFORMED;
+    if (dl != slen + p) return DER_MALFORMED;
+    if (p < dl && (d[p] & 0x80u)) return DER_MALFORMED;
+    s0 = p;
+    rn = rlen;
+    sn = slen;
+    if (rn > 0 && d[r0] == 0) {
+      if (rn > 1 && (d[r0 + 1] & 0x80u)) { r0++; rn--; } else return DER_MALFORMED;
+    }
+    if (sn > 0 && d[s0] == 0) {
+      if (sn > 1 && (d[s0 + 1] & 0x80u)) { s0++; sn--; } else return DER_MALFORMED;
+    }
+    return (rn > (u64)NBYTES || sn > (u64)NBYTES) ? DER_TOO_WIDE : DER_OK;
+  }
+  ELL_HD static void sig_from_der(size_t i, const u8* der, size_t stride, const u32* der_len,
+                                  u8* out_r, u8* out_s, u8* status) {
+    const u8* d = der + i * stride;
+    u64 dl = der_len[i];
+    u64 r0 = 0, rn = 0, s0 = 0, sn = 0;
+    u32 st = dl > stride ? (u32)DER_MALFORMED : der_parse(d, dl, r0, rn, s0, sn);
+    u8* ro = out_r + i * NBYTES;
+    u8* so = out_s + i * NBYTES;
+    ELL_NOUNROLL
+    for (int j = 0; j < NBYTES; j++) {
+      u64 back = (u64)(NBYTES - j);                            // distance from the end
+      ro[j] = (st == DER_OK && back <= rn) ? d[r0 + rn - back] : (u8)0;
+      so[j] = (st == DER_OK && back <= sn) ? d[s0 + sn - back] : (u8)0;
+    }
+    status[i] = (u8)st;
+  }
+  // Signature#toDER (signature.js:149-176) of (r, s) given NBYTES wide; out_len[i] = bytes
+  // written at out + i * stride (stride >= 2 * NBYTES + 9; the rest of the record is zeroed).  s = 0 sends the reference into an
+  // endless loop (signature.js:162-164): reported as length 0.
+  ELL_HD static void sig_to_der(size_t i, const u8* r, const u8* s, u8* out, size_t stride, u32* out_len) {
+    const u8* rp = r + i * NBYTES;
+    const u8* sp = s + i * NBYTES;
+    u8* o = out + i * stride;
+    int rz = 0, sz = 0;                                        // leading zero bytes; BN#toArray() of 0 is [0]
+    while (rz < NBYTES - 1 && rp[rz] == 0) rz++;
+    while (sz < NBYTES && sp[sz] == 0) sz++;
+    if (sz == NBYTES) {
+      ELL_NOUNROLL
+      for (size_t j = 0; j < stride; j++) o[j] = 0;
+      out_len[i] = 0;
+      return;
+    }
+    int rn = NBYTES - rz, sn = NBYTES - sz;
+    int rpad = (rp[rz] & 0x80u) ? 1 : 0, spad = (sp[sz] & 0x80u) ? 1 : 0;
+    int body = 2 + rpad + rn + 2 + spad + sn;                  // both integer lengths are < 0x80
+    int pos = 0;
+    o[pos++] = 0x30;
+    if (body >= 0x80) o[pos++] = 0x81;                         // constructLength (signature.js:136-147)
+    o[pos++] = (u8)body;
+    o[pos++] = 0x02;
+    o[pos++] = (u8)(rpad + rn);
+    if (rpad) o[pos++] = 0;
+    ELL_NOUNROLL
+    for (int j = 0; j < rn; j++) o[pos++] = rp[rz + j];
+    o[pos++] = 0x02;
+    o[pos++] = (u8)(spad + sn);
+    if (spad) o[pos++] = 0;
+    ELL_NOUNROLL
+    for (int j = 0; j < sn; j++) o[pos++] = sp[sz + j];
+    out_len[i] = (u32)pos;
+    ELL_NOUNROLL
+    for (size_t j = (size_t)pos; j < stride; j++) o[j] = 0;     // the rest of the record is defined
+  }
+  // EC#verify on wire formats: exceptions in the reference's order (keyFromPublic first, then
+  // the Signature constructor); err 1..3 = decodePoint's status, 4 = 'Signature without r or s'
+  ELL_HD static void wire_status(size_t i, const u8* key_st, const u8* sig_st, u8* ok, u8* err) {
+    u32 e = key_st[i] ? key_st[i] : (sig_st[i] == DER_MALFORMED ? 4u : 0u);
+    if (e || sig_st[i] == DER_TOO_WIDE) ok[i] = 0;
+    if (err) err[i] = (u8)e;
+  }
+
   // KeyPair#validate (ec/key.js:41-52), first two tests: 1 = 'Invalid public key' (infinity),
   // 2 = 'Public key is not a point' (ShortCurve#validate short.js:205-216), else 0
   enum { VALIDATE_OK = 0, VALIDATE_INF = 1, VALIDATE_NOT_POINT = 2, VALIDATE_ORDER = 3 };

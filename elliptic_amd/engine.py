@@ -224,6 +224,72 @@ class Context:
                                                   1 if check_order else 0, out_status.data_ptr(),
                                                   self._stream()))
 
+    @staticmethod
+    def _pack_records(items, stride=None):
+        """list of byte strings -> ((n, stride) uint8 array, (n,) uint32 lengths)"""
+        n = len(items)
+        stride = max([stride or 1] + [len(x) for x in items])
+        buf = np.zeros((n, stride), np.uint8)
+        lens = np.zeros(n, np.uint32)
+        for i, x in enumerate(items):
+            buf[i, :len(x)] = np.frombuffer(bytes(x), np.uint8)
+            lens[i] = len(x)
+        return buf, lens
+
+    def sig_from_der(self, curve, sigs):
+        """Signature#_importDER per item (sigs: list of byte strings) -> (r, s, status);
+        status 0 parsed, 1 malformed ('Signature without r or s'), 2 wider than n"""
+        NB = ORDER_BYTES[curve]
+        der, lens = self._pack_records(sigs)
+        n = len(sigs)
+        r = np.zeros((n, NB), np.uint8)
+        s = np.zeros((n, NB), np.uint8)
+        st = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_sig_from_der(self._ctx, self._cid(curve), n, der.ctypes.data,
+                                                  der.shape[1], lens.ctypes.data, r.ctypes.data,
+                                                  s.ctypes.data, st.ctypes.data))
+        return r, s, st
+
+    def sig_to_der(self, curve, r, s):
+        """Signature#toDER per (r, s) -> list of byte strings"""
+        NB = ORDER_BYTES[curve]
+        r = _u8(r, (-1, NB))
+        n = r.shape[0]
+        s = _u8(s, (n, NB))
+        stride = 2 * NB + 9
+        out = np.zeros((n, stride), np.uint8)
+        lens = np.zeros(n, np.uint32)
+        self._check(self._lib.ellgpu_sig_to_der(self._ctx, self._cid(curve), n, r.ctypes.data, s.ctypes.data,
+                                                out.ctypes.data, stride, lens.ctypes.data))
+        return [out[i, :lens[i]].tobytes() for i in range(n)]
+
+    def ecdsa_verify_wire(self, curve, hashes, sigs, pubs, msg_bits=0):
+        """EC#verify(msg, DER signature, encoded key) per item.  sigs: list of byte strings;
+        pubs: (n, pub_len) SEC1 encodings -> (ok, err); err 1..3 = decodePoint's status for the
+        key, 4 = 'Signature without r or s'"""
+        hashes = _u8(hashes)
+        if hashes.ndim != 2:
+            raise ValueError("hashes must be (n, hash_len)")
+        n, hash_len = hashes.shape
+        pubs = _u8(pubs)
+        if pubs.ndim != 2 or pubs.shape[0] != n or len(sigs) != n:
+            raise ValueError("pubs must be (n, pub_len), sigs a list of n byte strings")
+        der, lens = self._pack_records(sigs)
+        ok = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_ecdsa_verify_wire(self._ctx, self._cid(curve), n, hashes.ctypes.data,
+                                                       hash_len, int(msg_bits), der.ctypes.data, der.shape[1],
+                                                       lens.ctypes.data, pubs.ctypes.data, pubs.shape[1],
+                                                       ok.ctypes.data, err.ctypes.data))
+        return ok, err
+
+    def ecdsa_verify_wire_dev(self, curve, hashes, der, der_len, pubs, out_ok, out_err=None, msg_bits=0):
+        n, hash_len = hashes.shape
+        self._check(self._lib.ellgpu_ecdsa_verify_wire_dev(
+            self._ctx, self._cid(curve), n, hashes.data_ptr(), hash_len, int(msg_bits), der.data_ptr(),
+            der.shape[1], der_len.data_ptr(), pubs.data_ptr(), pubs.shape[1], out_ok.data_ptr(),
+            out_err.data_ptr() if out_err is not None else None, self._stream()))
+
     def ecdsa_sign(self, curve, hashes, priv, nonces, canonical=False, msg_bits=0):
         """one pass of EC#sign per item for supplied nonces -> (r, s, recid, ok)"""
         NB = ORDER_BYTES[curve]

@@ -28,6 +28,10 @@
  *           decodePoints(ctx, curve, enc, encLen) -> {xy, status}
  *           encodePoints(ctx, curve, xy, compact) -> Buffer
  *           validate(ctx, curve, xy, inf|null, checkOrder) -> Buffer (status bytes)
+ *           sigFromDer(ctx, curve, der, stride, lens) -> {r, s, status}
+ *           sigToDer(ctx, curve, r, s) -> {der, lens}     (stride = der.length / n)
+ *           ecdsaVerifyWire(ctx, curve, hash, hashLen, msgBits, der, stride, lens, keys, keyLen)
+ *             -> {ok, err};  lens: Buffer of n little-endian uint32
  *             offsets: Buffer of n+1 little-endian uint64 byte offsets into msgs
  *           callAsync(op, ctx, curve, hashLen, msgBits, b0, b1, b2, b3) -> Promise
  *             op 0 mulFixed(b0=k) 1 mulVar(k, xy) 2 mulAdd2(k1, p1|null, k2, p2)
@@ -77,6 +81,11 @@ static struct {
   int (*decode_points)(ellgpu_ctx*, int, size_t, const uint8_t*, size_t, uint8_t*, uint8_t*);
   int (*encode_points)(ellgpu_ctx*, int, size_t, const uint8_t*, int, uint8_t*);
   int (*validate)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, int, uint8_t*);
+  int (*sig_from_der)(ellgpu_ctx*, int, size_t, const uint8_t*, size_t, const uint32_t*, uint8_t*, uint8_t*,
+                      uint8_t*);
+  int (*sig_to_der)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, uint8_t*, size_t, uint32_t*);
+  int (*verify_wire)(ellgpu_ctx*, int, size_t, const uint8_t*, int, int, const uint8_t*, size_t,
+                     const uint32_t*, const uint8_t*, size_t, uint8_t*, uint8_t*);
 } L;
 
 #define THROW(env, msg) do { napi_throw_error((env), NULL, (msg)); return NULL; } while (0)
@@ -116,6 +125,9 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   SYM(decode_points, "ellgpu_decode_points");
   SYM(encode_points, "ellgpu_encode_points");
   SYM(validate, "ellgpu_validate");
+  SYM(sig_from_der, "ellgpu_sig_from_der");
+  SYM(sig_to_der, "ellgpu_sig_to_der");
+  SYM(verify_wire, "ellgpu_ecdsa_verify_wire");
   L.h = h;
   napi_value t; CHECK(env, napi_get_boolean(env, 1, &t));
   return t;
@@ -476,6 +488,76 @@ static napi_value fn_validate(napi_env env, napi_callback_info info) {
   return bst;
 }
 
+static napi_value fn_sig_from_der(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 5; napi_value argv[5];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  int32_t curve, stride;
+  if (napi_get_value_int32(env, argv[1], &curve) != napi_ok || napi_get_value_int32(env, argv[3], &stride) != napi_ok)
+    THROW(env, "sigFromDer(ctx, curve, der, stride, lens)");
+  int NB = L.order_bytes(curve); if (NB <= 0 || stride <= 0) THROW(env, "bad curve / stride");
+  const uint8_t *der, *lens; size_t ld, ll;
+  if (!get_buf(env, argv[2], &der, &ld, 0) || !get_buf(env, argv[4], &lens, &ll, 0)) return NULL;
+  if (ll % 4 || ((uintptr_t)lens & 3)) THROW(env, "lens must be an aligned Buffer of uint32");
+  size_t n = ll / 4;
+  if (ld != n * (size_t)stride) THROW(env, "buffer length mismatch");
+  napi_value br, bs, bst, o; void *dr, *ds, *dst;
+  CHECK(env, result_buffer(env, n * (size_t)NB, &dr, &br));
+  CHECK(env, result_buffer(env, n * (size_t)NB, &ds, &bs));
+  CHECK(env, result_buffer(env, n, &dst, &bst));
+  if (L.sig_from_der(c, curve, n, der, (size_t)stride, (const uint32_t*)lens, (uint8_t*)dr, (uint8_t*)ds,
+                     (uint8_t*)dst) != 0) return lib_error(env);
+  o = mk_result(env, "r", br, "s", bs); if (!o) return NULL;
+  CHECK(env, napi_set_named_property(env, o, "status", bst));
+  return o;
+}
+
+static napi_value fn_sig_to_der(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 4; napi_value argv[4];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  int32_t curve;
+  if (napi_get_value_int32(env, argv[1], &curve) != napi_ok) THROW(env, "sigToDer(ctx, curve, r, s)");
+  int NB = L.order_bytes(curve); if (NB <= 0) THROW(env, "unknown curve id");
+  const uint8_t *r, *s; size_t lr, ls;
+  if (!get_buf(env, argv[2], &r, &lr, 0) || !get_buf(env, argv[3], &s, &ls, 0)) return NULL;
+  if (lr % (size_t)NB || ls != lr) THROW(env, "buffer length mismatch");
+  size_t n = lr / (size_t)NB, stride = 2 * (size_t)NB + 9;
+  napi_value bd, bl; void *dd, *dl;
+  CHECK(env, result_buffer(env, n * stride, &dd, &bd));
+  CHECK(env, result_buffer(env, n * 4, &dl, &bl));
+  if (L.sig_to_der(c, curve, n, r, s, (uint8_t*)dd, stride, (uint32_t*)dl) != 0) return lib_error(env);
+  return mk_result(env, "der", bd, "lens", bl);
+}
+
+static napi_value fn_verify_wire(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 10; napi_value argv[10];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  int32_t curve, hl, mb, stride, kl;
+  if (napi_get_value_int32(env, argv[1], &curve) != napi_ok || napi_get_value_int32(env, argv[3], &hl) != napi_ok ||
+      napi_get_value_int32(env, argv[4], &mb) != napi_ok || napi_get_value_int32(env, argv[6], &stride) != napi_ok ||
+      napi_get_value_int32(env, argv[9], &kl) != napi_ok)
+    THROW(env, "ecdsaVerifyWire(ctx, curve, hash, hashLen, msgBits, der, stride, lens, keys, keyLen)");
+  if (hl <= 0 || stride <= 0 || kl <= 0) THROW(env, "bad hashLen / stride / keyLen");
+  const uint8_t *h, *der, *lens, *keys; size_t lh, ld, ll, lk;
+  if (!get_buf(env, argv[2], &h, &lh, 0) || !get_buf(env, argv[5], &der, &ld, 0) ||
+      !get_buf(env, argv[7], &lens, &ll, 0) || !get_buf(env, argv[8], &keys, &lk, 0)) return NULL;
+  if (lh % (size_t)hl) THROW(env, "hash buffer length is not a multiple of hashLen");
+  size_t n = lh / (size_t)hl;
+  if (ll != n * 4 || ((uintptr_t)lens & 3)) THROW(env, "lens must be an aligned Buffer of n uint32");
+  if (ld != n * (size_t)stride || lk != n * (size_t)kl) THROW(env, "buffer length mismatch");
+  napi_value bok, berr; void *dok, *derr;
+  CHECK(env, result_buffer(env, n, &dok, &bok));
+  CHECK(env, result_buffer(env, n, &derr, &berr));
+  if (L.verify_wire(c, curve, n, h, hl, mb, der, (size_t)stride, (const uint32_t*)lens, keys, (size_t)kl,
+                    (uint8_t*)dok, (uint8_t*)derr) != 0) return lib_error(env);
+  return mk_result(env, "ok", bok, "err", berr);
+}
+
 static napi_value fn_eddsa_verify(napi_env env, napi_callback_info info) {
   if (!need_lib(env)) return NULL;
   size_t argc = 6; napi_value argv[6];
@@ -638,6 +720,7 @@ static napi_value init(napi_env env, napi_value exports) {
     {"callAsync", fn_call_async}, {"decompress", fn_decompress},
     {"eddsaVerify", fn_eddsa_verify}, {"eddsaSign", fn_eddsa_sign}, {"ecdsaSign", fn_sign}, {"ecdsaRecover", fn_recover}, {"ecdsaSignDet", fn_sign_det},
     {"decodePoints", fn_decode_points}, {"encodePoints", fn_encode_points}, {"validate", fn_validate},
+    {"sigFromDer", fn_sig_from_der}, {"sigToDer", fn_sig_to_der}, {"ecdsaVerifyWire", fn_verify_wire},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

@@ -142,6 +142,44 @@ Engine.prototype.validateBatch = function validateBatch(curve, xy, o) {
   return this.addon.validate(this.ctx, id, xy, o.inf || null, o.checkOrder !== false);
 };
 
+// DER signatures and EC#verify on wire formats.
+function packRecords(items) {
+  var n = items.length, stride = 1, i;
+  for (i = 0; i < n; i++) stride = Math.max(stride, items[i].length);
+  var buf = Buffer.alloc(n * stride), lens = Buffer.alloc(n * 4);
+  for (i = 0; i < n; i++) {
+    Buffer.from(items[i]).copy(buf, i * stride);
+    lens.writeUInt32LE(items[i].length, i * 4);
+  }
+  return { buf: buf, lens: lens, stride: stride };
+}
+// sigs: array of Buffers (DER) -> { r, s: Buffer(n x NB), status: Buffer(n) }; status 0 parsed,
+// 1 where new Signature(der) throws 'Signature without r or s', 2 wider than the order
+Engine.prototype.sigFromDerBatch = function sigFromDerBatch(curve, sigs) {
+  var p = packRecords(sigs);
+  this.stats.gpuCalls++;
+  return this.addon.sigFromDer(this.ctx, this._id(curve), p.buf, p.stride, p.lens);
+};
+// r, s: Buffer(n x NB) -> array of Buffers, each Signature#toDER()
+Engine.prototype.sigToDerBatch = function sigToDerBatch(curve, r, s) {
+  this.stats.gpuCalls++;
+  var o = this.addon.sigToDer(this.ctx, this._id(curve), r, s);
+  var n = o.lens.length / 4, stride = n ? o.der.length / n : 0, out = [];
+  for (var i = 0; i < n; i++) out.push(o.der.slice(i * stride, i * stride + o.lens.readUInt32LE(i * 4)));
+  return out;
+};
+// EC#verify(msg, derSignature, encodedKey): hashes Buffer(n x hashLen), sigs array of DER Buffers,
+// keys Buffer(n x keyLen) of SEC1 encodings -> { ok, err: Buffer(n) }; err 1..3 = decodePoint's
+// exception for the key ('Unknown point format' / 'invalid point' / 'Assertion failed'),
+// 4 = 'Signature without r or s'
+Engine.WIRE_ERROR = [null, 'Unknown point format', 'invalid point', 'Assertion failed', 'Signature without r or s'];
+Engine.prototype.ecdsaVerifyWireBatch = function ecdsaVerifyWireBatch(curve, o) {
+  var p = packRecords(o.sigs);
+  this.stats.gpuCalls++; this.stats.gpuItems += o.sigs.length;
+  return this.addon.ecdsaVerifyWire(this.ctx, this._id(curve), o.hashes, o.hashLen, o.msgBits | 0,
+    p.buf, p.stride, p.lens, o.keys, o.keyLen);
+};
+
 // ed25519 EdDSA verify.  msgs: array of Buffers (any lengths); sigs: Buffer(n x 64) of R||S;
 // pubs: Buffer(n x 32).  -> { ok: Buffer(n), err: Buffer(n) }  (err = 1 where the
 // reference throws: R or A is not a curve point)

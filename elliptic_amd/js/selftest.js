@@ -184,6 +184,37 @@ function check(r, i, B, want, what) {
     checked++;
   });
 });
+['secp256k1', 'p256', 'p521'].forEach(function(name) {
+  var g = JSON.parse(fs.readFileSync(path.join(GOLD, 'wire_' + name + '.json')));
+  var byLen = {};
+  g.verify.forEach(function(c) {
+    if (!c.key.length) return;
+    (byLen[c.key.length / 2] = byLen[c.key.length / 2] || []).push(c);
+  });
+  Object.keys(byLen).forEach(function(len) {
+    var cs = byLen[len];
+    var r = eng.ecdsaVerifyWireBatch(name, { hashes: Buffer.from(cs.map(function(c) { return c.z; }).join(''), 'hex'),
+      hashLen: 32, sigs: cs.map(function(c) { return Buffer.from(c.der, 'hex'); }),
+      keys: Buffer.from(cs.map(function(c) { return c.key; }).join(''), 'hex'), keyLen: +len });
+    cs.forEach(function(c, i) {
+      var want = c.throws ? ellgpu.Engine.WIRE_ERROR.indexOf(c.throws) : 0;
+      if (r.err[i] !== want || (r.ok[i] === 1) !== (c.ok === true))
+        throw new Error('wire verify mismatch: ' + name + ' ' + c.note);
+      checked++;
+    });
+  });
+  var NB = g.der[0].r.length / 2;
+  var ders = eng.sigToDerBatch(name, hexBuf(g.der.map(function(c) { return c.r; }), NB), hexBuf(g.der.map(function(c) { return c.s; }), NB));
+  g.der.forEach(function(c, i) {
+    if (ders[i].toString('hex') !== c.der) throw new Error('toDER mismatch: ' + name + ' ' + c.r);
+    checked++;
+  });
+  var p = eng.sigFromDerBatch(name, g.parse.map(function(c) { return Buffer.from(c.der, 'hex'); }));
+  g.parse.forEach(function(c, i) {
+    if ((p.status[i] === 1) !== !!c.bad) throw new Error('_importDER mismatch: ' + name + ' ' + c.der);
+    checked++;
+  });
+});
 var lc = JSON.parse(fs.readFileSync(path.join(GOLD, 'mul_curve25519.json')));
 var rr = eng.x25519Batch(hexBuf(lc.map(function(c) { return c.k; }), 32), hexBuf(lc.map(function(c) { return c.px; }), 32));
 lc.forEach(function(c, i) {

@@ -165,6 +165,39 @@ int ellgpu_validate(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, con
 int ellgpu_validate_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, const uint8_t* inf,
                         int check_order, uint8_t* out_status, void* stream);
 
+/* Signature DER codec (lib/elliptic/ec/signature.js) and EC#verify on wire formats.
+ * ellgpu_sig_from_der: Signature#_importDER (signature.js:83-147, with getLength :30-59) of n
+ *   records of `stride` bytes, the first der_len[i] of each being the signature.  out_r / out_s
+ *   are order_bytes wide, big-endian.  status 0 = parsed; 1 = the reference's `return false`
+ *   (its constructor then throws 'Signature without r or s': bad tags, indefinite / overlong /
+ *   non-minimal lengths, negative or zero-padded integers, trailing bytes); 2 = well-formed but r
+ *   or s is wider than order_bytes (>= n, EC#verify answers false).  r, s are zeroed unless 0.
+ * ellgpu_sig_to_der: Signature#toDER (signature.js:149-176) of (r, s); out_len[i] bytes are
+ *   written at out_der + i * stride, the rest of the record is zeroed; stride >= 2 *
+ *   order_bytes + 9.  s = 0 (where the reference does not terminate) gives out_len 0.
+ * ellgpu_ecdsa_verify_wire: EC#verify(msg, der, key) (lib/elliptic/ec/index.js:188-229) with
+ *   key = n encodings of pub_len bytes as for ellgpu_decode_points (keyFromPublic ->
+ *   decodePoint) and DER signatures as above; point decoding, DER parsing, the double-scalar
+ *   multiplication and the x == r test all run on the device.  out_ok = 0/1; out_err (may be
+ *   NULL) names the exception the reference throws, in its order: 1..3 = decodePoint's status
+ *   for the key, 4 = 'Signature without r or s'; out_ok is 0 wherever out_err is not. */
+int ellgpu_sig_from_der(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* der, size_t stride,
+                        const uint32_t* der_len, uint8_t* out_r, uint8_t* out_s, uint8_t* out_status);
+int ellgpu_sig_from_der_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* der, size_t stride,
+                            const uint32_t* der_len, uint8_t* out_r, uint8_t* out_s, uint8_t* out_status,
+                            void* stream);
+int ellgpu_sig_to_der(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* r, const uint8_t* s,
+                      uint8_t* out_der, size_t stride, uint32_t* out_len);
+int ellgpu_sig_to_der_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* r, const uint8_t* s,
+                          uint8_t* out_der, size_t stride, uint32_t* out_len, void* stream);
+int ellgpu_ecdsa_verify_wire(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                             int msg_bits, const uint8_t* der, size_t der_stride, const uint32_t* der_len,
+                             const uint8_t* pub_enc, size_t pub_len, uint8_t* out_ok, uint8_t* out_err);
+int ellgpu_ecdsa_verify_wire_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
+                                 int msg_bits, const uint8_t* der, size_t der_stride,
+                                 const uint32_t* der_len, const uint8_t* pub_enc, size_t pub_len,
+                                 uint8_t* out_ok, uint8_t* out_err, void* stream);
+
 /* ECDSA sign for caller-supplied nonces: one pass of EC#sign's loop per item
  * (lib/elliptic/ec/index.js:153-185): k = _truncateToN(nonce, true), R = k*G (fixed-base comb),
  * r = R.x mod n, s = k^-1 (z + r d) mod n (k^-1 batched), recoveryParam (:174-175), and with

@@ -693,6 +693,106 @@ def ecdsa_recover(curve: ShortCurve, e: int, r: int, s: int, j: int) -> ShortPoi
     return curve.g.mul_add(s1, R, s2)
 
 
+def _der_get_length(buf: bytes, place: int):
+    """signature.js:30-59 getLength -> (value or None for the reference's `false`, place).
+    Reads past the end behave like JavaScript's `undefined` (| 0 -> 0, comparisons fail)."""
+    if place >= len(buf):
+        return "undefined", place + 1
+    initial = buf[place]
+    place += 1
+    if not initial & 0x80:
+        return initial, place
+    octets = initial & 0xF
+    if octets == 0 or octets > 4:
+        return None, place
+    if place < len(buf) and buf[place] == 0:
+        return None, place
+    val = 0
+    off = place
+    for _ in range(octets):
+        val = ((val << 8) | (buf[off] if off < len(buf) else 0)) & 0xFFFFFFFF
+        off += 1
+    if val <= 0x7F:
+        return None, place
+    return val, off
+
+
+def sig_import_der(data: bytes) -> Optional[Tuple[int, int]]:
+    """signature.js:83-147 Signature#_importDER -> (r, s), or None where it returns false (the
+    constructor then throws 'Signature without r or s')."""
+    d = bytes(data)
+
+    def at(i):
+        return d[i] if 0 <= i < len(d) else None
+    p = 0
+    if at(p) != 0x30:
+        return None
+    p += 1
+    ln, p = _der_get_length(d, p)
+    if ln is None or ln == "undefined" or ln + p != len(d):
+        return None
+    if at(p) != 0x02:
+        return None
+    p += 1
+    rlen, p = _der_get_length(d, p)
+    if rlen is None or rlen == "undefined":
+        return None                       # `undefined` runs into the next tag test with place = NaN
+    if (at(p) or 0) & 0x80:
+        return None
+    r = d[p:p + rlen]
+    p += rlen
+    if at(p) != 0x02:
+        return None
+    p += 1
+    slen, p = _der_get_length(d, p)
+    if slen is None or slen == "undefined" or len(d) != slen + p:
+        return None
+    if (at(p) or 0) & 0x80:
+        return None
+    s = d[p:p + slen]
+    if len(r) and r[0] == 0:
+        if len(r) > 1 and r[1] & 0x80:
+            r = r[1:]
+        else:
+            return None
+    if len(s) and s[0] == 0:
+        if len(s) > 1 and s[1] & 0x80:
+            s = s[1:]
+        else:
+            return None
+    return int.from_bytes(r, "big"), int.from_bytes(s, "big")
+
+
+def sig_to_der(r: int, s: int) -> bytes:
+    """signature.js:149-176 Signature#toDER (s = 0 does not terminate in the reference)"""
+    assert s != 0
+
+    def integer(v):
+        b = v.to_bytes(max(1, (v.bit_length() + 7) // 8), "big")
+        if b[0] & 0x80:
+            b = b"\x00" + b
+        return b
+
+    def length(n):
+        if n < 0x80:
+            return bytes([n])
+        octets = 1 + ((n.bit_length() - 1) >> 3)
+        return bytes([0x80 | octets]) + n.to_bytes(octets, "big")
+    rb, sb = integer(r), integer(s)
+    body = b"\x02" + length(len(rb)) + rb + b"\x02" + length(len(sb)) + sb
+    return b"\x30" + length(len(body)) + body
+
+
+def ecdsa_verify_wire(curve: ShortCurve, msg: int, msg_bytes: int, der: bytes, key: bytes) -> bool:
+    """ec/index.js:188-229 EC#verify(msg, der, key): keyFromPublic -> decodePoint, then
+    new Signature(der); raises ValueError with the reference's message where it throws."""
+    pub = decode_point(curve, key)
+    rs = sig_import_der(der)
+    if rs is None:
+        raise ValueError("Signature without r or s")
+    return ecdsa_verify(curve, msg, msg_bytes, rs[0], rs[1], pub)
+
+
 def decode_point(curve: ShortCurve, data: bytes) -> ShortPoint:
     """base.js:270-293 BaseCurve#decodePoint.  Raises ValueError with the reference's message:
     'Unknown point format', 'Assertion failed' (hybrid prefix vs. y's last bit), 'invalid point'

@@ -73,6 +73,11 @@ def test_codec_golden(ctx, curve):
     assert PC.check_codec_golden(ctx, curve) >= 100
 
 
+@pytest.mark.parametrize("curve", O.SHORT_CURVES)
+def test_wire_golden(ctx, curve):
+    assert PC.check_wire_golden(ctx, curve) >= 60
+
+
 def test_recover_unsupported(ctx):
     with pytest.raises(elliptic_amd.EllgpuError) as e:
         ctx.ecdsa_recover("p224", np.zeros((1, 28), np.uint8), np.ones((1, 28), np.uint8), np.ones((1, 28), np.uint8),

@@ -181,6 +181,37 @@ def test_codec_matches_reference(name):
     assert len(seen) >= 2
 
 
+@pytest.mark.parametrize("name", O.SHORT_CURVES)
+def test_wire_formats_match_reference(name):
+    """Signature#toDER / _importDER (ec/signature.js) and EC#verify(msg, der, key) with the
+    reference's exception messages"""
+    cur = O.get_curve(name)
+    g = load("wire_%s.json" % name)
+    seen = set()
+    for c in g["verify"]:
+        z = bytes.fromhex(c["z"])
+        try:
+            got = O.ecdsa_verify_wire(cur, int.from_bytes(z, "big") if z else 0, len(z),
+                                      bytes.fromhex(c["der"]), bytes.fromhex(c["key"]))
+        except ValueError as ex:
+            got = "throws: " + str(ex)
+        want = "throws: " + c["throws"] if "throws" in c else c["ok"]
+        assert got == want, c
+        seen.add(want)
+    assert len(seen) >= 3
+    for c in g["der"]:
+        assert O.sig_to_der(I(c["r"]), I(c["s"])).hex() == c["der"], c
+    bad = 0
+    for c in g["parse"]:
+        got = O.sig_import_der(bytes.fromhex(c["der"]))
+        if c.get("bad"):
+            assert got is None, c
+            bad += 1
+        else:
+            assert got == (I(c["r"]), I(c["s"])), c
+    assert bad > 3
+
+
 def test_eddsa_verify_matches_reference():
     """EDDSA#verify on the reference's own sign.input vectors + corrupted variants"""
     cur = O.get_curve("ed25519")

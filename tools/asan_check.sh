@@ -24,6 +24,8 @@ for c in ["secp256k1", "p256", "p521"]:
           "decompress", PC.check_decompress_golden(ctx, c))
 for c in ["secp256k1", "p224", "p521", "ed25519"]:
     print(c, "codec", PC.check_codec_golden(ctx, c))
+for c in ["secp256k1", "p224", "p521"]:
+    print(c, "wire", PC.check_wire_golden(ctx, c))
 print("eddsa verify", PC.check_eddsa_golden(ctx), "sign", PC.check_eddsa_sign_golden(ctx))
 ctx.close()
 print("ASAN/UBSAN run clean")

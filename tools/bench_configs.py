@@ -114,6 +114,16 @@ def main():
                 timed("%s KeyPair#validate (with n*P == O)" % curve, n,
                       lambda: ctx.validate_dev(curve, pts, None, True, st))
                 assert bool((st == 0).all())
+                # EC#verify on wire formats: DER signatures (built on the host from r_o, s_o with
+                # the engine's own toDER) + the compressed keys -> decode, parse, verify on device
+                ders = ctx.sig_to_der(curve, r_o.cpu().numpy(), s_o.cpu().numpy())
+                der_np, len_np = ctx._pack_records(ders)
+                der_d = torch.from_numpy(der_np).to(dev)
+                len_d = torch.from_numpy(len_np.view(np.int32)).to(dev)
+                err = torch.zeros(n, dtype=torch.uint8, device=dev)
+                timed("%s ECDSA verify, DER signatures + compressed keys" % curve, n,
+                      lambda: ctx.ecdsa_verify_wire_dev(curve, dk, der_d, len_d, enc, ok2, err))
+                assert bool(ok2[good].bool().all()) and bool((err == 0).all())
         if curve == "ed25519":
             # EdDSA verify on valid signatures (A = aG, R = rG, S = r + h a; built with the fixed-base
             # kernel + hashlib), 48-byte messages

@@ -464,6 +464,113 @@ function genCodec(name) {
   return out;
 }
 
+// ------------------------------------------------------------- wire_<curve>.json
+// EC#verify(msg, derSignature, encodedKey, 'hex') (ec/index.js:188-229 through keyFromPublic /
+// decodePoint and new Signature(der)), Signature#toDER / _importDER (ec/signature.js).
+//   verify: { z, der, key, ok } or { ..., throws: message }
+//   der:    { r, s, der } from toDER;   parse: { der, r, s } or { der, bad: true }
+function genWire(name) {
+  var pc = elliptic.curves[name];
+  var c = pc.curve;
+  var ec = new elliptic.ec(pc);
+  var NL = c.n.byteLength();
+  var rng = new Prng('ellgpu-golden-v1:wire:' + name);
+  var N = Math.max(12, COUNTS[name] >> 1);
+  var out = { verify: [], der: [], parse: [] };
+  var Signature = ec.sign(rng.bytes(32), ec.keyFromPrivate('01', 'hex')).constructor;
+  function ver(z, der, key, note) {
+    var o = { z: Buffer.from(z).toString('hex'), der: Buffer.from(der).toString('hex'),
+      key: Buffer.from(key).toString('hex'), note: note };
+    try { o.ok = ec.verify(o.z, o.der, o.key, 'hex'); } catch (e) { o.throws = e.message; }
+    out.verify.push(o);
+  }
+  function parse(der) {
+    var o = { der: Buffer.from(der).toString('hex') };
+    var sg = Object.create(Signature.prototype);
+    if (sg._importDER(o.der, 'hex')) { o.r = sg.r.toString(16); o.s = sg.s.toString(16); } else o.bad = true;
+    out.parse.push(o);
+  }
+  function toDer(r, s) {
+    var d = new Signature({ r: r, s: s }).toDER();
+    out.der.push({ r: hex(r, NL), s: hex(s, NL), der: Buffer.from(d).toString('hex') });
+    return d;
+  }
+  function intDer(bytes) { return [2, bytes.length].concat(bytes); }
+  function seq(body) {
+    return body.length < 128 ? [0x30, body.length].concat(body) : [0x30, 0x81, body.length].concat(body);
+  }
+  for (var i = 0; i < N; i++) {
+    var key = ec.keyFromPrivate(hex(rng.below(c.n.subn(1)).addn(1), NL), 'hex');
+    var z = rng.bytes(32);
+    var sig = ec.sign(z, key, { canonical: (i & 1) === 1 });
+    var der = toDer(sig.r, sig.s);
+    var compressed = name !== 'p224' && (i % 3) !== 0;
+    var pk = key.getPublic().encode('array', compressed);
+    ver(z, der, pk, 'valid');
+    parse(der);
+    var k = i % 12;
+    var bad;
+    if (k === 0) { bad = der.slice(); bad[0] = 0x31; ver(z, bad, pk, 'bad-seq-tag'); parse(bad); }
+    if (k === 1) { bad = der.concat([0]); ver(z, bad, pk, 'trailing-byte'); parse(bad); }
+    if (k === 2) { bad = der.slice(0, der.length - 1); ver(z, bad, pk, 'truncated'); parse(bad); }
+    if (k === 3) { bad = der.slice(); bad[der[1] & 0x80 ? 2 : 1] ^= 1; ver(z, bad, pk, 'bad-length'); parse(bad); }
+    if (k === 4) {                                   // non-minimal integer: extra leading zero
+      bad = seq(intDer([0].concat(sig.r.toArray('be', NL))).concat(intDer([0].concat(sig.s.toArray('be', NL)))));
+      ver(z, bad, pk, 'zero-padded'); parse(bad);
+    }
+    if (k === 5) {                                   // negative integer (high bit without the pad)
+      var rb = sig.r.toArray(); rb[0] |= 0x80;
+      bad = seq(intDer(rb).concat(intDer(sig.s.toArray('be', NL + 1))));
+      ver(z, bad, pk, 'negative-r'); parse(bad);
+    }
+    if (k === 6) {                                   // long-form length where the short form fits
+      var body = intDer(sig.r.toArray('be', NL + 1)).concat(intDer(sig.s.toArray('be', NL + 1)));
+      if (sig.r.toArray('be', NL)[0] & 0x80 && sig.s.toArray('be', NL)[0] & 0x80 && body.length < 128) {
+        bad = [0x30, 0x81, body.length].concat(body); ver(z, bad, pk, 'long-form-len'); parse(bad);
+      } else { bad = der.slice(); bad[der.length - 1] ^= 4; ver(z, bad, pk, 'bad-s'); parse(bad); }
+    }
+    if (k === 7) {                                   // r wider than n: well-formed, verify false
+      var wide = [1].concat(sig.r.toArray('be', NL));
+      bad = seq(intDer(wide).concat(intDer(sig.s.toArray())));
+      if (sig.s.toArray()[0] & 0x80) bad = seq(intDer(wide).concat(intDer([0].concat(sig.s.toArray()))));
+      ver(z, bad, pk, 'wide-r'); parse(bad);
+    }
+    if (k === 8) { var z2 = Buffer.from(z); z2[31] ^= 1; ver(z2, der, pk, 'bad-z'); }
+    if (k === 9) {                                   // key errors come first
+      var bk = pk.slice(); bk[0] = 5; ver(z, der, bk, 'bad-key-prefix');
+      bad = der.slice(); bad[0] = 0x31; ver(z, bad, bk, 'bad-key-and-sig');
+    }
+    if (k === 10) {
+      var un = key.getPublic().encode('array', false);
+      var odd = key.getPublic().getY().isOdd();
+      ver(z, der, [odd ? 7 : 6].concat(un.slice(1)), 'hybrid-key');
+      ver(z, der, [odd ? 6 : 7].concat(un.slice(1)), 'hybrid-key-mismatch');
+      if (name !== 'p224') ver(z, der, [2].concat(rng.below(c.p).toArray('be', c.p.byteLength())), 'random-x-key');
+    }
+    if (k === 11) {
+      ver(z, seq(intDer([0]).concat(intDer(sig.s.toArray('be', NL + 1).slice(sig.s.toArray('be', NL)[0] & 0x80 ? 0 : 1)))), pk, 'r=0 one byte');
+      ver(z, seq([2, 0].concat(intDer([1]))), pk, 'empty r');
+      ver(z, [], pk, 'empty');
+      ver(z, [0x30], pk, 'only tag');
+      ver(z, [0x30, 0x80], pk, 'indefinite');
+      ver(z, [0x30, 0x85, 1, 0, 0, 0, 6, 2, 1, 1, 2, 1, 1], pk, 'five length octets');
+      ver(z, [0x30, 0x06, 2, 1, 1, 2, 1, 1], pk, 'tiny r,s');
+      ver(z, [0x30, 0x82, 0, 6, 2, 1, 1, 2, 1, 1], pk, 'length with zero octet');
+      parse([0x30, 0x06, 2, 1, 1, 2, 1, 1]); parse([0x30, 0x82, 0, 6, 2, 1, 1, 2, 1, 1]);
+      parse([0x30, 0x81, 6, 2, 1, 1, 2, 1, 1]); parse([0x30, 0x06, 2, 0x81, 1, 1, 2, 1, 1]);
+      parse([]); parse([0x30]); parse([0x30, 4, 2, 0, 2, 0]); parse([0x30, 5, 2, 1, 0, 2, 0]);
+      parse([0x30, 6, 2, 1, 0x7f, 2, 1, 0]); parse([0x30, 7, 2, 2, 0, 0x80, 2, 1, 5]);
+    }
+    // toDER on small / edge values
+    toDer(new BN(i + 1), new BN(1).ushln(8 * (i % NL)).addn(i));
+    toDer(new BN(1).ushln(8 * NL - 1 - (i % 9)), rng.below(c.n.subn(1)).addn(1));
+  }
+  toDer(new BN(0), new BN(1));
+  toDer(c.n.subn(1), c.n.subn(1));
+  toDer(new BN(0x80), new BN(0x7f));
+  return out;
+}
+
 // ------------------------------------------------------ eddsa_verify_ed25519.json
 // EDDSA#verify (eddsa/index.js:52-63) on the official ed25519 sign.input vectors the
 // reference ships (test/fixtures/sign.input), plus corrupted / malformed variants.
@@ -815,6 +922,9 @@ SHORT.forEach(function(name) {
 });
 SHORT.concat(['ed25519']).forEach(function(name) {
   write('codec_' + name + '.json', genCodec(name));
+});
+SHORT.forEach(function(name) {
+  write('wire_' + name + '.json', genWire(name));
 });
 write('eddsa_verify_ed25519.json', genEddsa());
 write('eddsa_sign_ed25519.json', genEddsaSign());
