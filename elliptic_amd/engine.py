@@ -416,6 +416,22 @@ class Context:
             sigs.data_ptr(), pubs.data_ptr(), out_ok.data_ptr(),
             None if out_err is None else out_err.data_ptr(), self._stream()))
 
+    def ecdh_derive(self, curve, priv, pub_xy):
+        """KeyPair#derive per item (ec/key.js:102-107): pub.validate() then pub.mul(priv).getX()
+        -> (x, status); status 0 shared secret, 1 'public point not validated', 2 the product is
+        the point at infinity (getX throws in the reference).  Two launches: the curve-equation
+        kernel and the variable-base ladder."""
+        B = FIELD_BYTES[curve]
+        pub_xy = _u8(pub_xy, (-1, 2 * B))
+        n = pub_xy.shape[0]
+        priv = _u8(priv, (n, B))
+        st = self.validate(curve, pub_xy, check_order=False)
+        xy, inf = self.mul_var(curve, priv, pub_xy)
+        status = np.where(st != 0, 1, np.where(inf != 0, 2, 0)).astype(np.uint8)
+        x = np.ascontiguousarray(xy[:, :B])
+        x[status != 0] = 0
+        return x, status
+
     def x25519(self, k, x):
         k = _u8(k, (-1, 32))
         x = _u8(x, (-1, 32))

@@ -180,6 +180,21 @@ Engine.prototype.ecdsaVerifyWireBatch = function ecdsaVerifyWireBatch(curve, o) 
     p.buf, p.stride, p.lens, o.keys, o.keyLen);
 };
 
+// KeyPair#derive per item (ec/key.js:102-107): priv Buffer(n x B), pub Buffer(n x 2B) ->
+// { x: Buffer(n x B), status: Buffer(n) }; status 0 shared secret, 1 'public point not validated',
+// 2 the product is the point at infinity (the reference's getX throws)
+Engine.prototype.ecdhDeriveBatch = function ecdhDeriveBatch(curve, priv, pub) {
+  var st = this.validateBatch(curve, pub, { checkOrder: false });
+  var r = this.mulBatch(curve, priv, pub);
+  var n = st.length, B = n ? r.xy.length / n / 2 : 0;
+  var x = Buffer.alloc(n * B), status = Buffer.alloc(n);
+  for (var i = 0; i < n; i++) {
+    status[i] = st[i] ? 1 : (r.inf[i] ? 2 : 0);
+    if (!status[i]) r.xy.copy(x, i * B, i * 2 * B, i * 2 * B + B);
+  }
+  return { x: x, status: status };
+};
+
 // ed25519 EdDSA verify.  msgs: array of Buffers (any lengths); sigs: Buffer(n x 64) of R||S;
 // pubs: Buffer(n x 32).  -> { ok: Buffer(n), err: Buffer(n) }  (err = 1 where the
 // reference throws: R or A is not a curve point)

@@ -323,6 +323,33 @@ def check_wire_golden(ctx, curve):
     return total
 
 
+def check_ecdh(ctx, curve, n=24):
+    """KeyPair#derive: a*(b*G) == b*(a*G), equal to the oracle's pub.mul(priv).getX(); an
+    off-curve public point is refused as the reference's assert does; priv = n gives infinity"""
+    from oracle import ec_oracle as O
+    cur = O.get_curve(curve)
+    B = FIELD_BYTES[curve]
+    rng = np.random.default_rng(11)
+    a = [int.from_bytes(rng.bytes(B), "big") % (cur.n - 1) + 1 for _ in range(n)]
+    b = [int.from_bytes(rng.bytes(B), "big") % (cur.n - 1) + 1 for _ in range(n)]
+    A, _ = ctx.mul_fixed(curve, ints_to_be(a, B))
+    Bp, _ = ctx.mul_fixed(curve, ints_to_be(b, B))
+    s1, st1 = ctx.ecdh_derive(curve, ints_to_be(a, B), Bp)
+    s2, st2 = ctx.ecdh_derive(curve, ints_to_be(b, B), A)
+    assert not st1.any() and not st2.any() and np.array_equal(s1, s2)
+    for i in range(0, n, 5):
+        pub = cur.point(int.from_bytes(Bp[i, :B].tobytes(), "big"), int.from_bytes(Bp[i, B:].tobytes(), "big"))
+        assert cur.validate(pub)
+        assert pub.mul(a[i]).x == int.from_bytes(s1[i].tobytes(), "big")
+    bad = Bp.copy()
+    bad[::3, 2 * B - 1] ^= 1
+    ks = ints_to_be([cur.n if i % 4 == 1 else a[i] for i in range(n)], B)
+    _, st = ctx.ecdh_derive(curve, ks, bad)
+    for i in range(n):
+        assert st[i] == (1 if i % 3 == 0 else (2 if i % 4 == 1 else 0)), i
+    return n
+
+
 def check_eddsa_sign_golden(ctx):
     """EDDSA#sign / keyFromSecret goldens: sign.input vectors + seeded block-boundary lengths;
     the signatures must also verify"""

@@ -78,6 +78,11 @@ def test_wire_golden(ctx, curve):
     assert PC.check_wire_golden(ctx, curve) >= 60
 
 
+@pytest.mark.parametrize("curve", ["secp256k1", "p256", "p521"])
+def test_ecdh_derive(ctx, curve):
+    assert PC.check_ecdh(ctx, curve) > 0
+
+
 def test_recover_unsupported(ctx):
     with pytest.raises(elliptic_amd.EllgpuError) as e:
         ctx.ecdsa_recover("p224", np.zeros((1, 28), np.uint8), np.ones((1, 28), np.uint8), np.ones((1, 28), np.uint8),
