@@ -66,27 +66,30 @@ def main():
         timed("%s fixed-base G*k" % curve, n, lambda: ctx.mul_fixed_dev(curve, dd, pts, inf))
         timed("%s variable-base P*k" % curve, n, lambda: ctx.mul_var_dev(curve, dk, pts, out, inf))
         timed("%s k1*G + k2*P" % curve, n, lambda: ctx.mul_add2_dev(curve, dd, None, dk, pts, out, inf))
-        if curve in ("secp256k1", "p192", "p224", "p256", "p384"):
+        if curve in ("secp256k1", "p192", "p224", "p256", "p384", "p521"):
             # ECDSA sign for supplied nonces (hash = k bytes, priv = d, nonce = k ^ d: all < 2^256, a few
             # percent >= n are flagged per item), key decompression of the x coordinates just produced
             NB = elliptic_amd.ORDER_BYTES[curve]
+            # p521: 65-byte digests -- recoverPubKey does not truncate e (ec/index.js:231-254), so
+            # only digests no longer than n recover the signing key
+            hz = dk if curve != "p521" else dk[:, 1:].contiguous()
             nonce = torch.bitwise_xor(dk, dd)
             r_o = torch.zeros((n, NB), dtype=torch.uint8, device=dev)
             s_o = torch.zeros((n, NB), dtype=torch.uint8, device=dev)
             rec = torch.zeros(n, dtype=torch.uint8, device=dev)
             ok = torch.zeros(n, dtype=torch.uint8, device=dev)
             timed("%s ECDSA sign (nonces supplied)" % curve, n,
-                  lambda: ctx.ecdsa_sign_dev(curve, dk, dd, nonce, r_o, s_o, rec, ok, canonical=True))
+                  lambda: ctx.ecdsa_sign_dev(curve, hz, dd, nonce, r_o, s_o, rec, ok, canonical=True))
             ok_d = torch.zeros(n, dtype=torch.uint8, device=dev)
             timed("%s ECDSA sign (deterministic nonces, HMAC-DRBG on the device)" % curve, n,
-                  lambda: ctx.ecdsa_sign_det_dev(curve, dk, dd, r_o, s_o, rec, ok_d, canonical=True))
+                  lambda: ctx.ecdsa_sign_det_dev(curve, hz, dd, r_o, s_o, rec, ok_d, canonical=True))
             assert bool(ok_d.all())
             ok.copy_(ok_d)
             good = ok.bool()
             # ECDSA verify of those signatures against d*G (the bench.py headline is this row for
             # secp256k1, with its own signature generator)
             ok2 = torch.zeros(n, dtype=torch.uint8, device=dev)
-            timed("%s ECDSA verify" % curve, n, lambda: ctx.ecdsa_verify_dev(curve, dk, r_o, s_o, pts, ok2))
+            timed("%s ECDSA verify" % curve, n, lambda: ctx.ecdsa_verify_dev(curve, hz, r_o, s_o, pts, ok2))
             assert bool(ok2[good].bool().all())
             if curve == "p224":
                 continue                      # no point decompression for p = 1 (mod 4)
@@ -95,7 +98,7 @@ def main():
             q_o = torch.zeros((n, 2 * B), dtype=torch.uint8, device=dev)
             st = torch.zeros(n, dtype=torch.uint8, device=dev)
             timed("%s ECDSA public-key recovery" % curve, n,
-                  lambda: ctx.ecdsa_recover_dev(curve, dk, r_o, s_o, rec, q_o, st))
+                  lambda: ctx.ecdsa_recover_dev(curve, hz, r_o, s_o, rec, q_o, st))
             assert bool((st[good] == 0).all()) and torch.equal(q_o[good], pts[good])
             xs = pts[:, :B].contiguous()
             odd = (pts[:, 2 * B - 1] & 1).contiguous()
