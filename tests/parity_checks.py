@@ -323,6 +323,26 @@ def check_wire_golden(ctx, curve):
     return total
 
 
+def check_der_fuzz(ctx):
+    """Signature#_importDER on 2.4 k mutated encodings (reference verdicts, der_fuzz_secp256k1.json)"""
+    from golden_util import load
+    cases = load("der_fuzz_secp256k1.json")
+    pr, ps, st = ctx.sig_from_der("secp256k1", [bytes.fromhex(c["der"]) for c in cases])
+    kinds = [0, 0, 0]
+    for i, c in enumerate(cases):
+        if c.get("bad"):
+            want = 1
+        else:
+            ri, si = int(c["r"], 16), int(c["s"], 16)
+            want = 2 if max(ri.bit_length(), si.bit_length()) > 256 else 0
+            if want == 0:
+                assert int.from_bytes(pr[i].tobytes(), "big") == ri and int.from_bytes(ps[i].tobytes(), "big") == si, c
+        assert st[i] == want, (c, st[i])
+        kinds[want] += 1
+    assert min(kinds) > 50
+    return len(cases)
+
+
 def check_ecdh(ctx, curve, n=24):
     """KeyPair#derive: a*(b*G) == b*(a*G), equal to the oracle's pub.mul(priv).getX(); an
     off-curve public point is refused as the reference's assert does; priv = n gives infinity"""

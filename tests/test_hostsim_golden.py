@@ -237,6 +237,10 @@ def test_ecdh_derive(ctx, curve):
     assert PC.check_ecdh(ctx, curve) > 0
 
 
+def test_der_fuzz(ctx):
+    assert PC.check_der_fuzz(ctx) > 2000
+
+
 def test_recover_unsupported(ctx):
     with pytest.raises(elliptic_amd.EllgpuError) as e:
         ctx.ecdsa_recover("p224", np.zeros((1, 28), np.uint8), np.ones((1, 28), np.uint8), np.ones((1, 28), np.uint8),

@@ -212,6 +212,19 @@ def test_wire_formats_match_reference(name):
     assert bad > 3
 
 
+def test_der_fuzz_matches_reference():
+    """the oracle's _importDER against the reference's verdicts on mutated encodings"""
+    bad = 0
+    for c in load("der_fuzz_secp256k1.json"):
+        got = O.sig_import_der(bytes.fromhex(c["der"]))
+        if c.get("bad"):
+            assert got is None, c
+            bad += 1
+        else:
+            assert got == (I(c["r"]), I(c["s"])), c
+    assert bad > 500
+
+
 def test_eddsa_verify_matches_reference():
     """EDDSA#verify on the reference's own sign.input vectors + corrupted variants"""
     cur = O.get_curve("ed25519")

@@ -571,6 +571,49 @@ function genWire(name) {
   return out;
 }
 
+// ------------------------------------------------------- der_fuzz_secp256k1.json
+// Signature#_importDER on mutated encodings: byte flips, insertions, deletions, length-field
+// edits and splices of valid signatures (seeded).  { der, r, s } or { der, bad: true }.
+function genDerFuzz() {
+  var ec = new elliptic.ec('secp256k1');
+  var c = ec.curve;
+  var rng = new Prng('ellgpu-golden-v1:derfuzz');
+  var Signature = ec.sign(rng.bytes(32), ec.keyFromPrivate('01', 'hex')).constructor;
+  var out = [];
+  var seen = {};
+  function rec(bytes) {
+    var h = Buffer.from(bytes).toString('hex');
+    if (seen[h]) return;
+    seen[h] = true;
+    var o = { der: h };
+    var sg = Object.create(Signature.prototype);
+    if (sg._importDER(h, 'hex')) { o.r = sg.r.toString(16); o.s = sg.s.toString(16); } else o.bad = true;
+    out.push(o);
+  }
+  function rnd(n) { return rng.bytes(2).readUInt16BE(0) % n; }
+  for (var i = 0; i < 420; i++) {
+    // r, s of assorted widths so that pads, short integers and long forms all occur
+    var rb = 1 + rnd(40), sb = 1 + rnd(40);
+    var r = new BN(rng.bytes(rb)), s2 = new BN(rng.bytes(sb)).addn(1);
+    var der = new Signature({ r: r, s: s2 }).toDER();
+    rec(der);
+    for (var m = 0; m < 5; m++) {
+      var d = der.slice();
+      var kind = rnd(7);
+      var pos = rnd(d.length);
+      if (kind === 0) d[pos] ^= 1 << rnd(8);
+      else if (kind === 1) d.splice(pos, 1);
+      else if (kind === 2) d.splice(pos, 0, rng.bytes(1)[0]);
+      else if (kind === 3) d[Math.min(pos, 5)] = [0, 0x80, 0x81, 0x82, 0x84, 0x85, 0xff, 0x7f][rnd(8)];
+      else if (kind === 4) d = d.slice(0, pos);
+      else if (kind === 5) d = d.concat(Array.prototype.slice.call(rng.bytes(1 + rnd(3))));
+      else { d[1] = 0x81; d.splice(2, 0, d.length - 2); }       // long-form outer length
+      rec(d);
+    }
+  }
+  return out;
+}
+
 // ------------------------------------------------------ eddsa_verify_ed25519.json
 // EDDSA#verify (eddsa/index.js:52-63) on the official ed25519 sign.input vectors the
 // reference ships (test/fixtures/sign.input), plus corrupted / malformed variants.
@@ -926,6 +969,7 @@ SHORT.concat(['ed25519']).forEach(function(name) {
 SHORT.forEach(function(name) {
   write('wire_' + name + '.json', genWire(name));
 });
+write('der_fuzz_secp256k1.json', genDerFuzz());
 write('eddsa_verify_ed25519.json', genEddsa());
 write('eddsa_sign_ed25519.json', genEddsaSign());
 write('mul_ed25519.json', genEdwardsMul());
