@@ -42,6 +42,8 @@ _SIGS = {
     "ellgpu_sig_to_der_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, ctypes.c_size_t, c_u8p, ctypes.c_void_p]),
     "ellgpu_ecdsa_verify_wire": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, ctypes.c_size_t, c_u8p, c_u8p, ctypes.c_size_t, c_u8p, c_u8p]),
     "ellgpu_ecdsa_verify_wire_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, ctypes.c_size_t, c_u8p, c_u8p, ctypes.c_size_t, c_u8p, c_u8p, ctypes.c_void_p]),
+    "ellgpu_point_add": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "ellgpu_point_add_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
     "ellgpu_decompress_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
     "ellgpu_ecdsa_sign": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, c_u8p, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p]),
     "ellgpu_ecdsa_sign_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, c_u8p, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),

@@ -154,6 +154,19 @@ int ellgpu_validate_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy,
   return finish(ctx, ctx->eng->validate_dev(curve, n, xy, inf, check_order, out_status));
 }
 
+// Point#add on affine points
+int ellgpu_point_add(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy1, const uint8_t* inf1,
+                     const uint8_t* xy2, const uint8_t* inf2, uint8_t* out_xy, uint8_t* out_inf) {
+  ELL_ENTER(ctx, nullptr);
+  return finish(ctx, ctx->eng->point_add_host(curve, n, xy1, inf1, xy2, inf2, out_xy, out_inf));
+}
+int ellgpu_point_add_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy1, const uint8_t* inf1,
+                         const uint8_t* xy2, const uint8_t* inf2, uint8_t* out_xy, uint8_t* out_inf,
+                         void* stream) {
+  ELL_ENTER(ctx, stream);
+  return finish(ctx, ctx->eng->point_add_dev(curve, n, xy1, inf1, xy2, inf2, out_xy, out_inf));
+}
+
 // signature DER codec and EC#verify on wire formats
 int ellgpu_sig_from_der(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* der, size_t stride,
                         const uint32_t* der_len, uint8_t* out_r, uint8_t* out_s, uint8_t* out_status) {

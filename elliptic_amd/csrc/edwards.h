@@ -286,6 +286,18 @@ struct EdWork {
     return ok;
   }
 
+  // Point#add (edwards.js:350-360 -> _extAdd :279-309) for affine inputs -> extended; a set
+  // inf flag stands for the identity (0, 1)
+  ELL_HD static void point_add(size_t i, size_t n, const u8* xy1, const u8* inf1, const u8* xy2,
+                               const u8* inf2, u32* ext) {
+    P id = from_affine(F::zero(), F::one());
+    P p = load_affine(xy1, i);
+    P q = load_affine(xy2, i);
+    if (inf1 && inf1[i]) p = id;
+    if (inf2 && inf2[i]) q = id;
+    store_ext(ext, n, i, add(p, to_cached(q)));
+  }
+
   // ---- batch codecs / validation ---------------------------------------------------
   // EDDSA#decodePoint (eddsa/index.js:99-109): status 0 = point, 2 = 'invalid point'
   ELL_HD static void decode_points(size_t i, const u8* enc, u8* out_xy, u8* status) {

@@ -249,6 +249,24 @@ struct FnWireStatus {
     if (i < n) W::wire_status(i, key_st, sig_st, ok, err);
   }
 };
+template <class CV>
+struct FnPointAdd {
+  static constexpr const char* NAME = "point_add";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* xy1; const u8* inf1; const u8* xy2; const u8* inf2; u32* jac;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::point_add(i, n, xy1, inf1, xy2, inf2, jac);
+  }
+};
+struct FnEdPointAdd {
+  static constexpr const char* NAME = "ed_point_add";
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* xy1; const u8* inf1; const u8* xy2; const u8* inf2; u32* ext;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) EdWork::point_add(i, n, xy1, inf1, xy2, inf2, ext);
+  }
+};
 struct FnEdDecodePoint {
   static constexpr const char* NAME = "ed_decode_point";
   static constexpr int DS_PER_LANE = 0;
@@ -482,6 +500,10 @@ class Engine {
   int decompress_chunk(size_t n, const u8* x, const u8* odd, u8* out_xy, u8* out_ok);
   template <class CV>
   int codec_chunk(int op, size_t n, const u8* in, size_t len, int flag, const u8* inf, u8* out, u8* status);
+  template <class CV>
+  int point_add_chunk(size_t n, const u8* xy1, const u8* inf1, const u8* xy2, const u8* inf2, u8* out_xy, u8* out_inf);
+  template <int U = 0>
+  int ed_point_add_chunk(size_t n, const u8* xy1, const u8* inf1, const u8* xy2, const u8* inf2, u8* out_xy, u8* out_inf);
   template <class CV>
   int der_chunk(int op, size_t n, const u8* a, const u8* b, size_t stride, u32* lens, u8* o1, u8* o2, u8* o3);
   template <class CV>
@@ -1000,6 +1022,52 @@ class Engine {
     HostOut outs[1] = {{out_status, dst, 1}};
     return pipelined(n, ins, inf ? 2 : 1, outs, 1, [&](size_t o, size_t m) {
       return validate_dev(curve, m, dxy + o * 2 * B, dinf ? dinf + o : nullptr, check_order, dst + o);
+    });
+  }
+
+  // ---- Point#add on affine points (short.js:365-412, edwards.js:350-360) ----------------
+  int point_add_dev(int curve, size_t n, const u8* xy1, const u8* inf1, const u8* xy2, const u8* inf2,
+                    u8* out_xy, u8* out_inf) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (curve == CURVE_CURVE25519) return fail(E_UNSUPPORTED, "Not supported on Montgomery curve");   // mont.js:103-105
+    if (n && (!xy1 || !xy2 || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
+    const size_t B = ci->field_bytes;
+    int rc = E_OK;
+    for (size_t o = 0; o < n; o += CHUNK) {
+      size_t m = n - o < CHUNK ? n - o : CHUNK;
+      const u8* i1 = inf1 ? inf1 + o : nullptr;
+      const u8* i2 = inf2 ? inf2 + o : nullptr;
+      if (curve == CURVE_ED25519)
+        rc = ed_point_add_chunk(m, xy1 + o * 2 * B, i1, xy2 + o * 2 * B, i2, out_xy + o * 2 * B, out_inf + o);
+      else
+        ELL_SHORT_DISPATCH(curve, rc = point_add_chunk<CV>(m, xy1 + o * 2 * B, i1, xy2 + o * 2 * B, i2,
+                                                           out_xy + o * 2 * B, out_inf + o));
+      if (rc) return rc;
+    }
+    return E_OK;
+  }
+  int point_add_host(int curve, size_t n, const u8* xy1, const u8* inf1, const u8* xy2, const u8* inf2,
+                     u8* out_xy, u8* out_inf) {
+    const CurveInfo* ci = curve_info(curve);
+    if (!ci) return fail(E_ARG, "unknown curve id");
+    if (n && (!xy1 || !xy2 || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
+    const size_t B = ci->field_bytes;
+    u8* d1 = out_buf(G_IN0, n * 2 * B);
+    u8* d2 = out_buf(G_IN1, n * 2 * B);
+    u8* di1 = inf1 ? out_buf(G_IN2, n) : nullptr;
+    u8* di2 = inf2 ? out_buf(G_IN3, n) : nullptr;
+    u8* dxy = out_buf(G_OUT0, n * 2 * B);
+    u8* dinf = out_buf(G_OUT1, n);
+    if (!d1 || !d2 || !dxy || !dinf || (inf1 && !di1) || (inf2 && !di2)) return fail(E_NOMEM, "staging allocation failed");
+    HostIn ins[4] = {{d1, xy1, 2 * B}, {d2, xy2, 2 * B}, {nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+    int ni = 2;
+    if (inf1) ins[ni++] = HostIn{di1, inf1, 1};
+    if (inf2) ins[ni++] = HostIn{di2, inf2, 1};
+    HostOut outs[2] = {{out_xy, dxy, 2 * B}, {out_inf, dinf, 1}};
+    return pipelined(n, ins, ni, outs, 2, [&](size_t o, size_t m) {
+      return point_add_dev(curve, m, d1 + o * 2 * B, di1 ? di1 + o : nullptr, d2 + o * 2 * B,
+                           di2 ? di2 + o : nullptr, dxy + o * 2 * B, dinf + o);
     });
   }
 
@@ -1572,6 +1640,17 @@ int Engine<BK>::codec_chunk(int op, size_t n, const u8* in, size_t len, int flag
 }
 template <class BK>
 template <class CV>
+int Engine<BK>::point_add_chunk(size_t n, const u8* xy1, const u8* inf1, const u8* xy2, const u8* inf2,
+                                u8* out_xy, u8* out_inf) {
+  typedef Work<CV> W;
+  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+  if (!jac) return fail(E_NOMEM, "scratch allocation failed");
+  FnPointAdd<CV> f{n, xy1, inf1, xy2, inf2, jac};
+  bk.launch(f, n);
+  return normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
+}
+template <class BK>
+template <class CV>
 int Engine<BK>::der_chunk(int op, size_t n, const u8* a, const u8* b, size_t stride, u32* lens, u8* o1, u8* o2,
                           u8* o3) {
   if (op == OP_FROM_DER) {
@@ -1639,6 +1718,17 @@ int Engine<BK>::ed_decompress_chunk(size_t n, const u8* y, const u8* odd, u8* ou
   FnEdDecompress f{n, y, odd, out_xy, out_ok};
   bk.launch(f, n);
   return E_OK;
+}
+
+template <class BK>
+template <int U>
+int Engine<BK>::ed_point_add_chunk(size_t n, const u8* xy1, const u8* inf1, const u8* xy2, const u8* inf2,
+                                   u8* out_xy, u8* out_inf) {
+  u32* ext = (u32*)scratch(S_JAC, n * 4 * 8 * 4);
+  if (!ext) return fail(E_NOMEM, "scratch allocation failed");
+  FnEdPointAdd f{n, xy1, inf1, xy2, inf2, ext};
+  bk.launch(f, n);
+  return ed_normalize_chunk(n, ext, out_xy, out_inf, nullptr);
 }
 
 template <class BK>

@@ -31,6 +31,8 @@ namespace ell {
   KW template int Engine<HipBackend>::decompress_chunk<CV>(size_t, const u8*, const u8*, u8*, u8*); \
   KW template int Engine<HipBackend>::codec_chunk<CV>(int, size_t, const u8*, size_t, int,         \
                                                       const u8*, u8*, u8*);                         \
+  KW template int Engine<HipBackend>::point_add_chunk<CV>(size_t, const u8*, const u8*, const u8*, \
+                                                          const u8*, u8*, u8*);                     \
   KW template int Engine<HipBackend>::der_chunk<CV>(int, size_t, const u8*, const u8*, size_t,     \
                                                     u32*, u8*, u8*, u8*);                           \
   KW template int Engine<HipBackend>::sign_chunk<CV>(size_t, const u8*, int, int, const u8*,       \
@@ -41,7 +43,9 @@ namespace ell {
                                                          int, u8*, u8*, u8*, u8*);
 #define ELL_DECL_ED2(KW)                                                                            \
   KW template int Engine<HipBackend>::ed_decompress_chunk<0>(size_t, const u8*, const u8*, u8*, u8*); \
-  KW template int Engine<HipBackend>::ed_codec_chunk<0>(int, size_t, const u8*, int, const u8*, u8*, u8*);
+  KW template int Engine<HipBackend>::ed_codec_chunk<0>(int, size_t, const u8*, int, const u8*, u8*, u8*); \
+  KW template int Engine<HipBackend>::ed_point_add_chunk<0>(size_t, const u8*, const u8*, const u8*,  \
+                                                            const u8*, u8*, u8*);
 #define ELL_DECL_ED3(KW)                                                                          \
   KW template int Engine<HipBackend>::eddsa_chunk<0>(size_t, size_t, const u8*, const u64*, size_t, \
                                                      const u8*, const u8*, u8*, u8*);

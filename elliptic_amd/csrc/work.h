@@ -240,6 +240,23 @@ struct Work {
     store_jac(jac, n, i, r);
   }
 
+  // ---- affine point addition ---------------------------------------------------
+  // Point#add (short.js:365-392, with #dbl :394-412 for equal points): P + Q for affine
+  // inputs, O on either side, P == Q and P == -Q included -> Jacobian (normalized by the
+  // caller's batch inversion, where the reference inverts per addition).  The chord and
+  // tangent formulas are the reference's own, so off-curve inputs give its results too.
+  ELL_HD static void point_add(size_t i, size_t n, const u8* xy1, const u8* inf1, const u8* xy2,
+                               const u8* inf2, u32* jac) {
+    A p = load_affine(xy1, i);
+    A q = load_affine(xy2, i);
+    bool pinf = inf1 && inf1[i];
+    bool qinf = inf2 && inf2[i];
+    J P = G::select(pinf, G::infinity(), G::from_affine(p));
+    J r = G::add_mixed(P, q);
+    r = G::select(qinf, P, r);                      // P + O = P, O + O = O
+    store_jac(jac, n, i, r);
+  }
+
   // ---- fixed base ----------------------------------------------------------
   // k*G -> Jacobian (replaces _fixedNafMul, base.js:52-84)
   ELL_HD static void mul_fixed(size_t i, size_t n, const u8* ks, const A* comb, u32* jac) {

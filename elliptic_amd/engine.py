@@ -416,6 +416,29 @@ class Context:
             sigs.data_ptr(), pubs.data_ptr(), out_ok.data_ptr(),
             None if out_err is None else out_err.data_ptr(), self._stream()))
 
+    def point_add(self, curve, xy1, xy2, inf1=None, inf2=None):
+        """Point#add per pair of affine points (infinity through the optional flags) -> (xy, inf)"""
+        B = FIELD_BYTES[curve]
+        xy1 = _u8(xy1, (-1, 2 * B))
+        n = xy1.shape[0]
+        xy2 = _u8(xy2, (n, 2 * B))
+        inf1 = None if inf1 is None else _u8(inf1, (n,))
+        inf2 = None if inf2 is None else _u8(inf2, (n,))
+        out = np.zeros((n, 2 * B), np.uint8)
+        inf = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_point_add(self._ctx, self._cid(curve), n, xy1.ctypes.data,
+                                               None if inf1 is None else inf1.ctypes.data, xy2.ctypes.data,
+                                               None if inf2 is None else inf2.ctypes.data,
+                                               out.ctypes.data, inf.ctypes.data))
+        return out, inf
+
+    def point_add_dev(self, curve, xy1, xy2, out_xy, out_inf, inf1=None, inf2=None):
+        n = xy1.shape[0]
+        self._check(self._lib.ellgpu_point_add_dev(self._ctx, self._cid(curve), n, xy1.data_ptr(),
+                                                   None if inf1 is None else inf1.data_ptr(), xy2.data_ptr(),
+                                                   None if inf2 is None else inf2.data_ptr(),
+                                                   out_xy.data_ptr(), out_inf.data_ptr(), self._stream()))
+
     def ecdh_derive(self, curve, priv, pub_xy):
         """KeyPair#derive per item (ec/key.js:102-107): pub.validate() then pub.mul(priv).getX()
         -> (x, status); status 0 shared secret, 1 'public point not validated', 2 the product is

@@ -28,6 +28,7 @@
  *           decodePoints(ctx, curve, enc, encLen) -> {xy, status}
  *           encodePoints(ctx, curve, xy, compact) -> Buffer
  *           validate(ctx, curve, xy, inf|null, checkOrder) -> Buffer (status bytes)
+ *           pointAdd(ctx, curve, xy1, inf1|null, xy2, inf2|null) -> {xy, inf}
  *           sigFromDer(ctx, curve, der, stride, lens) -> {r, s, status}
  *           sigToDer(ctx, curve, r, s) -> {der, lens}     (stride = der.length / n)
  *           ecdsaVerifyWire(ctx, curve, hash, hashLen, msgBits, der, stride, lens, keys, keyLen)
@@ -81,6 +82,8 @@ static struct {
   int (*decode_points)(ellgpu_ctx*, int, size_t, const uint8_t*, size_t, uint8_t*, uint8_t*);
   int (*encode_points)(ellgpu_ctx*, int, size_t, const uint8_t*, int, uint8_t*);
   int (*validate)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, int, uint8_t*);
+  int (*point_add)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*,
+                   uint8_t*, uint8_t*);
   int (*sig_from_der)(ellgpu_ctx*, int, size_t, const uint8_t*, size_t, const uint32_t*, uint8_t*, uint8_t*,
                       uint8_t*);
   int (*sig_to_der)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, uint8_t*, size_t, uint32_t*);
@@ -125,6 +128,7 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   SYM(decode_points, "ellgpu_decode_points");
   SYM(encode_points, "ellgpu_encode_points");
   SYM(validate, "ellgpu_validate");
+  SYM(point_add, "ellgpu_point_add");
   SYM(sig_from_der, "ellgpu_sig_from_der");
   SYM(sig_to_der, "ellgpu_sig_to_der");
   SYM(verify_wire, "ellgpu_ecdsa_verify_wire");
@@ -488,6 +492,27 @@ static napi_value fn_validate(napi_env env, napi_callback_info info) {
   return bst;
 }
 
+static napi_value fn_point_add(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 6; napi_value argv[6];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  int32_t curve;
+  if (napi_get_value_int32(env, argv[1], &curve) != napi_ok) THROW(env, "pointAdd(ctx, curve, xy1, inf1|null, xy2, inf2|null)");
+  int B = L.field_bytes(curve); if (B <= 0) THROW(env, "unknown curve id");
+  const uint8_t *p1, *i1, *p2, *i2; size_t l1, li1, l2, li2;
+  if (!get_buf(env, argv[2], &p1, &l1, 0) || !get_buf(env, argv[3], &i1, &li1, 1) ||
+      !get_buf(env, argv[4], &p2, &l2, 0) || !get_buf(env, argv[5], &i2, &li2, 1)) return NULL;
+  if (l1 % (2 * (size_t)B) || l2 != l1) THROW(env, "buffer length mismatch");
+  size_t n = l1 / (2 * (size_t)B);
+  if ((i1 && li1 != n) || (i2 && li2 != n)) THROW(env, "buffer length mismatch");
+  napi_value bxy, binf; void *dxy, *dinf;
+  CHECK(env, result_buffer(env, n * 2 * (size_t)B, &dxy, &bxy));
+  CHECK(env, result_buffer(env, n, &dinf, &binf));
+  if (L.point_add(c, curve, n, p1, i1, p2, i2, (uint8_t*)dxy, (uint8_t*)dinf) != 0) return lib_error(env);
+  return mk_result(env, "xy", bxy, "inf", binf);
+}
+
 static napi_value fn_sig_from_der(napi_env env, napi_callback_info info) {
   if (!need_lib(env)) return NULL;
   size_t argc = 5; napi_value argv[5];
@@ -720,7 +745,7 @@ static napi_value init(napi_env env, napi_value exports) {
     {"callAsync", fn_call_async}, {"decompress", fn_decompress},
     {"eddsaVerify", fn_eddsa_verify}, {"eddsaSign", fn_eddsa_sign}, {"ecdsaSign", fn_sign}, {"ecdsaRecover", fn_recover}, {"ecdsaSignDet", fn_sign_det},
     {"decodePoints", fn_decode_points}, {"encodePoints", fn_encode_points}, {"validate", fn_validate},
-    {"sigFromDer", fn_sig_from_der}, {"sigToDer", fn_sig_to_der}, {"ecdsaVerifyWire", fn_verify_wire},
+    {"pointAdd", fn_point_add}, {"sigFromDer", fn_sig_from_der}, {"sigToDer", fn_sig_to_der}, {"ecdsaVerifyWire", fn_verify_wire},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

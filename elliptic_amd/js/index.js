@@ -142,6 +142,14 @@ Engine.prototype.validateBatch = function validateBatch(curve, xy, o) {
   return this.addon.validate(this.ctx, id, xy, o.inf || null, o.checkOrder !== false);
 };
 
+// Point#add per pair of affine points: p, q Buffer(n x 2B); o.infP / o.infQ optional Buffer(n)
+// flags for operands at infinity -> { xy, inf }
+Engine.prototype.pointAddBatch = function pointAddBatch(curve, p, q, o) {
+  o = o || {};
+  this.stats.gpuCalls++;
+  return this.addon.pointAdd(this.ctx, this._id(curve), p, o.infP || null, q, o.infQ || null);
+};
+
 // DER signatures and EC#verify on wire formats.
 function packRecords(items) {
   var n = items.length, stride = 1, i;

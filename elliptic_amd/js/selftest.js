@@ -215,6 +215,22 @@ function check(r, i, B, want, what) {
     checked++;
   });
 });
+['secp256k1', 'p384', 'ed25519'].forEach(function(name) {
+  var cs = JSON.parse(fs.readFileSync(path.join(GOLD, 'add_' + name + '.json')));
+  var B = (cs[0].r.x || cs[0].p.x).length / 2;
+  function pack(key) {
+    return { xy: Buffer.concat(cs.map(function(c) { return c[key].x ? hexBuf([c[key].x, c[key].y], B) : Buffer.alloc(2 * B); })),
+      inf: Buffer.from(cs.map(function(c) { return c[key].x ? 0 : 1; })) };
+  }
+  var p = pack('p'), q = pack('q');
+  var r = eng.pointAddBatch(name, p.xy, q.xy, { infP: p.inf, infQ: q.inf });
+  cs.forEach(function(c, i) {
+    var good = c.r.x ? r.xy.slice(i * 2 * B, (i + 1) * 2 * B).toString('hex') === c.r.x + c.r.y &&
+      (r.inf[i] === 1) === !!c.r.inf : r.inf[i] === 1;
+    if (!good) throw new Error('point add mismatch: ' + name + ' ' + c.note);
+    checked++;
+  });
+});
 var lc = JSON.parse(fs.readFileSync(path.join(GOLD, 'mul_curve25519.json')));
 var rr = eng.x25519Batch(hexBuf(lc.map(function(c) { return c.k; }), 32), hexBuf(lc.map(function(c) { return c.px; }), 32));
 lc.forEach(function(c, i) {

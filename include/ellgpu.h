@@ -165,6 +165,19 @@ int ellgpu_validate(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, con
 int ellgpu_validate_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, const uint8_t* inf,
                         int check_order, uint8_t* out_status, void* stream);
 
+/* Affine point addition: Point#add (lib/elliptic/curve/short.js:365-392, with Point#dbl
+ * :394-412 where the operands are equal; lib/elliptic/curve/edwards.js:350-360 -> _extAdd
+ * :279-309 for ed25519).  inf1 / inf2 (either may be NULL) flag operands that are the point at
+ * infinity (the identity (0, 1) on ed25519); out_inf as for ellgpu_mul_var.  One launch of the
+ * chord / tangent formula + the batched normalization, where the reference inverts once per
+ * addition.  On the short curves the formulas are the reference's own, so off-curve operands give
+ * the reference's coordinates as well. */
+int ellgpu_point_add(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy1, const uint8_t* inf1,
+                     const uint8_t* xy2, const uint8_t* inf2, uint8_t* out_xy, uint8_t* out_inf);
+int ellgpu_point_add_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy1, const uint8_t* inf1,
+                         const uint8_t* xy2, const uint8_t* inf2, uint8_t* out_xy, uint8_t* out_inf,
+                         void* stream);
+
 /* Signature DER codec (lib/elliptic/ec/signature.js) and EC#verify on wire formats.
  * ellgpu_sig_from_der: Signature#_importDER (signature.js:83-147, with getLength :30-59) of n
  *   records of `stride` bytes, the first der_len[i] of each being the signature.  out_r / out_s

@@ -83,6 +83,11 @@ def test_ecdh_derive(ctx, curve):
     assert PC.check_ecdh(ctx, curve) > 0
 
 
+@pytest.mark.parametrize("curve", O.SHORT_CURVES + ["ed25519"])
+def test_point_add_golden(ctx, curve):
+    assert PC.check_add_golden(ctx, curve) >= 20
+
+
 def test_der_fuzz(ctx):
     assert PC.check_der_fuzz(ctx) > 2000
 

@@ -212,6 +212,23 @@ def test_wire_formats_match_reference(name):
     assert bad > 3
 
 
+@pytest.mark.parametrize("name", O.SHORT_CURVES + ["ed25519"])
+def test_point_add_matches_reference(name):
+    """Point#add (short.js:365-412, edwards.js:350-360) incl. the exceptional cases"""
+    cur = O.get_curve(name)
+    for c in load("add_%s.json" % name):
+        if name == "ed25519":
+            p = cur.point(I(c["p"]["x"]), I(c["p"]["y"]))
+            q = cur.point(I(c["q"]["x"]), I(c["q"]["y"]))
+            assert p.add(q).normalized() == (I(c["r"]["x"]), I(c["r"]["y"])), c
+            continue
+        p = cur.point(None, None) if c["p"].get("inf") else cur.point(I(c["p"]["x"]), I(c["p"]["y"]))
+        q = cur.point(None, None) if c["q"].get("inf") else cur.point(I(c["q"]["x"]), I(c["q"]["y"]))
+        r = p.add(q)
+        want = None if c["r"].get("inf") else (I(c["r"]["x"]), I(c["r"]["y"]))
+        assert (None if r.inf else (r.x, r.y)) == want, c
+
+
 def test_der_fuzz_matches_reference():
     """the oracle's _importDER against the reference's verdicts on mutated encodings"""
     bad = 0

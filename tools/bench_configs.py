@@ -66,6 +66,10 @@ def main():
         timed("%s fixed-base G*k" % curve, n, lambda: ctx.mul_fixed_dev(curve, dd, pts, inf))
         timed("%s variable-base P*k" % curve, n, lambda: ctx.mul_var_dev(curve, dk, pts, out, inf))
         timed("%s k1*G + k2*P" % curve, n, lambda: ctx.mul_add2_dev(curve, dd, None, dk, pts, out, inf))
+        if curve in ("secp256k1", "ed25519"):
+            # Point#add of the two batches just produced (d*G and k1*G + k2*P), batched normalization
+            sm = torch.zeros((n, 2 * B), dtype=torch.uint8, device=dev)
+            timed("%s affine point addition P + Q" % curve, n, lambda: ctx.point_add_dev(curve, pts, out, sm, inf))
         if curve in ("secp256k1", "p192", "p224", "p256", "p384", "p521"):
             # ECDSA sign for supplied nonces (hash = k bytes, priv = d, nonce = k ^ d: all < 2^256, a few
             # percent >= n are flagged per item), key decompression of the x coordinates just produced

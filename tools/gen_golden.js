@@ -571,6 +571,56 @@ function genWire(name) {
   return out;
 }
 
+// -------------------------------------------------------------- add_<curve>.json
+// Point#add (short.js:365-412 / edwards.js:350-360): random pairs, P + P, P + (-P), O on
+// either side, points of order 2 where the curve has them, and (short curves) off-curve
+// operands -- the reference's chord / tangent formulas define those results too.
+function genAdd(name) {
+  var c = elliptic.curves[name].curve;
+  var L = flen(c);
+  var rng = new Prng('ellgpu-golden-v1:add:' + name);
+  var N = Math.max(10, COUNTS[name] >> 1);
+  var cases = [];
+  function enc(p) {
+    if (c.type === 'short') return p.inf ? { inf: true } : { x: hex(p.getX(), L), y: hex(p.getY(), L) };
+    return { x: hex(p.getX(), L), y: hex(p.getY(), L) };
+  }
+  function one(p, q, note) {
+    var r = p.add(q);
+    var o = { p: enc(p), q: enc(q), note: note };
+    if (c.type === 'short') o.r = r.inf ? { inf: true } : { x: hex(r.getX(), L), y: hex(r.getY(), L) };
+    else o.r = { x: hex(r.getX(), L), y: hex(r.getY(), L), inf: r.isInfinity() };
+    cases.push(o);
+  }
+  var O = c.type === 'short' ? c.point(null, null) : c.point(null, null, null);
+  for (var i = 0; i < N; i++) {
+    var P = c.g.mul(rng.below(c.n.subn(1)).addn(1));
+    var Q = c.g.mul(rng.below(c.n.subn(1)).addn(1));
+    if (c.type !== 'short') { P = c.point(P.getX(), P.getY()); Q = c.point(Q.getX(), Q.getY()); }
+    one(P, Q, 'random');
+    if (i % 4 === 0) one(P, P, 'P+P');
+    if (i % 4 === 1) one(P, P.neg(), 'P+(-P)');
+    if (i % 4 === 2) { one(P, O, 'P+O'); one(O, Q, 'O+Q'); }
+    if (i % 4 === 3) one(O, O, 'O+O');
+    if (c.type === 'short') {
+      var bx = rng.below(c.p), by = rng.below(c.p), cx = rng.below(c.p), cy = rng.below(c.p);
+      one(c.point(bx, by), c.point(cx, cy), 'off-curve');
+      if (i % 3 === 0) one(c.point(bx, by), c.point(bx, by), 'off-curve P+P');
+      if (i % 3 === 1) one(c.point(bx, by), c.point(bx, cy), 'off-curve same x');
+      if (i % 3 === 2) one(c.point(bx, new BN(0)), c.point(bx, new BN(0)), 'y = 0 doubled');
+    }
+  }
+  if (c.type !== 'short') {
+    var t8 = new elliptic.eddsa(name).decodePoint('26e8958fc2b227b045c3f489f2ef98f0d5dfac05d3c63339b13802886d53fc05');
+    t8 = c.point(t8.getX(), t8.getY());
+    var t4 = t8.dbl(); t4 = c.point(t4.getX(), t4.getY());
+    var t2 = t4.dbl(); t2 = c.point(t2.getX(), t2.getY());
+    one(t8, t8, 'order 8 doubled'); one(t4, t4, 'order 4 doubled'); one(t2, t2, 'order 2 doubled');
+    one(t8, c.point(c.g.getX(), c.g.getY()), 'order 8 + G');
+  }
+  return cases;
+}
+
 // ------------------------------------------------------- der_fuzz_secp256k1.json
 // Signature#_importDER on mutated encodings: byte flips, insertions, deletions, length-field
 // edits and splices of valid signatures (seeded).  { der, r, s } or { der, bad: true }.
@@ -970,6 +1020,9 @@ SHORT.forEach(function(name) {
   write('wire_' + name + '.json', genWire(name));
 });
 write('der_fuzz_secp256k1.json', genDerFuzz());
+SHORT.concat(['ed25519']).forEach(function(name) {
+  write('add_' + name + '.json', genAdd(name));
+});
 write('eddsa_verify_ed25519.json', genEddsa());
 write('eddsa_sign_ed25519.json', genEddsaSign());
 write('mul_ed25519.json', genEdwardsMul());
