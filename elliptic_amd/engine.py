@@ -264,7 +264,8 @@ class Context:
         return [out[i, :lens[i]].tobytes() for i in range(n)]
 
     def ecdsa_verify_wire(self, curve, hashes, sigs, pubs, msg_bits=0):
-        """EC#verify(msg, DER signature, encoded key) per item.  sigs: list of byte strings;
+        """EC#verify(msg, DER signature, encoded key) per item.  sigs: list of byte strings (or
+        the packed pair _pack_records returns);
         pubs: (n, pub_len) SEC1 encodings -> (ok, err); err 1..3 = decodePoint's status for the
         key, 4 = 'Signature without r or s'"""
         hashes = _u8(hashes)
@@ -272,9 +273,12 @@ class Context:
             raise ValueError("hashes must be (n, hash_len)")
         n, hash_len = hashes.shape
         pubs = _u8(pubs)
-        if pubs.ndim != 2 or pubs.shape[0] != n or len(sigs) != n:
-            raise ValueError("pubs must be (n, pub_len), sigs a list of n byte strings")
-        der, lens = self._pack_records(sigs)
+        if isinstance(sigs, tuple):                   # already packed: ((n, stride) uint8, (n,) uint32)
+            der, lens = _u8(sigs[0]), np.ascontiguousarray(sigs[1], np.uint32)
+        else:
+            der, lens = self._pack_records(sigs)
+        if pubs.ndim != 2 or pubs.shape[0] != n or der.shape[0] != n or lens.shape[0] != n:
+            raise ValueError("pubs must be (n, pub_len), sigs n byte strings (or packed records + lengths)")
         ok = np.zeros(n, np.uint8)
         err = np.zeros(n, np.uint8)
         self._check(self._lib.ellgpu_ecdsa_verify_wire(self._ctx, self._cid(curve), n, hashes.ctypes.data,

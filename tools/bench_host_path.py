@@ -41,6 +41,14 @@ def main():
     timed("secp256k1 ecdsa_verify, host buffers (H2D 160 B + D2H 1 B per item)",
           lambda: ctx.ecdsa_verify("secp256k1", hz, hr, hs, hq),
           lambda ok: np.array_equal(np.asarray(ok).astype(np.uint8), want.astype(np.uint8)))
+    # the same batch in wire formats: DER signatures + compressed keys (H2D 32 + 72 + 4 + 33 B)
+    packed = ctx._pack_records(ctx.sig_to_der("secp256k1", hr, hs))
+    keys = ctx.encode_points("secp256k1", hq, compact=True)
+    timed("secp256k1 ecdsa_verify_wire, host buffers (DER + compressed keys, H2D %d B + D2H 2 B per item)"
+          % (32 + packed[0].shape[1] + 4 + 33),
+          lambda: ctx.ecdsa_verify_wire("secp256k1", hz, packed, keys),
+          # (a corrupted key's x may have no y at all: err = 'invalid point', still not ok)
+          lambda o: np.array_equal(o[0], want.astype(np.uint8)) and not o[1][want.astype(bool)].any())
     xy0, inf0 = ctx.mul_var("secp256k1", hr, hq)
     timed("secp256k1 mul_var, host buffers (H2D 96 B + D2H 65 B per item)",
           lambda: ctx.mul_var("secp256k1", hr, hq),
