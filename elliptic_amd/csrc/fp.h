@@ -51,10 +51,13 @@ struct Fe {
 #ifndef ELL_P521_INLINE
 #define ELL_P521_INLINE 1
 #endif
-// ELL_P521_JTABLE = 1: p521 keeps the signed-window ladder over a Jacobian table; the odd-digit
-// affine-table ladder of the smaller curves measures slower there (4.8 M/s)
+// ELL_P521_JTABLE = 1 switches p521 back to the signed-window ladder over a Jacobian table.  The
+// odd-digit affine-table ladder of the smaller curves is faster there too (7.2 against 6.75 M
+// P*k/s, same box) and has the smaller loop body -- the p521 kernels are sensitive to that: their
+// inlined code no longer fits the instruction cache, and boxes of the pool whose memory side
+// runs slower (normalize -20 %) lose 40 % on them instead of the usual 5 %.
 #ifndef ELL_P521_JTABLE
-#define ELL_P521_JTABLE 1
+#define ELL_P521_JTABLE 0
 #endif
 #ifndef ELL_MUL_CHAIN
 #define ELL_MUL_CHAIN 1

@@ -161,8 +161,8 @@ struct Work {
       r.Z = F::mul(r.Z, zg);
       return r;
     } else if constexpr (L > 12 && ELL_P521_JTABLE) {
-      // p521: measured faster with the plain signed-window ladder over a Jacobian table (the
-      // 16 affine slots hold its 8 Jacobian entries)
+      // (developer switch, see fp.h) plain signed-window ladder over a Jacobian table: the
+      // 16 affine slots hold its 8 Jacobian entries
       static_assert(16 * sizeof(A) >= 8 * sizeof(J), "table slot too small");
       u32 negmask = 0;
       prepare_var(k, p, ds, 0, NSV, (J*)tbl, negmask);
