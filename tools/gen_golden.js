@@ -706,6 +706,28 @@ function genEddsa() {
     if (kind === 6) rec(msg, sig, flip(pub, 31, 7), 'A sign bit flipped');
     if (kind === 7) rec(msg, rng.bytes(64).toString('hex'), pub, 'random sig');
   });
+  // Small-order / non-canonical R: decodePoint reduces y mod p, so y = p + 1 (the identity,
+  // non-canonically) and y = p (the order-4 point (sqrt(-1), 0)... y = 0) are accepted as
+  // encodings.  Signatures with such an R are built by hand: S = h * a (R = identity: r = 0).
+  var p = ed.curve.p;
+  for (var t = 0; t < 6; t++) {
+    var key = ed.keyFromSecret(rng.bytes(32).toString('hex'));
+    var a = key.priv();
+    var m = rng.bytes(10 + t);
+    [p.addn(1), new BN(1)].forEach(function(y, which) {          // identity: non-canonical, canonical
+      var renc = y.toArray('le', 32);
+      var h = ed.hashInt(renc, key.pubBytes(), Array.prototype.slice.call(m));
+      var S = h.mul(a).umod(ed.curve.n);
+      var sg = Buffer.from(renc.concat(S.toArray('le', 32))).toString('hex');
+      rec(m.toString('hex'), sg, Buffer.from(key.pubBytes()).toString('hex'),
+        which === 0 ? 'R = identity, non-canonical y = p + 1' : 'R = identity, canonical');
+      if (t === 0) rec(m.toString('hex'), flip(sg, 40, 1), Buffer.from(key.pubBytes()).toString('hex'), 'same, bad S');
+    });
+    // non-canonical y in [p, 2^255): y = p + k for small k; valid only by accident, must agree anyway
+    var renc2 = p.addn(3 + t).toArray('le', 32);
+    rec(m.toString('hex'), Buffer.from(renc2.concat(rng.bytes(32).toJSON().data)).toString('hex').slice(0, 126) + '00',
+      Buffer.from(key.pubBytes()).toString('hex'), 'R non-canonical y = p + ' + (3 + t));
+  }
   return cases;
 }
 
