@@ -105,6 +105,21 @@ def cpu_baseline(h, r, s, pub, ok, budget_s=15.0):
             "sample": "first %d tuples of the rank-0 batch, oracle/ec_oracle.py (python ints), 1 thread" % done}
 
 
+def reference_js_from_profiles():
+    """The reference's own pure-JS path, timed by tools/bench_reference_js.js in the build
+    container (the GPU box holds no copy of the reference): quoted, never re-measured here."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*reference_js_cpu.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+    except ValueError:
+        return None
+    return {"verifies_per_s_per_core": d.get("verify_random_per_s"), "cpu": d.get("cpu"), "node": d.get("node"),
+            "where": d.get("where"), "source": os.path.relpath(files[-1], ROOT)}
+
+
 def traffic_from_profiles():
     """HBM bytes per ecdsa_main launch from the newest committed rocprofv3 PMC summary
     (profiles/*pmc_fetch_write*.txt; FETCH_SIZE / WRITE_SIZE are reported in KiB and were
@@ -291,6 +306,7 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(h, r, s, pub, expect)
+            out["cpu_baseline"]["reference_js"] = reference_js_from_profiles()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
