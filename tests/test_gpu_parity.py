@@ -250,6 +250,17 @@ def test_empty_batches_newer_entry_points(ctx):
     assert ctx.decompress("secp256k1", e32, np.zeros(0, np.uint8))[0].shape == (0, 64)
     assert ctx.eddsa_sign([], np.zeros((0, 32), np.uint8))[0].shape == (0, 64)
     assert ctx.eddsa_verify([], np.zeros((0, 64), np.uint8), np.zeros((0, 32), np.uint8))[0].shape == (0,)
+    assert ctx.decode_points("secp256k1", np.zeros((0, 33), np.uint8))[0].shape == (0, 64)
+    assert ctx.encode_points("secp256k1", np.zeros((0, 64), np.uint8), compact=True).shape == (0, 33)
+    assert ctx.validate("ed25519", np.zeros((0, 64), np.uint8)).shape == (0,)
+    assert ctx.sig_from_der("p256", [])[0].shape == (0, 32)
+    assert ctx.sig_to_der("p256", e32, e32) == []
+    assert ctx.ecdsa_verify_wire("secp256k1", z, [], np.zeros((0, 33), np.uint8))[0].shape == (0,)
+    assert ctx.point_add("p384", np.zeros((0, 96), np.uint8), np.zeros((0, 96), np.uint8))[0].shape == (0, 96)
+    with pytest.raises(elliptic_amd.EllgpuError):
+        ctx.decode_points("ed25519", np.zeros((1, 33), np.uint8))
+    with pytest.raises(elliptic_amd.EllgpuError):
+        ctx.point_add("curve25519", np.zeros((1, 64), np.uint8), np.zeros((1, 64), np.uint8))
 
 
 def _make_sigs(ctx, n, seed):

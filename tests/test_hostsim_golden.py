@@ -356,6 +356,25 @@ def test_empty_batches_newer_entry_points(ctx):
     assert sig.shape == (0, 64) and pub.shape == (0, 32)
     ok, err = ctx.eddsa_verify([], np.zeros((0, 64), np.uint8), np.zeros((0, 32), np.uint8))
     assert ok.shape == (0,)
+    # codecs, validation, DER, wire verify, point addition
+    xy, st = ctx.decode_points("secp256k1", np.zeros((0, 33), np.uint8))
+    assert xy.shape == (0, 64) and st.shape == (0,)
+    assert ctx.encode_points("secp256k1", np.zeros((0, 64), np.uint8), compact=True).shape == (0, 33)
+    assert ctx.validate("ed25519", np.zeros((0, 64), np.uint8)).shape == (0,)
+    r, s_, st = ctx.sig_from_der("p256", [])
+    assert r.shape == (0, 32) and st.shape == (0,)
+    assert ctx.sig_to_der("p256", e32, e32) == []
+    ok, err = ctx.ecdsa_verify_wire("secp256k1", z, [], np.zeros((0, 33), np.uint8))
+    assert ok.shape == (0,) and err.shape == (0,)
+    xy, inf = ctx.point_add("p384", np.zeros((0, 96), np.uint8), np.zeros((0, 96), np.uint8))
+    assert xy.shape == (0, 96)
+    # argument errors are reported, not computed
+    with pytest.raises(elliptic_amd.EllgpuError):
+        ctx.decode_points("ed25519", np.zeros((1, 33), np.uint8))
+    with pytest.raises(elliptic_amd.EllgpuError):
+        ctx.sig_from_der("ed25519", [b"\x30\x00"])
+    with pytest.raises(elliptic_amd.EllgpuError):
+        ctx.point_add("curve25519", np.zeros((1, 64), np.uint8), np.zeros((1, 64), np.uint8))
 
 
 def test_error_paths(ctx, hs):
