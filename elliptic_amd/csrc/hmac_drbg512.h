@@ -1,6 +1,6 @@
 // ellgpu -- HMAC_DRBG over SHA-384 / SHA-512, word-oriented (64-bit words): the register-resident
 // form of hmac_drbg.h for p384, where n.byteLength() = 48 is a whole number of words and one V
-// block covers a draw (p521's 66-byte draws stay on the byte-wise generator).  Layout and
+// block covers a draw; HmacDrbg512Bytes below handles p521's 66-byte seeds and draws.  Layout and
 // compression counts as in hmac_drbg256.h.  OUTW = digest words (6: SHA-384, 8: SHA-512),
 // SEEDW = 64-bit words of entropy || nonce.
 #pragma once
@@ -65,11 +65,19 @@ struct Sha512W {
 // The prefix words and every whole message word are assembled without byte loops (the message
 // is read with 8-byte loads + a byte swap); only the word holding the end of the message is put
 // together byte by byte.
+// `init` (optional) = the state after `prior` bytes (a whole number of blocks) already hashed:
+// HMAC's inner hash continues from the state of the ipad block.
 template <int PW>
-ELL_HD void sha512_prefixed(u64 (&st)[8], const u64* pre, const u8* msg, u64 len) {
+ELL_HD void sha512_prefixed(u64 (&st)[8], const u64* pre, const u8* msg, u64 len,
+                            const u64* init = nullptr, u64 prior = 0) {
   typedef Sha512W<8> H;
   static_assert(PW >= 0 && PW < 14, "prefix must leave room in the first block");
-  H::iv(st);
+  if (init) {
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) st[i] = init[i];
+  } else {
+    H::iv(st);
+  }
   const u64 total = 8ull * PW + len;
   const u64 nblk = (total + 1 + 16 + 127) / 128;
   // message word starting at byte `off` of msg (may lie beyond its end: padding)
@@ -101,7 +109,7 @@ ELL_HD void sha512_prefixed(u64 (&st)[8], const u64* pre, const u8* msg, u64 len
         w[t] = msg_word(blk * 128 + 8 * t - 8ull * PW);
       }
     }
-    if (last) { w[14] = 0; w[15] = total * 8; }       // 128-bit length; messages are < 2^61 bytes
+    if (last) { w[14] = 0; w[15] = (prior + total) * 8; }   // 128-bit length; messages are < 2^61 bytes
     H::compress(st, w);
   }
 }
@@ -215,6 +223,79 @@ struct HmacDrbg512 {
     ELL_UNROLL
     for (int i = 0; i < OUTW; i++) { Vw[i] = t[i]; out[i] = t[i]; }
     update<0>(nullptr);
+  }
+};
+
+// HMAC_DRBG over SHA-512 for seeds and draws that are not whole words (p521: 66-byte entropy,
+// nonce and draws): K, V and the two key states live in registers as 64-bit words, the
+// sep || seed tail of an update is read from a byte buffer 8 bytes at a time.
+struct HmacDrbg512Bytes {
+  typedef Sha512W<8> H;
+  u64 Kw[8], Vw[8], si[8], so[8];
+
+  ELL_HD void key_states() {
+    u64 blk[16];
+    ELL_UNROLL
+    for (int i = 0; i < 16; i++) blk[i] = (i < 8 ? Kw[i] : 0ull) ^ 0x3636363636363636ULL;
+    H::iv(si);
+    H::compress(si, blk);
+    ELL_UNROLL
+    for (int i = 0; i < 16; i++) blk[i] ^= 0x3636363636363636ULL ^ 0x5c5c5c5c5c5c5c5cULL;
+    H::iv(so);
+    H::compress(so, blk);
+  }
+  // out = HMAC(K, V || tail[0..len))
+  ELL_HD void hmac_v_tail(u64 (&out)[8], const u8* tail, u64 len) const {
+    u64 in[8];
+    sha512_prefixed<8>(in, Vw, tail, len, si, 128);
+    u64 blk[16];
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) blk[i] = in[i];
+    blk[8] = 0x8000000000000000ULL;
+    ELL_UNROLL
+    for (int i = 9; i < 15; i++) blk[i] = 0;
+    blk[15] = (128 + 64) * 8;
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) out[i] = so[i];
+    H::compress(out, blk);
+  }
+  // hmac-drbg.js:54-69 _update; buf[0] is the separator slot, buf[1..1+seedlen) the seed
+  ELL_HD void update(u8* buf, u64 seedlen) {
+    u64 t[8];
+    buf[0] = 0x00;
+    hmac_v_tail(t, buf, 1 + seedlen);
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) Kw[i] = t[i];
+    key_states();
+    hmac_v_tail(t, nullptr, 0);
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) Vw[i] = t[i];
+    if (seedlen == 0) return;
+    buf[0] = 0x01;
+    hmac_v_tail(t, buf, 1 + seedlen);
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) Kw[i] = t[i];
+    key_states();
+    hmac_v_tail(t, nullptr, 0);
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) Vw[i] = t[i];
+  }
+  ELL_HD void init(u8* buf, u64 seedlen) {
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) { Kw[i] = 0; Vw[i] = 0x0101010101010101ULL; }
+    key_states();
+    update(buf, seedlen);
+  }
+  // :91-113 generate(len), 64 < len <= 128: two V blocks, the first `len` bytes as big-endian words
+  ELL_HD void generate2(u64 (&out)[16], u8* sepbuf) {
+    u64 t[8];
+    hmac_v_tail(t, nullptr, 0);
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) { Vw[i] = t[i]; out[i] = t[i]; }
+    hmac_v_tail(t, nullptr, 0);
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) { Vw[i] = t[i]; out[8 + i] = t[i]; }
+    update(sepbuf, 0);
   }
 };
 

@@ -757,6 +757,27 @@ struct Work {
       ELL_UNROLL
       for (int w = 0; w < LN; w++) k[w] = done ? k[w] : 0u;
       store_be<LN>(nonce_out + i * NBYTES, k, NBYTES);
+    } else if constexpr (std::is_same<SignHash, Sha512>::value && NBYTES > 64 && NBYTES <= 128) {
+      // p521: 66-byte entropy, nonce and draws -- word-oriented state, byte-granular tails
+      u8 sb[1 + 2 * NBYTES], kb[NBYTES];
+      ELL_NOUNROLL
+      for (int b = 0; b < NBYTES; b++) sb[1 + b] = priv[i * NBYTES + b];
+      store_be<LN>(sb + 1 + NBYTES, e, NBYTES);
+      HmacDrbg512Bytes g;
+      g.init(sb, 2 * NBYTES);
+      bool done = false;
+      ELL_NOUNROLL
+      for (int it = 0; it < 16 && !done; it++) {
+        u64 v[16];
+        g.generate2(v, sb);
+        ELL_UNROLL
+        for (int b = 0; b < NBYTES; b++) kb[b] = (u8)(v[b >> 3] >> (56 - 8 * (b & 7)));
+        u32 k[LN];
+        load_nonce(k, kb);
+        done = !bn_is_zero<LN>(k) && !bn_eq<LN>(k, one1) && !bn_geq<LN>(k, nm1);
+      }
+      ELL_NOUNROLL
+      for (int b = 0; b < NBYTES; b++) nonce_out[i * NBYTES + b] = done ? kb[b] : (u8)0;
     } else {
       u8 eb[NBYTES], kb[NBYTES];
       store_be<LN>(eb, e, NBYTES);
