@@ -36,7 +36,9 @@
  *             offsets: Buffer of n+1 little-endian uint64 byte offsets into msgs
  *           callAsync(op, ctx, curve, hashLen, msgBits, b0, b1, b2, b3) -> Promise
  *             op 0 mulFixed(b0=k) 1 mulVar(k, xy) 2 mulAdd2(k1, p1|null, k2, p2)
- *             3 ecdsaVerify(hash, r, s, pub) 4 x25519(k, x); runs on a libuv worker
+ *             3 ecdsaVerify(hash, r, s, pub) 4 x25519(k, x) 5 ecdsaSignDet(hash, priv; i0 = canonical)
+ *             6 ecdsaRecover(hash, r, s, recid) 7 ecdsaVerifyWire(hash, der, lens, keys; i0 = der
+ *             stride, i1 = key length) 8 decodePoints(enc; i0 = encoding length); runs on a libuv worker
  *             thread (napi_async_work) so the JS thread is not blocked; resolves to the
  *             same value the synchronous form returns.  One call per context at a time:
  *             index.js serialises them.
@@ -642,6 +644,9 @@ typedef struct {
   size_t n;
   uint8_t* out0; size_t out0_len;      /* xy / ok / x */
   uint8_t* out1; size_t out1_len;      /* inf */
+  uint8_t* out2; size_t out2_len;      /* ops 5..: third / fourth result */
+  uint8_t* out3; size_t out3_len;
+  int i0, i1;                          /* op 5: canonical; op 7: der stride, key length; op 8: encoding length */
   int rc;
   char err[512];
 } async_job;
@@ -654,7 +659,14 @@ static void job_execute(napi_env env, void* data) {
     case 1: j->rc = L.mul_var(j->ctx, j->curve, j->n, j->in[0], j->in[1], j->out0, j->out1); break;
     case 2: j->rc = L.mul_add2(j->ctx, j->curve, j->n, j->in[0], j->in[1], j->in[2], j->in[3], j->out0, j->out1); break;
     case 3: j->rc = L.ecdsa_verify(j->ctx, j->curve, j->n, j->in[0], j->hash_len, j->msg_bits, j->in[1], j->in[2], j->in[3], j->out0); break;
-    default: j->rc = L.x25519(j->ctx, j->n, j->in[0], j->in[1], j->out0, j->out1); break;
+    case 4: j->rc = L.x25519(j->ctx, j->n, j->in[0], j->in[1], j->out0, j->out1); break;
+    case 5: j->rc = L.ecdsa_sign_det(j->ctx, j->curve, j->n, j->in[0], j->hash_len, j->msg_bits, j->in[1], j->i0,
+                                     j->out0, j->out1, j->out2, j->out3); break;
+    case 6: j->rc = L.ecdsa_recover(j->ctx, j->curve, j->n, j->in[0], j->hash_len, j->in[1], j->in[2], j->in[3],
+                                    j->out0, j->out1); break;
+    case 7: j->rc = L.verify_wire(j->ctx, j->curve, j->n, j->in[0], j->hash_len, j->msg_bits, j->in[1], (size_t)j->i0,
+                                  (const uint32_t*)j->in[2], j->in[3], (size_t)j->i1, j->out0, j->out1); break;
+    default: j->rc = L.decode_points(j->ctx, j->curve, j->n, j->in[0], (size_t)j->i0, j->out0, j->out1); break;
   }
   if (j->rc != 0) {               /* last_error is thread-local: read it on this thread */
     const char* m = L.last_error();
@@ -666,16 +678,25 @@ static void job_complete(napi_env env, napi_status status, void* data) {
   async_job* j = (async_job*)data;
   napi_value result = NULL;
   if (status == napi_ok && j->rc == 0) {
-    napi_value b0, b1;
-    napi_create_external_buffer(env, j->out0_len, j->out0, free_cb, NULL, &b0);
-    j->out0 = NULL;
-    if (j->op == 3) result = b0;
-    else {
-      napi_create_external_buffer(env, j->out1_len, j->out1, free_cb, NULL, &b1);
-      j->out1 = NULL;
+    /* result property names per op, in output order */
+    static const char* const names[9][4] = {
+      {"xy", "inf", 0, 0}, {"xy", "inf", 0, 0}, {"xy", "inf", 0, 0}, {0, 0, 0, 0}, {"x", "inf", 0, 0},
+      {"r", "s", "recid", "ok"}, {"xy", "status", 0, 0}, {"ok", "err", 0, 0}, {"xy", "status", 0, 0}};
+    uint8_t** outs[4] = {&j->out0, &j->out1, &j->out2, &j->out3};
+    size_t lens[4] = {j->out0_len, j->out1_len, j->out2_len, j->out3_len};
+    napi_value b0;
+    if (j->op == 3) {
+      napi_create_external_buffer(env, j->out0_len, j->out0, free_cb, NULL, &b0);
+      j->out0 = NULL;
+      result = b0;
+    } else {
       napi_create_object(env, &result);
-      napi_set_named_property(env, result, j->op == 4 ? "x" : "xy", b0);
-      napi_set_named_property(env, result, "inf", b1);
+      for (int k = 0; k < 4 && names[j->op][k]; k++) {
+        napi_value b;
+        napi_create_external_buffer(env, lens[k], *outs[k], free_cb, NULL, &b);
+        *outs[k] = NULL;
+        napi_set_named_property(env, result, names[j->op][k], b);
+      }
     }
     napi_resolve_deferred(env, j->deferred, result);
   } else {
@@ -686,13 +707,13 @@ static void job_complete(napi_env env, napi_status status, void* data) {
   }
   for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
   napi_delete_async_work(env, j->work);
-  free(j->out0); free(j->out1); free(j);
+  free(j->out0); free(j->out1); free(j->out2); free(j->out3); free(j);
 }
 static napi_value fn_call_async(napi_env env, napi_callback_info info) {
   if (!need_lib(env)) return NULL;
-  size_t argc = 9; napi_value argv[9];
+  size_t argc = 11; napi_value argv[11];
   CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  if (argc < 9) THROW(env, "callAsync(op, ctx, curve, hashLen, msgBits, b0, b1, b2, b3)");
+  if (argc < 9) THROW(env, "callAsync(op, ctx, curve, hashLen, msgBits, b0, b1, b2, b3[, i0, i1])");
   async_job* j = (async_job*)calloc(1, sizeof *j);
   int32_t op, curve, hl, mb;
   napi_get_value_int32(env, argv[0], &op);
@@ -701,7 +722,11 @@ static napi_value fn_call_async(napi_env env, napi_callback_info info) {
   napi_get_value_int32(env, argv[2], &curve); napi_get_value_int32(env, argv[3], &hl); napi_get_value_int32(env, argv[4], &mb);
   j->op = op; j->curve = op == 4 ? 7 : curve; j->hash_len = hl; j->msg_bits = mb;
   j->B = L.field_bytes(j->curve); j->NB = L.order_bytes(j->curve);
-  if (op < 0 || op > 4 || j->B <= 0) { free(j); THROW(env, "callAsync: bad op / curve"); }
+  if (op < 0 || op > 8 || j->B <= 0) { free(j); THROW(env, "callAsync: bad op / curve"); }
+  int32_t i0 = 0, i1 = 0;
+  if (argc > 9) napi_get_value_int32(env, argv[9], &i0);
+  if (argc > 10) napi_get_value_int32(env, argv[10], &i1);
+  j->i0 = i0; j->i1 = i1;
   size_t len[4] = {0, 0, 0, 0};
   for (int i = 0; i < 4; i++) {
     if (!get_buf(env, argv[5 + i], &j->in[i], &len[i], 1)) { free(j); return NULL; }
@@ -717,17 +742,33 @@ static napi_value fn_call_async(napi_env env, napi_callback_info info) {
     case 3: ok = hl > 0 && j->in[0] && j->in[1] && j->in[2] && j->in[3] && len[0] % (size_t)hl == 0;
             j->n = ok ? len[0] / (size_t)hl : 0;
             ok = ok && len[1] == j->n * NB && len[2] == j->n * NB && len[3] == j->n * 2 * B; break;
-    default: j->n = len[0] / 32; ok = j->in[0] && j->in[1] && len[0] % 32 == 0 && len[1] == len[0]; break;
+    case 4: j->n = len[0] / 32; ok = j->in[0] && j->in[1] && len[0] % 32 == 0 && len[1] == len[0]; break;
+    case 5: ok = hl > 0 && j->in[0] && j->in[1] && len[0] % (size_t)hl == 0;
+            j->n = ok ? len[0] / (size_t)hl : 0;
+            ok = ok && len[1] == j->n * NB; break;
+    case 6: ok = hl > 0 && j->in[0] && j->in[1] && j->in[2] && j->in[3] && len[0] % (size_t)hl == 0;
+            j->n = ok ? len[0] / (size_t)hl : 0;
+            ok = ok && len[1] == j->n * NB && len[2] == j->n * NB && len[3] == j->n; break;
+    case 7: ok = hl > 0 && i0 > 0 && i1 > 0 && j->in[0] && j->in[1] && j->in[2] && j->in[3] && len[0] % (size_t)hl == 0;
+            j->n = ok ? len[0] / (size_t)hl : 0;
+            ok = ok && len[1] == j->n * (size_t)i0 && len[2] == j->n * 4 && !((uintptr_t)j->in[2] & 3) &&
+                 len[3] == j->n * (size_t)i1; break;
+    default: ok = i0 > 0 && j->in[0] && len[0] % (size_t)i0 == 0;
+             j->n = ok ? len[0] / (size_t)i0 : 0; break;
   }
   if (!ok) {
     for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
     free(j);
     THROW(env, "callAsync: buffer length mismatch");
   }
-  j->out0_len = op == 3 ? j->n : op == 4 ? j->n * 32 : j->n * 2 * B;
-  j->out1_len = op == 3 ? 0 : j->n;
+  j->out0_len = op == 3 || op == 7 ? j->n : op == 4 ? j->n * 32 : op == 5 ? j->n * NB : j->n * 2 * B;
+  j->out1_len = op == 3 ? 0 : op == 5 ? j->n * NB : j->n;
+  j->out2_len = op == 5 ? j->n : 0;
+  j->out3_len = op == 5 ? j->n : 0;
   j->out0 = (uint8_t*)malloc(j->out0_len ? j->out0_len : 1);
   j->out1 = (uint8_t*)malloc(j->out1_len ? j->out1_len : 1);
+  j->out2 = (uint8_t*)malloc(j->out2_len ? j->out2_len : 1);
+  j->out3 = (uint8_t*)malloc(j->out3_len ? j->out3_len : 1);
   napi_value promise, name;
   CHECK(env, napi_create_promise(env, &j->deferred, &promise));
   CHECK(env, napi_create_string_utf8(env, "ellgpu", NAPI_AUTO_LENGTH, &name));

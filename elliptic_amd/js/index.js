@@ -237,13 +237,13 @@ Engine.prototype.eddsaSignBatch = function eddsaSignBatch(msgs, secrets) {
 // ---- asynchronous batch API: same arguments, returns a Promise; the work runs on a
 // libuv worker thread (napi_async_work), so the JS thread stays responsive during a large
 // batch.  A context processes one call at a time, so calls are chained.
-Engine.prototype._async = function _async(op, curve, hashLen, msgBits, b0, b1, b2, b3) {
+Engine.prototype._async = function _async(op, curve, hashLen, msgBits, b0, b1, b2, b3, i0, i1) {
   var self = this;
   var id = op === 4 ? 7 : this._id(curve);
   var run = function() {
     self.stats.gpuCalls++;
     return self.addon.callAsync(op, self.ctx, id, hashLen | 0, msgBits | 0, b0 || null,
-      b1 || null, b2 || null, b3 || null);
+      b1 || null, b2 || null, b3 || null, i0 | 0, i1 | 0);
   };
   var p = (this._tail || Promise.resolve()).then(run, run);
   this._tail = p.catch(function() {});
@@ -257,6 +257,19 @@ Engine.prototype.mulAddBatchAsync = function(curve, k1, points1, k2, points2) {
 };
 Engine.prototype.ecdsaVerifyBatchAsync = function(curve, o) {
   return this._async(3, curve, o.hashLen, o.msgBits | 0, o.hashes, o.r, o.s, o.pub);
+};
+Engine.prototype.ecdsaSignDetBatchAsync = function(curve, o) {
+  return this._async(5, curve, o.hashLen, o.msgBits | 0, o.hashes, o.priv, null, null, o.canonical ? 1 : 0, 0);
+};
+Engine.prototype.ecdsaRecoverBatchAsync = function(curve, o) {
+  return this._async(6, curve, o.hashLen, 0, o.hashes, o.r, o.s, o.recid);
+};
+Engine.prototype.ecdsaVerifyWireBatchAsync = function(curve, o) {
+  var p = packRecords(o.sigs);
+  return this._async(7, curve, o.hashLen, o.msgBits | 0, o.hashes, p.buf, p.lens, o.keys, p.stride, o.keyLen);
+};
+Engine.prototype.decodePointBatchAsync = function(curve, enc, encLen) {
+  return this._async(8, curve, 0, 0, enc, null, null, null, encLen, 0);
 };
 Engine.prototype.x25519BatchAsync = function(scalars, xs) {
   return this._async(4, 7, 0, 0, scalars, xs);

@@ -256,11 +256,31 @@ lc.forEach(function(c, i) {
   var s1 = eng.mulBatch('secp256k1', kf, null);
   var s2 = eng.mulBatch('secp256k1', kv, pv);
   var s3 = eng.ecdsaVerifyBatch('secp256k1', vo);
+  // the newer operations: deterministic sign, recovery of those signatures, wire-format verify, decodePoint
+  var so = { hashes: vo.hashes, hashLen: 32, canonical: true,
+    priv: hexBuf(vs.map(function(c, i) { return fixed[i % fixed.length].k; }), B) };
+  var s4 = eng.ecdsaSignDetBatch('secp256k1', so);
+  var ro = { hashes: vo.hashes, hashLen: 32, r: s4.r, s: s4.s, recid: s4.recid };
+  var s5 = eng.ecdsaRecoverBatch('secp256k1', ro);
+  var wg = JSON.parse(fs.readFileSync(path.join(GOLD, 'wire_secp256k1.json'))).verify
+    .filter(function(c) { return c.key.length === 66; });
+  var wo = { hashes: Buffer.from(wg.map(function(c) { return c.z; }).join(''), 'hex'), hashLen: 32,
+    sigs: wg.map(function(c) { return Buffer.from(c.der, 'hex'); }),
+    keys: Buffer.from(wg.map(function(c) { return c.key; }).join(''), 'hex'), keyLen: 33 };
+  var s6 = eng.ecdsaVerifyWireBatch('secp256k1', wo);
+  var s7 = eng.decodePointBatch('secp256k1', wo.keys, 33);
   Promise.all([eng.mulBatchAsync('secp256k1', kf, null), eng.mulBatchAsync('secp256k1', kv, pv),
     eng.ecdsaVerifyBatchAsync('secp256k1', vo),
     eng.mulBatchAsync('secp256k1', Buffer.alloc(31), null).then(function() { return 'no error'; },
-      function(e) { return 'rejected: ' + e.message; })])
+      function(e) { return 'rejected: ' + e.message; }),
+    eng.ecdsaSignDetBatchAsync('secp256k1', so), eng.ecdsaRecoverBatchAsync('secp256k1', ro),
+    eng.ecdsaVerifyWireBatchAsync('secp256k1', wo), eng.decodePointBatchAsync('secp256k1', wo.keys, 33)])
     .then(function(r) {
+      ['r', 's', 'recid', 'ok'].forEach(function(k) { if (!r[4][k].equals(s4[k])) throw new Error('async signDet differs: ' + k); });
+      if (!r[5].xy.equals(s5.xy) || !r[5].status.equals(s5.status)) throw new Error('async recover differs');
+      if (!r[6].ok.equals(s6.ok) || !r[6].err.equals(s6.err)) throw new Error('async wire verify differs');
+      if (!r[7].xy.equals(s7.xy) || !r[7].status.equals(s7.status)) throw new Error('async decodePoint differs');
+      checked += 2 * vs.length + 2 * wg.length;
       if (!r[0].xy.equals(s1.xy) || !r[0].inf.equals(s1.inf)) throw new Error('async mulFixed differs');
       if (!r[1].xy.equals(s2.xy) || !r[1].inf.equals(s2.inf)) throw new Error('async mulVar differs');
       if (!r[2].equals(s3)) throw new Error('async verify differs');
