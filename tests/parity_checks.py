@@ -371,6 +371,62 @@ def check_add_golden(ctx, curve):
     return len(cases)
 
 
+def check_codec_random(ctx, curve, n=3000, seed=5):
+    """decodePoint / encode / validate / Point#add on seeded random inputs against the oracle's
+    restatement: on-curve points (G multiples), random bytes (mostly off-curve / undecodable),
+    equal and opposite operands"""
+    from oracle import ec_oracle as O
+    cur = O.get_curve(curve)
+    B = FIELD_BYTES[curve]
+    rng = np.random.default_rng(seed)
+    ks = [int.from_bytes(rng.bytes(B), "big") % (cur.n - 1) + 1 for _ in range(n)]
+    pts, _ = ctx.mul_fixed(curve, ints_to_be(ks, B))
+    # compressed encodings of valid points and of random x: decode, then re-encode
+    enc = ctx.encode_points(curve, pts, compact=True)
+    junk = np.frombuffer(rng.bytes(n * (1 + B)), np.uint8).reshape(n, 1 + B).copy()
+    junk[:, 0] = 2 + (junk[:, 0] & 1)
+    if curve == "p521":
+        junk[:, 1] &= 1                                       # keep x below 2^521 half of the time
+    both = np.concatenate([enc, junk])
+    xy, st = ctx.decode_points(curve, both)
+    assert (st[:n] == 0).all() and np.array_equal(xy[:n], pts)
+    for i in range(n, 2 * n, 7):                              # the oracle on a sample of the random ones
+        try:
+            p = O.decode_point(cur, both[i].tobytes())
+            assert st[i] == 0 and xy[i].tobytes() == p.x.to_bytes(B, "big") + p.y.to_bytes(B, "big"), i
+        except ValueError:
+            assert st[i] == 2 and not xy[i].any(), i
+    ok = st == 0
+    assert 0.3 * n < ok[n:].sum() < 0.7 * n                   # about half of all x lift
+    assert np.array_equal(ctx.encode_points(curve, xy[ok], compact=True), both[ok])
+    # validate: decoded points are on the curve, perturbed ones are not
+    assert not ctx.validate(curve, xy[ok], check_order=False).any()
+    bad = xy[ok].copy()
+    bad[:, 2 * B - 1] ^= 1
+    assert (ctx.validate(curve, bad, check_order=False) == 2).all()
+    # Point#add: P + Q, P + P, P + (-P), and off-curve operands, against the oracle
+    q = np.roll(pts, 1, axis=0)
+    q[::5] = pts[::5]                                         # P + P
+    neg = (cur.p - np.array(be_to_ints(pts[1::5, B:]), dtype=object)) % cur.p
+    q[1::5, :B] = pts[1::5, :B]
+    q[1::5, B:] = ints_to_be([int(v) for v in neg], B)        # P + (-P)
+    q[2::5] = np.frombuffer(rng.bytes(len(q[2::5]) * 2 * B), np.uint8).reshape(-1, 2 * B)
+    if curve == "p521":
+        q[2::5, 0] &= 1
+        q[2::5, B] &= 1
+    out, inf = ctx.point_add(curve, pts, q)
+    px, py = be_to_ints(pts[:, :B]), be_to_ints(pts[:, B:])
+    qx, qy = be_to_ints(q[:, :B]), be_to_ints(q[:, B:])
+    for i in range(0, n, 3):
+        r = cur.point(px[i], py[i]).add(cur.point(qx[i] % cur.p, qy[i] % cur.p))
+        if r.inf:
+            assert inf[i] == 1, i
+        else:
+            assert inf[i] == 0 and out[i].tobytes() == r.x.to_bytes(B, "big") + r.y.to_bytes(B, "big"), i
+    assert (inf[1::5] == 1).all()
+    return n
+
+
 def check_ecdh(ctx, curve, n=24):
     """KeyPair#derive: a*(b*G) == b*(a*G), equal to the oracle's pub.mul(priv).getX(); an
     off-curve public point is refused as the reference's assert does; priv = n gives infinity"""

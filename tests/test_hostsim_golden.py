@@ -242,6 +242,11 @@ def test_point_add_golden(ctx, curve):
     assert PC.check_add_golden(ctx, curve) >= 20
 
 
+@pytest.mark.parametrize("curve", ["secp256k1", "p256", "p384", "p521"])
+def test_codec_random_vs_oracle(ctx, curve):
+    assert PC.check_codec_random(ctx, curve, n=600) > 0
+
+
 def test_der_fuzz(ctx):
     assert PC.check_der_fuzz(ctx) > 2000
 
