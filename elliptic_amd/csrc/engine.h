@@ -23,6 +23,11 @@
 #ifndef ELL_INV_BATCH
 #define ELL_INV_BATCH 16
 #endif
+// p521 (one wave per SIMD, 256 VGPRs + AGPRs, spill-free) issues at the lone-wave half rate.  A
+// second instantiation held to 256 registers runs two waves per SIMD: each wave is 1.6x slower
+// (spills), the pair 1.26x faster -- but only batches of more than one full single-wave round
+// (256 CUs x 4 SIMDs x 64 lanes) have a second wave to pair.
+#define ELL_P521_PAIR_MIN ((size_t)256 * 4 * 64 + 4096)
 #ifndef ELL_MULVAR_MIN_WAVES
 #define ELL_MULVAR_MIN_WAVES 4
 #endif
@@ -35,12 +40,12 @@ namespace ell {
 enum { E_OK = 0, E_NODEVICE = -1, E_ARG = -2, E_HIP = -3, E_NOMEM = -4, E_UNSUPPORTED = -5 };
 
 // ---- functors (one per kernel) ------------------------------------------------
-template <class CV>
+template <class CV, int MW = 0>
 struct FnMulVar {
   static constexpr const char* NAME = "mul_var";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
-  static constexpr int MIN_WAVES = W::L <= 8 ? ELL_MULVAR_MIN_WAVES : 1;   // <= 128 VGPRs for 256-bit curves: +2..4 % despite ~50 B of spills
+  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? ELL_MULVAR_MIN_WAVES : 1);   // <= 128 VGPRs for 256-bit curves: +2..4 % despite ~50 B of spills
   size_t n; const u8* k; const u8* xy; typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) W::mul_var(i, n, k, xy, tbl, ds, jac);
@@ -56,22 +61,23 @@ struct FnMulAdd2 {
     if (i < n) W::mul_add2(i, n, k1, xy1, k2, xy2, tbl, ds, jac);
   }
 };
-template <class CV>
+template <class CV, int MW = 0>
 struct FnMulAddG {
   static constexpr const char* NAME = "mul_add_g";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
-  static constexpr int MIN_WAVES = W::L == 12 ? 2 : 1;      // p384: 2 waves/SIMD (<= 256 registers) beats a spill-free single wave
+  static constexpr int MIN_WAVES = MW ? MW : (W::L == 12 ? 2 : 1);      // p384: 2 waves/SIMD (<= 256 registers) beats a spill-free single wave
   size_t n; const u8* k1; const u8* k2; const u8* xy2; const typename W::A* comb;
   typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) W::mul_add_g_item(i, n, k1, k2, xy2, comb, tbl, ds, jac);
   }
 };
-template <class CV>
+template <class CV, int MW = 0>
 struct FnMulFixed {
   static constexpr const char* NAME = "mul_fixed";
   typedef Work<CV> W;
+  static constexpr int MIN_WAVES = MW ? MW : 1;
   static constexpr int DS_PER_LANE = 0;
   size_t n; const u8* k; const typename W::A* comb; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore&) const {
@@ -100,11 +106,11 @@ struct FnEcdsaPrep {
     if (t < T) W::ecdsa_prep(t, T, n, K, hash, hash_len, shift, r, s, pre, u12, valid);
   }
 };
-template <class CV>
+template <class CV, int MW = 0>
 struct FnEcdsaMain {
   static constexpr const char* NAME = "ecdsa_main";
   typedef Work<CV> W;
-  static constexpr int MIN_WAVES = W::L <= 8 ? ELL_ECDSA_MIN_WAVES : (W::L == 12 ? 2 : 1);   // <= 168 VGPRs for 256-bit curves, <= 256 for p384
+  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? ELL_ECDSA_MIN_WAVES : (W::L == 12 ? 2 : 1));   // <= 168 VGPRs for 256-bit curves, <= 256 for p384
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
   size_t n; const u32* u12; const u8* valid; const u8* r; const u8* pub;
   const typename W::A* comb; typename W::VT* tbl; u8* ok;
@@ -113,10 +119,11 @@ struct FnEcdsaMain {
   }
 };
 
-template <class CV>
+template <class CV, int MW = 0>
 struct FnSignMul {
   static constexpr const char* NAME = "sign_mul";
   typedef Work<CV> W;
+  static constexpr int MIN_WAVES = MW ? MW : 1;
   static constexpr int DS_PER_LANE = 0;
   size_t n; const u8* nonces; const typename W::A* comb; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore&) const {
@@ -1431,8 +1438,13 @@ int Engine<BK>::mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u
   typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::VT));
   u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
-  FnMulVar<CV> f{n, k, xy, tbl, jac};
-  bk.launch(f, n);
+  if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
+    FnMulVar<CV, (W::L > 12 ? 2 : 0)> f{n, k, xy, tbl, jac};
+    bk.launch(f, n);
+  } else {
+    FnMulVar<CV> f{n, k, xy, tbl, jac};
+    bk.launch(f, n);
+  }
   return normalize_chunk<CV>(n, jac, out_xy, out_inf, raw);
 }
 
@@ -1443,8 +1455,13 @@ int Engine<BK>::mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf) 
   typedef Work<CV> W;
   u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
   if (!jac) return fail(E_NOMEM, "scratch allocation failed");
-  FnMulFixed<CV> f{n, k, (const typename W::A*)comb_[CV::ID], jac};
-  bk.launch(f, n);
+  if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
+    FnMulFixed<CV, (W::L > 12 ? 2 : 0)> f{n, k, (const typename W::A*)comb_[CV::ID], jac};
+    bk.launch(f, n);
+  } else {
+    FnMulFixed<CV> f{n, k, (const typename W::A*)comb_[CV::ID], jac};
+    bk.launch(f, n);
+  }
   return normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
 }
 
@@ -1470,8 +1487,13 @@ int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* 
   u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
   typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::VT));
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
-  FnMulAddG<CV> f{n, k1, k2, xy2, (const typename W::A*)comb_[CV::ID], tbl, jac};
-  bk.launch(f, n);
+  if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
+    FnMulAddG<CV, (W::L > 12 ? 2 : 0)> f{n, k1, k2, xy2, (const typename W::A*)comb_[CV::ID], tbl, jac};
+    bk.launch(f, n);
+  } else {
+    FnMulAddG<CV> f{n, k1, k2, xy2, (const typename W::A*)comb_[CV::ID], tbl, jac};
+    bk.launch(f, n);
+  }
   return normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
 }
 
@@ -1489,8 +1511,13 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
   size_t T = (n + INV_BATCH_N - 1) / INV_BATCH_N;
   FnEcdsaPrep<CV> f1{T, n, INV_BATCH_N, hash, hash_len, shift, r, s, pre, u12, valid};
   bk.launch(f1, T);
-  FnEcdsaMain<CV> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
-  bk.launch(f2, n);
+  if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
+    FnEcdsaMain<CV, (W::L > 12 ? 2 : 0)> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
+    bk.launch(f2, n);
+  } else {
+    FnEcdsaMain<CV> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
+    bk.launch(f2, n);
+  }
   return E_OK;
 }
 
@@ -1803,8 +1830,13 @@ int Engine<BK>::sign_chunk(size_t n, const u8* hash, int hash_len, int shift, co
   u8* kg = (u8*)scratch(S_U12, n * (2 * W::BYTES + 1));          // k*G affine + infinity flags
   if (!jac || !kg) return fail(E_NOMEM, "scratch allocation failed");
   u8* kg_inf = kg + n * 2 * W::BYTES;
-  FnSignMul<CV> f1{n, nonces, (const typename W::A*)comb_[CV::ID], jac};
-  bk.launch(f1, n);
+  if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
+    FnSignMul<CV, (W::L > 12 ? 2 : 0)> f1{n, nonces, (const typename W::A*)comb_[CV::ID], jac};
+    bk.launch(f1, n);
+  } else {
+    FnSignMul<CV> f1{n, nonces, (const typename W::A*)comb_[CV::ID], jac};
+    bk.launch(f1, n);
+  }
   int rc = normalize_chunk<CV>(n, jac, kg, kg_inf, nullptr);
   if (rc) return rc;
   u32* pre = (u32*)scratch(S_PRE, n * (W::LN > W::L ? W::LN : W::L) * 4);

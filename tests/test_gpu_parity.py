@@ -93,6 +93,36 @@ def test_codec_random_vs_oracle(ctx, curve):
     assert PC.check_codec_random(ctx, curve, n=3000) > 0
 
 
+def test_p521_paired_wave_kernels(ctx):
+    """p521 batches above one single-wave round run a second instantiation of the ladder kernels
+    (two waves per SIMD): same results as the one-wave kernels the smaller batches use"""
+    n, B = 74 * 1024, 66
+    rng = np.random.default_rng(521)
+    k = np.frombuffer(rng.bytes(n * B), np.uint8).reshape(n, B).copy()
+    d = np.frombuffer(rng.bytes(n * B), np.uint8).reshape(n, B).copy()
+    k[:, 0] &= 1
+    d[:, 0] &= 1
+    h = n // 2
+    pts, _ = ctx.mul_fixed("p521", d)
+    assert np.array_equal(pts, np.concatenate([ctx.mul_fixed("p521", d[:h])[0], ctx.mul_fixed("p521", d[h:])[0]]))
+    big, binf = ctx.mul_var("p521", k, pts)
+    lo, linf = ctx.mul_var("p521", k[:h], pts[:h])
+    hi, hinf = ctx.mul_var("p521", k[h:], pts[h:])
+    assert np.array_equal(big, np.concatenate([lo, hi])) and np.array_equal(binf, np.concatenate([linf, hinf]))
+    big, binf = ctx.mul_add2("p521", d, None, k, pts)
+    lo, linf = ctx.mul_add2("p521", d[:h], None, k[:h], pts[:h])
+    hi, hinf = ctx.mul_add2("p521", d[h:], None, k[h:], pts[h:])
+    assert np.array_equal(big, np.concatenate([lo, hi])) and np.array_equal(binf, np.concatenate([linf, hinf]))
+    z = np.ascontiguousarray(k[:, 1:])
+    r, s_, rec, ok = ctx.ecdsa_sign_det("p521", z, d)
+    assert ok.all()
+    r[::7, 40] ^= 1                                            # some must fail
+    v = ctx.ecdsa_verify("p521", z, r, s_, pts)
+    v2 = np.concatenate([ctx.ecdsa_verify("p521", z[:h], r[:h], s_[:h], pts[:h]),
+                         ctx.ecdsa_verify("p521", z[h:], r[h:], s_[h:], pts[h:])])
+    assert np.array_equal(v, v2) and not v[::7].any() and v[1::7].all()
+
+
 def test_der_fuzz(ctx):
     assert PC.check_der_fuzz(ctx) > 2000
 

@@ -48,7 +48,7 @@ def main():
         print(json.dumps(rows[-1]), flush=True)
 
     only = [c for c in a.curves.split(",") if c]
-    for curve, n in (("secp256k1", 1 << 20), ("p192", 1 << 19), ("p224", 1 << 19), ("p256", 1 << 19), ("p384", 1 << 18), ("p521", 1 << 16),
+    for curve, n in (("secp256k1", 1 << 20), ("p192", 1 << 19), ("p224", 1 << 19), ("p256", 1 << 19), ("p384", 1 << 18), ("p521", 1 << 18),
                      ("ed25519", 1 << 20)):
         if only and curve not in only:
             continue
