@@ -56,6 +56,7 @@ struct FnMulAdd2 {
   static constexpr const char* NAME = "mul_add2";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV * 2;
+  static constexpr int MIN_WAVES = W::L <= 8 ? 3 : 1;       // <= 168 VGPRs for the 256-bit curves
   size_t n; const u8* k1; const u8* xy1; const u8* k2; const u8* xy2; typename W::J* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) W::mul_add2(i, n, k1, xy1, k2, xy2, tbl, ds, jac);
@@ -66,7 +67,7 @@ struct FnMulAddG {
   static constexpr const char* NAME = "mul_add_g";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
-  static constexpr int MIN_WAVES = MW ? MW : (W::L == 12 ? 2 : 1);      // p384: 2 waves/SIMD (<= 256 registers) beats a spill-free single wave
+  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? ELL_ECDSA_MIN_WAVES : (W::L == 12 ? 2 : 1));      // p384: 2 waves/SIMD (<= 256 registers) beats a spill-free single wave
   size_t n; const u8* k1; const u8* k2; const u8* xy2; const typename W::A* comb;
   typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
