@@ -78,7 +78,7 @@ template <class CV, int MW = 0>
 struct FnMulFixed {
   static constexpr const char* NAME = "mul_fixed";
   typedef Work<CV> W;
-  static constexpr int MIN_WAVES = MW ? MW : 1;
+  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? 3 : 1);   // <= 168 VGPRs for the 256-bit curves (p256 takes 170 unconstrained)
   static constexpr int DS_PER_LANE = 0;
   size_t n; const u8* k; const typename W::A* comb; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore&) const {
@@ -124,7 +124,7 @@ template <class CV, int MW = 0>
 struct FnSignMul {
   static constexpr const char* NAME = "sign_mul";
   typedef Work<CV> W;
-  static constexpr int MIN_WAVES = MW ? MW : 1;
+  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? 3 : 1);   // <= 168 VGPRs for the 256-bit curves (p256 takes 170 unconstrained)
   static constexpr int DS_PER_LANE = 0;
   size_t n; const u8* nonces; const typename W::A* comb; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore&) const {
