@@ -56,7 +56,7 @@ struct FnMulAdd2 {
   static constexpr const char* NAME = "mul_add2";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV * 2;
-  static constexpr int MIN_WAVES = W::L <= 8 ? 3 : 1;       // <= 168 VGPRs for the 256-bit curves
+  static constexpr int MIN_WAVES = W::L <= 8 ? 3 : (W::L == 12 ? 2 : 1);   // <= 168 VGPRs for the 256-bit curves, <= 256 for p384
   size_t n; const u8* k1; const u8* xy1; const u8* k2; const u8* xy2; typename W::J* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) W::mul_add2(i, n, k1, xy1, k2, xy2, tbl, ds, jac);

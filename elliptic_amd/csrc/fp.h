@@ -27,9 +27,13 @@
 #include "mul_asm.h"
 #include "safegcd.h"
 
-// field multiplies of moduli with at least this many limbs are real function calls
+// field multiplies of moduli with at least this many limbs are real function calls: only the
+// 17-limb order field of p521 today.  The 12-limb fields of p384 were calls too (24 argument
+// words fit the 32 argument VGPRs) until the p521 lesson was applied to them: inlined, and held
+// to two waves per SIMD by the kernels' launch bounds, p384 gains 13-21 % (P*k 18.1 -> 20.5 M/s,
+// G*k 114 -> 138 M/s, same box).
 #ifndef ELL_MONT_CALL_MINL
-#define ELL_MONT_CALL_MINL 12
+#define ELL_MONT_CALL_MINL 13
 #endif
 
 namespace ell {
