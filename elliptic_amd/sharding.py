@@ -71,3 +71,48 @@ class ShardedVerifier:
                 ok_np = np.zeros(0, np.uint8)
             ok = torch.from_numpy(np.ascontiguousarray(ok_np))
         return gather_results(ok, n, self.dist)
+
+
+class ShardedMul:
+    """Scalar multiplication of a global batch across the ranks of a process group: rank r
+    computes its contiguous slice, the affine results (n x 2B bytes) and the infinity flags are
+    gathered on every rank -- SURVEY 8e's point-output gather (N/G x 64 B per rank on the
+    256-bit curves).  points = None multiplies the generator (fixed-base comb)."""
+
+    def __init__(self, ctx, curve, dist=None, device=None):
+        self.ctx = ctx
+        self.curve = curve
+        self.dist = dist
+        self.device = device
+
+    def mul(self, scalars, points=None):
+        import torch
+        from . import FIELD_BYTES
+        B = FIELD_BYTES[self.curve]
+        n = scalars.shape[0]
+        on = self.dist is not None and self.dist.is_initialized()
+        rank = self.dist.get_rank() if on else 0
+        world = self.dist.get_world_size() if on else 1
+        lo, hi = shard_range(n, rank, world)
+        if self.device is not None and self.device.type == "cuda":
+            k = torch.as_tensor(np.ascontiguousarray(scalars[lo:hi])).to(self.device)
+            xy = torch.zeros((hi - lo, 2 * B), dtype=torch.uint8, device=self.device)
+            inf = torch.zeros(hi - lo, dtype=torch.uint8, device=self.device)
+            if hi > lo:
+                if points is None:
+                    self.ctx.mul_fixed_dev(self.curve, k, xy, inf)
+                else:
+                    p = torch.as_tensor(np.ascontiguousarray(points[lo:hi])).to(self.device)
+                    self.ctx.mul_var_dev(self.curve, k, p, xy, inf)
+            torch.cuda.synchronize()
+        else:
+            if hi > lo:
+                if points is None:
+                    xy_np, inf_np = self.ctx.mul_fixed(self.curve, scalars[lo:hi])
+                else:
+                    xy_np, inf_np = self.ctx.mul_var(self.curve, scalars[lo:hi], points[lo:hi])
+            else:
+                xy_np, inf_np = np.zeros((0, 2 * B), np.uint8), np.zeros(0, np.uint8)
+            xy = torch.from_numpy(np.ascontiguousarray(xy_np))
+            inf = torch.from_numpy(np.ascontiguousarray(inf_np))
+        return gather_results(xy, n, self.dist), gather_results(inf, n, self.dist)

@@ -78,3 +78,55 @@ def test_world2_sharded_verify_matches_reference(n):
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res) and all(r[2] == n for r in res)
+
+
+def _mul_worker(rank, world, port, lib_path, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import elliptic_amd
+        from elliptic_amd import _lib
+        from elliptic_amd.sharding import ShardedMul
+        from golden_util import I, mul_cases, res_xy
+        from elliptic_amd import ints_to_be
+        lib = _lib.load(lib_path, optional=("ellgpu_probe_valu", "ellgpu_ctx_set_timing", "ellgpu_ctx_get_timing", "ellgpu_debug_field_op"))
+        ctx = elliptic_amd.Context(0, lib_path=lib)
+        good = True
+        for curve, B in (("secp256k1", 32), ("p384", 48)):
+            cs = [c for c in mul_cases(curve) if c["op"] == "var"][:23]      # odd count: uneven shards
+            k = ints_to_be([I(c["k"]) for c in cs], B)
+            pts = np.concatenate([ints_to_be([I(c["px"]) for c in cs], B), ints_to_be([I(c["py"]) for c in cs], B)], axis=1)
+            xy, inf = ShardedMul(ctx, curve, dist=dist).mul(k, pts)
+            xy, inf = xy.numpy(), inf.numpy()
+            for i, c in enumerate(cs):
+                want = res_xy(c["r"])
+                good = good and ((inf[i] == 1) if want is None else
+                                 (inf[i] == 0 and xy[i].tobytes() == want[0].to_bytes(B, "big") + want[1].to_bytes(B, "big")))
+            fx = [c for c in mul_cases(curve) if c["op"] == "fixed"][:9]
+            xy, inf = ShardedMul(ctx, curve, dist=dist).mul(ints_to_be([I(c["k"]) for c in fx], B))
+            xy, inf = xy.numpy(), inf.numpy()
+            for i, c in enumerate(fx):
+                want = res_xy(c["r"])
+                good = good and ((inf[i] == 1) if want is None else
+                                 (inf[i] == 0 and xy[i].tobytes() == want[0].to_bytes(B, "big") + want[1].to_bytes(B, "big")))
+        q.put((rank, bool(good)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_sharded_mul_gathers_points():
+    """the point-output gather: every rank ends with the whole batch's affine results"""
+    from hostsim.build import build as build_hostsim
+    lib_path = build_hostsim()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_mul_worker, args=(r, 2, port, lib_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res)
