@@ -66,8 +66,18 @@ struct Fe {
 #ifndef ELL_MUL_CHAIN
 #define ELL_MUL_CHAIN 1
 #endif
+// ELL_MUL_FAST = 1: the wide products first run the generated "fast" chains, in which the
+// first multiply-add of every column does not feed its carry-out into the column's extension
+// word: its addend (X.hi, E) of the previous column is below 2^36, so it overflows 64 bits only
+// when a_i * b_j >= 2^64 - 2^36 -- never for random operands, always possible for chosen ones
+// (limbs of 2^32 - 1).  The carry-out masks are OR-ed on the scalar unit instead, and a wave in
+// which any lane did overflow redoes the product with the all-carries chain (a uniform branch,
+// taken with probability ~2^-21 per product).  15 of 64 (8 limbs) carry additions less.
+#ifndef ELL_MUL_FAST
+#define ELL_MUL_FAST 1
+#endif
 template <int L>
-ELL_HD void fe_mul_wide(u32 (&r)[2 * L], const u32 (&a)[L], const u32 (&b)[L]) {
+ELL_HD void fe_mul_wide_plain(u32 (&r)[2 * L], const u32 (&a)[L], const u32 (&b)[L]) {
 #if defined(ELL_HAVE_MUL_ASM) && !defined(ELL_NO_ASM_MUL) && ELL_MUL_CHAIN
   if constexpr (L == 6) masm::mulc_wide_6(r, a, b);
   else if constexpr (L == 7) masm::mulc_wide_7(r, a, b);
@@ -87,10 +97,44 @@ ELL_HD void fe_mul_wide(u32 (&r)[2 * L], const u32 (&a)[L], const u32 (&b)[L]) {
 #endif
 }
 template <int L>
+ELL_HD void fe_mul_wide(u32 (&r)[2 * L], const u32 (&a)[L], const u32 (&b)[L]) {
+#if defined(ELL_HAVE_MUL_ASM) && !defined(ELL_NO_ASM_MUL) && ELL_MUL_CHAIN && ELL_MUL_FAST
+  if constexpr (L == 6 || L == 7 || L == 8 || L == 12 || L == 17) {
+    u64 ovf = 0;
+    if constexpr (L == 6) masm::mulf_wide_6(r, a, b, ovf);
+    else if constexpr (L == 7) masm::mulf_wide_7(r, a, b, ovf);
+    else if constexpr (L == 8) masm::mulf_wide_8(r, a, b, ovf);
+    else if constexpr (L == 12) masm::mulf_wide_12(r, a, b, ovf);
+    else masm::mulf_wide_17(r, a, b, ovf);
+    if (ELL_UNLIKELY(ovf != 0)) fe_mul_wide_plain<L>(r, a, b);
+  } else {
+    bn_mul_wide<L, L>(r, a, b);
+  }
+#else
+  fe_mul_wide_plain<L>(r, a, b);
+#endif
+}
+template <int L>
 ELL_HD void fe_sqr_wide(u32 (&r)[2 * L], const u32 (&a)[L]) {
 #if defined(ELL_HAVE_MUL_ASM) && !defined(ELL_NO_ASM_MUL)
   u32 off[2 * L];
-#if ELL_MUL_CHAIN
+#if ELL_MUL_CHAIN && ELL_MUL_FAST
+  if constexpr (L == 6 || L == 7 || L == 8 || L == 12 || L == 17) {
+    u64 ovf = 0;
+    if constexpr (L == 6) masm::sqrf_offdiag_6(off, a, ovf);
+    else if constexpr (L == 7) masm::sqrf_offdiag_7(off, a, ovf);
+    else if constexpr (L == 8) masm::sqrf_offdiag_8(off, a, ovf);
+    else if constexpr (L == 12) masm::sqrf_offdiag_12(off, a, ovf);
+    else masm::sqrf_offdiag_17(off, a, ovf);
+    if (ELL_UNLIKELY(ovf != 0)) {
+      if constexpr (L == 6) masm::sqrc_offdiag_6(off, a);
+      else if constexpr (L == 7) masm::sqrc_offdiag_7(off, a);
+      else if constexpr (L == 8) masm::sqrc_offdiag_8(off, a);
+      else if constexpr (L == 12) masm::sqrc_offdiag_12(off, a);
+      else masm::sqrc_offdiag_17(off, a);
+    }
+  } else { bn_sqr_wide<L>(r, a); return; }
+#elif ELL_MUL_CHAIN
   if constexpr (L == 6) masm::sqrc_offdiag_6(off, a);
   else if constexpr (L == 7) masm::sqrc_offdiag_7(off, a);
   else if constexpr (L == 8) masm::sqrc_offdiag_8(off, a);

@@ -4,9 +4,13 @@ CPU: the reference's own, unmodified mocha suite must pass with install()
 applied to the reference library; in this GPU-less container the addon is
 pointed at the CPU unit-test build of the device code (tests/hostsim), so what
 is exercised is the marshalling, the prototype patch and the device code's
-logic.  Needs Node and /root/reference (build container only).
-GPU (-m gpu): the batch API through the addon on the real libellgpu.so against
-the golden fixtures."""
+logic.  Needs Node and a copy of the reference: /root/reference (build container)
+or the git-ignored oracle/_ref that oracle/make_ref.py fills from it and that travels
+to the GPU box.
+GPU (-m gpu): the same two gates -- the reference's unmodified suite and the golden
+replay incl. every exception message -- through install() on the REAL libellgpu.so
+(generated-asm multiplier, 16-bit comb: the shipped hot path), and the batch API
+through the addon against the golden fixtures."""
 import json
 import os
 import shutil
@@ -19,6 +23,48 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def _reference():
+    """directory of a reference copy (ELLIPTIC_REFERENCE for tools/ref_loader.js), or skip"""
+    if os.path.exists("/root/reference/dist/elliptic.js"):
+        return "/root/reference"
+    from oracle import make_ref
+    d = make_ref.present()
+    if d is None:
+        pytest.skip("no copy of the reference (neither /root/reference nor oracle/_ref)")
+    return d
+
+
+def _run_suite(lib):
+    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
+    if lib:
+        env["ELLGPU_LIB"] = lib
+    else:
+        env.pop("ELLGPU_LIB", None)
+    p = subprocess.run(["node", os.path.join(ROOT, "tools", "run_ref_tests_patched.js")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["failed"] == 0 and res["passed"] == res["total"] >= 226
+    # the patched methods really were the ones running
+    # (pass-through: toy curves, and the RFC 6979 vectors that sign with another hash than the preset's)
+    assert res["engine"]["gpuCalls"] > 500 and res["engine"]["passthrough"] < 100
+    return res
+
+
+def _run_replay(lib):
+    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
+    if lib:
+        env["ELLGPU_LIB"] = lib
+    else:
+        env.pop("ELLGPU_LIB", None)
+    p = subprocess.run(["node", os.path.join(ROOT, "tools", "check_patched_results.js")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["checked"] > 1000 and res["thrown"] > 300
+    return res
+
+
 def _addon():
     from elliptic_amd.js import build as jb
     p = jb.build()
@@ -29,19 +75,9 @@ def _addon():
 
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
 def test_reference_suite_passes_with_install_patch():
-    if not os.path.exists("/root/reference/dist/elliptic.js"):
-        pytest.skip("reference checkout not present (GPU box)")
     _addon()
     from hostsim.build import build as build_hostsim
-    env = dict(os.environ, ELLGPU_LIB=build_hostsim())
-    p = subprocess.run(["node", os.path.join(ROOT, "tools", "run_ref_tests_patched.js")], env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    res = json.loads(p.stdout.strip().splitlines()[-1])
-    assert res["failed"] == 0 and res["passed"] == res["total"] >= 226
-    # the patched methods really were the ones running
-    # (pass-through: toy curves, and the RFC 6979 vectors that sign with another hash than the preset's)
-    assert res["engine"]["gpuCalls"] > 500 and res["engine"]["passthrough"] < 100
+    _run_suite(build_hostsim())
 
 
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
@@ -49,16 +85,25 @@ def test_patched_api_matches_goldens_including_exception_messages():
     """recoverPubKey / EDDSA sign / EDDSA verify / pointFromX / pointFromY through install():
     the results and the message of every thrown Error equal what the unpatched reference
     produced when the golden files were generated"""
-    if not os.path.exists("/root/reference/dist/elliptic.js"):
-        pytest.skip("reference checkout not present (GPU box)")
     _addon()
     from hostsim.build import build as build_hostsim
-    env = dict(os.environ, ELLGPU_LIB=build_hostsim())
-    p = subprocess.run(["node", os.path.join(ROOT, "tools", "check_patched_results.js")], env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    res = json.loads(p.stdout.strip().splitlines()[-1])
-    assert res["ok"] and res["checked"] > 1000 and res["thrown"] > 300
+    _run_replay(build_hostsim())
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_reference_suite_passes_with_install_patch_gpu():
+    """the reference's own 226 specs (RFC 6979, Maxwell-trick, Wycheproof, sign.input ...) with
+    install() routing the hot path into the real libellgpu.so on the MI355X"""
+    _addon()
+    _run_suite(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_patched_api_matches_goldens_including_exception_messages_gpu():
+    _addon()
+    _run_replay(None)
 
 
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")

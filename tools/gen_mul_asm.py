@@ -266,10 +266,14 @@ def gen_sqr_off(L):
 CHAIN_CH = 10       # products per statement (30-operand limit)
 
 
-def chain_stmt(name, prods, has_xin, has_ein, may_carry_first, need_e, square=False):
+def chain_stmt(name, prods, has_xin, has_ein, may_carry_first, need_e, square=False, ovf_first=False):
     """one statement: X = Xin + sum(products), E = Ein + carries.
        has_xin/has_ein: incoming values; may_carry_first: the first mad may overflow
-       need_e: the statement has to produce E at all"""
+       need_e: the statement has to produce E at all
+       ovf_first: the first mad's carry-out (Xin = (X.hi, E) of the previous column is < 2^36, so
+       it overflows only when a_i * b_j >= 2^64 - 2^36: never for random operands) is not added
+       to E but OR-ed into the caller's overflow mask on the scalar unit; the caller redoes the
+       product with the all-carries variant when the mask is non-zero"""
     # schedule: mads in order; each carrying mad's addc issued >= MIN_DIST positions later
     seq = []
     pend = []
@@ -282,6 +286,11 @@ def chain_stmt(name, prods, has_xin, has_ein, may_carry_first, need_e, square=Fa
         # its consumer), then the oldest pending carry, then a wait state
         if q:
             carry = need_e and (may_carry_first or not first)
+            if carry and first and ovf_first:
+                i, j = q.pop(0)
+                seq.append(("madf", i, j))
+                first = False
+                continue
             if not carry:
                 i, j = q.pop(0)
                 seq.append(("madnc", i, j))
@@ -312,11 +321,11 @@ def chain_stmt(name, prods, has_xin, has_ein, may_carry_first, need_e, square=Fa
         if ins[0] == "nop":
             lines.append("s_nop 0")
             continue
-        if ins[0] in ("mad", "madnc"):
+        if ins[0] in ("mad", "madnc", "madf"):
             i, j = ins[1], ins[2]
             bj = ("%%[a%d]" % j) if square else ("%%[b%d]" % j)
             src = "%[X]" if x_touched else ("%[Xi]" if has_xin else "0")
-            sr = "%%[s%d]" % ins[3] if ins[0] == "mad" else "%[sd]"
+            sr = "%%[s%d]" % ins[3] if ins[0] == "mad" else ("%[sf]" if ins[0] == "madf" else "%[sd]")
             lines.append("v_mad_u64_u32 %%[X], %s, %%[a%d], %s, %s" % (sr, i, bj, src))
             x_touched = True
         else:
@@ -325,11 +334,19 @@ def chain_stmt(name, prods, has_xin, has_ein, may_carry_first, need_e, square=Fa
             e_touched = True
     if need_e and not e_touched:
         lines.append("v_mov_b32 %%[E], %s" % ("%[Ei]" if has_ein else "0"))
+    has_f = any(x[0] == "madf" for x in seq)
+    if has_f:
+        # the scalar OR goes last: at least two instructions behind the mad that wrote sf
+        while len(lines) < 3:
+            lines.append("s_nop 0")
+        lines.append("s_or_b64 %[ovf], %[ovf], %[sf]")
     body = "\\n\\t".join(lines)
-    args = ["u64& X"] + (["u32& E"] if need_e else [])
+    args = ["u64& X"] + (["u32& E"] if need_e else []) + (["u64& ovf"] if has_f else [])
     args += ["u32 a%d" % i for i in used_a] + ["u32 b%d" % j for j in used_b]
     outs = ['[X] "=&v"(Xo)'] + (['[E] "=&v"(Eo)'] if need_e else [])
     outs += ['[s%d] "=&s"(s%d)' % (k, k) for k in range(NSREG)] + ['[sd] "=&s"(sd)']
+    if has_f:
+        outs += ['[sf] "=&s"(sf)', '[ovf] "+&s"(ovf)']
     ins_ = []
     if has_xin:
         ins_.append('[Xi] "v"(X)')
@@ -338,34 +355,42 @@ def chain_stmt(name, prods, has_xin, has_ein, may_carry_first, need_e, square=Fa
     ins_ += ['[a%d] "v"(a%d)' % (i, i) for i in used_a] + ['[b%d] "v"(b%d)' % (j, j) for j in used_b]
     code = "ELL_DEVASM void %s(%s) {\n" % (name, ", ".join(args))
     code += "  u64 %s, sd, Xo;\n" % ", ".join("s%d" % k for k in range(NSREG))
+    if has_f:
+        code += "  u64 sf;\n"
     if need_e:
         code += "  u32 Eo;\n"
-    code += '  asm("%s"\n      : %s\n      : %s\n      : );\n' % (body, ", ".join(outs), ", ".join(ins_) if ins_ else "")
+    code += '  asm("%s"\n      : %s\n      : %s\n      : %s);\n' % (body, ", ".join(outs), ", ".join(ins_) if ins_ else "",
+                                                               '"scc"' if has_f else "")
     code += "  X = Xo;" + (" E = Eo;" if need_e else "") + "\n"
-    code += "  (void)sd;" + "".join(" (void)s%d;" % k for k in range(NSREG)) + "\n}\n\n"
-    st = (sum(1 for x in seq if x[0] in ("mad", "madnc")), sum(1 for x in seq if x[0] == "addc"),
+    code += "  (void)sd;" + ("(void)sf;" if has_f else "") + "".join(" (void)s%d;" % k for k in range(NSREG)) + "\n}\n\n"
+    st = (sum(1 for x in seq if x[0] in ("mad", "madnc", "madf")), sum(1 for x in seq if x[0] == "addc"),
           sum(1 for x in seq if x[0] == "nop"))
-    return code, used_a, used_b, st
+    return code, used_a, used_b, st, has_f
 
 
-def gen_chain(L, square):
-    """single-chain wide product (square=False) or off-diagonal half of the square"""
+def gen_chain(L, square, fast=False):
+    """single-chain wide product (square=False) or off-diagonal half of the square.
+    fast=True: the variant whose columns do not add their first multiply-add's carry-out to E
+    (see chain_stmt, ovf_first); it takes a u64& ovf that comes back non-zero when that was
+    wrong for some lane, and the caller then calls the plain variant."""
     out = []
     stats = [0, 0, 0]
-    base = ("sqrc%d" if square else "mulc%d") % L
+    base = (("sqrf%d" if square else "mulf%d") if fast else ("sqrc%d" if square else "mulc%d")) % L
     cols = []
     for k in range(0, 2 * L - 1):
         pr = [(i, k - i) for i in range(L) if 0 <= k - i < L and (not square or i < k - i)]
         cols.append(pr)
     nz = [k for k in range(len(cols)) if cols[k]]
     first_col, last_col = nz[0], nz[-1]
-    fn_name = ("sqrc_offdiag_%d" if square else "mulc_wide_%d") % L
+    fn_name = ((("sqrf_offdiag_%d" if square else "mulf_wide_%d") if fast else
+                ("sqrc_offdiag_%d" if square else "mulc_wide_%d"))) % L
+    ovf_arg = ", u64& ovf" if fast else ""
     if square:
         fn = "// r[0..%d) = sum_{i<j} a_i*a_j*2^(32(i+j)), single accumulator chain\n" % (2 * L)
-        fn += "ELL_DEVASM void %s(u32 (&r)[%d], const u32 (&a)[%d]) {\n" % (fn_name, 2 * L, L)
+        fn += "ELL_DEVASM void %s(u32 (&r)[%d], const u32 (&a)[%d]%s) {\n" % (fn_name, 2 * L, L, ovf_arg)
     else:
         fn = "// r[0..%d) = a * b, single accumulator chain\n" % (2 * L)
-        fn += "ELL_DEVASM void %s(u32 (&r)[%d], const u32 (&a)[%d], const u32 (&b)[%d]) {\n" % (fn_name, 2 * L, L, L)
+        fn += "ELL_DEVASM void %s(u32 (&r)[%d], const u32 (&a)[%d], const u32 (&b)[%d]%s) {\n" % (fn_name, 2 * L, L, L, ovf_arg)
     fn += "  u64 X = 0; u32 E = 0;\n"
     for k in range(first_col):
         fn += "  r[%d] = 0;\n" % k
@@ -384,11 +409,12 @@ def gen_chain(L, square):
             has_ein = ci > 0 and need_e
             # first mad of the column: Xin = (X.hi, E_prev) < 2^32 when E_prev == 0 -> cannot overflow
             may_carry_first = (ci > 0) or (not e_prev_zero)
-            code, ua, ub, st = chain_stmt(name, ch, has_xin, has_ein, may_carry_first, need_e, square)
+            code, ua, ub, st, has_f = chain_stmt(name, ch, has_xin, has_ein, may_carry_first, need_e, square,
+                                                 ovf_first=fast and ci == 0 and has_xin)
             out.append(code)
             for t in range(3):
                 stats[t] += st[t]
-            call_args = ["X"] + (["E"] if need_e else [])
+            call_args = ["X"] + (["E"] if need_e else []) + (["ovf"] if has_f else [])
             call_args += ["a[%d]" % i for i in ua] + ["b[%d]" % j for j in ub]
             fn += "  %s(%s);\n" % (name, ", ".join(call_args))
         fn += "  r[%d] = (u32)X;\n" % k
@@ -447,6 +473,8 @@ def main():
         body += gen_sqr_off(L)
         body += gen_chain(L, False)
         body += gen_chain(L, True)
+        body += gen_chain(L, False, fast=True)
+        body += gen_chain(L, True, fast=True)
     body += gen_fold4()
     tail = "}  // namespace masm\n}  // namespace ell\n#endif  // __HIP_DEVICE_COMPILE__\n"
     with open(DST, "w") as f:

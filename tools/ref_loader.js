@@ -1,18 +1,23 @@
 'use strict';
-// Loader for the reference implementation (indutny/elliptic 6.6.1) in THIS
-// container only.  /root/reference/lib cannot be require()d (bn.js & friends
+// Loader for the reference implementation (indutny/elliptic 6.6.1): from
+// $ELLIPTIC_REFERENCE, else /root/reference (build container), else the copy
+// oracle/make_ref.py placed in the git-ignored oracle/_ref (that one travels to
+// the GPU box).  /root/reference/lib cannot be require()d (bn.js & friends
 // are not installed), but dist/elliptic.js is a browserify bundle that vendors
 // them (SURVEY.md Appendix C).  We evaluate the bundle with its trailing
 // "(1)" stripped so that browserify's internal require(id) is returned and
 // bn.js (16), brorand (17), hash.js (19), ec/signature (10) become reachable.
 //
-// Used by tools/gen_golden.js and tools/run_ref_tests.js.  Nothing on the GPU
-// box or in the product path touches this file.
+// Used by tools/gen_golden.js, tools/run_ref_tests*.js, tools/check_patched_results.js and
+// tools/bench_reference_verify.js (tests and the bench's CPU baseline).  Nothing in the
+// product path touches this file.
 
 var fs = require('fs');
 var path = require('path');
 
-var REF = process.env.ELLIPTIC_REFERENCE || '/root/reference';
+var REF = path.resolve(process.env.ELLIPTIC_REFERENCE ||
+  (fs.existsSync('/root/reference/dist/elliptic.js') ? '/root/reference'
+    : path.join(__dirname, '..', 'oracle', '_ref')));
 
 function load() {
   var file = path.join(REF, 'dist', 'elliptic.js');
