@@ -9,16 +9,21 @@ range checks, batched s^-1 mod n, u1*G + u2*Q with GLV, projective x-compare)
 over the whole batch.  Weak scaling: every rank owns its own 2^20 tuples, the
 only collective is the final gather of the ok-masks (RCCL all_gather).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 120 --warmup 10
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+At N = 1 the same line also carries `configs` (BASELINE configs #2, #4, #5 and
+the PCIe-inclusive host-buffer figure, each measured in this run) and
+`cpu_baseline` (the reference's own JavaScript timed under Node on this host).
 """
 import argparse
 import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,11 +32,20 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# algorithmic work per unit, SURVEY.md 8(d): reference field mul+sqr count x
-# (2*8^2 + 8) 32-bit MACs; bytes = 160 in + 1 out
-MACS_PER_VERIFY = 2236 * 136
-BYTES_PER_VERIFY = 161
+# algorithmic work per unit, SURVEY.md 8(d): reference field mul+sqr count x (2 L^2 + L)
+# 32-bit MACs; bytes = in + out at the C ABI
+ALG = {
+    "verify": {"macs": 2236 * 136, "bytes": 161},                 # secp256k1 ECDSA verify
+    "secp256k1_fixed": {"macs": 787 * 136, "bytes": 97},          # config #2
+    "secp256k1_var": {"macs": 1656 * 136, "bytes": 161},
+    "ed25519_var": {"macs": 2772 * 136, "bytes": 160},            # config #4
+    "p384_var": {"macs": 4276 * 300, "bytes": 241},               # config #5
+}
+MACS_PER_VERIFY = ALG["verify"]["macs"]
+BYTES_PER_VERIFY = ALG["verify"]["bytes"]
 HBM_PEAK_GBS = 8000.0
+N_SIMD = 256 * 4
+ORACLE_SAMPLE = 10240                 # tuples checked against the oracle in every run
 
 SECP_N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 
@@ -44,7 +58,9 @@ def make_signatures(ctx, n, seed, corrupt_every=100):
     """n synthetic secp256k1 signatures, all distinct keys/nonces, built without
     any modular inversion: pick d, k, s; r = x(kG) mod n; z = s*k - r*d mod n.
     Every `corrupt_every`-th tuple gets one bit flipped in z, r or s.
-    Returns (hash, r, s, pub, expected_ok) as numpy arrays."""
+    Returns (hash, r, s, pub, expected_ok) as numpy arrays.  (The public keys and the
+    nonce points come from the engine's own fixed-base kernel; bench.py checks a sample of
+    the tuples with the oracle in every run, so a wrong comb table cannot hide.)"""
     from elliptic_amd import ints_to_be
     N = SECP_N
     raw = xof(seed + ":d", n * 40).reshape(n, 40)
@@ -75,124 +91,312 @@ def make_signatures(ctx, n, seed, corrupt_every=100):
     return h, r, s, pub, ok
 
 
-def cpu_baseline(h, r, s, pub, ok, budget_s=15.0):
-    """The oracle (CPU restatement of the reference's algorithm, oracle/) timed on
-    this host on a bounded sample of the same tuples.  Checker only."""
-    built = None
+def cached_signatures(ctx, n, seed):
+    """make_signatures with a /tmp cache (the generator is ~10 s of Python big-int work per 2^20
+    tuples; the profiling passes call bench.py several times on one box)"""
+    key = hashlib.sha256(("%s:%d:v2" % (seed, n)).encode()).hexdigest()[:16]
+    path = os.path.join(tempfile.gettempdir(), "ellgpu_bench_%s.npz" % key)
+    if os.path.exists(path):
+        try:
+            d = np.load(path)
+            return d["h"], d["r"], d["s"], d["pub"], d["ok"]
+        except Exception:
+            pass
+    out = make_signatures(ctx, n, seed)
+    try:
+        np.savez(path + ".tmp.npz", h=out[0], r=out[1], s=out[2], pub=out[3], ok=out[4])
+        os.replace(path + ".tmp.npz", path)
+    except OSError:
+        pass
+    return out
+
+
+# ---- the checker ------------------------------------------------------------------------
+def oracle_check(h, r, s, pub, expect, m=ORACLE_SAMPLE):
+    """first m tuples of the batch through the oracle (oracle/ec_oracle.c on the host threads;
+    the pure-Python restatement on a smaller sample if the C build is unavailable): the
+    expected mask -- which the GPU mask is compared with on ALL tuples -- must be the oracle's"""
+    m = min(m, len(expect))
     try:
         from oracle import c_oracle
-        built = c_oracle.load()
+        c_oracle.load()
+        ok = c_oracle.verify("secp256k1", h[:m], r[:m], s[:m], pub[:m], threads=c_oracle._usable_cpus())
+        what = "oracle/ec_oracle.c"
     except Exception:
-        built = None
-    from elliptic_amd import be_to_ints
-    if built is not None:
-        return c_oracle.bench_verify(built, h, r, s, pub, ok, budget_s)
-    from oracle import ec_oracle as O
-    cur = O.get_curve("secp256k1")
-    m = min(len(ok), 4000)
-    zs, rs, ss = be_to_ints(h[:m]), be_to_ints(r[:m]), be_to_ints(s[:m])
-    qx, qy = be_to_ints(pub[:m, :32]), be_to_ints(pub[:m, 32:])
-    t0 = time.perf_counter()
-    done = 0
-    for i in range(m):
-        got = O.ecdsa_verify(cur, zs[i], 32, rs[i], ss[i], cur.point(qx[i], qy[i]))
-        assert got == bool(ok[i]), "oracle disagrees with the expected mask at %d" % i
-        done += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "verifies/s", "cores": 1, "kind": "port",
-            "sample": "first %d tuples of the rank-0 batch, oracle/ec_oracle.py (python ints), 1 thread" % done}
+        from oracle import ec_oracle as O
+        from elliptic_amd import be_to_ints
+        m = min(m, 400)
+        cur = O.get_curve("secp256k1")
+        zs, rs, ss = be_to_ints(h[:m]), be_to_ints(r[:m]), be_to_ints(s[:m])
+        qx, qy = be_to_ints(pub[:m, :32]), be_to_ints(pub[:m, 32:])
+        ok = np.array([O.ecdsa_verify(cur, zs[i], 32, rs[i], ss[i], cur.point(qx[i], qy[i])) for i in range(m)],
+                      np.uint8)
+        what = "oracle/ec_oracle.py"
+    if not np.array_equal(ok.astype(np.uint8), expect[:m].astype(np.uint8)):
+        raise SystemExit("PARITY FAILURE: the oracle disagrees with the expected mask on %d of the first %d tuples"
+                         % (int((ok.astype(np.uint8) != expect[:m]).sum()), m))
+    return {"tuples": int(m), "by": what}
 
 
-def reference_js_from_profiles():
-    """The reference's own pure-JS path, timed by tools/bench_reference_js.js in the build
-    container (the GPU box holds no copy of the reference): quoted, never re-measured here."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*reference_js_cpu.json")))
-    if not files:
+def reference_js_baseline(h, r, s, pub, expect, budget_s=8.0):
+    """The reference's own pure-JS path (oracle/_ref = indutny/elliptic's bundle, copied by
+    oracle/make_ref.py) under Node on THIS host: one process for the per-core figure, then one
+    process per usable core over disjoint slices of the rank-0 batch (SURVEY.md 8d row 1 /
+    benchmarks/index.js:106-109).  None when Node or the copy is missing."""
+    import shutil
+    from oracle import make_ref, c_oracle
+    ref = make_ref.present() or make_ref.build()
+    node = shutil.which("node")
+    if ref is None or node is None:
         return None
+    cores = c_oracle._usable_cpus()
+    per = 1536                                       # tuples per process (>= budget * ~150/s)
+    need = per * (cores + 1)
+    m = min(len(expect), need)
+    rec = np.concatenate([h[:m], r[:m], s[:m], pub[:m], expect[:m].reshape(-1, 1).astype(np.uint8)], axis=1)
+    assert rec.shape[1] == 161
+    path = os.path.join(tempfile.gettempdir(), "ellgpu_bench_tuples_%d.bin" % os.getpid())
+    rec.tofile(path)
+    script = os.path.join(ROOT, "tools", "bench_reference_verify.js")
+    env = dict(os.environ, ELLIPTIC_REFERENCE=ref)
+
+    def run(first, count, secs, extra=()):
+        return subprocess.Popen([node, script, path, str(first), str(count), str(secs)] + list(extra), env=env,
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    def collect(ps):
+        outs = []
+        for p in ps:
+            so, se = p.communicate(timeout=300)
+            if p.returncode != 0:
+                raise RuntimeError("bench_reference_verify.js failed: " + se[-400:])
+            outs.append(json.loads(so.strip().splitlines()[-1]))
+        return outs
     try:
-        d = json.load(open(files[-1]))
+        one = collect([run(0, min(per, m), budget_s * 0.4)])[0]
+        fixed = collect([run(0, 1, 2.0, ["fixed"])])[0]
+        slices = []
+        for c in range(cores):
+            first = per * (c + 1)
+            if first + 64 > m:
+                break
+            slices.append((first, min(per, m - first)))
+        many = collect([run(f, c, budget_s * 0.6) for f, c in slices]) if slices else []
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    bad = one["mismatches"] + sum(o["mismatches"] for o in many)
+    if bad:
+        raise SystemExit("PARITY FAILURE: the reference (Node) disagrees with the expected mask on %d tuples" % bad)
+    total = sum(o["per_s"] for o in many) if many else one["per_s"]
+    checked = one["done"] + sum(o["done"] for o in many)
+    return {"value": total, "unit": "verifies/s", "cores": len(many) if many else 1, "kind": "reference",
+            "single_core_value": one["per_s"], "single_core_fixed_tuple": fixed["per_s"],
+            "cpu": one["cpu"], "host_logical_cpus": one["logical_cpus"], "usable_cpus": cores,
+            "node": one["node"], "reference": "indutny/elliptic %s, dist/elliptic.js (bn.js 4.11.9) via oracle/_ref"
+                                              % one["version"],
+            "where": "this host (the GPU box when bench.py runs there)",
+            "tuples_verified_by_reference": checked,
+            "sample": "ec.verify(msg, Signature, KeyPair) as benchmarks/index.js:106-109 calls it, on tuples "
+                      "%d..%d of the rank-0 batch: %d Node processes x <= %d tuples, %.1f s each (sum of the "
+                      "per-process rates), after 1 process on the first %d; every verdict equals the expected mask"
+                      % (per, per * (len(many) + 1), len(many), per, budget_s * 0.6, min(per, m))}
+
+
+def port_baseline(h, r, s, pub, expect, budget_s=6.0):
+    """oracle/ec_oracle.c (C port of the reference's algorithm) on the host threads: the 'fair
+    native CPU' line beside the reference's JavaScript"""
+    try:
+        from oracle import c_oracle
+        return c_oracle.bench_verify(c_oracle.load(), h, r, s, pub, expect, budget_s)
+    except Exception as e:       # pragma: no cover
+        return {"error": str(e)}
+
+
+# ---- committed profile summaries ------------------------------------------------------------
+def _latest(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
+
+
+def kernel_counters():
+    """profiles/rNN_kernel_counters.json (tools/refresh_profiles.py: rocprofv3 PMC passes of this
+    very command): VALU instructions by class per unit for every benchmarked kernel, VALU-busy,
+    HBM traffic, and the source digest of the library they were taken from"""
+    f = _latest("*kernel_counters.json")
+    if not f:
+        return None, None
+    try:
+        return json.load(open(f)), os.path.relpath(f, ROOT)
     except ValueError:
+        return None, None
+
+
+def lib_digest():
+    try:
+        return open(os.path.join(ROOT, "elliptic_amd", "lib", "libellgpu.stamp")).read().strip()
+    except OSError:
         return None
-    return {"verifies_per_s_per_core": d.get("verify_random_per_s"), "cpu": d.get("cpu"), "node": d.get("node"),
-            "where": d.get("where"), "source": os.path.relpath(files[-1], ROOT)}
 
 
-def traffic_from_profiles():
-    """HBM bytes per ecdsa_main launch from the newest committed rocprofv3 PMC summary
-    (profiles/*pmc_fetch_write*.txt; FETCH_SIZE / WRITE_SIZE are reported in KiB and were
-    collected in separate --pmc passes).  The gfx950 x2 correction of FETCH_SIZE applies to
-    wide coalesced streams; this kernel's fetches are 16-byte-per-lane table gathers, for which
-    the factor is uncalibrated, so both figures are returned."""
-    import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_write*.txt")))
-    if not files:
-        return None
-    txt = open(files[-1]).read()
-    f = re.search(r"FnEcdsaMain<CvSecp256k1>>\s+FETCH_SIZE\s+\d+\s+n=\d+\s+per_dispatch=(\d+)", txt)
-    w = re.search(r"FnEcdsaMain<CvSecp256k1>>\s+WRITE_SIZE\s+\d+\s+n=\d+\s+per_dispatch=(\d+)", txt)
-    if not f or not w:
-        return None
-    fetch, write = int(f.group(1)) * 1024, int(w.group(1)) * 1024
-    return {"bytes_per_launch": fetch + write, "bytes_per_launch_fetch_x2": 2 * fetch + write,
-            "fetch_bytes": fetch, "write_bytes": write, "source": os.path.relpath(files[-1], ROOT),
-            "note": "per 2^20-tuple launch; dominated by the per-lane window tables (1 KiB written, "
-                    "~4.2 KiB gathered per verify), see DESIGN.md section 3"}
+def roofline_block(kernel_key, unit_key, n, kernel_ms, peak_gmads, clock_ghz, counters, csrc):
+    """roofline object for one kernel launch over n units that took kernel_ms"""
+    alg = ALG[unit_key]
+    theo = N_SIMD * 64 / 4.0 * clock_ghz                       # G mad/s if a wave-mad issued every 4 cycles
+    out = {"bound": "valu_int32_mac", "kernel": kernel_key, "unit": "G v_mad_u64_u32/s",
+           "peak": peak_gmads, "peak_theoretical_4cycle": theo, "kernel_ms": kernel_ms,
+           "alg_macs_per_unit": alg["macs"]}
+    ach_alg = n * alg["macs"] / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
+    out["frac_reference_alg"] = ach_alg / peak_gmads if peak_gmads else None
+    out["achieved_reference_alg"] = ach_alg
+    k = (counters or {}).get("kernels", {}).get(kernel_key)
+    if k and k.get("mad_u64_per_unit"):
+        mads = k["mad_u64_per_unit"]
+        ach = n * mads / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
+        out.update({"achieved": ach, "frac": ach / peak_gmads if peak_gmads else None,
+                    "frac_of_theoretical": ach / theo,
+                    "mads_issued_per_unit": mads, "valu_insts_per_unit": k.get("valu_per_unit"),
+                    "carry_int32_per_unit": k.get("int32_per_unit"),
+                    "multiply_share_of_valu_insts": mads / k["valu_per_unit"] if k.get("valu_per_unit") else None,
+                    "valu_busy_pmc": k.get("valu_busy"), "counters_source": csrc,
+                    "counters_stale": (counters.get("source_digest") != lib_digest())})
+        # issue accounting: instruction classes priced at their measured issue times
+        if k.get("valu_per_unit") and k.get("int32_per_unit") is not None:
+            other = max(k["valu_per_unit"] - mads - k["int32_per_unit"], 0.0)
+            need = 64 * (4.5 * mads + 4.2 * k["int32_per_unit"] + 2.5 * other)      # cycles per wavefront of 64 units
+            have = kernel_ms * 1e-3 * clock_ghz * 1e9 / ((n / 64.0) / N_SIMD)
+            out["issue"] = {"issue_cycles_per_wave": need, "elapsed_cycles_per_wave_slot": have,
+                            "frac": need / have if have else None,
+                            "prices": "4.5 / 4.2 / 2.5 cycles per wave-instruction (mad / carry-class / other), "
+                                      "profiles/*valu_patterns.log"}
+    else:
+        out.update({"achieved": None, "frac": None,
+                    "note": "no committed PMC instruction counts for this kernel (profiles/*kernel_counters.json)"})
+    ach_gbs = n * alg["bytes"] / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
+    out["hbm"] = {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
+                  "alg_bytes_per_unit": alg["bytes"]}
+    if k and k.get("fetch_bytes_per_unit") is not None:
+        out["traffic"] = {"bytes_per_launch": (k["fetch_bytes_per_unit"] + k["write_bytes_per_unit"]) * n,
+                          "fetch_bytes_per_unit": k["fetch_bytes_per_unit"],
+                          "write_bytes_per_unit": k["write_bytes_per_unit"],
+                          "fetch_calibration": counters.get("fetch_calibration"), "source": csrc}
+    else:
+        out["traffic"] = None
+    return out
 
 
-def issue_from_profiles(kernel_ms, n):
-    """Instruction-issue accounting of ecdsa_main from the newest committed rocprofv3 PMC
-    summaries (profiles/*pmc_sq_a*.txt: SQ_INSTS_VALU; *pmc_sq_b*.txt: SQ_INSTS_VALU_INT64 /
-    _INT32), priced at the issue times measured by tools/microbench/valu_patterns.hip
-    (profiles/*valu_patterns.log: 4.5 cycles per wavefront for v_mad_u64_u32, 4.2 for every
-    carry-consuming / VOP3 integer op, 2.5 for plain VOP1/VOP2 ops).  `frac` = issue cycles the
-    instruction mix needs / cycles the kernel took per SIMD: the honest utilisation figure for a
-    kernel in which a carry costs as much as a multiply."""
-    import glob
-    import re
+# ---- the other BASELINE configs (N = 1 only) ---------------------------------------------------
+def run_configs(ctx, dev, peak_gmads, clock_ghz, counters, csrc, h, r, s, pub, expect):
+    """BASELINE.json configs #2, #4, #5 (kernel-only, inputs in HBM, a sample of every result
+    checked against the oracle) and the PCIe-inclusive form of the headline (host buffers in,
+    mask out).  -> list of dicts"""
+    import elliptic_amd
+    from oracle import c_oracle, ec_oracle as O
+    rows = []
 
-    def counter(pattern, name):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
-        if not files:
-            return None, None
-        txt = open(files[-1]).read()
-        m = re.search(r"FnEcdsaMain<CvSecp256k1>>\s+" + name + r"\s+(\d+)\s+n=(\d+)", txt)
-        c = re.search(r"FnEcdsaMain<CvSecp256k1>>\s+(\d+)\s+\d+\s+\d+\s+[\d.]+", txt)   # kernel-stats row: calls
-        if not m or not c:
-            return None, None
-        return int(m.group(1)) / int(c.group(1)), os.path.relpath(files[-1], ROOT)
+    def rnd(seed, n, w):
+        return xof(seed, n * w).reshape(n, w).copy()
 
-    valu, src_a = counter("*pmc_sq_a*.txt", "SQ_INSTS_VALU")
-    i64, src_b = counter("*pmc_sq_b*.txt", "SQ_INSTS_VALU_INT64")
-    i32, _ = counter("*pmc_sq_b*.txt", "SQ_INSTS_VALU_INT32")
-    if not valu or not i64 or not i32:
-        return None
-    waves = (1 << 20) / 64.0                      # the profiled launches are 2^20-tuple launches
-    valu, i64, i32 = valu / waves, i64 / waves, i32 / waves
-    other = max(valu - i64 - i32, 0.0)
-    need = 4.5 * i64 + 4.2 * i32 + 2.5 * other    # issue cycles per wavefront
-    simds = 256 * 4
-    clock_khz = 2.4e6
-    have = kernel_ms * clock_khz / ((n / 64.0) / simds)
-    return {"valu_insts_per_unit": valu, "mad_u64_per_unit": i64, "carry_int32_per_unit": i32,
-            "other_per_unit": other, "issue_cycles_per_wave": need, "elapsed_cycles_per_wave_slot": have,
-            "frac": need / have if have else None, "clock_ghz": 2.4,
-            "sources": [src_a, src_b, "profiles/r01_valu_patterns.log"]}
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        ctx.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        tm = ctx.get_timing()
+        ctx.set_timing(False)
+        return dt, {k: v[1] / v[0] for k, v in tm.items()}
+
+    def sample_check(curve, ks, pts, got_xy, got_inf, m=2048):
+        """first m results against the oracle (C port for the short curves, python for ed25519)"""
+        m = min(m, len(ks))
+        if curve == "ed25519":
+            m = min(m, 96)
+            cur = O.get_curve("ed25519")
+            for i in range(m):
+                k = int.from_bytes(ks[i].tobytes(), "big")
+                if pts is None:
+                    w = cur.g.mul(k)
+                else:
+                    w = cur.point(int.from_bytes(pts[i, :32].tobytes(), "big"),
+                                  int.from_bytes(pts[i, 32:].tobytes(), "big")).mul(k)
+                wx, wy = w.normalized()
+                g = (int.from_bytes(got_xy[i, :32].tobytes(), "big"), int.from_bytes(got_xy[i, 32:].tobytes(), "big"))
+                assert g == (wx, wy), ("ed25519 parity", i)
+            return m
+        want, winf = c_oracle.mul(curve, ks[:m], None if pts is None else pts[:m])
+        assert np.array_equal(winf, got_inf[:m]) and np.array_equal(want, got_xy[:m]), curve + " parity vs oracle"
+        return m
+
+    for cfg, curve, n, unit_key, kernel_key, fixed in (
+            ("#2 secp256k1 fixed-base G*k, batch 2^20", "secp256k1", 1 << 20, "secp256k1_fixed", "mul_fixed<secp256k1>", True),
+            ("#3' secp256k1 variable-base P*k (GLV), batch 2^20", "secp256k1", 1 << 20, "secp256k1_var", "mul_var<secp256k1>", False),
+            ("#4 ed25519 variable-base P*k + batch inversion, batch 2^20", "ed25519", 1 << 20, "ed25519_var", "ed_mul_var", False),
+            ("#5 p384 variable-base P*k, batch 2^18", "p384", 1 << 18, "p384_var", "mul_var<p384>", False)):
+        B = elliptic_amd.FIELD_BYTES[curve]
+        ks = rnd("ellgpu-bench-v1:cfg:k:" + curve, n, B)
+        if curve == "ed25519":
+            ks[:, 0] &= 0x0F                       # scalars < 2^252 < n
+        dk = torch.from_numpy(ks).to(dev)
+        out = torch.zeros((n, 2 * B), dtype=torch.uint8, device=dev)
+        inf = torch.zeros(n, dtype=torch.uint8, device=dev)
+        pts_np = None
+        if fixed:
+            fn = lambda: ctx.mul_fixed_dev(curve, dk, out, inf)          # noqa: E731
+        else:
+            ds = rnd("ellgpu-bench-v1:cfg:d:" + curve, n, B)
+            if curve == "ed25519":
+                ds[:, 0] &= 0x0F
+            dd = torch.from_numpy(ds).to(dev)
+            pts = torch.zeros((n, 2 * B), dtype=torch.uint8, device=dev)
+            ctx.mul_fixed_dev(curve, dd, pts, inf)                        # P_i = d_i * G
+            torch.cuda.synchronize()
+            pts_np = pts.cpu().numpy()
+            fn = lambda: ctx.mul_var_dev(curve, dk, pts, out, inf)        # noqa: E731
+        reps = max(3, int(0.6 / (n / 100e6)) if fixed else 12)
+        dt, kms = timed(fn, min(reps, 40))
+        checked = sample_check(curve, ks, pts_np, out.cpu().numpy(), inf.cpu().numpy())
+        main_name = max(kms, key=kms.get)
+        row = {"config": cfg, "n": n, "items_per_s": n / dt, "ms_per_pass": dt * 1e3, "kernels_ms": kms,
+               "dominant_kernel": main_name, "oracle_checked": checked,
+               "roofline": roofline_block(kernel_key, unit_key, n, kms[main_name], peak_gmads, clock_ghz, counters, csrc)}
+        rows.append(row)
+        del dk, out, inf
+    # PCIe-inclusive headline: pageable host buffers in, mask out (H2D 160 B + D2H 1 B per tuple)
+    n = len(expect)
+    got = ctx.ecdsa_verify("secp256k1", h, r, s, pub)
+    assert np.array_equal(np.asarray(got).astype(np.uint8), expect.astype(np.uint8)), "host path parity"
+    ts = []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        ctx.ecdsa_verify("secp256k1", h, r, s, pub)
+        ts.append(time.perf_counter() - t0)
+    rows.append({"config": "#3 secp256k1 ECDSA verify through the host-buffer entry point "
+                           "(PCIe-inclusive: H2D 160 B + kernels + D2H 1 B per tuple), batch 2^20",
+                 "n": n, "items_per_s": n / (sum(ts) / len(ts)), "items_per_s_best": n / min(ts),
+                 "ms_per_pass": sum(ts) / len(ts) * 1e3, "note": "never `value`; mask == expected on all tuples"})
+    return rows
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1 << 20, help="tuples per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (self-test of the N>1 flow)")
     ap.add_argument("--force-device", type=int, default=None,
                     help="self-test only: every rank uses this device (lets the N>1 flow run on a 1-GPU box)")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="N = 1: initialise a 1-rank RCCL group and run the gather through it once")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -207,9 +411,14 @@ def main():
         local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    rccl_selftest = None
+    if world > 1 or args.rccl_selftest:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if world == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -218,11 +427,12 @@ def main():
     import elliptic_amd
     ctx = elliptic_amd.Context(local_rank)
     n = args.batch
-    h, r, s, pub, expect = make_signatures(ctx, n, "ellgpu-bench-v1:3:rank%d" % rank)
+    h, r, s, pub, expect = cached_signatures(ctx, n, "ellgpu-bench-v1:3:rank%d" % rank)
+    checked = oracle_check(h, r, s, pub, expect)
     dev = torch.device("cuda", local_rank)
     dh, dr, dsg, dq = (torch.from_numpy(x).to(dev) for x in (h, r, s, pub))
     dok = torch.zeros(n, dtype=torch.uint8, device=dev)
-    gathered = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(world)] if world > 1 else None
+    gathered = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(world)] if dist is not None else None
     ctx.reserve("secp256k1", n)
 
     def step():
@@ -242,6 +452,13 @@ def main():
     if not np.array_equal(got, expect):
         bad = int((got != expect).sum())
         raise SystemExit("PARITY FAILURE: %d of %d verify results differ from the expected mask" % (bad, n))
+    if world == 1 and dist is not None:
+        # the RCCL branch of the N > 1 flow, executed once on a 1-rank group
+        t0 = time.perf_counter()
+        dist.all_gather(gathered, dok)
+        torch.cuda.synchronize()
+        rccl_selftest = {"backend": args.dist_backend, "world": 1, "all_gather_ok": bool(torch.equal(gathered[0], dok)),
+                         "ms": (time.perf_counter() - t0) * 1e3}
 
     ctx.set_timing(True)
     if world > 1:
@@ -269,12 +486,16 @@ def main():
         k_ms = main_ms / max(cnt, 1)
         # integer-VALU peak: dependency-free v_mad_u64_u32 stream on every CU
         # (best of five short runs: a single one moves by +-3 % with the clock state)
-        peak_gmacs = 0.0
+        peak_gmads = 0.0
         for _ in range(5):
             ms, ops = ctx.probe_valu(0, 256 * 8 * 4, 4096)
-            peak_gmacs = max(peak_gmacs, ops / (ms * 1e-3) / 1e9)
-        ach_gmacs = n * MACS_PER_VERIFY / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
-        ach_gbs = n * BYTES_PER_VERIFY / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
+            peak_gmads = max(peak_gmads, ops / (ms * 1e-3) / 1e9)
+        clock_ghz = torch.cuda.get_device_properties(local_rank).clock_rate / 1e6 if hasattr(
+            torch.cuda.get_device_properties(local_rank), "clock_rate") else 2.4
+        counters, csrc = kernel_counters()
+        roof = roofline_block("ecdsa_main<secp256k1>", "verify", n, k_ms, peak_gmads, clock_ghz, counters, csrc)
+        roof["prep_kernel_ms"] = prep_ms / max(pcnt, 1)
+        roof["clock_ghz"] = clock_ghz
         out = {
             "metric": "secp256k1 ECDSA verify batch throughput (1 verify = 1 double-scalar mult u1*G+u2*Q)",
             "value": value,
@@ -284,6 +505,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "timed_region_s": dt,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -293,25 +515,32 @@ def main():
                                    "batch=2^20 tuples per GPU resident in HBM, 1% corrupted"
                                    if n == 1 << 20 else "secp256k1 ECDSA verify, batch=%d per GPU" % n,
                        "batch_per_gpu": n, "parallelism": "shard%d" % world,
-                       "parity": "ok-mask == expected mask on all %d tuples" % n},
-            "roofline": {
-                "bound": "valu_int32_mac",
-                "kernel": "ecdsa_main",
-                "achieved": ach_gmacs, "peak": peak_gmacs, "unit": "GMAC/s",
-                "frac": ach_gmacs / peak_gmacs if peak_gmacs else None,
-                "kernel_ms": k_ms, "prep_kernel_ms": prep_ms / max(pcnt, 1),
-                "alg_macs_per_unit": MACS_PER_VERIFY,
-                "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach_gbs / HBM_PEAK_GBS, "alg_bytes_per_unit": BYTES_PER_VERIFY},
-                "traffic": traffic_from_profiles() if n == 1 << 20 else None,
-                "issue": issue_from_profiles(k_ms, n) if n == 1 << 20 else None,
-            },
+                       "parity": "ok-mask == expected mask on all %d tuples; expected mask == oracle on the "
+                                 "first %d (%s)" % (n, checked["tuples"], checked["by"]),
+                       "library_digest": lib_digest()},
+            "roofline": roof,
         }
+        if rccl_selftest is not None:
+            out["rccl_selftest"] = rccl_selftest
+        if world == 1 and not args.no_configs:
+            out["configs"] = run_configs(ctx, dev, peak_gmads, clock_ghz, counters, csrc, h, r, s, pub, expect)
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(h, r, s, pub, expect)
-            out["cpu_baseline"]["reference_js"] = reference_js_from_profiles()
+            base = None
+            try:
+                base = reference_js_baseline(h, r, s, pub, expect)
+            except SystemExit:
+                raise
+            except Exception as e:
+                base = None
+                out["cpu_baseline_reference_error"] = str(e)[-300:]
+            port = port_baseline(h, r, s, pub, expect)
+            if base is not None:
+                base["port"] = port
+                out["cpu_baseline"] = base
+            else:
+                out["cpu_baseline"] = port
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

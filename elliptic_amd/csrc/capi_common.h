@@ -22,7 +22,10 @@ static int set_err(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
-static int finish(ellgpu_ctx* ctx, int rc) {
+// end of every entry point.  `stream_call` = a *_dev entry point: it returns without
+// synchronising, so the backend records where its work ends (see HipBackend::use_stream).
+static int finish(ellgpu_ctx* ctx, int rc, bool stream_call = false) {
+  ctx->eng->bk.end_call(stream_call);
   if (rc) g_last_error = ctx->eng->err.empty() ? "ellgpu error" : ctx->eng->err;
   return rc;
 }
@@ -119,7 +122,7 @@ int ellgpu_decompress(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, co
 int ellgpu_decompress_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, const uint8_t* odd,
                           uint8_t* out_xy, uint8_t* out_ok, void* stream) {
   ELL_ENTER(ctx, stream);
-  return finish(ctx, ctx->eng->decompress_dev(curve, n, v, odd, out_xy, out_ok));
+  return finish(ctx, ctx->eng->decompress_dev(curve, n, v, odd, out_xy, out_ok), true);
 }
 
 // point codecs and key validation (decodePoint / encode / KeyPair#validate)
@@ -131,7 +134,7 @@ int ellgpu_decode_points(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* en
 int ellgpu_decode_points_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* enc, size_t enc_len,
                              uint8_t* out_xy, uint8_t* out_status, void* stream) {
   ELL_ENTER(ctx, stream);
-  return finish(ctx, ctx->eng->decode_points_dev(curve, n, enc, enc_len, out_xy, out_status));
+  return finish(ctx, ctx->eng->decode_points_dev(curve, n, enc, enc_len, out_xy, out_status), true);
 }
 int ellgpu_encode_points(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, int compact,
                          uint8_t* out_enc) {
@@ -141,7 +144,7 @@ int ellgpu_encode_points(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy
 int ellgpu_encode_points_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, int compact,
                              uint8_t* out_enc, void* stream) {
   ELL_ENTER(ctx, stream);
-  return finish(ctx, ctx->eng->encode_points_dev(curve, n, xy, compact, out_enc));
+  return finish(ctx, ctx->eng->encode_points_dev(curve, n, xy, compact, out_enc), true);
 }
 int ellgpu_validate(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, const uint8_t* inf,
                     int check_order, uint8_t* out_status) {
@@ -151,7 +154,7 @@ int ellgpu_validate(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, con
 int ellgpu_validate_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, const uint8_t* inf,
                         int check_order, uint8_t* out_status, void* stream) {
   ELL_ENTER(ctx, stream);
-  return finish(ctx, ctx->eng->validate_dev(curve, n, xy, inf, check_order, out_status));
+  return finish(ctx, ctx->eng->validate_dev(curve, n, xy, inf, check_order, out_status), true);
 }
 
 // Point#add on affine points
@@ -164,7 +167,7 @@ int ellgpu_point_add_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy
                          const uint8_t* xy2, const uint8_t* inf2, uint8_t* out_xy, uint8_t* out_inf,
                          void* stream) {
   ELL_ENTER(ctx, stream);
-  return finish(ctx, ctx->eng->point_add_dev(curve, n, xy1, inf1, xy2, inf2, out_xy, out_inf));
+  return finish(ctx, ctx->eng->point_add_dev(curve, n, xy1, inf1, xy2, inf2, out_xy, out_inf), true);
 }
 
 // signature DER codec and EC#verify on wire formats
@@ -177,7 +180,7 @@ int ellgpu_sig_from_der_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t*
                             const uint32_t* der_len, uint8_t* out_r, uint8_t* out_s, uint8_t* out_status,
                             void* stream) {
   ELL_ENTER(ctx, stream);
-  return finish(ctx, ctx->eng->sig_from_der_dev(curve, n, der, stride, der_len, out_r, out_s, out_status));
+  return finish(ctx, ctx->eng->sig_from_der_dev(curve, n, der, stride, der_len, out_r, out_s, out_status), true);
 }
 int ellgpu_sig_to_der(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* r, const uint8_t* s,
                       uint8_t* out_der, size_t stride, uint32_t* out_len) {
@@ -187,7 +190,7 @@ int ellgpu_sig_to_der(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* r, co
 int ellgpu_sig_to_der_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* r, const uint8_t* s,
                           uint8_t* out_der, size_t stride, uint32_t* out_len, void* stream) {
   ELL_ENTER(ctx, stream);
-  return finish(ctx, ctx->eng->sig_to_der_dev(curve, n, r, s, out_der, stride, out_len));
+  return finish(ctx, ctx->eng->sig_to_der_dev(curve, n, r, s, out_der, stride, out_len), true);
 }
 int ellgpu_ecdsa_verify_wire(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
                              int msg_bits, const uint8_t* der, size_t der_stride, const uint32_t* der_len,
@@ -202,7 +205,7 @@ int ellgpu_ecdsa_verify_wire_dev(ellgpu_ctx* ctx, int curve, size_t n, const uin
                                  uint8_t* out_ok, uint8_t* out_err, void* stream) {
   ELL_ENTER(ctx, stream);
   return finish(ctx, ctx->eng->ecdsa_verify_wire_dev(curve, n, hash, hash_len, msg_bits, der, der_stride,
-                                                     der_len, pub_enc, pub_len, out_ok, out_err));
+                                                     der_len, pub_enc, pub_len, out_ok, out_err), true);
 }
 
 int ellgpu_ecdsa_sign(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len, int msg_bits,
@@ -218,7 +221,7 @@ int ellgpu_ecdsa_sign_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* h
                           void* stream) {
   ELL_ENTER(ctx, stream);
   return finish(ctx, ctx->eng->ecdsa_sign_dev(curve, n, hash, hash_len, msg_bits, priv, nonces, canonical,
-                                              out_r, out_s, out_recid, out_ok));
+                                              out_r, out_s, out_recid, out_ok), true);
 }
 
 int ellgpu_eddsa_verify(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off,
@@ -233,7 +236,7 @@ int ellgpu_eddsa_verify_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, cons
                             uint8_t* out_ok, uint8_t* out_err, void* stream) {
   ELL_ENTER(ctx, stream);
   return finish(ctx, ctx->eng->eddsa_verify_dev(n, msgs, (const ell::u64*)msg_off, msg_len, sigs, pubs,
-                                                out_ok, out_err));
+                                                out_ok, out_err), true);
 }
 
 int ellgpu_ecdsa_sign_det(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
@@ -248,7 +251,7 @@ int ellgpu_ecdsa_sign_det_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_
                               uint8_t* out_s, uint8_t* out_recid, uint8_t* out_ok, void* stream) {
   ELL_ENTER(ctx, stream);
   return finish(ctx, ctx->eng->ecdsa_sign_det_dev(curve, n, hash, hash_len, msg_bits, priv, canonical, out_r,
-                                                  out_s, out_recid, out_ok));
+                                                  out_s, out_recid, out_ok), true);
 }
 
 int ellgpu_ecdsa_recover(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
@@ -261,7 +264,7 @@ int ellgpu_ecdsa_recover_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t
                              const uint8_t* r, const uint8_t* s, const uint8_t* recid, uint8_t* out_xy,
                              uint8_t* out_status, void* stream) {
   ELL_ENTER(ctx, stream);
-  return finish(ctx, ctx->eng->ecdsa_recover_dev(curve, n, hash, hash_len, r, s, recid, out_xy, out_status));
+  return finish(ctx, ctx->eng->ecdsa_recover_dev(curve, n, hash, hash_len, r, s, recid, out_xy, out_status), true);
 }
 
 int ellgpu_eddsa_sign(ellgpu_ctx* ctx, size_t n, const uint8_t* secrets, const uint8_t* msgs,
@@ -275,36 +278,36 @@ int ellgpu_eddsa_sign_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* secrets, con
                           void* stream) {
   ELL_ENTER(ctx, stream);
   return finish(ctx, ctx->eng->eddsa_sign_dev(n, secrets, msgs, (const ell::u64*)msg_off, msg_len, out_sig,
-                                              out_pub));
+                                              out_pub), true);
 }
 
 int ellgpu_mul_fixed_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, uint8_t* out_xy,
                          uint8_t* out_inf, void* stream) {
   ELL_ENTER(ctx, stream);
-  return finish(ctx, ctx->eng->mul_fixed_dev(curve, n, k, out_xy, out_inf));
+  return finish(ctx, ctx->eng->mul_fixed_dev(curve, n, k, out_xy, out_inf), true);
 }
 int ellgpu_mul_var_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
                        const uint8_t* in_xy, uint8_t* out_xy, uint8_t* out_inf, void* stream) {
   ELL_ENTER(ctx, stream);
-  return finish(ctx, ctx->eng->mul_var_dev(curve, n, k, in_xy, out_xy, out_inf));
+  return finish(ctx, ctx->eng->mul_var_dev(curve, n, k, in_xy, out_xy, out_inf), true);
 }
 int ellgpu_mul_add2_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1,
                         const uint8_t* p1_xy, const uint8_t* k2, const uint8_t* p2_xy,
                         uint8_t* out_xy, uint8_t* out_inf, void* stream) {
   ELL_ENTER(ctx, stream);
-  return finish(ctx, ctx->eng->mul_add2_dev(curve, n, k1, p1_xy, k2, p2_xy, out_xy, out_inf));
+  return finish(ctx, ctx->eng->mul_add2_dev(curve, n, k1, p1_xy, k2, p2_xy, out_xy, out_inf), true);
 }
 int ellgpu_ecdsa_verify_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash,
                             int hash_len, int msg_bits, const uint8_t* r, const uint8_t* s,
                             const uint8_t* pub_xy, uint8_t* out_ok, void* stream) {
   ELL_ENTER(ctx, stream);
   return finish(ctx, ctx->eng->ecdsa_verify_dev(curve, n, hash, hash_len, msg_bits, r, s, pub_xy,
-                                                out_ok));
+                                                out_ok), true);
 }
 int ellgpu_x25519_ladder_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* in_x,
                              uint8_t* out_x, uint8_t* out_inf, void* stream) {
   ELL_ENTER(ctx, stream);
-  return finish(ctx, ctx->eng->x25519_dev(n, k, in_x, out_x, out_inf));
+  return finish(ctx, ctx->eng->x25519_dev(n, k, in_x, out_x, out_inf), true);
 }
 
 }  // extern "C"

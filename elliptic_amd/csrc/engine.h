@@ -459,7 +459,7 @@ class Engine {
 
   void* grow(Buf& b, size_t bytes) {
     if (bytes <= b.cap) return b.p;
-    if (b.p) { bk.sync(); bk.free_(b.p); b.p = nullptr; b.cap = 0; }
+    if (b.p) { bk.sync_all(); bk.free_(b.p); b.p = nullptr; b.cap = 0; }
     size_t want = bytes + bytes / 8;
     b.p = bk.alloc(want);
     if (!b.p) { b.p = bk.alloc(bytes); want = bytes; }

@@ -72,9 +72,13 @@ struct Fe {
 // when a_i * b_j >= 2^64 - 2^36 -- never for random operands, always possible for chosen ones
 // (limbs of 2^32 - 1).  The carry-out masks are OR-ed on the scalar unit instead, and a wave in
 // which any lane did overflow redoes the product with the all-carries chain (a uniform branch,
-// taken with probability ~2^-21 per product).  15 of 64 (8 limbs) carry additions less.
+// taken with probability ~2^-21 per product).  15 of 64 (8 limbs) carry additions less -- and
+// MEASURED SLOWER (round 2, same box: field mul 149.5 -> 153.5 issue units at 3 waves/SIMD,
+// ecdsa_main 8.57 -> 8.77 ms): the scalar ORs and the per-product scalar branch cost the wave
+// more issue turns than the 15 v_addc they replace (an instruction of ANY kind costs a wave of
+// this kernel ~4.3 cycles of SIMD time).  Kept as a build switch, off.
 #ifndef ELL_MUL_FAST
-#define ELL_MUL_FAST 1
+#define ELL_MUL_FAST 0
 #endif
 template <int L>
 ELL_HD void fe_mul_wide_plain(u32 (&r)[2 * L], const u32 (&a)[L], const u32 (&b)[L]) {

@@ -52,10 +52,33 @@ struct HipBackend {
   bool timing = false;             // record HIP events around every launch
   std::vector<TimedLaunch>* timed = nullptr;
 
+  // The scratch arena (window tables, Jacobian results, batch-inversion prefixes ...) belongs to
+  // the context, not to a stream, and the *_dev entry points return without synchronising: a call
+  // on another stream than the previous one first waits (on the device) for the event the
+  // previous call recorded after its last launch.  Host-buffer calls synchronise before they
+  // return, so nothing is left in flight behind them.
+  hipStream_t inflight = nullptr;  // stream of the last call that may still be running
+  hipEvent_t inflight_done = nullptr;
   void use_stream(void* s) {
     (void)hipSetDevice(device);
     cur = s ? (hipStream_t)s : own;
     last = 0;
+    if (inflight && inflight != cur && inflight_done) note(hipStreamWaitEvent(cur, inflight_done, 0));
+  }
+  // end of an entry point: `async` = the call returned without synchronising `cur`
+  void end_call(bool async) {
+    if (async && inflight_done) {
+      note(hipEventRecord(inflight_done, cur));
+      inflight = cur;
+    } else {
+      inflight = nullptr;
+    }
+  }
+  // everything this context may have in flight, on whatever stream (before freeing scratch)
+  void sync_all() {
+    if (inflight) note(hipStreamSynchronize(inflight));
+    inflight = nullptr;
+    note(hipStreamSynchronize(cur ? cur : own));
   }
   void note(hipError_t e) {
     if (e != hipSuccess && !last) last = (int)e;

@@ -155,8 +155,20 @@ struct Ladder {
   // tbl[s*8 + (|d|-1)/2] affine, point s negated when bit s of negmask is set; afterwards
   // P_s is subtracted once where bit s of evenmask is set (k_s had been made odd by +1).
   template <int NS, int NW>
-  ELL_HD static J run_odd_w4(const DigitStore& ds, const A* tbl, u32 negmask, u32 evenmask) {
-    J acc = G::infinity();
+  ELL_HD static J run_odd_w4(const DigitStore& ds, const A* tbl, u32 negmask, u32 evenmask, bool& inf) {
+    // table entry for digit string s at window w (digits are odd and non-zero); a function of
+    // (w, s) only, so that the additions' rarely taken branch can fetch it again
+    auto entry = [&](int w, int s) -> A {
+      int d = ds.get(w * NS + s);
+      int ad = d < 0 ? -d : d;
+      bool neg = (d < 0) != (((negmask >> s) & 1u) != 0);
+      A q = tbl[s * 8 + ((ad - 1) >> 1)];
+      q.y = fe_select<F>(neg, F::neg(q.y), q.y);
+      return q;
+    };
+    // top window, first string: acc = the entry itself (no addition into O)
+    J acc = G::from_affine(entry(NW - 1, 0));
+    inf = false;
     ELL_NOUNROLL
     for (int w = NW - 1; w >= 0; w--) {
       if (w != NW - 1) {
@@ -164,21 +176,19 @@ struct Ladder {
         for (int j = 0; j < 4; j++) acc = G::dbl(acc);
       }
       ELL_NOUNROLL
-      for (int s = 0; s < NS; s++) {
-        int d = ds.get(w * NS + s);
-        int ad = d < 0 ? -d : d;
-        bool neg = (d < 0) != (((negmask >> s) & 1u) != 0);
-        A q = tbl[s * 8 + ((ad - 1) >> 1)];
-        q.y = fe_select<F>(neg, F::neg(q.y), q.y);
-        acc = G::add_mixed(acc, q);
-      }
+      for (int s = (w == NW - 1 ? 1 : 0); s < NS; s++)
+        acc = G::add_mixed_lean(acc, entry(w, s), inf, [&]() { return entry(w, s); });
     }
     ELL_NOUNROLL
     for (int s = 0; s < NS; s++) {
-      A q = tbl[s * 8];
-      bool neg = ((negmask >> s) & 1u) == 0;          // subtract sign_s * P_s
-      q.y = fe_select<F>(neg, F::neg(q.y), q.y);
-      acc = G::add_mixed(acc, q, ((evenmask >> s) & 1u) != 0);
+      auto corr = [&]() -> A {
+        A q = tbl[s * 8];
+        bool neg = ((negmask >> s) & 1u) == 0;        // subtract sign_s * P_s
+        q.y = fe_select<F>(neg, F::neg(q.y), q.y);
+        return q;
+      };
+      // per-lane condition: lanes without the correction sit the addition out (exec mask)
+      if (((evenmask >> s) & 1u) != 0) acc = G::add_mixed_lean(acc, corr(), inf, corr);
     }
     return acc;
   }
@@ -208,25 +218,31 @@ struct Ladder {
     return acc;
   }
 
-  // fixed-base comb: sum_w d_w * 2^(CB*w) * G with d_w the w-th CB-bit digit of k (CB = 8
-  // or 16); comb[w*(2^CB - 1) + d-1] = d * 2^(CB*w) * G (affine, field-internal form).
+  // fixed-base comb: acc + sum_w d_w * 2^(CB*w) * G with d_w the w-th CB-bit digit of k (CB = 8
+  // or 16); comb[w*(2^CB - 1) + d-1] = d * 2^(CB*w) * G (affine, field-internal form).  Zero
+  // digits sit the addition out (exec mask).  `inf` = acc is O, updated.
   template <int LK, int W, int CB>
-  ELL_HD static J comb_mul(const u32 (&k)[LK], const A* comb) {
+  ELL_HD static J comb_add(J acc, bool& inf, const u32 (&k)[LK], const A* comb) {
     constexpr u32 MASK = (1u << CB) - 1u;
     u32 kk[LK];
     bn_copy<LK>(kk, k);
-    J acc = G::infinity();
     ELL_NOUNROLL
     for (int w = 0; w < W; w++) {
       u32 d = kk[0] & MASK;
       ELL_UNROLL
       for (int i = 0; i < LK - 1; i++) kk[i] = (kk[i] >> CB) | (kk[i + 1] << (32 - CB));
       kk[LK - 1] >>= CB;
-      u32 e = d ? d - 1 : 0;
-      A q = comb[(size_t)w * MASK + e];
-      acc = G::add_mixed(acc, q, d != 0);
+      if (d != 0) {
+        const A* e = comb + ((size_t)w * MASK + (d - 1));
+        acc = G::add_mixed_lean(acc, *e, inf, [&]() { return *e; });
+      }
     }
     return acc;
+  }
+  template <int LK, int W, int CB>
+  ELL_HD static J comb_mul(const u32 (&k)[LK], const A* comb) {
+    bool inf = true;
+    return comb_add<LK, W, CB>(G::infinity(), inf, k, comb);
   }
 };
 

@@ -65,19 +65,17 @@ struct ShortOps {
   ELL_HD static J dbl(const J& p) {
     J r;
     if (CV::A_KIND == 0) {
-      // dbl-2009-l, a = 0: 2M + 5S
-      El a = F::sqr(p.X);
+      // dbl-2009-l, a = 0: 2M + 5S.  Statement order = shortest live ranges (Y and Z die
+      // first, then X): at most five field elements are live next to a product's own words.
       El b = F::sqr(p.Y);
-      El c = F::sqr(b);
-      El t = F::sqr(F::add(p.X, b));
-      t = F::sub(F::sub(t, a), c);
-      El d = F::template mul_pow2<1>(t);
-      El e = F::add(F::template mul_pow2<1>(a), a);
-      El f = F::sqr(e);
-      r.X = F::sub(f, F::template mul_pow2<1>(d));
-      El c8 = F::template mul_pow2<3>(c);
       r.Z = F::template mul_pow2<1>(F::mul(p.Y, p.Z));
-      r.Y = F::sub(F::mul(e, F::sub(d, r.X)), c8);
+      El a = F::sqr(p.X);
+      El t = F::sub(F::sqr(F::add(p.X, b)), a);
+      El c = F::sqr(b);
+      El d = F::template mul_pow2<1>(F::sub(t, c));
+      El e = F::add(F::template mul_pow2<1>(a), a);
+      r.X = F::sub(F::sqr(e), F::template mul_pow2<1>(d));
+      r.Y = F::sub(F::mul(e, F::sub(d, r.X)), F::template mul_pow2<3>(c));
     } else {
       // dbl-2001-b, a = -3: 3M + 5S
       El delta = F::sqr(p.Z);
@@ -119,6 +117,41 @@ struct ShortOps {
       r = select(pinf, from_affine(q), r);                       // O + Q = Q  (P == -Q keeps Z3 = 0)
     }
     return select(do_add, r, p);
+  }
+
+  // P + Q for the ladders' inner loops, Q affine and finite.  Same formulas as add_mixed; what
+  // differs is how the exceptional inputs are paid for.  add_mixed decides P = O / P = Q / P = -Q
+  // from p, q and h at the end of the addition, which keeps all of them live through it (32 more
+  // registers than the arithmetic needs).  Here the caller carries "P is O" as a flag (`pinf`,
+  // updated on return -- an addition is the only step of a ladder that can produce or leave O),
+  // Z3 = Z1 * h == 0 then means h == 0 exactly when the flag is clear, and all three exceptional
+  // results depend on Q alone (Q, 2Q, O), which the rarely taken branch fetches again through
+  // `reload` instead of holding it.  Statement order = shortest live ranges.
+  template <class Reload>
+  ELL_HD static J add_mixed_lean(const J& p, const A& q, bool& pinf, const Reload& reload) {
+    El z1z1 = F::sqr(p.Z);
+    El u2 = F::mul(q.x, z1z1);
+    El s2 = F::mul(q.y, F::mul(p.Z, z1z1));
+    El h = F::sub(u2, p.X);
+    J r;
+    r.Z = F::mul(p.Z, h);
+    El rr = F::sub(s2, p.Y);
+    El hh = F::sqr(h);
+    El hhh = F::mul(h, hh);
+    El v = F::mul(p.X, hh);
+    r.X = F::sub(F::sub(F::sqr(rr), hhh), F::template mul_pow2<1>(v));
+    El yh = F::mul(p.Y, hhh);
+    r.Y = F::sub(F::mul(rr, F::sub(v, r.X)), yh);
+    bool z = F::is_zero(r.Z);
+    if (ELL_UNLIKELY(z)) {
+      const A qq = reload();
+      const bool same = !pinf && F::is_zero(rr);                 // h == 0 and rr == 0: P == Q
+      if (pinf) r = from_affine(qq);                              // O + Q = Q
+      else if (same) r = dbl(from_affine(qq));                    // (P == -Q keeps Z3 = 0)
+      z = F::is_zero(r.Z);
+    }
+    pinf = z;
+    return r;
   }
 
   // P + Q for table building: no exceptional cases are possible (P = j*Q0, Q = 2*Q0 on a

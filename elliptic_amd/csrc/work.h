@@ -133,7 +133,7 @@ struct Work {
   // k*P for one (k, P), result in true Jacobian coordinates.  secp256k1: GLV split, odd
   // signed digits, effective-affine tables of P and lambda*P (mixed adds only); other
   // curves: odd signed digits over an affine table of the odd multiples.
-  ELL_HD static J var_ladder(const u32 (&k)[L], const A& p, VT* tbl, const DigitStore& ds) {
+  ELL_HD static J var_ladder(const u32 (&k)[L], const A& p, VT* tbl, const DigitStore& ds, bool& inf) {
     if constexpr (ENDO) {
       u32 k1[5], k2[5];
       bool n1, n2;
@@ -157,7 +157,7 @@ struct Work {
         t.x = F::mul(t.x, beta);
         tbl[8 + e] = t;
       }
-      J r = LD::template run_odd_w4<2, NNIB>(ds, tbl, negmask, evenmask);
+      J r = LD::template run_odd_w4<2, NNIB>(ds, tbl, negmask, evenmask, inf);
       r.Z = F::mul(r.Z, zg);
       return r;
     } else if constexpr (L > 12 && ELL_P521_JTABLE) {
@@ -166,7 +166,9 @@ struct Work {
       static_assert(16 * sizeof(A) >= 8 * sizeof(J), "table slot too small");
       u32 negmask = 0;
       prepare_var(k, p, ds, 0, NSV, (J*)tbl, negmask);
-      return LD::template run_w4<NSV, NWIN>(ds, (const J*)tbl, negmask);
+      J r = LD::template run_w4<NSV, NWIN>(ds, (const J*)tbl, negmask);
+      inf = G::is_inf(r);
+      return r;
     } else {
       // no endomorphism: the same odd-digit ladder over the full-width scalar.  The table is
       // built on the isomorphic curves (additions do not involve a) and mapped back to the
@@ -189,7 +191,7 @@ struct Work {
         t.y = F::mul(t.y, zi3);
         tbl[e] = t;
       }
-      return LD::template run_odd_w4<1, NWIN>(ds, tbl, 0u, evenmask);
+      return LD::template run_odd_w4<1, NWIN>(ds, tbl, 0u, evenmask, inf);
     }
   }
 
@@ -200,7 +202,8 @@ struct Work {
     u32 k[L];
     load_be<L>(k, ks + i * BYTES, BYTES);
     A p = load_affine(xy, i);
-    J r = var_ladder(k, p, tbl_all + i * TBL1, ds);
+    bool inf;
+    J r = var_ladder(k, p, tbl_all + i * TBL1, ds, inf);
     store_jac(jac, n, i, r);
   }
 
@@ -221,13 +224,13 @@ struct Work {
     store_jac(jac, n, i, r);
   }
 
-  // k1*G + k2*P2 -> Jacobian (the shape ECDSA verify uses): comb for G, window
-  // ladder for P2, one final Jacobian add
+  // k1*G + k2*P2 -> Jacobian (the shape ECDSA verify uses): window ladder for P2, then the
+  // comb's mixed additions for G onto the same accumulator (no second point, no Jacobian add)
   ELL_HD static J mul_add_g(const u32 (&k1)[L], const u32 (&k2)[L], const A& p2, const A* comb,
                             VT* tbl, const DigitStore& ds) {
-    J b = var_ladder(k2, p2, tbl, ds);
-    J a = LD::template comb_mul<L, COMB_W, COMB_BITS>(k1, comb);
-    return G::add(a, b);
+    bool inf;
+    J b = var_ladder(k2, p2, tbl, ds, inf);
+    return LD::template comb_add<L, COMB_W, COMB_BITS>(b, inf, k1, comb);
   }
   ELL_HD static void mul_add_g_item(size_t i, size_t n, const u8* k1s, const u8* k2s,
                                     const u8* xy2, const A* comb, VT* tbl_all,

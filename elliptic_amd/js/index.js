@@ -281,20 +281,41 @@ function install(elliptic, options) {
   var BN = elliptic.curves.secp256k1.curve.p.constructor;
   var addon = eng.addon;
 
-  // preset lookup: a curve object is in the engine's domain iff its
-  // (type, p, generator) equal one of the reference's presets
+  // preset lookup: a curve object is in the engine's domain iff its type, p, coefficients,
+  // generator AND order equal one of the reference's presets (the engine's fixed-base tables,
+  // GLV constants and scalar field belong to the preset's G and n: a curve over a preset field
+  // with another generator -- or without one -- is passed through to the reference's own code)
   var presets = {};
   CURVES.forEach(function(name) {
     var c = elliptic.curves[name].curve;
     presets[c.type + ':' + c.p.toString(16)] = { name: name, id: addon.curveId(name),
       B: addon.fieldBytes(addon.curveId(name)), g: c.g };
   });
+  // affine coordinates of a generator as plain BNs, without touching the point object
+  function genCoords(curve, g) {
+    if (curve.type === 'short') return g.inf ? null : [g.x.fromRed(), g.y.fromRed()];
+    if (curve.type === 'edwards') {
+      var q = curve.point(g.x, g.y, g.z, g.t);        // clone: getX() normalizes in place
+      return [q.getX(), q.getY()];
+    }
+    var m = curve.point(g.x, g.z);
+    return m.isInfinity() ? null : [m.getX()];
+  }
+  function sameGenerator(curve, ref) {
+    if (!curve.g || !curve.n || !ref.n || curve.n.cmp(ref.n) !== 0) return false;
+    var a = genCoords(curve, curve.g), b = genCoords(ref, ref.g);
+    if (!a || !b || a.length !== b.length) return false;
+    for (var i = 0; i < a.length; i++) if (a[i].cmp(b[i]) !== 0) return false;
+    return true;
+  }
   function domain(curve) {
     if (curve._ellgpu !== undefined) return curve._ellgpu;
     var d = presets[curve.type + ':' + curve.p.toString(16)] || null;
+    // (methods of a curve under construction -- ShortCurve#_getEndomorphism multiplies g before
+    // the constructor returns -- see every field this test reads: p, n, g, a, b are set first)
     if (d && curve.type === 'short') {
       var ref = elliptic.curves[d.name].curve;
-      if (curve.a.fromRed().cmp(ref.a.fromRed()) !== 0 ||
+      if (!curve.a || !curve.b || curve.a.fromRed().cmp(ref.a.fromRed()) !== 0 ||
           curve.b.fromRed().cmp(ref.b.fromRed()) !== 0) d = null;
     } else if (d && curve.type === 'edwards') {
       var re = elliptic.curves[d.name].curve;
@@ -304,6 +325,7 @@ function install(elliptic, options) {
       if (curve.a.fromRed().cmp(elliptic.curves[d.name].curve.a.fromRed()) !== 0)
         d = null;
     }
+    if (d && !sameGenerator(curve, elliptic.curves[d.name].curve)) d = null;
     Object.defineProperty(curve, '_ellgpu', { value: d, enumerable: false,
       writable: true });
     return d;

@@ -90,6 +90,19 @@ def test_patched_api_matches_goldens_including_exception_messages():
     _run_replay(build_hostsim())
 
 
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_custom_generator_curves_pass_through():
+    """a curve over a preset's field with ANOTHER generator (or none) must not reach the engine,
+    whose tables belong to the preset's G and n: results equal the unpatched reference"""
+    _addon()
+    from hostsim.build import build as build_hostsim
+    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference(), ELLGPU_LIB=build_hostsim())
+    p = subprocess.run(["node", os.path.join(ROOT, "tools", "check_custom_generator.js")], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert json.loads(p.stdout.strip().splitlines()[-1])["checked"] >= 30
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
 def test_reference_suite_passes_with_install_patch_gpu():

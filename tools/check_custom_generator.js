@@ -1,0 +1,59 @@
+'use strict';
+// install() must leave curves that only SHARE a preset's field to the reference's own code:
+// same p, a, b as secp256k1 / p256 / ed25519 but another generator (or none at all).  The
+// patched library's results are compared with an unpatched copy of the reference.
+//   ELLGPU_LIB=<hostsim or real library> node tools/check_custom_generator.js
+var loader = require('./ref_loader');
+var plain = loader.load().elliptic;          // unpatched
+var patched = loader.load().elliptic;        // a second, independent copy -> patched
+var eng = require('../elliptic_amd/js').install(patched, { libPath: process.env.ELLGPU_LIB });
+var BN = plain.curves.secp256k1.curve.p.constructor;
+var checked = 0;
+
+function same(a, b, what) {
+  if (a.isInfinity() !== b.isInfinity()) throw new Error(what + ': infinity differs');
+  if (!a.isInfinity() && (a.getX().cmp(b.getX()) !== 0 || a.getY().cmp(b.getY()) !== 0))
+    throw new Error(what + ': ' + a.getX().toString(16) + ' != ' + b.getX().toString(16));
+  checked++;
+}
+
+['secp256k1', 'p256'].forEach(function(name) {
+  var ref = plain.curves[name].curve;
+  var g2 = ref.g.mul(new BN(2));
+  function build(lib, withG) {
+    var conf = { p: ref.p.toString(16), a: ref.a.fromRed().toString(16), b: ref.b.fromRed().toString(16),
+      n: ref.n.toString(16) };
+    if (withG) conf.g = [ g2.getX().toString(16), g2.getY().toString(16) ];
+    return new lib.curve.short(conf);
+  }
+  var before = eng.stats.gpuCalls;
+  var cp = build(plain, true), cq = build(patched, true);
+  [ '1', '2', 'deadbeef', ref.n.subn(1).toString(16), ref.n.toString(16),
+    'ab54a98ceb1f0ad2ab54a98ceb1f0ad2ab54a98ceb1f0ad2ab54a98ceb1f0ad2' ].forEach(function(k) {
+    same(cq.g.mul(new BN(k, 16)), cp.g.mul(new BN(k, 16)), name + ' custom g * ' + k);
+    same(cq.g.mulAdd(new BN(k, 16), cq.g.dbl(), new BN(7)), cp.g.mulAdd(new BN(k, 16), cp.g.dbl(), new BN(7)),
+      name + ' custom mulAdd ' + k);
+  });
+  // ECDSA over the custom generator: sign with the patched library, verify with both
+  var ecq = new patched.ec({ curve: { curve: cq, g: cq.g, n: cq.n, hash: patched.curves[name].hash } });
+  var ecp = new plain.ec({ curve: { curve: cp, g: cp.g, n: cp.n, hash: plain.curves[name].hash } });
+  var key = ecq.keyFromPrivate('1234567890abcdef1234567890abcdef1234567890abcdef1234567890abcdef', 'hex');
+  var msg = new BN('7777777777777777777777777777777777777777777777777777777777777777', 16);
+  var sig = ecq.sign(msg, key);
+  var pub = key.getPublic();
+  if (!ecq.verify(msg, sig, pub)) throw new Error(name + ': patched verify of its own signature');
+  var pubp = ecp.keyFromPublic({ x: pub.getX().toString(16), y: pub.getY().toString(16) });
+  if (!ecp.verify(msg, { r: sig.r.toString(16), s: sig.s.toString(16) }, pubp))
+    throw new Error(name + ': the reference rejects the patched library\'s signature');
+  checked += 2;
+  // a curve without a generator: arbitrary points still multiply (no TypeError on curve.g.x)
+  var np = build(plain, false), nq = build(patched, false);
+  var x = ref.g.getX().toString(16), y = ref.g.getY().toString(16);
+  same(nq.point(x, y).mul(new BN('c0ffee', 16)), np.point(x, y).mul(new BN('c0ffee', 16)), name + ' no generator');
+  if (eng.stats.gpuCalls !== before) throw new Error(name + ': a custom-generator curve reached the engine');
+});
+// the presets themselves still go to the engine
+var b0 = eng.stats.gpuCalls;
+same(patched.curves.secp256k1.curve.g.mul(new BN(5)), plain.curves.secp256k1.curve.g.mul(new BN(5)), 'preset');
+if (eng.stats.gpuCalls === b0) throw new Error('the preset did not reach the engine');
+console.log(JSON.stringify({ ok: true, checked: checked, engine: eng.stats }));

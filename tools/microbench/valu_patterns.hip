@@ -138,6 +138,65 @@ __global__ void __launch_bounds__(64) k(u32* out, int iters, u32 seed) {
           "v_lshrrev_b64 %0, 3, %0\n v_lshrrev_b64 %1, 3, %1\n v_lshrrev_b64 %2, 3, %2\n v_lshrrev_b64 %3, 3, %3\n"
           "v_lshrrev_b64 %4, 3, %4\n v_lshrrev_b64 %5, 3, %5\n v_lshrrev_b64 %6, 3, %6\n v_lshrrev_b64 %7, 3, %7\n")
           : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7));
+    } else if (P == 16) {  // 8 independent SIGNED mads (v_mad_i64_i32), carry-out to a dummy SGPR pair
+      asm volatile(REP4(
+          "v_mad_i64_i32 %0, s[20:21], %8, %9, %0\n v_mad_i64_i32 %1, s[20:21], %8, %9, %1\n"
+          "v_mad_i64_i32 %2, s[20:21], %8, %9, %2\n v_mad_i64_i32 %3, s[20:21], %8, %9, %3\n"
+          "v_mad_i64_i32 %4, s[20:21], %8, %9, %4\n v_mad_i64_i32 %5, s[20:21], %8, %9, %5\n"
+          "v_mad_i64_i32 %6, s[20:21], %8, %9, %6\n v_mad_i64_i32 %7, s[20:21], %8, %9, %7\n")
+          : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7)
+          : "v"(a), "v"(b) : "s20", "s21");
+    } else if (P == 17) {  // 8 independent unsigned mads, carry-out to VCC
+      asm volatile(REP4(
+          "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n"
+          "v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+          "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n"
+          "v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n")
+          : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7)
+          : "v"(a), "v"(b) : "vcc");
+    } else if (P == 18) {  // ONE dependent chain of unsigned mads (every mad reads the previous result)
+      asm volatile(REP4(
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %0, s[20:21], %9, %8, %0\n"
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %0, s[20:21], %9, %8, %0\n"
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %0, s[20:21], %9, %8, %0\n"
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %0, s[20:21], %9, %8, %0\n")
+          : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7)
+          : "v"(a), "v"(b) : "s20", "s21");
+    } else if (P == 19) {  // TWO interleaved dependent chains
+      asm volatile(REP4(
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %1, s[20:21], %9, %8, %1\n"
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %1, s[20:21], %9, %8, %1\n"
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %1, s[20:21], %9, %8, %1\n"
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %1, s[20:21], %9, %8, %1\n")
+          : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7)
+          : "v"(a), "v"(b) : "s20", "s21");
+    } else if (P == 20) {  // 8 independent 64-bit arithmetic right shifts
+      asm volatile(REP4(
+          "v_ashrrev_i64 %0, 3, %0\n v_ashrrev_i64 %1, 3, %1\n v_ashrrev_i64 %2, 3, %2\n v_ashrrev_i64 %3, 3, %3\n"
+          "v_ashrrev_i64 %4, 3, %4\n v_ashrrev_i64 %5, 3, %5\n v_ashrrev_i64 %6, 3, %6\n v_ashrrev_i64 %7, 3, %7\n")
+          : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7));
+    } else if (P == 21) {  // the unsaturated column pattern: two mad chains, a 64-bit shift and a mask per 6 mads
+      asm volatile(REP4(
+          "v_mad_i64_i32 %0, s[20:21], %8, %9, %0\n v_mad_i64_i32 %1, s[20:21], %9, %8, %1\n"
+          "v_mad_i64_i32 %0, s[20:21], %8, %9, %0\n v_mad_i64_i32 %1, s[20:21], %9, %8, %1\n"
+          "v_mad_i64_i32 %0, s[20:21], %8, %9, %0\n v_mad_i64_i32 %1, s[20:21], %9, %8, %1\n"
+          "v_and_b32 %10, 0x1fffffff, %8\n v_ashrrev_i64 %0, 29, %0\n")
+          : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7), "+v"(a), "+v"(b), "+v"(e0)
+          : : "s20", "s21");
+    } else if (P == 22) {  // same with unsigned mads and a logical shift
+      asm volatile(REP4(
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %1, s[20:21], %9, %8, %1\n"
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %1, s[20:21], %9, %8, %1\n"
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %1, s[20:21], %9, %8, %1\n"
+          "v_and_b32 %10, 0x1fffffff, %8\n v_lshrrev_b64 %0, 29, %0\n")
+          : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7), "+v"(a), "+v"(b), "+v"(e0)
+          : : "s20", "s21");
+    } else if (P == 23) {  // 4 mads + 4 plain adds interleaved (does a cheap op hide behind a multiply?)
+      asm volatile(REP4(
+          "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_add_u32 %10, %8, %10\n v_mad_u64_u32 %1, s[20:21], %8, %9, %1\n v_add_u32 %11, %8, %11\n"
+          "v_mad_u64_u32 %2, s[20:21], %8, %9, %2\n v_add_u32 %12, %8, %12\n v_mad_u64_u32 %3, s[20:21], %8, %9, %3\n v_add_u32 %13, %8, %13\n")
+          : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7), "+v"(a), "+v"(b), "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3)
+          : : "s20", "s21");
     } else if (P == 7) {   // 8 independent mads whose 64-bit accumulators sit in the same VGPR bank pattern as a, b
       asm volatile(REP4(
           "v_mad_u64_u32 %0, s[20:21], %8, %9, 0\n v_mad_u64_u32 %1, s[20:21], %8, %9, 0\n"
@@ -171,15 +230,18 @@ int main() {
   u32* out;
   hipMalloc(&out, 1024 * 16 * 64 * 4);
   const int iters = 20000;
-  const int ninstr[16] = {0, 32, 32, 32, 32, 64, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32};   // VALU instructions per loop iteration
-  const char* name[16] = {"", "mad vgpr*vgpr+acc", "mad vgpr*sgpr+acc", "v_add_u32", "v_addc e64 (sgpr carry)",
+  const int ninstr[24] = {0, 32, 32, 32, 32, 64, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32};   // VALU instructions per loop iteration
+  const char* name[24] = {"", "mad vgpr*vgpr+acc", "mad vgpr*sgpr+acc", "v_add_u32", "v_addc e64 (sgpr carry)",
                           "product pattern (mad+addc)", "vcc chain + s_nop 1", "mad vgpr*vgpr+0",
                           "single-chain mad+addc", "v_mov_b32", "v_alignbit_b32", "v_cndmask e64 (sgpr mask)",
-                          "v_cndmask e32 (vcc)", "v_add_co (carry out only)", "v_lshl_add_u64", "v_lshrrev_b64"};
+                          "v_cndmask e32 (vcc)", "v_add_co (carry out only)", "v_lshl_add_u64", "v_lshrrev_b64",
+                          "v_mad_i64_i32 (signed)", "mad, carry-out to vcc", "ONE dependent mad chain", "TWO dependent mad chains",
+                          "v_ashrrev_i64", "unsat column (6 signed mads + and + ashr64)", "unsat column (6 unsigned mads + and + lshr64)",
+                          "4 mads + 4 v_add_u32 interleaved"};
   int dev_clock_khz = 0;
   hipDeviceGetAttribute(&dev_clock_khz, hipDeviceAttributeClockRate, 0);
   printf("clock attribute %d kHz\n", dev_clock_khz);
-  for (int p = 1; p <= 15; p++) {
+  for (int p = 1; p <= 23; p++) {
     printf("%-30s ns per wave-instruction per SIMD at 1,2,3,4,8 waves:", name[p]);
     for (int w : {1, 2, 3, 4, 8}) {
       double ms = 0;
@@ -199,6 +261,14 @@ int main() {
         case 13: ms = run<13>(w, iters, out); break;
         case 14: ms = run<14>(w, iters, out); break;
         case 15: ms = run<15>(w, iters, out); break;
+        case 16: ms = run<16>(w, iters, out); break;
+        case 17: ms = run<17>(w, iters, out); break;
+        case 18: ms = run<18>(w, iters, out); break;
+        case 19: ms = run<19>(w, iters, out); break;
+        case 20: ms = run<20>(w, iters, out); break;
+        case 21: ms = run<21>(w, iters, out); break;
+        case 22: ms = run<22>(w, iters, out); break;
+        case 23: ms = run<23>(w, iters, out); break;
       }
       double per = ms * 1e6 / ((double)iters * ninstr[p] * w);   // ns of SIMD time per instruction
       printf(" %.3f", per);
