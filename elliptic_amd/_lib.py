@@ -21,6 +21,8 @@ _SIGS = {
     "ellgpu_curve_order_bytes": (ctypes.c_int, [ctypes.c_int]),
     "ellgpu_device_count": (ctypes.c_int, []),
     "ellgpu_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "ellgpu_group_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "ellgpu_group_size": (ctypes.c_int, [ctypes.c_void_p]),
     "ellgpu_ctx_destroy": (None, [ctypes.c_void_p]),
     "ellgpu_ctx_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
     "ellgpu_ctx_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]),

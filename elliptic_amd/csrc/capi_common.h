@@ -12,8 +12,19 @@
 #include "../../include/ellgpu.h"
 #include "engine.h"
 
+#include <thread>
+#include <vector>
+
+// A context owns one engine on one device.  A GROUP (ellgpu_group_create) is a context whose
+// `members` are ordinary contexts, one per listed device: the host-buffer scalar-multiplication
+// and verify entry points cut a batch into contiguous shards, one host thread per member drives
+// its device (its own streams, scratch arena and replicated tables), and every member copies its
+// results straight into the caller's buffers -- no device-to-device traffic at all (SURVEY.md 8e:
+// "a direct per-device D2H is the zero-collective alternative").  Any other entry point called on
+// a group runs on member 0.
 struct ellgpu_ctx {
   ell::Engine<ELL_BACKEND>* eng;
+  std::vector<ellgpu_ctx*> members;
 };
 
 static thread_local std::string g_last_error;
@@ -63,8 +74,59 @@ int ellgpu_ctx_create(int device, ellgpu_ctx** out) {
   *out = c;
   return ELLGPU_OK;
 }
+int ellgpu_group_create(const int* devices, int ndev, ellgpu_ctx** out) {
+  if (!out) return set_err(ELLGPU_E_ARG, "null out pointer");
+  *out = nullptr;
+  if (!devices || ndev < 1 || ndev > 64) return set_err(ELLGPU_E_ARG, "ellgpu_group_create: 1..64 devices");
+  ellgpu_ctx* g = new ellgpu_ctx;
+  g->eng = nullptr;
+  for (int i = 0; i < ndev; i++) {
+    ellgpu_ctx* m = nullptr;
+    int rc = ellgpu_ctx_create(devices[i], &m);
+    if (rc) {
+      for (ellgpu_ctx* x : g->members) ellgpu_ctx_destroy(x);
+      delete g;
+      return rc;                                    // message already set by ellgpu_ctx_create
+    }
+    g->members.push_back(m);
+  }
+  g->eng = g->members[0]->eng;                      // borrowed: entry points without a sharded form
+  *out = g;
+  return ELLGPU_OK;
+}
+int ellgpu_group_size(const ellgpu_ctx* ctx) {
+  if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  return ctx->members.empty() ? 1 : (int)ctx->members.size();
+}
+}  // extern "C"
+// run f(member, lo, hi) for the contiguous shard of every member on its own host thread
+template <class Fn>
+static int group_shard(ellgpu_ctx* g, size_t n, Fn f) {
+  const size_t m = g->members.size();
+  std::vector<int> rc(m, 0);
+  std::vector<std::string> msg(m);
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < m; i++) {
+    const size_t lo = n * i / m, hi = n * (i + 1) / m;
+    th.emplace_back([&, i, lo, hi]() {
+      rc[i] = lo < hi ? f(g->members[i], lo, hi) : 0;
+      if (rc[i]) msg[i] = g_last_error;             // the worker's thread-local message
+    });
+  }
+  for (auto& t : th) t.join();
+  for (size_t i = 0; i < m; i++)
+    if (rc[i]) return set_err(rc[i], "device shard " + std::to_string(i) + ": " + msg[i]);
+  return ELLGPU_OK;
+}
+extern "C" {
+
 void ellgpu_ctx_destroy(ellgpu_ctx* ctx) {
   if (!ctx) return;
+  if (!ctx->members.empty()) {
+    for (ellgpu_ctx* m : ctx->members) ellgpu_ctx_destroy(m);
+    delete ctx;
+    return;
+  }
   ctx->eng->bk.sync();
   ELL_BACKEND bk = ctx->eng->bk;
   delete ctx->eng;
@@ -86,24 +148,65 @@ int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n) {
   ctx->eng->err.clear();                                            \
   ctx->eng->bk.use_stream(stream);
 
+// byte widths of a curve's field elements and scalars (for slicing the flat buffers of a group call)
+static int curve_widths(int curve, size_t& B, size_t& NB) {
+  const ell::CurveInfo* ci = ell::curve_info(curve);
+  if (!ci) return set_err(ELLGPU_E_ARG, "unknown curve id");
+  B = (size_t)ci->field_bytes;
+  NB = (size_t)ci->order_bytes;
+  return 0;
+}
+
 int ellgpu_mul_fixed(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, uint8_t* out_xy,
                      uint8_t* out_inf) {
+  if (ctx && !ctx->members.empty()) {
+    size_t B, NB;
+    if (curve_widths(curve, B, NB)) return ELLGPU_E_ARG;
+    return group_shard(ctx, n, [=](ellgpu_ctx* m, size_t lo, size_t hi) {
+      return ellgpu_mul_fixed(m, curve, hi - lo, k + lo * B, out_xy + lo * 2 * B, out_inf ? out_inf + lo : nullptr);
+    });
+  }
   ELL_ENTER(ctx, nullptr);
   return finish(ctx, ctx->eng->mul_fixed_host(curve, n, k, out_xy, out_inf));
 }
 int ellgpu_mul_var(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, const uint8_t* in_xy,
                    uint8_t* out_xy, uint8_t* out_inf) {
+  if (ctx && !ctx->members.empty()) {
+    size_t B, NB;
+    if (curve_widths(curve, B, NB)) return ELLGPU_E_ARG;
+    if (!in_xy) return set_err(ELLGPU_E_ARG, "null point buffer");
+    return group_shard(ctx, n, [=](ellgpu_ctx* m, size_t lo, size_t hi) {
+      return ellgpu_mul_var(m, curve, hi - lo, k + lo * B, in_xy + lo * 2 * B, out_xy + lo * 2 * B,
+                            out_inf ? out_inf + lo : nullptr);
+    });
+  }
   ELL_ENTER(ctx, nullptr);
   return finish(ctx, ctx->eng->mul_var_host(curve, n, k, in_xy, out_xy, out_inf));
 }
 int ellgpu_mul_add2(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1, const uint8_t* p1_xy,
                     const uint8_t* k2, const uint8_t* p2_xy, uint8_t* out_xy, uint8_t* out_inf) {
+  if (ctx && !ctx->members.empty()) {
+    size_t B, NB;
+    if (curve_widths(curve, B, NB)) return ELLGPU_E_ARG;
+    return group_shard(ctx, n, [=](ellgpu_ctx* m, size_t lo, size_t hi) {
+      return ellgpu_mul_add2(m, curve, hi - lo, k1 + lo * B, p1_xy ? p1_xy + lo * 2 * B : nullptr, k2 + lo * B,
+                             p2_xy + lo * 2 * B, out_xy + lo * 2 * B, out_inf ? out_inf + lo : nullptr);
+    });
+  }
   ELL_ENTER(ctx, nullptr);
   return finish(ctx, ctx->eng->mul_add2_host(curve, n, k1, p1_xy, k2, p2_xy, out_xy, out_inf));
 }
 int ellgpu_ecdsa_verify(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
                         int msg_bits, const uint8_t* r, const uint8_t* s, const uint8_t* pub_xy,
                         uint8_t* out_ok) {
+  if (ctx && !ctx->members.empty()) {
+    size_t B, NB;
+    if (curve_widths(curve, B, NB)) return ELLGPU_E_ARG;
+    return group_shard(ctx, n, [=](ellgpu_ctx* m, size_t lo, size_t hi) {
+      return ellgpu_ecdsa_verify(m, curve, hi - lo, hash + lo * (size_t)hash_len, hash_len, msg_bits, r + lo * NB,
+                                 s + lo * NB, pub_xy + lo * 2 * B, out_ok + lo);
+    });
+  }
   ELL_ENTER(ctx, nullptr);
   return finish(ctx, ctx->eng->ecdsa_verify_host(curve, n, hash, hash_len, msg_bits, r, s, pub_xy,
                                                  out_ok));

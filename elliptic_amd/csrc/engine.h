@@ -838,6 +838,9 @@ class Engine {
   int eddsa_verify_host(size_t n, const u8* msgs, const u64* off, size_t msg_len, const u8* sigs,
                         const u8* pubs, u8* ok, u8* err) {
     if (n && (!sigs || !pubs || !ok)) return fail(E_ARG, "null pointer");
+    if (off)                       // len = off[i+1] - off[i] per item: offsets must not decrease
+      for (size_t i = 0; i < n; i++)
+        if (off[i] > off[i + 1]) return fail(E_ARG, "message offsets must be non-decreasing");
     size_t total = off ? (size_t)off[n] : n * msg_len;
     if (total && !msgs) return fail(E_ARG, "null message pointer");
     u8* dm = put(G_IN0, msgs ? msgs : (const u8*)"", total);
@@ -872,6 +875,9 @@ class Engine {
   int eddsa_sign_host(size_t n, const u8* secrets, const u8* msgs, const u64* off, size_t msg_len,
                       u8* sig, u8* pub) {
     if (n && (!secrets || !sig)) return fail(E_ARG, "null pointer");
+    if (off)                       // len = off[i+1] - off[i] per item: offsets must not decrease
+      for (size_t i = 0; i < n; i++)
+        if (off[i] > off[i + 1]) return fail(E_ARG, "message offsets must be non-decreasing");
     size_t total = off ? (size_t)off[n] : n * msg_len;
     if (total && !msgs) return fail(E_ARG, "null message pointer");
     u8* dm = put(G_IN0, msgs ? msgs : (const u8*)"", total);

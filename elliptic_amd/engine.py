@@ -48,13 +48,26 @@ def be_to_ints(arr):
 
 
 class Context:
-    def __init__(self, device=0, lib_path=None):
+    def __init__(self, device=0, lib_path=None, devices=None):
+        """device: one HIP ordinal; devices=[...]: a GROUP over several (ellgpu_group_create) --
+        mul_fixed / mul_var / mul_add2 / ecdsa_verify on host buffers are then sharded over the
+        devices, one host thread each, results copied straight into the caller's arrays"""
         self._lib = _lib.load(lib_path) if not hasattr(lib_path, "ellgpu_version") else lib_path
         self._ctx = ctypes.c_void_p()
-        rc = self._lib.ellgpu_ctx_create(int(device), ctypes.byref(self._ctx))
+        if devices is not None:
+            devs = [int(d) for d in devices]
+            arr = (ctypes.c_int * len(devs))(*devs)
+            rc = self._lib.ellgpu_group_create(arr, len(devs), ctypes.byref(self._ctx))
+            device = devs[0] if devs else 0
+        else:
+            rc = self._lib.ellgpu_ctx_create(int(device), ctypes.byref(self._ctx))
         if rc != 0:
             raise _lib.EllgpuError(rc, self._lib.ellgpu_last_error().decode())
         self.device = device
+        self.devices = list(devices) if devices is not None else [device]
+
+    def group_size(self):
+        return self._lib.ellgpu_group_size(self._ctx)
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx:
@@ -119,12 +132,12 @@ class Context:
         """k1*P1 + k2*P2; p1=None means P1 = G."""
         B = FIELD_BYTES[curve]
         k1 = _u8(k1, (-1, B))
-        k2 = _u8(k2, (-1, B))
-        p2 = _u8(p2, (-1, 2 * B))
         n = k1.shape[0]
+        k2 = _u8(k2, (n, B))
+        p2 = _u8(p2, (n, 2 * B))
         p1p = None
         if p1 is not None:
-            p1 = _u8(p1, (-1, 2 * B))
+            p1 = _u8(p1, (n, 2 * B))
             p1p = p1.ctypes.data
         out = np.zeros((n, 2 * B), np.uint8)
         inf = np.zeros(n, np.uint8)
@@ -139,9 +152,9 @@ class Context:
         if hashes.ndim != 2:
             raise ValueError("hashes must be (n, hash_len)")
         n, hash_len = hashes.shape
-        r = _u8(r, (-1, NB))
-        s = _u8(s, (-1, NB))
-        pub = _u8(pub, (-1, 2 * B))
+        r = _u8(r, (n, NB))                     # explicit row counts: a short array must not
+        s = _u8(s, (n, NB))                     # make the library read past a buffer
+        pub = _u8(pub, (n, 2 * B))
         ok = np.zeros(n, np.uint8)
         self._check(self._lib.ellgpu_ecdsa_verify(self._ctx, self._cid(curve), n, hashes.ctypes.data,
                                                   hash_len, int(msg_bits), r.ctypes.data,
@@ -329,6 +342,8 @@ class Context:
         err = np.zeros(n, np.uint8)
         if isinstance(msgs, np.ndarray) and msgs.ndim == 2:
             m = np.ascontiguousarray(msgs, np.uint8)
+            if m.shape[0] != n:
+                raise ValueError("msgs has %d rows for %d signatures" % (m.shape[0], n))
             off_p, mlen = None, m.shape[1]
         else:
             off = np.zeros(n + 1, np.uint64)
@@ -395,6 +410,8 @@ class Context:
         pub = np.zeros((n, 32), np.uint8)
         if isinstance(msgs, np.ndarray) and msgs.ndim == 2:
             m = np.ascontiguousarray(msgs, np.uint8)
+            if m.shape[0] != n:
+                raise ValueError("msgs has %d rows for %d signatures" % (m.shape[0], n))
             off_p, mlen = None, m.shape[1]
             if m.size == 0:
                 m = np.zeros(1, np.uint8)
@@ -470,10 +487,10 @@ class Context:
         return out, inf
 
     # ---- device buffers (torch CUDA uint8 tensors) ------------------------------
-    @staticmethod
-    def _stream():
+    def _stream(self):
+        """the current torch stream OF THIS CONTEXT'S DEVICE (not of torch's current device)"""
         import torch
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def mul_fixed_dev(self, curve, k, out_xy, out_inf):
         n = k.shape[0]

@@ -62,6 +62,8 @@ static struct {
   int (*order_bytes)(int);
   int (*device_count)(void);
   int (*ctx_create)(int, ellgpu_ctx**);
+  int (*group_create)(const int*, int, ellgpu_ctx**);
+  int (*group_size)(const ellgpu_ctx*);
   void (*ctx_destroy)(ellgpu_ctx*);
   int (*mul_fixed)(ellgpu_ctx*, int, size_t, const uint8_t*, uint8_t*, uint8_t*);
   int (*mul_var)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
@@ -119,6 +121,7 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   SYM(last_error, "ellgpu_last_error"); SYM(curve_id, "ellgpu_curve_id");
   SYM(field_bytes, "ellgpu_curve_field_bytes"); SYM(order_bytes, "ellgpu_curve_order_bytes");
   SYM(device_count, "ellgpu_device_count"); SYM(ctx_create, "ellgpu_ctx_create");
+  SYM(group_create, "ellgpu_group_create"); SYM(group_size, "ellgpu_group_size");
   SYM(ctx_destroy, "ellgpu_ctx_destroy"); SYM(mul_fixed, "ellgpu_mul_fixed"); SYM(mul_var, "ellgpu_mul_var");
   SYM(mul_add2, "ellgpu_mul_add2"); SYM(ecdsa_verify, "ellgpu_ecdsa_verify"); SYM(x25519, "ellgpu_x25519_ladder");
   SYM(decompress, "ellgpu_decompress");
@@ -147,9 +150,26 @@ static napi_value fn_create(napi_env env, napi_callback_info info) {
   if (!need_lib(env)) return NULL;
   size_t argc = 1; napi_value argv[1]; int32_t dev = 0;
   CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  if (argc >= 1) napi_get_value_int32(env, argv[0], &dev);
   ellgpu_ctx* c = NULL;
-  if (L.ctx_create(dev, &c) != 0) return lib_error(env);
+  bool is_arr = false;
+  if (argc >= 1) napi_is_array(env, argv[0], &is_arr);
+  if (is_arr) {
+    /* createContext([d0, d1, ...]): a device group (ellgpu_group_create) -- the batch entry
+     * points shard over the devices, every other call runs on the first one */
+    uint32_t nd = 0; int devs[64];
+    CHECK(env, napi_get_array_length(env, argv[0], &nd));
+    if (nd < 1 || nd > 64) THROW(env, "createContext([devices]): 1..64 devices");
+    for (uint32_t i = 0; i < nd; i++) {
+      napi_value e; int32_t d = 0;
+      CHECK(env, napi_get_element(env, argv[0], i, &e));
+      if (napi_get_value_int32(env, e, &d) != napi_ok) THROW(env, "createContext([devices]): integers expected");
+      devs[i] = d;
+    }
+    if (L.group_create(devs, (int)nd, &c) != 0) return lib_error(env);
+  } else {
+    if (argc >= 1) napi_get_value_int32(env, argv[0], &dev);
+    if (L.ctx_create(dev, &c) != 0) return lib_error(env);
+  }
   napi_value ext; CHECK(env, napi_create_external(env, c, ctx_finalize, NULL, &ext));
   return ext;
 }
@@ -238,6 +258,14 @@ static napi_value fn_field_bytes(napi_env e, napi_callback_info i) { return int_
 static napi_value fn_order_bytes(napi_env e, napi_callback_info i) { return int_fn(e, i, 1); }
 static napi_value fn_device_count(napi_env e, napi_callback_info i) { return int_fn(e, i, 2); }
 
+static napi_value fn_group_size(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 1; napi_value argv[1];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  napi_value v; CHECK(env, napi_create_int32(env, L.group_size(c), &v));
+  return v;
+}
 static napi_value fn_destroy(napi_env env, napi_callback_info info) {
   /* contexts are released by the GC finalizer; explicit destroy is a no-op hook */
   (void)info; napi_value u; napi_get_undefined(env, &u); return u;
@@ -599,6 +627,8 @@ static napi_value fn_eddsa_verify(napi_env env, napi_callback_info info) {
   if (off) {
     if (loff != (n + 1) * 8 || ((uintptr_t)off & 7)) THROW(env, "offsets must be an aligned Buffer of n+1 uint64");
     if (((const uint64_t*)off)[n] > lm) THROW(env, "offsets exceed the message buffer");
+    for (size_t i = 0; i < n; i++)        /* the kernels take len = off[i+1] - off[i]: must not wrap */
+      if (((const uint64_t*)off)[i] > ((const uint64_t*)off)[i + 1]) THROW(env, "offsets must be non-decreasing");
   } else if ((size_t)mlen * n > lm) THROW(env, "message buffer too short");
   napi_value bok, berr; void *dok, *derr;
   CHECK(env, result_buffer(env, n, &dok, &bok));
@@ -623,6 +653,8 @@ static napi_value fn_eddsa_sign(napi_env env, napi_callback_info info) {
   if (off) {
     if (loff != (n + 1) * 8 || ((uintptr_t)off & 7)) THROW(env, "offsets must be an aligned Buffer of n+1 uint64");
     if (((const uint64_t*)off)[n] > lm) THROW(env, "offsets exceed the message buffer");
+    for (size_t i = 0; i < n; i++)        /* the kernels take len = off[i+1] - off[i]: must not wrap */
+      if (((const uint64_t*)off)[i] > ((const uint64_t*)off)[i + 1]) THROW(env, "offsets must be non-decreasing");
   } else if ((size_t)mlen * n > lm) THROW(env, "message buffer too short");
   napi_value bsig, bpub; void *dsig, *dpub;
   CHECK(env, result_buffer(env, n * 64, &dsig, &bsig));
@@ -636,7 +668,7 @@ static napi_value fn_eddsa_sign(napi_env env, napi_callback_info info) {
 typedef struct {
   napi_async_work work;
   napi_deferred deferred;
-  napi_ref refs[4];
+  napi_ref refs[5];          /* four input Buffers + the context external */
   int nrefs;
   int op, curve, hash_len, msg_bits, B, NB;
   ellgpu_ctx* ctx;
@@ -717,8 +749,12 @@ static napi_value fn_call_async(napi_env env, napi_callback_info info) {
   async_job* j = (async_job*)calloc(1, sizeof *j);
   int32_t op, curve, hl, mb;
   napi_get_value_int32(env, argv[0], &op);
+  if (!j) THROW(env, "callAsync: out of memory");
   j->ctx = get_ctx(env, argv[1]);
   if (!j->ctx) { free(j); return NULL; }
+  /* the worker thread uses the context after this call returns: hold its external so that the
+   * GC finalizer (ctx_finalize -> ellgpu_ctx_destroy) cannot run under the job */
+  napi_create_reference(env, argv[1], 1, &j->refs[j->nrefs++]);
   napi_get_value_int32(env, argv[2], &curve); napi_get_value_int32(env, argv[3], &hl); napi_get_value_int32(env, argv[4], &mb);
   j->op = op; j->curve = op == 4 ? 7 : curve; j->hash_len = hl; j->msg_bits = mb;
   j->B = L.field_bytes(j->curve); j->NB = L.order_bytes(j->curve);
@@ -769,6 +805,11 @@ static napi_value fn_call_async(napi_env env, napi_callback_info info) {
   j->out1 = (uint8_t*)malloc(j->out1_len ? j->out1_len : 1);
   j->out2 = (uint8_t*)malloc(j->out2_len ? j->out2_len : 1);
   j->out3 = (uint8_t*)malloc(j->out3_len ? j->out3_len : 1);
+  if (!j->out0 || !j->out1 || !j->out2 || !j->out3) {
+    for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
+    free(j->out0); free(j->out1); free(j->out2); free(j->out3); free(j);
+    THROW(env, "callAsync: out of memory");
+  }
   napi_value promise, name;
   CHECK(env, napi_create_promise(env, &j->deferred, &promise));
   CHECK(env, napi_create_string_utf8(env, "ellgpu", NAPI_AUTO_LENGTH, &name));
@@ -781,7 +822,7 @@ static napi_value init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
     {"open", fn_open}, {"createContext", fn_create}, {"destroyContext", fn_destroy},
     {"curveId", fn_curve_id}, {"fieldBytes", fn_field_bytes}, {"orderBytes", fn_order_bytes},
-    {"deviceCount", fn_device_count}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
+    {"deviceCount", fn_device_count}, {"groupSize", fn_group_size}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
     {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519},
     {"callAsync", fn_call_async}, {"decompress", fn_decompress},
     {"eddsaVerify", fn_eddsa_verify}, {"eddsaSign", fn_eddsa_sign}, {"ecdsaSign", fn_sign}, {"ecdsaRecover", fn_recover}, {"ecdsaSignDet", fn_sign_det},

@@ -34,7 +34,13 @@ function Engine(options) {
     path.join(__dirname, 'ellgpu.node'));
   this.addon.open(options.libPath || process.env.ELLGPU_LIB ||
     path.join(__dirname, '..', 'lib', 'libellgpu.so'));
-  this.ctx = this.addon.createContext(options.device | 0);
+  // options.devices = [d0, d1, ...]: a device GROUP -- mulBatch / mulAddBatch / ecdsaVerifyBatch
+  // (and their Promise forms) shard every batch over the listed GPUs, one host thread per
+  // device, results written straight into the result Buffers; everything else (and the
+  // one-item calls of install()) runs on the first device.
+  this.devices = Array.isArray(options.devices) && options.devices.length ?
+    options.devices.map(function(d) { return d | 0; }) : null;
+  this.ctx = this.addon.createContext(this.devices || (options.device | 0));
   this.stats = { gpuCalls: 0, gpuItems: 0, passthrough: 0 };
 }
 

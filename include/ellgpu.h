@@ -88,6 +88,16 @@ int ellgpu_curve_order_bytes(int curve);     /* byte length of n */
 
 int ellgpu_device_count(void);               /* number of visible HIP devices, <0 on error */
 int ellgpu_ctx_create(int device, ellgpu_ctx** out);
+/* Multi-GPU (the reference has no counterpart -- it is one JS thread):
+ * a GROUP is a context over `ndev` devices (devices[i] = HIP ordinal; an ordinal may repeat).
+ * ellgpu_mul_fixed / _mul_var / _mul_add2 / _ecdsa_verify called on it cut the batch into ndev
+ * contiguous shards [n*i/ndev, n*(i+1)/ndev), drive every device from its own host thread
+ * (own streams, scratch and replicated tables) and let each device copy its results straight
+ * into the caller's buffers: items are independent, so there is no device-to-device traffic
+ * and no collective.  Every other entry point called on a group runs on its first device.
+ * Destroy with ellgpu_ctx_destroy. */
+int ellgpu_group_create(const int* devices, int ndev, ellgpu_ctx** out);
+int ellgpu_group_size(const ellgpu_ctx* ctx);          /* ndev of a group, 1 for a plain context */
 void ellgpu_ctx_destroy(ellgpu_ctx* ctx);
 int ellgpu_ctx_synchronize(ellgpu_ctx* ctx);
 

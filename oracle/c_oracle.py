@@ -37,6 +37,13 @@ def load():
         lib.eco_mul_add.argtypes = [vp, ctypes.c_size_t, vp, vp, vp, vp, vp, vp]
         lib.eco_verify.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
         lib.eco_verify_mt.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int]
+        lib.eco_ed_create.restype = vp
+        lib.eco_ed_create.argtypes = [ctypes.c_int, ctypes.c_int] + [vp] * 5
+        lib.eco_ed_mul.argtypes = [vp, ctypes.c_size_t, vp, vp, vp]
+        lib.eco_mont_create.restype = vp
+        lib.eco_mont_create.argtypes = [ctypes.c_int, vp, vp]
+        lib.eco_mont_mul.argtypes = [vp, ctypes.c_size_t, vp, vp, vp, vp]
+        lib.eco_bulk_mt.argtypes = [ctypes.c_int, vp, ctypes.c_size_t, vp, vp, vp, vp, ctypes.c_int]
         _lib = lib
     return _lib
 
@@ -84,6 +91,65 @@ def curve(name):
 
 def _p(a):
     return None if a is None else a.ctypes.data
+
+
+_special = {}
+
+
+def _special_curve(name):
+    """handle of ed25519 (Edwards) or curve25519 (Montgomery), parameters from curves.json"""
+    if name in _special:
+        return _special[name]
+    lib = load()
+    with open(_GOLDEN) as f:
+        c = json.load(f)[name]
+    B = c["bytes"]
+    b = lambda h: (ctypes.c_char * B).from_buffer_copy(int(h, 16).to_bytes(B, "big"))
+    if c["type"] == "edwards":
+        bufs = [b(c[k]) for k in ("p", "a", "d", "gx", "gy")]
+        h = lib.eco_ed_create(B, c["nbits"], *[ctypes.addressof(x) for x in bufs])
+    else:
+        bufs = [b(c[k]) for k in ("p", "a")]
+        h = lib.eco_mont_create(B, *[ctypes.addressof(x) for x in bufs])
+    _special[name] = (h, B, bufs)
+    return _special[name]
+
+
+def ed_mul(k, xy=None, threads=1, name="ed25519"):
+    """k*P on ed25519 (xy None: the generator, with Point#mul's table dispatch) -> affine x||y"""
+    h, B, _ = _special_curve(name)
+    k = np.ascontiguousarray(k, np.uint8).reshape(-1, B)
+    n = k.shape[0]
+    if xy is not None:
+        xy = np.ascontiguousarray(xy, np.uint8).reshape(n, 2 * B)
+    out = np.zeros((n, 2 * B), np.uint8)
+    load().eco_bulk_mt(1, h, n, _p(k), _p(xy), _p(out), None, max(1, threads))
+    return out
+
+
+def mont_mul(k, x, threads=1, name="curve25519"):
+    """getX(k * (x : 1)) on curve25519 -> (x bytes, inf flags)"""
+    h, B, _ = _special_curve(name)
+    k = np.ascontiguousarray(k, np.uint8).reshape(-1, B)
+    n = k.shape[0]
+    x = np.ascontiguousarray(x, np.uint8).reshape(n, B)
+    out = np.zeros((n, B), np.uint8)
+    inf = np.zeros(n, np.uint8)
+    load().eco_bulk_mt(2, h, n, _p(k), _p(x), _p(out), _p(inf), max(1, threads))
+    return out, inf
+
+
+def mul_mt(name, k, xy=None, threads=1):
+    """mul() over `threads` slices"""
+    h, B, NB, _ = curve(name)
+    k = np.ascontiguousarray(k, np.uint8).reshape(-1, B)
+    n = k.shape[0]
+    if xy is not None:
+        xy = np.ascontiguousarray(xy, np.uint8).reshape(n, 2 * B)
+    out = np.zeros((n, 2 * B), np.uint8)
+    inf = np.zeros(n, np.uint8)
+    load().eco_bulk_mt(0, h, n, _p(k), _p(xy), _p(out), _p(inf), max(1, threads))
+    return out, inf
 
 
 def mul(name, k, xy=None):

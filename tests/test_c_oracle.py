@@ -80,3 +80,37 @@ def test_c_oracle_vs_python_oracle_random():
     ok1 = C.verify("secp256k1", ints_to_be(ks, 32), ints_to_be(ds, 32), ints_to_be(ds[::-1], 32), pub)
     ok8 = C.verify("secp256k1", ints_to_be(ks, 32), ints_to_be(ds, 32), ints_to_be(ds[::-1], 32), pub, threads=4)
     assert np.array_equal(ok1, ok8) and not ok1.any()
+
+
+def test_c_oracle_edwards_and_montgomery_golden():
+    """eco_ed_mul / eco_mont_mul (the bulk checkers of the -m gpu full-size tests) against the
+    reference's own results in mul_ed25519.json / mul_curve25519.json"""
+    cases = mul_cases("ed25519")
+    n = 0
+    for op, use_p in (("fixed", False), ("var", True)):
+        cs = [c for c in cases if c["op"] == op and I(c["k"]) < (1 << 256)]
+        if not cs:
+            continue
+        ks = ints_to_be([I(c["k"]) for c in cs], 32)
+        pts = None
+        if use_p:
+            pts = np.concatenate([ints_to_be([I(c["px"]) for c in cs], 32), ints_to_be([I(c["py"]) for c in cs], 32)], axis=1)
+        out = C.ed_mul(ks, pts, threads=2)
+        for i, c in enumerate(cs):
+            want = res_xy(c["r"])
+            got = (int.from_bytes(out[i, :32].tobytes(), "big"), int.from_bytes(out[i, 32:].tobytes(), "big"))
+            assert got == (want if want is not None else (0, 1)), c
+            n += 1
+    assert n > 20
+    cs = [c for c in mul_cases("curve25519") if I(c["k"]) < (1 << 256)]
+    out, inf = C.mont_mul(ints_to_be([I(c["k"]) for c in cs], 32), ints_to_be([I(c["px"]) for c in cs], 32))
+    m = 0
+    for i, c in enumerate(cs):
+        r = c["r"]
+        if r is None or (isinstance(r, dict) and r.get("inf")):
+            assert inf[i] == 1, c
+        else:
+            x = I(r["x"]) if isinstance(r, dict) else I(r)
+            assert inf[i] == 0 and int.from_bytes(out[i].tobytes(), "big") == x, c
+        m += 1
+    assert m > 5

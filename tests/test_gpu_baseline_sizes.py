@@ -1,0 +1,170 @@
+"""Parity at BASELINE.json's stated sizes, inside the driver's `-m gpu` suite.
+
+Every config runs at its full batch through the C ABI with >= 10 240 results compared item by
+item with the oracle (oracle/ec_oracle.c -- itself pinned to the reference's golden vectors by
+tests/test_c_oracle.py -- on the host threads; SURVEY.md 8d "Parity sampling"), a stride of the
+whole batch included so that every region of the launch is sampled, and size-independent
+properties over ALL items where the domain offers one.  Bounded: the oracle legs are ~1-3 s each
+on the GPU box's 16 usable threads."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import elliptic_amd  # noqa: E402
+from oracle import c_oracle as C  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+SAMPLE = 10240
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = elliptic_amd.Context(0)
+    yield c
+    c.close()
+
+
+def rnd(seed, n, w):
+    return np.frombuffer(hashlib.shake_256(seed.encode()).digest(n * w), dtype=np.uint8).reshape(n, w).copy()
+
+
+def sample_idx(n, m=SAMPLE):
+    """first m/2 items + a stride over the whole batch + the last items"""
+    head = np.arange(min(m // 2, n))
+    stride = np.arange(0, n, max(1, n // (m // 2 - 64)))[: m // 2 - 64]
+    tail = np.arange(max(0, n - 64), n)
+    return np.unique(np.concatenate([head, stride, tail]))
+
+
+def threads():
+    return C._usable_cpus()
+
+
+def test_config2_secp256k1_fixed_base_1M(ctx):
+    n = 1 << 20
+    k = rnd("bl:cfg2", n, 32)
+    k[:8] = 0
+    k[1, 31] = 1                                                  # edge scalars: 0, 1, n-1, n, n+1, 2^256-1 ...
+    N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    for j, v in enumerate((N - 1, N, N + 1, (1 << 256) - 1, 2)):
+        k[2 + j] = np.frombuffer(v.to_bytes(32, "big"), np.uint8)
+    xy, inf = ctx.mul_fixed("secp256k1", k)
+    idx = sample_idx(n)
+    want, winf = C.mul_mt("secp256k1", k[idx], None, threads())
+    assert np.array_equal(inf[idx], winf) and np.array_equal(xy[idx], want)
+    assert inf[0] == 1 and inf[3] == 1 and inf[:8].sum() == 3     # 0*G, n*G and the other zero row
+
+
+def test_config3_secp256k1_variable_base_and_verify_1M(ctx):
+    import bench
+    n = 1 << 20
+    h, r, s, pub, expect = bench.cached_signatures(ctx, n, "ellgpu-bench-v1:3:rank0")
+    # P*k (GLV): k = the r column, P = the public keys
+    xy, inf = ctx.mul_var("secp256k1", r, pub)
+    idx = sample_idx(n)
+    want, winf = C.mul_mt("secp256k1", r[idx], pub[idx], threads())
+    assert np.array_equal(inf[idx], winf) and np.array_equal(xy[idx], want)
+    # verify: mask == expected on ALL tuples, expected == oracle on the sample
+    ok = ctx.ecdsa_verify("secp256k1", h, r, s, pub)
+    assert np.array_equal(np.asarray(ok).astype(np.uint8), expect)
+    wok = C.verify("secp256k1", h[idx], r[idx], s[idx], pub[idx], threads=threads())
+    assert np.array_equal(wok, expect[idx])
+
+
+def test_config4_ed25519_variable_base_1M(ctx):
+    n = 1 << 20
+    k = rnd("bl:cfg4:k", n, 32)
+    d = rnd("bl:cfg4:d", n, 32)
+    k[:, 0] &= 0x1F                                               # < 2^253 (the reference takes any BN)
+    d[:, 0] &= 0x0F
+    k[0] = 0
+    k[1] = 0
+    k[1, 31] = 1
+    pts, _ = ctx.mul_fixed("ed25519", d)
+    out, inf = ctx.mul_var("ed25519", k, pts)
+    idx = sample_idx(n)
+    # the generator leg and the variable-base leg against the C oracle
+    assert np.array_equal(pts[idx], C.ed_mul(d[idx], None, threads()))
+    want = C.ed_mul(k[idx], pts[idx], threads())
+    got = out[idx].copy()
+    # identity: the engine reports it through the flag with zeroed coordinates, the oracle as (0, 1)
+    ident = inf[idx] != 0
+    assert ident.sum() >= 1
+    assert np.array_equal(got[~ident], want[~ident])
+    one = np.zeros(64, np.uint8)
+    one[63] = 1
+    assert (want[ident] == one).all()
+
+
+def test_config5_p384_variable_base_256K(ctx):
+    n = 1 << 18
+    k = rnd("bl:cfg5:k", n, 48)
+    d = rnd("bl:cfg5:d", n, 48)
+    pts, pinf = ctx.mul_fixed("p384", d)
+    assert not pinf.any()
+    out, inf = ctx.mul_var("p384", k, pts)
+    idx = sample_idx(n)
+    want, winf = C.mul_mt("p384", k[idx], pts[idx], threads())
+    assert np.array_equal(inf[idx], winf) and np.array_equal(out[idx], want)
+    wantg, winfg = C.mul_mt("p384", d[idx[:2048]], None, threads())
+    assert np.array_equal(pts[idx[:2048]], wantg) and not winfg.any()
+
+
+def test_x25519_1M(ctx):
+    n = 1 << 20
+    k = rnd("bl:x:k", n, 32)
+    x = rnd("bl:x:x", n, 32)
+    x[:, 0] &= 0x7F
+    out, inf = ctx.x25519(k, x)
+    idx = sample_idx(n)
+    want, winf = C.mont_mul(k[idx], x[idx], threads())
+    assert np.array_equal(inf[idx], winf)
+    keep = winf == 0
+    assert np.array_equal(out[idx][keep], want[keep])
+
+
+def test_p521_large_batch_kernels_vs_oracle(ctx):
+    """batches above 65 536 items take the two-waves-per-SIMD instantiation of the p521 ladders
+    (engine.h ELL_P521_PAIR_MIN): those kernels directly against the oracle"""
+    n = (1 << 17) + 4096
+    k = rnd("bl:p521:k", n, 66)
+    d = rnd("bl:p521:d", n, 66)
+    k[:, 0] &= 1
+    d[:, 0] &= 1
+    pts, pinf = ctx.mul_fixed("p521", d)
+    out, inf = ctx.mul_var("p521", k, pts)
+    idx = sample_idx(n, 4096)
+    wg, wgi = C.mul_mt("p521", d[idx], None, threads())
+    assert np.array_equal(pinf[idx], wgi) and np.array_equal(pts[idx], wg)
+    want, winf = C.mul_mt("p521", k[idx], pts[idx], threads())
+    assert np.array_equal(inf[idx], winf) and np.array_equal(out[idx], want)
+    sm, sinf = ctx.mul_add2("p521", d, None, k, pts)
+    w2, w2i = C.mul_add("p521", d[idx[:1024]], None, k[idx[:1024]], pts[idx[:1024]])
+    assert np.array_equal(sinf[idx[:1024]], w2i) and np.array_equal(sm[idx[:1024]], w2)
+
+
+def test_device_group_on_gpu(ctx):
+    """ellgpu_group_create on hardware: ndev = 1 and a two-member group (the same GPU twice: two
+    contexts driven by two host threads at once) give the single-context results on an uneven
+    batch; the group is what `new Engine({devices})` / Context(devices=...) hand to callers"""
+    import bench
+    n = 300001
+    h, r, s, pub, expect = bench.cached_signatures(ctx, 1 << 20, "ellgpu-bench-v1:3:rank0")
+    h, r, s, pub, expect = h[:n], r[:n], s[:n], pub[:n], expect[:n]
+    for devs in ([0], [0, 0]):
+        g = elliptic_amd.Context(devices=devs)
+        assert g.group_size() == len(devs)
+        ok = g.ecdsa_verify("secp256k1", h, r, s, pub)
+        assert np.array_equal(np.asarray(ok).astype(np.uint8), expect)
+        xy, inf = g.mul_var("secp256k1", r, pub)
+        xy1, inf1 = ctx.mul_var("secp256k1", r, pub)
+        assert np.array_equal(xy, xy1) and np.array_equal(inf, inf1)
+        fx, fi = g.mul_fixed("secp256k1", s)
+        fx1, fi1 = ctx.mul_fixed("secp256k1", s)
+        assert np.array_equal(fx, fx1) and np.array_equal(fi, fi1)
+        g.close()

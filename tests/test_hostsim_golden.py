@@ -393,3 +393,47 @@ def test_error_paths(ctx, hs):
     # empty batch is a no-op
     out, inf = ctx.mul_fixed("secp256k1", np.zeros((0, 32), np.uint8))
     assert out.shape == (0, 64)
+
+
+def test_device_group_shards_match_single_context():
+    """ellgpu_group_create: the sharded host entry points (one host thread per member, results
+    written straight into the caller's buffers) give exactly the single-context results, for
+    uneven shard sizes and for batches smaller than the group (CPU build of the
+    same C ABI code, group members = two contexts of the simulated device)"""
+    lib = _lib.load(build_hostsim(), optional=("ellgpu_probe_valu", "ellgpu_ctx_set_timing", "ellgpu_ctx_get_timing",
+                                               "ellgpu_debug_field_op"))
+    one = elliptic_amd.Context(0, lib_path=lib)
+    grp = elliptic_amd.Context(lib_path=lib, devices=[0, 0, 0])
+    assert one.group_size() == 1 and grp.group_size() == 3
+    rnd = np.random.RandomState(7)
+    for curve, n in (("secp256k1", 101), ("p256", 2), ("ed25519", 37), ("secp256k1", 1)):
+        B = elliptic_amd.FIELD_BYTES[curve]
+        k = rnd.randint(0, 256, (n, B)).astype(np.uint8)
+        d = rnd.randint(0, 256, (n, B)).astype(np.uint8)
+        if curve == "ed25519":
+            k[:, 0] &= 0x0F
+            d[:, 0] &= 0x0F
+        p1, i1 = one.mul_fixed(curve, d)
+        pg, ig = grp.mul_fixed(curve, d)
+        assert np.array_equal(p1, pg) and np.array_equal(i1, ig)
+        a1, b1 = one.mul_var(curve, k, p1)
+        ag, bg = grp.mul_var(curve, k, p1)
+        assert np.array_equal(a1, ag) and np.array_equal(b1, bg)
+        a1, b1 = one.mul_add2(curve, k, None, d, p1)
+        ag, bg = grp.mul_add2(curve, k, None, d, p1)
+        assert np.array_equal(a1, ag) and np.array_equal(b1, bg)
+    # verify: golden tuples through the group
+    from golden_util import I, verify_cases
+    cs = [c for c in verify_cases("secp256k1") if len(c["z"]) == 64]
+    from elliptic_amd import ints_to_be
+    h = ints_to_be([I(c["z"]) for c in cs], 32)
+    r = ints_to_be([I(c["r"]) for c in cs], 32)
+    s = ints_to_be([I(c["s"]) for c in cs], 32)
+    q = np.concatenate([ints_to_be([I(c["qx"]) for c in cs], 32), ints_to_be([I(c["qy"]) for c in cs], 32)], axis=1)
+    ok = grp.ecdsa_verify("secp256k1", h, r, s, q)
+    assert [bool(x) for x in ok] == [c["ok"] for c in cs]
+    # an error inside a shard surfaces with the shard's message
+    with pytest.raises(elliptic_amd.EllgpuError):
+        grp.mul_var("curve25519", np.zeros((4, 32), np.uint8), np.zeros((4, 64), np.uint8))
+    one.close()
+    grp.close()

@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
 """Copy the summaries tools/refresh_profiles.sh produced on the GPU box (gpurun_out/refresh/)
-into profiles/ under the round prefix.
+into profiles/ under the round prefix, and distil profiles/<round>_kernel_counters.json -- the
+per-kernel instruction counts, VALU-busy and HBM traffic bench.py's `roofline` block reads.
 
-    gpurun -- 'bash tools/refresh_profiles.sh' && python tools/refresh_profiles.py [--round r01]
+    gpurun -- 'bash tools/refresh_profiles.sh' && python tools/refresh_profiles.py --round r02
 """
 import argparse
+import json
 import os
+import re
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MAP = {
@@ -14,33 +18,148 @@ MAP = {
     "bench.json.log": "bench.json.log",
     "valu_probe.log": "valu_probe.log",
     "valu_patterns.log": "valu_patterns.log",
+    "u29_probe.log": "u29_probe.log",
     "configs.jsonl": "configs.jsonl",
     "host_path.jsonl": "host_path.jsonl",
-    "latency.jsonl": "latency.jsonl",
     "js_bench.jsonl": "js_bench.jsonl",
-    "js_selftest.log": "js_selftest.log",
+    "soak.log": "soak.log",
     "bench_under_rocprof.log": "bench_under_rocprof.log",
     "rocprof_stats.txt": "rocprof_kernel_stats.txt",
     "rocprof_fw.txt": "rocprof_pmc_fetch_write.txt",
     "rocprof_sqa.txt": "rocprof_pmc_sq_a.txt",
     "rocprof_sqb.txt": "rocprof_pmc_sq_b.txt",
+    "rocprof_gc.txt": "rocprof_pmc_gather_calib.txt",
+    "gather_calib.log": "gather_calib.log",
 }
+
+# kernel name in the summaries -> (key bench.py uses, units per dispatch in the profiled command)
+N20, N18 = 1 << 20, 1 << 18
+KERNELS = {
+    "k_run<FnEcdsaMain<CvSecp256k1>>": ("ecdsa_main<secp256k1>", N20),
+    "k_run<FnMulVar<CvSecp256k1>>": ("mul_var<secp256k1>", N20),
+    "k_run<FnMulFixed<CvSecp256k1>>": ("mul_fixed<secp256k1>", None),      # several grid sizes: per-lane figures only
+    "k_run<FnMulVar<CvP384>>": ("mul_var<p384>", N18),
+    "k_run<FnEdMulVar>": ("ed_mul_var", N20),
+}
+
+
+def counters(txt):
+    """{kernel: {counter: (sum, dispatches)}} from a rocprof_summary.py text"""
+    out = {}
+    for m in re.finditer(r"^(\S.*?)\s{2,}(\w+)\s+(\d+)\s+n=(\d+)\s+per_dispatch=(\d+)\s*$", txt, re.M):
+        out.setdefault(m.group(1).strip(), {})[m.group(2)] = (int(m.group(3)), int(m.group(4)))
+    return out
+
+
+def calls(txt):
+    """{kernel: dispatches} from the kernel-stats table of a summary"""
+    out = {}
+    sec = txt.split("## durations per dispatch")[0]
+    for m in re.finditer(r"^(\S.*?)\s{2,}(\d+)\s+(\d+)\s+(\d+)\s+([\d.]+)\s*$", sec, re.M):
+        out[m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+def grids(txt):
+    """{kernel: total work-items over all dispatches} from the dispatch table (first grid only per kernel)"""
+    out = {}
+    for m in re.finditer(r"^(\S.*?)\s+grid=(\d+)\s+wg=", txt, re.M):
+        out.setdefault(m.group(1).strip(), []).append(int(m.group(2)))
+    return out
+
+
+def distil(src, digest):
+    def read(name):
+        p = os.path.join(src, name)
+        return open(p).read() if os.path.exists(p) else ""
+    sqa, sqb, fw, gc = read("rocprof_sqa.txt"), read("rocprof_sqb.txt"), read("rocprof_fw.txt"), read("rocprof_gc.txt")
+    ca, cb, cf = counters(sqa), counters(sqb), counters(fw)
+    na, nb = calls(sqa), calls(sqb)
+    out = {"source_digest": digest, "how": "rocprofv3 --kernel-trace --pmc (separate passes) over "
+           "`python bench.py --steps 2 --warmup 1 --no-cpu`; tools/refresh_profiles.sh",
+           "kernels": {}}
+    # FETCH_SIZE / WRITE_SIZE calibration on a known-bytes gather / scatter in this engine's pattern
+    cal = None
+    m = re.search(r"\{.*gather_bytes_per_dispatch.*\}", read("gather_calib.log"))
+    if m and gc:
+        known = json.loads(m.group(0))
+        cg = counters(gc)
+        for kname, c in cg.items():
+            if "k_gather64" in kname and "FETCH_SIZE" in c:
+                per = c["FETCH_SIZE"][0] / c["FETCH_SIZE"][1] * 1024.0     # KiB -> bytes per dispatch
+                cal = {"known_gather_bytes": known["gather_bytes_per_dispatch"], "fetch_size_bytes": per,
+                       "true_bytes_per_counted_byte": known["gather_bytes_per_dispatch"] / per if per else None,
+                       "pattern": "64 B per lane (4 x dwordx4) at random 64-B-aligned offsets in a 2 GiB table"}
+    out["fetch_calibration"] = cal
+    for kname, (key, units) in KERNELS.items():
+        a, b, f = ca.get(kname, {}), cb.get(kname, {}), cf.get(kname, {})
+        if "SQ_INSTS_VALU" not in a:
+            continue
+        # counters are summed over the dispatches of the pass; SQ_* count per wave, x64 lanes = per unit
+        disp_a, disp_b = na.get(kname), nb.get(kname)
+        ent = {}
+        waves = None
+        if "SQ_WAVES" in b and disp_b:
+            waves = b["SQ_WAVES"][0] / disp_b
+        if units is not None or waves:
+            w = (units / 64.0) if units else waves
+            ent["waves_per_dispatch"] = w
+            ent["valu_per_unit"] = a["SQ_INSTS_VALU"][0] / disp_a / w if disp_a else None
+            ent["salu_per_unit"] = a.get("SQ_INSTS_SALU", (0, 1))[0] / disp_a / w if disp_a else None
+            if "SQ_INSTS_VALU_INT64" in b and disp_b:
+                ent["mad_u64_per_unit"] = b["SQ_INSTS_VALU_INT64"][0] / disp_b / w
+                ent["int32_per_unit"] = b["SQ_INSTS_VALU_INT32"][0] / disp_b / w
+            # NB: "per unit" = per wavefront instruction count, i.e. what ONE lane (one verify / one
+            # scalar multiplication) executes
+        # VALU-busy: the gfx94x formulas rocprofv3 falls back to on gfx950
+        if "SQ_ACTIVE_INST_VALU" in a and "SQ_BUSY_CYCLES" in a:
+            act, busy = a["SQ_ACTIVE_INST_VALU"][0], a["SQ_BUSY_CYCLES"][0]
+            gui = a.get("GRBM_GUI_ACTIVE", (0, 1))[0]
+            ent["valu_busy"] = {
+                "SQ_ACTIVE_INST_VALU": act, "SQ_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": gui,
+                "SQ_THREAD_CYCLES_VALU": a.get("SQ_THREAD_CYCLES_VALU", (None,))[0],
+                "SQ_WAVE_CYCLES": a.get("SQ_WAVE_CYCLES", (None,))[0],
+                # VALUBusy (gfx94x derived metric) = 100 * SQ_ACTIVE_INST_VALU * 4 / SIMD_NUM / GRBM_GUI_ACTIVE
+                # with the counters summed over the 32 SEs' SQs and GRBM over 8 XCDs as this summary has them:
+                "valu_busy_pct_gfx94x_formula": (100.0 * act * 4 / 1024 / (gui / 8.0)) if gui else None,
+                "active_inst_valu_over_busy_cycles": act / busy if busy else None,
+            }
+        if "FETCH_SIZE" in f and "WRITE_SIZE" in f and units:
+            fb = f["FETCH_SIZE"][0] / f["FETCH_SIZE"][1] * 1024.0
+            wb = f["WRITE_SIZE"][0] / f["WRITE_SIZE"][1] * 1024.0
+            k = cal["true_bytes_per_counted_byte"] if cal and cal.get("true_bytes_per_counted_byte") else 1.0
+            ent["fetch_bytes_per_unit_raw"] = fb / units
+            ent["fetch_bytes_per_unit"] = fb * k / units
+            ent["write_bytes_per_unit"] = wb / units
+        out["kernels"][key] = ent
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r01")
+    ap.add_argument("--round", default="r02")
+    ap.add_argument("--src", default=os.path.join(ROOT, "gpurun_out", "refresh"))
     a = ap.parse_args()
-    src = os.path.join(ROOT, "gpurun_out", "refresh")
     dst = os.path.join(ROOT, "profiles")
     for s, d in MAP.items():
-        p = os.path.join(src, s)
+        p = os.path.join(a.src, s)
         if not os.path.exists(p) or os.path.getsize(p) == 0:
             print("missing or empty:", s)
             continue
         shutil.copyfile(p, os.path.join(dst, "%s_%s" % (a.round, d)))
         print("profiles/%s_%s" % (a.round, d))
+    try:
+        digest = open(os.path.join(ROOT, "elliptic_amd", "lib", "libellgpu.stamp")).read().strip()
+    except OSError:
+        digest = None
+    kc = distil(a.src, digest)
+    if kc["kernels"]:
+        with open(os.path.join(dst, "%s_kernel_counters.json" % a.round), "w") as f:
+            json.dump(kc, f, indent=1)
+        print("profiles/%s_kernel_counters.json: %s" % (a.round, ", ".join(kc["kernels"])))
+    else:
+        print("no PMC counters found: kernel_counters.json not written")
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
