@@ -154,15 +154,21 @@ struct Ladder {
   // acc = sum_s k_s * P_s on the effective-affine curve: digits odd (recode_odd_w4), tables
   // tbl[s*8 + (|d|-1)/2] affine, point s negated when bit s of negmask is set; afterwards
   // P_s is subtracted once where bit s of evenmask is set (k_s had been made odd by +1).
-  template <int NS, int NW>
-  ELL_HD static J run_odd_w4(const DigitStore& ds, const A* tbl, u32 negmask, u32 evenmask, bool& inf) {
+  // LAMBDA_AT_LOOKUP (secp256k1, NS = 2): the second digit string's table (lambda * P = (beta x, y))
+  // is not stored; its entries are the first table's with x multiplied by beta at every lookup.
+  // Halves the table bytes written per item and the region the gathers touch, for one more
+  // field multiplication per addition of the second string (ELL_LAMBDA_AT_LOOKUP).
+  template <int NS, int NW, bool LAMBDA_AT_LOOKUP = false>
+  ELL_HD static J run_odd_w4(const DigitStore& ds, const A* tbl, u32 negmask, u32 evenmask, bool& inf,
+                             const El* beta = nullptr) {
     // table entry for digit string s at window w (digits are odd and non-zero); a function of
     // (w, s) only, so that the additions' rarely taken branch can fetch it again
     auto entry = [&](int w, int s) -> A {
       int d = ds.get(w * NS + s);
       int ad = d < 0 ? -d : d;
       bool neg = (d < 0) != (((negmask >> s) & 1u) != 0);
-      A q = tbl[s * 8 + ((ad - 1) >> 1)];
+      A q = tbl[(LAMBDA_AT_LOOKUP ? 0 : s * 8) + ((ad - 1) >> 1)];
+      if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, *beta);
       q.y = fe_select<F>(neg, F::neg(q.y), q.y);
       return q;
     };
@@ -182,7 +188,8 @@ struct Ladder {
     ELL_NOUNROLL
     for (int s = 0; s < NS; s++) {
       auto corr = [&]() -> A {
-        A q = tbl[s * 8];
+        A q = tbl[LAMBDA_AT_LOOKUP ? 0 : s * 8];
+        if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, *beta);
         bool neg = ((negmask >> s) & 1u) == 0;        // subtract sign_s * P_s
         q.y = fe_select<F>(neg, F::neg(q.y), q.y);
         return q;

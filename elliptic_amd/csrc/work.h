@@ -27,6 +27,12 @@
 #ifndef ELL_COMB_BITS_256
 #define ELL_COMB_BITS_256 16
 #endif
+// 1 (default) = lambda*P entries are computed at lookup (x * beta) instead of being stored as a
+// second window table: measured on one box (round 2, gpurun_out/r02d) ecdsa_main 8.61 -> 8.52 ms,
+// FETCH_SIZE 6.03 -> 4.76 GB and WRITE_SIZE 2.20 -> 1.53 GB per 2^20 verifies (-24 % bytes)
+#ifndef ELL_LAMBDA_AT_LOOKUP
+#define ELL_LAMBDA_AT_LOOKUP 1
+#endif
 
 namespace ell {
 
@@ -151,6 +157,9 @@ struct Work {
       El beta;
       ELL_UNROLL
       for (int i = 0; i < L; i++) beta.v[i] = C::beta[i];
+#if ELL_LAMBDA_AT_LOOKUP
+      J r = LD::template run_odd_w4<2, NNIB, true>(ds, tbl, negmask, evenmask, inf, &beta);
+#else
       ELL_NOUNROLL
       for (int e = 0; e < 8; e++) {
         A t = tbl[e];
@@ -158,6 +167,7 @@ struct Work {
         tbl[8 + e] = t;
       }
       J r = LD::template run_odd_w4<2, NNIB>(ds, tbl, negmask, evenmask, inf);
+#endif
       r.Z = F::mul(r.Z, zg);
       return r;
     } else if constexpr (L > 12 && ELL_P521_JTABLE) {

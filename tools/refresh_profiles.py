@@ -38,7 +38,7 @@ KERNELS = {
     "k_run<FnEcdsaMain<CvSecp256k1>>": ("ecdsa_main<secp256k1>", N20),
     "k_run<FnMulVar<CvSecp256k1>>": ("mul_var<secp256k1>", N20),
     "k_run<FnMulFixed<CvSecp256k1>>": ("mul_fixed<secp256k1>", None),      # several grid sizes: per-lane figures only
-    "k_run<FnMulVar<CvP384>>": ("mul_var<p384>", N18),
+    "k_run<FnMulVar<CvNist>>": ("mul_var<p384>", N18),        # the only NIST curve bench.py runs (names collapse to CvNist)
     "k_run<FnEdMulVar>": ("ed_mul_var", N20),
 }
 
@@ -46,7 +46,7 @@ KERNELS = {
 def counters(txt):
     """{kernel: {counter: (sum, dispatches)}} from a rocprof_summary.py text"""
     out = {}
-    for m in re.finditer(r"^(\S.*?)\s{2,}(\w+)\s+(\d+)\s+n=(\d+)\s+per_dispatch=(\d+)\s*$", txt, re.M):
+    for m in re.finditer(r"^(\S.*?)\s+([A-Z][A-Z0-9_]+)\s+(\d+)\s+n=(\d+)\s+per_dispatch=(\d+)\s*$", txt, re.M):
         out.setdefault(m.group(1).strip(), {})[m.group(2)] = (int(m.group(3)), int(m.group(4)))
     return out
 
@@ -93,24 +93,19 @@ def distil(src, digest):
     out["fetch_calibration"] = cal
     for kname, (key, units) in KERNELS.items():
         a, b, f = ca.get(kname, {}), cb.get(kname, {}), cf.get(kname, {})
-        if "SQ_INSTS_VALU" not in a:
+        if "SQ_INSTS_VALU" not in a or "SQ_WAVES" not in b:
             continue
-        # counters are summed over the dispatches of the pass; SQ_* count per wave, x64 lanes = per unit
-        disp_a, disp_b = na.get(kname), nb.get(kname)
-        ent = {}
-        waves = None
-        if "SQ_WAVES" in b and disp_b:
-            waves = b["SQ_WAVES"][0] / disp_b
-        if units is not None or waves:
-            w = (units / 64.0) if units else waves
-            ent["waves_per_dispatch"] = w
-            ent["valu_per_unit"] = a["SQ_INSTS_VALU"][0] / disp_a / w if disp_a else None
-            ent["salu_per_unit"] = a.get("SQ_INSTS_SALU", (0, 1))[0] / disp_a / w if disp_a else None
-            if "SQ_INSTS_VALU_INT64" in b and disp_b:
-                ent["mad_u64_per_unit"] = b["SQ_INSTS_VALU_INT64"][0] / disp_b / w
-                ent["int32_per_unit"] = b["SQ_INSTS_VALU_INT32"][0] / disp_b / w
-            # NB: "per unit" = per wavefront instruction count, i.e. what ONE lane (one verify / one
-            # scalar multiplication) executes
+        # Every pass runs the same command, so a kernel's dispatches (of whatever grid sizes: the
+        # host-buffer leg cuts its batch into chunks) add up to the same number of wavefronts in
+        # every pass.  SQ_INSTS_* count wavefront instructions: total / total waves = what ONE
+        # lane (one verify / one scalar multiplication) executes.
+        waves = float(b["SQ_WAVES"][0])
+        ent = {"waves_in_pass": waves, "dispatches_in_pass": nb.get(kname)}
+        ent["valu_per_unit"] = a["SQ_INSTS_VALU"][0] / waves
+        ent["salu_per_unit"] = a.get("SQ_INSTS_SALU", (0, 1))[0] / waves
+        if "SQ_INSTS_VALU_INT64" in b:
+            ent["mad_u64_per_unit"] = b["SQ_INSTS_VALU_INT64"][0] / waves
+            ent["int32_per_unit"] = b["SQ_INSTS_VALU_INT32"][0] / waves
         # VALU-busy: the gfx94x formulas rocprofv3 falls back to on gfx950
         if "SQ_ACTIVE_INST_VALU" in a and "SQ_BUSY_CYCLES" in a:
             act, busy = a["SQ_ACTIVE_INST_VALU"][0], a["SQ_BUSY_CYCLES"][0]
@@ -124,13 +119,14 @@ def distil(src, digest):
                 "valu_busy_pct_gfx94x_formula": (100.0 * act * 4 / 1024 / (gui / 8.0)) if gui else None,
                 "active_inst_valu_over_busy_cycles": act / busy if busy else None,
             }
-        if "FETCH_SIZE" in f and "WRITE_SIZE" in f and units:
-            fb = f["FETCH_SIZE"][0] / f["FETCH_SIZE"][1] * 1024.0
-            wb = f["WRITE_SIZE"][0] / f["WRITE_SIZE"][1] * 1024.0
+        if "FETCH_SIZE" in f and "WRITE_SIZE" in f:
+            lanes = waves * 64.0
+            fb = f["FETCH_SIZE"][0] * 1024.0                       # KiB, summed over the pass
+            wb = f["WRITE_SIZE"][0] * 1024.0
             k = cal["true_bytes_per_counted_byte"] if cal and cal.get("true_bytes_per_counted_byte") else 1.0
-            ent["fetch_bytes_per_unit_raw"] = fb / units
-            ent["fetch_bytes_per_unit"] = fb * k / units
-            ent["write_bytes_per_unit"] = wb / units
+            ent["fetch_bytes_per_unit_raw"] = fb / lanes
+            ent["fetch_bytes_per_unit"] = fb * k / lanes
+            ent["write_bytes_per_unit"] = wb / lanes
         out["kernels"][key] = ent
     return out
 
