@@ -48,20 +48,23 @@ __global__ void __launch_bounds__(256) k_probe(u32* out, int iters, u32 seed) {
 // interleaved mul chains, 13 add+sub chain, 14 Jacobian doubling chain, 15 mixed-add chain.
 template <int KIND>
 __global__ void __launch_bounds__(64) k_probe_field(u32* out, int iters, u32 seed) {
-  typedef FpK256 F;
+  typedef CvSecp256k1::F F;                  // the field the secp256k1 kernels run on (ELL_K256_LAZY)
   typedef ShortOps<CvSecp256k1> G;
-  F::El x, y, z;
+  u32 xs[8], ys[8], zs[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    x.v[i] = seed * (i + 1) + threadIdx.x * 2654435761u;
-    y.v[i] = (seed ^ 0x9E3779B9u) * (i + 3) + threadIdx.x;
-    z.v[i] = seed + i * 0x1234567u + threadIdx.x * 7u;
+    xs[i] = seed * (i + 1) + threadIdx.x * 2654435761u;
+    ys[i] = (seed ^ 0x9E3779B9u) * (i + 3) + threadIdx.x;
+    zs[i] = seed + i * 0x1234567u + threadIdx.x * 7u;
   }
-  x.v[7] &= 0x7FFFFFFFu; y.v[7] &= 0x7FFFFFFFu; z.v[7] &= 0x7FFFFFFFu;
+  xs[7] &= 0x7FFFFFFFu; ys[7] &= 0x7FFFFFFFu; zs[7] &= 0x7FFFFFFFu;
+  F::El x = F::from_plain(xs), y = F::from_plain(ys), z = F::from_plain(zs);
   G::J p;
   p.X = x; p.Y = y; p.Z = z;
   G::A q;
   q.x = y; q.y = z;
+  bool inf = false;
+  u32 acc = 0;
 #pragma nounroll
   for (int it = 0; it < iters; it++) {
     if (KIND == 10) x = F::mul(x, y);
@@ -69,28 +72,33 @@ __global__ void __launch_bounds__(64) k_probe_field(u32* out, int iters, u32 see
     else if (KIND == 12) { x = F::mul(x, y); z = F::mul(z, y); }
     else if (KIND == 13) { x = F::add(x, y); x = F::sub(x, z); }
     else if (KIND == 14) p = G::dbl(p);
-    else if (KIND == 15) p = G::add_mixed(p, q);
-    else if (KIND == 16) {                       // wide product only (no reduction)
-      u32 t[16];
-      fe_mul_wide<8>(t, x.v, y.v);
+    else if (KIND == 15) p = G::add_mixed_lean(p, q, inf, [&]() { return q; });
+    else {
+      // 16 / 17 / 18: wide product / wide square / reduction of the SATURATED field only
+      FpK256::El sx, sy;
 #pragma unroll
-      for (int i = 0; i < 8; i++) x.v[i] = t[i] ^ t[i + 8];
-    } else if (KIND == 17) {                     // wide square only
+      for (int i = 0; i < 8; i++) { sx.v[i] = xs[i]; sy.v[i] = ys[i]; }
       u32 t[16];
-      fe_sqr_wide<8>(t, x.v);
+      if (KIND == 16) fe_mul_wide<8>(t, sx.v, sy.v);
+      else if (KIND == 17) fe_sqr_wide<8>(t, sx.v);
+      else {
 #pragma unroll
-      for (int i = 0; i < 8; i++) x.v[i] = t[i] ^ t[i + 8];
-    } else {                                     // reduction only
-      u32 t[16];
+        for (int i = 0; i < 8; i++) { t[i] = sx.v[i]; t[i + 8] = sy.v[i]; }
+        sx = FpK256::reduce_wide(t);
 #pragma unroll
-      for (int i = 0; i < 8; i++) { t[i] = x.v[i]; t[i + 8] = y.v[i]; }
-      x = F::reduce_wide(t);
+        for (int i = 0; i < 8; i++) t[i] = sx.v[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i++) { xs[i] = t[i] ^ (KIND == 18 ? 0u : t[i + 8]); }
+      xs[7] &= 0x7FFFFFFFu;
     }
   }
-  u32 acc = 0;
+  constexpr int NS = sizeof(F::El) / 4;
 #pragma unroll
-  for (int i = 0; i < 8; i++) acc ^= x.v[i] ^ z.v[i] ^ p.X.v[i] ^ p.Y.v[i] ^ p.Z.v[i];
-  out[(size_t)blockIdx.x * 64 + threadIdx.x] = acc;
+  for (int i = 0; i < NS; i++) acc ^= x.v[i] ^ z.v[i] ^ p.X.v[i] ^ p.Y.v[i] ^ p.Z.v[i];
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc ^= xs[i];
+  out[(size_t)blockIdx.x * 64 + threadIdx.x] = acc ^ (inf ? 1u : 0u);
 }
 
 // ---- white-box probe: one field operation per lane (tests/test_gpu_field.py) ----
@@ -115,6 +123,11 @@ __global__ void k_field_op(int op, size_t n, const u32* a, const u32* b, u32* r)
   }
   if constexpr (std::is_same<F, Fp25519>::value) {
     if (op == 10) z = F::mul_u32(x, tb[0]);               // one-limb constant
+  }
+  if constexpr (std::is_same<F, FpK256L>::value) {
+    // lazy forms through the generated asm: x*y + (4p - x)*(x - y + 4p), and (3 x^2) / 2
+    if (op == 11) z = F::mul2(x, y, F::template neg_l<4>(x), F::template sub_l<4>(x, y));
+    if (op == 12) { typename F::El a = F::sqr(x); z = F::norm(F::add_l(a, F::half_l(a))); }
   }
   F::to_plain(tr, z);
   for (int l = 0; l < F::L; l++) r[i * F::L + l] = tr[l];
@@ -263,7 +276,7 @@ extern "C" int ellgpu_debug_field_op(ellgpu_ctx* ctx, int field, int op, size_t 
   ELL_ENTER(ctx, nullptr);
   int L = 0;
   switch (field) {
-    case 0: case 1: case 10: case 13: case 20: case 23: case 26: L = 8; break;
+    case 0: case 1: case 2: case 10: case 13: case 20: case 23: case 26: L = 8; break;
     case 11: case 21: L = 6; break;
     case 12: case 22: L = 7; break;
     case 14: case 24: L = 12; break;
@@ -278,6 +291,7 @@ extern "C" int ellgpu_debug_field_op(ellgpu_ctx* ctx, int field, int op, size_t 
   switch (field) {
     case 0: run_field_op<FpK256>(bk, op, n, da, db, dr); break;
     case 1: run_field_op<Fp25519>(bk, op, n, da, db, dr); break;
+    case 2: run_field_op<FpK256L>(bk, op, n, da, db, dr); break;      // the 9 x 29-bit field (op 11: mul2, op 12: half)
     case 10: run_field_op<FpMont<consts::SECP256K1_P>>(bk, op, n, da, db, dr); break;
     case 11: run_field_op<CvP192::F>(bk, op, n, da, db, dr); break;
     case 12: run_field_op<CvP224::F>(bk, op, n, da, db, dr); break;

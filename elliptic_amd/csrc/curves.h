@@ -4,6 +4,7 @@
 
 #include "curve_consts.h"
 #include "fp.h"
+#include "fpk256l.h"
 
 namespace ell {
 
@@ -20,8 +21,24 @@ enum CurveId {
   CURVE_COUNT = 8
 };
 
+// ELL_K256_LAZY = 1: the secp256k1 base field is the 9 x 29-bit signed-limb field of fpk256l.h
+// (carry-free column products, lazy additions, two-product multiplies); 0 (default): the
+// saturated 8 x 32-bit field of fp.h.  Both are bit-exact on the whole GPU suite.  MEASURED,
+// round 2, same boxes (profiles/r02_lazy_field_*): the lazy field's operations are faster in
+// isolation (doubling 923 vs 1038 issue units, mixed addition 1441 vs 1792, 148 instead of 168
+// VGPRs, no scratch) but ecdsa_main as a whole is 4-5 % SLOWER (8.83 vs 8.49 ms, 9.15 vs 8.68 ms):
+// it needs only 1.7 % fewer GPU cycles (GRBM_GUI_ACTIVE 19.68 M vs 20.02 M per launch) and its
+// multiply-heavier mix (164 k instead of 117 k v_mad per verify) runs at a 7 % lower sustained
+// clock (2.15 vs 2.31 GHz).  Kept as a build switch; DESIGN.md section 9.
+#ifndef ELL_K256_LAZY
+#define ELL_K256_LAZY 0
+#endif
 struct CvSecp256k1 {
+#if ELL_K256_LAZY
+  typedef FpK256L F;
+#else
   typedef FpK256 F;
+#endif
   typedef FpMont<consts::SECP256K1_N> Fn;
   typedef consts::SECP256K1_C C;
   static constexpr int A_KIND = 0;

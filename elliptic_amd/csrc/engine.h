@@ -1371,7 +1371,7 @@ class Engine {
     int rc = prepare_curve(curve);
     if (rc) return rc;
     size_t m = n < CHUNK ? n : CHUNK;
-    size_t L = (size_t)(ci->field_bytes + 3) / 4;
+    size_t L = (size_t)(ci->field_bytes + 3) / 4 + 1;       // +1: the 29-bit secp256k1 field stores 9 limbs
     size_t ent = (curve == CURVE_ED25519) ? 16 * 4 * L * 4 : 32 * 3 * L * 4;
     if (!scratch(S_TBL, m * ent) || !scratch(S_JAC, m * 4 * L * 4) || !scratch(S_PRE, m * L * 4) ||
         !scratch(S_U12, m * 2 * L * 4) || !scratch(S_VALID, m))
@@ -1432,7 +1432,7 @@ template <class BK>
 template <class CV>
 int Engine<BK>::normalize_chunk(size_t n, const u32* jac, u8* out_xy, u8* out_inf, typename Work<CV>::A* raw) {
   typedef Work<CV> W;
-  u32* pre = (u32*)scratch(S_PRE, n * W::L * 4);
+  u32* pre = (u32*)scratch(S_PRE, n * W::NS * 4);
   if (!pre) return fail(E_NOMEM, "scratch allocation failed");
   size_t T = (n + INV_BATCH - 1) / INV_BATCH;
   FnNormalize<CV> f{T, n, INV_BATCH, jac, pre, out_xy, out_inf, raw};
@@ -1447,7 +1447,7 @@ int Engine<BK>::mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u
                   typename Work<CV>::A* raw) {
   typedef Work<CV> W;
   typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::VT));
-  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::NS * 4);
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
   if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
     FnMulVar<CV, (W::L > 12 ? 2 : 0)> f{n, k, xy, tbl, jac};
@@ -1464,7 +1464,7 @@ template <class BK>
 template <class CV>
 int Engine<BK>::mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf) {
   typedef Work<CV> W;
-  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::NS * 4);
   if (!jac) return fail(E_NOMEM, "scratch allocation failed");
   if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
     FnMulFixed<CV, (W::L > 12 ? 2 : 0)> f{n, k, (const typename W::A*)comb_[CV::ID], jac};
@@ -1482,7 +1482,7 @@ template <class CV>
 int Engine<BK>::mul_add2_chunk(size_t n, const u8* k1, const u8* xy1, const u8* k2, const u8* xy2,
                    u8* out_xy, u8* out_inf) {
   typedef Work<CV> W;
-  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::NS * 4);
   typename W::J* tbl = (typename W::J*)scratch(S_TBL, n * 2 * W::TBLJ * sizeof(typename W::J));
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
   FnMulAdd2<CV> f{n, k1, xy1, k2, xy2, tbl, jac};
@@ -1495,7 +1495,7 @@ template <class CV>
 int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* xy2, u8* out_xy,
                     u8* out_inf) {
   typedef Work<CV> W;
-  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::NS * 4);
   typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::VT));
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
   if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
@@ -1515,7 +1515,7 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
                 const u8* pub, u8* ok) {
   typedef Work<CV> W;
   typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::VT));
-  u32* pre = (u32*)scratch(S_PRE, n * (W::LN > W::L ? W::LN : W::L) * 4);
+  u32* pre = (u32*)scratch(S_PRE, n * (W::LN > W::NS ? W::LN : W::NS) * 4);
   u32* u12 = (u32*)scratch(S_U12, n * 2 * W::LN * 4);
   u8* valid = (u8*)scratch(S_VALID, n);
   if (!tbl || !pre || !u12 || !valid) return fail(E_NOMEM, "scratch allocation failed");
@@ -1681,7 +1681,7 @@ template <class CV>
 int Engine<BK>::point_add_chunk(size_t n, const u8* xy1, const u8* inf1, const u8* xy2, const u8* inf2,
                                 u8* out_xy, u8* out_inf) {
   typedef Work<CV> W;
-  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::NS * 4);
   if (!jac) return fail(E_NOMEM, "scratch allocation failed");
   FnPointAdd<CV> f{n, xy1, inf1, xy2, inf2, jac};
   bk.launch(f, n);
@@ -1837,7 +1837,7 @@ int Engine<BK>::sign_chunk(size_t n, const u8* hash, int hash_len, int shift, co
                            const u8* nonces, int canonical, u8* out_r, u8* out_s, u8* out_recid,
                            u8* out_ok) {
   typedef Work<CV> W;
-  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::L * 4);
+  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::NS * 4);
   u8* kg = (u8*)scratch(S_U12, n * (2 * W::BYTES + 1));          // k*G affine + infinity flags
   if (!jac || !kg) return fail(E_NOMEM, "scratch allocation failed");
   u8* kg_inf = kg + n * 2 * W::BYTES;
@@ -1850,7 +1850,7 @@ int Engine<BK>::sign_chunk(size_t n, const u8* hash, int hash_len, int shift, co
   }
   int rc = normalize_chunk<CV>(n, jac, kg, kg_inf, nullptr);
   if (rc) return rc;
-  u32* pre = (u32*)scratch(S_PRE, n * (W::LN > W::L ? W::LN : W::L) * 4);
+  u32* pre = (u32*)scratch(S_PRE, n * (W::LN > W::NS ? W::LN : W::NS) * 4);
   if (!pre) return fail(E_NOMEM, "scratch allocation failed");
   size_t T = (n + INV_BATCH_N - 1) / INV_BATCH_N;
   FnSignFinish<CV> f2{T, n, INV_BATCH_N, hash, hash_len, shift, priv, nonces, kg, kg_inf, canonical, pre,

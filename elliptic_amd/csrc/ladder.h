@@ -100,6 +100,13 @@ struct Ladder {
   typedef Jac<F> J;
   typedef Aff<F> A;
 
+  // neg ? -y : y for a table entry's y (a direct product output): lazy fields negate limb-wise
+  // with the offset 2p, without a normalisation pass
+  ELL_HD static El cneg_y(const El& y, bool neg) {
+    if constexpr (is_lazy<F>::value) return F::template cneg_l<2>(y, neg);
+    else return fe_select<F>(neg, F::neg(y), y);
+  }
+
   // tbl[j-1] = j*P for j = 1..8 (Jacobian, distinct Z)
   ELL_HD static void build_table8(J* tbl, const A& p) {
     tbl[0] = G::from_affine(p);
@@ -169,7 +176,7 @@ struct Ladder {
       bool neg = (d < 0) != (((negmask >> s) & 1u) != 0);
       A q = tbl[(LAMBDA_AT_LOOKUP ? 0 : s * 8) + ((ad - 1) >> 1)];
       if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, *beta);
-      q.y = fe_select<F>(neg, F::neg(q.y), q.y);
+      q.y = cneg_y(q.y, neg);
       return q;
     };
     // top window, first string: acc = the entry itself (no addition into O)
@@ -191,7 +198,7 @@ struct Ladder {
         A q = tbl[LAMBDA_AT_LOOKUP ? 0 : s * 8];
         if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, *beta);
         bool neg = ((negmask >> s) & 1u) == 0;        // subtract sign_s * P_s
-        q.y = fe_select<F>(neg, F::neg(q.y), q.y);
+        q.y = cneg_y(q.y, neg);
         return q;
       };
       // per-lane condition: lanes without the correction sit the addition out (exec mask)

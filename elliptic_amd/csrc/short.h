@@ -22,17 +22,26 @@ struct Jac {
   typename F::El X, Y, Z;      // Z == 0 <=> infinity
 };
 
+// 16-byte aligned: a table entry is fetched with dwordx4 loads (the 9-limb field's 72-byte
+// entry is padded to 80 bytes: 5 loads instead of 18 single-dword ones)
 template <class F>
-struct Aff {
+struct alignas(16) Aff {
   typename F::El x, y;
 };
 
 template <class F>
 ELL_HD typename F::El fe_select(bool c, const typename F::El& a, const typename F::El& b) {
   typename F::El r;
-  bn_select<F::L>(r.v, c, a.v, b.v);
+  bn_select<sizeof(typename F::El) / sizeof(u32)>(r.v, c, a.v, b.v);
   return r;
 }
+
+// F::LAZY (fpk256l.h): the field offers unnormalised add / sub and two-product multiplies; the
+// group law below then takes its lazy formulas
+template <class F, class = void>
+struct is_lazy { static constexpr bool value = false; };
+template <class F>
+struct is_lazy<F, decltype((void)F::LAZY)> { static constexpr bool value = F::LAZY; };
 
 template <class CV>
 struct ShortOps {
@@ -46,7 +55,10 @@ struct ShortOps {
   }
   ELL_HD static bool is_inf(const J& p) { return F::is_zero(p.Z); }
   ELL_HD static J from_affine(const A& q) {
-    J r; r.X = q.x; r.Y = q.y; r.Z = F::one(); return r;
+    J r; r.X = q.x; r.Y = q.y; r.Z = F::one();
+    // lazy fields: a table entry's y may carry an unnormalised conditional negation (Ladder::cneg_y)
+    if constexpr (is_lazy<F>::value) r.Y = F::norm(q.y);
+    return r;
   }
   ELL_HD static J select(bool c, const J& a, const J& b) {
     J r;
@@ -62,9 +74,36 @@ struct ShortOps {
   }
 
   // 2P.  Z == 0 (infinity) and Y == 0 (order-2 point) both give Z3 == 0.
+  // Lazy-field doubling, a = 0 (secp256k1 over FpK256L).  Formulas of libsecp256k1's gej_double
+  // (the result is the usual one scaled by lambda = 1/2: same affine point), chosen because their
+  // only constants are 3/2 and 2:
+  //     L = 3/2 X^2,  S = Y^2,  T = X S,  X3 = L^2 - 2T,  Y3 = L (T - X3) - S^2,  Z3 = Y Z.
+  // 3 S + 2 M + one two-product multiply; inputs and outputs in N form.
+  template <class FF = F>
+  ELL_HD static J dbl_lazy(const J& p) {
+    J r;
+    ELL_K256L_AT("dbl_lazy");
+    El s = FF::sqr(p.Y);                                             // N x N
+    r.Z = FF::mul(p.Y, p.Z);
+    El a = FF::sqr(p.X);
+    // L = a + a / 2 (limbs below 2^30 + 2^28), normalised
+    El l = FF::norm(FF::add_l(a, FF::half_l(a)));
+    El t = FF::mul(p.X, s);
+    // X3 = L^2 - 2T + 4p: limbs in (-2^30 - 2^19, 2^29 + 2^18), value > 0 (2T < 4p); an output -> N
+    El l2 = FF::sqr(l);
+    r.X = FF::norm(FF::template sub_l<4>(l2, FF::add_l(t, t)));
+    // W = T - X3 + 4p (X3 is a norm output: < 2^257 + eps < 4p); Y3 = L W + (2p - S) S, one reduction
+    El w = FF::template sub_l<4>(t, r.X);
+    r.Y = FF::mul2(l, w, FF::template neg_l<2>(s), s);
+    ELL_K256L_AT("after dbl_lazy");
+    return r;
+  }
+
   ELL_HD static J dbl(const J& p) {
     J r;
-    if (CV::A_KIND == 0) {
+    if constexpr (is_lazy<F>::value && CV::A_KIND == 0) {
+      return dbl_lazy<F>(p);
+    } else if (CV::A_KIND == 0) {
       // dbl-2009-l, a = 0: 2M + 5S.  Statement order = shortest live ranges (Y and Z die
       // first, then X): at most five field elements are live next to a product's own words.
       El b = F::sqr(p.Y);
@@ -127,8 +166,52 @@ struct ShortOps {
   // Z3 = Z1 * h == 0 then means h == 0 exactly when the flag is clear, and all three exceptional
   // results depend on Q alone (Q, 2Q, O), which the rarely taken branch fetches again through
   // `reload` instead of holding it.  Statement order = shortest live ranges.
+  // Lazy-field form of add_mixed_lean / add_mixed_zr (same formulas; p in N form, q = table entry
+  // = direct product outputs): differences stay unnormalised with an offset K p that keeps their
+  // VALUE positive, X3 is normalised once, Y3 = rr (v - X3) + (4p - Y1) hhh is one two-product
+  // multiply.  3 S + 6 M + one two-product multiply.  `h_out` (optional) receives h.
+  template <class FF = F>
+  ELL_HD static J add_mixed_lazy(const J& p, const A& q, El* h_out, El* rr_out = nullptr) {
+    ELL_K256L_AT("add_mixed_lazy");
+    El z1z1 = FF::sqr(p.Z);
+    El u2 = FF::mul(q.x, z1z1);
+    El s2 = FF::mul(q.y, FF::mul(p.Z, z1z1));
+    El h = FF::template sub_l<4>(u2, p.X);                    // p.X, p.Y: N form (< 4p)
+    J r;
+    r.Z = FF::mul(p.Z, h);
+    El rr = FF::template sub_l<4>(s2, p.Y);
+    El hh = FF::sqr(h);
+    El hhh = FF::mul(h, hh);
+    El v = FF::mul(p.X, hh);
+    // X3 = rr^2 - hhh - 2v + 4p  (three direct outputs, each < 2^256 + eps: their sum < 4p)
+    El x3 = FF::template sub_l<4>(FF::sqr(rr), FF::add_l(hhh, FF::add_l(v, v)));
+    r.X = FF::norm(x3);
+    El w = FF::template sub_l<4>(v, r.X);                     // v - X3 + 4p
+    r.Y = FF::mul2(rr, w, FF::template neg_l<4>(p.Y), hhh);
+    if (h_out) *h_out = FF::norm(h);
+    if (rr_out) *rr_out = rr;
+    ELL_K256L_AT("after add_mixed_lazy");
+    return r;
+  }
+
   template <class Reload>
   ELL_HD static J add_mixed_lean(const J& p, const A& q, bool& pinf, const Reload& reload) {
+    if constexpr (is_lazy<F>::value) {
+      El rr;
+      J r = add_mixed_lazy<F>(p, q, nullptr, &rr);
+      bool z = F::is_zero_w(r.Z);
+      if (ELL_UNLIKELY(z)) {
+        const A qq = reload();
+        // Z3 = Z1 h = 0 with P finite means h = 0; then rr = S2 - Y1 (still at hand, lazy: the
+        // canonical zero test takes any non-negative lazy value) decides P == Q / P == -Q
+        const bool same = !pinf && F::is_zero(rr);
+        if (pinf) r = from_affine(qq);
+        else if (same) r = dbl(from_affine(qq));
+        z = F::is_zero(r.Z);
+      }
+      pinf = z;
+      return r;
+    }
     El z1z1 = F::sqr(p.Z);
     El u2 = F::mul(q.x, z1z1);
     El s2 = F::mul(q.y, F::mul(p.Z, z1z1));
@@ -157,6 +240,7 @@ struct ShortOps {
   // P + Q for table building: no exceptional cases are possible (P = j*Q0, Q = 2*Q0 on a
   // prime-order curve), returns the ratio h with Z3 = Z1 * h.  8M + 3S.
   ELL_HD static J add_mixed_zr(const J& p, const A& q, El& h) {
+    if constexpr (is_lazy<F>::value) return add_mixed_lazy<F>(p, q, &h);
     El z1z1 = F::sqr(p.Z);
     El u2 = F::mul(q.x, z1z1);
     El s2 = F::mul(q.y, F::mul(p.Z, z1z1));

@@ -48,7 +48,8 @@ struct Work {
   typedef Jac<F> J;
   typedef Aff<F> A;
 
-  static constexpr int L = F::L;
+  static constexpr int L = F::L;                           // 32-bit words of a plain value
+  static constexpr int NS = sizeof(El) / sizeof(u32);      // stored limbs of a field element (9 for the 29-bit secp256k1 field)
   static constexpr int LN = Fn::L;
   static constexpr int BYTES = C::BYTES;
   static constexpr int NBYTES = C::NBYTES;
@@ -90,21 +91,33 @@ struct Work {
   }
   ELL_HD static void store_jac(u32* jac, size_t n, size_t i, const J& p) {
     ELL_UNROLL
-    for (int l = 0; l < L; l++) {
-      jac[(size_t)(0 * L + l) * n + i] = p.X.v[l];
-      jac[(size_t)(1 * L + l) * n + i] = p.Y.v[l];
-      jac[(size_t)(2 * L + l) * n + i] = p.Z.v[l];
+    for (int l = 0; l < NS; l++) {
+      jac[(size_t)(0 * NS + l) * n + i] = p.X.v[l];
+      jac[(size_t)(1 * NS + l) * n + i] = p.Y.v[l];
+      jac[(size_t)(2 * NS + l) * n + i] = p.Z.v[l];
     }
   }
   ELL_HD static J load_jac(const u32* jac, size_t n, size_t i) {
     J p;
     ELL_UNROLL
-    for (int l = 0; l < L; l++) {
-      p.X.v[l] = jac[(size_t)(0 * L + l) * n + i];
-      p.Y.v[l] = jac[(size_t)(1 * L + l) * n + i];
-      p.Z.v[l] = jac[(size_t)(2 * L + l) * n + i];
+    for (int l = 0; l < NS; l++) {
+      p.X.v[l] = jac[(size_t)(0 * NS + l) * n + i];
+      p.Y.v[l] = jac[(size_t)(1 * NS + l) * n + i];
+      p.Z.v[l] = jac[(size_t)(2 * NS + l) * n + i];
     }
     return p;
+  }
+
+  // beta (curves.js:189-198) in the field's internal form
+  ELL_HD static El load_beta() {
+    if constexpr (ENDO) {
+      u32 b[L];
+      ELL_UNROLL
+      for (int i = 0; i < L; i++) b[i] = C::beta[i];
+      return F::from_plain(b);
+    } else {
+      return F::zero();
+    }
   }
 
   // ---- variable base -----------------------------------------------------
@@ -122,9 +135,7 @@ struct Work {
       negmask |= (n1 ? 1u : 0u) << s0;
       negmask |= (n2 ? 1u : 0u) << (s0 + 1);
       // lambda*P table: (beta*X, Y, Z)   (short.js:282-310 _getBeta)
-      El beta;
-      ELL_UNROLL
-      for (int i = 0; i < L; i++) beta.v[i] = C::beta[i];
+      El beta = load_beta();
       ELL_NOUNROLL
       for (int e = 0; e < 8; e++) {
         J t = tbl[e];
@@ -154,9 +165,7 @@ struct Work {
       LD::build_table_odd8(tbl, p, zg);
       // lambda*P table: (beta*x, y)   (short.js:282-310 _getBeta); beta commutes with the
       // isomorphisms, which only scale x and y
-      El beta;
-      ELL_UNROLL
-      for (int i = 0; i < L; i++) beta.v[i] = C::beta[i];
+      El beta = load_beta();
 #if ELL_LAMBDA_AT_LOOKUP
       J r = LD::template run_odd_w4<2, NNIB, true>(ds, tbl, negmask, evenmask, inf, &beta);
 #else
@@ -503,11 +512,11 @@ struct Work {
       if (i >= n) break;
       El z;
       ELL_UNROLL
-      for (int l = 0; l < L; l++) z.v[l] = jac[(size_t)(2 * L + l) * n + i];
+      for (int l = 0; l < NS; l++) z.v[l] = jac[(size_t)(2 * NS + l) * n + i];
       bool inf = F::is_zero(z);
       z = fe_select<F>(inf, F::one(), z);
       ELL_UNROLL
-      for (int l = 0; l < L; l++) pre[(size_t)l * n + i] = acc.v[l];
+      for (int l = 0; l < NS; l++) pre[(size_t)l * n + i] = acc.v[l];
       acc = F::mul(acc, z);
     }
     El inv = F::inv(acc);
@@ -520,7 +529,7 @@ struct Work {
       El z = fe_select<F>(inf, F::one(), p.Z);
       El pr;
       ELL_UNROLL
-      for (int l = 0; l < L; l++) pr.v[l] = pre[(size_t)l * n + i];
+      for (int l = 0; l < NS; l++) pr.v[l] = pre[(size_t)l * n + i];
       El zinv = F::mul(inv, pr);
       inv = F::mul(inv, z);
       El zi2 = F::sqr(zinv);

@@ -18,21 +18,28 @@ def _digest():
     for f in src:
         with open(f, "rb") as fh:
             h.update(fh.read())
+    h.update(b"flags:-DELL_COMB_BITS_256=8 -DELL_BOUNDS_CHECK=1")
     return h.hexdigest()
 
 
-def build(force=False):
+def build(force=False, lazy_k256=False):
+    """lazy_k256: the variant in which secp256k1 runs on the 9 x 29-bit field (-DELL_K256_LAZY=1,
+    fpk256l.h) -- a build switch of the product that the default build does not exercise"""
     os.makedirs(OUT, exist_ok=True)
-    stamp = os.path.join(OUT, "stamp")
+    tag = "_lazy" if lazy_k256 else ""
+    lib = LIB.replace(".so", tag + ".so")
+    stamp = os.path.join(OUT, "stamp" + tag)
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
-        return LIB
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing", "-pthread", "-DELL_COMB_BITS_256=8",
-           "-o", LIB, os.path.join(HERE, "hostsim.cpp")]
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return lib
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing", "-pthread", "-DELL_COMB_BITS_256=8", "-DELL_BOUNDS_CHECK=1"]
+    if lazy_k256:
+        cmd.append("-DELL_K256_LAZY=1")
+    cmd += ["-o", lib, os.path.join(HERE, "hostsim.cpp")]
     subprocess.run(cmd, check=True)
     with open(stamp, "w") as f:
         f.write(dig)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -87,6 +87,10 @@ static void field_op(int op, const u32* a, const u32* b, u32* r) {
     case 8: z = F::template mul_pow2<3>(x); break;
     default: z = x;
   }
+  if constexpr (std::is_same<F, FpK256L>::value) {
+    if (op == 11) z = F::mul2(x, y, F::template neg_l<4>(x), F::template sub_l<4>(x, y));
+    if (op == 12) { typename F::El a = F::sqr(x); z = F::norm(F::add_l(a, F::half_l(a))); }
+  }
   F::to_plain(tr, z);
   for (int i = 0; i < F::L; i++) r[i] = tr[i];
 }
@@ -95,7 +99,7 @@ extern "C" {
 // field: 0 k256, 1 25519, 2.. mont(curve p): 10+curve -> base field, 20+curve -> order field
 int hs_field_limbs(int field) {
   switch (field) {
-    case 0: case 1: return 8;
+    case 0: case 1: case 2: return 8;
     case 10: return 8; case 11: return 6; case 12: return 7; case 13: return 8; case 14: return 12; case 15: return 17;
     case 20: return 8; case 21: return 6; case 22: return 7; case 23: return 8; case 24: return 12; case 25: return 17;
     case 26: return 8;
@@ -105,6 +109,7 @@ int hs_field_limbs(int field) {
 int hs_field_op(int field, int op, const u32* a, const u32* b, u32* r) {
   switch (field) {
     case 0: field_op<FpK256>(op, a, b, r); break;
+    case 2: field_op<FpK256L>(op, a, b, r); break;
     case 1:
       if (op == 10) {                      // mul_u32 by the one-limb constant b[0]
         u32 ta[8];

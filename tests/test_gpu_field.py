@@ -16,7 +16,7 @@ from oracle import ec_oracle as O  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 FIELDS = {
-    0: O.get_curve("secp256k1", False).p, 1: 2 ** 255 - 19,
+    0: O.get_curve("secp256k1", False).p, 1: 2 ** 255 - 19, 2: O.get_curve("secp256k1", False).p,   # 2 = the 9 x 29-bit form (generated asm)
     10: O.get_curve("secp256k1", False).p, 11: O.get_curve("p192", False).p,
     12: O.get_curve("p224", False).p, 13: O.get_curve("p256", False).p,
     14: O.get_curve("p384", False).p, 15: O.get_curve("p521", False).p,
@@ -114,3 +114,21 @@ def test_rare_branches_solinas_gpu(ctx):
                                                   R.ctypes.data) == 0
             for v, g in zip(sel, _unpack(R)):
                 assert g == v[4], (field, op, hex(v[2]), hex(v[3]), hex(g))
+
+
+def test_lazy_field_asm_gpu(ctx):
+    """field id 2 = FpK256L through the generated v_mad_i64_i32 column statements
+    (csrc/k256l_asm.h): the two-product multiply and the 3/2 x^2 of the lazy doubling, 20 000 random
+    + edge operand pairs against Python integers (mul / sqr / add / sub / inv / neg of the same
+    field run in test_field_ops_gpu[2])"""
+    p = FIELDS[2]
+    rnd = random.Random(4711)
+    edge = [0, 1, 2, p - 1, p - 2, p, p + 1, 2 ** 256 - 1, 2 ** 255, 2 ** 232, 2 ** 232 - 1, 2 ** 29, 2 ** 29 - 1, (p + 1) // 2]
+    vals = [(x, y) for x in edge for y in edge] + [(rnd.getrandbits(256), rnd.getrandbits(256)) for _ in range(20000)]
+    A, B = _pack([v[0] for v in vals], 8), _pack([v[1] for v in vals], 8)
+    inv2 = pow(2, -1, p)
+    for op, fn in ((11, lambda x, y: (2 * x * y - x * x) % p), (12, lambda x, y: 3 * x * x * inv2 % p)):
+        R = np.zeros((len(vals), 8), np.uint32)
+        assert ctx._lib.ellgpu_debug_field_op(ctx._ctx, 2, op, len(vals), A.ctypes.data, B.ctypes.data, R.ctypes.data) == 0
+        for (x, y), g in zip(vals, _unpack(R)):
+            assert g == fn(x, y), (op, hex(x), hex(y), hex(g))

@@ -35,7 +35,7 @@ def ctx(hs):
 
 
 FIELDS = {
-    0: int(O.get_curve("secp256k1", False).p), 1: 2 ** 255 - 19,
+    0: int(O.get_curve("secp256k1", False).p), 1: 2 ** 255 - 19, 2: int(O.get_curve("secp256k1", False).p),
     10: O.get_curve("secp256k1", False).p, 11: O.get_curve("p192", False).p,
     12: O.get_curve("p224", False).p, 13: O.get_curve("p256", False).p,
     14: O.get_curve("p384", False).p, 15: O.get_curve("p521", False).p,
@@ -437,3 +437,36 @@ def test_device_group_shards_match_single_context():
         grp.mul_var("curve25519", np.zeros((4, 32), np.uint8), np.zeros((4, 64), np.uint8))
     one.close()
     grp.close()
+
+
+def test_secp256k1_on_the_lazy_field():
+    """-DELL_K256_LAZY=1 (secp256k1 on the 9 x 29-bit signed-limb field, fpk256l.h: lazy
+    additions, two-product multiplies, the libsecp256k1-style doubling) is a build switch of the
+    product: its whole secp256k1 path against the reference's goldens, with the run-time column
+    bound checks of the host build (ELL_BOUNDS_CHECK) armed"""
+    lib = _lib.load(build_hostsim(lazy_k256=True), optional=("ellgpu_probe_valu", "ellgpu_ctx_set_timing",
+                                                              "ellgpu_ctx_get_timing", "ellgpu_debug_field_op"))
+    c = elliptic_amd.Context(0, lib_path=lib)
+    assert PC.check_mul_golden(c, "secp256k1") > 100
+    assert PC.check_verify_golden(c, "secp256k1") > 20
+    assert PC.check_sign_golden(c, "secp256k1") >= 10
+    assert PC.check_recover_golden(c, "secp256k1") >= 30
+    assert PC.check_decompress_golden(c, "secp256k1") >= 20
+    assert PC.check_add_golden(c, "secp256k1") >= 10
+    c.close()
+
+
+def test_lazy_field_two_product_and_half(hs):
+    """FpK256L's lazy forms (field id 2): x*y + (4p - x)*(x - y + 4p) through mul2 and 3/2 x^2
+    through half_l, edge and random operands, incl. p - 1 (whose products fold to a slightly
+    NEGATIVE value: the canonicalisation must cope)"""
+    p = FIELDS[2]
+    rnd = random.Random(77)
+    edge = [0, 1, 2, p - 1, p - 2, p, p + 1, 2 ** 256 - 1, 2 ** 255, 2 ** 232, 2 ** 232 - 1, 2 ** 29, 2 ** 29 - 1, (p + 1) // 2]
+    vals = [(x, y) for x in edge for y in edge] + [(rnd.getrandbits(256), rnd.getrandbits(256)) for _ in range(400)]
+    inv2 = pow(2, -1, p)
+    for x, y in vals:
+        for op, want in ((11, (2 * x * y - x * x) % p), (12, 3 * x * x * inv2 % p), (2, x * y % p), (1, (x - y) % p)):
+            r = (ctypes.c_uint32 * 8)()
+            assert hs.hs_field_op(2, op, _limbs(x, 8), _limbs(y, 8), r) == 0
+            assert _val(r) == want, (op, hex(x), hex(y))
