@@ -33,7 +33,7 @@ def units():
     for c in CURVES:
         for g in GROUPS:
             u.append(("inst_%s_g%d" % (c, g), "inst.hip", ["-DELL_INST_CURVE=" + c, "-DELL_INST_GROUP=%d" % g]))
-    for g in (10, 11, 12, 13, 14, 15):
+    for g in (10, 11, 12, 13, 14, 15, 16):
         u.append(("inst_g%d" % g, "inst.hip", ["-DELL_INST_GROUP=%d" % g]))
     u.append(("capi", "capi.hip", []))
     return u
@@ -75,7 +75,7 @@ def build_dev_k256(verbose=True, curve="CvSecp256k1"):
     tflag = "-DELL_ONLY_TYPE=" + curve
     work = [("inst_%s_g%d" % (curve, g), "inst.hip", ["-DELL_INST_CURVE=" + curve, "-DELL_INST_GROUP=%d" % g,
                                                       dflag, tflag], digest, ["-Rpass-analysis=kernel-resource-usage"]) for g in GROUPS]
-    for g in (10, 11, 12, 13, 14, 15):       # ed25519 / x25519 units are referenced by the engine, keep them linkable
+    for g in (10, 11, 12, 13, 14, 15, 16):   # ed25519 / x25519 units are referenced by the engine, keep them linkable
         work.append(("inst_g%d" % g, "inst.hip", ["-DELL_INST_GROUP=%d" % g, dflag, tflag], digest, []))
     work.append(("capi_%s" % curve, "capi.hip", [dflag, tflag], digest, []))
     for f in os.listdir(OBJ):

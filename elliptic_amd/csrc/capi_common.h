@@ -143,6 +143,27 @@ int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n) {
   return finish(ctx, ctx->eng->reserve(curve, n));
 }
 
+int ellgpu_curve_define_short(ellgpu_ctx* ctx, const uint8_t* p, const uint8_t* a, const uint8_t* b,
+                              int* out_curve) {
+  if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  if (!ctx->members.empty()) {
+    int id = -1;
+    for (size_t i = 0; i < ctx->members.size(); i++) {
+      int mid = -1;
+      int rc = ellgpu_curve_define_short(ctx->members[i], p, a, b, &mid);
+      if (rc) return rc;
+      if (i && mid != id) return set_err(ELLGPU_E_ARG, "group members disagree on the curve id (curves were defined on a member directly)");
+      id = mid;
+    }
+    if (out_curve) *out_curve = id;
+    return ELLGPU_OK;
+  }
+  ctx->eng->err.clear();
+  int rc = ctx->eng->define_short(p, a, b, out_curve);
+  if (rc) g_last_error = ctx->eng->err.empty() ? "ellgpu error" : ctx->eng->err;
+  return rc;
+}
+
 #define ELL_ENTER(ctx, stream)                                      \
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");           \
   ctx->eng->err.clear();                                            \

@@ -5,6 +5,7 @@
 #include "curve_consts.h"
 #include "fp.h"
 #include "fpk256l.h"
+#include "fp_rt.h"
 
 namespace ell {
 
@@ -43,6 +44,7 @@ struct CvSecp256k1 {
   typedef consts::SECP256K1_C C;
   static constexpr int A_KIND = 0;
   static constexpr bool ENDO = true;
+  static constexpr bool JTABLE = false;
   static constexpr int ID = CURVE_SECP256K1;
 };
 
@@ -55,8 +57,41 @@ struct CvNist {
   typedef CC C;
   static constexpr int A_KIND = 3;
   static constexpr bool ENDO = false;
+  static constexpr bool JTABLE = false;
   static constexpr int ID = ID_;
 };
+
+// User-defined short Weierstrass curve over a run-time prime (fp_rt.h): arbitrary a, no
+// endomorphism, no fixed-base tables, Jacobian window tables (JTABLE: the effective-affine table
+// of the presets would need an inversion per item to get back to a curve whose a the doubling
+// knows).  Only the scalar-multiplication kernels are instantiated for it.
+namespace consts {
+struct CUSTOM_C {
+  static constexpr int L = 8;
+  static constexpr int LN = 8;
+  static constexpr int BYTES = 32;      // scalars and coordinates are 32-byte big-endian whatever p's size
+  static constexpr int NBYTES = 32;
+  static constexpr int NBITS = 256;
+  static constexpr int PBITS = 256;
+  static constexpr int A_KIND = 1;
+  static constexpr u32 n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static constexpr u32 p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static constexpr u32 gx_plain[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static constexpr u32 gy_plain[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static constexpr u32 b_plain[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+}  // namespace consts
+struct CvCustom {
+  typedef FpMontRT F;
+  typedef FpMont<consts::SECP256K1_N> Fn;        // unused (no ECDSA on custom curves)
+  typedef consts::CUSTOM_C C;
+  static constexpr int A_KIND = 1;
+  static constexpr bool ENDO = false;
+  static constexpr bool JTABLE = true;
+  static constexpr int ID = 16;
+};
+constexpr int CURVE_CUSTOM0 = 16;                 // C-ABI ids 16..23: ellgpu_curve_define_short
+constexpr int CURVE_CUSTOM_MAX = 8;
 
 typedef CvNist<FpSolinas<SolP192>, consts::P192_N, consts::P192_C, CURVE_P192> CvP192;
 typedef CvNist<FpSolinas<SolP224>, consts::P224_N, consts::P224_C, CURVE_P224> CvP224;

@@ -13,6 +13,7 @@
 
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -425,8 +426,20 @@ inline const CurveInfo* curve_info(int id) {
       {"secp256k1", 32, 32, 256}, {"p192", 24, 24, 192}, {"p224", 28, 28, 224},
       {"p256", 32, 32, 256},      {"p384", 48, 48, 384}, {"p521", 66, 66, 521},
       {"ed25519", 32, 32, 253},   {"curve25519", 32, 32, 253}};
+  // user-defined short curves (Engine::define_short): every width is 32 bytes whatever the prime's size
+  static const CurveInfo custom = {"custom", 32, 32, 256};
+  if (id >= CURVE_CUSTOM0 && id < CURVE_CUSTOM0 + CURVE_CUSTOM_MAX) return &custom;
   if (id < 0 || id >= CURVE_COUNT) return nullptr;
   return &tab[id];
+}
+
+inline bool is_custom(int curve) { return curve >= CURVE_CUSTOM0 && curve < CURVE_CUSTOM0 + CURVE_CUSTOM_MAX; }
+// The custom-curve kernels read their modulus from ONE parameter block per device (fp_rt.h):
+// calls on user-defined curves are serialised per device, from the upload of the block to the
+// end of the call's device work.
+inline std::mutex& custom_mutex(int device) {
+  static std::mutex m[64];
+  return m[(unsigned)device % 64u];
 }
 
 // ---- the engine ----------------------------------------------------------------
@@ -545,7 +558,7 @@ class Engine {
 #define ELL_SHORT_DISPATCH(curve, CALL)                         \
   switch (curve) {                                              \
     case ELL_ONLY_CURVE: { typedef ELL_ONLY_TYPE CV; CALL; } break; \
-    default: return fail(E_UNSUPPORTED, "developer build: single curve only"); \
+    default: return fail(E_UNSUPPORTED, is_custom(curve) ? "not available on user-defined curves (scalar multiplication and point addition only)" : "developer build: single curve only"); \
   }
 #else
 #define ELL_SHORT_DISPATCH(curve, CALL)                         \
@@ -556,9 +569,111 @@ class Engine {
     case CURVE_P256: { typedef CvP256 CV; CALL; } break;           \
     case CURVE_P384: { typedef CvP384 CV; CALL; } break;           \
     case CURVE_P521: { typedef CvP521 CV; CALL; } break;           \
-    default: return fail(E_ARG, "unknown curve id");            \
+    default: return is_custom(curve) ? fail(E_UNSUPPORTED, "not available on user-defined curves (scalar multiplication and point addition only)") \
+                                     : fail(E_ARG, "unknown curve id");            \
   }
 #endif
+
+  // ---- user-defined short Weierstrass curves (run-time prime, arbitrary a) ----------------
+  // `new elliptic.curve.short({p, a, b})` (short.js:11-24) with parameters that are no preset:
+  // p an odd prime < 2^256 (primality is the caller's business, as it is the reference's), a and
+  // b any residues.  Registers the curve under an id >= CURVE_CUSTOM0 of this context; Point#mul,
+  // mulAdd / jmulAdd and Point#add then run on the device through the generic-a doubling
+  // (ShortOps::dbl, A_KIND 1) and a Montgomery field whose modulus is a kernel-time constant.
+  int define_short(const u8* p_be, const u8* a_be, const u8* b_be, int* out_curve) {
+    if (!p_be || !a_be || !b_be || !out_curve) return fail(E_ARG, "null pointer");
+    RtField f;
+    memset(&f, 0, sizeof(f));
+    u32 a[8], b[8];
+    load_be<8>(f.p, p_be, 32);
+    load_be<8>(a, a_be, 32);
+    load_be<8>(b, b_be, 32);
+    if (!(f.p[0] & 1u)) return fail(E_ARG, "define_short: the modulus must be odd");
+    bool small = true;
+    for (int i = 1; i < 8; i++) small = small && f.p[i] == 0;
+    if (small && f.p[0] < 5) return fail(E_ARG, "define_short: the modulus must be a prime > 3");
+    u32 inv = 1;                                          // p^-1 mod 2^32 (Newton)
+    for (int i = 0; i < 5; i++) inv *= 2u - f.p[0] * inv;
+    f.n0 = 0u - inv;
+    auto reduce = [&](u32 (&r)[8], const u32 (&x)[8]) {    // x mod p, bit by bit
+      bn_zero<8>(r);
+      for (int i = 255; i >= 0; i--) {
+        u32 t[8];
+        mod_add<8>(t, r, r, f.p);
+        bn_copy<8>(r, t);
+        if ((x[i >> 5] >> (i & 31)) & 1u) {
+          u32 o[8];
+          bn_zero<8>(o);
+          o[0] = 1;
+          mod_add<8>(t, r, o, f.p);
+          bn_copy<8>(r, t);
+        }
+      }
+    };
+    auto times_r = [&](u32 (&r)[8]) {                      // r * 2^256 mod p
+      for (int i = 0; i < 256; i++) {
+        u32 t[8];
+        mod_add<8>(t, r, r, f.p);
+        bn_copy<8>(r, t);
+      }
+    };
+    u32 one[8];
+    bn_zero<8>(one);
+    one[0] = 1;
+    u32 t[8];
+    reduce(t, one);                                       // p > 1: 1
+    times_r(t);
+    bn_copy<8>(f.one, t);
+    times_r(t);
+    bn_copy<8>(f.r2, t);
+    u32 two[8];
+    bn_zero<8>(two);
+    two[0] = 2;
+    bn_sub<8>(f.pm2, f.p, two);
+    u32 ar[8], br[8];
+    reduce(ar, a);
+    reduce(br, b);
+    u32 three[8], pm3[8];
+    bn_zero<8>(three);
+    three[0] = 3;
+    bn_sub<8>(pm3, f.p, three);
+    f.a_kind = bn_is_zero<8>(ar) ? 0u : (bn_eq<8>(ar, pm3) ? 3u : 1u);
+    times_r(ar);
+    times_r(br);
+    bn_copy<8>(f.a_m, ar);
+    bn_copy<8>(f.b_m, br);
+    for (size_t i = 0; i < custom_.size(); i++)
+      if (memcmp(&custom_[i], &f, sizeof(f)) == 0) { *out_curve = CURVE_CUSTOM0 + (int)i; return E_OK; }
+    if ((int)custom_.size() >= CURVE_CUSTOM_MAX)
+      return fail(E_UNSUPPORTED, "define_short: at most 8 user-defined curves per context");
+    custom_.push_back(f);
+    *out_curve = CURVE_CUSTOM0 + (int)custom_.size() - 1;
+    return E_OK;
+  }
+  // Brackets one call on a user-defined curve: takes the device's custom-curve lock, uploads the
+  // curve's parameter block (synchronously: every earlier user of the block has finished, see the
+  // destructor) and, at the end, waits for the call's device work before the lock is released.
+  // Nested uses (the host-buffer wrappers call the *_dev forms chunk by chunk) are no-ops.
+  struct CustomScope {
+    Engine* e;
+    bool owner = false;
+    int rc = E_OK;
+    CustomScope(Engine* eng, int curve) : e(eng) {
+      if (!is_custom(curve) || e->custom_active_) return;
+      size_t slot = (size_t)(curve - CURVE_CUSTOM0);
+      if (slot >= e->custom_.size()) { rc = e->fail(E_ARG, "unknown curve id"); return; }
+      custom_mutex(e->bk.device_index()).lock();
+      owner = true;
+      e->custom_active_ = true;
+      e->bk.rt_upload(e->custom_[slot]);
+    }
+    ~CustomScope() {
+      if (!owner) return;
+      e->bk.sync();
+      e->custom_active_ = false;
+      custom_mutex(e->bk.device_index()).unlock();
+    }
+  };
 
   int prepare_curve(int curve) {
 #if defined(ELL_ONLY_CURVE)
@@ -597,9 +712,13 @@ class Engine {
     if (n && (!k || !xy || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
     const size_t B = ci->field_bytes;
     int rc = E_OK;
+    CustomScope sc(this, curve);
+    if (sc.rc) return sc.rc;
     for (size_t o = 0; o < n; o += CHUNK) {
       size_t m = n - o < CHUNK ? n - o : CHUNK;
-      if (curve == CURVE_ED25519)
+      if (is_custom(curve))
+        rc = mul_var_chunk<CvCustom>(m, k + o * B, xy + o * 2 * B, out_xy + o * 2 * B, out_inf + o, nullptr);
+      else if (curve == CURVE_ED25519)
         rc = ed_mul_var_chunk(m, k + o * B, xy + o * 2 * B, out_xy + o * 2 * B, out_inf + o, nullptr);
       else
         ELL_SHORT_DISPATCH(curve, rc = mul_var_chunk<CV>(m, k + o * B, xy + o * 2 * B,
@@ -617,12 +736,19 @@ class Engine {
       return fail(E_UNSUPPORTED, "Not supported on Montgomery curve");     // mont.js:155-157
     if (n && (!k1 || !k2 || !xy2 || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
     int rc = E_OK;
+    if (is_custom(curve) && !xy1)
+      return fail(E_UNSUPPORTED, "user-defined curves have no fixed-base table: pass the generator as p1");
     if (!xy1) { rc = prepare_curve(curve); if (rc) return rc; }
     const size_t B = ci->field_bytes;
+    CustomScope sc(this, curve);
+    if (sc.rc) return sc.rc;
     for (size_t o = 0; o < n; o += CHUNK) {
       size_t m = n - o < CHUNK ? n - o : CHUNK;
       const u8* p1 = xy1 ? xy1 + o * 2 * B : nullptr;
-      if (curve == CURVE_ED25519)
+      if (is_custom(curve))
+        rc = mul_add2_chunk<CvCustom>(m, k1 + o * B, p1, k2 + o * B, xy2 + o * 2 * B, out_xy + o * 2 * B,
+                                      out_inf + o);
+      else if (curve == CURVE_ED25519)
         rc = ed_mul_add2_chunk(m, k1 + o * B, p1, k2 + o * B, xy2 + o * 2 * B, out_xy + o * 2 * B,
                                out_inf + o);
       else
@@ -1052,11 +1178,15 @@ class Engine {
     if (n && (!xy1 || !xy2 || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
     const size_t B = ci->field_bytes;
     int rc = E_OK;
+    CustomScope sc(this, curve);
+    if (sc.rc) return sc.rc;
     for (size_t o = 0; o < n; o += CHUNK) {
       size_t m = n - o < CHUNK ? n - o : CHUNK;
       const u8* i1 = inf1 ? inf1 + o : nullptr;
       const u8* i2 = inf2 ? inf2 + o : nullptr;
-      if (curve == CURVE_ED25519)
+      if (is_custom(curve))
+        rc = point_add_chunk<CvCustom>(m, xy1 + o * 2 * B, i1, xy2 + o * 2 * B, i2, out_xy + o * 2 * B, out_inf + o);
+      else if (curve == CURVE_ED25519)
         rc = ed_point_add_chunk(m, xy1 + o * 2 * B, i1, xy2 + o * 2 * B, i2, out_xy + o * 2 * B, out_inf + o);
       else
         ELL_SHORT_DISPATCH(curve, rc = point_add_chunk<CV>(m, xy1 + o * 2 * B, i1, xy2 + o * 2 * B, i2,
@@ -1071,6 +1201,8 @@ class Engine {
     if (!ci) return fail(E_ARG, "unknown curve id");
     if (n && (!xy1 || !xy2 || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
     const size_t B = ci->field_bytes;
+    CustomScope sc(this, curve);
+    if (sc.rc) return sc.rc;
     u8* d1 = out_buf(G_IN0, n * 2 * B);
     u8* d2 = out_buf(G_IN1, n * 2 * B);
     u8* di1 = inf1 ? out_buf(G_IN2, n) : nullptr;
@@ -1296,6 +1428,8 @@ class Engine {
     if (!ci) return fail(E_ARG, "unknown curve id");
     if (n && (!k || !xy || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
     size_t B = ci->field_bytes;
+    CustomScope sc(this, curve);
+    if (sc.rc) return sc.rc;
     u8* dk = out_buf(G_IN0, n * B);
     u8* dp = out_buf(G_IN1, n * 2 * B);
     u8* dxy = out_buf(G_OUT0, n * 2 * B);
@@ -1313,6 +1447,8 @@ class Engine {
     if (!ci) return fail(E_ARG, "unknown curve id");
     if (n && (!k1 || !k2 || !xy2 || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
     size_t B = ci->field_bytes;
+    CustomScope sc(this, curve);
+    if (sc.rc) return sc.rc;
     u8* d1 = out_buf(G_IN0, n * B);
     u8* dp1 = xy1 ? out_buf(G_IN1, n * 2 * B) : nullptr;
     u8* d2 = out_buf(G_IN2, n * B);
@@ -1384,6 +1520,8 @@ class Engine {
   Buf scratch_[2][S_COUNT];   // one scratch arena per compute lane (see pipelined())
   int lane_ = 0;
   Buf staging_[G_COUNT];
+  std::vector<RtField> custom_;  // user-defined curves of this context (id = CURVE_CUSTOM0 + index)
+  bool custom_active_ = false;
 };
 
 // ---- out-of-class definitions of the per-(curve, operation) members: NOT inline, so that

@@ -41,6 +41,16 @@ namespace ell {
                                                         const u8*, const u8*, u8*, u8*);           \
   KW template int Engine<HipBackend>::sign_det_chunk<CV>(size_t, const u8*, int, int, const u8*,   \
                                                          int, u8*, u8*, u8*, u8*);
+// user-defined short curves (CvCustom): scalar multiplication and point addition only
+#define ELL_DECL_CUSTOM(KW)                                                                          \
+  KW template int Engine<HipBackend>::mul_var_chunk<CvCustom>(size_t, const u8*, const u8*, u8*, u8*, \
+                                                              Work<CvCustom>::A*);                   \
+  KW template int Engine<HipBackend>::normalize_chunk<CvCustom>(size_t, const u32*, u8*, u8*,        \
+                                                                Work<CvCustom>::A*);                 \
+  KW template int Engine<HipBackend>::mul_add2_chunk<CvCustom>(size_t, const u8*, const u8*,         \
+                                                               const u8*, const u8*, u8*, u8*);      \
+  KW template int Engine<HipBackend>::point_add_chunk<CvCustom>(size_t, const u8*, const u8*, const u8*, \
+                                                                const u8*, u8*, u8*);
 #define ELL_DECL_ED2(KW)                                                                            \
   KW template int Engine<HipBackend>::ed_decompress_chunk<0>(size_t, const u8*, const u8*, u8*, u8*); \
   KW template int Engine<HipBackend>::ed_codec_chunk<0>(int, size_t, const u8*, int, const u8*, u8*, u8*); \
@@ -77,5 +87,6 @@ ELL_DECL_X(extern)
 ELL_DECL_ED2(extern)
 ELL_DECL_ED3(extern)
 ELL_DECL_ED4(extern)
+ELL_DECL_CUSTOM(extern)
 
 }  // namespace ell

@@ -38,6 +38,10 @@ struct TimedLaunch {
   hipEvent_t e0, e1;
 };
 
+// defined next to `__constant__ RtField g_rt` (inst.hip, group 16): blocking copy of a
+// user-defined curve's parameter block into the current device's constant memory
+int rt_upload_device(const RtField* f);
+
 struct HipBackend {
   int device = 0;
   hipStream_t own = nullptr;       // the context's stream
@@ -80,6 +84,8 @@ struct HipBackend {
     inflight = nullptr;
     note(hipStreamSynchronize(cur ? cur : own));
   }
+  int device_index() const { return device; }
+  void rt_upload(const RtField& f) { note((hipError_t)rt_upload_device(&f)); }
   void note(hipError_t e) {
     if (e != hipSuccess && !last) last = (int)e;
   }

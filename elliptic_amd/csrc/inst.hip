@@ -29,6 +29,13 @@ ELL_DECL_ED0(ELL_NOKW)
 ELL_DECL_ED1(ELL_NOKW)
 #elif ELL_INST_GROUP == 12
 ELL_DECL_X(ELL_NOKW)
+#elif ELL_INST_GROUP == 16
+// the custom-curve kernels and the parameter block they read live in this one code object
+__constant__ RtField g_rt;
+int rt_upload_device(const RtField* f) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rt), f, sizeof(RtField), 0, hipMemcpyHostToDevice);
+}
+ELL_DECL_CUSTOM(ELL_NOKW)
 #else
 #error "unknown ELL_INST_GROUP"
 #endif

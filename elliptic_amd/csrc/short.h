@@ -103,6 +103,19 @@ struct ShortOps {
     J r;
     if constexpr (is_lazy<F>::value && CV::A_KIND == 0) {
       return dbl_lazy<F>(p);
+    } else if constexpr (CV::A_KIND == 1) {
+      // dbl-2007-bl, arbitrary a (user-defined curves; the reference's JPoint#_dbl / dblp,
+      // short.js:802-830, 605-654): 2M + 8S, a = F::curve_a() from the run-time parameter block
+      El xx = F::sqr(p.X);
+      El yy = F::sqr(p.Y);
+      El yyyy = F::sqr(yy);
+      El zz = F::sqr(p.Z);
+      El s = F::template mul_pow2<1>(F::sub(F::sub(F::sqr(F::add(p.X, yy)), xx), yyyy));
+      El m = F::add(F::add(F::template mul_pow2<1>(xx), xx), F::mul(F::curve_a(), F::sqr(zz)));
+      r.X = F::sub(F::sqr(m), F::template mul_pow2<1>(s));
+      r.Z = F::sub(F::sub(F::sqr(F::add(p.Y, p.Z)), yy), zz);
+      r.Y = F::sub(F::mul(m, F::sub(s, r.X)), F::template mul_pow2<3>(yyyy));
+      return r;
     } else if (CV::A_KIND == 0) {
       // dbl-2009-l, a = 0: 2M + 5S.  Statement order = shortest live ranges (Y and Z die
       // first, then X): at most five field elements are live next to a product's own words.

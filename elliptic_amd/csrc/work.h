@@ -179,7 +179,7 @@ struct Work {
 #endif
       r.Z = F::mul(r.Z, zg);
       return r;
-    } else if constexpr (L > 12 && ELL_P521_JTABLE) {
+    } else if constexpr ((L > 12 && ELL_P521_JTABLE) || CV::JTABLE) {
       // (developer switch, see fp.h) plain signed-window ladder over a Jacobian table: the
       // 16 affine slots hold its 8 Jacobian entries
       static_assert(16 * sizeof(A) >= 8 * sizeof(J), "table slot too small");

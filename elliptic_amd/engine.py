@@ -23,6 +23,11 @@ CURVE_ID = {n: i for i, n in enumerate(CURVES)}
 FIELD_BYTES = {"secp256k1": 32, "p192": 24, "p224": 28, "p256": 32, "p384": 48, "p521": 66,
                "ed25519": 32, "curve25519": 32}
 ORDER_BYTES = dict(FIELD_BYTES)
+# user-defined short curves (Context.define_short) are addressed by the integer id the library
+# hands out; their scalars and coordinates are 32 bytes wide whatever the prime's size
+CURVE_CUSTOM0 = 16
+for _i in range(CURVE_CUSTOM0, CURVE_CUSTOM0 + 8):
+    FIELD_BYTES[_i] = ORDER_BYTES[_i] = 32
 
 
 def _u8(a, shape=None):
@@ -90,6 +95,15 @@ class Context:
 
     def synchronize(self):
         self._check(self._lib.ellgpu_ctx_synchronize(self._ctx))
+
+    def define_short(self, p, a, b):
+        """Register y^2 = x^3 + a x + b over the odd prime p < 2^256 (`new curve.short({p, a, b})`
+        with parameters that are no preset, lib/elliptic/curve/short.js:11-24) and return its
+        curve id: valid for mul_var / mul_add2 (both points given) / point_add and their _dev forms."""
+        cid = ctypes.c_int(-1)
+        enc = [int(v % p if i else v).to_bytes(32, "big") for i, v in enumerate((int(p), int(a), int(b)))]
+        self._check(self._lib.ellgpu_curve_define_short(self._ctx, enc[0], enc[1], enc[2], ctypes.byref(cid)))
+        return cid.value
 
     def reserve(self, curve, n):
         self._check(self._lib.ellgpu_ctx_reserve(self._ctx, self._cid(curve), int(n)))

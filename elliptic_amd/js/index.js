@@ -50,6 +50,17 @@ Engine.prototype._id = function _id(curve) {
   return id;
 };
 
+// Register y^2 = x^3 + a x + b over an odd prime p < 2^256 that is none of the presets
+// (`new elliptic.curve.short({p, a, b})`, lib/elliptic/curve/short.js:11-24) and return its curve
+// id: usable with mulBatch (points given), mulAddBatch (both points given) and pointAddBatch, with
+// 32-byte scalars and coordinates.  p, a, b: BN-like (toArray) or 32-byte Buffers.
+Engine.prototype.defineShort = function defineShort(p, a, b) {
+  function buf(v) {
+    return Buffer.isBuffer(v) ? v : Buffer.from(v.toArray('be', 32));
+  }
+  return this.addon.defineShort(this.ctx, buf(p), buf(a), buf(b));
+};
+
 // ---- batch API on flat Buffers (fixed-width big-endian, item-major) ----------
 // scalars: n x B bytes; points: n x 2B bytes (x||y) or null for the generator.
 // -> { xy: Buffer(n x 2B), inf: Buffer(n) }.  out (optional): { xy, inf } Buffers of those sizes to
@@ -336,6 +347,25 @@ function install(elliptic, options) {
       writable: true });
     return d;
   }
+  // A short curve that is no preset still gets its Point#mul / mulAdd / jmulAdd from the device:
+  // run-time prime (<= 256 bits), arbitrary a (the generic `_dbl` / `dblp` of short.js:802-830,
+  // 605-654), no fixed-base table.  options.customCurves === false keeps such curves on the
+  // reference's own code, as do primes wider than 256 bits and a ninth distinct curve.
+  function customDomain(curve) {
+    if (curve._ellgpuCustom !== undefined) return curve._ellgpuCustom;
+    var d = null;
+    if (options && options.customCurves === false) return null;
+    if (curve.type === 'short' && curve.a && curve.b && curve.p.bitLength() <= 256 &&
+        curve.p.isOdd() && curve.p.cmpn(3) > 0) {
+      try {
+        d = { name: 'custom', custom: true, B: 32,
+          id: eng.defineShort(curve.p, curve.a.fromRed(), curve.b.fromRed()) };
+      } catch (e) { d = null; }
+    }
+    Object.defineProperty(curve, '_ellgpuCustom', { value: d, enumerable: false,
+      writable: true });
+    return d;
+  }
   function scalarBuf(k, B) {
     if (!BN.isBN(k) || k.isNeg() || k.byteLength() > B) return null;
     return Buffer.from(k.toArray('be', B));
@@ -353,6 +383,7 @@ function install(elliptic, options) {
       Buffer.from(y.toArray('be', B))]);
   }
   function isG(curve, d, p) {
+    if (d.custom) return false;
     if (curve.type === 'short')
       return !p.inf && p.x.cmp(curve.g.x) === 0 && p.y.cmp(curve.g.y) === 0;
     return p === curve.g;
@@ -379,7 +410,7 @@ function install(elliptic, options) {
   };
 
   function mul1(curve, p, k, origFn, origArgs) {
-    var d = curve.type === 'mont' ? null : domain(curve);
+    var d = curve.type === 'mont' ? null : (domain(curve) || customDomain(curve));
     var kb = d && scalarBuf(k, d.B);
     var pb = kb && affineBuf(curve, p, d.B);
     if (!d || !kb || !pb) { eng.stats.passthrough++; return origFn.apply(curve, origArgs); }
@@ -387,7 +418,7 @@ function install(elliptic, options) {
     return resultPoint(curve, d, r, false);
   }
   function mulAdd(curve, p1, k1, p2, k2, jacobian, origFn, origArgs) {
-    var d = curve.type === 'mont' ? null : domain(curve);
+    var d = curve.type === 'mont' ? null : (domain(curve) || customDomain(curve));
     var b1 = d && scalarBuf(k1, d.B);
     var b2 = b1 && scalarBuf(k2, d.B);
     var q1 = b2 && affineBuf(curve, p1, d.B);

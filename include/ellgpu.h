@@ -101,6 +101,21 @@ int ellgpu_group_size(const ellgpu_ctx* ctx);          /* ndev of a group, 1 for
 void ellgpu_ctx_destroy(ellgpu_ctx* ctx);
 int ellgpu_ctx_synchronize(ellgpu_ctx* ctx);
 
+/* User-defined short Weierstrass curve y^2 = x^3 + a x + b over an odd prime p < 2^256 -- the
+ * reference's `new elliptic.curve.short({p, a, b, ...})` (lib/elliptic/curve/short.js:11-24) with
+ * parameters that are none of the presets; p, a, b are 32-byte big-endian (a, b reduced mod p).
+ * Registers the curve with the context (a group: with every member) and returns its id
+ * (>= ELLGPU_CURVE_CUSTOM0, at most 8 per context; defining the same parameters twice returns the
+ * same id).  The id is valid for ellgpu_mul_var / _mul_add2 (both points given) / _point_add and
+ * their _dev forms, with 32-byte scalars and coordinates whatever p's size: Point#mul, mulAdd /
+ * jmulAdd and Point#add with the generic-a doubling of JPoint#_dbl / dblp (short.js:802-830,
+ * 605-654) on the device.  Every other entry point answers ELLGPU_E_UNSUPPORTED for it (the
+ * reference's own JavaScript keeps serving those).  The primality of p is not checked, as the
+ * reference does not check it either. */
+#define ELLGPU_CURVE_CUSTOM0 16
+int ellgpu_curve_define_short(ellgpu_ctx* ctx, const uint8_t* p, const uint8_t* a, const uint8_t* b,
+                              int* out_curve);
+
 /* ---- host-buffer entry points (what the N-API addon binds) -------------- */
 
 /* out[i] = k[i] * G */

@@ -89,6 +89,21 @@ def curve(name):
     return _curves[name]
 
 
+def define_short(name, p, a, b, n, gx, gy):
+    """register a user-defined short curve (arbitrary a: JPoint#_dbl, short.js:802-830) under
+    `name`, 32-byte widths like ellgpu_curve_define_short; usable with mul / mul_mt / mul_add"""
+    if name in _curves:
+        return name
+    lib = load()
+    b32 = lambda v: (ctypes.c_char * 32).from_buffer_copy(int(v).to_bytes(32, "big"))
+    bufs = [b32(p), b32(a % p), b32(b % p), b32(n), b32(gx), b32(gy)]
+    negs = (ctypes.c_int * 4)(0, 0, 0, 0)
+    h = lib.eco_curve_create(32, 32, *[ctypes.addressof(x) for x in bufs], 8, 0, None, None, None,
+                             ctypes.addressof(negs))
+    _curves[name] = (h, 32, 32, bufs)
+    return name
+
+
 def _p(a):
     return None if a is None else a.ctypes.data
 

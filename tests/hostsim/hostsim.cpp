@@ -25,6 +25,8 @@ struct LoopBackend {
   void h2d(void* d, const void* h, size_t bytes) { memcpy(d, h, bytes); }
   void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
   int sync() { return 0; }
+  int device_index() const { return 0; }
+  void rt_upload(const RtField& f) { rt_host_block() = f; }
   void sync_all() {}
   void end_call(bool) {}
   // Engine::pipelined: tiny quantum so that ordinary test batches are cut into several chunks

@@ -498,3 +498,51 @@ def check_sign_golden(ctx, curve):
                 assert ok[i] == 1 and got == (I(c["r"]), I(c["s"]), c["recid"]), (curve, c)
             n_checked += 1
     return n_checked
+
+
+def custom_curves():
+    """tests/golden/custom_short.json (tools/gen_golden_custom.js): user-defined short curves"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "custom_short.json")) as f:
+        return json.load(f)
+
+
+def check_custom_short_golden(ctx, spec):
+    """Point#mul, mulAdd / jmulAdd, Point#add and JPoint#dblp of the reference on a user-defined
+    short curve (run-time prime, arbitrary a) against ellgpu_curve_define_short's curve id."""
+    p, a, b = I(spec["p"]), I(spec["a"]), I(spec["b"])
+    cid = ctx.define_short(p, a, b)
+    assert cid >= 16 and ctx.define_short(p, a, b) == cid            # same parameters, same id
+
+    def xy(list_of_pts):
+        return np.concatenate([ints_to_be([I(q["x"]) for q in list_of_pts], 32),
+                               ints_to_be([I(q["y"]) for q in list_of_pts], 32)], axis=1)
+
+    def want(r):
+        return None if r.get("inf") else (I(r["x"]), I(r["y"]))
+    cases = spec["cases"]
+    mul = [c for c in cases if c["op"] == "mul"]
+    out, inf = ctx.mul_var(cid, ints_to_be([I(c["k"]) for c in mul], 32), xy([c["p"] for c in mul]))
+    for i, c in enumerate(mul):
+        assert _res_from(out, inf, i, 32) == want(c["r"]), ("mul", spec["name"], c)
+    madd = [c for c in cases if c["op"] == "muladd"]
+    out, inf = ctx.mul_add2(cid, ints_to_be([I(c["k1"]) for c in madd], 32), xy([c["p1"] for c in madd]),
+                            ints_to_be([I(c["k2"]) for c in madd], 32), xy([c["p2"] for c in madd]))
+    for i, c in enumerate(madd):
+        assert c["r"] == c["rj"]
+        assert _res_from(out, inf, i, 32) == want(c["r"]), ("muladd", spec["name"], c)
+    add = [c for c in cases if c["op"] == "add"]
+    zero = {"x": "0", "y": "0"}
+    out, inf = ctx.point_add(cid, xy([zero if c["p1"].get("inf") else c["p1"] for c in add]),
+                             xy([zero if c["p2"].get("inf") else c["p2"] for c in add]),
+                             inf1=np.array([1 if c["p1"].get("inf") else 0 for c in add], np.uint8),
+                             inf2=np.array([1 if c["p2"].get("inf") else 0 for c in add], np.uint8))
+    for i, c in enumerate(add):
+        assert _res_from(out, inf, i, 32) == want(c["r"]), ("add", spec["name"], c)
+    # dblp(pow) = 2^pow * P
+    dbl = [c for c in cases if c["op"] == "dblp"]
+    out, inf = ctx.mul_var(cid, ints_to_be([1 << c["pow"] for c in dbl], 32), xy([c["p"] for c in dbl]))
+    for i, c in enumerate(dbl):
+        assert _res_from(out, inf, i, 32) == want(c["r"]), ("dblp", spec["name"], c)
+    return len(mul) + len(madd) + len(add) + len(dbl)

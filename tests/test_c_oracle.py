@@ -114,3 +114,34 @@ def test_c_oracle_edwards_and_montgomery_golden():
             assert inf[i] == 0 and int.from_bytes(out[i].tobytes(), "big") == x, c
         m += 1
     assert m > 5
+
+
+def test_c_oracle_user_defined_curves_golden():
+    """the C restatement's generic-a path (JPoint#_dbl) against the reference's own results on
+    user-defined curves (tests/golden/custom_short.json, tools/gen_golden_custom.js)"""
+    import parity_checks as PC
+    from golden_util import I
+    from elliptic_amd import ints_to_be
+    n_checked = 0
+    for spec in PC.custom_curves():
+        if not spec["n"]:
+            continue
+        name = C.define_short("custom:" + spec["name"], I(spec["p"]), I(spec["a"]), I(spec["b"]), I(spec["n"]),
+                              I(spec["g"]["x"]), I(spec["g"]["y"]))
+        xy = lambda pts: np.concatenate([ints_to_be([I(q["x"]) for q in pts], 32),
+                                         ints_to_be([I(q["y"]) for q in pts], 32)], axis=1)
+        want = lambda r: None if r.get("inf") else (I(r["x"]), I(r["y"]))
+
+        def got(out, inf, i):
+            return None if inf[i] else (int.from_bytes(out[i, :32].tobytes(), "big"), int.from_bytes(out[i, 32:].tobytes(), "big"))
+        mul = [c for c in spec["cases"] if c["op"] == "mul"]
+        out, inf = C.mul(name, ints_to_be([I(c["k"]) for c in mul], 32), xy([c["p"] for c in mul]))
+        for i, c in enumerate(mul):
+            assert got(out, inf, i) == want(c["r"]), (spec["name"], c)
+        madd = [c for c in spec["cases"] if c["op"] == "muladd"]
+        out, inf = C.mul_add(name, ints_to_be([I(c["k1"]) for c in madd], 32), xy([c["p1"] for c in madd]),
+                             ints_to_be([I(c["k2"]) for c in madd], 32), xy([c["p2"] for c in madd]))
+        for i, c in enumerate(madd):
+            assert got(out, inf, i) == want(c["r"]), (spec["name"], c)
+        n_checked += len(mul) + len(madd)
+    assert n_checked > 200

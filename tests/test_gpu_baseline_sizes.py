@@ -168,3 +168,51 @@ def test_device_group_on_gpu(ctx):
         fx1, fi1 = ctx.mul_fixed("secp256k1", s)
         assert np.array_equal(fx, fx1) and np.array_equal(fi, fi1)
         g.close()
+
+
+def test_user_defined_curve_large_batch(ctx):
+    """brainpoolP256r1 as a user-defined curve (ellgpu_curve_define_short: run-time prime,
+    arbitrary a), 2^17 scalar multiplications and 2^16 k1*P1 + k2*P2 with >= 10 240 of each
+    compared with the oracle's generic-a path, a second user-defined curve interleaved (the
+    parameter block is swapped per call), and (n-1)*P == -P over every item."""
+    import parity_checks as PC
+    from golden_util import I
+    specs = {s["name"]: s for s in PC.custom_curves()}
+    sp = specs["brainpoolP256r1"]
+    p, n_ord = I(sp["p"]), I(sp["n"])
+    cid = ctx.define_short(p, I(sp["a"]), I(sp["b"]))
+    s2 = specs["secp192k1"]
+    cid2 = ctx.define_short(I(s2["p"]), I(s2["a"]), I(s2["b"]))
+    name = C.define_short("custom:brainpoolP256r1", p, I(sp["a"]), I(sp["b"]), n_ord, I(sp["g"]["x"]), I(sp["g"]["y"]))
+    name2 = C.define_short("custom:secp192k1", I(s2["p"]), I(s2["a"]), I(s2["b"]), I(s2["n"]), I(s2["g"]["x"]), I(s2["g"]["y"]))
+    n = 1 << 17
+    g = np.frombuffer(I(sp["g"]["x"]).to_bytes(32, "big") + I(sp["g"]["y"]).to_bytes(32, "big"), np.uint8)
+    # points: r_i * G on the device itself (checked through the sample below)
+    pts, pinf = ctx.mul_var(cid, rnd("bl:custom:r", n, 32), np.tile(g, (n, 1)))
+    assert pinf.sum() == 0
+    k = rnd("bl:custom:k", n, 32)
+    xy, inf = ctx.mul_var(cid, k, pts)
+    # the other curve in between: its block replaces brainpool's in constant memory
+    g2 = np.frombuffer(I(s2["g"]["x"]).to_bytes(32, "big") + I(s2["g"]["y"]).to_bytes(32, "big"), np.uint8)
+    k2 = rnd("bl:custom:k2", 4096, 32)
+    xy2, inf2 = ctx.mul_var(cid2, k2, np.tile(g2, (4096, 1)))
+    w2, wi2 = C.mul_mt(name2, k2, np.tile(g2, (4096, 1)), threads())
+    assert np.array_equal(inf2, wi2) and np.array_equal(xy2, w2)
+    idx = sample_idx(n)
+    wp, wpi = C.mul_mt(name, rnd("bl:custom:r", n, 32)[idx], np.tile(g, (len(idx), 1)), threads())
+    assert np.array_equal(pts[idx], wp) and wpi.sum() == 0
+    want, winf = C.mul_mt(name, k[idx], pts[idx], threads())
+    assert np.array_equal(inf[idx], winf) and np.array_equal(xy[idx], want)
+    # (n-1) * P == -P for every item
+    km1 = np.tile(np.frombuffer((n_ord - 1).to_bytes(32, "big"), np.uint8), (n, 1))
+    neg, ninf = ctx.mul_var(cid, km1, pts)
+    assert ninf.sum() == 0 and np.array_equal(neg[:, :32], pts[:, :32])
+    ysum = [int.from_bytes(neg[i, 32:].tobytes(), "big") + int.from_bytes(pts[i, 32:].tobytes(), "big") for i in range(0, n, 997)]
+    assert all(v == p for v in ysum)
+    # k1*P1 + k2*P2
+    m = 1 << 16
+    ka, kb = rnd("bl:custom:ka", m, 32), rnd("bl:custom:kb", m, 32)
+    out, oinf = ctx.mul_add2(cid, ka, pts[:m], kb, pts[m:2 * m])
+    idx = sample_idx(m)
+    want, winf = C.mul_add(name, ka[idx], pts[:m][idx], kb[idx], pts[m:2 * m][idx])
+    assert np.array_equal(oinf[idx], winf) and np.array_equal(out[idx], want)

@@ -381,3 +381,12 @@ def test_chunk_boundary(ctx):
     for i in (0, (1 << 21) - 1, 1 << 21, n - 1):
         w = cur.g.mul(int.from_bytes(raw[i].tobytes(), "big")).mul(int.from_bytes(k[i].tobytes(), "big"))
         assert (int.from_bytes(out[i, :32].tobytes(), "big"), int.from_bytes(out[i, 32:].tobytes(), "big")) == (w.x, w.y)
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_user_defined_short_curves_gpu(ctx, idx):
+    """`new curve.short({p, a, b})` with parameters that are no preset (the
+    generic-a `_dbl` / `dblp`): Point#mul, mulAdd / jmulAdd, Point#add against the reference's
+    results (tests/golden/custom_short.json)"""
+    spec = PC.custom_curves()[idx]
+    assert PC.check_custom_short_golden(ctx, spec) > 80

@@ -470,3 +470,26 @@ def test_lazy_field_two_product_and_half(hs):
             r = (ctypes.c_uint32 * 8)()
             assert hs.hs_field_op(2, op, _limbs(x, 8), _limbs(y, 8), r) == 0
             assert _val(r) == want, (op, hex(x), hex(y))
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_user_defined_short_curves(ctx, idx):
+    """`new curve.short({p, a, b})` with parameters that are no preset: run-time modulus, generic-a
+    doubling (CvCustom / FpMontRT) against the reference's results"""
+    spec = PC.custom_curves()[idx]
+    assert PC.check_custom_short_golden(ctx, spec) > 80
+
+
+def test_user_defined_curve_errors(ctx):
+    import elliptic_amd
+    with pytest.raises(elliptic_amd._lib.EllgpuError):
+        ctx.define_short(2 ** 200, 1, 1)                     # even modulus
+    with pytest.raises(elliptic_amd._lib.EllgpuError):
+        ctx.define_short(3, 1, 1)
+    cid = ctx.define_short(PC.I(PC.custom_curves()[2]["p"]), 5, 7)
+    k = np.zeros((1, 32), np.uint8)
+    with pytest.raises(elliptic_amd._lib.EllgpuError) as e:
+        ctx.mul_fixed(cid, k)
+    assert e.value.code == -5                                # ELLGPU_E_UNSUPPORTED
+    with pytest.raises(elliptic_amd._lib.EllgpuError):
+        ctx.mul_var(23, k, np.zeros((1, 64), np.uint8))        # an id nobody defined

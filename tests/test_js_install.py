@@ -91,12 +91,15 @@ def test_patched_api_matches_goldens_including_exception_messages():
 
 
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
-def test_custom_generator_curves_pass_through():
-    """a curve over a preset's field with ANOTHER generator (or none) must not reach the engine,
-    whose tables belong to the preset's G and n: results equal the unpatched reference"""
+@pytest.mark.parametrize("custom", ["0", "1"])
+def test_custom_generator_curves_pass_through(custom):
+    """a curve over a preset's field with ANOTHER generator (or none) must not be served from the
+    preset's tables, which belong to the preset's G and n: with customCurves off it
+    stays on the reference's code, by default it takes the device's user-defined-curve path;
+    results equal the unpatched reference either way"""
     _addon()
     from hostsim.build import build as build_hostsim
-    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference(), ELLGPU_LIB=build_hostsim())
+    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference(), ELLGPU_LIB=build_hostsim(), ELLGPU_CUSTOM=custom)
     p = subprocess.run(["node", os.path.join(ROOT, "tools", "check_custom_generator.js")], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
@@ -117,6 +120,21 @@ def test_reference_suite_passes_with_install_patch_gpu():
 def test_patched_api_matches_goldens_including_exception_messages_gpu():
     _addon()
     _run_replay(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_user_defined_curves_through_install_gpu():
+    """custom-generator / generator-less curves through install() on the real library: the
+    user-defined-curve kernels (run-time prime, generic-a doubling) against the unpatched reference"""
+    _addon()
+    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
+    env.pop("ELLGPU_LIB", None)
+    p = subprocess.run(["node", os.path.join(ROOT, "tools", "check_custom_generator.js")], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["checked"] >= 30 and out["custom"] is True
 
 
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")

@@ -1,12 +1,17 @@
 'use strict';
-// install() must leave curves that only SHARE a preset's field to the reference's own code:
-// same p, a, b as secp256k1 / p256 / ed25519 but another generator (or none at all).  The
-// patched library's results are compared with an unpatched copy of the reference.
-//   ELLGPU_LIB=<hostsim or real library> node tools/check_custom_generator.js
+// install() must not serve curves that only SHARE a preset's field from the preset's tables:
+// same p, a, b as secp256k1 / p256 but another generator (or none at all).  Such a curve is a
+// user-defined curve: with options.customCurves === false it stays on the reference's own code
+// (no engine call at all), by default it runs on the device's generic path (run-time prime, no
+// fixed-base table, no GLV).  Either way the patched library's results are compared with an
+// unpatched copy of the reference.
+//   ELLGPU_LIB=<hostsim or real library> [ELLGPU_CUSTOM=0] node tools/check_custom_generator.js
 var loader = require('./ref_loader');
 var plain = loader.load().elliptic;          // unpatched
 var patched = loader.load().elliptic;        // a second, independent copy -> patched
-var eng = require('../elliptic_amd/js').install(patched, { libPath: process.env.ELLGPU_LIB });
+var CUSTOM = process.env.ELLGPU_CUSTOM !== '0';
+var eng = require('../elliptic_amd/js').install(patched, { libPath: process.env.ELLGPU_LIB,
+  customCurves: CUSTOM });
 var BN = plain.curves.secp256k1.curve.p.constructor;
 var checked = 0;
 
@@ -50,10 +55,15 @@ function same(a, b, what) {
   var np = build(plain, false), nq = build(patched, false);
   var x = ref.g.getX().toString(16), y = ref.g.getY().toString(16);
   same(nq.point(x, y).mul(new BN('c0ffee', 16)), np.point(x, y).mul(new BN('c0ffee', 16)), name + ' no generator');
-  if (eng.stats.gpuCalls !== before) throw new Error(name + ': a custom-generator curve reached the engine');
+  if (!CUSTOM && eng.stats.gpuCalls !== before)
+    throw new Error(name + ': a custom-generator curve reached the engine');
+  if (CUSTOM && eng.stats.gpuCalls === before)
+    throw new Error(name + ': the user-defined curve did not reach the engine');
+  if (CUSTOM && (cq._ellgpu !== null || !cq._ellgpuCustom || cq._ellgpuCustom.id < 16))
+    throw new Error(name + ': a custom-generator curve was taken for the preset');
 });
 // the presets themselves still go to the engine
 var b0 = eng.stats.gpuCalls;
 same(patched.curves.secp256k1.curve.g.mul(new BN(5)), plain.curves.secp256k1.curve.g.mul(new BN(5)), 'preset');
 if (eng.stats.gpuCalls === b0) throw new Error('the preset did not reach the engine');
-console.log(JSON.stringify({ ok: true, checked: checked, engine: eng.stats }));
+console.log(JSON.stringify({ ok: true, custom: CUSTOM, checked: checked, engine: eng.stats }));
