@@ -32,6 +32,9 @@
 #ifndef ELL_MULVAR_MIN_WAVES
 #define ELL_MULVAR_MIN_WAVES 4
 #endif
+#ifndef ELL_CUSTOM_MIN_WAVES
+#define ELL_CUSTOM_MIN_WAVES 3      // user-defined curves (Jacobian window table, generic-a doubling)
+#endif
 #ifndef ELL_ECDSA_MIN_WAVES
 #define ELL_ECDSA_MIN_WAVES 3
 #endif
@@ -50,7 +53,7 @@ struct FnMulVar {
   static constexpr const char* NAME = "mul_var";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
-  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? ELL_MULVAR_MIN_WAVES : (W::L == 12 ? ELL_P384_MIN_WAVES : 1));   // <= 128 VGPRs for 256-bit curves: +2..4 % despite ~50 B of spills
+  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? (CV::JTABLE ? ELL_CUSTOM_MIN_WAVES : ELL_MULVAR_MIN_WAVES) : (W::L == 12 ? ELL_P384_MIN_WAVES : 1));   // <= 128 VGPRs for 256-bit curves: +2..4 % despite ~50 B of spills
   size_t n; const u8* k; const u8* xy; typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) W::mul_var(i, n, k, xy, tbl, ds, jac);
