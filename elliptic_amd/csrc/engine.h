@@ -1069,8 +1069,6 @@ class Engine {
     if (n && (!enc || !out_xy || !out_status)) return fail(E_ARG, "null pointer");
     const size_t B = ci->field_bytes;
     if (curve == CURVE_ED25519 && enc_len != 32) return fail(E_ARG, "ed25519 encodings are 32 bytes");
-    if (curve == CURVE_P224 && enc_len == 1 + B)
-      return fail(E_UNSUPPORTED, "point decompression needs p = 3 (mod 4) (not p224)");
     if (enc_len == 0) return fail(E_ARG, "enc_len must be positive");
     int rc = E_OK;
     for (size_t o = 0; o < n; o += CHUNK) {
@@ -1778,7 +1776,7 @@ template <class BK>
 template <class CV>
 int Engine<BK>::decompress_chunk(size_t n, const u8* x, const u8* odd, u8* out_xy, u8* out_ok) {
   if constexpr (!CV::F::HAS_SQRT) {
-    return fail(E_UNSUPPORTED, "point decompression needs p = 3 (mod 4) (not p224)");
+    return fail(E_UNSUPPORTED, "point decompression is not available in this field");
   } else {
     FnDecompress<CV> f{n, x, odd, out_xy, out_ok};
     bk.launch(f, n);
@@ -1861,7 +1859,7 @@ template <class CV>
 int Engine<BK>::recover_chunk(size_t n, const u8* hash, int hash_len, const u8* r, const u8* s,
                               const u8* recid, u8* out_xy, u8* out_status) {
   if constexpr (!CV::F::HAS_SQRT) {
-    return fail(E_UNSUPPORTED, "public-key recovery needs point decompression: p = 3 (mod 4) (not p224)");
+    return fail(E_UNSUPPORTED, "public-key recovery needs point decompression, which this field does not have");
   } else {
     typedef Work<CV> W;
     const size_t B = W::BYTES, NB = W::NBYTES;

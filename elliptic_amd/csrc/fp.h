@@ -932,7 +932,8 @@ struct FpSolinas {
   typedef typename R::MP MP;
   static constexpr int L = MP::L;
   typedef Fe<MP::L> El;
-  static constexpr bool HAS_SQRT = MP::P3MOD4;
+  // p = 3 (mod 4): one exponentiation; p224 (the only other prime here, L == 7): Tonelli-Shanks
+  static constexpr bool HAS_SQRT = MP::P3MOD4 || L == 7;
 
   ELL_HD static void get_p(u32 (&p)[L]) {
     ELL_UNROLL
@@ -1065,7 +1066,58 @@ struct FpSolinas {
     SafeGcd<MP>::inv(r.v, a.v);
     return r;
   }
-  static ELL_HD_NOINLINE El sqrt(const El& a) { return pow_const_window<FpSolinas<R>, L>(a, MP::pp1d4); }
+  // Square root modulo p224 = 2^96 (2^128 - 1) + 1, where bn.js takes its generic Tonelli-Shanks
+  // loop (Red#sqrt, dist/elliptic.js:7259-7311).  Same algorithm with the data-dependent inner
+  // search replaced by a fixed schedule, so that all lanes run the same instructions: with
+  // q = 2^128 - 1, x = a^((q+1)/2), b = a^q and c = 11^q (11 = the least non-residue; c generates the
+  // 2^96 roots of unity), step k = 0..94 clears bit k of b's discrete logarithm:
+  //     if b^(2^(94-k)) != 1:  x *= c, b *= c^2;      c = c^2        (x^2 == a b throughout)
+  // 4.5 k squarings + 0.2 k multiplications.  For a non-residue the result is garbage and the
+  // caller's x^2 == a test fails (the reference: 'Assertion failed' out of the loop's
+  // assert(i < m)).  Any root will do: every caller fixes the parity afterwards.
+  ELL_HD static El sqrt_ts224(const El& a) {
+    static_assert(L == 7 || MP::P3MOD4, "Tonelli-Shanks constants are p224's");
+    // a^(2^127 - 1): 126 S + 12 M over exponents 2^n - 1
+    El e1 = a;
+    El e2 = mul(sqr(e1), e1);
+    El e3 = mul(sqr(e2), e1);
+    El e6 = mul(sqr_n(e3, 3), e3);
+    El e7 = mul(sqr(e6), e1);
+    El e14 = mul(sqr_n(e7, 7), e7);
+    El e15 = mul(sqr(e14), e1);
+    El e30 = mul(sqr_n(e15, 15), e15);
+    El e31 = mul(sqr(e30), e1);
+    El e62 = mul(sqr_n(e31, 31), e31);
+    El e63 = mul(sqr(e62), e1);
+    El e126 = mul(sqr_n(e63, 63), e63);
+    El t = mul(sqr(e126), e1);
+    El x = mul(a, t);
+    El b = mul(x, t);
+    El c = zero();
+    constexpr u32 C0[7] = {0xDC691B74u, 0xF3FB3632u, 0xBEA3D8CEu, 0x0B2D6FFBu, 0x0C55B2D4u, 0x8598A792u, 0x6A0FEC67u};
+    ELL_UNROLL
+    for (int i = 0; i < 7 && i < L; i++) c.v[i] = C0[i];
+    const El o = one();
+    ELL_NOUNROLL
+    for (int k = 0; k <= 94; k++) {
+      El w = sqr_n(b, 94 - k);
+      bool hit = !eq(w, o);
+      El c2 = sqr(c);
+      El xc = mul(x, c);
+      El bc = mul(b, c2);
+      ELL_UNROLL
+      for (int i = 0; i < L; i++) {
+        x.v[i] = hit ? xc.v[i] : x.v[i];
+        b.v[i] = hit ? bc.v[i] : b.v[i];
+      }
+      c = c2;
+    }
+    return x;
+  }
+  static ELL_HD_NOINLINE El sqrt(const El& a) {
+    if constexpr (MP::P3MOD4) return pow_const_window<FpSolinas<R>, L>(a, MP::pp1d4);
+    else return sqrt_ts224(a);
+  }
 };
 
 // fold rules B^L == sum_f fold_sign[f] * B^fold_pos[f]  (B = 2^32), positions listed highest first;

@@ -346,7 +346,9 @@ struct Work {
     } else if ((tag == 2 || tag == 3) && len == 1 + (size_t)BYTES) {
       if constexpr (F::HAS_SQRT) {
         x = load_fe(e + 1);
-        st = lift_x(y, x, tag == 3) ? DECODE_OK : DECODE_INVALID;
+        // no y for this x: 'invalid point' (short.js:196-197) -- except over p224, where bn.js's
+        // Tonelli-Shanks loop gives up first ('Assertion failed', dist/elliptic.js:7296)
+        st = lift_x(y, x, tag == 3) ? DECODE_OK : (CV::ID == CURVE_P224 ? DECODE_ASSERT : DECODE_INVALID);
         if (st != DECODE_OK) { x = F::zero(); y = F::zero(); }
       }
     }

@@ -462,7 +462,7 @@ function install(elliptic, options) {
     var d = domain(this);
     var xb = new BN(x, 16);
     if (xb.red) xb = xb.fromRed();
-    if (!d || d.name === 'p224' || xb.isNeg() || xb.byteLength() > d.B) {
+    if (!d || xb.isNeg() || xb.byteLength() > d.B) {
       eng.stats.passthrough++;
       return orig.pointFromX.apply(this, arguments);
     }
@@ -486,7 +486,7 @@ function install(elliptic, options) {
   };
 
   // EC#recoverPubKey (ec/index.js:231-259): decompression of R, r^-1, both scalars and
-  // s1*G + s2*R in one call.  Anything the engine does not take (p224, toy curves, r outside
+  // s1*G + s2*R in one call.  Anything the engine does not take (toy curves, r outside
   // [1, n), digests longer than twice the order, non-byte messages) and every case where the
   // reference throws is run by the reference's own method, so results and exceptions are its own.
   var ecProto = elliptic.ec.prototype;
@@ -526,7 +526,7 @@ function install(elliptic, options) {
     var d = domain(this.curve);
     var e, r, s, NB;
     try {
-      if (!d || d.name === 'p224' || (3 & j) !== j) throw null;
+      if (!d || (3 & j) !== j) throw null;
       // the reference's Signature class is not exported; {r, s} objects (which include its own
       // instances) are decoded as it does (signature.js:20-21), DER input goes to the reference
       if (!signature || signature.r === undefined || signature.s === undefined) throw null;

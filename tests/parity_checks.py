@@ -219,16 +219,6 @@ def check_codec_golden(ctx, curve):
     for c in g["decode"]:
         groups.setdefault(len(c["enc"]) // 2, []).append(c)
     for ln, cs in sorted(groups.items()):
-        if curve == "p224" and ln == 1 + B:
-            # compressed p224 stays in JavaScript (p = 1 mod 4): the library says so, loudly
-            enc = np.frombuffer(b"".join(bytes.fromhex(c["enc"]) for c in cs), np.uint8).reshape(-1, ln)
-            try:
-                ctx.decode_points(curve, enc)
-            except Exception as e:                     # noqa: BLE001
-                assert "p224" in str(e)
-            else:
-                raise AssertionError("compressed p224 must be refused")
-            continue
         enc = np.frombuffer(b"".join(bytes.fromhex(c["enc"]) for c in cs), np.uint8).reshape(-1, ln)
         xy, st = ctx.decode_points(curve, enc)
         for i, c in enumerate(cs):
@@ -284,8 +274,6 @@ def check_wire_golden(ctx, curve):
     for (klen, zlen), cs in sorted(groups.items()):
         if klen == 0:
             continue
-        if curve == "p224" and klen == 1 + FIELD_BYTES[curve]:
-            continue                                  # compressed p224 keys stay in JavaScript
         z = np.frombuffer(b"".join(bytes.fromhex(c["z"]) for c in cs), np.uint8).reshape(-1, zlen)
         keys = np.frombuffer(b"".join(bytes.fromhex(c["key"]) for c in cs), np.uint8).reshape(-1, klen)
         ok, err = ctx.ecdsa_verify_wire(curve, z, [bytes.fromhex(c["der"]) for c in cs], keys)

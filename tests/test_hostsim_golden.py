@@ -201,10 +201,8 @@ def test_decompress_golden(ctx, curve):
     assert PC.check_decompress_golden(ctx, curve) > 40
 
 
-def test_decompress_unsupported(ctx):
-    with pytest.raises(elliptic_amd.EllgpuError) as e:
-        ctx.decompress("p224", np.zeros((1, 28), np.uint8), np.zeros(1, np.uint8))
-    assert e.value.code == -5
+def test_decompress_p224_tonelli_shanks(ctx):
+    assert PC.check_decompress_golden(ctx, "p224") > 40
 
 
 @pytest.mark.parametrize("curve", O.SHORT_CURVES)
@@ -251,11 +249,9 @@ def test_der_fuzz(ctx):
     assert PC.check_der_fuzz(ctx) > 2000
 
 
-def test_recover_unsupported(ctx):
-    with pytest.raises(elliptic_amd.EllgpuError) as e:
-        ctx.ecdsa_recover("p224", np.zeros((1, 28), np.uint8), np.ones((1, 28), np.uint8), np.ones((1, 28), np.uint8),
-                          np.zeros(1, np.uint8))
-    assert e.value.code == -5
+def test_recover_p224_tonelli_shanks(ctx):
+    """p224 (p = 1 mod 4) recovers through the device's Tonelli-Shanks square root"""
+    assert PC.check_recover_golden(ctx, "p224") > 20
 
 
 def test_eddsa_sign_golden(ctx):
