@@ -238,6 +238,7 @@ struct EdWork {
   // x with the requested parity.  ok = 0 when there is no such point -- also for the
   // reference's two throwing corner cases: x = 0 with odd requested, and d y^2 + 1 == 0.
   ELL_HD static void decompress(size_t i, const u8* ys, const u8* odd, u8* out_xy, u8* out_ok) {
+    if (odd[i] & 2u) { from_x(i, ys, odd, out_xy, out_ok); return; }
     El y = load_fe(ys + i * 32);
     El d;
     ELL_UNROLL
@@ -247,12 +248,34 @@ struct EdWork {
     El v = F::add(F::mul(y2, d), F::one());
     El x;
     bool ok = F::sqrt_ratio(x, u, v);
-    bool want_odd = odd[i] != 0;
+    bool want_odd = (odd[i] & 1u) != 0;
     bool xzero = F::is_zero(x);
     ok = ok && !F::is_zero(v) && !(xzero && want_odd);
     bool is_odd = (x.v[0] & 1u) != 0;
     El xn = F::neg(x);
     bn_select<8>(x.v, is_odd != want_odd, xn.v, x.v);
+    if (!ok) { x = F::zero(); y = F::zero(); }
+    store_be<8>(out_xy + i * 64, x.v, 32);
+    store_be<8>(out_xy + i * 64 + 32, y.v, 32);
+    out_ok[i] = ok ? 1 : 0;
+  }
+  // EdwardsCurve#pointFromX (edwards.js:50-69, c = 1, a = -1): y^2 = (1 + x^2)/(1 - d x^2), y with
+  // the requested parity (no special case for y = 0: -0 = 0 is what redNeg gives).  1 - d x^2
+  // is never 0 (d is not a square).  ok = 0 where the reference throws 'invalid point'.
+  ELL_HD static void from_x(size_t i, const u8* xs, const u8* odd, u8* out_xy, u8* out_ok) {
+    El x = load_fe(xs + i * 32);
+    El d;
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++) d.v[l] = C::d[l];
+    El x2 = F::sqr(x);
+    El u = F::add(F::one(), x2);
+    El v = F::sub(F::one(), F::mul(x2, d));
+    El y;
+    bool ok = F::sqrt_ratio(y, u, v);
+    bool want_odd = (odd[i] & 1u) != 0;
+    bool is_odd = (y.v[0] & 1u) != 0;
+    El yn = F::neg(y);
+    bn_select<8>(y.v, is_odd != want_odd, yn.v, y.v);
     if (!ok) { x = F::zero(); y = F::zero(); }
     store_be<8>(out_xy + i * 64, x.v, 32);
     store_be<8>(out_xy + i * 64 + 32, y.v, 32);

@@ -428,6 +428,35 @@ function install(elliptic, options) {
     return resultPoint(curve, d, r, jacobian);
   }
 
+  // sum_i k_i * P_i for 3..8 points (the general form of _wnafMulAdd, base.js:128-253 -- even
+  // counts only, as in the reference -- and of _endoWnafMulAdd, short.js:218-249; the reference's
+  // own callers pass at most two points): the points
+  // are paired up, every pair is one item of ONE k1*P1 + k2*P2 launch, and the partial sums are
+  // added with the reference's Point#add.
+  function mulAddMany(curve, points, coeffs, len, jacobian, origFn, origArgs) {
+    var d = curve.type === 'mont' ? null : (domain(curve) || customDomain(curve));
+    var k1 = [], p1 = [], k2 = [], p2 = [];
+    var ok = !!d && len >= 3 && len <= 8;
+    for (var i = 0; ok && i < len; i += 2) {
+      var j = i + 1 < len ? i + 1 : i;               // odd tail: k * P + 0 * P
+      var a = scalarBuf(coeffs[i], d.B), pa = affineBuf(curve, points[i], d.B);
+      var b = j === i ? Buffer.alloc(d.B) : scalarBuf(coeffs[j], d.B);
+      var pb = affineBuf(curve, points[j], d.B);
+      if (!a || !pa || !b || !pb) { ok = false; break; }
+      k1.push(a); p1.push(pa); k2.push(b); p2.push(pb);
+    }
+    if (!ok) { eng.stats.passthrough++; return origFn.apply(curve, origArgs); }
+    var r = eng.mulAddBatch(d.id, Buffer.concat(k1), Buffer.concat(p1), Buffer.concat(k2),
+      Buffer.concat(p2));
+    var acc = null;
+    for (var t = 0; t < k1.length; t++) {
+      var pt = resultPoint(curve, d, { xy: r.xy.slice(t * 2 * d.B, (t + 1) * 2 * d.B),
+        inf: r.inf.slice(t, t + 1) }, false);
+      acc = acc ? acc.add(pt) : pt;
+    }
+    return jacobian && acc.toJ ? acc.toJ() : acc;
+  }
+
   base._fixedNafMul = function _fixedNafMul(p, k) {
     return mul1(this, p, k, orig.fixedNafMul, arguments);
   };
@@ -436,6 +465,9 @@ function install(elliptic, options) {
   };
   base._wnafMulAdd = function _wnafMulAdd(defW, points, coeffs, len,
     jacobianResult) {
+    // (an odd len > 1 never worked in the reference: its pairing loop leaves naf[0] unset)
+    if (len > 2 && len % 2 === 0)
+      return mulAddMany(this, points, coeffs, len, !!jacobianResult, orig.wnafMulAdd, arguments);
     if (len !== 2) { eng.stats.passthrough++; return orig.wnafMulAdd.apply(this, arguments); }
     return mulAdd(this, points[0], coeffs[0], points[1], coeffs[1], !!jacobianResult,
       orig.wnafMulAdd, arguments);
@@ -449,8 +481,8 @@ function install(elliptic, options) {
     if (points.length === 2)
       return mulAdd(this, points[0], coeffs[0], points[1], coeffs[1],
         !!jacobianResult, orig.endoWnafMulAdd, arguments);
-    eng.stats.passthrough++;
-    return orig.endoWnafMulAdd.apply(this, arguments);
+    return mulAddMany(this, points, coeffs, points.length, !!jacobianResult,
+      orig.endoWnafMulAdd, arguments);
   };
 
   // point decompression: ShortCurve#pointFromX (short.js:187-204) and
@@ -482,6 +514,21 @@ function install(elliptic, options) {
     }
     var r = eng.decompressBatch(d.id, Buffer.from(yb.toArray('be', d.B)), Buffer.from([odd ? 1 : 0]));
     if (!r.ok[0]) return orig.pointFromY.apply(this, arguments);      // throws as the reference does
+    return this.point(new BN(r.xy.slice(0, d.B)), new BN(r.xy.slice(d.B, 2 * d.B)));
+  };
+
+  // EdwardsCurve#pointFromX (edwards.js:50-69): bit 1 of the parity byte selects it on the device
+  orig.edPointFromX = edw.pointFromX;
+  edw.pointFromX = function pointFromX(x, odd) {
+    var d = domain(this);
+    var xb = new BN(x, 16);
+    if (xb.red) xb = xb.fromRed();
+    if (!d || xb.isNeg() || xb.byteLength() > d.B) {
+      eng.stats.passthrough++;
+      return orig.edPointFromX.apply(this, arguments);
+    }
+    var r = eng.decompressBatch(d.id, Buffer.from(xb.toArray('be', d.B)), Buffer.from([odd ? 3 : 2]));
+    if (!r.ok[0]) return orig.edPointFromX.apply(this, arguments);    // throws as the reference does
     return this.point(new BN(r.xy.slice(0, d.B)), new BN(r.xy.slice(d.B, 2 * d.B)));
   };
 
@@ -617,6 +664,7 @@ function install(elliptic, options) {
     ecProto.recoverPubKey = orig.recoverPubKey;
     ecProto.sign = orig.sign;
     edw.pointFromY = orig.pointFromY;
+    edw.pointFromX = orig.edPointFromX;
   };
 
   // EC#verify over many signatures with the reference's own decoding

@@ -148,9 +148,11 @@ int ellgpu_x25519_ladder(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint
  * (lib/elliptic/curve/short.js:187-204) -- v[i] is the abscissa, the result has
  * y = sqrt(x^3 + a x + b) with parity odd[i] (SEC1 02/03 prefixes: odd = prefix & 1,
  * base.js:283-289).  ed25519: EdwardsCurve#pointFromY (edwards.js:71-97) -- v[i] is y, the
- * result has the x of parity odd[i].  out_ok[i] = 0 (x||y zeroed) where the reference
- * throws 'invalid point'.  Needs p = 3 (mod 4) on short curves: p224 returns
- * ELLGPU_E_UNSUPPORTED (the reference's generic Tonelli-Shanks stays in JavaScript). */
+ * result has the x of parity odd[i] & 1; with bit 1 of odd[i] set (odd[i] = 2 or 3) the item is
+ * EdwardsCurve#pointFromX instead (edwards.js:50-69): v[i] is x, the result has the y of parity
+ * odd[i] & 1.  out_ok[i] = 0 (x||y zeroed) where the reference throws: 'invalid point', or --
+ * over p224 (p = 1 mod 4), whose square root is bn.js's Tonelli-Shanks loop, run here on a
+ * fixed schedule -- 'Assertion failed' out of that loop (dist/elliptic.js:7296). */
 int ellgpu_decompress(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, const uint8_t* odd,
                       uint8_t* out_xy, uint8_t* out_ok);
 int ellgpu_decompress_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, const uint8_t* odd,
@@ -164,8 +166,9 @@ int ellgpu_decompress_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v
  *     -> pointFromX).  status 0 = point; 1 = 'Unknown point format' (prefix does not fit
  *     enc_len); 2 = 'invalid point' (no y for that x); 3 = 'Assertion failed' (hybrid prefix
  *     contradicts y's last bit, base.js:279-282).  As in the reference an uncompressed point
- *     is NOT checked against the curve equation -- that is ellgpu_validate.  Compressed
- *     encodings on p224 return ELLGPU_E_UNSUPPORTED (see ellgpu_decompress).
+ *     is NOT checked against the curve equation -- that is ellgpu_validate.  A compressed
+ *     p224 encoding without a y has status 3, not 2: the reference's 'Assertion failed' out of
+ *     bn.js's Tonelli-Shanks loop (see ellgpu_decompress).
  *   ed25519: EDDSA#decodePoint (lib/elliptic/eddsa/index.js:99-109), enc_len = 32: little-endian
  *     y with x's parity in the top bit.  status 0 / 2.
  * ellgpu_encode_points: affine x||y -> BasePoint#encode (base.js:295-311): compact = 0 gives

@@ -126,6 +126,26 @@ def check_decompress_golden(ctx, curve):
     return len(cases)
 
 
+def check_ed_from_x_golden(ctx):
+    """EdwardsCurve#pointFromX goldens (tools/gen_golden.js genEdFromX) through ellgpu_decompress
+    with bit 1 of the parity byte set"""
+    from golden_util import load
+    cases = load("fromx_ed25519.json")
+    v = ints_to_be([I(c["v"]) % (1 << 256) for c in cases], 32)
+    odd = np.array([3 if c["odd"] else 2 for c in cases], np.uint8)
+    out, ok = ctx.decompress("ed25519", v, odd)
+    n_inv = 0
+    for i, c in enumerate(cases):
+        if "invalid" in c["r"]:
+            assert ok[i] == 0 and not out[i].any(), c
+            n_inv += 1
+        else:
+            assert ok[i] == 1, c
+            assert out[i].tobytes().hex() == c["r"]["x"] + c["r"]["y"], c
+    assert n_inv > 10
+    return len(cases)
+
+
 def check_eddsa_golden(ctx):
     """EDDSA#verify goldens: the reference's sign.input vectors + corrupted / malformed ones"""
     from golden_util import load

@@ -201,6 +201,10 @@ def test_decompress_golden(ctx, curve):
     assert PC.check_decompress_golden(ctx, curve) > 40
 
 
+def test_edwards_point_from_x_golden(ctx):
+    assert PC.check_ed_from_x_golden(ctx) > 100
+
+
 def test_decompress_p224_tonelli_shanks(ctx):
     assert PC.check_decompress_golden(ctx, "p224") > 40
 

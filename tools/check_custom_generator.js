@@ -62,6 +62,36 @@ function same(a, b, what) {
   if (CUSTOM && (cq._ellgpu !== null || !cq._ellgpuCustom || cq._ellgpuCustom.id < 16))
     throw new Error(name + ': a custom-generator curve was taken for the preset');
 });
+// the general forms of _wnafMulAdd / _endoWnafMulAdd: 3 and 4 points (paired up on the device)
+['secp256k1', 'p256', 'p521'].forEach(function(name) {
+  var cp = plain.curves[name].curve, cq = patched.curves[name].curve;
+  var ks = ['3', 'deadbeefcafebabe0123456789abcdef', 'ab54a98ceb1f0ad2ab54a98ceb1f0ad2ab54a98ceb1f0ad2ab54a98ceb1f0ad',
+    '1'].map(function(k) { return new BN(k, 16); });
+  function pts(c) {
+    return [3, 5, 7, 11].map(function(m) { return c.g.mul(new BN(m)); });
+  }
+  var b0 = eng.stats.gpuCalls;
+  [3, 4].forEach(function(len) {
+    [false, true].forEach(function(jac) {
+      var a, b;
+      if (len % 2 === 0) {              // (an odd count never worked in the reference itself)
+        a = cq._wnafMulAdd(1, pts(cq).slice(0, len), ks.slice(0, len), len, jac);
+        b = cp._wnafMulAdd(1, pts(cp).slice(0, len), ks.slice(0, len), len, jac);
+        same(a.toP ? a.toP() : a, b.toP ? b.toP() : b, name + ' _wnafMulAdd ' + len);
+      }
+      if (name === 'secp256k1') {
+        a = cq._endoWnafMulAdd(pts(cq).slice(0, len), ks.slice(0, len), jac);
+        b = cp._endoWnafMulAdd(pts(cp).slice(0, len), ks.slice(0, len), jac);
+        same(a.toP ? a.toP() : a, b.toP ? b.toP() : b, name + ' _endoWnafMulAdd ' + len);
+      }
+    });
+  });
+  // P + (-P) + Q: a partial sum at infinity
+  var q = pts(cq), r = pts(cp);
+  same(cq._wnafMulAdd(1, [q[0], q[0].neg(), q[1], q[2]], [ks[1], ks[1], ks[0], ks[2]], 4, false),
+    cp._wnafMulAdd(1, [r[0], r[0].neg(), r[1], r[2]], [ks[1], ks[1], ks[0], ks[2]], 4, false), name + ' cancelling pair');
+  if (eng.stats.gpuCalls === b0) throw new Error(name + ': the 3/4-point forms did not reach the engine');
+});
 // the presets themselves still go to the engine
 var b0 = eng.stats.gpuCalls;
 same(patched.curves.secp256k1.curve.g.mul(new BN(5)), plain.curves.secp256k1.curve.g.mul(new BN(5)), 'preset');

@@ -65,7 +65,7 @@ load('eddsa_verify_ed25519.json').forEach(function(c) {
   if (run() !== c.ok) throw new Error('eddsa verify mismatch: ' + c.note);
   checked++;
 });
-['secp256k1', 'p192', 'p256', 'p384', 'p521', 'ed25519'].forEach(function(name) {
+['secp256k1', 'p192', 'p224', 'p256', 'p384', 'p521', 'ed25519'].forEach(function(name) {
   var curve = elliptic.curves[name].curve;
   var L = curve.p.byteLength();
   load('decompress_' + name + '.json').forEach(function(c) {
@@ -79,4 +79,16 @@ load('eddsa_verify_ed25519.json').forEach(function(c) {
     checked++;
   });
 });
+// EdwardsCurve#pointFromX (edwards.js:50-69)
+(function() {
+  var curve = elliptic.curves.ed25519.curve;
+  load('fromx_ed25519.json').forEach(function(c) {
+    var run = function() { return curve.pointFromX(c.v, c.odd); };
+    if (c.r.invalid !== undefined) return expectThrow(run, c.r.invalid, 'ed25519 pointFromX');
+    var q = run();
+    if (q.getX().toString(16, 64) !== c.r.x || q.getY().toString(16, 64) !== c.r.y)
+      throw new Error('ed25519 pointFromX mismatch');
+    checked++;
+  });
+})();
 console.log(JSON.stringify({ ok: true, checked: checked, thrown: thrown, engine: eng.stats }));

@@ -361,6 +361,30 @@ function genDecompress(name) {
   return cases;
 }
 
+// EdwardsCurve#pointFromX (edwards.js:50-69): x -> (x, y), y of the requested parity
+function genEdFromX() {
+  var c = elliptic.curves.ed25519.curve;
+  var rng = new Prng('ellgpu-golden-v1:fromx:ed25519');
+  var cases = [];
+  function one(v, odd) {
+    var o = { v: hex(v, 32), odd: odd };
+    try {
+      var p = c.pointFromX(v, odd);
+      o.r = { x: hex(p.getX(), 32), y: hex(p.getY(), 32) };
+    } catch (e) { o.r = { invalid: e.message }; }
+    cases.push(o);
+  }
+  for (var i = 0; i < 40; i++) {
+    var P = c.g.mul(rng.below(c.n.subn(1)).addn(1));
+    one(P.getX(), (i & 1) === 1);
+    one(P.getX(), (i & 1) === 0);
+    one(rng.below(c.p), (i & 2) === 2);            // ~half of these are no abscissa of the curve
+  }
+  [new BN(0), new BN(1), new BN(2), c.p.subn(1), c.p.subn(2), c.p.clone(), c.p.addn(1)]
+    .forEach(function(v) { one(v, false); one(v, true); });
+  return cases;
+}
+
 // ------------------------------------------------------------ codec_<curve>.json
 // BaseCurve#decodePoint / BasePoint#encode (base.js:270-311), KeyPair#validate
 // (ec/key.js:41-52); for ed25519 EDDSA#decodePoint / encodePoint (eddsa/index.js:94-109),
@@ -1039,6 +1063,7 @@ SHORT.forEach(function(name) {
 SHORT.concat(['ed25519']).forEach(function(name) {
   write('decompress_' + name + '.json', genDecompress(name));
 });
+write('fromx_ed25519.json', genEdFromX());
 SHORT.concat(['ed25519']).forEach(function(name) {
   write('codec_' + name + '.json', genCodec(name));
 });
