@@ -25,14 +25,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 FLAGS += os.environ.get("ELLGPU_CXXFLAGS", "").split()      # developer experiments (-DELL_...=...)
 
 CURVES = ["CvP521", "CvP384", "CvP256", "CvSecp256k1", "CvP224", "CvP192"]   # slowest first
-GROUPS = [4, 2, 3, 0, 1, 5]
+GROUPS = [4, 2, 3, 0, 1, 5, 6]
+# per-group extra compiler flags: group 6 = the scalar-field kernels (see Engine::launch_fn)
+GROUP_FLAGS = {6: ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def units():
     u = []
     for c in CURVES:
         for g in GROUPS:
-            u.append(("inst_%s_g%d" % (c, g), "inst.hip", ["-DELL_INST_CURVE=" + c, "-DELL_INST_GROUP=%d" % g]))
+            u.append(("inst_%s_g%d" % (c, g), "inst.hip",
+                      ["-DELL_INST_CURVE=" + c, "-DELL_INST_GROUP=%d" % g] + GROUP_FLAGS.get(g, [])))
     for g in (10, 11, 12, 13, 14, 15, 16):
         u.append(("inst_g%d" % g, "inst.hip", ["-DELL_INST_GROUP=%d" % g]))
     u.append(("capi", "capi.hip", []))
@@ -46,7 +49,7 @@ def source_digest():
     for f in files:
         with open(f, "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(GROUP_FLAGS.items()))).encode())
     return h.hexdigest()[:16]
 
 
@@ -74,7 +77,8 @@ def build_dev_k256(verbose=True, curve="CvSecp256k1"):
     dflag = "-DELL_ONLY_CURVE=%d" % cid
     tflag = "-DELL_ONLY_TYPE=" + curve
     work = [("inst_%s_g%d" % (curve, g), "inst.hip", ["-DELL_INST_CURVE=" + curve, "-DELL_INST_GROUP=%d" % g,
-                                                      dflag, tflag], digest, ["-Rpass-analysis=kernel-resource-usage"]) for g in GROUPS]
+                                                      dflag, tflag] + GROUP_FLAGS.get(g, []), digest,
+             ["-Rpass-analysis=kernel-resource-usage"]) for g in GROUPS]
     for g in (10, 11, 12, 13, 14, 15, 16):   # ed25519 / x25519 units are referenced by the engine, keep them linkable
         work.append(("inst_g%d" % g, "inst.hip", ["-DELL_INST_GROUP=%d" % g, dflag, tflag], digest, []))
     work.append(("capi_%s" % curve, "capi.hip", [dflag, tflag], digest, []))

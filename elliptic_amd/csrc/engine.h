@@ -511,6 +511,13 @@ class Engine {
   template <class CV>
   int ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* r, const u8* s,
                   const u8* pub, u8* ok);
+  // launch of a scalar-field kernel (ecdsa_prep, sign_finish, recover_prep: batched inversion
+  // and Montgomery arithmetic mod n, long dependent chains).  A member of its own so that these
+  // kernels are instantiated in their own translation units (inst.hip group 6), which are
+  // compiled with LLVM's max-ILP scheduling strategy: measured ecdsa_prep 0.334 -> 0.234 ms per
+  // 2^20, while the ladder kernels are 0.4-1.3 % slower under it and keep the default.
+  template <class Fn>
+  int launch_fn(const Fn& f, size_t nthreads);
   template <int U = 0>
   int ensure_ed_comb();
   template <int U = 0>
@@ -1649,6 +1656,13 @@ int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* 
 
 
 template <class BK>
+template <class Fn>
+int Engine<BK>::launch_fn(const Fn& f, size_t nthreads) {
+  bk.launch(f, nthreads);
+  return E_OK;
+}
+
+template <class BK>
 template <class CV>
 int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* r, const u8* s,
                 const u8* pub, u8* ok) {
@@ -1660,7 +1674,7 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
   if (!tbl || !pre || !u12 || !valid) return fail(E_NOMEM, "scratch allocation failed");
   size_t T = (n + INV_BATCH_N - 1) / INV_BATCH_N;
   FnEcdsaPrep<CV> f1{T, n, INV_BATCH_N, hash, hash_len, shift, r, s, pre, u12, valid};
-  bk.launch(f1, T);
+  launch_fn(f1, T);
   if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
     FnEcdsaMain<CV, (W::L > 12 ? 2 : 0)> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
     bk.launch(f2, n);
@@ -1878,7 +1892,7 @@ int Engine<BK>::recover_chunk(size_t n, const u8* hash, int hash_len, const u8* 
     u8* inf = flags + 2 * n;
     size_t T = (n + INV_BATCH_N - 1) / INV_BATCH_N;
     FnRecoverPrep<CV> f1{T, n, INV_BATCH_N, hash, hash_len, r, s, recid, pre, xs, odd, s1, s2, out_status};
-    bk.launch(f1, T);
+    launch_fn(f1, T);
     int rc = decompress_chunk<CV>(n, xs, odd, rxy, dec_ok);
     if (rc) return rc;
     rc = mul_add_g_chunk<CV>(n, s1, s2, rxy, out_xy, inf);         // s1 * G + s2 * R
@@ -1994,7 +2008,7 @@ int Engine<BK>::sign_chunk(size_t n, const u8* hash, int hash_len, int shift, co
   size_t T = (n + INV_BATCH_N - 1) / INV_BATCH_N;
   FnSignFinish<CV> f2{T, n, INV_BATCH_N, hash, hash_len, shift, priv, nonces, kg, kg_inf, canonical, pre,
                       out_r, out_s, out_recid, out_ok};
-  bk.launch(f2, T);
+  launch_fn(f2, T);
   return E_OK;
 }
 

@@ -41,6 +41,12 @@ namespace ell {
                                                         const u8*, const u8*, u8*, u8*);           \
   KW template int Engine<HipBackend>::sign_det_chunk<CV>(size_t, const u8*, int, int, const u8*,   \
                                                          int, u8*, u8*, u8*, u8*);
+// scalar-field kernels (batched inversion / Montgomery arithmetic mod n): their own translation
+// units, compiled with -mllvm -amdgpu-sched-strategy=max-ilp (build.py)
+#define ELL_DECL_G6(KW, CV)                                                                        \
+  KW template int Engine<HipBackend>::launch_fn<FnEcdsaPrep<CV>>(const FnEcdsaPrep<CV>&, size_t);   \
+  KW template int Engine<HipBackend>::launch_fn<FnSignFinish<CV>>(const FnSignFinish<CV>&, size_t); \
+  KW template int Engine<HipBackend>::launch_fn<FnRecoverPrep<CV>>(const FnRecoverPrep<CV>&, size_t);
 // user-defined short curves (CvCustom): scalar multiplication and point addition only
 #define ELL_DECL_CUSTOM(KW)                                                                          \
   KW template int Engine<HipBackend>::mul_var_chunk<CvCustom>(size_t, const u8*, const u8*, u8*, u8*, \
@@ -79,7 +85,7 @@ namespace ell {
 // everything is extern by default ...
 #define ELL_EXT_ALL(CV) \
   ELL_DECL_G0(extern, CV) ELL_DECL_G1(extern, CV) ELL_DECL_G2(extern, CV) ELL_DECL_G3(extern, CV) ELL_DECL_G4(extern, CV) \
-  ELL_DECL_G5(extern, CV)
+  ELL_DECL_G5(extern, CV) ELL_DECL_G6(extern, CV)
 ELL_FOR_SHORT_CURVES(ELL_EXT_ALL)
 ELL_DECL_ED0(extern)
 ELL_DECL_ED1(extern)

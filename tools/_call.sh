@@ -1,6 +1,14 @@
-set -x
-mkdir -p gpurun_out/c1
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_sizes.py tests/test_js_install.py -m gpu -x -q -k "user_defined or custom" > gpurun_out/c1/pytest_custom.log 2>&1
-tail -5 gpurun_out/c1/pytest_custom.log
-for l in elliptic_amd/lib/libellgpu.so ab_libs/custom_w2.so ab_libs/custom_w4.so; do ELLGPU_LIB=$l timeout 300 python tools/bench_custom.py 18 >> gpurun_out/c1/bench_custom.jsonl 2>gpurun_out/c1/bench_custom.err; done
-cat gpurun_out/c1/bench_custom.jsonl
+mkdir -p gpurun_out/c6
+for l in ab_libs/a_base.so elliptic_amd/lib/libellgpu.so; do
+  ELLGPU_LIB=$l timeout 900 python tools/bench_configs.py --reps 3 > gpurun_out/c6/configs_$(basename $l).jsonl 2> gpurun_out/c6/err_$(basename $l).log
+done
+python - <<'PY'
+import json,glob
+rows={}
+for f in sorted(glob.glob('gpurun_out/c6/configs_*.jsonl')):
+    for l in open(f):
+        if l.startswith('{'):
+            d=json.loads(l); rows.setdefault((d.get('curve'),d.get('op')),{})[f.split('configs_')[1]]=d
+for k,v in rows.items():
+    print(k, {lib:(round(d.get('items_per_s',0)/1e6,2), d.get('kernels_ms')) for lib,d in v.items()})
+PY

@@ -73,6 +73,9 @@ def child(lib, n, reps):
         out[name + "_Mps"] = n * max(reps // 3, 3) / dt / 1e6
         c, ms = tm.get(name, (0, 0.0))
         out[name + "_kernel_ms"] = round(ms / max(c, 1), 4)
+        for k2, (c2, ms2) in tm.items():
+            if k2 != name:
+                out["%s/%s_ms" % (name, k2)] = round(ms2 / max(c2, 1), 4)
     # field-layer probes at 3 and 4 waves / SIMD (units of one v_mad_u64_u32 issue)
     try:
         best = 0
