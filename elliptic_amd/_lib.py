@@ -25,6 +25,8 @@ _SIGS = {
     "ellgpu_group_size": (ctypes.c_int, [ctypes.c_void_p]),
     "ellgpu_curve_define_short": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
                                                  ctypes.POINTER(ctypes.c_int)]),
+    "ellgpu_curve_define_edwards": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                                   ctypes.POINTER(ctypes.c_int)]),
     "ellgpu_ctx_destroy": (None, [ctypes.c_void_p]),
     "ellgpu_ctx_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
     "ellgpu_ctx_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]),

@@ -143,14 +143,14 @@ int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n) {
   return finish(ctx, ctx->eng->reserve(curve, n));
 }
 
-int ellgpu_curve_define_short(ellgpu_ctx* ctx, const uint8_t* p, const uint8_t* a, const uint8_t* b,
-                              int* out_curve) {
+static int define_custom(ellgpu_ctx* ctx, int edwards, const uint8_t* p, const uint8_t* a, const uint8_t* b,
+                         int* out_curve) {
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
   if (!ctx->members.empty()) {
     int id = -1;
     for (size_t i = 0; i < ctx->members.size(); i++) {
       int mid = -1;
-      int rc = ellgpu_curve_define_short(ctx->members[i], p, a, b, &mid);
+      int rc = define_custom(ctx->members[i], edwards, p, a, b, &mid);
       if (rc) return rc;
       if (i && mid != id) return set_err(ELLGPU_E_ARG, "group members disagree on the curve id (curves were defined on a member directly)");
       id = mid;
@@ -159,9 +159,17 @@ int ellgpu_curve_define_short(ellgpu_ctx* ctx, const uint8_t* p, const uint8_t* 
     return ELLGPU_OK;
   }
   ctx->eng->err.clear();
-  int rc = ctx->eng->define_short(p, a, b, out_curve);
+  int rc = edwards ? ctx->eng->define_edwards(p, a, b, out_curve) : ctx->eng->define_short(p, a, b, out_curve);
   if (rc) g_last_error = ctx->eng->err.empty() ? "ellgpu error" : ctx->eng->err;
   return rc;
+}
+int ellgpu_curve_define_short(ellgpu_ctx* ctx, const uint8_t* p, const uint8_t* a, const uint8_t* b,
+                              int* out_curve) {
+  return define_custom(ctx, 0, p, a, b, out_curve);
+}
+int ellgpu_curve_define_edwards(ellgpu_ctx* ctx, const uint8_t* p, const uint8_t* a, const uint8_t* d,
+                                int* out_curve) {
+  return define_custom(ctx, 1, p, a, d, out_curve);
 }
 
 #define ELL_ENTER(ctx, stream)                                      \

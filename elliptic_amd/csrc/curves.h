@@ -90,8 +90,8 @@ struct CvCustom {
   static constexpr bool JTABLE = true;
   static constexpr int ID = 16;
 };
-constexpr int CURVE_CUSTOM0 = 16;                 // C-ABI ids 16..23: ellgpu_curve_define_short
-constexpr int CURVE_CUSTOM_MAX = 8;
+constexpr int CURVE_CUSTOM0 = 16;                 // C-ABI ids 16..31: ellgpu_curve_define_short / _edwards
+constexpr int CURVE_CUSTOM_MAX = 16;
 
 typedef CvNist<FpSolinas<SolP192>, consts::P192_N, consts::P192_C, CURVE_P192> CvP192;
 typedef CvNist<FpSolinas<SolP224>, consts::P224_N, consts::P224_C, CURVE_P224> CvP224;

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "edwards.h"
+#include "edcustom.h"
 #include "mont.h"
 #include "work.h"
 
@@ -417,6 +418,42 @@ struct FnX25519Normalize {
   }
 };
 
+// user-defined Edwards curves (edcustom.h)
+struct FnEdcMulVar {
+  static constexpr const char* NAME = "edc_mul_var";
+  static constexpr int DS_PER_LANE = EdcWork::NWIN;
+  static constexpr int MIN_WAVES = 3;
+  size_t n; const u8* k; const u8* xy; EdcWork::P* tbl; u32* out;
+  ELL_HD void operator()(size_t i, const DigitStore& ds) const {
+    if (i < n) EdcWork::mul_var(i, n, k, xy, tbl, ds, out);
+  }
+};
+struct FnEdcMulAdd2 {
+  static constexpr const char* NAME = "edc_mul_add2";
+  static constexpr int DS_PER_LANE = EdcWork::NWIN * 2;
+  static constexpr int MIN_WAVES = 3;
+  size_t n; const u8* k1; const u8* xy1; const u8* k2; const u8* xy2; EdcWork::P* tbl; u32* out;
+  ELL_HD void operator()(size_t i, const DigitStore& ds) const {
+    if (i < n) EdcWork::mul_add2(i, n, k1, xy1, k2, xy2, tbl, ds, out);
+  }
+};
+struct FnEdcPointAdd {
+  static constexpr const char* NAME = "edc_point_add";
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* xy1; const u8* inf1; const u8* xy2; const u8* inf2; u32* out;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) EdcWork::point_add(i, n, xy1, inf1, xy2, inf2, out);
+  }
+};
+struct FnEdcNormalize {
+  static constexpr const char* NAME = "edc_normalize";
+  static constexpr int DS_PER_LANE = 0;
+  size_t T; size_t n; int K; const u32* proj; u32* pre; u8* out_xy; u8* out_inf;
+  ELL_HD void operator()(size_t t, const DigitStore&) const {
+    if (t < T) EdcWork::normalize(t, T, n, K, proj, pre, out_xy, out_inf);
+  }
+};
+
 // ---- curve metadata ----------------------------------------------------------
 struct CurveInfo {
   const char* name;
@@ -531,6 +568,10 @@ class Engine {
                         u8* out_xy, u8* out_inf);
   template <int U = 0>
   int x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf);
+  // user-defined Edwards curves: op 0 = k*P, 1 = k1*P1 + k2*P2, 2 = P1 + P2 (a, b = the inf flags)
+  template <int U = 0>
+  int edc_chunk(int op, size_t n, const u8* k1, const u8* xy1, const u8* k2, const u8* xy2,
+                const u8* a, const u8* b, u8* out_xy, u8* out_inf);
   template <class CV>
   int decompress_chunk(size_t n, const u8* x, const u8* odd, u8* out_xy, u8* out_ok);
   template <class CV>
@@ -590,75 +631,104 @@ class Engine {
   // b any residues.  Registers the curve under an id >= CURVE_CUSTOM0 of this context; Point#mul,
   // mulAdd / jmulAdd and Point#add then run on the device through the generic-a doubling
   // (ShortOps::dbl, A_KIND 1) and a Montgomery field whose modulus is a kernel-time constant.
-  int define_short(const u8* p_be, const u8* a_be, const u8* b_be, int* out_curve) {
-    if (!p_be || !a_be || !b_be || !out_curve) return fail(E_ARG, "null pointer");
-    RtField f;
+  // modulus-dependent constants of a parameter block
+  int rt_field_init(RtField& f, const u8* p_be) {
     memset(&f, 0, sizeof(f));
-    u32 a[8], b[8];
     load_be<8>(f.p, p_be, 32);
-    load_be<8>(a, a_be, 32);
-    load_be<8>(b, b_be, 32);
-    if (!(f.p[0] & 1u)) return fail(E_ARG, "define_short: the modulus must be odd");
+    if (!(f.p[0] & 1u)) return fail(E_ARG, "user-defined curve: the modulus must be odd");
     bool small = true;
     for (int i = 1; i < 8; i++) small = small && f.p[i] == 0;
-    if (small && f.p[0] < 5) return fail(E_ARG, "define_short: the modulus must be a prime > 3");
+    if (small && f.p[0] < 5) return fail(E_ARG, "user-defined curve: the modulus must be a prime > 3");
     u32 inv = 1;                                          // p^-1 mod 2^32 (Newton)
     for (int i = 0; i < 5; i++) inv *= 2u - f.p[0] * inv;
     f.n0 = 0u - inv;
-    auto reduce = [&](u32 (&r)[8], const u32 (&x)[8]) {    // x mod p, bit by bit
-      bn_zero<8>(r);
-      for (int i = 255; i >= 0; i--) {
-        u32 t[8];
-        mod_add<8>(t, r, r, f.p);
-        bn_copy<8>(r, t);
-        if ((x[i >> 5] >> (i & 31)) & 1u) {
-          u32 o[8];
-          bn_zero<8>(o);
-          o[0] = 1;
-          mod_add<8>(t, r, o, f.p);
-          bn_copy<8>(r, t);
-        }
-      }
-    };
-    auto times_r = [&](u32 (&r)[8]) {                      // r * 2^256 mod p
-      for (int i = 0; i < 256; i++) {
-        u32 t[8];
-        mod_add<8>(t, r, r, f.p);
-        bn_copy<8>(r, t);
-      }
-    };
     u32 one[8];
     bn_zero<8>(one);
     one[0] = 1;
-    u32 t[8];
-    reduce(t, one);                                       // p > 1: 1
-    times_r(t);
-    bn_copy<8>(f.one, t);
-    times_r(t);
-    bn_copy<8>(f.r2, t);
+    rt_to_mont(f, f.one, one);
+    bn_copy<8>(f.r2, f.one);
+    rt_times_r(f, f.r2);
     u32 two[8];
     bn_zero<8>(two);
     two[0] = 2;
     bn_sub<8>(f.pm2, f.p, two);
-    u32 ar[8], br[8];
-    reduce(ar, a);
-    reduce(br, b);
-    u32 three[8], pm3[8];
-    bn_zero<8>(three);
-    three[0] = 3;
-    bn_sub<8>(pm3, f.p, three);
-    f.a_kind = bn_is_zero<8>(ar) ? 0u : (bn_eq<8>(ar, pm3) ? 3u : 1u);
-    times_r(ar);
-    times_r(br);
-    bn_copy<8>(f.a_m, ar);
-    bn_copy<8>(f.b_m, br);
+    return E_OK;
+  }
+  static void rt_times_r(const RtField& f, u32 (&r)[8]) {          // r * 2^256 mod p, r < p
+    for (int i = 0; i < 256; i++) {
+      u32 t[8];
+      mod_add<8>(t, r, r, f.p);
+      bn_copy<8>(r, t);
+    }
+  }
+  // out = x * 2^256 mod p for any x < 2^256 (reduced bit by bit first)
+  static void rt_to_mont(const RtField& f, u32 (&out)[8], const u32 (&x)[8]) {
+    u32 r[8];
+    bn_zero<8>(r);
+    for (int i = 255; i >= 0; i--) {
+      u32 t[8];
+      mod_add<8>(t, r, r, f.p);
+      bn_copy<8>(r, t);
+      if ((x[i >> 5] >> (i & 31)) & 1u) {
+        u32 o[8];
+        bn_zero<8>(o);
+        o[0] = 1;
+        mod_add<8>(t, r, o, f.p);
+        bn_copy<8>(r, t);
+      }
+    }
+    rt_times_r(f, r);
+    bn_copy<8>(out, r);
+  }
+  int register_custom(const RtField& f, int* out_curve) {
     for (size_t i = 0; i < custom_.size(); i++)
       if (memcmp(&custom_[i], &f, sizeof(f)) == 0) { *out_curve = CURVE_CUSTOM0 + (int)i; return E_OK; }
     if ((int)custom_.size() >= CURVE_CUSTOM_MAX)
-      return fail(E_UNSUPPORTED, "define_short: at most 8 user-defined curves per context");
+      return fail(E_UNSUPPORTED, "at most 16 user-defined curves per context");
     custom_.push_back(f);
     *out_curve = CURVE_CUSTOM0 + (int)custom_.size() - 1;
     return E_OK;
+  }
+  int define_short(const u8* p_be, const u8* a_be, const u8* b_be, int* out_curve) {
+    if (!p_be || !a_be || !b_be || !out_curve) return fail(E_ARG, "null pointer");
+    RtField f;
+    int rc = rt_field_init(f, p_be);
+    if (rc) return rc;
+    u32 a[8], b[8];
+    load_be<8>(a, a_be, 32);
+    load_be<8>(b, b_be, 32);
+    rt_to_mont(f, f.a_m, a);
+    rt_to_mont(f, f.b_m, b);
+    u32 three[8], m3[8];
+    bn_zero<8>(three);
+    three[0] = 3;
+    bn_sub<8>(m3, f.p, three);
+    rt_to_mont(f, m3, m3);
+    f.a_kind = bn_is_zero<8>(f.a_m) ? 0u : (bn_eq<8>(f.a_m, m3) ? 3u : 1u);
+    f.kind = 0;
+    return register_custom(f, out_curve);
+  }
+  // `new elliptic.curve.edwards({p, a, c: 1, d})` (edwards.js:11-31) with parameters that are not
+  // ed25519's: a x^2 + y^2 = 1 + d x^2 y^2 over an odd prime p < 2^256; Point#mul, mulAdd and
+  // Point#add run on the device in projective coordinates (edcustom.h).
+  int define_edwards(const u8* p_be, const u8* a_be, const u8* d_be, int* out_curve) {
+    if (!p_be || !a_be || !d_be || !out_curve) return fail(E_ARG, "null pointer");
+    RtField f;
+    int rc = rt_field_init(f, p_be);
+    if (rc) return rc;
+    u32 a[8], d[8];
+    load_be<8>(a, a_be, 32);
+    load_be<8>(d, d_be, 32);
+    rt_to_mont(f, f.a_m, a);
+    rt_to_mont(f, f.d_m, d);
+    if (bn_is_zero<8>(f.a_m) || bn_is_zero<8>(f.d_m) || bn_eq<8>(f.a_m, f.d_m))
+      return fail(E_ARG, "user-defined Edwards curve: a and d must be non-zero and distinct");
+    f.kind = 1;
+    return register_custom(f, out_curve);
+  }
+  bool custom_is_edwards(int curve) const {
+    size_t slot = (size_t)(curve - CURVE_CUSTOM0);
+    return is_custom(curve) && slot < custom_.size() && custom_[slot].kind == 1;
   }
   // Brackets one call on a user-defined curve: takes the device's custom-curve lock, uploads the
   // curve's parameter block (synchronously: every earlier user of the block has finished, see the
@@ -726,7 +796,9 @@ class Engine {
     if (sc.rc) return sc.rc;
     for (size_t o = 0; o < n; o += CHUNK) {
       size_t m = n - o < CHUNK ? n - o : CHUNK;
-      if (is_custom(curve))
+      if (custom_is_edwards(curve))
+        rc = edc_chunk(0, m, k + o * B, xy + o * 2 * B, nullptr, nullptr, nullptr, nullptr, out_xy + o * 2 * B, out_inf + o);
+      else if (is_custom(curve))
         rc = mul_var_chunk<CvCustom>(m, k + o * B, xy + o * 2 * B, out_xy + o * 2 * B, out_inf + o, nullptr);
       else if (curve == CURVE_ED25519)
         rc = ed_mul_var_chunk(m, k + o * B, xy + o * 2 * B, out_xy + o * 2 * B, out_inf + o, nullptr);
@@ -755,7 +827,10 @@ class Engine {
     for (size_t o = 0; o < n; o += CHUNK) {
       size_t m = n - o < CHUNK ? n - o : CHUNK;
       const u8* p1 = xy1 ? xy1 + o * 2 * B : nullptr;
-      if (is_custom(curve))
+      if (custom_is_edwards(curve))
+        rc = edc_chunk(1, m, k1 + o * B, p1, k2 + o * B, xy2 + o * 2 * B, nullptr, nullptr, out_xy + o * 2 * B,
+                       out_inf + o);
+      else if (is_custom(curve))
         rc = mul_add2_chunk<CvCustom>(m, k1 + o * B, p1, k2 + o * B, xy2 + o * 2 * B, out_xy + o * 2 * B,
                                       out_inf + o);
       else if (curve == CURVE_ED25519)
@@ -1192,7 +1267,9 @@ class Engine {
       size_t m = n - o < CHUNK ? n - o : CHUNK;
       const u8* i1 = inf1 ? inf1 + o : nullptr;
       const u8* i2 = inf2 ? inf2 + o : nullptr;
-      if (is_custom(curve))
+      if (custom_is_edwards(curve))
+        rc = edc_chunk(2, m, nullptr, xy1 + o * 2 * B, nullptr, xy2 + o * 2 * B, i1, i2, out_xy + o * 2 * B, out_inf + o);
+      else if (is_custom(curve))
         rc = point_add_chunk<CvCustom>(m, xy1 + o * 2 * B, i1, xy2 + o * 2 * B, i2, out_xy + o * 2 * B, out_inf + o);
       else if (curve == CURVE_ED25519)
         rc = ed_point_add_chunk(m, xy1 + o * 2 * B, i1, xy2 + o * 2 * B, i2, out_xy + o * 2 * B, out_inf + o);
@@ -1654,6 +1731,30 @@ int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* 
   return normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
 }
 
+
+template <class BK>
+template <int U>
+int Engine<BK>::edc_chunk(int op, size_t n, const u8* k1, const u8* xy1, const u8* k2, const u8* xy2,
+                          const u8* a, const u8* b, u8* out_xy, u8* out_inf) {
+  u32* proj = (u32*)scratch(S_JAC, n * 3 * 8 * 4);
+  u32* pre = (u32*)scratch(S_PRE, n * 8 * 4);
+  EdcWork::P* tbl = (EdcWork::P*)scratch(S_TBL, n * 16 * sizeof(EdcWork::P));
+  if (!proj || !pre || !tbl) return fail(E_NOMEM, "scratch allocation failed");
+  if (op == 0) {
+    FnEdcMulVar f{n, k1, xy1, tbl, proj};
+    bk.launch(f, n);
+  } else if (op == 1) {
+    FnEdcMulAdd2 f{n, k1, xy1, k2, xy2, tbl, proj};
+    bk.launch(f, n);
+  } else {
+    FnEdcPointAdd f{n, xy1, a, xy2, b, proj};
+    bk.launch(f, n);
+  }
+  size_t T = (n + INV_BATCH - 1) / INV_BATCH;
+  FnEdcNormalize g{T, n, INV_BATCH, proj, pre, out_xy, out_inf};
+  bk.launch(g, T);
+  return E_OK;
+}
 
 template <class BK>
 template <class Fn>

@@ -56,7 +56,9 @@ namespace ell {
   KW template int Engine<HipBackend>::mul_add2_chunk<CvCustom>(size_t, const u8*, const u8*,         \
                                                                const u8*, const u8*, u8*, u8*);      \
   KW template int Engine<HipBackend>::point_add_chunk<CvCustom>(size_t, const u8*, const u8*, const u8*, \
-                                                                const u8*, u8*, u8*);
+                                                                const u8*, u8*, u8*);                \
+  KW template int Engine<HipBackend>::edc_chunk<0>(int, size_t, const u8*, const u8*, const u8*,     \
+                                                   const u8*, const u8*, const u8*, u8*, u8*);
 #define ELL_DECL_ED2(KW)                                                                            \
   KW template int Engine<HipBackend>::ed_decompress_chunk<0>(size_t, const u8*, const u8*, u8*, u8*); \
   KW template int Engine<HipBackend>::ed_codec_chunk<0>(int, size_t, const u8*, int, const u8*, u8*, u8*); \

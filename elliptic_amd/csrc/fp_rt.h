@@ -24,6 +24,8 @@ struct RtField {
   u32 a_m[8];      // curve coefficient a, Montgomery form
   u32 b_m[8];      // curve coefficient b, Montgomery form
   u32 a_kind;      // 0: a == 0, 3: a == p - 3, 1: anything else
+  u32 d_m[8];      // Edwards curves (edcustom.h): coefficient d, Montgomery form; a_m holds a
+  u32 kind;        // 0: short Weierstrass (a_m, b_m), 1: (twisted) Edwards with c = 1 (a_m, d_m)
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)

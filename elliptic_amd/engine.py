@@ -26,7 +26,7 @@ ORDER_BYTES = dict(FIELD_BYTES)
 # user-defined short curves (Context.define_short) are addressed by the integer id the library
 # hands out; their scalars and coordinates are 32 bytes wide whatever the prime's size
 CURVE_CUSTOM0 = 16
-for _i in range(CURVE_CUSTOM0, CURVE_CUSTOM0 + 8):
+for _i in range(CURVE_CUSTOM0, CURVE_CUSTOM0 + 16):
     FIELD_BYTES[_i] = ORDER_BYTES[_i] = 32
 
 
@@ -103,6 +103,14 @@ class Context:
         cid = ctypes.c_int(-1)
         enc = [int(v % p if i else v).to_bytes(32, "big") for i, v in enumerate((int(p), int(a), int(b)))]
         self._check(self._lib.ellgpu_curve_define_short(self._ctx, enc[0], enc[1], enc[2], ctypes.byref(cid)))
+        return cid.value
+
+    def define_edwards(self, p, a, d):
+        """Register a x^2 + y^2 = 1 + d x^2 y^2 over the odd prime p < 2^256 (`new curve.edwards({p, a,
+        c: 1, d})` with parameters that are not ed25519's) and return its curve id (as define_short)."""
+        cid = ctypes.c_int(-1)
+        enc = [int(v % p if i else v).to_bytes(32, "big") for i, v in enumerate((int(p), int(a), int(d)))]
+        self._check(self._lib.ellgpu_curve_define_edwards(self._ctx, enc[0], enc[1], enc[2], ctypes.byref(cid)))
         return cid.value
 
     def reserve(self, curve, n):

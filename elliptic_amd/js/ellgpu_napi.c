@@ -12,7 +12,7 @@
  * Exports:  open(path) -> true
  *           createContext(device) -> external
  *           destroyContext(ctx)
- *           curveId(name), fieldBytes(id), orderBytes(id), deviceCount(), defineShort(ctx, p, a, b)
+ *           curveId(name), fieldBytes(id), orderBytes(id), deviceCount(), defineShort(ctx, p, a, b), defineEdwards(ctx, p, a, d)
  *           mulFixed(ctx, curve, k) -> {xy, inf}
  *           mulVar(ctx, curve, k, xy) -> {xy, inf}
  *           mulAdd2(ctx, curve, k1, p1|null, k2, p2) -> {xy, inf}
@@ -65,6 +65,7 @@ static struct {
   int (*group_create)(const int*, int, ellgpu_ctx**);
   int (*group_size)(const ellgpu_ctx*);
   int (*define_short)(ellgpu_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, int*);
+  int (*define_edwards)(ellgpu_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, int*);
   void (*ctx_destroy)(ellgpu_ctx*);
   int (*mul_fixed)(ellgpu_ctx*, int, size_t, const uint8_t*, uint8_t*, uint8_t*);
   int (*mul_var)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
@@ -124,6 +125,7 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   SYM(device_count, "ellgpu_device_count"); SYM(ctx_create, "ellgpu_ctx_create");
   SYM(group_create, "ellgpu_group_create"); SYM(group_size, "ellgpu_group_size");
   SYM(define_short, "ellgpu_curve_define_short");
+  SYM(define_edwards, "ellgpu_curve_define_edwards");
   SYM(ctx_destroy, "ellgpu_ctx_destroy"); SYM(mul_fixed, "ellgpu_mul_fixed"); SYM(mul_var, "ellgpu_mul_var");
   SYM(mul_add2, "ellgpu_mul_add2"); SYM(ecdsa_verify, "ellgpu_ecdsa_verify"); SYM(x25519, "ellgpu_x25519_ladder");
   SYM(decompress, "ellgpu_decompress");
@@ -268,8 +270,9 @@ static napi_value fn_group_size(napi_env env, napi_callback_info info) {
   napi_value v; CHECK(env, napi_create_int32(env, L.group_size(c), &v));
   return v;
 }
-/* defineShort(ctx, p, a, b) -> curve id: 32-byte big-endian Buffers (ellgpu_curve_define_short) */
-static napi_value fn_define_short(napi_env env, napi_callback_info info) {
+/* defineShort(ctx, p, a, b) / defineEdwards(ctx, p, a, d) -> curve id: 32-byte big-endian Buffers
+ * (ellgpu_curve_define_short / ellgpu_curve_define_edwards) */
+static napi_value define_common(napi_env env, napi_callback_info info, int edwards) {
   if (!need_lib(env)) return NULL;
   size_t argc = 4; napi_value argv[4];
   CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
@@ -281,10 +284,12 @@ static napi_value fn_define_short(napi_env env, napi_callback_info info) {
     if (l[i] != 32) THROW(env, "defineShort: p, a, b are 32-byte big-endian Buffers");
   }
   int id = -1;
-  if (L.define_short(c, b[0], b[1], b[2], &id) != 0) THROW(env, L.last_error());
+  if ((edwards ? L.define_edwards : L.define_short)(c, b[0], b[1], b[2], &id) != 0) THROW(env, L.last_error());
   napi_value v; CHECK(env, napi_create_int32(env, id, &v));
   return v;
 }
+static napi_value fn_define_short(napi_env e, napi_callback_info i) { return define_common(e, i, 0); }
+static napi_value fn_define_edwards(napi_env e, napi_callback_info i) { return define_common(e, i, 1); }
 static napi_value fn_destroy(napi_env env, napi_callback_info info) {
   /* contexts are released by the GC finalizer; explicit destroy is a no-op hook */
   (void)info; napi_value u; napi_get_undefined(env, &u); return u;
@@ -841,7 +846,7 @@ static napi_value init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
     {"open", fn_open}, {"createContext", fn_create}, {"destroyContext", fn_destroy},
     {"curveId", fn_curve_id}, {"fieldBytes", fn_field_bytes}, {"orderBytes", fn_order_bytes},
-    {"deviceCount", fn_device_count}, {"groupSize", fn_group_size}, {"defineShort", fn_define_short}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
+    {"deviceCount", fn_device_count}, {"groupSize", fn_group_size}, {"defineShort", fn_define_short}, {"defineEdwards", fn_define_edwards}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
     {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519},
     {"callAsync", fn_call_async}, {"decompress", fn_decompress},
     {"eddsaVerify", fn_eddsa_verify}, {"eddsaSign", fn_eddsa_sign}, {"ecdsaSign", fn_sign}, {"ecdsaRecover", fn_recover}, {"ecdsaSignDet", fn_sign_det},

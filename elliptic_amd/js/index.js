@@ -60,6 +60,14 @@ Engine.prototype.defineShort = function defineShort(p, a, b) {
   }
   return this.addon.defineShort(this.ctx, buf(p), buf(a), buf(b));
 };
+// The same for a (twisted) Edwards curve a x^2 + y^2 = 1 + d x^2 y^2 (c = 1) that is not ed25519
+// (`new elliptic.curve.edwards({p, a, c: 1, d})`, lib/elliptic/curve/edwards.js:11-31)
+Engine.prototype.defineEdwards = function defineEdwards(p, a, d) {
+  function buf(v) {
+    return Buffer.isBuffer(v) ? v : Buffer.from(v.toArray('be', 32));
+  }
+  return this.addon.defineEdwards(this.ctx, buf(p), buf(a), buf(d));
+};
 
 // ---- batch API on flat Buffers (fixed-width big-endian, item-major) ----------
 // scalars: n x B bytes; points: n x 2B bytes (x||y) or null for the generator.
@@ -350,7 +358,7 @@ function install(elliptic, options) {
   // A short curve that is no preset still gets its Point#mul / mulAdd / jmulAdd from the device:
   // run-time prime (<= 256 bits), arbitrary a (the generic `_dbl` / `dblp` of short.js:802-830,
   // 605-654), no fixed-base table.  options.customCurves === false keeps such curves on the
-  // reference's own code, as do primes wider than 256 bits and a ninth distinct curve.
+  // reference's own code, as do primes wider than 256 bits and a seventeenth distinct curve.
   function customDomain(curve) {
     if (curve._ellgpuCustom !== undefined) return curve._ellgpuCustom;
     var d = null;
@@ -360,6 +368,15 @@ function install(elliptic, options) {
       try {
         d = { name: 'custom', custom: true, B: 32,
           id: eng.defineShort(curve.p, curve.a.fromRed(), curve.b.fromRed()) };
+      } catch (e) { d = null; }
+    } else if (curve.type === 'edwards' && curve.a && curve.d && curve.c &&
+        curve.c.fromRed().cmpn(1) === 0 && curve.p.bitLength() <= 256 && curve.p.isOdd() &&
+        curve.p.cmpn(3) > 0) {
+      // (twisted) Edwards curves other than ed25519, c = 1: projective ladder on the device
+      // (the reference's _projDbl / _projAdd for a != -1, its extended forms for a = -1)
+      try {
+        d = { name: 'custom-edwards', custom: true, B: 32,
+          id: eng.defineEdwards(curve.p, curve.a.fromRed(), curve.d.fromRed()) };
       } catch (e) { d = null; }
     }
     Object.defineProperty(curve, '_ellgpuCustom', { value: d, enumerable: false,

@@ -105,7 +105,7 @@ int ellgpu_ctx_synchronize(ellgpu_ctx* ctx);
  * reference's `new elliptic.curve.short({p, a, b, ...})` (lib/elliptic/curve/short.js:11-24) with
  * parameters that are none of the presets; p, a, b are 32-byte big-endian (a, b reduced mod p).
  * Registers the curve with the context (a group: with every member) and returns its id
- * (>= ELLGPU_CURVE_CUSTOM0, at most 8 per context; defining the same parameters twice returns the
+ * (>= ELLGPU_CURVE_CUSTOM0, at most 16 per context; defining the same parameters twice returns the
  * same id).  The id is valid for ellgpu_mul_var / _mul_add2 (both points given) / _point_add and
  * their _dev forms, with 32-byte scalars and coordinates whatever p's size: Point#mul, mulAdd /
  * jmulAdd and Point#add with the generic-a doubling of JPoint#_dbl / dblp (short.js:802-830,
@@ -115,6 +115,18 @@ int ellgpu_ctx_synchronize(ellgpu_ctx* ctx);
 #define ELLGPU_CURVE_CUSTOM0 16
 int ellgpu_curve_define_short(ellgpu_ctx* ctx, const uint8_t* p, const uint8_t* a, const uint8_t* b,
                               int* out_curve);
+/* User-defined (twisted) Edwards curve a x^2 + y^2 = 1 + d x^2 y^2 (c = 1) over an odd prime
+ * p < 2^256 -- `new elliptic.curve.edwards({p, a, c: 1, d, ...})` (lib/elliptic/curve/edwards.js:
+ * 11-31) with parameters that are not ed25519's.  Same id space, widths (32 bytes) and entry
+ * points as ellgpu_curve_define_short; points are affine x || y, the identity is the ordinary
+ * point (0, 1) (out_inf stays 0; a set inf flag on input of ellgpu_point_add means (0, 1)).
+ * Point#mul / mulAdd / Point#add with the projective formulas the reference uses for a != -1
+ * (_projDbl / _projAdd, edwards.js:207-266, 311-348) and, for a = -1, the same group law its
+ * extended formulas compute.  The addition law is complete when a is a square and d is not;
+ * on other curves exceptional inputs give what the formulas give (a zero denominator comes out
+ * as (0, 0)). */
+int ellgpu_curve_define_edwards(ellgpu_ctx* ctx, const uint8_t* p, const uint8_t* a, const uint8_t* d,
+                                int* out_curve);
 
 /* ---- host-buffer entry points (what the N-API addon binds) -------------- */
 

@@ -554,3 +554,49 @@ def check_custom_short_golden(ctx, spec):
     for i, c in enumerate(dbl):
         assert _res_from(out, inf, i, 32) == want(c["r"]), ("dblp", spec["name"], c)
     return len(mul) + len(madd) + len(add) + len(dbl)
+
+
+def custom_edwards_curves():
+    """tests/golden/custom_edwards.json (tools/gen_golden_custom.js): user-defined Edwards curves"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "custom_edwards.json")) as f:
+        return json.load(f)
+
+
+def check_custom_edwards_golden(ctx, spec):
+    """Point#mul, Point#add and dbl of the reference on a user-defined (twisted) Edwards curve --
+    the projective _projDbl / _projAdd for a != -1, the extended forms for a = -1 -- against
+    ellgpu_curve_define_edwards's curve id; k1*P1 + k2*P2 against the sum of the two products"""
+    p, a, d = I(spec["p"]), I(spec["a"]), I(spec["d"])
+    cid = ctx.define_edwards(p, a, d)
+    assert cid >= 16 and ctx.define_edwards(p, a, d) == cid
+
+    def xy(pts):
+        return np.concatenate([ints_to_be([I(q["x"]) for q in pts], 32),
+                               ints_to_be([I(q["y"]) for q in pts], 32)], axis=1)
+    cases = spec["cases"]
+    mul = [c for c in cases if c["op"] == "mul"]
+    ks = ints_to_be([I(c["k"]) for c in mul], 32)
+    out, inf = ctx.mul_var(cid, ks, xy([c["p"] for c in mul]))
+    assert not inf.any()
+    for i, c in enumerate(mul):
+        assert _res_from(out, inf, i, 32) == (I(c["r"]["x"]), I(c["r"]["y"])), ("mul", spec["name"], c)
+    add = [c for c in cases if c["op"] == "add"]
+    out, inf = ctx.point_add(cid, xy([c["p1"] for c in add]), xy([c["p2"] for c in add]))
+    for i, c in enumerate(add):
+        assert _res_from(out, inf, i, 32) == (I(c["r"]["x"]), I(c["r"]["y"])), ("add", spec["name"], c)
+    # the identity through the inf flags: (0, 1) + P = P
+    flags = np.ones(len(add), np.uint8)
+    out, inf = ctx.point_add(cid, xy([c["p1"] for c in add]), xy([c["p2"] for c in add]), inf1=flags)
+    assert np.array_equal(out, xy([c["p2"] for c in add]))
+    dbl = [c for c in cases if c["op"] == "dbl"]
+    out, inf = ctx.point_add(cid, xy([c["p"] for c in dbl]), xy([c["p"] for c in dbl]))
+    for i, c in enumerate(dbl):
+        assert _res_from(out, inf, i, 32) == (I(c["r"]["x"]), I(c["r"]["y"])), ("dbl", spec["name"], c)
+    # k1*P1 + k2*P2 == (k1*P1) + (k2*P2)
+    m = len(mul) // 2
+    got, _ = ctx.mul_add2(cid, ks[:m], xy([c["p"] for c in mul[:m]]), ks[m:2 * m], xy([c["p"] for c in mul[m:2 * m]]))
+    want, _ = ctx.point_add(cid, xy([c["r"] for c in mul[:m]]), xy([c["r"] for c in mul[m:2 * m]]))
+    assert np.array_equal(got, want)
+    return len(mul) + len(add) + len(dbl) + m

@@ -388,3 +388,10 @@ def test_user_defined_short_curves_gpu(ctx, idx):
     results (tests/golden/custom_short.json)"""
     spec = PC.custom_curves()[idx]
     assert PC.check_custom_short_golden(ctx, spec) > 80
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_user_defined_edwards_curves_gpu(ctx, idx):
+    """`new curve.edwards({p, a, c: 1, d})` with parameters that are not ed25519's (SURVEY.md 8 row
+    a16: _projDbl / _projAdd): the reference's results on four such curves"""
+    assert PC.check_custom_edwards_golden(ctx, PC.custom_edwards_curves()[idx]) > 80

@@ -492,4 +492,12 @@ def test_user_defined_curve_errors(ctx):
         ctx.mul_fixed(cid, k)
     assert e.value.code == -5                                # ELLGPU_E_UNSUPPORTED
     with pytest.raises(elliptic_amd._lib.EllgpuError):
-        ctx.mul_var(23, k, np.zeros((1, 64), np.uint8))        # an id nobody defined
+        ctx.mul_var(31, k, np.zeros((1, 64), np.uint8))        # an id nobody defined
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_user_defined_edwards_curves(ctx, idx):
+    """`new curve.edwards({p, a, c: 1, d})` with parameters that are not ed25519's: projective
+    (a != -1) and extended (a = -1) curves of the reference against the device's run-time-prime
+    projective ladder (EdcWork)"""
+    assert PC.check_custom_edwards_golden(ctx, PC.custom_edwards_curves()[idx]) > 80

@@ -92,6 +92,28 @@ function same(a, b, what) {
     cp._wnafMulAdd(1, [r[0], r[0].neg(), r[1], r[2]], [ks[1], ks[1], ks[0], ks[2]], 4, false), name + ' cancelling pair');
   if (eng.stats.gpuCalls === b0) throw new Error(name + ': the 3/4-point forms did not reach the engine');
 });
+// Edwards curves that are not ed25519 (projective coordinates for a != -1): Point#mul on the device
+(function() {
+  function build(lib) {
+    var p = new BN(1).ushln(251).subn(9);                       // Curve1174
+    return new lib.curve.edwards({ p: p.toString(16), a: '1', c: '1', d: p.subn(1174).toString(16) });
+  }
+  var cp = build(plain), cq = build(patched);
+  var gp = null, gq = null;
+  for (var y = 2; !gp; y++) {
+    try { gp = cp.pointFromY(new BN(y), false); gq = cq.pointFromY(new BN(y), false); } catch (e) { gp = null; }
+  }
+  var b0 = eng.stats.gpuCalls;
+  [ '1', '2', 'deadbeef', 'ab54a98ceb1f0ad2ab54a98ceb1f0ad2ab54a98ceb1f0ad2ab54a98ceb1f0ad',
+    'ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff' ].forEach(function(k) {
+    var a = gq.mul(new BN(k, 16)), b = gp.mul(new BN(k, 16));
+    if (a.getX().cmp(b.getX()) !== 0 || a.getY().cmp(b.getY()) !== 0) throw new Error('curve1174 mul ' + k);
+    if (!cq.validate(a)) throw new Error('curve1174: result not on the curve');
+    checked++;
+  });
+  if (CUSTOM && eng.stats.gpuCalls === b0) throw new Error('curve1174 did not reach the engine');
+  if (!CUSTOM && eng.stats.gpuCalls !== b0) throw new Error('curve1174 reached the engine');
+})();
 // the presets themselves still go to the engine
 var b0 = eng.stats.gpuCalls;
 same(patched.curves.secp256k1.curve.g.mul(new BN(5)), plain.curves.secp256k1.curve.g.mul(new BN(5)), 'preset');

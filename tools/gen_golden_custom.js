@@ -140,3 +140,64 @@ var out = CURVES.map(gen);
 var file = path.join(OUT, 'custom_short.json');
 fs.writeFileSync(file, JSON.stringify(out, null, 1) + '\n');
 console.log('wrote', file, out.map(function(c) { return c.name + ':' + c.cases.length; }).join(' '));
+
+// ---- user-defined (twisted) Edwards curves, c = 1: custom_edwards.json ---------------------------
+// Curve1174 (p = 2^251 - 9, a = 1, d = -1174) and E-222 (p = 2^222 - 117, a = 1, d = 160102):
+// a = 1, so the reference runs _projDbl / _projAdd in their untwisted branches; two curves over
+// 2^255 - 19: a = 4 (twisted, projective branch with _mulA) and a = -1 with a d that is not
+// ed25519's (extended coordinates).  d is a non-square on all four (checked below), so the
+// addition laws are complete.  Base points come from pointFromY.
+var ED = [
+  { name: 'curve1174', p: new BN(1).ushln(251).subn(9), a: new BN(1), d: new BN(1).ushln(251).subn(9).subn(1174) },
+  { name: 'e222', p: new BN(1).ushln(222).subn(117), a: new BN(1), d: new BN(160102) },
+  { name: 'twisted_a4', p: new BN(1).ushln(255).subn(19), a: new BN(4), d: null },
+  { name: 'twisted_am1', p: new BN(1).ushln(255).subn(19), a: new BN(1).ushln(255).subn(20), d: null, aconf: '-1' },
+];
+function legendre(x, p) {
+  var red = BN.red(p);
+  return x.toRed(red).redPow(p.subn(1).ushrn(1)).fromRed().cmpn(1) === 0 ? 1 : -1;
+}
+function genEd(spec) {
+  var d = spec.d;
+  if (!d) for (d = new BN(121666); legendre(d, spec.p) !== -1; d = d.addn(1)) { /* next */ }
+  if (legendre(d, spec.p) !== -1) throw new Error(spec.name + ': d is a square');
+  var curve = new elliptic.curve.edwards({ p: spec.p.toString(16), a: spec.aconf || spec.a.toString(16), c: '1',
+    d: d.toString(16) });
+  var G = null;
+  for (var y = 2; !G; y++) {
+    try { G = curve.pointFromY(new BN(y), false); } catch (e) { G = null; }
+    if (G && G.getX().isZero()) G = null;
+  }
+  if (!curve.validate(G)) throw new Error(spec.name + ': base point not on the curve');
+  var rng = new Prng('ellgpu-golden-v1:custom-edwards:' + spec.name);
+  var cases = [];
+  function pt(p) { var q = curve.point(p.x, p.y, p.z, p.t); return { x: hex32(q.getX()), y: hex32(q.getY()) }; }
+  function randPoint() { return G.mul(rng.bits(spec.p.bitLength() + 8)); }
+  var P0 = randPoint();
+  var edge = [new BN(0), new BN(1), new BN(2), new BN(3), new BN(7), new BN(8), new BN(9), new BN(15), new BN(16),
+    new BN(17), new BN(1).ushln(128), new BN(1).ushln(255), new BN(1).ushln(256).subn(1)];
+  edge.forEach(function(k) {
+    cases.push({ op: 'mul', k: hex32(k), p: pt(P0), r: pt(P0.mul(k)) });
+    cases.push({ op: 'mul', k: hex32(k), p: pt(G), r: pt(G.mul(k)) });
+  });
+  var i;
+  for (i = 0; i < 24; i++) {
+    var P = randPoint();
+    var k = (i % 3 === 2) ? rng.bits(256) : rng.bits(spec.p.bitLength());
+    cases.push({ op: 'mul', k: hex32(k), p: pt(P), r: pt(P.mul(k)) });
+  }
+  var O = curve.point(null, null, null);
+  var Q0 = randPoint();
+  var adds = [[P0, Q0], [P0, P0], [P0, P0.neg()], [O, P0], [P0, O], [O, O], [G, G]];
+  for (i = 0; i < 10; i++) adds.push([randPoint(), randPoint()]);
+  adds.forEach(function(s) {
+    cases.push({ op: 'add', p1: pt(s[0]), p2: pt(s[1]), r: pt(s[0].add(s[1])) });
+  });
+  [P0, G, Q0].forEach(function(p) { cases.push({ op: 'dbl', p: pt(p), r: pt(p.dbl()) }); });
+  return { name: spec.name, p: hex32(curve.p), a: hex32(curve.a.fromRed()), d: hex32(curve.d.fromRed()),
+    extended: curve.extended, twisted: curve.twisted, g: pt(G), cases: cases };
+}
+var outE = ED.map(genEd);
+file = path.join(OUT, 'custom_edwards.json');
+fs.writeFileSync(file, JSON.stringify(outE, null, 1) + '\n');
+console.log('wrote', file, outE.map(function(c) { return c.name + ':' + c.cases.length + (c.extended ? ':ext' : ':proj'); }).join(' '));
