@@ -723,6 +723,13 @@ struct Work {
   // within 16 draws (never in practice; the item is then reported as not signed).
   typedef typename std::conditional<CV::ID == CURVE_P384, Sha384,
           typename std::conditional<CV::ID == CURVE_P521, Sha512, Sha256>::type>::type SignHash;
+  // the private key as the reference's DRBG sees it: KeyPair#_importPrivate reduces it mod n
+  // (ec/key.js:91-96) before EC#sign takes getPrivate().toArray('be', n.byteLength())
+  ELL_HD static void load_priv_mod_n(u32 (&d)[LN], const u8* priv, size_t i) {
+    u32 t[LN];
+    load_be<LN>(t, priv + i * NBYTES, NBYTES);
+    Fn::to_plain(d, Fn::from_plain(t));
+  }
   ELL_HD static void det_nonce(size_t i, const u8* hash, int hash_len, int shift, const u8* priv,
                                u8* nonce_out) {
     u32 e[LN], nn[LN], nm1[LN], one1[LN];
@@ -739,7 +746,7 @@ struct Work {
       // word-oriented generator: n.byteLength() is a whole number of words, one V per draw
       constexpr int NW = NBYTES / 4;
       u32 d[LN], seed[2 * NW];
-      load_be<LN>(d, priv + i * NBYTES, NBYTES);
+      load_priv_mod_n(d, priv, i);
       ELL_UNROLL
       for (int w = 0; w < NW; w++) { seed[w] = d[NW - 1 - w]; seed[NW + w] = e[NW - 1 - w]; }
       HmacDrbg256<2 * NW> g;
@@ -759,7 +766,7 @@ struct Work {
     } else if constexpr (std::is_same<SignHash, Sha384>::value && NBYTES == 48) {
       // p384: the same with 64-bit words (SHA-384: 6-word K / V, one V per 48-byte draw)
       u32 d[LN];
-      load_be<LN>(d, priv + i * NBYTES, NBYTES);
+      load_priv_mod_n(d, priv, i);
       u64 seed[12];
       ELL_UNROLL
       for (int w = 0; w < 6; w++) {
@@ -784,8 +791,11 @@ struct Work {
     } else if constexpr (std::is_same<SignHash, Sha512>::value && NBYTES > 64 && NBYTES <= 128) {
       // p521: 66-byte entropy, nonce and draws -- word-oriented state, byte-granular tails
       u8 sb[1 + 2 * NBYTES], kb[NBYTES];
-      ELL_NOUNROLL
-      for (int b = 0; b < NBYTES; b++) sb[1 + b] = priv[i * NBYTES + b];
+      {
+        u32 d[LN];
+        load_priv_mod_n(d, priv, i);
+        store_be<LN>(sb + 1, d, NBYTES);
+      }
       store_be<LN>(sb + 1 + NBYTES, e, NBYTES);
       HmacDrbg512Bytes g;
       g.init(sb, 2 * NBYTES);
@@ -803,10 +813,15 @@ struct Work {
       ELL_NOUNROLL
       for (int b = 0; b < NBYTES; b++) nonce_out[i * NBYTES + b] = done ? kb[b] : (u8)0;
     } else {
-      u8 eb[NBYTES], kb[NBYTES];
+      u8 eb[NBYTES], kb[NBYTES], pb[NBYTES];
       store_be<LN>(eb, e, NBYTES);
+      {
+        u32 d[LN];
+        load_priv_mod_n(d, priv, i);
+        store_be<LN>(pb, d, NBYTES);
+      }
       HmacDrbg<SignHash> g;
-      g.init(priv + i * NBYTES, NBYTES, eb, NBYTES);
+      g.init(pb, NBYTES, eb, NBYTES);
       bool done = false;
       ELL_NOUNROLL
       for (int it = 0; it < 16 && !done; it++) {

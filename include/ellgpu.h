@@ -285,8 +285,9 @@ int ellgpu_eddsa_verify_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, cons
  * HmacDRBG (hmac-drbg 1.0.1) over the curve's hash (SHA-256; SHA-384 for p384, SHA-512 for p521;
  * lib/elliptic/curves.js `hash:`), entropy = the private key, nonce = the truncated message,
  * candidates drawn until one is accepted (:151-158); no personalisation string (options.pers).
- * Arguments and outputs as ellgpu_ecdsa_sign without `nonces`; priv must be the
- * n.byteLength()-byte big-endian encoding the reference feeds to the DRBG.  out_ok[i] = 0 only
+ * Arguments and outputs as ellgpu_ecdsa_sign without `nonces`; priv is n.byteLength() bytes,
+ * big-endian, and -- like KeyPair#_importPrivate (ec/key.js:91-96) -- reduced mod n before it
+ * seeds the DRBG, so a key >= n signs exactly like its residue.  out_ok[i] = 0 only
  * in the (never observed) case that the reference would go on to a further candidate because
  * r or s came out zero. */
 int ellgpu_ecdsa_sign_det(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,

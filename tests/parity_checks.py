@@ -186,6 +186,16 @@ def check_signdet_golden(ctx, curve):
             assert ok[i] == 1, c["note"]
             assert (r[i].tobytes().hex(), s[i].tobytes().hex(), int(rec[i])) == (c["r"], c["s"], c["recid"]), c["note"]
             total += 1
+    # a private key >= n signs like its residue (KeyPair#_importPrivate reduces it, ec/key.js:91-96):
+    # the DRBG is seeded with d mod n
+    n_int = int.from_bytes(bytes.fromhex(load("curves.json")[curve]["n"].rjust(2 * NB, "0")), "big")
+    d0 = 0x1234567
+    ds = [d0] + [d0 + m * n_int for m in (1, 100) if d0 + m * n_int < 1 << (8 * NB)]
+    if len(ds) > 1:
+        z = np.tile(np.frombuffer(bytes(range(1, 33)), np.uint8), (len(ds), 1))
+        r, s, rec, ok = ctx.ecdsa_sign_det(curve, z, ints_to_be(ds, NB))
+        assert ok.all() and (r == r[0]).all() and (s == s[0]).all() and (rec == rec[0]).all()
+        total += len(ds) - 1
     return total
 
 
