@@ -23,6 +23,7 @@ MAP = {
     "host_path.jsonl": "host_path.jsonl",
     "js_bench.jsonl": "js_bench.jsonl",
     "soak.log": "soak.log",
+    "custom_curve_bench.jsonl": "custom_curve_bench.jsonl",
     "bench_under_rocprof.log": "bench_under_rocprof.log",
     "rocprof_stats.txt": "rocprof_kernel_stats.txt",
     "rocprof_fw.txt": "rocprof_pmc_fetch_write.txt",

@@ -10,10 +10,9 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/refresh
 MODE="$1"
 rm -rf $O && mkdir -p $O
+ROUND="${ELL_ROUND:-r02}"
 ( time timeout 900 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
 tail -3 $O/pytest_gpu.log
-timeout 600 python bench.py > $O/bench.json.log 2> $O/bench.err
-tail -c 600 $O/bench.json.log
 # the workload of the PMC passes: one pass of every benchmarked kernel (headline + configs), 2 timed steps
 PROF="python bench.py --steps 2 --warmup 1 --no-cpu"
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o stats -- python bench.py --steps 30 --warmup 5 --no-cpu --no-configs > $O/bench_under_rocprof.log 2>&1
@@ -32,6 +31,11 @@ for t in stats sqa sqb fwa fwb gc; do
 done
 cat $O/rocprof_fwa.txt $O/rocprof_fwb.txt > $O/rocprof_fw.txt 2>/dev/null
 rm -rf $O/prof_stats $O/prof_fwa $O/prof_fwb $O/prof_sqa $O/prof_sqb $O/prof_gc
+# distil the counters HERE first (into this box's copy of profiles/), so that the bench.py run
+# below prices its roofline with the instruction counts of the very binaries it runs
+python tools/refresh_profiles.py --round $ROUND --src $O > $O/distil.log 2>&1
+timeout 600 python bench.py > $O/bench.json.log 2> $O/bench.err
+tail -c 600 $O/bench.json.log
 if [ "$MODE" != "quick" ]; then
   timeout 300 python tools/gpu_probe.py > $O/valu_probe.log 2>&1
   timeout 200 tools/microbench/_build/valu_patterns > $O/valu_patterns.log 2>&1
@@ -39,6 +43,7 @@ if [ "$MODE" != "quick" ]; then
   timeout 600 python tools/bench_configs.py 2>/dev/null | grep '"config"' > $O/configs.jsonl
   timeout 300 python tools/bench_host_path.py --reps 8 2>/dev/null | grep '"config"' > $O/host_path.jsonl
   timeout 120 node elliptic_amd/js/bench.js 2>/dev/null | grep '^{' > $O/js_bench.jsonl
+  timeout 300 python tools/bench_custom.py 18 > $O/custom_curve_bench.jsonl 2>/dev/null
   timeout 300 python tests/soak.py --seconds 40 > $O/soak.log 2>&1
 fi
 ls -la $O
