@@ -263,15 +263,19 @@ def roofline_block(kernel_key, unit_key, n, kernel_ms, peak_gmads, clock_ghz, co
                     "multiply_share_of_valu_insts": mads / k["valu_per_unit"] if k.get("valu_per_unit") else None,
                     "valu_busy_pmc": k.get("valu_busy"), "counters_source": csrc,
                     "counters_stale": (counters.get("source_digest") != lib_digest())})
-        # issue accounting: instruction classes priced at their measured issue times
-        if k.get("valu_per_unit") and k.get("int32_per_unit") is not None:
-            other = max(k["valu_per_unit"] - mads - k["int32_per_unit"], 0.0)
-            need = 64 * (4.5 * mads + 4.2 * k["int32_per_unit"] + 2.5 * other)      # cycles per wavefront of 64 units
-            have = kernel_ms * 1e-3 * clock_ghz * 1e9 / ((n / 64.0) / N_SIMD)
-            out["issue"] = {"issue_cycles_per_wave": need, "elapsed_cycles_per_wave_slot": have,
-                            "frac": need / have if have else None,
-                            "prices": "4.5 / 4.2 / 2.5 cycles per wave-instruction (mad / carry-class / other), "
-                                      "profiles/*valu_patterns.log"}
+        # issue accounting: a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles; the
+        # per-unit counts are per lane, i.e. per wavefront-instruction stream
+        if k.get("valu_per_unit"):
+            waves_per_simd = (n / 64.0) / N_SIMD
+            elapsed = kernel_ms * 1e-3 * clock_ghz * 1e9
+            cpi = elapsed / (waves_per_simd * k["valu_per_unit"]) if waves_per_simd else None
+            out["issue"] = {"valu_insts_per_wave": k["valu_per_unit"], "waves_per_simd": waves_per_simd,
+                            "elapsed_cycles_at_nominal_clock": elapsed, "cycles_per_valu_inst": cpi,
+                            "floor_cycles_per_valu_inst": 4.0,
+                            "valu_busy_pct_pmc": (k.get("valu_busy") or {}).get("valu_busy_pct_gfx94x_formula"),
+                            "note": "SIMD cycles per VALU wave-instruction at the nominal clock; 4 is the wave64 issue "
+                                    "floor of mixed code (runs of plain VOP1/VOP2 issue faster, "
+                                    "profiles/*valu_patterns.log): at or below it the VALU pipe never idles"}
     else:
         out.update({"achieved": None, "frac": None,
                     "note": "no committed PMC instruction counts for this kernel (profiles/*kernel_counters.json)"})

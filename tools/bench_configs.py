@@ -95,8 +95,6 @@ def main():
             ok2 = torch.zeros(n, dtype=torch.uint8, device=dev)
             timed("%s ECDSA verify" % curve, n, lambda: ctx.ecdsa_verify_dev(curve, hz, r_o, s_o, pts, ok2))
             assert bool(ok2[good].bool().all())
-            if curve == "p224":
-                continue                      # no point decompression for p = 1 (mod 4)
             # public-key recovery from those signatures (decompress R, r^-1, s1*G + s2*R): must
             # give back d*G wherever the signing pass accepted the nonce
             q_o = torch.zeros((n, 2 * B), dtype=torch.uint8, device=dev)
