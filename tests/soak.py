@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential soak on the GPU box: large seeded batches of every ladder-shaped
-entry point on every short curve against the C port of the reference's algorithm
+entry point on every short curve, ed25519, curve25519 and a user-defined curve against the C port of the reference's algorithm
 (oracle/ec_oracle.c, run on host threads), item by item.  Checker use of oracle/ only.
 
     python tests/soak.py [--seconds 120] [--seed 1]
@@ -16,6 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import elliptic_amd
 from oracle import c_oracle
 
@@ -45,6 +46,7 @@ def main():
     t_end = time.time() + a.seconds
     rounds = 0
     checked = 0
+    custom = None
     while time.time() < t_end:
         for curve in CURVES:
             B = elliptic_amd.FIELD_BYTES[curve]
@@ -84,6 +86,41 @@ def main():
             assert np.array_equal(got, want), (curve, "verify")
             assert want[2::5].all() and not want[::5].any()
             checked += 6 * n
+        # ed25519 (Edwards) and curve25519 (x-only Montgomery): variable base against the C oracle's
+        # _extAdd / _extDbl and diffAdd / dbl; a user-defined curve (brainpoolP256r1) against its
+        # generic-a _dbl path
+        n = 6000
+        tag = "soak:%d:%d:25519" % (a.seed, rounds)
+        k, r0 = rnd(tag + ":k", n, 32), rnd(tag + ":r", n, 32)
+        k[::53] = 0
+        k[1::53, :31] = 0
+        base = c_oracle.ed_mul(r0, None, threads=threads)
+        want = c_oracle.ed_mul(k, base, threads=threads)
+        got = ctx.mul_var("ed25519", k, base)
+        assert np.array_equal(got[0], want), "ed25519 mul_var"
+        gotf = ctx.mul_fixed("ed25519", r0)
+        assert np.array_equal(gotf[0], base), "ed25519 mul_fixed"
+        xs = rnd(tag + ":x", n, 32)
+        xs[:, 0] &= 0x7F
+        wx, wi = c_oracle.mont_mul(k, xs, threads=threads)
+        gx, gi = ctx.x25519(k, xs)
+        assert np.array_equal(gi, wi) and np.array_equal(gx, wx), "x25519"
+        if custom is None:
+            import parity_checks as PC
+            from golden_util import I
+            sp = [c for c in PC.custom_curves() if c["name"] == "brainpoolP256r1"][0]
+            cid = ctx.define_short(I(sp["p"]), I(sp["a"]), I(sp["b"]))
+            cname = c_oracle.define_short("custom:brainpoolP256r1", I(sp["p"]), I(sp["a"]), I(sp["b"]), I(sp["n"]),
+                                          I(sp["g"]["x"]), I(sp["g"]["y"]))
+            g = np.frombuffer(I(sp["g"]["x"]).to_bytes(32, "big") + I(sp["g"]["y"]).to_bytes(32, "big"), np.uint8)
+            custom = (cid, cname, g)
+        cid, cname, g = custom
+        m = 4000
+        cp, ci = ctx.mul_var(cid, r0[:m], np.tile(g, (m, 1)))
+        want = c_oracle.mul_mt(cname, k[:m], cp, threads)
+        got = ctx.mul_var(cid, k[:m], cp)
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]), "custom mul_var"
+        checked += 3 * n + m
         rounds += 1
     print(json.dumps({"ok": True, "rounds": rounds, "items_checked": checked, "threads": threads}))
 
