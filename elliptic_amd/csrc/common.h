@@ -7,6 +7,20 @@
 // oracle without a GPU.  That host build is test infrastructure -- it is not
 // linked into libellgpu.so, which has no CPU fallback.
 #pragma once
+// Register-pressure switches of the secp256k1 ladder kernels (engine.h: ELL_ENDO_MIN_WAVES):
+//   ELL_BETA_REMAT   beta moved in from scalar registers at every lambda*P lookup instead of
+//                    eight VGPRs held across the ladder
+//   ELL_SPILL_ZG     the table's common Z parked in a free table slot during the ladder
+//   ELL_LATE_LOADS   u1 / k1 and r loaded after the ladder, behind compiler barriers
+#ifndef ELL_BETA_REMAT
+#define ELL_BETA_REMAT 1
+#endif
+#ifndef ELL_SPILL_ZG
+#define ELL_SPILL_ZG 1
+#endif
+#ifndef ELL_LATE_LOADS
+#define ELL_LATE_LOADS 1
+#endif
 
 #include <stdint.h>
 #include <stddef.h>

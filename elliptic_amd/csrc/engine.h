@@ -36,6 +36,17 @@
 #ifndef ELL_CUSTOM_MIN_WAVES
 #define ELL_CUSTOM_MIN_WAVES 3      // user-defined curves (Jacobian window table, generic-a doubling)
 #endif
+// secp256k1's verify / k1*G + k2*P kernels: 4 waves/SIMD (128 VGPRs).  With beta re-materialised
+// at each lookup, zg parked in a free table slot and u1 / r loaded behind compiler barriers
+// (common.h: ELL_BETA_REMAT, ELL_SPILL_ZG, ELL_LATE_LOADS) the ladder loop holds no spills at 128
+// registers: ecdsa_main 8.43 -> 8.20 ms per 2^20 (3 waves, 168 VGPRs before; 5 waves = 96 VGPRs
+// spills 304 B and is 13 % slower), profiles/r02_four_waves_ab.jsonl
+#ifndef ELL_ENDO_MIN_WAVES
+#define ELL_ENDO_MIN_WAVES 4
+#endif
+#ifndef ELL_FIXED_MIN_WAVES
+#define ELL_FIXED_MIN_WAVES 4       // fixed-base comb kernels (mul_fixed, sign_mul) of the <= 256-bit curves: 128 VGPRs, -2..3.5 % on secp256k1, neutral elsewhere
+#endif
 #ifndef ELL_ECDSA_MIN_WAVES
 #define ELL_ECDSA_MIN_WAVES 3
 #endif
@@ -76,7 +87,7 @@ struct FnMulAddG {
   static constexpr const char* NAME = "mul_add_g";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
-  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? ELL_ECDSA_MIN_WAVES : (W::L == 12 ? ELL_P384_MIN_WAVES : 1));      // p384: 2 waves/SIMD (<= 256 registers) beats a spill-free single wave
+  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? (CV::ENDO ? ELL_ENDO_MIN_WAVES : ELL_ECDSA_MIN_WAVES) : (W::L == 12 ? ELL_P384_MIN_WAVES : 1));      // p384: 2 waves/SIMD (<= 256 registers) beats a spill-free single wave
   size_t n; const u8* k1; const u8* k2; const u8* xy2; const typename W::A* comb;
   typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
@@ -87,7 +98,7 @@ template <class CV, int MW = 0>
 struct FnMulFixed {
   static constexpr const char* NAME = "mul_fixed";
   typedef Work<CV> W;
-  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? 3 : 1);   // <= 168 VGPRs for the 256-bit curves (p256 takes 170 unconstrained)
+  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? ELL_FIXED_MIN_WAVES : 1);
   static constexpr int DS_PER_LANE = 0;
   size_t n; const u8* k; const typename W::A* comb; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore&) const {
@@ -120,7 +131,7 @@ template <class CV, int MW = 0>
 struct FnEcdsaMain {
   static constexpr const char* NAME = "ecdsa_main";
   typedef Work<CV> W;
-  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? ELL_ECDSA_MIN_WAVES : (W::L == 12 ? ELL_P384_MIN_WAVES : 1));   // <= 168 VGPRs for 256-bit curves, <= 256 for p384
+  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? (CV::ENDO ? ELL_ENDO_MIN_WAVES : ELL_ECDSA_MIN_WAVES) : (W::L == 12 ? ELL_P384_MIN_WAVES : 1));   // 128 VGPRs for secp256k1, <= 168 for the other 256-bit curves, <= 256 for p384
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
   size_t n; const u32* u12; const u8* valid; const u8* r; const u8* pub;
   const typename W::A* comb; typename W::VT* tbl; u8* ok;
@@ -133,7 +144,7 @@ template <class CV, int MW = 0>
 struct FnSignMul {
   static constexpr const char* NAME = "sign_mul";
   typedef Work<CV> W;
-  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? 3 : 1);   // <= 168 VGPRs for the 256-bit curves (p256 takes 170 unconstrained)
+  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? ELL_FIXED_MIN_WAVES : 1);
   static constexpr int DS_PER_LANE = 0;
   size_t n; const u8* nonces; const typename W::A* comb; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore&) const {

@@ -100,6 +100,25 @@ struct Ladder {
   typedef Jac<F> J;
   typedef Aff<F> A;
 
+  // beta for the lambda-at-lookup entries.  ELL_BETA_REMAT = 1 (experiment): instead of holding the
+  // eight limbs in VGPRs across the whole ladder, move them in from scalar registers at every
+  // lookup (8 v_mov per lambda*P lookup, 8 registers fewer live in the loop)
+  template <bool L>
+  ELL_HD static El lookup_beta(const El* beta) {
+#if ELL_BETA_REMAT && defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (L && !is_lazy<F>::value) {
+      El b;
+      ELL_UNROLL
+      for (int i = 0; i < F::L; i++) {
+        u32 c;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "s"(CV::C::beta[i]));
+        b.v[i] = c;
+      }
+      return b;
+    }
+#endif
+    return *beta;
+  }
   // neg ? -y : y for a table entry's y (a direct product output): lazy fields negate limb-wise
   // with the offset 2p, without a normalisation pass
   ELL_HD static El cneg_y(const El& y, bool neg) {
@@ -175,7 +194,7 @@ struct Ladder {
       int ad = d < 0 ? -d : d;
       bool neg = (d < 0) != (((negmask >> s) & 1u) != 0);
       A q = tbl[(LAMBDA_AT_LOOKUP ? 0 : s * 8) + ((ad - 1) >> 1)];
-      if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, *beta);
+      if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP>(beta));
       q.y = cneg_y(q.y, neg);
       return q;
     };
@@ -196,7 +215,7 @@ struct Ladder {
     for (int s = 0; s < NS; s++) {
       auto corr = [&]() -> A {
         A q = tbl[LAMBDA_AT_LOOKUP ? 0 : s * 8];
-        if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, *beta);
+        if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP>(beta));
         bool neg = ((negmask >> s) & 1u) == 0;        // subtract sign_s * P_s
         q.y = cneg_y(q.y, neg);
         return q;

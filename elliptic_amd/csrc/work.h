@@ -167,7 +167,16 @@ struct Work {
       // isomorphisms, which only scale x and y
       El beta = load_beta();
 #if ELL_LAMBDA_AT_LOOKUP
+#if ELL_SPILL_ZG && defined(__HIP_DEVICE_COMPILE__)
+      // zg is needed again only after the ladder: park it in a free table slot (slots 8..15 are
+      // the build's scratch) instead of eight registers held across the loop
+      tbl[15].x = zg;
       J r = LD::template run_odd_w4<2, NNIB, true>(ds, tbl, negmask, evenmask, inf, &beta);
+      asm volatile("" ::: "memory");
+      zg = tbl[15].x;
+#else
+      J r = LD::template run_odd_w4<2, NNIB, true>(ds, tbl, negmask, evenmask, inf, &beta);
+#endif
 #else
       ELL_NOUNROLL
       for (int e = 0; e < 8; e++) {
@@ -245,20 +254,19 @@ struct Work {
 
   // k1*G + k2*P2 -> Jacobian (the shape ECDSA verify uses): window ladder for P2, then the
   // comb's mixed additions for G onto the same accumulator (no second point, no Jacobian add)
-  ELL_HD static J mul_add_g(const u32 (&k1)[L], const u32 (&k2)[L], const A& p2, const A* comb,
-                            VT* tbl, const DigitStore& ds) {
-    bool inf;
-    J b = var_ladder(k2, p2, tbl, ds, inf);
-    return LD::template comb_add<L, COMB_W, COMB_BITS>(b, inf, k1, comb);
-  }
   ELL_HD static void mul_add_g_item(size_t i, size_t n, const u8* k1s, const u8* k2s,
                                     const u8* xy2, const A* comb, VT* tbl_all,
                                     const DigitStore& ds, u32* jac) {
     u32 k1[L], k2[L];
-    load_be<L>(k1, k1s + i * BYTES, BYTES);
     load_be<L>(k2, k2s + i * BYTES, BYTES);
     A p2 = load_affine(xy2, i);
-    J r = mul_add_g(k1, k2, p2, comb, tbl_all + i * TBL1, ds);
+    bool inf;
+    J b = var_ladder(k2, p2, tbl_all + i * TBL1, ds, inf);
+#if ELL_LATE_LOADS && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::: "memory");                 // k1 is loaded after the ladder (see ecdsa_main)
+#endif
+    load_be<L>(k1, k1s + i * BYTES, BYTES);
+    J r = LD::template comb_add<L, COMB_W, COMB_BITS>(b, inf, k1, comb);
     store_jac(jac, n, i, r);
   }
 
@@ -964,13 +972,22 @@ struct Work {
                                 const DigitStore& ds, u8* out_ok) {
     u32 u1[L], u2[L], r[LN];
     ELL_UNROLL
-    for (int l = 0; l < L; l++) {
-      u1[l] = l < LN ? u12[(size_t)(0 * LN + l) * n + i] : 0u;
-      u2[l] = l < LN ? u12[(size_t)(1 * LN + l) * n + i] : 0u;
-    }
-    load_be<LN>(r, rs + i * NBYTES, NBYTES);
+    for (int l = 0; l < L; l++) u2[l] = l < LN ? u12[(size_t)(1 * LN + l) * n + i] : 0u;
     A q = load_affine(pub_xy, i);
-    J p = mul_add_g(u1, u2, q, comb, tbl_all + i * TBL1, ds);
+    // u2 * Q first; u1 and r are loaded where they are used, behind compiler barriers, so that
+    // they do not occupy registers across the ladder (ELL_LATE_LOADS: the 128-register build)
+    bool inf;
+    J b = var_ladder(u2, q, tbl_all + i * TBL1, ds, inf);
+#if ELL_LATE_LOADS && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::: "memory");
+#endif
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) u1[l] = l < LN ? u12[(size_t)(0 * LN + l) * n + i] : 0u;
+    J p = LD::template comb_add<L, COMB_W, COMB_BITS>(b, inf, u1, comb);
+#if ELL_LATE_LOADS && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::: "memory");
+#endif
+    load_be<LN>(r, rs + i * NBYTES, NBYTES);
     bool ok = valid[i] != 0 && !G::is_inf(p);
     ok = ok && eq_x_to_p(p, r);
     out_ok[i] = ok ? 1 : 0;
