@@ -395,3 +395,31 @@ def test_user_defined_edwards_curves_gpu(ctx, idx):
     """`new curve.edwards({p, a, c: 1, d})` with parameters that are not ed25519's (SURVEY.md 8 row
     a16: _projDbl / _projAdd): the reference's results on four such curves"""
     assert PC.check_custom_edwards_golden(ctx, PC.custom_edwards_curves()[idx]) > 80
+
+
+def test_dev_calls_on_alternating_streams(ctx):
+    """*_dev calls share the context's scratch arena: issued from two torch streams without any host
+    synchronisation in between (they used to race on the window tables), every call's
+    result must equal the one-stream result.  The library orders them on the device through the
+    event each call records (HipBackend::use_stream / end_call)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 1 << 16
+    rng = np.random.default_rng(7)
+    ks = [rng.integers(0, 256, (n, 32), dtype=np.uint8) for _ in range(6)]
+    g = np.frombuffer(O.get_curve("secp256k1").g.x.to_bytes(32, "big") + O.get_curve("secp256k1").g.y.to_bytes(32, "big"), np.uint8)
+    pts, _ = ctx.mul_fixed("secp256k1", ks[0])
+    want = [ctx.mul_var("secp256k1", k, pts) for k in ks]
+    dk = [torch.from_numpy(k).to(dev) for k in ks]
+    dp = torch.from_numpy(pts).to(dev)
+    outs = [(torch.zeros(n, 64, dtype=torch.uint8, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)) for _ in ks]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i, k in enumerate(dk):
+            with torch.cuda.stream(streams[i & 1]):
+                ctx.mul_var_dev("secp256k1", k, dp, outs[i][0], outs[i][1])
+        torch.cuda.synchronize()
+        for i in range(len(ks)):
+            assert np.array_equal(outs[i][0].cpu().numpy(), want[i][0]) and np.array_equal(outs[i][1].cpu().numpy(), want[i][1]), (rep, i)
+            outs[i][0].zero_()
