@@ -44,6 +44,13 @@
 #ifndef ELL_ENDO_MIN_WAVES
 #define ELL_ENDO_MIN_WAVES 4
 #endif
+#ifndef ELL_PIPE_STEP_DEFAULT
+#ifdef ELL_PIPE_STEP
+#define ELL_PIPE_STEP_DEFAULT ELL_PIPE_STEP
+#else
+#define ELL_PIPE_STEP_DEFAULT 3      // hip_backend.h documents the sweep
+#endif
+#endif
 #ifndef ELL_FIXED_MIN_WAVES
 #define ELL_FIXED_MIN_WAVES 4       // fixed-base comb kernels (mul_fixed, sign_mul) of the <= 256-bit curves: 128 VGPRs, -2..3.5 % on secp256k1, neutral elsewhere
 #endif
@@ -736,6 +743,11 @@ class Engine {
       return fail(E_ARG, "user-defined Edwards curve: a and d must be non-zero and distinct");
     f.kind = 1;
     return register_custom(f, out_curve);
+  }
+  static size_t pipe_step_default() {
+    const char* e = getenv("ELLGPU_PIPE_STEP");          // developer override
+    int v = e ? atoi(e) : ELL_PIPE_STEP_DEFAULT;
+    return (size_t)(v >= 1 && v <= 64 ? v : ELL_PIPE_STEP_DEFAULT);
   }
   bool custom_is_edwards(int curve) const {
     size_t slot = (size_t)(curve - CURVE_CUSTOM0);
@@ -1491,7 +1503,7 @@ class Engine {
       }
       pev = ev; po = o; pm = m;
       o += m;
-      step = 4 * q;                               // measured: every chunk boundary costs ~0.4 ms
+      step = pipe_step_ * q;                      // measured: every chunk boundary costs ~0.4 ms
     }
     if (pev >= 0 && !rc) {
       bk.copy_after(pev);
@@ -1618,6 +1630,7 @@ class Engine {
   Buf staging_[G_COUNT];
   std::vector<RtField> custom_;  // user-defined curves of this context (id = CURVE_CUSTOM0 + index)
   bool custom_active_ = false;
+  size_t pipe_step_ = pipe_step_default();   // chunks after the first, in quanta
 };
 
 // ---- out-of-class definitions of the per-(curve, operation) members: NOT inline, so that

@@ -17,6 +17,17 @@
 namespace ell {
 
 constexpr int BLOCK = 128;
+// Chunking of the pipelined host-buffer entry points (Engine::pipelined): the first chunk is one
+// quantum of 256 CUs x 4 SIMDs x ELL_PIPE_WAVES x 64 items, the following ones ELL_PIPE_STEP quanta.
+// Swept on one box (profiles/r02_host_pipeline_sweep.log): 2 waves x 3 quanta -- chunks of 131 072,
+// 393 216 and the rest of a 2^20 batch -- gives 108 M verifies/s from host buffers against 97 M/s
+// with the round-1 setting (3 waves x 4 quanta), G*k 512 against 403 M/s.
+#ifndef ELL_PIPE_WAVES
+#define ELL_PIPE_WAVES 2
+#endif
+#ifndef ELL_PIPE_STEP
+#define ELL_PIPE_STEP 3
+#endif
 
 // Fn::MIN_WAVES (optional, default 1) = waves per SIMD the register allocator must
 // leave room for (__launch_bounds__'s second argument counts waves per SIMD here).
@@ -109,8 +120,16 @@ struct HipBackend {
     return last ? E_HIP : E_OK;
   }
   // ---- copy stream for the pipelined host-buffer entry points (Engine::pipelined) ----
-  // items resident in one round of wavefronts at 3 waves/SIMD (256 CUs x 4 SIMDs x 3 x 64)
-  static size_t pipeline_quantum() { return (size_t)256 * 4 * 3 * 64; }
+  // ELLGPU_PIPE_WAVES (developer override): resident waves per SIMD the quantum assumes
+  static size_t pipeline_quantum() {
+    static const size_t q = []() {
+      const char* e = getenv("ELLGPU_PIPE_WAVES");
+      int w = e ? atoi(e) : ELL_PIPE_WAVES;
+      if (w < 1 || w > 8) w = ELL_PIPE_WAVES;
+      return (size_t)256 * 4 * (size_t)w * 64;
+    }();
+    return q;
+  }
   void h2d_copy(void* d, const void* h, size_t bytes) {
     if (bytes) note(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, copy));
   }
