@@ -23,6 +23,7 @@ _SIGS = {
     "ellgpu_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "ellgpu_group_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "ellgpu_group_size": (ctypes.c_int, [ctypes.c_void_p]),
+    "ellgpu_ctx_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
     "ellgpu_curve_define_short": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
                                                  ctypes.POINTER(ctypes.c_int)]),
     "ellgpu_curve_define_edwards": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,

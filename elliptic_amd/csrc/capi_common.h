@@ -137,6 +137,10 @@ int ellgpu_ctx_synchronize(ellgpu_ctx* ctx) {
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
   return finish(ctx, ctx->eng->bk.sync());
 }
+void* ellgpu_ctx_stream(ellgpu_ctx* ctx) {
+  if (!ctx) return nullptr;
+  return ctx->eng->bk.own_stream();
+}
 int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n) {
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
   ctx->eng->bk.use_stream(nullptr);

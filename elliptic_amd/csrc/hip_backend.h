@@ -98,6 +98,7 @@ struct HipBackend {
     note(hipStreamSynchronize(cur ? cur : own));
   }
   int device_index() const { return device; }
+  void* own_stream() const { return (void*)own; }
   void rt_upload(const RtField& f) { note((hipError_t)rt_upload_device(&f)); }
   void note(hipError_t e) {
     if (e != hipSuccess && !last) last = (int)e;

@@ -59,6 +59,8 @@ class Context:
         devices, one host thread each, results copied straight into the caller's arrays"""
         self._lib = _lib.load(lib_path) if not hasattr(lib_path, "ellgpu_version") else lib_path
         self._ctx = ctypes.c_void_p()
+        self._own = None
+        self._pending_default = None
         if devices is not None:
             devs = [int(d) for d in devices]
             arr = (ctypes.c_int * len(devs))(*devs)
@@ -70,6 +72,8 @@ class Context:
             raise _lib.EllgpuError(rc, self._lib.ellgpu_last_error().decode())
         self.device = device
         self.devices = list(devices) if devices is not None else [device]
+        self._own = None                  # torch view of the context's own stream (see _stream)
+        self._pending_default = None
 
     def group_size(self):
         return self._lib.ellgpu_group_size(self._ctx)
@@ -86,6 +90,9 @@ class Context:
             pass
 
     def _check(self, rc):
+        if self._pending_default is not None:              # see _stream()
+            cur, self._pending_default = self._pending_default, None
+            cur.wait_stream(self._own)
         if rc != 0:
             raise _lib.EllgpuError(rc, self._lib.ellgpu_last_error().decode())
 
@@ -512,7 +519,17 @@ class Context:
     def _stream(self):
         """the current torch stream OF THIS CONTEXT'S DEVICE (not of torch's current device)"""
         import torch
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream:
+            return ctypes.c_void_p(cur.cuda_stream)
+        # torch's default stream is the NULL handle, which the C ABI reads as "the context's own
+        # (non-blocking) stream": run there, ordered after the default stream's work so far, and
+        # let the default stream wait for the call's work afterwards (_check)
+        if self._own is None:
+            self._own = torch.cuda.ExternalStream(self._lib.ellgpu_ctx_stream(self._ctx), device=self.device)
+        self._own.wait_stream(cur)
+        self._pending_default = cur
+        return ctypes.c_void_p(self._own.cuda_stream)
 
     def mul_fixed_dev(self, curve, k, out_xy, out_inf):
         n = k.shape[0]

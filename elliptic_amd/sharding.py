@@ -59,11 +59,15 @@ class ShardedVerifier:
         world = self.dist.get_world_size() if self.dist is not None and self.dist.is_initialized() else 1
         lo, hi = shard_range(n, rank, world)
         if self.device is not None and self.device.type == "cuda":
-            sl = [torch.as_tensor(np.ascontiguousarray(x[lo:hi])).to(self.device) for x in (hashes, r, s, pub)]
+            # device-resident global arrays (torch CUDA tensors) are sliced in place; host arrays
+            # are copied once.  No host synchronisation: the kernels run on torch's current stream
+            # of this device, which the collective is ordered after.
+            sl = [x[lo:hi].contiguous() if torch.is_tensor(x) and x.is_cuda
+                  else torch.from_numpy(np.array(x[lo:hi], copy=True)).to(self.device, non_blocking=True)
+                  for x in (hashes, r, s, pub)]
             ok = torch.zeros(hi - lo, dtype=torch.uint8, device=self.device)
             if hi > lo:
                 self.ctx.ecdsa_verify_dev(self.curve, sl[0], sl[1], sl[2], sl[3], ok, msg_bits)
-            torch.cuda.synchronize()
         else:
             if hi > lo:
                 ok_np = self.ctx.ecdsa_verify(self.curve, hashes[lo:hi], r[lo:hi], s[lo:hi], pub[lo:hi], msg_bits)
@@ -95,16 +99,17 @@ class ShardedMul:
         world = self.dist.get_world_size() if on else 1
         lo, hi = shard_range(n, rank, world)
         if self.device is not None and self.device.type == "cuda":
-            k = torch.as_tensor(np.ascontiguousarray(scalars[lo:hi])).to(self.device)
+            def dev(x):
+                return (x[lo:hi].contiguous() if torch.is_tensor(x) and x.is_cuda
+                        else torch.from_numpy(np.array(x[lo:hi], copy=True)).to(self.device, non_blocking=True))
+            k = dev(scalars)
             xy = torch.zeros((hi - lo, 2 * B), dtype=torch.uint8, device=self.device)
             inf = torch.zeros(hi - lo, dtype=torch.uint8, device=self.device)
             if hi > lo:
                 if points is None:
                     self.ctx.mul_fixed_dev(self.curve, k, xy, inf)
                 else:
-                    p = torch.as_tensor(np.ascontiguousarray(points[lo:hi])).to(self.device)
-                    self.ctx.mul_var_dev(self.curve, k, p, xy, inf)
-            torch.cuda.synchronize()
+                    self.ctx.mul_var_dev(self.curve, k, dev(points), xy, inf)
         else:
             if hi > lo:
                 if points is None:

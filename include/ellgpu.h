@@ -45,7 +45,8 @@
  *     context are serialised by the caller (one process / thread per GPU, see
  *     DESIGN.md multi-GPU).  Host-buffer entry points are synchronous.
  *     The *_dev entry points take DEVICE pointers, enqueue on the given
- *     hipStream_t (passed as void*, NULL = the context's stream) and return
+ *     hipStream_t (passed as void*, NULL = the context's own non-blocking stream, which
+ *     ellgpu_ctx_stream returns so that a caller can order other streams against it) and return
  *     without synchronising; outputs are valid once that stream is.
  */
 #ifndef ELLGPU_H
@@ -100,6 +101,9 @@ int ellgpu_group_create(const int* devices, int ndev, ellgpu_ctx** out);
 int ellgpu_group_size(const ellgpu_ctx* ctx);          /* ndev of a group, 1 for a plain context */
 void ellgpu_ctx_destroy(ellgpu_ctx* ctx);
 int ellgpu_ctx_synchronize(ellgpu_ctx* ctx);
+/* the context's own stream (a hipStream_t; a group: its first member's): what a NULL `stream`
+ * argument of the *_dev entry points means */
+void* ellgpu_ctx_stream(ellgpu_ctx* ctx);
 
 /* User-defined short Weierstrass curve y^2 = x^3 + a x + b over an odd prime p < 2^256 -- the
  * reference's `new elliptic.curve.short({p, a, b, ...})` (lib/elliptic/curve/short.js:11-24) with

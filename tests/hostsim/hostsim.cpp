@@ -26,6 +26,7 @@ struct LoopBackend {
   void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
   int sync() { return 0; }
   int device_index() const { return 0; }
+  void* own_stream() const { return nullptr; }
   void rt_upload(const RtField& f) { rt_host_block() = f; }
   void sync_all() {}
   void end_call(bool) {}

@@ -423,3 +423,26 @@ def test_dev_calls_on_alternating_streams(ctx):
         for i in range(len(ks)):
             assert np.array_equal(outs[i][0].cpu().numpy(), want[i][0]) and np.array_equal(outs[i][1].cpu().numpy(), want[i][1]), (rep, i)
             outs[i][0].zero_()
+
+
+def test_sharded_helpers_on_device(ctx):
+    """elliptic_amd.sharding on a CUDA device (world size 1: the slicing, the stream-ordered
+    launch without host synchronisation, device-resident and host inputs)"""
+    import torch
+    from elliptic_amd.sharding import ShardedMul, ShardedVerifier
+    from golden_util import I, verify_cases
+    dev = torch.device("cuda", 0)
+    cs = [c for c in verify_cases("secp256k1") if len(c["z"]) == 64 and len(c["r"]) <= 64 and len(c["s"]) <= 64]
+    z = np.frombuffer(b"".join(bytes.fromhex(c["z"]) for c in cs), np.uint8).reshape(-1, 32)
+    r = ints_to_be([I(c["r"]) % (1 << 256) for c in cs], 32)
+    s = ints_to_be([I(c["s"]) % (1 << 256) for c in cs], 32)
+    q = np.concatenate([ints_to_be([I(c["qx"]) for c in cs], 32), ints_to_be([I(c["qy"]) for c in cs], 32)], axis=1)
+    want = np.array([1 if c["ok"] else 0 for c in cs], np.uint8)
+    sv = ShardedVerifier(ctx, "secp256k1", dist=None, device=dev)
+    assert np.array_equal(sv.verify(z, r, s, q).cpu().numpy(), want)
+    tz, tr, ts, tq = (torch.from_numpy(a).to(dev) for a in (z, r, s, q))
+    assert np.array_equal(sv.verify(tz, tr, ts, tq).cpu().numpy(), want)
+    k = ints_to_be([5, 7, 0, 11], 32)
+    xy, inf = ShardedMul(ctx, "secp256k1", dist=None, device=dev).mul(k)
+    wxy, winf = ctx.mul_fixed("secp256k1", k)
+    assert np.array_equal(xy.cpu().numpy(), wxy) and np.array_equal(inf.cpu().numpy(), winf)
