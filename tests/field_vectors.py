@@ -286,3 +286,35 @@ def solinas_vectors():
             out.append((field, 3, a, 0, a * a % p))
         assert n_c2 >= 5 and n_top >= 10, (field, n_c2, n_top)
     return out
+
+
+def solinas_addsub_vectors():
+    """(field, op, a, b, expected) for the rarely taken branches of FpSolinas::add / sub (p192, p224,
+    p384: the fields whose 2^(32L) mod p is shorter than the modulus): a folded carry that ripples
+    out of the low limbs, a carry-less sum in [p, 2^(32L)), a folded borrow that ripples"""
+    out = []
+    for field in (11, 12, 14):
+        p, L, fold = SOL_FIELDS[field]
+        top = fold[0][0] + 1
+        C = (1 << (32 * L)) - p
+        assert C == sum(sg << (32 * pos) for pos, sg in fold) and C < 1 << (32 * top)
+        BT = 1 << (32 * top)
+        pairs = [
+            (p - 1, C + BT),                 # a + b = 2^(32L) + B^TOP - 1: adding C carries out of limb TOP-1
+            (p - 1, C + BT - 1), (p - 2, C + BT + 5),
+            (p - 1, 1), (p - 1, C - 1), (p - 5, 7),              # carry-less sums in [p, 2^(32L))
+            (p - 1, p - 1), ((p + 1) // 2, (p + 1) // 2),
+        ]
+        for a, b in pairs:
+            assert 0 <= a < p and 0 <= b < p
+            out.append((field, 0, a, b, (a + b) % p))
+            out.append((field, 0, b, a, (a + b) % p))
+        subs = [
+            (0, p - BT + 1),                 # t = B^TOP + C - 1: subtracting C borrows out of limb TOP-1
+            (5, p - BT + 6), (0, p - BT), (0, p - 1), (0, 1), (1, 2), (C, C + 1),
+        ]
+        for a, b in subs:
+            assert 0 <= a < p and 0 <= b < p
+            out.append((field, 1, a, b, (a - b) % p))
+            out.append((field, 5, b, 0, (-b) % p))
+    return out

@@ -104,10 +104,12 @@ def test_rare_branches_gpu(ctx):
 
 def test_rare_branches_solinas_gpu(ctx):
     import field_vectors
-    vecs = field_vectors.solinas_vectors()
+    vecs = field_vectors.solinas_vectors() + field_vectors.solinas_addsub_vectors()
     for field, L in ((11, 6), (12, 7), (13, 8), (14, 12)):
-        for op in (2, 3):
+        for op in (0, 1, 2, 3, 5):
             sel = [v for v in vecs if v[0] == field and v[1] == op]
+            if not sel:
+                continue
             A, B = _pack([v[2] for v in sel], L), _pack([v[3] for v in sel], L)
             R = np.zeros((len(sel), L), np.uint32)
             assert ctx._lib.ellgpu_debug_field_op(ctx._ctx, field, op, len(sel), A.ctypes.data, B.ctypes.data,

@@ -123,7 +123,7 @@ def test_rare_branches_k256_25519(hs):
 def test_rare_branches_solinas(hs):
     """operands that drive the p256 / p384 lazy-accumulator fold into its rare branch"""
     import field_vectors
-    vecs = field_vectors.solinas_vectors()
+    vecs = field_vectors.solinas_vectors() + field_vectors.solinas_addsub_vectors()
     assert len(vecs) > 300
     for field, op, a, b, want in vecs:
         L = {11: 6, 12: 7, 13: 8, 14: 12}[field]
