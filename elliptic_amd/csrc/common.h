@@ -12,6 +12,14 @@
 //                    eight VGPRs held across the ladder
 //   ELL_SPILL_ZG     the table's common Z parked in a free table slot during the ladder
 //   ELL_LATE_LOADS   u1 / k1 and r loaded after the ladder, behind compiler barriers
+// FpSolinas::reduce_wide (experiment, off): product words join the signed 64-bit accumulators
+// through v_mad_u64_u32 (w * 1 + acc) and carries come from v_ashrrev_i64, instead of widening
+// every product word to a register pair first.  4.5 % fewer VALU instructions in the p384 ladder
+// kernel -- and 4-8 % SLOWER on all four NIST curves (profiles/r02_solinas_mad_fold_ab.txt): the
+// extra 2 000 multiplier-pipe instructions cost more than the 2 600 moves they replace.
+#ifndef ELL_SOLINAS_MAD_FOLD
+#define ELL_SOLINAS_MAD_FOLD 0
+#endif
 #ifndef ELL_BETA_REMAT
 #define ELL_BETA_REMAT 1
 #endif

@@ -1043,7 +1043,53 @@ struct FpSolinas {
   // folded the same way into the lowest max(pos)+1 words; a ripple beyond those and the final
   // range correction are rare (they need a word equal to 0 / 2^32-1) and share one branch.
   // Same value as the FIPS 186-4 D.2 word sums, ~45 % fewer carry-class instructions.
+  // acc + w for a 32-bit word w: ONE v_mad_u64_u32 (w * 1 + acc) instead of building the 64-bit
+  // pair (w, 0) with two moves and adding it -- the product words never become 64-bit values
+  ELL_HD static i64 add_word(i64 acc, u32 w) {
+#if defined(__HIP_DEVICE_COMPILE__) && ELL_SOLINAS_MAD_FOLD
+    u64 out, sd;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(out), "=s"(sd) : "v"(w), "v"((u64)acc));
+    (void)sd;
+    return (i64)out;
+#else
+    return acc + (i64)(u64)w;
+#endif
+  }
+  // x >> 32 (arithmetic) as one v_ashrrev_i64 instead of a 32-bit shift plus a move into a pair
+  ELL_HD static i64 sar32(i64 x) {
+#if defined(__HIP_DEVICE_COMPILE__) && ELL_SOLINAS_MAD_FOLD
+    i64 out;
+    asm("v_ashrrev_i64 %0, 32, %1" : "=v"(out) : "v"(x));
+    return out;
+#else
+    return x >> 32;
+#endif
+  }
   ELL_HD static El reduce_wide(const u32 (&t)[2 * L]) {
+#if ELL_SOLINAS_MAD_FOLD
+    // A[k] holds only what has been folded INTO position k; the product word t[k] itself joins
+    // through add_word where the position is consumed
+    i64 A[2 * L];
+    ELL_UNROLL
+    for (int k = 0; k < 2 * L; k++) A[k] = 0;
+    ELL_UNROLL
+    for (int k = 2 * L - 1; k >= L; k--) {
+      const i64 v = add_word(A[k], t[k]);
+      ELL_UNROLL
+      for (int f = 0; f < R::NFOLD; f++) {
+        if (R::fold_sign[f] > 0) A[k - L + R::fold_pos[f]] += v;
+        else A[k - L + R::fold_pos[f]] -= v;
+      }
+    }
+    u32 r[L];
+    i64 c = 0;
+    ELL_UNROLL
+    for (int k = 0; k < L; k++) {
+      i64 sum = add_word(A[k] + c, t[k]);
+      r[k] = (u32)sum;
+      c = sar32(sum);
+    }
+#else
     i64 A[2 * L];
     ELL_UNROLL
     for (int k = 0; k < 2 * L; k++) A[k] = (i64)(u64)t[k];
@@ -1062,6 +1108,7 @@ struct FpSolinas {
       r[k] = (u32)sum;
       c = sum >> 32;
     }
+#endif
     // c * B^L: the same fold on the low words
     constexpr int TOP = R::fold_pos[0] + 1;            // fold_pos is listed highest first
     i64 c2 = 0;
@@ -1073,14 +1120,14 @@ struct FpSolinas {
         if (R::fold_pos[f] == k) e += R::fold_sign[f] > 0 ? c : -c;
       i64 sum = (i64)(u64)r[k] + e + c2;
       r[k] = (u32)sum;
-      c2 = sum >> 32;
+      c2 = sar32(sum);
     }
     if (ELL_UNLIKELY(c2 != 0 || r[L - 1] == 0xFFFFFFFFu)) {
       ELL_UNROLL
       for (int k = TOP; k < L; k++) {
         i64 sum = (i64)(u64)r[k] + c2;
         r[k] = (u32)sum;
-        c2 = sum >> 32;
+        c2 = sar32(sum);
       }
       // value = c2 * B^L + r with |c2| <= 1: bring it into [0, p)
       u32 p[L]; get_p(p);
