@@ -318,3 +318,24 @@ def solinas_addsub_vectors():
             out.append((field, 1, a, b, (a - b) % p))
             out.append((field, 5, b, 0, (-b) % p))
     return out
+
+
+def p521_addsub_vectors():
+    """(15, op, a, b, expected) for the rare branches of FpP521::add / sub: the folded bit 521 that
+    carries out of limb 0, a sum equal to p, a repaid borrow that ripples"""
+    p = (1 << 521) - 1
+    out = []
+    adds = [(p - 1, (1 << 32) + 1), (p - 1, 1 << 32), (p - 1, 1), ((p + 1) // 2, (p - 1) // 2), (p - 1, p - 1),
+            (p - (1 << 32), 1 << 32), (p - 1, 2), ((1 << 521) - (1 << 480), (1 << 480) - 1),
+            ((1 << 520) + 0xFFFFFFFF, 1 << 520), ((1 << 520) + 0xFFFFFFFE, (1 << 520) + 1)]
+    for a, b in adds:
+        assert 0 <= a < p and 0 <= b < p
+        out.append((15, 0, a, b, (a + b) % p))
+        out.append((15, 0, b, a, (a + b) % p))
+    subs = [(0, 1), (0, 1 << 32), (0, (1 << 64)), (5, (1 << 32) + 5), (0, p - 1), (1, 2), ((1 << 96), (1 << 96) + (1 << 32)),
+            (0, (1 << 520)), ((1 << 300), (1 << 300) + (1 << 512))]
+    for a, b in subs:
+        assert 0 <= a < p and 0 <= b < p
+        out.append((15, 1, a, b, (a - b) % p))
+        out.append((15, 5, b, 0, (-b) % p))
+    return out

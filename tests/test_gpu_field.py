@@ -104,8 +104,8 @@ def test_rare_branches_gpu(ctx):
 
 def test_rare_branches_solinas_gpu(ctx):
     import field_vectors
-    vecs = field_vectors.solinas_vectors() + field_vectors.solinas_addsub_vectors()
-    for field, L in ((11, 6), (12, 7), (13, 8), (14, 12)):
+    vecs = field_vectors.solinas_vectors() + field_vectors.solinas_addsub_vectors() + field_vectors.p521_addsub_vectors()
+    for field, L in ((11, 6), (12, 7), (13, 8), (14, 12), (15, 17)):
         for op in (0, 1, 2, 3, 5):
             sel = [v for v in vecs if v[0] == field and v[1] == op]
             if not sel:

@@ -123,10 +123,10 @@ def test_rare_branches_k256_25519(hs):
 def test_rare_branches_solinas(hs):
     """operands that drive the p256 / p384 lazy-accumulator fold into its rare branch"""
     import field_vectors
-    vecs = field_vectors.solinas_vectors() + field_vectors.solinas_addsub_vectors()
+    vecs = field_vectors.solinas_vectors() + field_vectors.solinas_addsub_vectors() + field_vectors.p521_addsub_vectors()
     assert len(vecs) > 300
     for field, op, a, b, want in vecs:
-        L = {11: 6, 12: 7, 13: 8, 14: 12}[field]
+        L = {11: 6, 12: 7, 13: 8, 14: 12, 15: 17}[field]
         r = (ctypes.c_uint32 * L)()
         assert hs.hs_field_op(field, op, _limbs(a, L), _limbs(b, L), r) == 0
         assert _val(r) == want, (field, op, hex(a), hex(b))
