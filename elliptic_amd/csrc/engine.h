@@ -57,9 +57,12 @@
 #ifndef ELL_ECDSA_MIN_WAVES
 #define ELL_ECDSA_MIN_WAVES 3
 #endif
-// p384 (12 limbs): waves per SIMD the ladder kernels leave room for (2 = <= 256 registers)
+#ifndef ELL_P521_MIN_WAVES
+#define ELL_P521_MIN_WAVES 1        // (the p521 ladders take 232-234 VGPRs: two waves either way; 3 waves spill 560 B)
+#endif
+// p384 (12 limbs): waves per SIMD the ladder kernels leave room for
 #ifndef ELL_P384_MIN_WAVES
-#define ELL_P384_MIN_WAVES 2
+#define ELL_P384_MIN_WAVES 3        // 168 VGPRs: +2..3 % over 2 waves since the leaner add / sub (profiles/r02_p384_waves_ab.txt)
 #endif
 
 namespace ell {
@@ -72,7 +75,7 @@ struct FnMulVar {
   static constexpr const char* NAME = "mul_var";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
-  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? (CV::JTABLE ? ELL_CUSTOM_MIN_WAVES : ELL_MULVAR_MIN_WAVES) : (W::L == 12 ? ELL_P384_MIN_WAVES : 1));   // <= 128 VGPRs for 256-bit curves: +2..4 % despite ~50 B of spills
+  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? (CV::JTABLE ? ELL_CUSTOM_MIN_WAVES : ELL_MULVAR_MIN_WAVES) : (W::L == 12 ? ELL_P384_MIN_WAVES : ELL_P521_MIN_WAVES));   // <= 128 VGPRs for 256-bit curves: +2..4 % despite ~50 B of spills
   size_t n; const u8* k; const u8* xy; typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) W::mul_var(i, n, k, xy, tbl, ds, jac);
@@ -94,7 +97,7 @@ struct FnMulAddG {
   static constexpr const char* NAME = "mul_add_g";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
-  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? (CV::ENDO ? ELL_ENDO_MIN_WAVES : ELL_ECDSA_MIN_WAVES) : (W::L == 12 ? ELL_P384_MIN_WAVES : 1));      // p384: 2 waves/SIMD (<= 256 registers) beats a spill-free single wave
+  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? (CV::ENDO ? ELL_ENDO_MIN_WAVES : ELL_ECDSA_MIN_WAVES) : (W::L == 12 ? ELL_P384_MIN_WAVES : ELL_P521_MIN_WAVES));      // p384: 2 waves/SIMD (<= 256 registers) beats a spill-free single wave
   size_t n; const u8* k1; const u8* k2; const u8* xy2; const typename W::A* comb;
   typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
@@ -138,7 +141,7 @@ template <class CV, int MW = 0>
 struct FnEcdsaMain {
   static constexpr const char* NAME = "ecdsa_main";
   typedef Work<CV> W;
-  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? (CV::ENDO ? ELL_ENDO_MIN_WAVES : ELL_ECDSA_MIN_WAVES) : (W::L == 12 ? ELL_P384_MIN_WAVES : 1));   // 128 VGPRs for secp256k1, <= 168 for the other 256-bit curves, <= 256 for p384
+  static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? (CV::ENDO ? ELL_ENDO_MIN_WAVES : ELL_ECDSA_MIN_WAVES) : (W::L == 12 ? ELL_P384_MIN_WAVES : ELL_P521_MIN_WAVES));   // 128 VGPRs for secp256k1, <= 168 for the other 256-bit curves, <= 256 for p384
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
   size_t n; const u32* u12; const u8* valid; const u8* r; const u8* pub;
   const typename W::A* comb; typename W::VT* tbl; u8* ok;
