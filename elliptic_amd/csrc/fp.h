@@ -952,22 +952,22 @@ struct FpSolinas {
   ELL_HD static bool is_zero(const El& a) { return bn_is_zero<L>(a.v); }
   ELL_HD static bool eq(const El& a, const El& b) { return bn_eq<L>(a.v, b.v); }
   ELL_HD static bool is_odd(const El& a) { return a.v[0] & 1; }
-  // 2^(32L) mod p as TOPW little-endian words: the fold rule B^L == sum_f sign_f B^pos_f read as a
-  // number (p384: B^4 + B^3 - B + 1 = {1, 2^32-1, 2^32-1, 0, 1}).  When it is shorter than the
-  // modulus, a + b that carries out of 32L bits is reduced by adding these words to the low limbs
-  // (and a - b that borrows by subtracting them), as FpK256::add / sub do with 2^32 + 977: a
-  // carry out of limb TOPW-1 needs that limb at 2^32 - 1 (0 for a borrow), and a carry-less sum
-  // in [p, 2^(32L)) needs a top limb of 2^32 - 1, so the ripple through the upper limbs and the
-  // final subtraction share one rarely taken branch.  p192 12 instead of 18 instructions,
-  // p224 15 / 21, p384 22 / 36; p256's words span all eight limbs (generic form kept).
-  static constexpr int TOPW = R::fold_pos[0] + 1;
-  struct CWords { u32 w[TOPW]; };
+  // 2^(32L) mod p as L little-endian words: the fold rule B^L == sum_f sign_f B^pos_f read as a
+  // number (p384: B^4 + B^3 - B + 1 = {1, 2^32-1, 2^32-1, 0, 1, 0...}; p256: {1, 0, 0, 2^32-1,
+  // 2^32-1, 2^32-1, 2^32-2, 0}).  a + b that carries out of 32L bits is reduced by adding these
+  // words (a - b that borrows by subtracting them), as FpK256::add / sub do with 2^32 + 977 --
+  // and only where they are not zero: a carry that would have to travel through a limb whose
+  // word is zero after a SMALL word was added (or through a second zero limb in a row) needs
+  // that limb at 2^32 - 1 (0 for a borrow), and a carry-less sum in [p, 2^(32L)) needs a top
+  // limb of 2^32 - 1; those lanes take a rarely entered branch that redoes the operation the
+  // generic way.  p192 10 instead of 18 instructions, p224 14 / 21, p256 16 / 24, p384 20 / 36.
+  struct CWords { u32 w[L]; };
   static constexpr CWords cwords() {
-    long long acc[TOPW] = {};
+    long long acc[L] = {};
     for (int f = 0; f < R::NFOLD; f++) acc[R::fold_pos[f]] += R::fold_sign[f];
     CWords c{};
     long long carry = 0;
-    for (int k = 0; k < TOPW; k++) {
+    for (int k = 0; k < L; k++) {
       long long v = acc[k] + carry;
       long long q = v >= 0 ? v / 4294967296LL : -((-v + 4294967295LL) / 4294967296LL);
       c.w[k] = (u32)(v - q * 4294967296LL);
@@ -975,54 +975,54 @@ struct FpSolinas {
     }
     return c;
   }
+  // what limb k does in the masked add / sub of the words: 2 = the word itself joins the chain,
+  // 1 = zero word, but the limb below added a large word (its carry is common): chain continues,
+  // 0 = zero word and a carry into it is rare: the limb is copied, an arriving carry is flagged
+  static constexpr int limb_mode(int k) {
+    constexpr CWords C = cwords();
+    if (C.w[k] != 0) return 2;
+    if (k > 0 && C.w[k - 1] >= 0x10000u) return 1;
+    return 0;
+  }
   ELL_HD static El add(const El& a, const El& b) {
-    if constexpr (TOPW >= L) {
-      u32 p[L]; get_p(p);
-      El r; mod_add<L>(r.v, a.v, b.v, p); return r;
-    } else {
-      constexpr CWords C = cwords();
-      u32 t[L];
-      u32 c = bn_add<L>(t, a.v, b.v);
-      El r;
-      u32 cc = 0;
-      ELL_UNROLL
-      for (int k = 0; k < TOPW; k++) r.v[k] = addc32(t[k], c ? C.w[k] : 0u, cc, cc);
-      ELL_UNROLL
-      for (int k = TOPW; k < L; k++) r.v[k] = t[k];
-      if (ELL_UNLIKELY(cc != 0 || t[L - 1] == 0xFFFFFFFFu)) {
-        ELL_UNROLL
-        for (int k = TOPW; k < L; k++) r.v[k] = addc32(t[k], 0, cc, cc);
-        if (c == 0) {                     // no fold happened: the sum may lie in [p, 2^(32L))
-          u32 p[L]; get_p(p);
-          u32 s[L];
-          u32 br = bn_sub<L>(s, r.v, p);
-          ELL_UNROLL
-          for (int k = 0; k < L; k++) r.v[k] = br ? r.v[k] : s[k];
-        }
-      }
-      return r;
+    constexpr CWords C = cwords();
+    u32 t[L];
+    u32 c = bn_add<L>(t, a.v, b.v);
+    El r;
+    u32 cc = 0, rare = (t[L - 1] == 0xFFFFFFFFu) ? 1u : 0u;
+    ELL_UNROLL
+    for (int k = 0; k < L; k++) {
+      const int m = limb_mode(k);
+      if (m == 2) r.v[k] = addc32(t[k], c ? C.w[k] : 0u, cc, cc);
+      else if (m == 1) r.v[k] = addc32(t[k], 0u, cc, cc);
+      else { rare |= cc; cc = 0; r.v[k] = t[k]; }
     }
+    rare |= cc;                                   // (cannot happen for canonical inputs; harmless)
+    if (ELL_UNLIKELY(rare != 0)) {
+      u32 p[L]; get_p(p);
+      mod_add<L>(r.v, a.v, b.v, p);
+    }
+    return r;
   }
   ELL_HD static El sub(const El& a, const El& b) {
-    if constexpr (TOPW >= L) {
-      u32 p[L]; get_p(p);
-      El r; mod_sub<L>(r.v, a.v, b.v, p); return r;
-    } else {
-      constexpr CWords C = cwords();
-      u32 t[L];
-      u32 bw = bn_sub<L>(t, a.v, b.v);
-      El r;
-      u32 bb = 0;
-      ELL_UNROLL
-      for (int k = 0; k < TOPW; k++) r.v[k] = subb32(t[k], bw ? C.w[k] : 0u, bb, bb);
-      ELL_UNROLL
-      for (int k = TOPW; k < L; k++) r.v[k] = t[k];
-      if (ELL_UNLIKELY(bb != 0)) {
-        ELL_UNROLL
-        for (int k = TOPW; k < L; k++) r.v[k] = subb32(t[k], 0, bb, bb);
-      }
-      return r;
+    constexpr CWords C = cwords();
+    u32 t[L];
+    u32 bw = bn_sub<L>(t, a.v, b.v);
+    El r;
+    u32 bb = 0, rare = 0;
+    ELL_UNROLL
+    for (int k = 0; k < L; k++) {
+      const int m = limb_mode(k);
+      if (m == 2) r.v[k] = subb32(t[k], bw ? C.w[k] : 0u, bb, bb);
+      else if (m == 1) r.v[k] = subb32(t[k], 0u, bb, bb);
+      else { rare |= bb; bb = 0; r.v[k] = t[k]; }
     }
+    rare |= bb;
+    if (ELL_UNLIKELY(rare != 0)) {
+      u32 p[L]; get_p(p);
+      mod_sub<L>(r.v, a.v, b.v, p);
+    }
+    return r;
   }
   ELL_HD static El neg(const El& a) { return sub(zero(), a); }
   ELL_HD static El dbl(const El& a) { return add(a, a); }

@@ -289,35 +289,75 @@ def solinas_vectors():
 
 
 def solinas_addsub_vectors():
-    """(field, op, a, b, expected) for the rarely taken branches of FpSolinas::add / sub (p192, p224,
-    p384: the fields whose 2^(32L) mod p is shorter than the modulus): a folded carry that ripples
-    out of the low limbs, a carry-less sum in [p, 2^(32L)), a folded borrow that ripples"""
+    """(field, op, a, b, expected) for the rarely taken branch of FpSolinas::add / sub (p192, p224,
+    p256, p384): a folded carry / borrow arriving at a limb whose word of 2^(32L) mod p is zero, and
+    a carry-less sum in [p, 2^(32L))"""
     out = []
-    for field in (11, 12, 14):
+    for field in (11, 12, 13, 14):
         p, L, fold = SOL_FIELDS[field]
-        top = fold[0][0] + 1
         C = (1 << (32 * L)) - p
-        assert C == sum(sg << (32 * pos) for pos, sg in fold) and C < 1 << (32 * top)
-        BT = 1 << (32 * top)
-        pairs = [
-            (p - 1, C + BT),                 # a + b = 2^(32L) + B^TOP - 1: adding C carries out of limb TOP-1
-            (p - 1, C + BT - 1), (p - 2, C + BT + 5),
-            (p - 1, 1), (p - 1, C - 1), (p - 5, 7),              # carry-less sums in [p, 2^(32L))
-            (p - 1, p - 1), ((p + 1) // 2, (p + 1) // 2),
-        ]
+        assert C == sum(sg << (32 * pos) for pos, sg in fold)
+        w = [(C >> (32 * k)) & 0xFFFFFFFF for k in range(L)]
+        # limbs that are copied (mode 0 of FpSolinas::limb_mode): a carry arriving there is the rare case
+        mode0 = [k for k in range(L) if w[k] == 0 and not (k > 0 and w[k - 1] >= 0x10000)]
+        pairs = [(p - 1, 1), (p - 1, C - 1) if C > 1 else (p - 1, 2), (p - 5, 7), (p - 1, p - 1),
+                 ((p + 1) // 2, (p + 1) // 2)]
+        subs = [(0, p - 1), (0, 1), (1, 2), (C, C + 1)]
+        for k in mode0:
+            # a + b = 2^(32L) + (B^k - 1) + x: every limb below k is 2^32 - 1 after the chain reaches it
+            t = (1 << (32 * k)) - 1
+            b_ = (1 << (32 * L)) + t - (p - 1)
+            if 0 <= b_ < p:
+                pairs.append((p - 1, b_))
+            t2 = (1 << (32 * k)) - C if k and (1 << (32 * k)) > C else None
+            if t2 is not None:
+                b2 = (1 << (32 * L)) + t2 + (C - 1) - (p - 1)       # t + C ends in k limbs of ones + carry
+                if 0 <= b2 < p:
+                    pairs.append((p - 1, b2))
+            # a - b borrows and t's limbs below k are smaller than C's: the borrow reaches limb k
+            tt = (1 << (32 * k)) + C - 1 if k else None
+            if tt is not None:
+                bb = (1 << (32 * L)) - tt
+                if 0 < bb < p:
+                    subs.append((0, bb))
+                    subs.append((5, bb + 5) if bb + 5 < p else (0, bb))
+        n_rare_add = n_rare_sub = 0
         for a, b in pairs:
-            assert 0 <= a < p and 0 <= b < p
+            assert 0 <= a < p and 0 <= b < p, (field, hex(a), hex(b))
+            n_rare_add += solinas_addsub_rare(field, a, b, False)
             out.append((field, 0, a, b, (a + b) % p))
             out.append((field, 0, b, a, (a + b) % p))
-        subs = [
-            (0, p - BT + 1),                 # t = B^TOP + C - 1: subtracting C borrows out of limb TOP-1
-            (5, p - BT + 6), (0, p - BT), (0, p - 1), (0, 1), (1, 2), (C, C + 1),
-        ]
         for a, b in subs:
             assert 0 <= a < p and 0 <= b < p
+            n_rare_sub += solinas_addsub_rare(field, a, b, True)
             out.append((field, 1, a, b, (a - b) % p))
             out.append((field, 5, b, 0, (-b) % p))
+        assert n_rare_add >= 3 and n_rare_sub >= 1, (field, n_rare_add, n_rare_sub)
     return out
+
+
+def solinas_addsub_rare(field, a, b, sub):
+    """mirror of FpSolinas::add / sub: does (a, b) enter the rarely taken branch?"""
+    p, L, fold = SOL_FIELDS[field]
+    C = (1 << (32 * L)) - p
+    w = [(C >> (32 * k)) & 0xFFFFFFFF for k in range(L)]
+    full = (a - b) if sub else (a + b)
+    c = 1 if (full < 0 or full >> (32 * L)) else 0
+    t = full % (1 << (32 * L))
+    tl = [(t >> (32 * k)) & 0xFFFFFFFF for k in range(L)]
+    rare = (not sub) and tl[L - 1] == 0xFFFFFFFF
+    cc = 0
+    for k in range(L):
+        if w[k] != 0:
+            v = tl[k] - (w[k] if c else 0) - cc if sub else tl[k] + (w[k] if c else 0) + cc
+        elif k > 0 and w[k - 1] >= 0x10000:
+            v = tl[k] - cc if sub else tl[k] + cc
+        else:
+            rare = rare or cc != 0
+            cc = 0
+            continue
+        cc = 1 if (v < 0 or v >> 32) else 0
+    return bool(rare or cc)
 
 
 def p521_addsub_vectors():
