@@ -20,6 +20,9 @@
 #ifndef ELL_SOLINAS_MAD_FOLD
 #define ELL_SOLINAS_MAD_FOLD 0
 #endif
+#ifndef ELL_P224_TS_WINDOW
+#define ELL_P224_TS_WINDOW 1      // p224 square root: windowed Tonelli-Shanks (fp.h)
+#endif
 #ifndef ELL_BETA_REMAT
 #define ELL_BETA_REMAT 1
 #endif

@@ -1181,11 +1181,11 @@ struct FpSolinas {
   // loop (Red#sqrt, dist/elliptic.js:7259-7311).  Same algorithm with the data-dependent inner
   // search replaced by a fixed schedule, so that all lanes run the same instructions: with
   // q = 2^128 - 1, x = a^((q+1)/2), b = a^q and c = 11^q (11 = the least non-residue; c generates the
-  // 2^96 roots of unity), step k = 0..94 clears bit k of b's discrete logarithm:
-  //     if b^(2^(94-k)) != 1:  x *= c, b *= c^2;      c = c^2        (x^2 == a b throughout)
-  // 4.5 k squarings + 0.2 k multiplications.  For a non-residue the result is garbage and the
-  // caller's x^2 == a test fails (the reference: 'Assertion failed' out of the loop's
-  // assert(i < m)).  Any root will do: every caller fixes the parity afterwards.
+  // 2^96 roots of unity), the discrete logarithm of b is cleared from the bottom while x^2 == a b
+  // is kept: four bits per step from tables (default, below), or -- ELL_P224_TS_WINDOW = 0, the
+  // first version -- one bit per step with c squared along (4.5 k squarings).  For a non-residue
+  // the result is garbage and the caller's x^2 == a test fails (the reference: 'Assertion failed'
+  // out of the loop's assert(i < m)).  Any root will do: every caller fixes the parity afterwards.
   ELL_HD static El sqrt_ts224(const El& a) {
     static_assert(L == 7 || MP::P3MOD4, "Tonelli-Shanks constants are p224's");
     // a^(2^127 - 1): 126 S + 12 M over exponents 2^n - 1
@@ -1204,6 +1204,37 @@ struct FpSolinas {
     El t = mul(sqr(e126), e1);
     El x = mul(a, t);
     El b = mul(x, t);
+#if ELL_P224_TS_WINDOW
+    // Windowed form (round 2): with g = c^2 (order 2^95) the logarithm e of b to the base g is
+    // found four bits at a time from the bottom -- b_j^(2^(91-4j)) = H[e_j] for the sixteen
+    // powers H of g^(2^91) -- and digit j is removed by x *= CN[j][e_j] = c^(-16^j e_j),
+    // b *= CN[j][e_j]^2 (consts::P224_TS, tools/gen_consts.py).  1 081 squarings instead of 4 465;
+    // the table entry is picked per lane by compare-and-select, every lane runs the same code.
+    typedef consts::P224_TS TS;
+    ELL_NOUNROLL
+    for (int j = 0; j < TS::WINDOWS; j++) {
+      El w = b;
+      if (j < TS::WINDOWS - 1) w = sqr_n(b, 91 - 4 * j);
+      // last window: three bits left, b itself = H[2 e_j]
+      const int step = (j < TS::WINDOWS - 1) ? 1 : 2;
+      u32 idx = 0;
+      ELL_NOUNROLL
+      for (int i = 1; i * step < 16; i++) {
+        u32 d = 0;
+        ELL_UNROLL
+        for (int l = 0; l < 7 && l < L; l++) d |= w.v[l] ^ TS::H[(i * step) * 7 + l];
+        idx = d == 0 ? (u32)i : idx;
+      }
+      El f = zero();
+      ELL_NOUNROLL
+      for (int i = 0; i < 16; i++) {
+        ELL_UNROLL
+        for (int l = 0; l < 7 && l < L; l++) f.v[l] = idx == (u32)i ? TS::CN[(j * 16 + i) * 7 + l] : f.v[l];
+      }
+      x = mul(x, f);
+      b = mul(b, sqr(f));
+    }
+#else
     El c = zero();
     constexpr u32 C0[7] = {0xDC691B74u, 0xF3FB3632u, 0xBEA3D8CEu, 0x0B2D6FFBu, 0x0C55B2D4u, 0x8598A792u, 0x6A0FEC67u};
     ELL_UNROLL
@@ -1223,6 +1254,7 @@ struct FpSolinas {
       }
       c = c2;
     }
+#endif
     return x;
   }
   static ELL_HD_NOINLINE El sqrt(const El& a) {
