@@ -236,9 +236,11 @@ def kernel_counters():
 
 
 def lib_digest():
+    """the source digest compiled into the libellgpu.so this process loaded (ellgpu_source_digest)"""
+    from elliptic_amd import _lib
     try:
-        return open(os.path.join(ROOT, "elliptic_amd", "lib", "libellgpu.stamp")).read().strip()
-    except OSError:
+        return _lib.load().ellgpu_source_digest().decode()
+    except (ImportError, AttributeError, OSError):
         return None
 
 

@@ -15,6 +15,7 @@ c_u8p = ctypes.c_void_p      # raw addresses (numpy .ctypes.data / torch .data_p
 
 _SIGS = {
     "ellgpu_version": (ctypes.c_int, []),
+    "ellgpu_source_digest": (ctypes.c_char_p, []),
     "ellgpu_last_error": (ctypes.c_char_p, []),
     "ellgpu_curve_id": (ctypes.c_int, [ctypes.c_char_p]),
     "ellgpu_curve_field_bytes": (ctypes.c_int, [ctypes.c_int]),

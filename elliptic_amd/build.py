@@ -42,15 +42,47 @@ def units():
     return u
 
 
+def digest_define(name, digest):
+    """capi.hip carries the source digest into the binary."""
+    return ['-DELLGPU_SOURCE_DIGEST="%s"' % digest] if name.startswith("capi") else []
+
+
+def source_files():
+    """The explicit list of files the library is built from, as paths RELATIVE to the repo root
+    (the digest must not depend on where the tree is checked out)."""
+    root = os.path.normpath(os.path.join(HERE, ".."))
+    files = sorted(os.path.join("elliptic_amd", "csrc", f) for f in os.listdir(CSRC)
+                   if f.endswith((".h", ".hip")) and os.path.isfile(os.path.join(CSRC, f)))
+    files.append(os.path.join("include", "ellgpu.h"))
+    return root, files
+
+
 def source_digest():
+    """sha256 over (relative name, bytes) of every source file + the compiler flags.  The same
+    string is compiled into the library (-DELLGPU_SOURCE_DIGEST on capi.hip) and exported as
+    ellgpu_source_digest(): provenance is read from the loaded binary, not from a sidecar file."""
     h = hashlib.sha256()
-    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))
-    files = [os.path.join(CSRC, f) for f in files] + [os.path.join(HERE, "..", "include", "ellgpu.h")]
+    root, files = source_files()
     for f in files:
-        with open(f, "rb") as fh:
-            h.update(f.encode() + b"\0" + fh.read())
+        with open(os.path.join(root, f), "rb") as fh:
+            h.update(f.replace(os.sep, "/").encode() + b"\0" + fh.read() + b"\0")
     h.update((" ".join(FLAGS) + repr(sorted(GROUP_FLAGS.items()))).encode())
     return h.hexdigest()[:16]
+
+
+def library_digest(path=None):
+    """The digest embedded in a built libellgpu.so (None if the file is missing or predates
+    ellgpu_source_digest)."""
+    import ctypes
+    path = path or LIB
+    if not os.path.exists(path):
+        return None
+    try:
+        fn = ctypes.CDLL(path).ellgpu_source_digest
+    except (OSError, AttributeError):
+        return None
+    fn.restype = ctypes.c_char_p
+    return fn().decode()
 
 
 def compile_one(args):
@@ -59,7 +91,7 @@ def compile_one(args):
     if os.path.exists(obj):
         return name, obj, 0.0, ""
     t0 = time.time()
-    cmd = [HIPCC] + FLAGS + extra + defs + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp"]
+    cmd = [HIPCC] + FLAGS + extra + defs + digest_define(name, digest) + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp"]
     p = subprocess.run(cmd, capture_output=True, text=True)
     if p.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (name, " ".join(cmd), p.stderr[-4000:]))
@@ -105,8 +137,7 @@ def build(jobs=None, force=False, verbose=True, remarks=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     digest = source_digest()
-    stamp = os.path.join(LIBDIR, "libellgpu.stamp")
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
+    if not force and library_digest(LIB) == digest:
         if verbose:
             print("libellgpu.so up to date (%s)" % digest)
         return LIB
@@ -131,8 +162,6 @@ def build(jobs=None, force=False, verbose=True, remarks=False):
     if p.returncode != 0:
         raise RuntimeError("link failed:\n" + p.stderr[-4000:])
     os.replace(LIB + ".tmp", LIB)
-    with open(stamp, "w") as f:
-        f.write(digest)
     if remarks:
         with open(os.path.join(OBJ, "resource_usage.log"), "w") as f:
             f.write("\n".join(log))

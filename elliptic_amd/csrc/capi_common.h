@@ -44,6 +44,10 @@ static int finish(ellgpu_ctx* ctx, int rc, bool stream_call = false) {
 extern "C" {
 
 int ellgpu_version(void) { return ELLGPU_VERSION; }
+#ifndef ELLGPU_SOURCE_DIGEST
+#define ELLGPU_SOURCE_DIGEST "unstamped"
+#endif
+const char* ellgpu_source_digest(void) { return ELLGPU_SOURCE_DIGEST; }
 const char* ellgpu_last_error(void) { return g_last_error.c_str(); }
 
 int ellgpu_curve_id(const char* name) {

@@ -81,6 +81,12 @@ extern "C" {
 typedef struct ellgpu_ctx ellgpu_ctx;
 
 int ellgpu_version(void);
+/* 16 hex digits: sha256 over the (repo-relative name, bytes) of every source file this library
+ * was compiled from + the compiler flags (elliptic_amd/build.py::source_digest, passed to the
+ * compiler as -DELLGPU_SOURCE_DIGEST).  Provenance of measurements and of the smoke gate is read
+ * from the loaded binary through this call, never from a sidecar file.  No reference
+ * counterpart (package.json "version" is the nearest thing). */
+const char* ellgpu_source_digest(void);
 const char* ellgpu_last_error(void);
 
 int ellgpu_curve_id(const char* name);       /* "secp256k1", "p192", ... ; -1 if unknown */

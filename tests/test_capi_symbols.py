@@ -50,6 +50,33 @@ def test_metadata_calls_work_without_gpu(lib_path):
     assert lib.ellgpu_curve_id(b"brainpool") == -1
 
 
+def test_source_digest_is_embedded_and_path_independent(lib_path, tmp_path):
+    """the library carries the digest of the sources it was built from (ellgpu_source_digest),
+    and that digest does not depend on where the tree lives: a copy of the sources elsewhere
+    hashes to the same value (round 2's smoke gate failed on exactly this)"""
+    import subprocess
+    import sys
+    from elliptic_amd import build as b, _lib
+    lib = _lib.load(lib_path)
+    emb = lib.ellgpu_source_digest().decode()
+    assert re.fullmatch(r"[0-9a-f]{16}", emb), emb
+    assert emb == b.source_digest() == b.library_digest(lib_path)
+    root, files = b.source_files()
+    assert all(not os.path.isabs(f) for f in files) and files == sorted(files[:-1]) + [files[-1]]
+    # same sources at another path (and reached through a symlink) -> same digest
+    dst = tmp_path / "elsewhere" / "copy"
+    for f in files + [os.path.join("elliptic_amd", "build.py"), os.path.join("elliptic_amd", "__init__.py")]:
+        os.makedirs(os.path.dirname(dst / f), exist_ok=True)
+        shutil.copyfile(os.path.join(root, f), dst / f)
+    open(dst / "elliptic_amd" / "__init__.py", "w").close()
+    os.symlink(dst, tmp_path / "link")
+    for where in (dst, tmp_path / "link"):
+        out = subprocess.run([sys.executable, "-c", "from elliptic_amd import build as b; print(b.source_digest())"],
+                             cwd=str(where), capture_output=True, text=True, check=True,
+                             env={**os.environ, "PYTHONPATH": str(where)})
+        assert out.stdout.strip() == emb
+
+
 def test_no_cpu_fallback(lib_path):
     """on a box without an MI355X the product must refuse to run"""
     import torch

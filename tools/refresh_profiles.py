@@ -145,10 +145,9 @@ def main():
             continue
         shutil.copyfile(p, os.path.join(dst, "%s_%s" % (a.round, d)))
         print("profiles/%s_%s" % (a.round, d))
-    try:
-        digest = open(os.path.join(ROOT, "elliptic_amd", "lib", "libellgpu.stamp")).read().strip()
-    except OSError:
-        digest = None
+    sys.path.insert(0, ROOT)
+    from elliptic_amd import build as _b
+    digest = _b.library_digest()          # read from the built binary itself
     kc = distil(a.src, digest)
     if kc["kernels"]:
         with open(os.path.join(dst, "%s_kernel_counters.json" % a.round), "w") as f:
