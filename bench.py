@@ -6,11 +6,19 @@ scalar-mults/sec (secp256k1 verify batch)" is quoted on): a batch of 2^20
 synthetic (hash, r, s, pubkey) tuples per GPU, 1 % of them corrupted, already
 resident in HBM; one "step" = one pass of the hot path (ellgpu_ecdsa_verify_dev:
 range checks, batched s^-1 mod n, u1*G + u2*Q with GLV, projective x-compare)
-over the whole batch.  Weak scaling: every rank owns its own 2^20 tuples, the
-only collective is the final gather of the ok-masks (RCCL all_gather).
+over the whole batch.  Weak scaling (default): every rank owns its own 2^20 tuples, the
+only collective is the final gather of the ok-masks (RCCL all_gather).  `--scaling strong`
+= BASELINE configs[2] as written: ONE global batch of 2^20 tuples cut into contiguous shards
+(elliptic_amd.sharding.shard_range), every rank verifies its shard, the masks are gathered.
 
     python bench.py --gpus 1 --steps 120 --warmup 10
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... [--scaling strong]
+
+At N = 1 the roofline's instruction counts and HBM bytes come from rocprofv3 PMC passes made
+by this very run on this very box (`live_counters`; a 2-step child of this script under
+`rocprofv3 --kernel-trace --pmc ...`, separate passes); if rocprofv3 is unavailable the
+committed profiles/*kernel_counters.json is used, and only if its source digest equals the
+digest compiled into the loaded library -- otherwise `frac` is null and says why.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 At N = 1 the same line also carries `configs` (BASELINE configs #2, #4, #5 and
@@ -235,6 +243,86 @@ def kernel_counters():
         return None, None
 
 
+def _tool(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ellgpu_tool_" + name, os.path.join(ROOT, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+LIVE_PASSES = (
+    ("sqa", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES",
+             "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"]),
+    ("sqb", ["SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD",
+             "SQ_INSTS_VMEM_WR", "SQ_WAVES", "SQ_ACTIVE_INST_ANY"]),
+    ("fwa", ["FETCH_SIZE"]),
+    ("fwb", ["WRITE_SIZE"]),
+)
+
+
+def live_counters(batch, per_pass_timeout=200, keep=None):
+    """The roofline's instruction counts and HBM bytes, measured by THIS run: one rocprofv3 PMC
+    pass per counter group (--kernel-trace + --pmc only, MI355X_MICROARCH.md's recipe) over a
+    2-step child of this script -- the same binaries, box and inputs as the timed region --
+    distilled by tools/refresh_profiles.distil into the structure of profiles/*kernel_counters.json.
+    -> (counters | None, source string, note)"""
+    import glob
+    import io
+    import contextlib
+    import shutil
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None, None, "rocprofv3 not found"
+    tmp = os.path.abspath(keep) if keep else tempfile.mkdtemp(prefix="ellgpu_pmc_")
+    os.makedirs(tmp, exist_ok=True)
+    summ = _tool("rocprof_summary")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu",
+             "--no-live-counters", "--batch", str(batch)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    notes = []
+    for tag, ctrs in LIVE_PASSES:
+        d = os.path.join(tmp, "prof_" + tag)
+        cmd = [rp, "--kernel-trace", "--pmc"] + ctrs + ["-d", d, "-o", tag, "--"] + child
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=per_pass_timeout)
+        except subprocess.TimeoutExpired:
+            notes.append("%s: timeout" % tag)
+            continue
+        dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+        if p.returncode != 0 or not dbs:
+            notes.append("%s: rc=%d %s" % (tag, p.returncode, (p.stderr or "")[-160:].replace("\n", " ")))
+            continue
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            summ.main(dbs[0])
+        with open(os.path.join(tmp, "rocprof_%s.txt" % tag), "w") as f:
+            f.write(buf.getvalue())
+        shutil.rmtree(d, ignore_errors=True)
+    with open(os.path.join(tmp, "rocprof_fw.txt"), "w") as f:
+        for t in ("fwa", "fwb"):
+            q = os.path.join(tmp, "rocprof_%s.txt" % t)
+            if os.path.exists(q):
+                f.write(open(q).read())
+    kc = _tool("refresh_profiles").distil(tmp, lib_digest())
+    kc["how"] = ("LIVE: rocprofv3 --kernel-trace --pmc, one pass per counter group, over `bench.py --steps 2 "
+                 "--warmup 1 --no-cpu` run as a child of this bench.py on this box (%.0f s)" % (time.perf_counter() - t0))
+    if kc.get("fetch_calibration") is None:
+        # the gather calibration (tools/microbench/gather_calib.hip) is not re-run here; the
+        # committed one reads 0.9994 true bytes per counted byte for this access pattern
+        old, _ = kernel_counters()
+        kc["fetch_calibration"] = (old or {}).get("fetch_calibration")
+        kc["fetch_calibration_source"] = "committed profiles/*kernel_counters.json (not re-measured in this run)"
+    if keep is None:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if not kc["kernels"]:
+        return None, None, "live PMC passes produced no counters (%s)" % "; ".join(notes)
+    return kc, "live rocprofv3 --pmc passes of this run", "; ".join(notes) or None
+
+
 def lib_digest():
     """the source digest compiled into the libellgpu.so this process loaded (ellgpu_source_digest)"""
     from elliptic_amd import _lib
@@ -255,7 +343,16 @@ def roofline_block(kernel_key, unit_key, n, kernel_ms, peak_gmads, clock_ghz, co
     out["frac_reference_alg"] = ach_alg / peak_gmads if peak_gmads else None
     out["achieved_reference_alg"] = ach_alg
     k = (counters or {}).get("kernels", {}).get(kernel_key)
-    if k and k.get("mad_u64_per_unit"):
+    stale = bool(counters) and counters.get("source_digest") != lib_digest()
+    if k and stale:
+        # instruction counts of OTHER binaries do not price this run: no fraction at all
+        out.update({"achieved": None, "frac": None, "counters_stale": True, "counters_source": csrc,
+                    "note": "PMC instruction counts in %s were taken from library digest %s, the loaded "
+                            "library is %s: refusing to compute a fraction from them (re-run "
+                            "tools/refresh_profiles.sh or let bench.py make its live PMC passes)"
+                            % (csrc, counters.get("source_digest"), lib_digest())})
+        k = None
+    elif k and k.get("mad_u64_per_unit"):
         mads = k["mad_u64_per_unit"]
         ach = n * mads / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
         out.update({"achieved": ach, "frac": ach / peak_gmads if peak_gmads else None,
@@ -264,7 +361,7 @@ def roofline_block(kernel_key, unit_key, n, kernel_ms, peak_gmads, clock_ghz, co
                     "carry_int32_per_unit": k.get("int32_per_unit"),
                     "multiply_share_of_valu_insts": mads / k["valu_per_unit"] if k.get("valu_per_unit") else None,
                     "valu_busy_pmc": k.get("valu_busy"), "counters_source": csrc,
-                    "counters_stale": (counters.get("source_digest") != lib_digest())})
+                    "counters_stale": False, "counters_digest": counters.get("source_digest")})
         # issue accounting: a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles; the
         # per-unit counts are per lane, i.e. per wavefront-instruction stream
         if k.get("valu_per_unit"):
@@ -278,9 +375,9 @@ def roofline_block(kernel_key, unit_key, n, kernel_ms, peak_gmads, clock_ghz, co
                             "note": "SIMD cycles per VALU wave-instruction at the nominal clock; 4 is the wave64 issue "
                                     "floor of mixed code (runs of plain VOP1/VOP2 issue faster, "
                                     "profiles/*valu_patterns.log): at or below it the VALU pipe never idles"}
-    else:
+    elif not stale:
         out.update({"achieved": None, "frac": None,
-                    "note": "no committed PMC instruction counts for this kernel (profiles/*kernel_counters.json)"})
+                    "note": "no PMC instruction counts for this kernel (neither live nor profiles/*kernel_counters.json)"})
     ach_gbs = n * alg["bytes"] / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
     out["hbm"] = {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                   "alg_bytes_per_unit": alg["bytes"]}
@@ -389,6 +486,12 @@ def main():
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1 << 20, help="tuples per GPU")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): --batch tuples on EVERY GPU; strong: ONE global batch of --batch tuples "
+                         "cut into contiguous shards, one per GPU (BASELINE configs[2] as written)")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="do not make the rocprofv3 PMC passes; price the roofline with the committed counters")
+    ap.add_argument("--keep-counters", default=None, help="directory to keep the live PMC summaries in")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (self-test of the N>1 flow)")
@@ -424,20 +527,35 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     import elliptic_amd
+    from elliptic_amd.sharding import shard_range, gather_results
     ctx = elliptic_amd.Context(local_rank)
-    n = args.batch
-    h, r, s, pub, expect = cached_signatures(ctx, n, "ellgpu-bench-v1:3:rank%d" % rank)
-    checked = oracle_check(h, r, s, pub, expect)
+    strong = args.scaling == "strong"
+    n_global = args.batch if strong else args.batch * world
+    if strong:
+        # one global batch (every rank derives the same tuples), rank r owns [lo, hi)
+        h, r, s, pub, expect = cached_signatures(ctx, args.batch, "ellgpu-bench-v1:3:rank0")
+        checked = oracle_check(h, r, s, pub, expect) if rank == 0 else {"tuples": 0, "by": "rank 0"}
+        lo, hi = shard_range(args.batch, rank, world)
+        h, r, s, pub, expect = (x[lo:hi] for x in (h, r, s, pub, expect))
+    else:
+        h, r, s, pub, expect = cached_signatures(ctx, args.batch, "ellgpu-bench-v1:3:rank%d" % rank)
+        checked = oracle_check(h, r, s, pub, expect)
+    n = len(expect)
     dev = torch.device("cuda", local_rank)
-    dh, dr, dsg, dq = (torch.from_numpy(x).to(dev) for x in (h, r, s, pub))
+    dh, dr, dsg, dq = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (h, r, s, pub))
     dok = torch.zeros(n, dtype=torch.uint8, device=dev)
-    gathered = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(world)] if dist is not None else None
+    gathered = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(world)] if dist is not None and not strong else None
     ctx.reserve("secp256k1", n)
+    full_mask = None
 
     def step():
+        nonlocal full_mask
         ctx.ecdsa_verify_dev("secp256k1", dh, dr, dsg, dq, dok)
         if world > 1:
-            if args.dist_backend == "nccl":
+            if strong:                              # uneven shards: padded all_gather, trimmed
+                src = dok if args.dist_backend == "nccl" else dok.cpu()
+                full_mask = gather_results(src, args.batch, dist)
+            elif args.dist_backend == "nccl":
                 dist.all_gather(gathered, dok)      # the final gather, RCCL over xGMI
             else:                                   # gloo self-test: host tensors
                 hg = [torch.zeros(n, dtype=torch.uint8) for _ in range(world)]
@@ -451,9 +569,15 @@ def main():
     if not np.array_equal(got, expect):
         bad = int((got != expect).sum())
         raise SystemExit("PARITY FAILURE: %d of %d verify results differ from the expected mask" % (bad, n))
+    if strong and world > 1:
+        # the gathered mask is the global batch's expected mask on every rank
+        _, _, _, _, expect_all = cached_signatures(ctx, args.batch, "ellgpu-bench-v1:3:rank0")
+        if not np.array_equal(full_mask.cpu().numpy(), expect_all):
+            raise SystemExit("PARITY FAILURE: gathered mask differs from the expected mask of the global batch")
     if world == 1 and dist is not None:
         # the RCCL branch of the N > 1 flow, executed once on a 1-rank group
         t0 = time.perf_counter()
+        gathered = gathered or [torch.zeros_like(dok)]
         dist.all_gather(gathered, dok)
         torch.cuda.synchronize()
         rccl_selftest = {"backend": args.dist_backend, "world": 1, "all_gather_ok": bool(torch.equal(gathered[0], dok)),
@@ -478,7 +602,7 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        total = n * world * args.steps
+        total = n_global * args.steps
         value = total / dt
         cnt, main_ms = timing.get("ecdsa_main", (0, 0.0))
         pcnt, prep_ms = timing.get("ecdsa_prep", (0, 0.0))
@@ -491,10 +615,19 @@ def main():
             peak_gmads = max(peak_gmads, ops / (ms * 1e-3) / 1e9)
         clock_ghz = torch.cuda.get_device_properties(local_rank).clock_rate / 1e6 if hasattr(
             torch.cuda.get_device_properties(local_rank), "clock_rate") else 2.4
-        counters, csrc = kernel_counters()
+        counters, csrc, counters_note = None, None, None
+        if world == 1 and not args.no_live_counters:
+            try:
+                counters, csrc, counters_note = live_counters(args.batch, keep=args.keep_counters)
+            except Exception as e:          # never lose the bench line to the profiler
+                counters_note = "live PMC passes failed: %s" % str(e)[-200:]
+        if counters is None:
+            counters, csrc = kernel_counters()
         roof = roofline_block("ecdsa_main<secp256k1>", "verify", n, k_ms, peak_gmads, clock_ghz, counters, csrc)
         roof["prep_kernel_ms"] = prep_ms / max(pcnt, 1)
         roof["clock_ghz"] = clock_ghz
+        if counters_note:
+            roof["counters_note"] = counters_note
         out = {
             "metric": "secp256k1 ECDSA verify batch throughput (1 verify = 1 double-scalar mult u1*G+u2*Q)",
             "value": value,
@@ -506,14 +639,17 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "timed_region_s": dt,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "secp256k1 ECDSA verify (GLV variable-base + fixed-base comb), "
-                                   "batch=2^20 tuples per GPU resident in HBM, 1% corrupted"
-                                   if n == 1 << 20 else "secp256k1 ECDSA verify, batch=%d per GPU" % n,
-                       "batch_per_gpu": n, "parallelism": "shard%d" % world,
+            "config": {"workload": ("secp256k1 ECDSA verify (GLV variable-base + fixed-base comb), "
+                                    "batch=2^20 tuples per GPU resident in HBM, 1% corrupted"
+                                    if args.batch == 1 << 20 and not strong else
+                                    "secp256k1 ECDSA verify, ONE global batch of %d tuples sharded over %d GPU(s) "
+                                    "(BASELINE configs[2]), resident in HBM, 1%% corrupted" % (args.batch, world)
+                                    if strong else "secp256k1 ECDSA verify, batch=%d per GPU" % n),
+                       "batch_per_gpu": n, "global_batch": n_global, "parallelism": "shard%d" % world,
                        "parity": "ok-mask == expected mask on all %d tuples; expected mask == oracle on the "
                                  "first %d (%s)" % (n, checked["tuples"], checked["by"]),
                        "library_digest": lib_digest()},

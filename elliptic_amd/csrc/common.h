@@ -32,6 +32,11 @@
 #ifndef ELL_LATE_LOADS
 #define ELL_LATE_LOADS 1
 #endif
+//   ELL_PREFETCH     (the opposite trade, for the two-waves-per-SIMD build) table entries are
+//                    requested one step ahead of their use, Ladder::run_odd_w4
+#ifndef ELL_PREFETCH
+#define ELL_PREFETCH 0
+#endif
 
 #include <stdint.h>
 #include <stddef.h>

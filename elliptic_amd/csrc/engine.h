@@ -11,6 +11,7 @@
 // runs once per thread id with a DigitStore of Fn::DS_PER_LANE bytes per lane.
 #pragma once
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -56,6 +57,10 @@
 #endif
 #ifndef ELL_ECDSA_MIN_WAVES
 #define ELL_ECDSA_MIN_WAVES 3
+#endif
+// batches of at most this many verifies (three waves on every SIMD) take the WIDE ecdsa_main
+#ifndef ELL_SMALL_GRID
+#define ELL_SMALL_GRID ((size_t)256 * 4 * 64 * 3)
 #endif
 #ifndef ELL_P521_MIN_WAVES
 #define ELL_P521_MIN_WAVES 1        // (the p521 ladders take 232-234 VGPRs: two waves either way; 3 waves spill 560 B)
@@ -137,7 +142,11 @@ struct FnEcdsaPrep {
     if (t < T) W::ecdsa_prep(t, T, n, K, hash, hash_len, shift, r, s, pre, u12, valid);
   }
 };
-template <class CV, int MW = 0>
+// WIDE: the small-grid tuning (secp256k1 only; Engine::ecdsa_chunk picks it for batches of at most
+// ELL_SMALL_GRID items): 3 waves/SIMD worth of registers, beta / zg / u1 resident, table and comb
+// entries requested one step ahead.  Same results; 3 % faster where only two waves per SIMD are
+// resident and gather latency is exposed, 0.6 % slower on a full grid (profiles/r03_small_grid_ab.jsonl).
+template <class CV, int MW = 0, bool WIDE = false>
 struct FnEcdsaMain {
   static constexpr const char* NAME = "ecdsa_main";
   typedef Work<CV> W;
@@ -146,7 +155,7 @@ struct FnEcdsaMain {
   size_t n; const u32* u12; const u8* valid; const u8* r; const u8* pub;
   const typename W::A* comb; typename W::VT* tbl; u8* ok;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
-    if (i < n) W::ecdsa_main(i, n, u12, valid, r, pub, comb, tbl, ds, ok);
+    if (i < n) W::template ecdsa_main<WIDE>(i, n, u12, valid, r, pub, comb, tbl, ds, ok);
   }
 };
 
@@ -515,6 +524,25 @@ class Engine {
   // (ecdsa_prep 0.41 -> 0.34 ms, sign_finish 0.45 -> 0.30 ms per 2^20); normalize is best at 16.
   static constexpr int INV_BATCH = ELL_INV_BATCH;
   static constexpr int INV_BATCH_N = ELL_INV_BATCH / 2;
+  // Items per inversion in the scalar-field kernels (ecdsa_prep ...): kmax for batches that fill
+  // the device anyway; for smaller ones fewer items per thread, so that the n / K threads still
+  // give every SIMD a wave (one inversion costs about what two items' other work does; a batch
+  // of 131 072 verifies -- one GPU's share of 2^20 over eight -- ran its prep on 256 waves, one
+  // per CU, at the lone-wave issue rate: 0.137 ms of a 1.52 ms pass).  ELLGPU_PREP_K overrides.
+  // largest batch that takes the small-grid (WIDE) kernels; ELLGPU_SMALL_GRID overrides (tests run
+  // both tunings of a kernel on the same inputs with it; 0 = never)
+  static size_t small_grid() {
+    const char* e = getenv("ELLGPU_SMALL_GRID");
+    return e ? (size_t)strtoull(e, nullptr, 10) : ELL_SMALL_GRID;
+  }
+  static int inv_batch_for(size_t n, int kmax) {
+    static const int forced = []() { const char* e = getenv("ELLGPU_PREP_K"); return e ? atoi(e) : 0; }();
+    if (forced >= 1 && forced <= 64) return forced;
+    const size_t lanes = (size_t)256 * 4 * 64;             // one wave on every SIMD
+    int k = kmax;
+    while (k > 1 && n / (size_t)k < 2 * lanes) k >>= 1;
+    return k;
+  }
   static constexpr size_t CHUNK = 1u << 21;   // max items per launch (bounds the scratch arena)
 
   explicit Engine(const BK& b) : bk(b) {
@@ -1800,16 +1828,23 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
   u32* u12 = (u32*)scratch(S_U12, n * 2 * W::LN * 4);
   u8* valid = (u8*)scratch(S_VALID, n);
   if (!tbl || !pre || !u12 || !valid) return fail(E_NOMEM, "scratch allocation failed");
-  size_t T = (n + INV_BATCH_N - 1) / INV_BATCH_N;
-  FnEcdsaPrep<CV> f1{T, n, INV_BATCH_N, hash, hash_len, shift, r, s, pre, u12, valid};
+  const int K = inv_batch_for(n, INV_BATCH_N);
+  size_t T = (n + K - 1) / K;
+  FnEcdsaPrep<CV> f1{T, n, K, hash, hash_len, shift, r, s, pre, u12, valid};
   launch_fn(f1, T);
   if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
     FnEcdsaMain<CV, (W::L > 12 ? 2 : 0)> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
     bk.launch(f2, n);
-  } else {
-    FnEcdsaMain<CV> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
-    bk.launch(f2, n);
+    return E_OK;
   }
+  if constexpr (CV::ENDO && W::L <= 8) {
+    if (n <= small_grid()) {                // at most three waves per SIMD: the register-rich tuning
+      FnEcdsaMain<CV, 3, true> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
+      return launch_fn(f2, n);
+    }
+  }
+  FnEcdsaMain<CV> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
+  bk.launch(f2, n);
   return E_OK;
 }
 

@@ -47,6 +47,10 @@ namespace ell {
   KW template int Engine<HipBackend>::launch_fn<FnEcdsaPrep<CV>>(const FnEcdsaPrep<CV>&, size_t);   \
   KW template int Engine<HipBackend>::launch_fn<FnSignFinish<CV>>(const FnSignFinish<CV>&, size_t); \
   KW template int Engine<HipBackend>::launch_fn<FnRecoverPrep<CV>>(const FnRecoverPrep<CV>&, size_t);
+// the small-grid (WIDE) verify kernel of the endomorphism curve: its own translation unit
+#define ELL_DECL_G7(KW)                                                                              \
+  KW template int Engine<HipBackend>::launch_fn<FnEcdsaMain<CvSecp256k1, 3, true>>(                  \
+      const FnEcdsaMain<CvSecp256k1, 3, true>&, size_t);
 // user-defined short curves (CvCustom): scalar multiplication and point addition only
 #define ELL_DECL_CUSTOM(KW)                                                                          \
   KW template int Engine<HipBackend>::mul_var_chunk<CvCustom>(size_t, const u8*, const u8*, u8*, u8*, \
@@ -96,5 +100,6 @@ ELL_DECL_ED2(extern)
 ELL_DECL_ED3(extern)
 ELL_DECL_ED4(extern)
 ELL_DECL_CUSTOM(extern)
+ELL_DECL_G7(extern)
 
 }  // namespace ell

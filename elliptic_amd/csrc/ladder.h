@@ -100,13 +100,14 @@ struct Ladder {
   typedef Jac<F> J;
   typedef Aff<F> A;
 
-  // beta for the lambda-at-lookup entries.  ELL_BETA_REMAT = 1 (experiment): instead of holding the
+  // beta for the lambda-at-lookup entries.  ELL_BETA_REMAT = 1: instead of holding the
   // eight limbs in VGPRs across the whole ladder, move them in from scalar registers at every
-  // lookup (8 v_mov per lambda*P lookup, 8 registers fewer live in the loop)
-  template <bool L>
+  // lookup (8 v_mov per lambda*P lookup, 8 registers fewer live in the loop).  WIDE (the
+  // register-rich small-grid build, common.h) keeps them in VGPRs.
+  template <bool L, bool WIDE = false>
   ELL_HD static El lookup_beta(const El* beta) {
 #if ELL_BETA_REMAT && defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (L && !is_lazy<F>::value) {
+    if constexpr (L && !WIDE && !is_lazy<F>::value) {
       El b;
       ELL_UNROLL
       for (int i = 0; i < F::L; i++) {
@@ -184,7 +185,7 @@ struct Ladder {
   // is not stored; its entries are the first table's with x multiplied by beta at every lookup.
   // Halves the table bytes written per item and the region the gathers touch, for one more
   // field multiplication per addition of the second string (ELL_LAMBDA_AT_LOOKUP).
-  template <int NS, int NW, bool LAMBDA_AT_LOOKUP = false>
+  template <int NS, int NW, bool LAMBDA_AT_LOOKUP = false, bool WIDE = false>
   ELL_HD static J run_odd_w4(const DigitStore& ds, const A* tbl, u32 negmask, u32 evenmask, bool& inf,
                              const El* beta = nullptr) {
     // table entry for digit string s at window w (digits are odd and non-zero); a function of
@@ -194,13 +195,50 @@ struct Ladder {
       int ad = d < 0 ? -d : d;
       bool neg = (d < 0) != (((negmask >> s) & 1u) != 0);
       A q = tbl[(LAMBDA_AT_LOOKUP ? 0 : s * 8) + ((ad - 1) >> 1)];
-      if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP>(beta));
+      if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP, WIDE>(beta));
       q.y = cneg_y(q.y, neg);
       return q;
     };
     // top window, first string: acc = the entry itself (no addition into O)
     J acc = G::from_affine(entry(NW - 1, 0));
     inf = false;
+    if constexpr (WIDE || ELL_PREFETCH) {
+    // Software-pipelined form (the register-rich small-grid build): the table entry of the next
+    // addition is requested before the work that precedes that addition -- the first string's
+    // entry before the window's four doublings, the second string's before the first addition --
+    // so that at two resident waves per SIMD no gather latency is exposed.  `raw` = the stored
+    // entry; sign and beta are applied at the point of use.
+    auto raw = [&](int w, int s, bool& neg, const A*& at) -> A {
+      int d = ds.get(w * NS + s);
+      int ad = d < 0 ? -d : d;
+      neg = (d < 0) != (((negmask >> s) & 1u) != 0);
+      at = tbl + (LAMBDA_AT_LOOKUP ? 0 : s * 8) + ((ad - 1) >> 1);
+      return *at;
+    };
+    auto finish = [&](A q, int s, bool neg) -> A {
+      if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP, WIDE>(beta));
+      q.y = cneg_y(q.y, neg);
+      return q;
+    };
+    static_assert(NS <= 2, "prefetch form written for one or two digit strings");
+    ELL_NOUNROLL
+    for (int w = NW - 1; w >= 0; w--) {
+      bool neg0 = false, neg1 = false;
+      const A* at0 = tbl;
+      const A* at1 = tbl;
+      A q0, q1;
+      if (w != NW - 1) {
+        q0 = raw(w, 0, neg0, at0);
+        ELL_NOUNROLL
+        for (int j = 0; j < 4; j++) acc = G::dbl(acc);
+      }
+      if (NS > 1) q1 = raw(w, NS - 1, neg1, at1);
+      if (w != NW - 1)
+        acc = G::add_mixed_lean(acc, finish(q0, 0, neg0), inf, [&]() { return finish(*at0, 0, neg0); });
+      if (NS > 1)
+        acc = G::add_mixed_lean(acc, finish(q1, NS - 1, neg1), inf, [&]() { return finish(*at1, NS - 1, neg1); });
+    }
+    } else {
     ELL_NOUNROLL
     for (int w = NW - 1; w >= 0; w--) {
       if (w != NW - 1) {
@@ -211,11 +249,12 @@ struct Ladder {
       for (int s = (w == NW - 1 ? 1 : 0); s < NS; s++)
         acc = G::add_mixed_lean(acc, entry(w, s), inf, [&]() { return entry(w, s); });
     }
+    }
     ELL_NOUNROLL
     for (int s = 0; s < NS; s++) {
       auto corr = [&]() -> A {
         A q = tbl[LAMBDA_AT_LOOKUP ? 0 : s * 8];
-        if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP>(beta));
+        if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP, WIDE>(beta));
         bool neg = ((negmask >> s) & 1u) == 0;        // subtract sign_s * P_s
         q.y = cneg_y(q.y, neg);
         return q;
@@ -254,11 +293,39 @@ struct Ladder {
   // fixed-base comb: acc + sum_w d_w * 2^(CB*w) * G with d_w the w-th CB-bit digit of k (CB = 8
   // or 16); comb[w*(2^CB - 1) + d-1] = d * 2^(CB*w) * G (affine, field-internal form).  Zero
   // digits sit the addition out (exec mask).  `inf` = acc is O, updated.
-  template <int LK, int W, int CB>
+  template <int LK, int W, int CB, bool WIDE = false>
   ELL_HD static J comb_add(J acc, bool& inf, const u32 (&k)[LK], const A* comb) {
     constexpr u32 MASK = (1u << CB) - 1u;
     u32 kk[LK];
     bn_copy<LK>(kk, k);
+    if constexpr (WIDE || ELL_PREFETCH) {
+    // software-pipelined (see run_odd_w4): window w+1's entry is requested before window w's
+    // addition; a zero digit fetches the window's first entry and sits the addition out
+    auto digit = [&]() -> u32 {
+      u32 d = kk[0] & MASK;
+      ELL_UNROLL
+      for (int i = 0; i < LK - 1; i++) kk[i] = (kk[i] >> CB) | (kk[i + 1] << (32 - CB));
+      kk[LK - 1] >>= CB;
+      return d;
+    };
+    u32 d = digit();
+    const A* e = comb + (d ? d - 1 : 0);
+    A q = *e;
+    ELL_NOUNROLL
+    for (int w = 0; w < W; w++) {
+      u32 dn = 0;
+      const A* en = comb;
+      A qn = q;
+      if (w + 1 < W) {
+        dn = digit();
+        en = comb + ((size_t)(w + 1) * MASK + (dn ? dn - 1 : 0));
+        qn = *en;
+      }
+      if (d != 0) acc = G::add_mixed_lean(acc, q, inf, [&]() { return *e; });
+      d = dn; e = en; q = qn;
+    }
+    return acc;
+    } else {
     ELL_NOUNROLL
     for (int w = 0; w < W; w++) {
       u32 d = kk[0] & MASK;
@@ -271,6 +338,7 @@ struct Ladder {
       }
     }
     return acc;
+    }
   }
   template <int LK, int W, int CB>
   ELL_HD static J comb_mul(const u32 (&k)[LK], const A* comb) {

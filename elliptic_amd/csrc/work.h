@@ -150,6 +150,9 @@ struct Work {
   // k*P for one (k, P), result in true Jacobian coordinates.  secp256k1: GLV split, odd
   // signed digits, effective-affine tables of P and lambda*P (mixed adds only); other
   // curves: odd signed digits over an affine table of the odd multiples.
+  // WIDE = the register-rich tuning of the secp256k1 ladder (common.h): beta and zg stay in
+  // registers, table entries are requested one step ahead (Ladder::run_odd_w4)
+  template <bool WIDE = false>
   ELL_HD static J var_ladder(const u32 (&k)[L], const A& p, VT* tbl, const DigitStore& ds, bool& inf) {
     if constexpr (ENDO) {
       u32 k1[5], k2[5];
@@ -167,16 +170,20 @@ struct Work {
       // isomorphisms, which only scale x and y
       El beta = load_beta();
 #if ELL_LAMBDA_AT_LOOKUP
+      J r;
 #if ELL_SPILL_ZG && defined(__HIP_DEVICE_COMPILE__)
-      // zg is needed again only after the ladder: park it in a free table slot (slots 8..15 are
-      // the build's scratch) instead of eight registers held across the loop
-      tbl[15].x = zg;
-      J r = LD::template run_odd_w4<2, NNIB, true>(ds, tbl, negmask, evenmask, inf, &beta);
-      asm volatile("" ::: "memory");
-      zg = tbl[15].x;
-#else
-      J r = LD::template run_odd_w4<2, NNIB, true>(ds, tbl, negmask, evenmask, inf, &beta);
+      if constexpr (!WIDE) {
+        // zg is needed again only after the ladder: park it in a free table slot (slots 8..15 are
+        // the build's scratch) instead of eight registers held across the loop
+        tbl[15].x = zg;
+        r = LD::template run_odd_w4<2, NNIB, true>(ds, tbl, negmask, evenmask, inf, &beta);
+        asm volatile("" ::: "memory");
+        zg = tbl[15].x;
+      } else
 #endif
+      {
+        r = LD::template run_odd_w4<2, NNIB, true, WIDE>(ds, tbl, negmask, evenmask, inf, &beta);
+      }
 #else
       ELL_NOUNROLL
       for (int e = 0; e < 8; e++) {
@@ -967,6 +974,7 @@ struct Work {
   }
 
   // Pass 2: R = u1*G + u2*Q, accept iff R != O and R.x == r (mod n)
+  template <bool WIDE = false>
   ELL_HD static void ecdsa_main(size_t i, size_t n, const u32* u12, const u8* valid,
                                 const u8* rs, const u8* pub_xy, const A* comb, VT* tbl_all,
                                 const DigitStore& ds, u8* out_ok) {
@@ -977,15 +985,15 @@ struct Work {
     // u2 * Q first; u1 and r are loaded where they are used, behind compiler barriers, so that
     // they do not occupy registers across the ladder (ELL_LATE_LOADS: the 128-register build)
     bool inf;
-    J b = var_ladder(u2, q, tbl_all + i * TBL1, ds, inf);
+    J b = var_ladder<WIDE>(u2, q, tbl_all + i * TBL1, ds, inf);
 #if ELL_LATE_LOADS && defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" ::: "memory");
+    if constexpr (!WIDE) asm volatile("" ::: "memory");
 #endif
     ELL_UNROLL
     for (int l = 0; l < L; l++) u1[l] = l < LN ? u12[(size_t)(0 * LN + l) * n + i] : 0u;
-    J p = LD::template comb_add<L, COMB_W, COMB_BITS>(b, inf, u1, comb);
+    J p = LD::template comb_add<L, COMB_W, COMB_BITS, WIDE>(b, inf, u1, comb);
 #if ELL_LATE_LOADS && defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" ::: "memory");
+    if constexpr (!WIDE) asm volatile("" ::: "memory");
 #endif
     load_be<LN>(r, rs + i * NBYTES, NBYTES);
     bool ok = valid[i] != 0 && !G::is_inf(p);

@@ -76,6 +76,38 @@ def test_config3_secp256k1_variable_base_and_verify_1M(ctx):
     assert np.array_equal(wok, expect[idx])
 
 
+def test_config3_strong_scaling_shards_both_tunings(ctx, monkeypatch):
+    """BASELINE configs[2] sharded 1 -> 8: a GPU's share of the 2^20 batch is 2^20 / N tuples.
+    Shards of at most three waves per SIMD run the small-grid tuning of ecdsa_main
+    (FnEcdsaMain<.., WIDE>), larger ones the full-grid tuning; both must give the expected mask on
+    every shard of every split, and the two tunings the same bytes on the same shard."""
+    import bench
+    import torch
+    from elliptic_amd.sharding import shard_range
+    n = 1 << 20
+    h, r, s, pub, expect = bench.cached_signatures(ctx, n, "ellgpu-bench-v1:3:rank0")
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(x).to(dev) for x in (h, r, s, pub)]
+    for world in (2, 4, 8, 7):
+        for rank in (0, world - 1):
+            lo, hi = shard_range(n, rank, world)
+            ok = torch.zeros(hi - lo, dtype=torch.uint8, device=dev)
+            ctx.ecdsa_verify_dev("secp256k1", *(x[lo:hi] for x in t), ok)
+            torch.cuda.synchronize()
+            assert np.array_equal(ok.cpu().numpy(), expect[lo:hi]), (world, rank)
+    lo, hi = shard_range(n, 3, 8)
+    masks = []
+    for forced in ("0", str(1 << 30)):                     # full-grid tuning, then small-grid tuning
+        monkeypatch.setenv("ELLGPU_SMALL_GRID", forced)
+        ok = torch.zeros(hi - lo, dtype=torch.uint8, device=dev)
+        ctx.ecdsa_verify_dev("secp256k1", *(x[lo:hi] for x in t), ok)
+        torch.cuda.synchronize()
+        masks.append(ok.cpu().numpy())
+    assert np.array_equal(masks[0], masks[1]) and np.array_equal(masks[0], expect[lo:hi])
+    idx = sample_idx(hi - lo, 2048) + lo
+    assert np.array_equal(C.verify("secp256k1", h[idx], r[idx], s[idx], pub[idx], threads=threads()), expect[idx])
+
+
 def test_config4_ed25519_variable_base_1M(ctx):
     n = 1 << 20
     k = rnd("bl:cfg4:k", n, 32)

@@ -196,6 +196,16 @@ def test_verify_golden(ctx, curve):
     assert PC.check_verify_golden(ctx, curve) > 15
 
 
+def test_verify_golden_secp256k1_both_tunings(ctx, monkeypatch):
+    """ecdsa_main exists in two tunings for secp256k1 (engine.h: FnEcdsaMain<.., WIDE>): the
+    full-grid one (lean registers) and the small-grid one (entries requested one step ahead).
+    Small batches take the second by default; ELLGPU_SMALL_GRID=0 forces the first."""
+    monkeypatch.setenv("ELLGPU_SMALL_GRID", "0")
+    assert PC.check_verify_golden(ctx, "secp256k1") > 15
+    monkeypatch.setenv("ELLGPU_SMALL_GRID", str(1 << 30))
+    assert PC.check_verify_golden(ctx, "secp256k1") > 15
+
+
 @pytest.mark.parametrize("curve", ["secp256k1", "p192", "p256", "p384", "p521", "ed25519"])
 def test_decompress_golden(ctx, curve):
     assert PC.check_decompress_golden(ctx, curve) > 40

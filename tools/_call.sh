@@ -1,8 +1,4 @@
-set -x
-O=gpurun_out/r03a; mkdir -p $O
-python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_inplace.log 2>&1; echo "rc=$?" >> $O/smoke_inplace.log
-rm -rf /tmp/treecopy && mkdir -p /tmp/treecopy && cp -rL . /tmp/treecopy/repo2 2>/dev/null
-(cd /tmp/treecopy/repo2 && pwd && python -c "import __graft_entry__ as g; g.smoke()") > $O/smoke_copied_tree.log 2>&1; echo "rc=$?" >> $O/smoke_copied_tree.log
-python tools/strong_proxy.py > $O/strong_proxy.jsonl 2> $O/strong_proxy.err
-python bench.py --no-cpu --no-configs --steps 40 --warmup 5 > $O/bench_short.json 2> $O/bench_short.err
-tail -3 $O/*.log; cat $O/strong_proxy.jsonl | cut -c1-300
+O=gpurun_out/r03d; mkdir -p $O
+( time timeout 900 python bench.py --keep-counters $O/live_counters ) > $O/bench.json.log 2> $O/bench.err; tail -c 300 $O/bench.err
+( time timeout 900 python bench.py --steps 20 --warmup 3 --no-cpu --no-configs ) > $O/bench2.json.log 2> $O/bench2.err; tail -c 300 $O/bench2.err
+ls $O/live_counters

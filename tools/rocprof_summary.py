@@ -8,9 +8,11 @@ import sys
 
 
 def short(name):
-    m = re.search(r"k_run<ell::(\w+)(?:<ell::(\w+)[,<>])?", name)
+    m = re.search(r"k_run<ell::(\w+)(?:<ell::(\w+)([^()]*?)>)?", name)
     if m:
-        return "k_run<%s%s>" % (m.group(1), ("<" + m.group(2) + ">") if m.group(2) else "")
+        # the small-grid (WIDE) instantiation of a functor is a kernel of its own
+        wide = ",wide" if (m.group(3) or "").replace(" ", "").endswith(",true") else ""
+        return "k_run<%s%s%s>" % (m.group(1), ("<" + m.group(2) + ">") if m.group(2) else "", wide)
     return name[:90]
 
 
