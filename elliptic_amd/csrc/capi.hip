@@ -102,6 +102,10 @@ __global__ void __launch_bounds__(64) k_probe_field(u32* out, int iters, u32 see
 }
 
 // ---- white-box probe: one field operation per lane (tests/test_gpu_field.py) ----
+template <class F, class = void>
+struct ell_has_wide_probe { static constexpr bool value = false; };
+template <class RR>
+struct ell_has_wide_probe<FpSolinas<RR>, void> { static constexpr bool value = true; };
 template <class F>
 __global__ void k_field_op(int op, size_t n, const u32* a, const u32* b, u32* r) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,6 +127,15 @@ __global__ void k_field_op(int op, size_t n, const u32* a, const u32* b, u32* r)
   }
   if constexpr (std::is_same<F, Fp25519>::value) {
     if (op == 10) z = F::mul_u32(x, tb[0]);               // one-limb constant
+  }
+  if constexpr (ell_has_wide_probe<F>::value) {
+    // the reduction itself on ANY 2L-word value (a = low half, b = high half, not reduced first):
+    // directed tests of FpSolinas's rarely taken fold branches, which products reach too seldom
+    if (op == 13) {
+      u32 w[2 * F::L];
+      for (int l = 0; l < F::L; l++) { w[l] = ta[l]; w[F::L + l] = tb[l]; }
+      z = F::reduce_wide(w);
+    }
   }
   if constexpr (std::is_same<F, FpK256L>::value) {
     // lazy forms through the generated asm: x*y + (4p - x)*(x - y + 4p), and (3 x^2) / 2

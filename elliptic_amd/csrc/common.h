@@ -20,6 +20,11 @@
 #ifndef ELL_SOLINAS_MAD_FOLD
 #define ELL_SOLINAS_MAD_FOLD 0
 #endif
+// FpSolinas::reduce_wide of p192 / p224 / p384: 1 = the two-stage carry-chain fold
+// (reduce_wide_chain), 0 = the lazy-accumulator fold for every Solinas prime (p256 always)
+#ifndef ELL_SOLINAS_CHAIN
+#define ELL_SOLINAS_CHAIN 1
+#endif
 #ifndef ELL_P224_TS_WINDOW
 #define ELL_P224_TS_WINDOW 1      // p224 square root: windowed Tonelli-Shanks (fp.h)
 #endif

@@ -927,6 +927,23 @@ struct FpMont {
 // R supplies: MP (constant struct with p, pm2, pp1d4, the inversion constants) and the rule
 //   NFOLD, fold_pos[NFOLD] (highest first), fold_sign[NFOLD].
 // --------------------------------------------------------------------------
+// ELL_CHAIN_SCHED = 1: the chains of reduce_wide_chain are kept apart from each other and from
+// the product by scheduling barriers (the scheduler otherwise runs three chains side by side and
+// pulls them up into the product: more live words)
+#ifndef ELL_CHAIN_SCHED
+#define ELL_CHAIN_SCHED 0
+#endif
+#ifndef ELL_P384_CHAIN
+#define ELL_P384_CHAIN 0
+#endif
+#ifndef ELL_SOLINAS_DIRECT_SUB
+#define ELL_SOLINAS_DIRECT_SUB 1
+#endif
+#if ELL_CHAIN_SCHED && defined(__HIP_DEVICE_COMPILE__)
+#define ELL_CHAIN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ELL_CHAIN_FENCE() ((void)0)
+#endif
 template <class R>
 struct FpSolinas {
   typedef typename R::MP MP;
@@ -1065,7 +1082,116 @@ struct FpSolinas {
     return x >> 32;
 #endif
   }
+  // ---- chain fold (R::CHAIN: p192, p224, p384 -- the primes whose fold rule reaches at most
+  // half way up, B^L == sum_f sign_f B^pos_f with pos_0 <= L/2) --------------------------------
+  // With T = Lo + H B^L:   V = Lo + sum_f sign_f H B^pos_f   is NFOLD multi-word add / subtract
+  // chains of L words each (carry flags, no 64-bit widening, no negation), V < 2 B^(L + pos_0).
+  // Its excess G = V >> 32L has only pos_0 + 1 words, so the same step once more,
+  // V' = V_lo + sum_f sign_f G B^pos_f, is NFOLD chains of pos_0 + 1 words -- and V' < B^L.
+  // Every chain carries one word past its operand; a carry / borrow that wants to travel FURTHER
+  // needs that word to be 2^32 - 1 (0): those lanes (~2^-29 per product) finish the ripple in a
+  // rarely entered branch right behind the chain (nothing of the product has to stay live for a
+  // fallback), and a V' outside [0, p) -- a carry out of the top, or a top word of 2^32 - 1 --
+  // takes the final correction branch.  p384: ~90 instructions instead
+  // of ~150 (55 + 24 chain words instead of 48 64-bit accumulations + 48 widening moves + 24
+  // negation words + the carry pass).  Additions first, subtractions last: V and V' never dip
+  // below zero on the way (H B^4 >= H B, H B^3 >= H).
+  // One chain.  Its still-pending carry (0 / 1) is shifted into `pend` (pend = 2 pend + c: one
+  // v_addc), so that after all 2 NFOLD chains bit (2 NFOLD - 1 - i) of pend belongs to chain i.
+  template <bool SUB, int N, int OFF, int NV>
+  ELL_HD static void chain(u32 (&v)[NV], const u32* src, u32& pend) {
+    ELL_CHAIN_FENCE();
+    u32 c = 0;
+    ELL_UNROLL
+    for (int k = 0; k < N; k++) {
+      if (SUB) v[OFF + k] = subb32(v[OFF + k], src[k], c, c);
+      else v[OFF + k] = addc32(v[OFF + k], src[k], c, c);
+    }
+    if constexpr (OFF + N < NV) {                         // one word past the operand
+      if (SUB) v[OFF + N] = subb32(v[OFF + N], 0u, c, c);
+      else v[OFF + N] = addc32(v[OFF + N], 0u, c, c);
+    }
+    u32 dummy;
+    pend = addc32(pend, pend, c, dummy);
+  }
+  template <int STAGE, bool SUB, int F, int NV>
+  ELL_HD static void chain_folds(u32 (&v)[NV], const u32* src, u32& pend) {
+    if constexpr (F < R::NFOLD) {
+      constexpr int N = STAGE == 1 ? L : R::fold_pos[0] + 1;
+      if constexpr ((R::fold_sign[F] < 0) == SUB) chain<SUB, N, R::fold_pos[F], NV>(v, src, pend);
+      chain_folds<STAGE, SUB, F + 1, NV>(v, src, pend);
+    }
+  }
+  // the pending carries as signed corrections: chain i's carry has the weight
+  // B^(pos + N + 1) -- B^(pos + N) where the chain had no extra word -- in its stage's frame
+  template <int STAGE, bool SUB, int F, int IDX>
+  ELL_HD static void chain_pending(i64* A, u32 pend) {
+    if constexpr (F < R::NFOLD) {
+      if constexpr ((R::fold_sign[F] < 0) == SUB) {
+        constexpr int N = STAGE == 1 ? L : R::fold_pos[0] + 1;
+        constexpr int NV = STAGE == 1 ? L + R::fold_pos[0] + 1 : L;
+        constexpr int E = R::fold_pos[F] + N + (R::fold_pos[F] + N < NV ? 1 : 0);
+        const i64 c = (pend >> (2 * R::NFOLD - 1 - IDX)) & 1u;
+        A[E] += SUB ? -c : c;
+        chain_pending<STAGE, SUB, F + 1, IDX + 1>(A, pend);
+      } else {
+        chain_pending<STAGE, SUB, F + 1, IDX>(A, pend);
+      }
+    }
+  }
+  static constexpr int n_pos() {
+    int n = 0;
+    for (int f = 0; f < R::NFOLD; f++) n += R::fold_sign[f] > 0 ? 1 : 0;
+    return n;
+  }
+  ELL_HD static El reduce_wide_chain(const u32 (&t)[2 * L]) {
+    constexpr int P = R::fold_pos[0];                     // positions are listed highest first
+    static_assert(2 * P <= L, "chain fold needs the fold rule to reach at most half way up");
+    constexpr int NV = L + P + 1;
+    u32 v[NV], h[L];
+    ELL_UNROLL
+    for (int k = 0; k < NV; k++) v[k] = k < L ? t[k] : 0u;
+    ELL_UNROLL
+    for (int k = 0; k < L; k++) h[k] = t[L + k];
+    u32 pend = 0;
+    chain_folds<1, false, 0, NV>(v, h, pend);
+    chain_folds<1, true, 0, NV>(v, h, pend);
+    ELL_CHAIN_FENCE();
+    u32 g[P + 1], r[L];
+    ELL_UNROLL
+    for (int k = 0; k <= P; k++) g[k] = v[L + k];
+    ELL_UNROLL
+    for (int k = 0; k < L; k++) r[k] = v[k];
+    chain_folds<2, false, 0, L>(r, g, pend);
+    chain_folds<2, true, 0, L>(r, g, pend);
+    if (ELL_UNLIKELY(pend != 0 || r[L - 1] == 0xFFFFFFFFu)) {
+      // V' + the carries that were left pending, as a word vector for the lazy fold: stage-2
+      // carries sit at their own position, a stage-1 carry at B^e with e >= L is a word of the
+      // excess and folds like one.  (Stage 1's words above L were consumed as G already: only the
+      // corrections remain there.)
+      constexpr int NP = n_pos();
+      i64 A[2 * L];
+      ELL_UNROLL
+      for (int k = 0; k < 2 * L; k++) A[k] = k < L ? (i64)(u64)r[k] : 0;
+      chain_pending<1, false, 0, 0>(A, pend);
+      chain_pending<1, true, 0, NP>(A, pend);
+      chain_pending<2, false, 0, R::NFOLD>(A, pend);
+      chain_pending<2, true, 0, R::NFOLD + NP>(A, pend);
+      return finish_lazy(A);
+    }
+    El out;
+    bn_copy<L>(out.v, r);
+    return out;
+  }
+  template <class RR, class = void>
+  struct has_chain { static constexpr bool value = false; };
+  template <class RR>
+  struct has_chain<RR, decltype((void)RR::CHAIN)> { static constexpr bool value = RR::CHAIN; };
   ELL_HD static El reduce_wide(const u32 (&t)[2 * L]) {
+    if constexpr (has_chain<R>::value && ELL_SOLINAS_CHAIN) return reduce_wide_chain(t);
+    else return reduce_wide_lazy(t);
+  }
+  ELL_HD static El reduce_wide_lazy(const u32 (&t)[2 * L]) {
 #if ELL_SOLINAS_MAD_FOLD
     // A[k] holds only what has been folded INTO position k; the product word t[k] itself joins
     // through add_word where the position is consumed
@@ -1089,16 +1215,32 @@ struct FpSolinas {
       r[k] = (u32)sum;
       c = sar32(sum);
     }
+    return finish_top(r, c);
 #else
     i64 A[2 * L];
     ELL_UNROLL
     for (int k = 0; k < 2 * L; k++) A[k] = (i64)(u64)t[k];
+    return finish_lazy(A);
+#endif
+  }
+  // the lazy-accumulator fold of a signed word vector A[0 .. 2L)
+  ELL_HD static El finish_lazy(i64 (&A)[2 * L]) {
     ELL_UNROLL
     for (int k = 2 * L - 1; k >= L; k--) {
       const i64 v = A[k];
-      const i64 nv = -v;
-      ELL_UNROLL
-      for (int f = 0; f < R::NFOLD; f++) A[k - L + R::fold_pos[f]] += R::fold_sign[f] > 0 ? v : nv;
+      if constexpr (R::NFOLD - n_pos() == 1 && ELL_SOLINAS_DIRECT_SUB) {
+        // a single subtracted position (p384, p224): subtract v there (two instructions) instead
+        // of negating it first (two) and adding (one)
+        ELL_UNROLL
+        for (int f = 0; f < R::NFOLD; f++) {
+          if (R::fold_sign[f] > 0) A[k - L + R::fold_pos[f]] += v;
+          else A[k - L + R::fold_pos[f]] -= v;
+        }
+      } else {
+        const i64 nv = -v;
+        ELL_UNROLL
+        for (int f = 0; f < R::NFOLD; f++) A[k - L + R::fold_pos[f]] += R::fold_sign[f] > 0 ? v : nv;
+      }
     }
     u32 r[L];
     i64 c = 0;
@@ -1108,7 +1250,9 @@ struct FpSolinas {
       r[k] = (u32)sum;
       c = sum >> 32;
     }
-#endif
+    return finish_top(r, c);
+  }
+  ELL_HD static El finish_top(u32 (&r)[L], i64 c) {
     // c * B^L: the same fold on the low words
     constexpr int TOP = R::fold_pos[0] + 1;            // fold_pos is listed highest first
     i64 c2 = 0;
@@ -1267,12 +1411,14 @@ struct FpSolinas {
 // every one of these primes has 2^32 - 1 as its top word (FpSolinas's rare-branch test)
 struct SolP192 {                       // p192 = 2^192 - 2^64 - 1:            B^6 == B^2 + 1
   typedef consts::P192_P MP;
+  static constexpr bool CHAIN = true;
   static constexpr int NFOLD = 2;
   static constexpr int fold_pos[2] = {2, 0};
   static constexpr int fold_sign[2] = {1, 1};
 };
 struct SolP224 {                       // p224 = 2^224 - 2^96 + 1:            B^7 == B^3 - 1
   typedef consts::P224_P MP;
+  static constexpr bool CHAIN = true;
   static constexpr int NFOLD = 2;
   static constexpr int fold_pos[2] = {3, 0};
   static constexpr int fold_sign[2] = {1, -1};
@@ -1285,6 +1431,10 @@ struct SolP256 {                       // p256 = 2^256 - 2^224 + 2^192 + 2^96 - 
 };
 struct SolP384 {                       // p384 = 2^384 - 2^128 - 2^96 + 2^32 - 1:    B^12 == B^4 + B^3 - B + 1
   typedef consts::P384_P MP;
+  // the chain fold is 15 % fewer instructions here too (388 instead of 455 per multiplication) and
+  // measures 2 % SLOWER (P*k 21.0 against 21.4 M/s, profiles/r03_solinas_chain_ab.txt): four
+  // 13-word carry chains are latency, where the lazy fold's 64-bit adds have no flag to wait for
+  static constexpr bool CHAIN = ELL_P384_CHAIN;
   static constexpr int NFOLD = 4;
   static constexpr int fold_pos[4] = {4, 3, 1, 0};
   static constexpr int fold_sign[4] = {1, 1, -1, 1};

@@ -288,6 +288,87 @@ def solinas_vectors():
     return out
 
 
+def solinas_chain_trace(T, field):
+    """mirror of FpSolinas::reduce_wide_chain (p192 / p224 / p384) on a 2L-word value T ->
+    (list of chain indices whose carry / borrow wanted to travel past the extra word,
+     top word of the candidate result, candidate result).  Chains are numbered in execution
+    order: stage 1 additions, stage 1 subtractions, stage 2 additions, stage 2 subtractions."""
+    p, L, fold = SOL_FIELDS[field]
+    P = fold[0][0]
+    W = 1 << 32
+
+    def run(words, src, n, flagged, base):
+        order = [f for f in fold if f[1] > 0] + [f for f in fold if f[1] < 0]
+        for idx, (pos, sg) in enumerate(order):
+            c = 0
+            for k in range(n):
+                x = words[pos + k] + sg * (src[k] + c)
+                c = 1 if (x < 0 or x >= W) else 0
+                words[pos + k] = x % W
+            if pos + n < len(words):
+                x = words[pos + n] + sg * c
+                c = 1 if (x < 0 or x >= W) else 0
+                words[pos + n] = x % W
+            if c:
+                flagged.append(base + idx)
+    t = [(T >> (32 * k)) & 0xFFFFFFFF for k in range(2 * L)]
+    v = t[:L] + [0] * (P + 1)
+    flagged = []
+    run(v, t[L:], L, flagged, 0)
+    g = v[L:]
+    lo = v[:L]
+    run(lo, g, P + 1, flagged, len(fold))
+    return flagged, lo[L - 1], sum(w << (32 * k) for k, w in enumerate(lo))
+
+
+def solinas_chain_vectors():
+    """(field, op 13, low half, high half, T mod p): raw 2L-word values for the chain fold of
+    p192 / p224 / p384 -- words drawn mostly from {0, 1, 2^32 - 2, 2^32 - 1} so that every chain's
+    carry / borrow ripple and the top-word test are entered (counted with the mirror), next to
+    values that stop one short of them, and plain random ones."""
+    import random
+    rnd = random.Random(384)
+    special = [0, 1, 2, 0xFFFFFFFE, 0xFFFFFFFF, 0x80000000, 0x7FFFFFFF]
+    out = []
+    for field in (11, 12, 14):
+        p, L, fold = SOL_FIELDS[field]
+        hits = {}
+        n_top = n_clean = 0
+        for trial in range(6000):
+            mode = trial % 3
+            ws = []
+            for k in range(2 * L):
+                if mode == 0 or rnd.random() < (0.75 if mode == 1 else 0.3):
+                    ws.append(rnd.choice(special))
+                else:
+                    ws.append(rnd.getrandbits(32))
+            if trial % 7 == 0:
+                ws = [rnd.getrandbits(32) for _ in range(2 * L)]
+            T = sum(w << (32 * k) for k, w in enumerate(ws))
+            flagged, top, cand = solinas_chain_trace(T, field)
+            keep = False
+            for c in flagged:
+                if hits.get(c, 0) < 12:
+                    hits[c] = hits.get(c, 0) + 1
+                    keep = True
+            if not flagged and top == 0xFFFFFFFF and n_top < 25:
+                n_top += 1
+                keep = True
+            if not flagged and top != 0xFFFFFFFF:
+                assert cand == T % p, (field, hex(T))            # the common path is exact
+                if n_clean < 60:
+                    n_clean += 1
+                    keep = True
+            if keep:
+                lo, hi = T % (1 << (32 * L)), T >> (32 * L)
+                out.append((field, 13, lo, hi, T % p))
+        # every chain but the very first (whose extra word is V's zero top word) must have been
+        # driven into its ripple
+        assert set(hits) == set(range(1, 2 * len(fold))), (field, hits)
+        assert n_top >= 5, (field, n_top)
+    return out
+
+
 def solinas_addsub_vectors():
     """(field, op, a, b, expected) for the rarely taken branch of FpSolinas::add / sub (p192, p224,
     p256, p384): a folded carry / borrow arriving at a limb whose word of 2^(32L) mod p is zero, and

@@ -71,6 +71,10 @@ static int ell_device_count() { return 1; }
 // ---- white-box probes (hostsim only) -------------------------------------------
 using namespace ell;
 
+template <class F, class = void>
+struct has_wide_probe { static constexpr bool value = false; };
+template <class RR>
+struct has_wide_probe<FpSolinas<RR>, void> { static constexpr bool value = true; };
 template <class F>
 static void field_op(int op, const u32* a, const u32* b, u32* r) {
   typename F::El x, y, z;
@@ -89,6 +93,13 @@ static void field_op(int op, const u32* a, const u32* b, u32* r) {
     case 7: z = F::template mul_pow2<2>(x); break;
     case 8: z = F::template mul_pow2<3>(x); break;
     default: z = x;
+  }
+  if constexpr (has_wide_probe<F>::value) {
+    if (op == 13) {                          // reduce_wide of the raw 2L words (a | b << 32L)
+      u32 w[2 * F::L];
+      for (int i = 0; i < F::L; i++) { w[i] = ta[i]; w[F::L + i] = tb[i]; }
+      z = F::reduce_wide(w);
+    }
   }
   if constexpr (std::is_same<F, FpK256L>::value) {
     if (op == 11) z = F::mul2(x, y, F::template neg_l<4>(x), F::template sub_l<4>(x, y));

@@ -118,6 +118,30 @@ def test_rare_branches_solinas_gpu(ctx):
                 assert g == v[4], (field, op, hex(v[2]), hex(v[3]), hex(g))
 
 
+def test_solinas_chain_fold_raw_words_gpu(ctx):
+    """FpSolinas::reduce_wide_chain (p192 / p224 / p384) on raw 2L-word values (field-op probe 13):
+    directed values for every chain's rarely taken ripple and for the top-word test (the wave then
+    redoes the reduction with the lazy-accumulator fold), near misses, and 20 000 random 2L-word
+    values per field, lanes of one wave disagreeing about the branch"""
+    import field_vectors
+    vecs = field_vectors.solinas_chain_vectors()
+    rnd = random.Random(1384)
+    for field, L in ((11, 6), (12, 7), (14, 12)):
+        p = FIELDS[field]
+        sel = [(v[2], v[3], v[4]) for v in vecs if v[0] == field]
+        assert len(sel) > 80
+        for _ in range(20000):
+            T = rnd.getrandbits(64 * L)
+            sel.append((T % (1 << (32 * L)), T >> (32 * L), T % p))
+        rnd.shuffle(sel)
+        A, B = _pack([v[0] for v in sel], L), _pack([v[1] for v in sel], L)
+        R = np.zeros((len(sel), L), np.uint32)
+        assert ctx._lib.ellgpu_debug_field_op(ctx._ctx, field, 13, len(sel), A.ctypes.data, B.ctypes.data,
+                                              R.ctypes.data) == 0
+        for v, g in zip(sel, _unpack(R)):
+            assert g == v[2], (field, hex(v[0]), hex(v[1]), hex(g))
+
+
 def test_lazy_field_asm_gpu(ctx):
     """field id 2 = FpK256L through the generated v_mad_i64_i32 column statements
     (csrc/k256l_asm.h): the two-product multiply and the 3/2 x^2 of the lazy doubling, 20 000 random

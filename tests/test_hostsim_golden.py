@@ -132,6 +132,19 @@ def test_rare_branches_solinas(hs):
         assert _val(r) == want, (field, op, hex(a), hex(b))
 
 
+def test_solinas_chain_fold_raw_words(hs):
+    """FpSolinas::reduce_wide_chain (p192 / p224 / p384) on raw 2L-word values: the rarely taken
+    ripple of every chain, the top-word test, near misses and random values (field-op probe 13)"""
+    import field_vectors
+    vecs = field_vectors.solinas_chain_vectors()
+    assert len(vecs) > 300
+    for field, op, lo, hi, want in vecs:
+        L = {11: 6, 12: 7, 14: 12}[field]
+        r = (ctypes.c_uint32 * L)()
+        assert hs.hs_field_op(field, op, _limbs(lo, L), _limbs(hi, L), r) == 0
+        assert _val(r) == want, (field, hex(lo), hex(hi))
+
+
 def test_p521_from_plain_overrange(hs):
     """The Mersenne fold must canonicalise any 17-limb input (decompress hands raw 66-byte
     values to from_plain): p -> 0, 2^521 -> 1, all-ones limbs, ..."""
