@@ -120,6 +120,46 @@ struct FnMulFixed {
     if (i < n) W::mul_fixed(i, n, k, comb, jac);
   }
 };
+// comb construction: entry idx = w * PER + (d - 1) of the fixed-base table is (d << (CB w)) * G;
+// this writes the scalar (reduced mod n) and the generator for entries [first, first + n)
+template <class CV>
+struct FnCombGen {
+  static constexpr const char* NAME = "comb_gen";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; size_t first; u8* k; u8* xy;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i >= n) return;
+    const size_t idx = first + i;
+    const int w = (int)(idx / W::COMB_DIG);
+    const u32 d = (u32)(idx % W::COMB_DIG) + 1u;
+    const int sh = w * W::COMB_BITS;
+    // (d << sh) mod n: the value can exceed the scalar's byte length in the top window (the
+    // signed recoding's carry window of a narrow comb: 2^256 * G), so it goes through the order
+    // field like any over-long byte string (Work::bytes_mod_n)
+    constexpr int LN = W::LN;
+    u32 v[2 * LN];
+    ELL_UNROLL
+    for (int l = 0; l < 2 * LN; l++) v[l] = 0;
+    const int li = sh >> 5, bs = sh & 31;
+    ELL_UNROLL
+    for (int l = 0; l < 2 * LN; l++) {
+      if (l == li) v[l] = d << bs;
+      if (l == li + 1 && bs) v[l] = d >> (32 - bs);
+    }
+    u8 vb[8 * LN];
+    store_be<2 * LN>(vb, v, 8 * LN);
+    typename W::Nl km = W::bytes_mod_n(vb, 8 * LN);
+    u32 kn[LN];
+    W::Fn::to_plain(kn, km);
+    u32 kk[W::L], gx[W::L], gy[W::L];
+    ELL_UNROLL
+    for (int l = 0; l < W::L; l++) { kk[l] = l < LN ? kn[l] : 0u; gx[l] = W::C::gx_plain[l]; gy[l] = W::C::gy_plain[l]; }
+    store_be<W::L>(k + i * W::BYTES, kk, W::BYTES);
+    store_be<W::L>(xy + i * 2 * W::BYTES, gx, W::BYTES);
+    store_be<W::L>(xy + i * 2 * W::BYTES + W::BYTES, gy, W::BYTES);
+  }
+};
 template <class CV>
 struct FnNormalize {
   static constexpr const char* NAME = "normalize";
@@ -1671,32 +1711,28 @@ template <class CV>
 int Engine<BK>::ensure_comb() {
   typedef Work<CV> W;
   if (comb_[CV::ID]) return E_OK;
+  // Built by the engine itself: the variable-base kernel on the scalars d << (COMB_BITS w) and
+  // the generator, in slices of at most 2^20 entries (the 22-bit signed comb of the 256-bit
+  // curves has 25 M entries = 1.6 GB; a slice needs 1 GB of window-table scratch).
   const size_t n = W::COMB_ENTRIES;
   const int B = W::BYTES;
-  std::vector<u8> ks(n * B, 0), pts(n * 2 * B, 0);
-  u8 g[2 * 66];
-  {
-    u32 gx[W::L], gy[W::L];
-    for (int i = 0; i < W::L; i++) { gx[i] = W::C::gx_plain[i]; gy[i] = W::C::gy_plain[i]; }
-    store_be<W::L>(g, gx, B);
-    store_be<W::L>(g + B, gy, B);
-  }
-  for (int w = 0; w < W::COMB_W; w++)
-    for (int d = 1; d <= W::COMB_DIG; d++) {
-      size_t i = (size_t)w * W::COMB_DIG + (d - 1);
-      // d << (COMB_BITS*w), big-endian (COMB_BITS is 8 or 16: whole bytes)
-      int byte0 = w * (W::COMB_BITS / 8);
-      for (int bb = 0; bb < W::COMB_BITS / 8; bb++)
-        if (byte0 + bb < B) ks[i * B + (B - 1 - (byte0 + bb))] = (u8)(d >> (8 * bb));
-      memcpy(&pts[i * 2 * B], g, 2 * B);
-    }
+  const size_t slice = n < ((size_t)1 << 20) ? n : ((size_t)1 << 20);
   void* comb = bk.alloc(n * sizeof(typename W::A));
-  u8* dk = (u8*)bk.alloc(ks.size());
-  u8* dp = (u8*)bk.alloc(pts.size());
-  if (!comb || !dk || !dp) return fail(E_NOMEM, "comb table allocation failed");
-  bk.h2d(dk, ks.data(), ks.size());
-  bk.h2d(dp, pts.data(), pts.size());
-  int rc = mul_var_chunk<CV>(n, dk, dp, nullptr, nullptr, (typename W::A*)comb);
+  u8* dk = (u8*)bk.alloc(slice * B);
+  u8* dp = (u8*)bk.alloc(slice * 2 * B);
+  if (!comb || !dk || !dp) {
+    if (comb) bk.free_(comb);
+    if (dk) bk.free_(dk);
+    if (dp) bk.free_(dp);
+    return fail(E_NOMEM, "comb table allocation failed");
+  }
+  int rc = E_OK;
+  for (size_t first = 0; first < n && rc == E_OK; first += slice) {
+    const size_t m = n - first < slice ? n - first : slice;
+    FnCombGen<CV> g{m, first, dk, dp};
+    bk.launch(g, m);
+    rc = mul_var_chunk<CV>(m, dk, dp, nullptr, nullptr, (typename W::A*)comb + first);
+  }
   bk.sync();
   bk.free_(dk);
   bk.free_(dp);

@@ -290,60 +290,81 @@ struct Ladder {
     return acc;
   }
 
-  // fixed-base comb: acc + sum_w d_w * 2^(CB*w) * G with d_w the w-th CB-bit digit of k (CB = 8
-  // or 16); comb[w*(2^CB - 1) + d-1] = d * 2^(CB*w) * G (affine, field-internal form).  Zero
-  // digits sit the addition out (exec mask).  `inf` = acc is O, updated.
-  template <int LK, int W, int CB, bool WIDE = false>
+  // fixed-base comb: acc + sum_w d_w * 2^(CB*w) * G with d_w the w-th CB-bit digit of k;
+  // UNSIGNED (CB = 8): comb[w*(2^CB - 1) + d-1] = d * 2^(CB*w) * G;  SIGNED (the 256-bit curves,
+  // CB = 22): digits recoded on the fly into [-2^(CB-1), 2^(CB-1)] (a window above 2^(CB-1) takes
+  // its value minus 2^CB and carries one into the next), comb[w*2^(CB-1) + |d|-1] = |d| * 2^(CB*w) * G
+  // and y negated at lookup -- half the table per window bit, so wider windows for the same bytes.
+  // Entries are affine, field-internal form.  Zero digits sit the addition out (exec mask).
+  // `inf` = acc is O, updated.  WIDE: window w+1's entry is requested before window w's addition.
+  template <int LK, int W, int CB, bool WIDE = false, bool SIGNED = false>
   ELL_HD static J comb_add(J acc, bool& inf, const u32 (&k)[LK], const A* comb) {
     constexpr u32 MASK = (1u << CB) - 1u;
+    constexpr u32 HALF = 1u << (CB - 1);
+    constexpr u32 PER = SIGNED ? HALF : MASK;             // entries per window
     u32 kk[LK];
     bn_copy<LK>(kk, k);
-    if constexpr (WIDE || ELL_PREFETCH) {
-    // software-pipelined (see run_odd_w4): window w+1's entry is requested before window w's
-    // addition; a zero digit fetches the window's first entry and sits the addition out
-    auto digit = [&]() -> u32 {
-      u32 d = kk[0] & MASK;
+    u32 carry = 0;
+    // next digit -> (table index within the window, negate flag); d == 0 -> idx 0 with zero = true
+    auto digit = [&](u32& idx, bool& neg, bool& zero) {
+      u32 d = (kk[0] & MASK) + carry;
       ELL_UNROLL
       for (int i = 0; i < LK - 1; i++) kk[i] = (kk[i] >> CB) | (kk[i + 1] << (32 - CB));
       kk[LK - 1] >>= CB;
-      return d;
+      if (SIGNED) {
+        neg = d > HALF;
+        carry = neg ? 1u : 0u;
+        d = neg ? (MASK + 1u) - d : d;                     // |d| in [0, 2^(CB-1)]
+      } else {
+        neg = false;
+      }
+      zero = d == 0;
+      idx = zero ? 0u : d - 1u;
     };
-    u32 d = digit();
-    const A* e = comb + (d ? d - 1 : 0);
-    A q = *e;
-    ELL_NOUNROLL
-    for (int w = 0; w < W; w++) {
-      u32 dn = 0;
-      const A* en = comb;
-      A qn = q;
-      if (w + 1 < W) {
-        dn = digit();
-        en = comb + ((size_t)(w + 1) * MASK + (dn ? dn - 1 : 0));
-        qn = *en;
+    auto fetch = [&](const A* e, bool neg) -> A {
+      A q = *e;
+      if (SIGNED) q.y = cneg_y(q.y, neg);
+      return q;
+    };
+    if constexpr (WIDE || ELL_PREFETCH) {
+      u32 idx; bool neg, zero;
+      digit(idx, neg, zero);
+      const A* e = comb + idx;
+      A q = *e;
+      ELL_NOUNROLL
+      for (int w = 0; w < W; w++) {
+        u32 idxn = 0; bool negn = false, zeron = true;
+        const A* en = comb;
+        A qn = q;
+        if (w + 1 < W) {
+          digit(idxn, negn, zeron);
+          en = comb + ((size_t)(w + 1) * PER + idxn);
+          qn = *en;
+        }
+        if (!zero) {
+          if (SIGNED) q.y = cneg_y(q.y, neg);
+          acc = G::add_mixed_lean(acc, q, inf, [&]() { return fetch(e, neg); });
+        }
+        idx = idxn; neg = negn; zero = zeron; e = en; q = qn;
       }
-      if (d != 0) acc = G::add_mixed_lean(acc, q, inf, [&]() { return *e; });
-      d = dn; e = en; q = qn;
-    }
-    return acc;
+      return acc;
     } else {
-    ELL_NOUNROLL
-    for (int w = 0; w < W; w++) {
-      u32 d = kk[0] & MASK;
-      ELL_UNROLL
-      for (int i = 0; i < LK - 1; i++) kk[i] = (kk[i] >> CB) | (kk[i + 1] << (32 - CB));
-      kk[LK - 1] >>= CB;
-      if (d != 0) {
-        const A* e = comb + ((size_t)w * MASK + (d - 1));
-        acc = G::add_mixed_lean(acc, *e, inf, [&]() { return *e; });
+      ELL_NOUNROLL
+      for (int w = 0; w < W; w++) {
+        u32 idx; bool neg, zero;
+        digit(idx, neg, zero);
+        if (!zero) {
+          const A* e = comb + ((size_t)w * PER + idx);
+          acc = G::add_mixed_lean(acc, fetch(e, neg), inf, [&]() { return fetch(e, neg); });
+        }
       }
-    }
-    return acc;
+      return acc;
     }
   }
-  template <int LK, int W, int CB>
+  template <int LK, int W, int CB, bool SIGNED = false>
   ELL_HD static J comb_mul(const u32 (&k)[LK], const A* comb) {
     bool inf = true;
-    return comb_add<LK, W, CB>(G::infinity(), inf, k, comb);
+    return comb_add<LK, W, CB, false, SIGNED>(G::infinity(), inf, k, comb);
   }
 };
 

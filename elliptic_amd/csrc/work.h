@@ -27,6 +27,21 @@
 #ifndef ELL_COMB_BITS_256
 #define ELL_COMB_BITS_256 16
 #endif
+// Short-curve comb of the 256-bit curves: SIGNED windows of this many bits (digits in
+// [-2^(c-1), 2^(c-1)], table of the positive multiples, y negated at lookup).  22 bits: 12 windows
+// x 2^21 affine entries = 1.6 GB per curve in use (of 288 GB), 12 mixed additions per k*G instead
+// of the 16 of round 2's unsigned 16-bit comb (67 MB).  The CPU unit-test build (8 above) keeps
+// its value.
+#ifndef ELL_COMB_BITS_SHORT256
+#if ELL_COMB_BITS_256 == 16
+#define ELL_COMB_BITS_SHORT256 22
+#else
+#define ELL_COMB_BITS_SHORT256 ELL_COMB_BITS_256
+#endif
+#endif
+#ifndef ELL_COMB_SIGNED_256
+#define ELL_COMB_SIGNED_256 1
+#endif
 // 1 (default) = lambda*P entries are computed at lookup (x * beta) instead of being stored as a
 // second window table: measured on one box (round 2, gpurun_out/r02d) ecdsa_main 8.61 -> 8.52 ms,
 // FETCH_SIZE 6.03 -> 4.76 GB and WRITE_SIZE 2.20 -> 1.53 GB per 2^20 verifies (-24 % bytes)
@@ -67,9 +82,11 @@ struct Work {
   // fixed-base comb: COMB_BITS-bit unsigned windows, table of d * 2^(COMB_BITS*w) * G.
   // 16-bit windows for the 256-bit curves (16 adds per k*G, 67 MB table that lives in
   // MALL/HBM and is gathered 64 B at a time); 8-bit windows otherwise.
-  static constexpr int COMB_BITS = (L == 8) ? ELL_COMB_BITS_256 : 8;
-  static constexpr int COMB_W = (8 * BYTES + COMB_BITS - 1) / COMB_BITS;
-  static constexpr int COMB_DIG = (1 << COMB_BITS) - 1;    // non-zero digits per window
+  static constexpr int COMB_BITS = (L == 8) ? ELL_COMB_BITS_SHORT256 : 8;
+  static constexpr bool COMB_SIGNED = (L == 8) && ELL_COMB_SIGNED_256;
+  // signed windows: one more bit for the recoding's carry out of the top data window
+  static constexpr int COMB_W = (8 * BYTES + (COMB_SIGNED ? 1 : 0) + COMB_BITS - 1) / COMB_BITS;
+  static constexpr int COMB_DIG = COMB_SIGNED ? (1 << (COMB_BITS - 1)) : (1 << COMB_BITS) - 1;   // table entries per window
   static constexpr size_t COMB_ENTRIES = (size_t)COMB_W * COMB_DIG;
 
   // ---- I/O helpers -------------------------------------------------------
@@ -273,7 +290,7 @@ struct Work {
     asm volatile("" ::: "memory");                 // k1 is loaded after the ladder (see ecdsa_main)
 #endif
     load_be<L>(k1, k1s + i * BYTES, BYTES);
-    J r = LD::template comb_add<L, COMB_W, COMB_BITS>(b, inf, k1, comb);
+    J r = LD::template comb_add<L, COMB_W, COMB_BITS, false, COMB_SIGNED>(b, inf, k1, comb);
     store_jac(jac, n, i, r);
   }
 
@@ -299,7 +316,7 @@ struct Work {
   ELL_HD static void mul_fixed(size_t i, size_t n, const u8* ks, const A* comb, u32* jac) {
     u32 k[L];
     load_be<L>(k, ks + i * BYTES, BYTES);
-    J r = LD::template comb_mul<L, COMB_W, COMB_BITS>(k, comb);
+    J r = LD::template comb_mul<L, COMB_W, COMB_BITS, COMB_SIGNED>(k, comb);
     store_jac(jac, n, i, r);
   }
 
@@ -877,7 +894,7 @@ struct Work {
     load_nonce(k, nonces + i * NBYTES);
     ELL_UNROLL
     for (int l = 0; l < L; l++) kk[l] = l < LN ? k[l] : 0u;
-    J r = LD::template comb_mul<L, COMB_W, COMB_BITS>(kk, comb);
+    J r = LD::template comb_mul<L, COMB_W, COMB_BITS, COMB_SIGNED>(kk, comb);
     store_jac(jac, n, i, r);
   }
   // pass B: thread t finishes items t, t+T, ...: r = x mod n, s = k^-1 (z + r d) mod n with
@@ -991,7 +1008,7 @@ struct Work {
 #endif
     ELL_UNROLL
     for (int l = 0; l < L; l++) u1[l] = l < LN ? u12[(size_t)(0 * LN + l) * n + i] : 0u;
-    J p = LD::template comb_add<L, COMB_W, COMB_BITS, WIDE>(b, inf, u1, comb);
+    J p = LD::template comb_add<L, COMB_W, COMB_BITS, WIDE, COMB_SIGNED>(b, inf, u1, comb);
 #if ELL_LATE_LOADS && defined(__HIP_DEVICE_COMPILE__)
     if constexpr (!WIDE) asm volatile("" ::: "memory");
 #endif
