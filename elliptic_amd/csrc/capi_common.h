@@ -139,6 +139,13 @@ void ellgpu_ctx_destroy(ellgpu_ctx* ctx) {
 }
 int ellgpu_ctx_synchronize(ellgpu_ctx* ctx) {
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  if (!ctx->members.empty()) {                       // a group: every member's device
+    for (ellgpu_ctx* m : ctx->members) {
+      int rc = ellgpu_ctx_synchronize(m);
+      if (rc) return rc;
+    }
+    return ELLGPU_OK;
+  }
   return finish(ctx, ctx->eng->bk.sync());
 }
 void* ellgpu_ctx_stream(ellgpu_ctx* ctx) {
@@ -147,6 +154,14 @@ void* ellgpu_ctx_stream(ellgpu_ctx* ctx) {
 }
 int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n) {
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  if (!ctx->members.empty()) {
+    // a group: every member gets its shard's worth (tables and scratch are per device), so that
+    // the first sharded call does not allocate and build tables inside its worker threads
+    const size_t m = ctx->members.size();
+    return group_shard(ctx, m, [=](ellgpu_ctx* mem, size_t lo, size_t) {
+      return ellgpu_ctx_reserve(mem, curve, (n * (lo + 1) / m) - (n * lo / m));
+    });
+  }
   ctx->eng->bk.use_stream(nullptr);
   return finish(ctx, ctx->eng->reserve(curve, n));
 }
@@ -155,13 +170,21 @@ static int define_custom(ellgpu_ctx* ctx, int edwards, const uint8_t* p, const u
                          int* out_curve) {
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
   if (!ctx->members.empty()) {
+    // all or nothing: a member that cannot take the curve (table full), or would give it another
+    // id than member 0 (curves were defined on a member directly), is found BEFORE anything is
+    // registered -- the engine dedups identical parameters, so the probe is the definition's own
+    // first half (Engine::custom_slot_for)
     int id = -1;
+    for (size_t i = 0; i < ctx->members.size(); i++) {
+      int mid = ctx->members[i]->eng->custom_slot_for(edwards, p, a, b);
+      if (mid < 0) return set_err(ELLGPU_E_UNSUPPORTED, "user-defined curve table of a group member is full");
+      if (i && mid != id) return set_err(ELLGPU_E_ARG, "group members disagree on the curve id (curves were defined on a member directly)");
+      id = mid;
+    }
     for (size_t i = 0; i < ctx->members.size(); i++) {
       int mid = -1;
       int rc = define_custom(ctx->members[i], edwards, p, a, b, &mid);
-      if (rc) return rc;
-      if (i && mid != id) return set_err(ELLGPU_E_ARG, "group members disagree on the curve id (curves were defined on a member directly)");
-      id = mid;
+      if (rc) return rc;                             // (parameter errors are the same on every member: member 0 fails first)
     }
     if (out_curve) *out_curve = id;
     return ELLGPU_OK;
@@ -199,6 +222,7 @@ int ellgpu_mul_fixed(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, uin
   if (ctx && !ctx->members.empty()) {
     size_t B, NB;
     if (curve_widths(curve, B, NB)) return ELLGPU_E_ARG;
+    if (n && (!k || !out_xy)) return set_err(ELLGPU_E_ARG, "null buffer");
     return group_shard(ctx, n, [=](ellgpu_ctx* m, size_t lo, size_t hi) {
       return ellgpu_mul_fixed(m, curve, hi - lo, k + lo * B, out_xy + lo * 2 * B, out_inf ? out_inf + lo : nullptr);
     });
@@ -211,7 +235,7 @@ int ellgpu_mul_var(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, const
   if (ctx && !ctx->members.empty()) {
     size_t B, NB;
     if (curve_widths(curve, B, NB)) return ELLGPU_E_ARG;
-    if (!in_xy) return set_err(ELLGPU_E_ARG, "null point buffer");
+    if (n && (!k || !in_xy || !out_xy)) return set_err(ELLGPU_E_ARG, "null buffer");
     return group_shard(ctx, n, [=](ellgpu_ctx* m, size_t lo, size_t hi) {
       return ellgpu_mul_var(m, curve, hi - lo, k + lo * B, in_xy + lo * 2 * B, out_xy + lo * 2 * B,
                             out_inf ? out_inf + lo : nullptr);
@@ -225,6 +249,7 @@ int ellgpu_mul_add2(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1, con
   if (ctx && !ctx->members.empty()) {
     size_t B, NB;
     if (curve_widths(curve, B, NB)) return ELLGPU_E_ARG;
+    if (n && (!k1 || !k2 || !p2_xy || !out_xy)) return set_err(ELLGPU_E_ARG, "null buffer");
     return group_shard(ctx, n, [=](ellgpu_ctx* m, size_t lo, size_t hi) {
       return ellgpu_mul_add2(m, curve, hi - lo, k1 + lo * B, p1_xy ? p1_xy + lo * 2 * B : nullptr, k2 + lo * B,
                              p2_xy + lo * 2 * B, out_xy + lo * 2 * B, out_inf ? out_inf + lo : nullptr);
@@ -239,6 +264,7 @@ int ellgpu_ecdsa_verify(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* has
   if (ctx && !ctx->members.empty()) {
     size_t B, NB;
     if (curve_widths(curve, B, NB)) return ELLGPU_E_ARG;
+    if (n && (!hash || !r || !s || !pub_xy || !out_ok)) return set_err(ELLGPU_E_ARG, "null buffer");
     return group_shard(ctx, n, [=](ellgpu_ctx* m, size_t lo, size_t hi) {
       return ellgpu_ecdsa_verify(m, curve, hi - lo, hash + lo * (size_t)hash_len, hash_len, msg_bits, r + lo * NB,
                                  s + lo * NB, pub_xy + lo * 2 * B, out_ok + lo);

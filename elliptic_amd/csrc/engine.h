@@ -778,42 +778,60 @@ class Engine {
     *out_curve = CURVE_CUSTOM0 + (int)custom_.size() - 1;
     return E_OK;
   }
-  int define_short(const u8* p_be, const u8* a_be, const u8* b_be, int* out_curve) {
-    if (!p_be || !a_be || !b_be || !out_curve) return fail(E_ARG, "null pointer");
-    RtField f;
+  // parameter block of a user-defined curve (edwards = 0: short Weierstrass, b; 1: Edwards, d)
+  int build_custom(int edwards, const u8* p_be, const u8* a_be, const u8* bd_be, RtField& f) {
+    if (!p_be || !a_be || !bd_be) return fail(E_ARG, "null pointer");
     int rc = rt_field_init(f, p_be);
     if (rc) return rc;
     u32 a[8], b[8];
     load_be<8>(a, a_be, 32);
-    load_be<8>(b, b_be, 32);
+    load_be<8>(b, bd_be, 32);
     rt_to_mont(f, f.a_m, a);
-    rt_to_mont(f, f.b_m, b);
-    u32 three[8], m3[8];
-    bn_zero<8>(three);
-    three[0] = 3;
-    bn_sub<8>(m3, f.p, three);
-    rt_to_mont(f, m3, m3);
-    f.a_kind = bn_is_zero<8>(f.a_m) ? 0u : (bn_eq<8>(f.a_m, m3) ? 3u : 1u);
-    f.kind = 0;
-    return register_custom(f, out_curve);
+    if (!edwards) {
+      rt_to_mont(f, f.b_m, b);
+      u32 three[8], m3[8];
+      bn_zero<8>(three);
+      three[0] = 3;
+      bn_sub<8>(m3, f.p, three);
+      rt_to_mont(f, m3, m3);
+      f.a_kind = bn_is_zero<8>(f.a_m) ? 0u : (bn_eq<8>(f.a_m, m3) ? 3u : 1u);
+      f.kind = 0;
+    } else {
+      rt_to_mont(f, f.d_m, b);
+      if (bn_is_zero<8>(f.a_m) || bn_is_zero<8>(f.d_m) || bn_eq<8>(f.a_m, f.d_m))
+        return fail(E_ARG, "user-defined Edwards curve: a and d must be non-zero and distinct");
+      f.kind = 1;
+    }
+    return E_OK;
+  }
+  int define_short(const u8* p_be, const u8* a_be, const u8* b_be, int* out_curve) {
+    if (!out_curve) return fail(E_ARG, "null pointer");
+    RtField f;
+    int rc = build_custom(0, p_be, a_be, b_be, f);
+    return rc ? rc : register_custom(f, out_curve);
   }
   // `new elliptic.curve.edwards({p, a, c: 1, d})` (edwards.js:11-31) with parameters that are not
   // ed25519's: a x^2 + y^2 = 1 + d x^2 y^2 over an odd prime p < 2^256; Point#mul, mulAdd and
   // Point#add run on the device in projective coordinates (edcustom.h).
   int define_edwards(const u8* p_be, const u8* a_be, const u8* d_be, int* out_curve) {
-    if (!p_be || !a_be || !d_be || !out_curve) return fail(E_ARG, "null pointer");
+    if (!out_curve) return fail(E_ARG, "null pointer");
     RtField f;
-    int rc = rt_field_init(f, p_be);
-    if (rc) return rc;
-    u32 a[8], d[8];
-    load_be<8>(a, a_be, 32);
-    load_be<8>(d, d_be, 32);
-    rt_to_mont(f, f.a_m, a);
-    rt_to_mont(f, f.d_m, d);
-    if (bn_is_zero<8>(f.a_m) || bn_is_zero<8>(f.d_m) || bn_eq<8>(f.a_m, f.d_m))
-      return fail(E_ARG, "user-defined Edwards curve: a and d must be non-zero and distinct");
-    f.kind = 1;
-    return register_custom(f, out_curve);
+    int rc = build_custom(1, p_be, a_be, d_be, f);
+    return rc ? rc : register_custom(f, out_curve);
+  }
+  // the id a definition WOULD get (the existing one for parameters already registered, else the
+  // next free one), -1 when the table is full; registers nothing.  Invalid parameters report the
+  // next free id: the definition itself then fails with its own message, on the first member.
+  int custom_slot_for(int edwards, const u8* p_be, const u8* a_be, const u8* bd_be) {
+    RtField f;
+    std::string keep = err;
+    int rc = build_custom(edwards, p_be, a_be, bd_be, f);
+    err = keep;
+    if (rc == E_OK)
+      for (size_t i = 0; i < custom_.size(); i++)
+        if (memcmp(&custom_[i], &f, sizeof(f)) == 0) return CURVE_CUSTOM0 + (int)i;
+    if ((int)custom_.size() >= CURVE_CUSTOM_MAX) return rc == E_OK ? -1 : CURVE_CUSTOM0 + (int)custom_.size();
+    return CURVE_CUSTOM0 + (int)custom_.size();
   }
   static size_t pipe_step_default() {
     const char* e = getenv("ELLGPU_PIPE_STEP");          // developer override

@@ -8,7 +8,9 @@
 //           kernels (inst.hip group 16), uploaded on the call's stream before the launches;
 //           scalar loads, so the limbs of p sit in SGPRs like the presets' literals do
 //   host    (tests/hostsim) a plain global.
-// One block per process: custom-curve calls are serialised (Engine::custom_guard).
+// One block per DEVICE: a call on a user-defined curve takes that device's lock, uploads the
+// curve's block, and waits for its own device work before releasing the lock (Engine::CustomScope,
+// engine.h) -- such calls are synchronous and serialised per device, whatever stream they name.
 #pragma once
 
 #include "fp.h"

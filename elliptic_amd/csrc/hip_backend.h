@@ -72,12 +72,14 @@ struct HipBackend {
   // on another stream than the previous one first waits (on the device) for the event the
   // previous call recorded after its last launch.  Host-buffer calls synchronise before they
   // return, so nothing is left in flight behind them.
+  bool host_synced = false;        // the current call has synchronised `cur` on the host
   hipStream_t inflight = nullptr;  // stream of the last call that may still be running
   hipEvent_t inflight_done = nullptr;
   void use_stream(void* s) {
     (void)hipSetDevice(device);
     cur = s ? (hipStream_t)s : own;
     last = 0;
+    host_synced = false;
 #ifndef ELL_NO_STREAM_ORDER          // (test switch: shows that test_dev_calls_on_alternating_streams fails without it)
     if (inflight && inflight != cur && inflight_done) note(hipStreamWaitEvent(cur, inflight_done, 0));
 #endif
@@ -87,15 +89,20 @@ struct HipBackend {
     if (async && inflight_done) {
       note(hipEventRecord(inflight_done, cur));
       inflight = cur;
-    } else {
+    } else if (host_synced) {
+      // the call waited for `cur` on the host, and `cur` had been ordered after whatever was in
+      // flight (use_stream): nothing is left running
       inflight = nullptr;
     }
+    // else: a call that neither launched asynchronously nor synchronised (ellgpu_ctx_reserve with
+    // nothing to grow): what was in flight before it still is -- keep its stream and event
   }
   // everything this context may have in flight, on whatever stream (before freeing scratch)
   void sync_all() {
     if (inflight) note(hipStreamSynchronize(inflight));
     inflight = nullptr;
     note(hipStreamSynchronize(cur ? cur : own));
+    host_synced = true;
   }
   int device_index() const { return device; }
   void* own_stream() const { return (void*)own; }
@@ -118,6 +125,7 @@ struct HipBackend {
   }
   int sync() {
     note(hipStreamSynchronize(cur ? cur : own));
+    host_synced = true;
     return last ? E_HIP : E_OK;
   }
   // ---- copy stream for the pipelined host-buffer entry points (Engine::pipelined) ----
@@ -158,6 +166,7 @@ struct HipBackend {
     note(hipStreamSynchronize(copy_out));
     note(hipStreamSynchronize(own2));
     note(hipStreamSynchronize(own));
+    host_synced = true;                               // `own` had been ordered after whatever was in flight
     return last ? E_HIP : E_OK;
   }
   template <class Fn>

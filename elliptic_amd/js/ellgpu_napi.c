@@ -765,6 +765,12 @@ static void job_complete(napi_env env, napi_status status, void* data) {
   napi_delete_async_work(env, j->work);
   free(j->out0); free(j->out1); free(j->out2); free(j->out3); free(j);
 }
+/* every early exit of fn_call_async: release the references taken so far (the context external
+ * first of all -- a leaked reference keeps ctx_finalize / ellgpu_ctx_destroy from ever running) */
+static void drop_job_refs(napi_env env, async_job* j) {
+  for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
+  j->nrefs = 0;
+}
 static napi_value fn_call_async(napi_env env, napi_callback_info info) {
   if (!need_lib(env)) return NULL;
   size_t argc = 11; napi_value argv[11];
@@ -782,14 +788,14 @@ static napi_value fn_call_async(napi_env env, napi_callback_info info) {
   napi_get_value_int32(env, argv[2], &curve); napi_get_value_int32(env, argv[3], &hl); napi_get_value_int32(env, argv[4], &mb);
   j->op = op; j->curve = op == 4 ? 7 : curve; j->hash_len = hl; j->msg_bits = mb;
   j->B = L.field_bytes(j->curve); j->NB = L.order_bytes(j->curve);
-  if (op < 0 || op > 8 || j->B <= 0) { free(j); THROW(env, "callAsync: bad op / curve"); }
+  if (op < 0 || op > 8 || j->B <= 0) { drop_job_refs(env, j); free(j); THROW(env, "callAsync: bad op / curve"); }
   int32_t i0 = 0, i1 = 0;
   if (argc > 9) napi_get_value_int32(env, argv[9], &i0);
   if (argc > 10) napi_get_value_int32(env, argv[10], &i1);
   j->i0 = i0; j->i1 = i1;
   size_t len[4] = {0, 0, 0, 0};
   for (int i = 0; i < 4; i++) {
-    if (!get_buf(env, argv[5 + i], &j->in[i], &len[i], 1)) { free(j); return NULL; }
+    if (!get_buf(env, argv[5 + i], &j->in[i], &len[i], 1)) { drop_job_refs(env, j); free(j); return NULL; }
     if (j->in[i]) napi_create_reference(env, argv[5 + i], 1, &j->refs[j->nrefs++]);   /* keep alive */
   }
   size_t B = (size_t)j->B, NB = (size_t)j->NB;

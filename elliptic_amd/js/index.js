@@ -359,10 +359,44 @@ function install(elliptic, options) {
   // run-time prime (<= 256 bits), arbitrary a (the generic `_dbl` / `dblp` of short.js:802-830,
   // 605-654), no fixed-base table.  options.customCurves === false keeps such curves on the
   // reference's own code, as do primes wider than 256 bits and a seventeenth distinct curve.
+  // Miller-Rabin to twelve prime bases: the device inverts by Fermat's a^(p-2), which equals the
+  // reference's extended-Euclid BN#invm only for a prime modulus -- a composite `p` (which the
+  // reference accepts) stays on the reference's own code
+  function probablyPrime(p) {
+    var small = [2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37];
+    for (var i = 0; i < small.length; i++) {
+      if (p.cmpn(small[i]) === 0) return true;
+      if (p.modn(small[i]) === 0) return false;
+    }
+    var red = BN.red(p);
+    var pm1 = p.subn(1);
+    var s = 0;
+    var dd = pm1.clone();
+    while (dd.isEven()) { dd = dd.shrn(1); s++; }
+    var one = new BN(1).toRed(red);
+    var m1 = pm1.toRed(red);
+    for (i = 0; i < small.length; i++) {
+      var x = new BN(small[i]).toRed(red).redPow(dd);
+      if (x.cmp(one) === 0 || x.cmp(m1) === 0) continue;
+      var composite = true;
+      for (var r = 1; r < s; r++) {
+        x = x.redSqr();
+        if (x.cmp(m1) === 0) { composite = false; break; }
+      }
+      if (composite) return false;
+    }
+    return true;
+  }
   function customDomain(curve) {
     if (curve._ellgpuCustom !== undefined) return curve._ellgpuCustom;
     var d = null;
     if (options && options.customCurves === false) return null;
+    if (curve.p && curve.p.bitLength() <= 256 && curve.p.isOdd() && curve.p.cmpn(3) > 0 &&
+        !probablyPrime(curve.p)) {
+      Object.defineProperty(curve, '_ellgpuCustom', { value: null, enumerable: false,
+        writable: true });
+      return null;
+    }
     if (curve.type === 'short' && curve.a && curve.b && curve.p.bitLength() <= 256 &&
         curve.p.isOdd() && curve.p.cmpn(3) > 0) {
       try {

@@ -48,6 +48,11 @@
  *     hipStream_t (passed as void*, NULL = the context's own non-blocking stream, which
  *     ellgpu_ctx_stream returns so that a caller can order other streams against it) and return
  *     without synchronising; outputs are valid once that stream is.
+ *     EXCEPTION: on a user-defined curve (ellgpu_curve_define_short / _edwards) a *_dev call is
+ *     SYNCHRONOUS: the curve's parameter block lives in the device's constant memory, one block
+ *     per device, so such a call takes a per-device lock, uploads the block, and waits for its
+ *     own device work before the lock is released -- it blocks the host until its stream has
+ *     drained, and serialises against other contexts' user-defined-curve calls on that device.
  */
 #ifndef ELLGPU_H
 #define ELLGPU_H
@@ -121,7 +126,11 @@ void* ellgpu_ctx_stream(ellgpu_ctx* ctx);
  * jmulAdd and Point#add with the generic-a doubling of JPoint#_dbl / dblp (short.js:802-830,
  * 605-654) on the device.  Every other entry point answers ELLGPU_E_UNSUPPORTED for it (the
  * reference's own JavaScript keeps serving those).  The primality of p is not checked, as the
- * reference does not check it either. */
+ * reference does not check it either -- but field inversion here is Fermat's a^(p-2), so for a
+ * composite p results differ from the reference's (its BN#invm is an extended Euclid); callers
+ * that cannot vouch for p keep such curves on the reference (the JS layer runs a Miller-Rabin
+ * test before it registers a curve).  On a group, either every member registers the curve or
+ * none does. */
 #define ELLGPU_CURVE_CUSTOM0 16
 int ellgpu_curve_define_short(ellgpu_ctx* ctx, const uint8_t* p, const uint8_t* a, const uint8_t* b,
                               int* out_curve);
