@@ -403,6 +403,13 @@ ELL_HD bool abs9(u32 (&r)[9]) {
   return neg;
 }
 
+// ODD = true: both halves come back odd.  (k1, k2) may be moved by any lattice vector
+// (a_i, b_i) -- a_i + b_i * lambda == 0 (mod n) -- and the basis' parities, (a1, b1) = (1, 1) and
+// (a2, b2) = (0, 1) mod 2, span all four cases: one conditional add / subtract of each vector fixes
+// both parities, |k1|, |k2| stay below 2^130 (the 33-window odd recoding takes < 2^132), and the
+// ladder needs no "k was even: subtract P once more" additions at its end (two mixed additions
+// that every wave executed, 1 % of a verify).  Signs are chosen towards zero.
+template <bool ODD = false>
 ELL_HD void glv_split(const u32 (&k)[8], u32 (&k1)[5], bool& neg1, u32 (&k2)[5], bool& neg2) {
   typedef consts::SECP256K1_C C;
   u32 g1[8], g2[8], a1[4], mb1[4], a2[5], b2[4];
@@ -436,11 +443,8 @@ ELL_HD void glv_split(const u32 (&k)[8], u32 (&k1)[5], bool& neg1, u32 (&k2)[5],
       br = (u32)(t >> 63);
     }
   }
-  neg1 = abs9(r);
-  ELL_UNROLL
-  for (int i = 0; i < 5; i++) k1[i] = r[i];
   // k2 = -(c1*b1 + c2*b2) = c1*|b1| - c2*b2
-  u32 q1[8], q2[8];
+  u32 q1[8], q2[8], r2[9];
   bn_mul_wide<4, 4>(q1, c1, mb1);
   bn_mul_wide<4, 4>(q2, c2, b2);
   {
@@ -448,13 +452,40 @@ ELL_HD void glv_split(const u32 (&k)[8], u32 (&k1)[5], bool& neg1, u32 (&k2)[5],
     ELL_UNROLL
     for (int i = 0; i < 9; i++) {
       u64 t = (u64)(i < 8 ? q1[i] : 0u) - (i < 8 ? q2[i] : 0u) - br;
-      r[i] = (u32)t;
+      r2[i] = (u32)t;
       br = (u32)(t >> 63);
     }
   }
-  neg2 = abs9(r);
+  if constexpr (ODD) {
+    // 9-limb two's complement x += sign * v (v >= 0, nv limbs), sign = +1 / -1, only where `on`
+    auto addv = [](u32 (&x)[9], const u32* v, int nv, bool minus, bool on) {
+      u64 c = (on && minus) ? 1 : 0;                      // x - v = x + ~v + 1 over all nine limbs
+      ELL_UNROLL
+      for (int i = 0; i < 9; i++) {
+        const u32 vi = i < nv ? v[i] : 0u;
+        const u32 w = on ? (minus ? ~vi : vi) : 0u;
+        c += (u64)x[i] + w;
+        x[i] = (u32)c;
+        c >>= 32;
+      }
+    };
+    // v1 = (a1, -|b1|): fixes k1's parity; towards zero in its large component, k2
+    const bool x1 = (r[0] & 1u) == 0;
+    const bool k2pos = (r2[8] >> 31) == 0;
+    addv(r, a1, 4, !k2pos, x1);                           // k2 > 0: + v1 (k2 shrinks by |b1|), else - v1
+    addv(r2, mb1, 4, k2pos, x1);
+    // v2 = (a2, b2): k2's parity (a2 is even); towards zero in its large component, k1
+    const bool x2 = (r2[0] & 1u) == 0;
+    const bool k1pos = (r[8] >> 31) == 0;
+    addv(r, a2, 5, k1pos, x2);                            // k1 > 0: - v2, else + v2
+    addv(r2, b2, 4, k1pos, x2);
+  }
+  neg1 = abs9(r);
   ELL_UNROLL
-  for (int i = 0; i < 5; i++) k2[i] = r[i];
+  for (int i = 0; i < 5; i++) k1[i] = r[i];
+  neg2 = abs9(r2);
+  ELL_UNROLL
+  for (int i = 0; i < 5; i++) k2[i] = r2[i];
 }
 
 }  // namespace ell

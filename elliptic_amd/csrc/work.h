@@ -174,10 +174,8 @@ struct Work {
     if constexpr (ENDO) {
       u32 k1[5], k2[5];
       bool n1, n2;
-      glv_split(k, k1, n1, k2, n2);
-      u32 evenmask = ((k1[0] & 1u) ? 0u : 1u) | ((k2[0] & 1u) ? 0u : 2u);
-      k1[0] |= 1u;                                  // k even -> k + 1, P subtracted at the end
-      k2[0] |= 1u;
+      glv_split<true>(k, k1, n1, k2, n2);           // both halves odd: no correction at the end
+      const u32 evenmask = 0u;
       recode_odd_w4<5, NNIB>(k1, ds, 0, 2);
       recode_odd_w4<5, NNIB>(k2, ds, 1, 2);
       u32 negmask = (n1 ? 1u : 0u) | (n2 ? 2u : 0u);

@@ -160,6 +160,15 @@ void hs_glv_split(const u32* k, u32* k1, int* neg1, u32* k2, int* neg2) {
   for (int i = 0; i < 5; i++) { k1[i] = a[i]; k2[i] = b[i]; }
   *neg1 = n1; *neg2 = n2;
 }
+// the same with both halves made odd by lattice vectors (what the secp256k1 ladders use)
+void hs_glv_split_odd(const u32* k, u32* k1, int* neg1, u32* k2, int* neg2) {
+  u32 kk[8], a[5], b[5];
+  bool n1, n2;
+  for (int i = 0; i < 8; i++) kk[i] = k[i];
+  glv_split<true>(kk, a, n1, b, n2);
+  for (int i = 0; i < 5; i++) { k1[i] = a[i]; k2[i] = b[i]; }
+  *neg1 = n1; *neg2 = n2;
+}
 // signed 4-bit recoding probe: NNIB = 64 with carry window (65 digits)
 void hs_recode64(const u32* k, signed char* digits) {
   u32 kk[8];

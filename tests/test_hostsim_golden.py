@@ -185,6 +185,37 @@ def test_glv_split(hs):
     assert worst <= 129, worst
 
 
+def test_glv_split_odd(hs):
+    """glv_split<true>: the halves the secp256k1 ladders recode -- both odd (made so with the
+    lattice vectors, not with a +1 that a later addition has to undo), still k1 + k2 lambda == k,
+    and below 2^130 (the 33-window odd recoding takes < 2^132)"""
+    cur = O.get_curve("secp256k1", False)
+    lam, n = cur.endo["lambda"], cur.n
+    rnd = random.Random(6)
+    ks = [0, 1, 2, 3, n - 1, n, n + 1, 2 ** 256 - 1, 2 ** 256 - 2, lam, lam + 1, lam - 1, n - lam, 2 ** 128, 2 ** 255,
+          2 ** 129, 2 ** 129 + 1]
+    ks += [rnd.getrandbits(256) for _ in range(6000)]
+    ks += [rnd.getrandbits(rnd.randrange(1, 257)) for _ in range(2000)]
+    worst = 0
+    seen = set()
+    for k in ks:
+        k1 = (ctypes.c_uint32 * 5)()
+        k2 = (ctypes.c_uint32 * 5)()
+        n1, n2 = ctypes.c_int(), ctypes.c_int()
+        hs.hs_glv_split_odd(_limbs(k, 8), k1, ctypes.byref(n1), k2, ctypes.byref(n2))
+        a, b = _val(k1), _val(k2)
+        assert a & 1 and b & 1, hex(k)
+        if n1.value:
+            a = -a
+        if n2.value:
+            b = -b
+        assert (a + b * lam - k) % n == 0, hex(k)
+        worst = max(worst, abs(a).bit_length(), abs(b).bit_length())
+        seen.add((n1.value, n2.value))
+    assert worst <= 130, worst
+    assert len(seen) == 4                      # every sign combination occurs
+
+
 def test_recode_w4(hs):
     rnd = random.Random(9)
     for k in [0, 1, 7, 8, 9, 2 ** 256 - 1, 2 ** 255, 0x8888 << 240] + [rnd.getrandbits(256) for _ in range(300)]:

@@ -1,12 +1,8 @@
-O=gpurun_out/r03j; mkdir -p $O
-( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=8 ) > $O/pytest_gpu.log 2>&1; tail -16 $O/pytest_gpu.log
-python - <<'PY' > gpurun_out/r03j/comb_build_time.txt 2>&1
-import time, numpy as np, elliptic_amd
-ctx = elliptic_amd.Context(0)
-for curve in ("secp256k1", "p256", "p192", "p384"):
-    B = elliptic_amd.FIELD_BYTES[curve]
-    k = np.ones((64, B), np.uint8)
-    t0 = time.perf_counter(); ctx.mul_fixed(curve, k); t1 = time.perf_counter(); ctx.mul_fixed(curve, k); t2 = time.perf_counter()
-    print(curve, "first mul_fixed (builds the comb): %.3f s, second: %.4f s" % (t1 - t0, t2 - t1))
+O=gpurun_out/r03k; mkdir -p $O
+python tools/ab_variants.py ab_libs/base.so ab_libs/glvodd.so --reps=30 > $O/glvodd_ab.jsonl 2> $O/ab.err
+python - <<'PY'
+import json
+for l in open('gpurun_out/r03k/glvodd_ab.jsonl'):
+    d=json.loads(l)
+    print({k:d[k] for k in d if k in ('lib','mask_ok','ecdsa_main_ms','mul_var_same','mul_fixed_same','mul_fixed_kernel_ms','mul_var_kernel_ms','error')})
 PY
-cat gpurun_out/r03j/comb_build_time.txt
