@@ -25,6 +25,11 @@
 #ifndef ELL_SOLINAS_CHAIN
 #define ELL_SOLINAS_CHAIN 1
 #endif
+// Ladder::build_table_odd8: 1 = the odd multiples are chained with co-Z additions (4M + 2S each),
+// 0 = with mixed additions (8M + 3S)
+#ifndef ELL_COZ_TABLE
+#define ELL_COZ_TABLE 1
+#endif
 #ifndef ELL_P224_TS_WINDOW
 #define ELL_P224_TS_WINDOW 1      // p224 square root: windowed Tonelli-Shanks (fp.h)
 #endif

@@ -158,14 +158,40 @@ struct Ladder {
     t.Y = F::mul(p.y, zd3);
     t.Z = F::one();
     tbl[0].x = t.X; tbl[0].y = t.Y;
-    ELL_NOUNROLL
-    for (int i = 1; i < 8; i++) {
-      El h;
-      t = G::add_mixed_zr(t, dd, h);
-      tbl[i].x = t.X; tbl[i].y = t.Y;
-      tbl[8 + i].x = h;
+    if constexpr (is_lazy<F>::value || !ELL_COZ_TABLE) {
+      ELL_NOUNROLL
+      for (int i = 1; i < 8; i++) {
+        El h;
+        t = G::add_mixed_zr(t, dd, h);
+        tbl[i].x = t.X; tbl[i].y = t.Y;
+        tbl[8 + i].x = h;
+      }
+    } else {
+      // Co-Z chain (Meloni's ZADDU): on the first isomorphic curve P and 2P are both affine, i.e.
+      // share Z = 1; an addition of two points with a COMMON Z costs 4M + 2S here -- the product
+      // Z3 = Z h is never formed, only its factor h = X_2P - X_jP is kept for the rescaling pass --
+      // and hands back 2P on the new Z, ready for the next step: 4M + 2S per odd multiple instead
+      // of the mixed addition's 8M + 3S.
+      El x2 = t.X, y2 = t.Y;                               // the current odd multiple j P
+      ELL_NOUNROLL
+      for (int i = 1; i < 8; i++) {
+        El h = F::sub(dd.x, x2);
+        El c = F::sqr(h);
+        El w1 = F::mul(dd.x, c);
+        El w2 = F::mul(x2, c);
+        El dy = F::sub(dd.y, y2);
+        El dsq = F::sqr(dy);
+        El a1 = F::mul(dd.y, F::sub(w1, w2));
+        El x3 = F::sub(F::sub(dsq, w1), w2);
+        El y3 = F::sub(F::mul(dy, F::sub(w1, x3)), a1);
+        dd.x = w1; dd.y = a1;                              // 2P on the new Z
+        x2 = x3; y2 = y3;                                  // (j + 2) P
+        tbl[i].x = x3; tbl[i].y = y3;
+        tbl[8 + i].x = h;
+      }
     }
-    zg = F::mul(t.Z, d.Z);
+    // every entry to the last entry's Z: zr = h_(i+1) ... h_7, x zr^2, y zr^3; entry 0 had Z = 1,
+    // so its ratio is the chain's final Z
     El zr = F::one();
     ELL_NOUNROLL
     for (int i = 6; i >= 0; i--) {
@@ -176,6 +202,7 @@ struct Ladder {
       e.y = F::mul(e.y, F::mul(zr2, zr));
       tbl[i] = e;
     }
+    zg = F::mul(zr, d.Z);
   }
 
   // acc = sum_s k_s * P_s on the effective-affine curve: digits odd (recode_odd_w4), tables

@@ -1,8 +1,10 @@
-O=gpurun_out/r03k; mkdir -p $O
-python tools/ab_variants.py ab_libs/base.so ab_libs/glvodd.so --reps=30 > $O/glvodd_ab.jsonl 2> $O/ab.err
+O=gpurun_out/r03l; mkdir -p $O
+( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1; tail -5 $O/pytest_gpu.log
+python tools/strong_proxy.py > $O/strong_proxy.jsonl 2> $O/strong_proxy.err; cut -c1-260 $O/strong_proxy.jsonl
+timeout 600 python tools/bench_configs.py --reps 4 2>/dev/null | grep '"config"' > $O/configs.jsonl
 python - <<'PY'
 import json
-for l in open('gpurun_out/r03k/glvodd_ab.jsonl'):
-    d=json.loads(l)
-    print({k:d[k] for k in d if k in ('lib','mask_ok','ecdsa_main_ms','mul_var_same','mul_fixed_same','mul_fixed_kernel_ms','mul_var_kernel_ms','error')})
+for l in open('gpurun_out/r03l/configs.jsonl'):
+    r=json.loads(l)
+    print(r['config'], round(r['items_per_s']/1e6,2))
 PY
