@@ -243,6 +243,28 @@ def kernel_counters():
         return None, None
 
 
+_STATIC_MIX = None
+
+
+def static_mix():
+    """{kernel key: multiply / other-64-bit counts per unit} from profiles/*static_op_mix.json
+    (tools/static_mix.py), only if it was made from the sources of the loaded library"""
+    global _STATIC_MIX
+    if _STATIC_MIX is None:
+        _STATIC_MIX = {}
+        f = _latest("*static_op_mix.json")
+        try:
+            d = json.load(open(f)) if f else None
+        except ValueError:
+            d = None
+        if d and d.get("source_digest") == lib_digest():
+            for curve, key in (("p384", "mul_var<p384>"), ("p256", "mul_var<p256>")):
+                m = d["curves"].get(curve, {}).get("mul_var_model")
+                if m:
+                    _STATIC_MIX[key] = dict(m, source=os.path.relpath(f, ROOT))
+    return _STATIC_MIX
+
+
 def _tool(name):
     import importlib.util
     spec = importlib.util.spec_from_file_location("ellgpu_tool_" + name, os.path.join(ROOT, "tools", name + ".py"))
@@ -354,6 +376,17 @@ def roofline_block(kernel_key, unit_key, n, kernel_ms, peak_gmads, clock_ghz, co
         k = None
     elif k and k.get("mad_u64_per_unit"):
         mads = k["mad_u64_per_unit"]
+        # NIST curves: SQ_INSTS_VALU_INT64 also counts the Solinas fold's 64-bit adds / shifts.
+        # tools/static_mix.py counts those per field operation from the ISA; the ladder's shape
+        # gives the field operations per unit: multiplies = PMC INT64 - that many.
+        sm = static_mix().get(kernel_key)
+        if sm and sm.get("other_int64_per_unit"):
+            out["int64_pmc_per_unit"] = mads
+            out["int64_non_multiply_static_per_unit"] = sm["other_int64_per_unit"]
+            out["mads_static_model_per_unit"] = sm["mad_u64_u32_per_unit"]
+            out["multiply_count_source"] = ("SQ_INSTS_VALU_INT64 minus the fold's 64-bit adds/shifts counted from "
+                                            "the ISA x the ladder's field-operation count (%s)" % sm["source"])
+            mads = mads - sm["other_int64_per_unit"]
         ach = n * mads / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
         out.update({"achieved": ach, "frac": ach / peak_gmads if peak_gmads else None,
                     "frac_of_theoretical": ach / theo,
