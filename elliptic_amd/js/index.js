@@ -724,24 +724,99 @@ function install(elliptic, options) {
   eng.verifyMany = function verifyMany(ec, items) {
     var d = domain(ec.curve);
     if (!d || ec.curve.type !== 'short') throw new Error('verifyMany: unsupported curve');
+    var m = marshalVerify(ec, d, items);
+    var ok = eng.ecdsaVerifyBatch(d.id, m.o);
+    return items.map(function(_, i) { return m.pre[i] && ok[i] === 1; });
+  };
+  // Promise form of verifyMany: the batch runs on a libuv worker thread (ecdsaVerifyBatchAsync)
+  // ec/signature.js is not exported by the library: its constructor is taken, once per
+  // install(), from the first signature an EC instance makes
+  var SignatureClass = null;
+  function signatureClass(ec) {
+    if (!SignatureClass) SignatureClass = ec.sign('00', ec.keyFromPrivate('01', 'hex')).constructor;
+    return SignatureClass;
+  }
+  // one (msg, signature, key) as the engine's fixed-width fields; throws what EC#verify throws
+  function marshalOne(ec, d, it) {
     var NB = ec.n.byteLength();
-    var Signature = ec.sign('00', ec.keyFromPrivate('01', 'hex')).constructor;
+    var Signature = signatureClass(ec);
+    var key = ec.keyFromPublic(it.key, it.enc);
+    var sig = new Signature(it.signature, 'hex');
+    var bad = sig.r.isNeg() || sig.s.isNeg() || sig.r.byteLength() > NB || sig.s.byteLength() > NB;
+    return { pre: !bad, h: Buffer.from(it.msg),
+      r: Buffer.from((bad ? new BN(0) : sig.r).toArray('be', NB)),
+      s: Buffer.from((bad ? new BN(0) : sig.s).toArray('be', NB)),
+      q: affineBuf(ec.curve, key.getPublic(), d.B) };
+  }
+  function packVerify(ms, hl) {
+    return { pre: ms.map(function(m) { return m.pre; }),
+      o: { hashes: Buffer.concat(ms.map(function(m) { return m.h; })), hashLen: hl, msgBits: 0,
+        r: Buffer.concat(ms.map(function(m) { return m.r; })), s: Buffer.concat(ms.map(function(m) { return m.s; })),
+        pub: Buffer.concat(ms.map(function(m) { return m.q; })) } };
+  }
+  function marshalVerify(ec, d, items) {
     var hl = items.length ? items[0].msg.length : 1;
-    var hs = [], rs = [], ss = [], qs = [], pre = [];
-    items.forEach(function(it, i) {
+    return packVerify(items.map(function(it) {
       if (it.msg.length !== hl) throw new Error('verifyMany: digests must share one length');
-      var key = ec.keyFromPublic(it.key, it.enc);
-      var sig = new Signature(it.signature, 'hex');
-      var bad = sig.r.isNeg() || sig.s.isNeg() || sig.r.byteLength() > NB || sig.s.byteLength() > NB;
-      pre[i] = !bad;
-      hs.push(Buffer.from(it.msg));
-      rs.push(Buffer.from((bad ? new BN(0) : sig.r).toArray('be', NB)));
-      ss.push(Buffer.from((bad ? new BN(0) : sig.s).toArray('be', NB)));
-      qs.push(affineBuf(ec.curve, key.getPublic(), d.B));
+      return marshalOne(ec, d, it);
+    }), hl);
+  }
+  eng.verifyManyAsync = function verifyManyAsync(ec, items) {
+    var d = domain(ec.curve);
+    if (!d || ec.curve.type !== 'short')
+      return Promise.reject(new Error('verifyMany: unsupported curve'));
+    var m;
+    try { m = marshalVerify(ec, d, items); } catch (e) { return Promise.reject(e); }
+    if (!items.length) return Promise.resolve([]);
+    return eng.ecdsaVerifyBatchAsync(d.id, m.o).then(function(ok) {
+      return items.map(function(_, i) { return m.pre[i] && ok[i] === 1; });
     });
-    var ok = eng.ecdsaVerifyBatch(d.id, { hashes: Buffer.concat(hs), hashLen: hl, msgBits: 0,
-      r: Buffer.concat(rs), s: Buffer.concat(ss), pub: Buffer.concat(qs) });
-    return items.map(function(_, i) { return pre[i] && ok[i] === 1; });
+  };
+  // One verification as a Promise -- and the answer to "one ec.verify is one launch of one lane"
+  // (ec/index.js:188-229 costs the device ~1 ms per call, what the reference's own JavaScript
+  // costs): every verifyAsync issued before the event loop turns joins ONE batch (a microtask
+  // flushes the queue), so N concurrent callers share a launch instead of queueing N of them.
+  // Digests of different lengths, or different EC instances, form separate batches; a call whose
+  // key or signature the reference would throw on rejects with that error, alone.
+  var pendingVerify = [];
+  function flushVerify() {
+    var q = pendingVerify;
+    pendingVerify = [];
+    var groups = [];
+    q.forEach(function(p) {
+      var g = null;
+      for (var i = 0; i < groups.length && !g; i++)
+        if (groups[i].ec === p.ec && groups[i].hl === p.item.msg.length) g = groups[i];
+      if (!g) { g = { ec: p.ec, hl: p.item.msg.length, ps: [] }; groups.push(g); }
+      g.ps.push(p);
+    });
+    groups.forEach(function(g) {
+      var good = [], ms = [];
+      var d = domain(g.ec.curve);
+      g.ps.forEach(function(p) {           // a throwing item rejects alone
+        try { ms.push(marshalOne(g.ec, d, p.item)); good.push(p); }
+        catch (e) { p.reject(e); }
+      });
+      if (!good.length) return;
+      eng.stats.coalescedBatches = (eng.stats.coalescedBatches || 0) + 1;
+      eng.stats.coalescedItems = (eng.stats.coalescedItems || 0) + good.length;
+      var m = packVerify(ms, g.hl);
+      eng.ecdsaVerifyBatchAsync(d.id, m.o).then(function(ok) {
+        good.forEach(function(p, i) { p.resolve(m.pre[i] && ok[i] === 1); });
+      }, function(e) { good.forEach(function(p) { p.reject(e); }); });
+    });
+  }
+  eng.verifyAsync = function verifyAsync(ec, msg, signature, key, enc) {
+    var d = domain(ec.curve);
+    if (!d || ec.curve.type !== 'short' || !(Buffer.isBuffer(msg) || Array.isArray(msg) || msg instanceof Uint8Array)) {
+      // outside the engine's batch domain: the (patched) synchronous path, as a Promise
+      return new Promise(function(resolve) { resolve(ec.verify(msg, signature, key, enc)); });
+    }
+    return new Promise(function(resolve, reject) {
+      pendingVerify.push({ ec: ec, item: { msg: Buffer.from(msg), signature: signature, key: key, enc: enc },
+        resolve: resolve, reject: reject });
+      if (pendingVerify.length === 1) Promise.resolve().then(flushVerify);
+    });
   };
   return eng;
 }

@@ -137,6 +137,38 @@ def test_user_defined_curves_through_install_gpu():
     assert out["checked"] >= 30 and out["custom"] is True
 
 
+def _run_coalescing(lib):
+    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
+    if lib:
+        env["ELLGPU_LIB"] = lib
+    else:
+        env.pop("ELLGPU_LIB", None)
+    p = subprocess.run(["node", os.path.join(ROOT, "tools", "check_verify_coalescing.js")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["calls"] == 98 and res["engine_calls"] <= 4 and res["rejected"] == 2
+    return res
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_verify_async_coalesces_concurrent_calls():
+    """98 concurrent eng.verifyAsync calls (two curves, two digest lengths, corrupted tuples, two
+    calls the reference throws on) -> at most four engine calls, every verdict and every rejection
+    message equal to the unpatched reference's synchronous EC#verify"""
+    _addon()
+    from hostsim.build import build as build_hostsim
+    _run_coalescing(build_hostsim())
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_verify_async_coalesces_concurrent_calls_gpu():
+    from elliptic_amd.js import build as jb
+    jb.build()
+    _run_coalescing(None)
+
+
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
 def test_js_batch_api_hostsim():
     _addon()
