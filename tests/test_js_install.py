@@ -147,13 +147,13 @@ def _run_coalescing(lib):
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     res = json.loads(p.stdout.strip().splitlines()[-1])
-    assert res["ok"] and res["calls"] == 98 and res["engine_calls"] <= 4 and res["rejected"] == 2
+    assert res["ok"] and res["calls"] == 99 and res["engine_calls"] <= 4 and res["rejected"] == 2
     return res
 
 
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
 def test_verify_async_coalesces_concurrent_calls():
-    """98 concurrent eng.verifyAsync calls (two curves, two digest lengths, corrupted tuples, two
+    """99 concurrent eng.verifyAsync calls (two curves, two digest lengths, corrupted tuples, two
     calls the reference throws on) -> at most four engine calls, every verdict and every rejection
     message equal to the unpatched reference's synchronous EC#verify"""
     _addon()

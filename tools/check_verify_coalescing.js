@@ -23,7 +23,9 @@ for (var i = 0; i < N; i++) {
   if (i % 6 === 5) msg = Buffer.concat([ msg.slice(0, msg.length - 1), Buffer.from([ msg[msg.length - 1] ^ 1 ]) ]);  // corrupted
   calls.push({ p256: ec === ecp256, msg: msg, sig: sig, key: kp.getPublic('hex'), enc: 'hex' });
 }
-// two calls the reference throws on: an invalid public key, a malformed DER signature
+// two calls the reference throws on: an undecodable public key, a malformed DER signature
+calls.push({ p256: false, msg: calls[0].msg, sig: calls[0].sig, key: '05abcdef', enc: 'hex' });
+// ... and a well-formed key that is not on the curve (the reference answers without validating it)
 calls.push({ p256: false, msg: calls[0].msg, sig: calls[0].sig, key: '04' + '11'.repeat(64), enc: 'hex' });
 calls.push({ p256: false, msg: calls[1].msg, sig: '3006020101', key: calls[1].key, enc: 'hex' });
 
