@@ -31,6 +31,11 @@ MAP = {
     "rocprof_sqb.txt": "rocprof_pmc_sq_b.txt",
     "rocprof_gc.txt": "rocprof_pmc_gather_calib.txt",
     "gather_calib.log": "gather_calib.log",
+    "smoke.log": "smoke.log",
+    "strong_proxy.jsonl": "strong_proxy.jsonl",
+    "latency.jsonl": "latency.jsonl",
+    "bench_strong_two_ranks_one_gpu.jsonl": "bench_strong_two_ranks_one_gpu.jsonl",
+    "rccl_selftest.jsonl": "rccl_selftest.jsonl",
 }
 
 # kernel name in the summaries -> (key bench.py uses, units per dispatch in the profiled command)
@@ -135,7 +140,7 @@ def distil(src, digest):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r02")
+    ap.add_argument("--round", default="r03")
     ap.add_argument("--src", default=os.path.join(ROOT, "gpurun_out", "refresh"))
     a = ap.parse_args()
     dst = os.path.join(ROOT, "profiles")

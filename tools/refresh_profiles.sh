@@ -10,7 +10,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/refresh
 MODE="$1"
 rm -rf $O && mkdir -p $O
-ROUND="${ELL_ROUND:-r02}"
+ROUND="${ELL_ROUND:-r03}"
 ( time timeout 900 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
 tail -3 $O/pytest_gpu.log
 # the workload of the PMC passes: one pass of every benchmarked kernel (headline + configs), 2 timed steps
@@ -31,11 +31,22 @@ for t in stats sqa sqb fwa fwb gc; do
 done
 cat $O/rocprof_fwa.txt $O/rocprof_fwb.txt > $O/rocprof_fw.txt 2>/dev/null
 rm -rf $O/prof_stats $O/prof_fwa $O/prof_fwb $O/prof_sqa $O/prof_sqb $O/prof_gc
-# distil the counters HERE first (into this box's copy of profiles/), so that the bench.py run
-# below prices its roofline with the instruction counts of the very binaries it runs
+# distil the counters HERE first (into this box's copy of profiles/), so that a bench.py run
+# without its own live passes prices its roofline with the instruction counts of these binaries
 python tools/refresh_profiles.py --round $ROUND --src $O > $O/distil.log 2>&1
-timeout 600 python bench.py > $O/bench.json.log 2> $O/bench.err
+# the smoke gate, in place and from a copy of the tree at another path (provenance must not
+# depend on where the tree lives)
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log
+rm -rf /tmp/treecopy && mkdir -p /tmp/treecopy && cp -rL . /tmp/treecopy/repo2 2>/dev/null
+( cd /tmp/treecopy/repo2 && echo "# same tree copied to $PWD" && python -c "import __graft_entry__ as g; g.smoke()" ) >> $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log
+rm -rf /tmp/treecopy
+# the driver's command: default bench.py (live PMC passes of its own, configs, cpu_baseline)
+( time timeout 900 python bench.py --keep-counters $O/live_counters ) > $O/bench.json.log 2> $O/bench.err
 tail -c 600 $O/bench.json.log
+timeout 300 python tools/strong_proxy.py > $O/strong_proxy.jsonl 2> $O/strong_proxy.err
+timeout 300 python tools/bench_latency.py > $O/latency.jsonl 2> $O/latency.err
+( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 2 --scaling strong --dist-backend gloo --force-device 0 ) > $O/bench_strong_two_ranks_one_gpu.jsonl 2> $O/bench_strong2.err
+( timeout 300 python bench.py --rccl-selftest --steps 5 --warmup 2 --no-cpu --no-configs --no-live-counters ) > $O/rccl_selftest.jsonl 2> $O/rccl_selftest.err
 if [ "$MODE" != "quick" ]; then
   timeout 300 python tools/gpu_probe.py > $O/valu_probe.log 2>&1
   timeout 200 tools/microbench/_build/valu_patterns > $O/valu_patterns.log 2>&1
