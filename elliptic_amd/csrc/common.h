@@ -27,6 +27,14 @@
 #endif
 // Ladder::build_table_odd8: 1 = the odd multiples are chained with co-Z additions (4M + 2S each),
 // 0 = with mixed additions (8M + 3S)
+// window width of the secp256k1 odd-digit ladder (Work::Endo): 4 = 33 windows over 8 odd
+// multiples (the full-grid tuning), 5 = 26 windows over 16 (the small-grid tuning, WIDE)
+#ifndef ELL_ENDO_WBITS
+#define ELL_ENDO_WBITS 4
+#endif
+#ifndef ELL_ENDO_WBITS_WIDE
+#define ELL_ENDO_WBITS_WIDE 5
+#endif
 #ifndef ELL_COZ_TABLE
 #define ELL_COZ_TABLE 1
 #endif

@@ -71,24 +71,25 @@ ELL_HD void recode_w4(const u32 (&k)[LW], const DigitStore& ds, int s, int NS) {
   }
 }
 
-// Signed ODD 4-bit recoding of an odd k < 2^(4*NW): with the bit 2^(4*NW) forced on,
-//   k = sum_i d_i 16^i,  d_i = 2*((k' >> (4i+1)) & 15) - 15  in {+-1, +-3, ..., +-15}
-// (every window non-zero, so the ladder adds at every step and needs only the eight
-// odd multiples).  Digits go to ds at index w*NS + s.
-template <int LW, int NW>
+// Signed ODD WB-bit recoding of an odd k < 2^(WB*NW): with the bit 2^(WB*NW) forced on,
+//   k = sum_i d_i 2^(WB i),  d_i = 2*((k' >> (WB i + 1)) & (2^WB - 1)) - (2^WB - 1)  in {+-1, +-3, ..., +-(2^WB - 1)}
+// (every window non-zero, so the ladder adds at every step and needs only the 2^(WB-1) odd
+// multiples).  Digits go to ds at index w*NS + s.
+template <int LW, int NW, int WB = 4>
 ELL_HD void recode_odd_w4(const u32 (&k)[LW], const DigitStore& ds, int s, int NS) {
-  constexpr int LK = (4 * NW) / 32 + 1;
+  constexpr int LK = (WB * NW) / 32 + 1;
+  constexpr u32 DM = (1u << WB) - 1u;
   u32 kp[LK + 1];
   ELL_UNROLL
   for (int i = 0; i < LK + 1; i++) kp[i] = i < LW ? k[i] : 0u;
-  kp[(4 * NW) >> 5] |= 1u << ((4 * NW) & 31);
+  kp[(WB * NW) >> 5] |= 1u << ((WB * NW) & 31);
   ELL_UNROLL
   for (int i = 0; i < NW; i++) {
-    const int bit = 4 * i + 1;
+    const int bit = WB * i + 1;
     const int li = bit >> 5, sh = bit & 31;
     u32 v = kp[li] >> sh;
-    if (sh > 28) v |= kp[li + 1] << (32 - sh);
-    ds.set(i * NS + s, 2 * (int)(v & 15u) - 15);
+    if (sh > 32 - WB) v |= kp[li + 1] << (32 - sh);
+    ds.set(i * NS + s, 2 * (int)(v & DM) - (int)DM);
   }
 }
 
@@ -148,6 +149,7 @@ struct Ladder {
   // zg = Z_last * Zd -- when a = 0, whose doubling formula holds on every isomorphic curve;
   // for a = -3 the caller maps the TABLE back to the true curve with zg^-1 instead
   // (Work::var_ladder).   tbl[0..8) = table, tbl[8..16) is used as scratch for the ratios.
+  template <int NE = 8>
   ELL_HD static void build_table_odd8(A* tbl, const A& p, El& zg) {
     J d = G::dbl(G::from_affine(p));
     El zd2 = F::sqr(d.Z);
@@ -160,11 +162,11 @@ struct Ladder {
     tbl[0].x = t.X; tbl[0].y = t.Y;
     if constexpr (is_lazy<F>::value || !ELL_COZ_TABLE) {
       ELL_NOUNROLL
-      for (int i = 1; i < 8; i++) {
+      for (int i = 1; i < NE; i++) {
         El h;
         t = G::add_mixed_zr(t, dd, h);
         tbl[i].x = t.X; tbl[i].y = t.Y;
-        tbl[8 + i].x = h;
+        tbl[NE + i].x = h;
       }
     } else {
       // Co-Z chain (Meloni's ZADDU): on the first isomorphic curve P and 2P are both affine, i.e.
@@ -174,7 +176,7 @@ struct Ladder {
       // of the mixed addition's 8M + 3S.
       El x2 = t.X, y2 = t.Y;                               // the current odd multiple j P
       ELL_NOUNROLL
-      for (int i = 1; i < 8; i++) {
+      for (int i = 1; i < NE; i++) {
         El h = F::sub(dd.x, x2);
         El c = F::sqr(h);
         El w1 = F::mul(dd.x, c);
@@ -187,15 +189,15 @@ struct Ladder {
         dd.x = w1; dd.y = a1;                              // 2P on the new Z
         x2 = x3; y2 = y3;                                  // (j + 2) P
         tbl[i].x = x3; tbl[i].y = y3;
-        tbl[8 + i].x = h;
+        tbl[NE + i].x = h;
       }
     }
     // every entry to the last entry's Z: zr = h_(i+1) ... h_7, x zr^2, y zr^3; entry 0 had Z = 1,
     // so its ratio is the chain's final Z
     El zr = F::one();
     ELL_NOUNROLL
-    for (int i = 6; i >= 0; i--) {
-      zr = F::mul(zr, tbl[8 + i + 1].x);
+    for (int i = NE - 2; i >= 0; i--) {
+      zr = F::mul(zr, tbl[NE + i + 1].x);
       El zr2 = F::sqr(zr);
       A e = tbl[i];
       e.x = F::mul(e.x, zr2);
@@ -212,7 +214,7 @@ struct Ladder {
   // is not stored; its entries are the first table's with x multiplied by beta at every lookup.
   // Halves the table bytes written per item and the region the gathers touch, for one more
   // field multiplication per addition of the second string (ELL_LAMBDA_AT_LOOKUP).
-  template <int NS, int NW, bool LAMBDA_AT_LOOKUP = false, bool WIDE = false>
+  template <int NS, int NW, bool LAMBDA_AT_LOOKUP = false, bool WIDE = false, int WB = 4>
   ELL_HD static J run_odd_w4(const DigitStore& ds, const A* tbl, u32 negmask, u32 evenmask, bool& inf,
                              const El* beta = nullptr) {
     // table entry for digit string s at window w (digits are odd and non-zero); a function of
@@ -221,7 +223,7 @@ struct Ladder {
       int d = ds.get(w * NS + s);
       int ad = d < 0 ? -d : d;
       bool neg = (d < 0) != (((negmask >> s) & 1u) != 0);
-      A q = tbl[(LAMBDA_AT_LOOKUP ? 0 : s * 8) + ((ad - 1) >> 1)];
+      A q = tbl[(LAMBDA_AT_LOOKUP ? 0 : s * (1 << (WB - 1))) + ((ad - 1) >> 1)];
       if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP, WIDE>(beta));
       q.y = cneg_y(q.y, neg);
       return q;
@@ -239,7 +241,7 @@ struct Ladder {
       int d = ds.get(w * NS + s);
       int ad = d < 0 ? -d : d;
       neg = (d < 0) != (((negmask >> s) & 1u) != 0);
-      at = tbl + (LAMBDA_AT_LOOKUP ? 0 : s * 8) + ((ad - 1) >> 1);
+      at = tbl + (LAMBDA_AT_LOOKUP ? 0 : s * (1 << (WB - 1))) + ((ad - 1) >> 1);
       return *at;
     };
     auto finish = [&](A q, int s, bool neg) -> A {
@@ -257,7 +259,7 @@ struct Ladder {
       if (w != NW - 1) {
         q0 = raw(w, 0, neg0, at0);
         ELL_NOUNROLL
-        for (int j = 0; j < 4; j++) acc = G::dbl(acc);
+        for (int j = 0; j < WB; j++) acc = G::dbl(acc);
       }
       if (NS > 1) q1 = raw(w, NS - 1, neg1, at1);
       if (w != NW - 1)
@@ -270,7 +272,7 @@ struct Ladder {
     for (int w = NW - 1; w >= 0; w--) {
       if (w != NW - 1) {
         ELL_NOUNROLL
-        for (int j = 0; j < 4; j++) acc = G::dbl(acc);
+        for (int j = 0; j < WB; j++) acc = G::dbl(acc);
       }
       ELL_NOUNROLL
       for (int s = (w == NW - 1 ? 1 : 0); s < NS; s++)
@@ -280,7 +282,7 @@ struct Ladder {
     ELL_NOUNROLL
     for (int s = 0; s < NS; s++) {
       auto corr = [&]() -> A {
-        A q = tbl[LAMBDA_AT_LOOKUP ? 0 : s * 8];
+        A q = tbl[LAMBDA_AT_LOOKUP ? 0 : s * (1 << (WB - 1))];
         if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP, WIDE>(beta));
         bool neg = ((negmask >> s) & 1u) == 0;        // subtract sign_s * P_s
         q.y = cneg_y(q.y, neg);

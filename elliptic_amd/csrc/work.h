@@ -76,7 +76,24 @@ struct Work {
   static constexpr int NWIN = NNIB + (TOP ? 1 : 0);
   // variable-base window table: 8 affine odd multiples per digit string (16 entries per item:
   // P and lambda*P for secp256k1; the second half is build_table_odd8's scratch otherwise)
-  static constexpr int TBL1 = 16;
+  // The secp256k1 odd-digit ladder (GLV halves below 2^130): WB-bit windows over the 2^(WB-1)
+  // odd multiples.  4 bits = 33 windows (128 doublings, 65 additions) over 8 entries; 5 bits = 26
+  // windows (125 doublings, 51 additions) over 16.  Since the table's entries cost a co-Z addition
+  // and a rescaling each (1.7 k instructions; they were 2.6 k) the 5-bit form executes 3 % fewer
+  // instructions -- and writes twice the table bytes: on a full grid (4 waves/SIMD) the two
+  // measure the same (7.98 against 7.94 ms per 2^20), where only two or three waves per SIMD are
+  // resident the 5-bit form is 2 % faster (profiles/r03_window_width_ab.txt).  So the small-grid
+  // tuning (WIDE) takes 5 bits, the full-grid tuning 4.
+  template <bool WIDE>
+  struct Endo {
+    static constexpr int WB = ENDO ? (WIDE ? ELL_ENDO_WBITS_WIDE : ELL_ENDO_WBITS) : 4;
+    static constexpr int NW = (130 + WB - 1) / WB;                     // 26 (5 bits) / 33 (4 bits)
+    static constexpr int NE = 1 << (WB - 1);                           // table entries
+    static constexpr int TBL = 2 * NE > 16 ? 2 * NE : 16;             // slots per item: entries + the build's ratios
+    static_assert(!ENDO || NW * 2 <= NWIN * NSV, "digit store too small for the odd ladder");
+  };
+  // slots per item the scratch arena is sized for (the larger tuning's)
+  static constexpr int TBL1 = ENDO ? (Endo<true>::TBL > Endo<false>::TBL ? Endo<true>::TBL : Endo<false>::TBL) : 16;
   typedef A VT;
   static constexpr int TBLJ = 8 * NSV;                     // mul_add2: Jacobian entries per (k, P)
   // fixed-base comb: COMB_BITS-bit unsigned windows, table of d * 2^(COMB_BITS*w) * G.
@@ -172,15 +189,16 @@ struct Work {
   template <bool WIDE = false>
   ELL_HD static J var_ladder(const u32 (&k)[L], const A& p, VT* tbl, const DigitStore& ds, bool& inf) {
     if constexpr (ENDO) {
+      typedef Endo<WIDE> E;
       u32 k1[5], k2[5];
       bool n1, n2;
       glv_split<true>(k, k1, n1, k2, n2);           // both halves odd: no correction at the end
       const u32 evenmask = 0u;
-      recode_odd_w4<5, NNIB>(k1, ds, 0, 2);
-      recode_odd_w4<5, NNIB>(k2, ds, 1, 2);
+      recode_odd_w4<5, E::NW, E::WB>(k1, ds, 0, 2);
+      recode_odd_w4<5, E::NW, E::WB>(k2, ds, 1, 2);
       u32 negmask = (n1 ? 1u : 0u) | (n2 ? 2u : 0u);
       El zg;
-      LD::build_table_odd8(tbl, p, zg);
+      LD::template build_table_odd8<E::NE>(tbl, p, zg);
       // lambda*P table: (beta*x, y)   (short.js:282-310 _getBeta); beta commutes with the
       // isomorphisms, which only scale x and y
       El beta = load_beta();
@@ -190,23 +208,23 @@ struct Work {
       if constexpr (!WIDE) {
         // zg is needed again only after the ladder: park it in a free table slot (slots 8..15 are
         // the build's scratch) instead of eight registers held across the loop
-        tbl[15].x = zg;
-        r = LD::template run_odd_w4<2, NNIB, true>(ds, tbl, negmask, evenmask, inf, &beta);
+        tbl[2 * E::NE - 1].x = zg;
+        r = LD::template run_odd_w4<2, E::NW, true, false, E::WB>(ds, tbl, negmask, evenmask, inf, &beta);
         asm volatile("" ::: "memory");
-        zg = tbl[15].x;
+        zg = tbl[2 * E::NE - 1].x;
       } else
 #endif
       {
-        r = LD::template run_odd_w4<2, NNIB, true, WIDE>(ds, tbl, negmask, evenmask, inf, &beta);
+        r = LD::template run_odd_w4<2, E::NW, true, WIDE, E::WB>(ds, tbl, negmask, evenmask, inf, &beta);
       }
 #else
       ELL_NOUNROLL
-      for (int e = 0; e < 8; e++) {
+      for (int e = 0; e < E::NE; e++) {
         A t = tbl[e];
         t.x = F::mul(t.x, beta);
-        tbl[8 + e] = t;
+        tbl[E::NE + e] = t;
       }
-      J r = LD::template run_odd_w4<2, NNIB>(ds, tbl, negmask, evenmask, inf);
+      J r = LD::template run_odd_w4<2, E::NW, false, false, E::WB>(ds, tbl, negmask, evenmask, inf);
 #endif
       r.Z = F::mul(r.Z, zg);
       return r;
@@ -253,7 +271,7 @@ struct Work {
     load_be<L>(k, ks + i * BYTES, BYTES);
     A p = load_affine(xy, i);
     bool inf;
-    J r = var_ladder(k, p, tbl_all + i * TBL1, ds, inf);
+    J r = var_ladder(k, p, tbl_all + i * Endo<false>::TBL, ds, inf);
     store_jac(jac, n, i, r);
   }
 
@@ -283,7 +301,7 @@ struct Work {
     load_be<L>(k2, k2s + i * BYTES, BYTES);
     A p2 = load_affine(xy2, i);
     bool inf;
-    J b = var_ladder(k2, p2, tbl_all + i * TBL1, ds, inf);
+    J b = var_ladder(k2, p2, tbl_all + i * Endo<false>::TBL, ds, inf);
 #if ELL_LATE_LOADS && defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" ::: "memory");                 // k1 is loaded after the ladder (see ecdsa_main)
 #endif
@@ -1000,7 +1018,7 @@ struct Work {
     // u2 * Q first; u1 and r are loaded where they are used, behind compiler barriers, so that
     // they do not occupy registers across the ladder (ELL_LATE_LOADS: the 128-register build)
     bool inf;
-    J b = var_ladder<WIDE>(u2, q, tbl_all + i * TBL1, ds, inf);
+    J b = var_ladder<WIDE>(u2, q, tbl_all + i * Endo<WIDE>::TBL, ds, inf);
 #if ELL_LATE_LOADS && defined(__HIP_DEVICE_COMPILE__)
     if constexpr (!WIDE) asm volatile("" ::: "memory");
 #endif
