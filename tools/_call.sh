@@ -1,3 +1,3 @@
-O=gpurun_out/r03o; mkdir -p $O
-( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
-python tools/strong_proxy.py > $O/strong_proxy.jsonl 2> $O/strong_proxy.err; cut -c1-230 $O/strong_proxy.jsonl
+O=gpurun_out/r03p; mkdir -p $O
+python tools/ab_small.py ab_libs/base.so ab_libs/fake.so --sizes=1048576,262144 > $O/fake.jsonl 2>$O/ab.err
+cat $O/fake.jsonl
