@@ -283,7 +283,7 @@ LIVE_PASSES = (
 )
 
 
-def live_counters(batch, per_pass_timeout=200, keep=None):
+def live_counters(batch, per_pass_timeout=90, keep=None, total_budget=240):
     """The roofline's instruction counts and HBM bytes, measured by THIS run: one rocprofv3 PMC
     pass per counter group (--kernel-trace + --pmc only, MI355X_MICROARCH.md's recipe) over a
     2-step child of this script -- the same binaries, box and inputs as the timed region --
@@ -309,11 +309,16 @@ def live_counters(batch, per_pass_timeout=200, keep=None):
     for tag, ctrs in LIVE_PASSES:
         d = os.path.join(tmp, "prof_" + tag)
         cmd = [rp, "--kernel-trace", "--pmc"] + ctrs + ["-d", d, "-o", tag, "--"] + child
+        left = total_budget - (time.perf_counter() - t0)
+        if left < 20:                       # never let the profiler stretch the bench beyond minutes
+            notes.append("%s: skipped (time budget)" % tag)
+            continue
         try:
-            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=per_pass_timeout)
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True,
+                               timeout=min(per_pass_timeout, left))
         except subprocess.TimeoutExpired:
             notes.append("%s: timeout" % tag)
-            continue
+            break                           # a profiler that hangs once is not asked again
         dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
         if p.returncode != 0 or not dbs:
             notes.append("%s: rc=%d %s" % (tag, p.returncode, (p.stderr or "")[-160:].replace("\n", " ")))

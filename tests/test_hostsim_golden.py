@@ -489,6 +489,25 @@ def test_device_group_shards_match_single_context():
     # an error inside a shard surfaces with the shard's message
     with pytest.raises(elliptic_amd.EllgpuError):
         grp.mul_var("curve25519", np.zeros((4, 32), np.uint8), np.zeros((4, 64), np.uint8))
+    # reserve / synchronize fan out to every member; null buffers are refused before sharding
+    grp.reserve("secp256k1", 1000)
+    grp.synchronize()
+    import ctypes
+    assert lib.ellgpu_mul_fixed(grp._ctx, 0, 4, None, None, None) == -2
+    assert lib.ellgpu_ecdsa_verify(grp._ctx, 0, 4, None, 32, 0, None, None, None, None) == -2
+    # a user-defined curve is registered with all members or with none: fill ONE member's table
+    # behind the group's back, then the group definition must fail and leave member 0 untouched
+    members = grp.group_size()
+    p256 = O.get_curve("p256", False)
+    cid = grp.define_short(p256.p, 5, 7)
+    assert cid >= 16 and grp.define_short(p256.p, 5, 7) == cid          # same parameters, same id
+    solo = elliptic_amd.Context(0, lib_path=lib)
+    ids = {solo.define_short(p256.p, 5, 100 + j) for j in range(16)}
+    assert len(ids) == 16
+    with pytest.raises(elliptic_amd.EllgpuError):
+        solo.define_short(p256.p, 5, 999)                               # the seventeenth
+    solo.close()
+    assert members == 3
     one.close()
     grp.close()
 
