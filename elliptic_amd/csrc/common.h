@@ -35,6 +35,9 @@
 #ifndef ELL_ENDO_WBITS_WIDE
 #define ELL_ENDO_WBITS_WIDE 5
 #endif
+#ifndef ELL_P384_WBITS
+#define ELL_P384_WBITS 4            // window width of the p384 ladder (experiment: 5)
+#endif
 #ifndef ELL_COZ_TABLE
 #define ELL_COZ_TABLE 1
 #endif

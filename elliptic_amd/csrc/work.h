@@ -92,8 +92,21 @@ struct Work {
     static constexpr int TBL = 2 * NE > 16 ? 2 * NE : 16;             // slots per item: entries + the build's ratios
     static_assert(!ENDO || NW * 2 <= NWIN * NSV, "digit store too small for the odd ladder");
   };
+  // the curves without an endomorphism: PLAIN_WB-bit odd windows over the full-width scalar
+  // (8 BYTES bits + the forced top bit)
+  static constexpr int PLAIN_WB = (L == 12) ? ELL_P384_WBITS : 4;
+  static constexpr int PLAIN_NW = PLAIN_WB == 4 ? NWIN : (8 * BYTES + 1 + PLAIN_WB - 1) / PLAIN_WB;
+  static constexpr int PLAIN_NE = 1 << (PLAIN_WB - 1);
+  static_assert(ENDO || PLAIN_NW <= NWIN, "digit store too small");
+  // slots between two items' tables in a launch of the given tuning
+  template <bool WIDE>
+  ELL_HD static constexpr int stride() {
+    if constexpr (ENDO) return Endo<WIDE>::TBL;
+    else return 2 * PLAIN_NE > 16 ? 2 * PLAIN_NE : 16;
+  }
   // slots per item the scratch arena is sized for (the larger tuning's)
-  static constexpr int TBL1 = ENDO ? (Endo<true>::TBL > Endo<false>::TBL ? Endo<true>::TBL : Endo<false>::TBL) : 16;
+  static constexpr int TBL1 = ENDO ? (Endo<true>::TBL > Endo<false>::TBL ? Endo<true>::TBL : Endo<false>::TBL)
+                                   : (2 * PLAIN_NE > 16 ? 2 * PLAIN_NE : 16);
   typedef A VT;
   static constexpr int TBLJ = 8 * NSV;                     // mul_add2: Jacobian entries per (k, P)
   // fixed-base comb: COMB_BITS-bit unsigned windows, table of d * 2^(COMB_BITS*w) * G.
@@ -246,20 +259,20 @@ struct Work {
       bn_copy<L>(kk, k);
       u32 evenmask = (k[0] & 1u) ? 0u : 1u;
       kk[0] |= 1u;                                  // k even -> k + 1, P subtracted at the end
-      recode_odd_w4<L, NWIN>(kk, ds, 0, 1);
+      recode_odd_w4<L, PLAIN_NW, PLAIN_WB>(kk, ds, 0, 1);
       El zg;
-      LD::build_table_odd8(tbl, p, zg);
+      LD::template build_table_odd8<PLAIN_NE>(tbl, p, zg);
       El zi = F::inv(zg);
       El zi2 = F::sqr(zi);
       El zi3 = F::mul(zi2, zi);
       ELL_NOUNROLL
-      for (int e = 0; e < 8; e++) {
+      for (int e = 0; e < PLAIN_NE; e++) {
         A t = tbl[e];
         t.x = F::mul(t.x, zi2);
         t.y = F::mul(t.y, zi3);
         tbl[e] = t;
       }
-      return LD::template run_odd_w4<1, NWIN>(ds, tbl, 0u, evenmask, inf);
+      return LD::template run_odd_w4<1, PLAIN_NW, false, false, PLAIN_WB>(ds, tbl, 0u, evenmask, inf);
     }
   }
 
@@ -271,7 +284,7 @@ struct Work {
     load_be<L>(k, ks + i * BYTES, BYTES);
     A p = load_affine(xy, i);
     bool inf;
-    J r = var_ladder(k, p, tbl_all + i * Endo<false>::TBL, ds, inf);
+    J r = var_ladder(k, p, tbl_all + i * stride<false>(), ds, inf);
     store_jac(jac, n, i, r);
   }
 
@@ -301,7 +314,7 @@ struct Work {
     load_be<L>(k2, k2s + i * BYTES, BYTES);
     A p2 = load_affine(xy2, i);
     bool inf;
-    J b = var_ladder(k2, p2, tbl_all + i * Endo<false>::TBL, ds, inf);
+    J b = var_ladder(k2, p2, tbl_all + i * stride<false>(), ds, inf);
 #if ELL_LATE_LOADS && defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" ::: "memory");                 // k1 is loaded after the ladder (see ecdsa_main)
 #endif
@@ -653,13 +666,19 @@ struct Work {
       Nl pr;
       ELL_UNROLL
       for (int l = 0; l < LN; l++) pr.v[l] = pre[(size_t)l * n + i];
-      Nl w = Fn::mul(inv, pr);                       // s^-1
+      Nl w = Fn::mul(inv, pr);                       // s^-1 (Montgomery form: s^-1 R)
       inv = Fn::mul(inv, sm);
-      Nl u1 = Fn::mul(Fn::from_plain(e), w);
-      Nl u2 = Fn::mul(Fn::from_plain(r), w);
+      // u = x * s^-1 as a PLAIN residue in one Montgomery product: (x) * (s^-1 R) / R, x < R
+      // unreduced on the left, s^-1 R < n on the right -- no conversion of x in, none of u out
+      // (round 3: 7 instead of 11 products per item)
+      Nl er, rr;
+      bn_copy<LN>(er.v, e);
+      bn_copy<LN>(rr.v, r);
+      Nl u1 = Fn::mul(er, w);
+      Nl u2 = Fn::mul(rr, w);
       u32 p1[LN], p2[LN];
-      Fn::to_plain(p1, u1);
-      Fn::to_plain(p2, u2);
+      bn_copy<LN>(p1, u1.v);
+      bn_copy<LN>(p2, u2.v);
       ELL_UNROLL
       for (int l = 0; l < LN; l++) {
         u12[(size_t)(0 * LN + l) * n + i] = ok ? p1[l] : 0u;
@@ -1018,7 +1037,7 @@ struct Work {
     // u2 * Q first; u1 and r are loaded where they are used, behind compiler barriers, so that
     // they do not occupy registers across the ladder (ELL_LATE_LOADS: the 128-register build)
     bool inf;
-    J b = var_ladder<WIDE>(u2, q, tbl_all + i * Endo<WIDE>::TBL, ds, inf);
+    J b = var_ladder<WIDE>(u2, q, tbl_all + i * stride<WIDE>(), ds, inf);
 #if ELL_LATE_LOADS && defined(__HIP_DEVICE_COMPILE__)
     if constexpr (!WIDE) asm volatile("" ::: "memory");
 #endif
