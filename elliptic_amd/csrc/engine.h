@@ -75,7 +75,8 @@ namespace ell {
 enum { E_OK = 0, E_NODEVICE = -1, E_ARG = -2, E_HIP = -3, E_NOMEM = -4, E_UNSUPPORTED = -5 };
 
 // ---- functors (one per kernel) ------------------------------------------------
-template <class CV, int MW = 0>
+// WIDE: the small-grid tuning of the secp256k1 ladder (see FnEcdsaMain)
+template <class CV, int MW = 0, bool WIDE = false>
 struct FnMulVar {
   static constexpr const char* NAME = "mul_var";
   typedef Work<CV> W;
@@ -83,7 +84,7 @@ struct FnMulVar {
   static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? (CV::JTABLE ? ELL_CUSTOM_MIN_WAVES : ELL_MULVAR_MIN_WAVES) : (W::L == 12 ? ELL_P384_MIN_WAVES : ELL_P521_MIN_WAVES));   // <= 128 VGPRs for 256-bit curves: +2..4 % despite ~50 B of spills
   size_t n; const u8* k; const u8* xy; typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
-    if (i < n) W::mul_var(i, n, k, xy, tbl, ds, jac);
+    if (i < n) W::template mul_var<WIDE>(i, n, k, xy, tbl, ds, jac);
   }
 };
 template <class CV>
@@ -1781,7 +1782,16 @@ int Engine<BK>::mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u
   typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::VT));
   u32* jac = (u32*)scratch(S_JAC, n * 3 * W::NS * 4);
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
-  if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
+  bool launched = false;
+  if constexpr (CV::ENDO && W::L <= 8) {
+    if (n <= small_grid()) {                // at most three waves per SIMD: the register-rich tuning
+      FnMulVar<CV, 3, true> f{n, k, xy, tbl, jac};
+      launch_fn(f, n);
+      launched = true;
+    }
+  }
+  if (launched) {
+  } else if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
     FnMulVar<CV, (W::L > 12 ? 2 : 0)> f{n, k, xy, tbl, jac};
     bk.launch(f, n);
   } else {

@@ -50,7 +50,9 @@ namespace ell {
 // the small-grid (WIDE) verify kernel of the endomorphism curve: its own translation unit
 #define ELL_DECL_G7(KW)                                                                              \
   KW template int Engine<HipBackend>::launch_fn<FnEcdsaMain<CvSecp256k1, 3, true>>(                  \
-      const FnEcdsaMain<CvSecp256k1, 3, true>&, size_t);
+      const FnEcdsaMain<CvSecp256k1, 3, true>&, size_t);                                             \
+  KW template int Engine<HipBackend>::launch_fn<FnMulVar<CvSecp256k1, 3, true>>(                     \
+      const FnMulVar<CvSecp256k1, 3, true>&, size_t);
 // user-defined short curves (CvCustom): scalar multiplication and point addition only
 #define ELL_DECL_CUSTOM(KW)                                                                          \
   KW template int Engine<HipBackend>::mul_var_chunk<CvCustom>(size_t, const u8*, const u8*, u8*, u8*, \

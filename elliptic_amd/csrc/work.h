@@ -278,13 +278,14 @@ struct Work {
 
   // k*P -> Jacobian (Point#mul's ladder: short.js:422-432 -> base.js:86-126 /
   // short.js:218-249)
+  template <bool WIDE = false>
   ELL_HD static void mul_var(size_t i, size_t n, const u8* ks, const u8* xy, VT* tbl_all,
                              const DigitStore& ds, u32* jac) {
     u32 k[L];
     load_be<L>(k, ks + i * BYTES, BYTES);
     A p = load_affine(xy, i);
     bool inf;
-    J r = var_ladder(k, p, tbl_all + i * stride<false>(), ds, inf);
+    J r = var_ladder<WIDE>(k, p, tbl_all + i * stride<WIDE>(), ds, inf);
     store_jac(jac, n, i, r);
   }
 
@@ -985,10 +986,20 @@ struct Work {
       u32 r[LN];
       ELL_UNROLL
       for (int l = 0; l < LN; l++) r[l] = wrapped ? xr[l] : x[l];
-      Nl rm = Fn::from_plain(r);
-      Nl sm = Fn::mul(kinv, Fn::add(Fn::mul(rm, Fn::from_plain(d)), Fn::from_plain(e)));
+      // s = k^-1 (e + r d) with three Montgomery products instead of six: (r) * (d R) / R = r d as a
+      // PLAIN residue, e joins it plain (e < 2^bits(n) < 2n: one conditional subtraction), and
+      // (e + r d) * (k^-1 R) / R is s, plain -- r, e are never converted in, s never out
+      Nl rp, ep;
+      bn_copy<LN>(rp.v, r);
+      {
+        u32 en[LN];
+        u32 be = bn_sub<LN>(en, e, nn);
+        ELL_UNROLL
+        for (int l = 0; l < LN; l++) ep.v[l] = be ? e[l] : en[l];
+      }
+      Nl sm = Fn::mul(Fn::add(Fn::mul(rp, Fn::from_plain(d)), ep), kinv);
       u32 sp[LN];
-      Fn::to_plain(sp, sm);
+      bn_copy<LN>(sp, sm.v);
       ok = ok && !bn_is_zero<LN>(r) && !bn_is_zero<LN>(sp);
       u32 recid = (y[0] & 1u) | (wrapped ? 2u : 0u);
       // low-s form: s > n >> 1  ->  s = n - s, recid ^= 1

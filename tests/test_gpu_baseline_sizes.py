@@ -104,6 +104,15 @@ def test_config3_strong_scaling_shards_both_tunings(ctx, monkeypatch):
         torch.cuda.synchronize()
         masks.append(ok.cpu().numpy())
     assert np.array_equal(masks[0], masks[1]) and np.array_equal(masks[0], expect[lo:hi])
+    # P*k on the same shard in both tunings: identical bytes, and the oracle's on a sample
+    outs = []
+    for forced in ("0", str(1 << 30)):
+        monkeypatch.setenv("ELLGPU_SMALL_GRID", forced)
+        outs.append(ctx.mul_var("secp256k1", r[lo:hi], pub[lo:hi]))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    j = sample_idx(hi - lo, 1024)
+    want, winf = C.mul_mt("secp256k1", r[lo:hi][j], pub[lo:hi][j], threads())
+    assert np.array_equal(outs[1][1][j], winf) and np.array_equal(outs[1][0][j], want)
     idx = sample_idx(hi - lo, 2048) + lo
     assert np.array_equal(C.verify("secp256k1", h[idx], r[idx], s[idx], pub[idx], threads=threads()), expect[idx])
 

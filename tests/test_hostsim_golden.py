@@ -246,8 +246,10 @@ def test_verify_golden_secp256k1_both_tunings(ctx, monkeypatch):
     Small batches take the second by default; ELLGPU_SMALL_GRID=0 forces the first."""
     monkeypatch.setenv("ELLGPU_SMALL_GRID", "0")
     assert PC.check_verify_golden(ctx, "secp256k1") > 15
+    assert PC.check_mul_golden(ctx, "secp256k1") > 50          # mul_var has the two tunings too
     monkeypatch.setenv("ELLGPU_SMALL_GRID", str(1 << 30))
     assert PC.check_verify_golden(ctx, "secp256k1") > 15
+    assert PC.check_mul_golden(ctx, "secp256k1") > 50
 
 
 @pytest.mark.parametrize("curve", ["secp256k1", "p192", "p256", "p384", "p521", "ed25519"])

@@ -44,6 +44,7 @@ KERNELS = {
     "k_run<FnEcdsaMain<CvSecp256k1>>": ("ecdsa_main<secp256k1>", N20),
     "k_run<FnEcdsaMain<CvSecp256k1>,wide>": ("ecdsa_main_small_grid<secp256k1>", None),   # host-buffer leg's first chunk
     "k_run<FnMulVar<CvSecp256k1>>": ("mul_var<secp256k1>", N20),
+    "k_run<FnMulVar<CvSecp256k1>,wide>": ("mul_var_small_grid<secp256k1>", None),
     "k_run<FnMulFixed<CvSecp256k1>>": ("mul_fixed<secp256k1>", None),      # several grid sizes: per-lane figures only
     "k_run<FnMulVar<CvNist>>": ("mul_var<p384>", N18),        # the only NIST curve bench.py runs (names collapse to CvNist)
     "k_run<FnEdMulVar>": ("ed_mul_var", N20),
