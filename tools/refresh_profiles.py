@@ -35,6 +35,7 @@ MAP = {
     "strong_proxy.jsonl": "strong_proxy.jsonl",
     "latency.jsonl": "latency.jsonl",
     "bench_strong_two_ranks_one_gpu.jsonl": "bench_strong_two_ranks_one_gpu.jsonl",
+    "bench_two_ranks_one_gpu.jsonl": "bench_two_ranks_one_gpu.jsonl",
     "rccl_selftest.jsonl": "rccl_selftest.jsonl",
 }
 

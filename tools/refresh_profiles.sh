@@ -46,6 +46,7 @@ tail -c 600 $O/bench.json.log
 timeout 300 python tools/strong_proxy.py > $O/strong_proxy.jsonl 2> $O/strong_proxy.err
 timeout 300 python tools/bench_latency.py > $O/latency.jsonl 2> $O/latency.err
 ( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 2 --scaling strong --dist-backend gloo --force-device 0 ) > $O/bench_strong_two_ranks_one_gpu.jsonl 2> $O/bench_strong2.err
+( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --steps 10 --warmup 2 --dist-backend gloo --force-device 0 ) > $O/bench_two_ranks_one_gpu.jsonl 2> $O/bench_weak2.err
 ( timeout 300 python bench.py --rccl-selftest --steps 5 --warmup 2 --no-cpu --no-configs --no-live-counters ) > $O/rccl_selftest.jsonl 2> $O/rccl_selftest.err
 if [ "$MODE" != "quick" ]; then
   timeout 300 python tools/gpu_probe.py > $O/valu_probe.log 2>&1
