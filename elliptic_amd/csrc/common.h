@@ -53,8 +53,11 @@
 #ifndef ELL_LATE_LOADS
 #define ELL_LATE_LOADS 1
 #endif
-//   ELL_PREFETCH     (the opposite trade, for the two-waves-per-SIMD build) table entries are
-//                    requested one step ahead of their use, Ladder::run_odd_w4
+// The opposite trade is the small-grid tuning (template parameter WIDE of the secp256k1 verify /
+// P*k kernels, engine.h): more registers, beta / zg / u1 resident, table and comb entries requested
+// one step ahead of their use (Ladder::run_odd_w4, comb_add).
+//   ELL_PREFETCH     developer switch: 1 forces the one-step-ahead requests in EVERY ladder
+//                    kernel of a build (how the p384 A/B of DESIGN.md section 9 was made)
 #ifndef ELL_PREFETCH
 #define ELL_PREFETCH 0
 #endif
