@@ -610,3 +610,25 @@ def check_custom_edwards_golden(ctx, spec):
     want, _ = ctx.point_add(cid, xy([c["r"] for c in mul[:m]]), xy([c["r"] for c in mul[m:2 * m]]))
     assert np.array_equal(got, want)
     return len(mul) + len(add) + len(dbl) + m
+
+
+def comb_boundary_scalars(bits, cb, count, seed=22):
+    """scalars whose cb-bit windows sit on the signed comb's recoding boundaries: 0, 1, 2^(cb-1) - 1,
+    2^(cb-1) (the largest positive digit), 2^(cb-1) + 1 (the first one that is taken negative and
+    carries), 2^cb - 2, 2^cb - 1 (with a carry arriving: digit 0 and a carry out) -- mixed so that
+    carries run through several windows; plus the all-ones and the alternating patterns"""
+    import random
+    rnd = random.Random(seed)
+    half, mask = 1 << (cb - 1), (1 << cb) - 1
+    vals = [0, 1, half - 1, half, half + 1, mask - 1, mask]
+    nw = (bits + cb - 1) // cb
+    out = [0, 1, (1 << bits) - 1, int("5" * (bits // 4), 16), int("a" * (bits // 4), 16)]
+    for v in vals:
+        out.append(sum(v << (cb * w) for w in range(nw)) & ((1 << bits) - 1))
+    while len(out) < count:
+        k = 0
+        for w in range(nw):
+            v = rnd.choice(vals) if rnd.random() < 0.8 else rnd.getrandbits(cb)
+            k |= v << (cb * w)
+        out.append(k & ((1 << bits) - 1))
+    return out

@@ -60,6 +60,29 @@ def test_config2_secp256k1_fixed_base_1M(ctx):
     assert inf[0] == 1 and inf[3] == 1 and inf[:8].sum() == 3     # 0*G, n*G and the other zero row
 
 
+@pytest.mark.parametrize("curve", ["secp256k1", "p256"])
+def test_signed_comb_window_boundaries(ctx, curve):
+    """the signed 22-bit comb of the 256-bit curves: 4 096 scalars whose windows sit on the
+    recoding's boundaries (largest positive digit, first negative one, carries through several
+    windows, a carry into the top window) -- G*k against the C oracle, item by item, and the
+    same scalars through k1*G + k2*P (the comb onto the ladder's accumulator)"""
+    import parity_checks as PC
+    from elliptic_amd import ints_to_be
+    ks = PC.comb_boundary_scalars(256, 22, 4096)
+    k = ints_to_be(ks, 32)
+    xy, inf = ctx.mul_fixed(curve, k)
+    want, winf = C.mul_mt(curve, k, None, threads())
+    assert np.array_equal(inf, winf) and np.array_equal(xy, want)
+    # k*G + 1*G == (k + 1)*G through mul_add2 with P1 = G (NULL)
+    one = ints_to_be([1] * len(ks), 32)
+    g, _ = ctx.mul_fixed(curve, one)
+    s_xy, s_inf = ctx.mul_add2(curve, k, None, one, g)
+    k1 = ints_to_be([(v + 1) % (1 << 256) for v in ks], 32)
+    w_xy, w_inf = C.mul_mt(curve, k1, None, threads())
+    keep = np.array([v + 1 < (1 << 256) for v in ks])
+    assert np.array_equal(s_inf[keep], w_inf[keep]) and np.array_equal(s_xy[keep], w_xy[keep])
+
+
 def test_config3_secp256k1_variable_base_and_verify_1M(ctx):
     import bench
     n = 1 << 20

@@ -132,6 +132,21 @@ def test_rare_branches_solinas(hs):
         assert _val(r) == want, (field, op, hex(a), hex(b))
 
 
+@pytest.mark.parametrize("curve", ["secp256k1", "p256"])
+def test_signed_comb_window_boundaries(ctx, curve):
+    """the signed comb's recoding (8-bit windows in this build, 22-bit on the device): scalars whose
+    windows sit on the boundaries -- largest positive digit, first negative one, carries through
+    several windows and into the carry window -- G*k against the Python oracle"""
+    from elliptic_amd import ints_to_be
+    ks = PC.comb_boundary_scalars(256, 8, 160)
+    xy, inf = ctx.mul_fixed(curve, ints_to_be(ks, 32))
+    cur = O.get_curve(curve)
+    for i, k in enumerate(ks):
+        w = cur.g.mul(k)
+        got = None if inf[i] else (int.from_bytes(xy[i, :32].tobytes(), "big"), int.from_bytes(xy[i, 32:].tobytes(), "big"))
+        assert got == (None if w.inf else (w.x, w.y)), hex(k)
+
+
 def test_solinas_chain_fold_raw_words(hs):
     """FpSolinas::reduce_wide_chain (p192 / p224 / p384) on raw 2L-word values: the rarely taken
     ripple of every chain, the top-word test, near misses and random values (field-op probe 13)"""
