@@ -206,11 +206,13 @@ class ShortPoint:
             doubles.append(acc)
         return step, doubles
 
-    def precompute(self, power):
-        """base.js:312-327."""
+    def precompute(self, power, wnd=8):
+        """base.js:312-327 (wnd = 8 there; the table secp256k1 SHIPS has wnd 7,
+        precomputed/secp256k1.js:268 -- on the curve the window does not change a
+        result, off the curve, where the reference still computes, it does)."""
         if self.pre is not None:
             return self
-        w, pts = self.get_naf_points(8)
+        w, pts = self.get_naf_points(wnd)
         s, dbl = self.get_doubles(4, power)
         self.pre = _Tables(w, pts, s, dbl)
         return self
@@ -1251,7 +1253,8 @@ def _signed_hex(s: str) -> int:
 def get_curve(name: str, precompute: bool = True):
     """Instantiate a preset the way `new EC(name)` / `new EDDSA(name)` leaves
     it: G carries naf(8)+doubles(4) tables (ec/index.js:36, eddsa/index.js:19;
-    secp256k1 ships them precomputed, curves.js:169-205)."""
+    secp256k1 ships them precomputed with naf(7), curves.js:169-205,
+    precomputed/secp256k1.js:268)."""
     key = (name, precompute)
     if key in _CACHE:
         return _CACHE[key]
@@ -1266,7 +1269,7 @@ def get_curve(name: str, precompute: bool = True):
         cur = ShortCurve(name, I(c["p"]), I(c["a"]), I(c["b"]), I(c["n"]), I(c["gx"]),
                          I(c["gy"]), endo)
         if precompute:
-            cur.g.precompute(cur.n.bit_length() + 1)
+            cur.g.precompute(cur.n.bit_length() + 1, 7 if name == "secp256k1" else 8)
     elif c["type"] == "edwards":
         cur = EdwardsCurve(name, I(c["p"]), I(c["a"]), I(c["d"]), I(c["n"]), I(c["gx"]),
                            I(c["gy"]))

@@ -145,3 +145,33 @@ def test_c_oracle_user_defined_curves_golden():
             assert got(out, inf, i) == want(c["r"]), (spec["name"], c)
         n_checked += len(mul) + len(madd)
     assert n_checked > 200
+
+
+@pytest.mark.parametrize("name", O.SHORT_CURVES)
+def test_c_oracle_offcurve_golden(name):
+    """offcurve_<curve>.json: the reference computes with points that are not on the curve, and the
+    C port -- same operation order, same window of G's shipped table -- has to give its results."""
+    from golden_util import load
+    B = BYTES[name]
+    cases = load("offcurve_%s.json" % name)
+
+    def pts(cs, x, y):
+        return np.concatenate([ints_to_be([I(c[x]) for c in cs], B), ints_to_be([I(c[y]) for c in cs], B)], axis=1)
+
+    var = [c for c in cases if c["op"] == "var"]
+    out, inf = C.mul(name, ints_to_be([I(c["k"]) for c in var], B), pts(var, "px", "py"))
+    for i, c in enumerate(var):
+        assert _res(out, inf, i, B) == res_xy(c["r"]), c
+    for g1 in (True, False):
+        madd = [c for c in cases if c["op"] == "muladd" and c["g1"] == g1]
+        out, inf = C.mul_add(name, ints_to_be([I(c["k1"]) for c in madd], B), None if g1 else pts(madd, "p1x", "p1y"),
+                             ints_to_be([I(c["k2"]) for c in madd], B), pts(madd, "p2x", "p2y"))
+        for i, c in enumerate(madd):
+            assert _res(out, inf, i, B) == res_xy(c["r"]), c
+    ver = [c for c in cases if c["op"] == "verify"]
+    hl = len(ver[0]["z"]) // 2
+    ok = C.verify(name, ints_to_be([I(c["z"]) for c in ver], hl), ints_to_be([I(c["r"]) for c in ver], B),
+                  ints_to_be([I(c["s"]) for c in ver], B), pts(ver, "qx", "qy"))
+    for i, c in enumerate(ver):
+        assert bool(ok[i]) == c["ok"], c
+    assert sum(1 for c in ver if c["ok"] and not c["on"]) >= 8

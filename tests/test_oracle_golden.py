@@ -314,3 +314,47 @@ def test_ecdsa_sign_matches_reference(name):
         else:
             assert got == (I(c["r"]), I(c["s"]), c["recid"]), c
     assert rej >= 3
+
+
+# ---- points that are not on the curve (offcurve_<curve>.json) ----------------------------
+# The reference computes with them (it never validates on this path), and off the curve its
+# result depends on the exact order of its operations -- the window of G's shipped table
+# included.  The oracle restates that order, so it has to agree item by item.
+@pytest.mark.parametrize("name", O.SHORT_CURVES)
+def test_short_offcurve_matches_reference(name):
+    cur = O.get_curve(name)
+    seen = {"var": 0, "muladd": 0, "verify_true": 0, "verify_false": 0}
+    for c in load("offcurve_%s.json" % name):
+        if c["op"] == "var":
+            P = cur.point(I(c["px"]), I(c["py"]))
+            assert cur.validate(P) == c["on"]
+            assert _aff(P.mul(I(c["k"]))) == res_xy(c["r"]), (name, c)
+            seen["var"] += 1
+        elif c["op"] == "muladd":
+            A = cur.g if c["g1"] else cur.point(I(c["p1x"]), I(c["p1y"]))
+            B = cur.point(I(c["p2x"]), I(c["p2y"]))
+            assert _aff(A.mul_add(I(c["k1"]), B, I(c["k2"]))) == res_xy(c["r"]), (name, c)
+            seen["muladd"] += 1
+        else:
+            Q = cur.point(I(c["qx"]), I(c["qy"]))
+            assert cur.validate(Q) == c["on"]
+            got = O.ecdsa_verify(cur, I(c["z"]), len(c["z"]) // 2, I(c["r"]), I(c["s"]), Q)
+            assert got == c["ok"], (name, c)
+            if not c["on"]:
+                seen["verify_true" if c["ok"] else "verify_false"] += 1
+    assert seen["var"] >= 10 and seen["muladd"] >= 5
+    assert seen["verify_true"] >= 8 and seen["verify_false"] >= 4
+
+
+def test_ed25519_offcurve_matches_reference():
+    cur = O.get_curve("ed25519")
+    n = 0
+    for c in load("offcurve_ed25519.json"):
+        if c["op"] == "var":
+            R = cur.point(I(c["px"]), I(c["py"])).mul(I(c["k"]))
+        else:
+            R = cur.g.mul_add(I(c["k1"]), cur.point(I(c["p2x"]), I(c["p2y"])), I(c["k2"]))
+        got = None if R.is_infinity() else R.normalized()
+        assert got == res_xy(c["r"]), c
+        n += 1
+    assert n >= 20

@@ -7,6 +7,7 @@
 //   curves.json             preset parameters as the reference holds them
 //   mul_<curve>.json        seeded + edge cases for Point.mul / mulAdd
 //   verify_<curve>.json     ECDSA verify tuples (valid + corrupted)
+//   offcurve_<curve>.json   points that are not on the curve: what the reference answers
 //   captured_<curve>.json   every call the reference's OWN mocha suite makes
 //                           into the hot path (Point.mul / mulAdd / jmulAdd /
 //                           ec.verify), captured at the prototype boundary
@@ -645,6 +646,121 @@ function genAdd(name) {
   return cases;
 }
 
+
+// ---------------------------------------------------------- offcurve_<curve>.json
+// Points that are NOT on the curve.  The reference never validates them on this path
+// (ec/index.js:192 keyFromPublic, ec/key.js:27-35, short.js:422-432, edwards.js:362-367): it
+// runs its formulas on whatever (x, y) it is given, and the result depends on the exact order
+// of its operations (off the curve the "group law" is not associative).  These fixtures pin
+// what it answers, so that (i) the engine's C ABI can be shown to report such items as
+// outside its domain instead of guessing, and (ii) the patched library can be shown to return
+// the reference's own result for them.
+//   var     k * P, P off the curve (incl. y = 0, k = 0, 1, n)
+//   muladd  k1 * P1 + k2 * P2 with one or both points off the curve (g1: P1 is the curve's G)
+//   verify  ECDSA tuples over an off-curve key built so that the reference ANSWERS TRUE
+//           (R = u1 G + u2 Q as the reference computes it, r = R.x mod n, s = r / u2,
+//           z = u1 s), plus corrupted ones it answers false, plus r / s out of range
+//   on      control items (on-curve points) mixed in: the engine must still compute those
+function genOffCurve(name) {
+  var pc = elliptic.curves[name];
+  var c = pc.curve;
+  var short = c.type === 'short';
+  if (!short) c.g.precompute(c.n.bitLength() + 1);
+  var L = flen(c);
+  var rng = new Prng('ellgpu-golden-v1:offcurve:' + name);
+  var N = Math.max(8, COUNTS[name] >> 2);
+  var cases = [];
+  var G = c.g;
+  function rec(op, o) { o.op = op; cases.push(o); }
+  function offPoint() {
+    for (;;) {
+      var x = rng.below(c.p), y = rng.below(c.p);
+      var P = c.point(x, y);
+      if (!c.validate(P)) return P;
+    }
+  }
+  function onPoint() {
+    var P = G.mul(rng.below(c.n.subn(1)).addn(1));
+    return c.point(P.getX(), P.getY());
+  }
+  function xy(P) { return affine(c, P); }
+  var i, k, P, a;
+  // k * P
+  var P0 = offPoint();
+  [new BN(0), new BN(1), new BN(2), c.n.clone(), c.n.subn(1)].forEach(function(k) {
+    a = xy(P0);
+    rec('var', { k: hex(k, L), px: a.x, py: a.y, on: false, r: affine(c, P0.mul(k)) });
+  });
+  if (short) {
+    // a point with y = 0 (order 2 on "its" curve)
+    var Z = c.point(rng.below(c.p), new BN(0));
+    [new BN(1), new BN(2), new BN(3), rng.below(c.n)].forEach(function(k) {
+      rec('var', { k: hex(k, L), px: hex(Z.getX(), L), py: hex(Z.getY(), L), on: false,
+        r: affine(c, Z.mul(k)) });
+    });
+  }
+  for (i = 0; i < N; i++) {
+    var on = i % 4 === 3;
+    P = on ? onPoint() : offPoint();
+    k = rng.below(c.n);
+    a = xy(P);
+    rec('var', { k: hex(k, L), px: a.x, py: a.y, on: on, r: affine(c, P.mul(k)) });
+  }
+  // k1 * P1 + k2 * P2.  Edwards mulAdd works in the reference only with a precomputed first
+  // operand (base.js:175 calls toJ()), so P1 = G there.
+  for (i = 0; i < N; i++) {
+    var kind = short ? i % 5 : 0;        // 0: G + off, 1: on + off, 2: off + on, 3: off + off, 4: on + on (control)
+    var A = kind === 0 ? G : ((kind === 1 || kind === 4) ? onPoint() : offPoint());
+    var B = (kind === 2 || kind === 4) ? onPoint() : offPoint();
+    var k1 = rng.below(c.n), k2 = rng.below(c.n);
+    var aa = xy(A), bb = xy(B);
+    rec('muladd', { k1: hex(k1, L), p1x: aa.x, p1y: aa.y, k2: hex(k2, L), p2x: bb.x, p2y: bb.y,
+      g1: kind === 0, on: kind === 4, r: affine(c, A.mulAdd(k1, B, k2)) });
+  }
+  if (!short) return cases;
+  // ECDSA over off-curve keys
+  var ec = new elliptic.ec(pc);
+  var NL = c.n.byteLength();
+  var ZL = (c.n.bitLength() % 8 === 0) ? NL : NL - 1;      // digest bytes that _truncateToN leaves alone
+  function verifyCase(Q, z, r, s, note) {
+    var zhex = z.toString(16, ZL * 2);
+    var key = ec.keyFromPublic({ x: hex(Q.getX(), L), y: hex(Q.getY(), L) });
+    var ok = ec.verify(zhex, { r: r, s: s }, key);
+    rec('verify', { z: zhex, r: hex(r, NL), s: hex(s, NL), qx: hex(Q.getX(), L), qy: hex(Q.getY(), L),
+      ok: ok, on: c.validate(Q), note: note });
+    return ok;
+  }
+  var made = 0;
+  for (i = 0; made < N && i < 20 * N; i++) {
+    var Q = offPoint();
+    var u1 = rng.below(c.n.subn(1)).addn(1), u2 = rng.below(c.n.subn(1)).addn(1);
+    var R = G.mulAdd(u1, Q, u2);
+    if (R.isInfinity()) continue;
+    var r = R.getX().umod(c.n);
+    if (r.isZero()) continue;
+    var s = r.mul(u2.invm(c.n)).umod(c.n);
+    var z = u1.mul(s).umod(c.n);
+    if (s.isZero() || z.byteLength() > ZL) continue;
+    if (!verifyCase(Q, z, r, s, 'off-curve key, reference says true'))
+      throw new Error('construction failed: the reference rejected its own R');
+    made++;
+    var m = made % 4;
+    if (m === 0) verifyCase(Q, z.xor(new BN(1)), r, s, 'off-curve key, bad z');
+    if (m === 1) verifyCase(Q, z, new BN(0), s, 'off-curve key, r = 0');
+    if (m === 2) verifyCase(Q, z, r, c.n.clone(), 'off-curve key, s = n');
+    if (m === 3) {
+      // control: a real signature under an on-curve key
+      var key = ec.keyFromPrivate(hex(rng.below(c.n.subn(1)).addn(1), NL), 'hex');
+      var zz = new BN(rng.bytes(ZL));
+      if (c.n.bitLength() % 8 !== 0) zz = zz.maskn(8 * ZL);
+      var sig = ec.sign(zz.toString(16, ZL * 2), key);
+      verifyCase(key.getPublic(), zz, sig.r, sig.s, 'on-curve control');
+    }
+  }
+  if (made < N) throw new Error('too few off-curve verify tuples for ' + name);
+  return cases;
+}
+
 // ------------------------------------------------------- der_fuzz_secp256k1.json
 // Signature#_importDER on mutated encodings: byte flips, insertions, deletions, length-field
 // edits and splices of valid signatures (seeded).  { der, r, s } or { der, bad: true }.
@@ -1073,6 +1189,9 @@ SHORT.forEach(function(name) {
 write('der_fuzz_secp256k1.json', genDerFuzz());
 SHORT.concat(['ed25519']).forEach(function(name) {
   write('add_' + name + '.json', genAdd(name));
+});
+SHORT.concat(['ed25519']).forEach(function(name) {
+  write('offcurve_' + name + '.json', genOffCurve(name));
 });
 write('eddsa_verify_ed25519.json', genEddsa());
 write('eddsa_sign_ed25519.json', genEddsaSign());
