@@ -13,6 +13,13 @@ only collective is the final gather of the ok-masks (RCCL all_gather).  `--scali
 
     python bench.py --gpus 1 --steps 120 --warmup 10
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... [--scaling strong]
+    python bench.py --gpus N ...        # plain python: re-launches ITSELF under torch.distributed.run
+
+At N > 1 one invocation measures BOTH forms: `value` is the weak-scaling figure (2^20 tuples on
+every GPU -- what the N = 1, 2, 4, 8 runs of the contract compare), and `strong` carries BASELINE
+configs[2] as written (ONE batch of 2^20 tuples cut into N shards, masks gathered, gathered mask
+checked on every rank) timed in the same process group right after it; `rccl` records the backend
+and the number of ranks the collective actually saw.
 
 At N = 1 the roofline's instruction counts and HBM bytes come from rocprofv3 PMC passes made
 by this very run on this very box (`live_counters`; a 2-step child of this script under
@@ -539,12 +546,26 @@ def main():
                     help="N = 1: initialise a 1-rank RCCL group and run the gather through it once")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: become the launcher.  One rank per GPU under
+        # torch.distributed.run on 127.0.0.1; rank 0 of the children prints the JSON line on this
+        # process's stdout.
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
-                         "--nproc-per-node %d" % (args.gpus, world, args.gpus))
+                         "--nproc-per-node %d (or as plain `python bench.py --gpus %d`, which launches itself)"
+                         % (args.gpus, world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     if args.force_device is not None:
@@ -621,23 +642,85 @@ def main():
         rccl_selftest = {"backend": args.dist_backend, "world": 1, "all_gather_ok": bool(torch.equal(gathered[0], dok)),
                          "ms": (time.perf_counter() - t0) * 1e3}
 
+    def timed(fn, steps):
+        """exactly `steps` calls of fn between barrier + synchronize on both sides -> max over ranks"""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     ctx.set_timing(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = timed(step, args.steps)
     timing = ctx.get_timing()
     ctx.set_timing(False)
+
+    rccl = None
+    strong_block = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # how many ranks does the collective really see?
+        ones = torch.ones(1, dtype=torch.int64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        rccl = {"backend": args.dist_backend + (" (= RCCL)" if args.dist_backend == "nccl" else ""), "world": world,
+                "nranks_seen": int(ones.item()),
+                "collectives": "one all_gather of the ok-masks per step (1 B per tuple); max-over-ranks timing "
+                               "and this census are all_reduce calls outside the timed steps"}
+    if world > 1 and not strong:
+        # BASELINE configs[2] as written, in the same process group: ONE batch of --batch tuples
+        # (rank 0's, broadcast -- every rank then verifies its contiguous shard), masks gathered,
+        # the gathered mask compared with the batch's expected mask on EVERY rank
+        nb = args.batch
+        if args.dist_backend == "nccl":
+            pack = torch.cat([dh, dr, dsg, dq], dim=1) if rank == 0 else torch.zeros((nb, 160), dtype=torch.uint8, device=dev)
+            exp_all = torch.from_numpy(expect).to(dev) if rank == 0 else torch.zeros(nb, dtype=torch.uint8, device=dev)
+            dist.broadcast(pack, 0)
+            dist.broadcast(exp_all, 0)
+        else:                                           # gloo self-test: through host memory
+            pack = torch.cat([dh, dr, dsg, dq], dim=1).cpu() if rank == 0 else torch.zeros((nb, 160), dtype=torch.uint8)
+            exp_all = torch.from_numpy(expect.copy()) if rank == 0 else torch.zeros(nb, dtype=torch.uint8)
+            dist.broadcast(pack, 0)
+            dist.broadcast(exp_all, 0)
+            pack, exp_all = pack.to(dev), exp_all.to(dev)
+        lo, hi = shard_range(nb, rank, world)
+        sh = pack[lo:hi]
+        sh_h, sh_r, sh_s, sh_q = (sh[:, a:b].contiguous() for a, b in ((0, 32), (32, 64), (64, 96), (96, 160)))
+        sh_ok = torch.zeros(hi - lo, dtype=torch.uint8, device=dev)
+        gmask = [None]
+
+        def strong_step():
+            ctx.ecdsa_verify_dev("secp256k1", sh_h, sh_r, sh_s, sh_q, sh_ok)
+            gmask[0] = gather_results(sh_ok if args.dist_backend == "nccl" else sh_ok.cpu(), nb, dist)
+
+        for _ in range(args.warmup):
+            strong_step()
+        torch.cuda.synchronize()
+        mask_ok = bool(torch.equal(gmask[0].to(exp_all.device), exp_all))
+        flag = torch.tensor([1 if mask_ok else 0], dtype=torch.int64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            raise SystemExit("PARITY FAILURE: strong-scaling pass: a rank's gathered mask differs from the expected mask")
+        ctx.set_timing(True)
+        sdt = timed(strong_step, args.steps)
+        stiming = ctx.get_timing()
+        ctx.set_timing(False)
+        scnt, smain = stiming.get("ecdsa_main", (0, 0.0))
+        spc, sprep = stiming.get("ecdsa_prep", (0, 0.0))
+        strong_block = {"value": nb * args.steps / sdt, "unit": "verifies/s", "ms_per_step": sdt / args.steps * 1e3,
+                        "global_batch": nb, "shard_rank0": hi - lo, "steps": args.steps, "warmup": args.warmup,
+                        "rank0_kernel_ms": {"ecdsa_main": smain / max(scnt, 1), "ecdsa_prep": sprep / max(spc, 1)},
+                        "parity": "the gathered mask equals the global batch's expected mask on every rank",
+                        "workload": "BASELINE configs[2] as written: ONE batch of %d tuples sharded over %d GPUs, "
+                                    "one all_gather of the masks per step" % (nb, world)}
 
     if rank == 0:
         total = n_global * args.steps
@@ -693,6 +776,10 @@ def main():
                        "library_digest": lib_digest()},
             "roofline": roof,
         }
+        if rccl is not None:
+            out["rccl"] = rccl
+        if strong_block is not None:
+            out["strong"] = strong_block
         if rccl_selftest is not None:
             out["rccl_selftest"] = rccl_selftest
         if world == 1 and not args.no_configs:

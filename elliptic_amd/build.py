@@ -72,17 +72,27 @@ def source_digest():
 
 def library_digest(path=None):
     """The digest embedded in a built libellgpu.so (None if the file is missing or predates
-    ellgpu_source_digest)."""
-    import ctypes
+    ellgpu_source_digest).  Read in a CHILD process: dlopen()ing the library here would leave it
+    mapped in the building process, and since glibc matches already-loaded objects by path, a
+    later load of a relinked file at the same path (build() followed by smoke() in one process)
+    would silently get the OLD binary back."""
     path = path or LIB
     if not os.path.exists(path):
         return None
+    code = ("import ctypes, sys\n"
+            "try:\n"
+            "    fn = ctypes.CDLL(sys.argv[1]).ellgpu_source_digest\n"
+            "except (OSError, AttributeError):\n"
+            "    sys.exit(3)\n"
+            "fn.restype = ctypes.c_char_p\n"
+            "sys.stdout.write(fn().decode())\n")
     try:
-        fn = ctypes.CDLL(path).ellgpu_source_digest
-    except (OSError, AttributeError):
+        p = subprocess.run([sys.executable, "-c", code, os.path.abspath(path)], capture_output=True, text=True,
+                           timeout=120)
+    except (OSError, subprocess.TimeoutExpired):
         return None
-    fn.restype = ctypes.c_char_p
-    return fn().decode()
+    out = p.stdout.strip()
+    return out if p.returncode == 0 and out else None
 
 
 def compile_one(args):

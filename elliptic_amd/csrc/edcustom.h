@@ -156,6 +156,25 @@ struct EdcWork {
     recode_w4<8, NNIB, true>(k2, ds, 1, 2);
     store_proj(out, n, i, run_w4<2>(ds, tbl));
   }
+  // a x^2 + y^2 == 1 + d x^2 y^2 (EdwardsCurve#validate, edwards.js:99-112, c = 1)
+  ELL_HD static bool on_curve(const El& x, const El& y) {
+    El x2 = F::sqr(x), y2 = F::sqr(y);
+    El lhs = F::add(F::mul(ca(), x2), y2);
+    El rhs = F::add(F::one(), F::mul(F::mul(cd(), x2), y2));
+    return F::eq(lhs, rhs);
+  }
+  // operands that are not on the curve are outside the engine's domain (edwards.h domain_mark)
+  ELL_HD static void domain_mark(size_t i, const u8* xy1, const u8* xy2, u8* out_xy, u8* out_inf) {
+    bool on = true;
+    if (xy1) on = on_curve(load_fe(xy1 + i * 64), load_fe(xy1 + i * 64 + 32));
+    if (xy2) on = on && on_curve(load_fe(xy2 + i * 64), load_fe(xy2 + i * 64 + 32));
+    if (on) return;
+    out_inf[i] = 2;
+    if (out_xy) {
+      ELL_NOUNROLL
+      for (int b = 0; b < 64; b++) out_xy[i * 64 + b] = 0;
+    }
+  }
   // a set inf flag stands for the identity (0, 1)
   ELL_HD static void point_add(size_t i, size_t n, const u8* xy1, const u8* inf1, const u8* xy2,
                                const u8* inf2, u32* out) {

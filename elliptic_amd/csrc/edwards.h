@@ -345,16 +345,35 @@ struct EdWork {
   // EdwardsCurve#validate (edwards.js:99-112) of an affine point: a x^2 + y^2 == 1 + d x^2 y^2
   // (a = -1, c = 1).  status 0 = on the curve, 2 = not a point, 1 = flagged as the identity by
   // the caller (`inf`, for symmetry with the short curves' KeyPair#validate).
-  ELL_HD static void validate_point(size_t i, const u8* xy, const u8* inf, u8* status) {
-    if (inf && inf[i]) { status[i] = 1; return; }
-    El x = load_fe(xy + i * 64), y = load_fe(xy + i * 64 + 32);
+  ELL_HD static bool on_curve(const El& x, const El& y) {
     El d;
     ELL_UNROLL
     for (int l = 0; l < 8; l++) d.v[l] = C::d[l];
     El x2 = F::sqr(x), y2 = F::sqr(y);
     El lhs = F::sub(y2, x2);
     El rhs = F::add(F::one(), F::mul(F::mul(d, x2), y2));
-    status[i] = F::eq(lhs, rhs) ? 0 : 2;
+    return F::eq(lhs, rhs);
+  }
+  ELL_HD static void validate_point(size_t i, const u8* xy, const u8* inf, u8* status) {
+    if (inf && inf[i]) { status[i] = 1; return; }
+    El x = load_fe(xy + i * 64), y = load_fe(xy + i * 64 + 32);
+    status[i] = on_curve(x, y) ? 0 : 2;
+  }
+  // The engine's domain is points ON the curve (work.h: Work::on_curve has the reasoning; here the
+  // reference's doubling, edwards.js:183-205, even differs from its addition of a point to itself
+  // off the curve).  After the ladder + normalization of a point-valued call: items with an
+  // operand (xy1 / xy2, either may be null) that is not on the curve get out_inf = 2 and a zeroed
+  // result, never a guessed one.
+  ELL_HD static void domain_mark(size_t i, const u8* xy1, const u8* xy2, u8* out_xy, u8* out_inf) {
+    bool on = true;
+    if (xy1) on = on_curve(load_fe(xy1 + i * 64), load_fe(xy1 + i * 64 + 32));
+    if (xy2) on = on && on_curve(load_fe(xy2 + i * 64), load_fe(xy2 + i * 64 + 32));
+    if (on) return;
+    out_inf[i] = 2;
+    if (out_xy) {
+      ELL_NOUNROLL
+      for (int b = 0; b < 64; b++) out_xy[i * 64 + b] = 0;
+    }
   }
   ELL_HD static void fill_order(size_t i, u8* scal) {
     typedef FpMont<consts::ED25519_N> Fn;

@@ -172,6 +172,34 @@ struct FnNormalize {
     if (t < T) W::normalize(t, T, n, K, jac, pre, out_xy, out_inf, raw);
   }
 };
+// post-pass of the point-valued calls: operands that are not on the curve are outside the
+// engine's domain -> out_inf = 2, result zeroed (Work::domain_mark)
+template <class CV>
+struct FnDomainMark {
+  static constexpr const char* NAME = "domain_mark";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* xy1; const u8* xy2; u8* out_xy; u8* out_inf;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::domain_mark(i, xy1, xy2, out_xy, out_inf);
+  }
+};
+struct FnEdDomainMark {
+  static constexpr const char* NAME = "ed_domain_mark";
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* xy1; const u8* xy2; u8* out_xy; u8* out_inf;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) EdWork::domain_mark(i, xy1, xy2, out_xy, out_inf);
+  }
+};
+struct FnEdcDomainMark {
+  static constexpr const char* NAME = "edc_domain_mark";
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* xy1; const u8* xy2; u8* out_xy; u8* out_inf;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) EdcWork::domain_mark(i, xy1, xy2, out_xy, out_inf);
+  }
+};
 template <class CV>
 struct FnEcdsaPrep {
   static constexpr const char* NAME = "ecdsa_prep";
@@ -1798,7 +1826,12 @@ int Engine<BK>::mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u
     FnMulVar<CV> f{n, k, xy, tbl, jac};
     bk.launch(f, n);
   }
-  return normalize_chunk<CV>(n, jac, out_xy, out_inf, raw);
+  int rc = normalize_chunk<CV>(n, jac, out_xy, out_inf, raw);
+  if (rc == E_OK && out_inf) {                  // (the comb build has no out_inf: its points are G)
+    FnDomainMark<CV> g{n, xy, nullptr, out_xy, out_inf};
+    bk.launch(g, n);
+  }
+  return rc;
 }
 
 
@@ -1829,7 +1862,12 @@ int Engine<BK>::mul_add2_chunk(size_t n, const u8* k1, const u8* xy1, const u8* 
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
   FnMulAdd2<CV> f{n, k1, xy1, k2, xy2, tbl, jac};
   bk.launch(f, n);
-  return normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
+  int rc = normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
+  if (rc == E_OK && out_inf) {
+    FnDomainMark<CV> g{n, xy1, xy2, out_xy, out_inf};
+    bk.launch(g, n);
+  }
+  return rc;
 }
 
 template <class BK>
@@ -1847,7 +1885,12 @@ int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* 
     FnMulAddG<CV> f{n, k1, k2, xy2, (const typename W::A*)comb_[CV::ID], tbl, jac};
     bk.launch(f, n);
   }
-  return normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
+  int rc = normalize_chunk<CV>(n, jac, out_xy, out_inf, nullptr);
+  if (rc == E_OK && out_inf) {
+    FnDomainMark<CV> g{n, nullptr, xy2, out_xy, out_inf};
+    bk.launch(g, n);
+  }
+  return rc;
 }
 
 
@@ -1872,6 +1915,10 @@ int Engine<BK>::edc_chunk(int op, size_t n, const u8* k1, const u8* xy1, const u
   size_t T = (n + INV_BATCH - 1) / INV_BATCH;
   FnEdcNormalize g{T, n, INV_BATCH, proj, pre, out_xy, out_inf};
   bk.launch(g, T);
+  if (op != 2 && out_inf) {                       // Point#add is one formula: the reference's own
+    FnEdcDomainMark h{n, xy1, op == 1 ? xy2 : nullptr, out_xy, out_inf};
+    bk.launch(h, n);
+  }
   return E_OK;
 }
 
@@ -1968,7 +2015,12 @@ int Engine<BK>::ed_mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy
   if (!tbl || !ext) return fail(E_NOMEM, "scratch allocation failed");
   FnEdMulVar f{n, k, xy, tbl, ext};
   bk.launch(f, n);
-  return ed_normalize_chunk(n, ext, out_xy, out_inf, raw);
+  int rc = ed_normalize_chunk(n, ext, out_xy, out_inf, raw);
+  if (rc == E_OK && out_inf) {
+    FnEdDomainMark g{n, xy, nullptr, out_xy, out_inf};
+    bk.launch(g, n);
+  }
+  return rc;
 }
 
 template <class BK>
@@ -1995,7 +2047,12 @@ int Engine<BK>::ed_mul_add2_chunk(size_t n, const u8* k1, const u8* xy1, const u
     FnEdMulAddG f{n, k1, k2, xy2, (const EdWork::P*)comb_[CURVE_ED25519], tbl, ext};
     bk.launch(f, n);
   }
-  return ed_normalize_chunk(n, ext, out_xy, out_inf, nullptr);
+  int rc = ed_normalize_chunk(n, ext, out_xy, out_inf, nullptr);
+  if (rc == E_OK && out_inf) {
+    FnEdDomainMark g{n, xy1, xy2, out_xy, out_inf};
+    bk.launch(g, n);
+  }
+  return rc;
 }
 
 template <class BK>

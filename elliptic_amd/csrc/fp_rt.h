@@ -60,6 +60,12 @@ struct FpMontRT {
     for (int i = 0; i < 8; i++) r.v[i] = ELL_RT.a_m[i];
     return r;
   }
+  ELL_HD static El curve_b() {
+    El r;
+    ELL_UNROLL
+    for (int i = 0; i < 8; i++) r.v[i] = ELL_RT.b_m[i];
+    return r;
+  }
   ELL_HD static bool is_zero(const El& a) { return bn_is_zero<8>(a.v); }
   ELL_HD static bool eq(const El& a, const El& b) { return bn_eq<8>(a.v, b.v); }
   ELL_HD static El add(const El& a, const El& b) {

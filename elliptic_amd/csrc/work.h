@@ -353,14 +353,44 @@ struct Work {
   // ---- point decompression (ShortCurve#pointFromX, short.js:187-204) --------------
   // rhs = x^3 + a x + b  (ShortCurve#validate short.js:205-216 and pointFromX share it)
   ELL_HD static El curve_rhs(const El& x) {
+    El x2 = F::sqr(x);
+    if constexpr (CV::A_KIND == 1) {
+      // user-defined curve: a and b come from the run-time parameter block (fp_rt.h)
+      return F::add(F::mul(F::add(x2, F::curve_a()), x), F::curve_b());
+    } else {
     u32 bp[L];
     ELL_UNROLL
     for (int l = 0; l < L; l++) bp[l] = C::b_plain[l];
     El b = F::from_plain(bp);
-    El x2 = F::sqr(x);
     if (CV::A_KIND == 0) return F::add(F::mul(x2, x), b);
     El three = F::add(F::one(), F::dbl(F::one()));
     return F::add(F::mul(F::sub(x2, three), x), b);            // x^3 - 3x + b
+    }
+  }
+  // ---- the engine's domain: points ON the curve -----------------------------------------
+  // The reference never validates a point on this path (ec/index.js:192 keyFromPublic,
+  // ec/key.js:27-35, short.js:422-432): it runs its formulas on any (x, y).  Off the curve
+  // those formulas are no group law -- the result depends on the exact order of the
+  // reference's operations (its wNAF / JSF digits, its GLV split, the window of G's shipped
+  // table), which the ladders here deliberately do not share.  So an off-curve operand is
+  // OUTSIDE the engine's domain: it is detected (one squaring more than ShortCurve#validate,
+  // short.js:205-216) and reported per item -- out_inf = 2 / out_ok = 2 at the C ABI -- never
+  // answered with a guess; the JS layer hands such items to the reference's own method.
+  enum { DOMAIN_OFF_CURVE = 2 };
+  ELL_HD static bool on_curve(const A& a) { return F::eq(F::sqr(a.y), curve_rhs(a.x)); }
+  // after the ladder + normalization of a point-valued call: items with an operand that is not
+  // on the curve get out_inf = 2 and a zeroed result (xy1 / xy2: the call's point operands,
+  // either may be null)
+  ELL_HD static void domain_mark(size_t i, const u8* xy1, const u8* xy2, u8* out_xy, u8* out_inf) {
+    bool on = true;
+    if (xy1) on = on_curve(load_affine(xy1, i));
+    if (xy2) on = on && on_curve(load_affine(xy2, i));
+    if (on) return;
+    out_inf[i] = (u8)DOMAIN_OFF_CURVE;
+    if (out_xy) {
+      ELL_NOUNROLL
+      for (int b = 0; b < 2 * BYTES; b++) out_xy[i * 2 * BYTES + b] = 0;
+    }
   }
   // y = sqrt(x^3 + a x + b) with the requested parity; false ('invalid point') when x is
   // not the abscissa of a curve point.  One exponentiation.
@@ -538,9 +568,12 @@ struct Work {
   }
   // EC#verify on wire formats: exceptions in the reference's order (keyFromPublic first, then
   // the Signature constructor); err 1..3 = decodePoint's status, 4 = 'Signature without r or s'
+  // err 5 (with ok = 2): an uncompressed key that is not on the curve -- no exception of the
+  // reference's, it computes with such keys; outside the engine's domain (on_curve below)
   ELL_HD static void wire_status(size_t i, const u8* key_st, const u8* sig_st, u8* ok, u8* err) {
     u32 e = key_st[i] ? key_st[i] : (sig_st[i] == DER_MALFORMED ? 4u : 0u);
     if (e || sig_st[i] == DER_TOO_WIDE) ok[i] = 0;
+    else if (ok[i] == 2) e = 5u;
     if (err) err[i] = (u8)e;
   }
 
@@ -1059,9 +1092,18 @@ struct Work {
     if constexpr (!WIDE) asm volatile("" ::: "memory");
 #endif
     load_be<LN>(r, rs + i * NBYTES, NBYTES);
-    bool ok = valid[i] != 0 && !G::is_inf(p);
+    bool ok = !G::is_inf(p);
     ok = ok && eq_x_to_p(p, r);
-    out_ok[i] = ok ? 1 : 0;
+    // The key is re-read and tested against the curve equation HERE, after the ladder, where
+    // nothing but the verdict is live (a flag carried across the ladder would cost the
+    // 128-register build a spill): r or s out of range -> 0 as in the reference, which returns
+    // false before it touches the key (ec/index.js:199-202); a key that is not on the curve ->
+    // 2, outside the engine's domain (see on_curve above); else the verdict.
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::: "memory");
+#endif
+    const bool on = on_curve(load_affine(pub_xy, i));
+    out_ok[i] = valid[i] == 0 ? (u8)0 : (!on ? (u8)DOMAIN_OFF_CURVE : (ok ? (u8)1 : (u8)0));
   }
 };
 

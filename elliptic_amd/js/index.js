@@ -20,7 +20,10 @@
 // eqXToP() (the affine result lifted with Z = 1); k is not reduced mod n; inputs
 // are never mutated.  Anything outside the engine's domain -- a curve that is not
 // one of the reference's presets (the toy curves of test/curve-test.js), a scalar
-// wider than the curve's byte length, a negative scalar -- is handed to the
+// wider than the curve's byte length, a negative scalar, a point that is NOT ON THE
+// CURVE (the reference computes with those -- ec/index.js:192 never validates a key --
+// and off the curve its answer depends on the order of its own operations; the engine
+// reports such an item with status 2 instead of guessing) -- is handed to the
 // reference's own original method, untouched.
 
 var path = require('path');
@@ -41,7 +44,7 @@ function Engine(options) {
   this.devices = Array.isArray(options.devices) && options.devices.length ?
     options.devices.map(function(d) { return d | 0; }) : null;
   this.ctx = this.addon.createContext(this.devices || (options.device | 0));
-  this.stats = { gpuCalls: 0, gpuItems: 0, passthrough: 0 };
+  this.stats = { gpuCalls: 0, gpuItems: 0, passthrough: 0, offCurve: 0 };
 }
 
 Engine.prototype._id = function _id(curve) {
@@ -460,12 +463,24 @@ function install(elliptic, options) {
     endoWnafMulAdd: short._endoWnafMulAdd,
   };
 
+  // status 2 of the engine (ELLGPU_STATUS_OFF_CURVE): an operand is not on the curve.  The
+  // reference computes with such points all the same; its own method gives its own answer.
+  var OFF_CURVE = 2;
+  // > 0 while the reference's own method runs on such an item: the ladders it calls internally
+  // (_endoWnafMulAdd -> _wnafMulAdd) are the patched ones, and must not ask the engine again
+  var refOnly = 0;
+  function offCurve(curve, origFn, origArgs) {
+    eng.stats.offCurve++; eng.stats.passthrough++;
+    refOnly++;
+    try { return origFn.apply(curve, origArgs); } finally { refOnly--; }
+  }
   function mul1(curve, p, k, origFn, origArgs) {
     var d = curve.type === 'mont' ? null : (domain(curve) || customDomain(curve));
     var kb = d && scalarBuf(k, d.B);
     var pb = kb && affineBuf(curve, p, d.B);
     if (!d || !kb || !pb) { eng.stats.passthrough++; return origFn.apply(curve, origArgs); }
     var r = isG(curve, d, p) ? eng.mulBatch(d.id, kb, null) : eng.mulBatch(d.id, kb, pb);
+    if (r.inf[0] === OFF_CURVE) return offCurve(curve, origFn, origArgs);
     return resultPoint(curve, d, r, false);
   }
   function mulAdd(curve, p1, k1, p2, k2, jacobian, origFn, origArgs) {
@@ -476,6 +491,7 @@ function install(elliptic, options) {
     var q2 = q1 && affineBuf(curve, p2, d.B);
     if (!q2) { eng.stats.passthrough++; return origFn.apply(curve, origArgs); }
     var r = eng.mulAddBatch(d.id, b1, isG(curve, d, p1) ? null : q1, b2, q2);
+    if (r.inf[0] === OFF_CURVE) return offCurve(curve, origFn, origArgs);
     return resultPoint(curve, d, r, jacobian);
   }
 
@@ -499,6 +515,8 @@ function install(elliptic, options) {
     if (!ok) { eng.stats.passthrough++; return origFn.apply(curve, origArgs); }
     var r = eng.mulAddBatch(d.id, Buffer.concat(k1), Buffer.concat(p1), Buffer.concat(k2),
       Buffer.concat(p2));
+    for (var u = 0; u < k1.length; u++)
+      if (r.inf[u] === OFF_CURVE) return offCurve(curve, origFn, origArgs);
     var acc = null;
     for (var t = 0; t < k1.length; t++) {
       var pt = resultPoint(curve, d, { xy: r.xy.slice(t * 2 * d.B, (t + 1) * 2 * d.B),
@@ -509,13 +527,16 @@ function install(elliptic, options) {
   }
 
   base._fixedNafMul = function _fixedNafMul(p, k) {
+    if (refOnly) return orig.fixedNafMul.apply(this, arguments);
     return mul1(this, p, k, orig.fixedNafMul, arguments);
   };
   base._wnafMul = function _wnafMul(p, k) {
+    if (refOnly) return orig.wnafMul.apply(this, arguments);
     return mul1(this, p, k, orig.wnafMul, arguments);
   };
   base._wnafMulAdd = function _wnafMulAdd(defW, points, coeffs, len,
     jacobianResult) {
+    if (refOnly) return orig.wnafMulAdd.apply(this, arguments);
     // (an odd len > 1 never worked in the reference: its pairing loop leaves naf[0] unset)
     if (len > 2 && len % 2 === 0)
       return mulAddMany(this, points, coeffs, len, !!jacobianResult, orig.wnafMulAdd, arguments);
@@ -525,6 +546,7 @@ function install(elliptic, options) {
   };
   short._endoWnafMulAdd = function _endoWnafMulAdd(points, coeffs,
     jacobianResult) {
+    if (refOnly) return orig.endoWnafMulAdd.apply(this, arguments);
     if (points.length === 1) {
       var r = mul1(this, points[0], coeffs[0], orig.endoWnafMulAdd, arguments);
       return jacobianResult && r.toJ ? r.toJ() : r;
@@ -726,8 +748,18 @@ function install(elliptic, options) {
     if (!d || ec.curve.type !== 'short') throw new Error('verifyMany: unsupported curve');
     var m = marshalVerify(ec, d, items);
     var ok = eng.ecdsaVerifyBatch(d.id, m.o);
-    return items.map(function(_, i) { return m.pre[i] && ok[i] === 1; });
+    return items.map(function(it, i) { return verdict(ec, it, m.pre[i], ok[i]); });
   };
+  // a key that is not on the curve (status 2): the reference computes with it -- and can answer
+  // true -- so that item goes through EC#verify itself, with the reference's own ladders
+  function verdict(ec, it, pre, ok) {
+    if (pre && ok === OFF_CURVE) {
+      eng.stats.offCurve++;
+      refOnly++;
+      try { return ec.verify(it.msg, it.signature, it.key, it.enc, it.options); } finally { refOnly--; }
+    }
+    return pre && ok === 1;
+  }
   // Promise form of verifyMany: the batch runs on a libuv worker thread (ecdsaVerifyBatchAsync)
   // ec/signature.js is not exported by the library: its constructor is taken, once per
   // install(), from the first signature an EC instance makes
@@ -748,18 +780,23 @@ function install(elliptic, options) {
       s: Buffer.from((bad ? new BN(0) : sig.s).toArray('be', NB)),
       q: affineBuf(ec.curve, key.getPublic(), d.B) };
   }
-  function packVerify(ms, hl) {
+  function msgBitsOf(it) {
+    return it.options && typeof it.options.msgBitLength === 'number' ? it.options.msgBitLength : 0;
+  }
+  function packVerify(ms, hl, msgBits) {
     return { pre: ms.map(function(m) { return m.pre; }),
-      o: { hashes: Buffer.concat(ms.map(function(m) { return m.h; })), hashLen: hl, msgBits: 0,
+      o: { hashes: Buffer.concat(ms.map(function(m) { return m.h; })), hashLen: hl, msgBits: msgBits | 0,
         r: Buffer.concat(ms.map(function(m) { return m.r; })), s: Buffer.concat(ms.map(function(m) { return m.s; })),
         pub: Buffer.concat(ms.map(function(m) { return m.q; })) } };
   }
   function marshalVerify(ec, d, items) {
     var hl = items.length ? items[0].msg.length : 1;
+    var mb = items.length ? msgBitsOf(items[0]) : 0;
     return packVerify(items.map(function(it) {
-      if (it.msg.length !== hl) throw new Error('verifyMany: digests must share one length');
+      if (it.msg.length !== hl || msgBitsOf(it) !== mb)
+        throw new Error('verifyMany: digests must share one length (and one options.msgBitLength)');
       return marshalOne(ec, d, it);
-    }), hl);
+    }), hl, mb);
   }
   eng.verifyManyAsync = function verifyManyAsync(ec, items) {
     var d = domain(ec.curve);
@@ -769,15 +806,16 @@ function install(elliptic, options) {
     try { m = marshalVerify(ec, d, items); } catch (e) { return Promise.reject(e); }
     if (!items.length) return Promise.resolve([]);
     return eng.ecdsaVerifyBatchAsync(d.id, m.o).then(function(ok) {
-      return items.map(function(_, i) { return m.pre[i] && ok[i] === 1; });
+      return items.map(function(it, i) { return verdict(ec, it, m.pre[i], ok[i]); });
     });
   };
   // One verification as a Promise -- and the answer to "one ec.verify is one launch of one lane"
   // (ec/index.js:188-229 costs the device ~1 ms per call, what the reference's own JavaScript
   // costs): every verifyAsync issued before the event loop turns joins ONE batch (a microtask
   // flushes the queue), so N concurrent callers share a launch instead of queueing N of them.
-  // Digests of different lengths, or different EC instances, form separate batches; a call whose
-  // key or signature the reference would throw on rejects with that error, alone.
+  // Digests of different lengths (or options.msgBitLength), or different EC instances, form
+  // separate batches; a call whose key or signature the reference would throw on rejects with
+  // that error, alone; a key that is not on the curve gets the reference's own verdict.
   var pendingVerify = [];
   function flushVerify() {
     var q = pendingVerify;
@@ -785,9 +823,10 @@ function install(elliptic, options) {
     var groups = [];
     q.forEach(function(p) {
       var g = null;
+      var mb = msgBitsOf(p.item);
       for (var i = 0; i < groups.length && !g; i++)
-        if (groups[i].ec === p.ec && groups[i].hl === p.item.msg.length) g = groups[i];
-      if (!g) { g = { ec: p.ec, hl: p.item.msg.length, ps: [] }; groups.push(g); }
+        if (groups[i].ec === p.ec && groups[i].hl === p.item.msg.length && groups[i].mb === mb) g = groups[i];
+      if (!g) { g = { ec: p.ec, hl: p.item.msg.length, mb: mb, ps: [] }; groups.push(g); }
       g.ps.push(p);
     });
     groups.forEach(function(g) {
@@ -800,21 +839,33 @@ function install(elliptic, options) {
       if (!good.length) return;
       eng.stats.coalescedBatches = (eng.stats.coalescedBatches || 0) + 1;
       eng.stats.coalescedItems = (eng.stats.coalescedItems || 0) + good.length;
-      var m = packVerify(ms, g.hl);
+      var m = packVerify(ms, g.hl, g.mb);
       eng.ecdsaVerifyBatchAsync(d.id, m.o).then(function(ok) {
-        good.forEach(function(p, i) { p.resolve(m.pre[i] && ok[i] === 1); });
+        good.forEach(function(p, i) {
+          try { p.resolve(verdict(g.ec, p.item, m.pre[i], ok[i])); } catch (e) { p.reject(e); }
+        });
       }, function(e) { good.forEach(function(p) { p.reject(e); }); });
     });
   }
-  eng.verifyAsync = function verifyAsync(ec, msg, signature, key, enc) {
+  // msg as the batch takes it: a non-empty array-like of BYTES (an Array with other elements goes
+  // through the reference's `new BN(msg, 16)`, which does not truncate them mod 256; an empty
+  // message is z = 0 there, not a zero-length digest)
+  function byteMessage(msg) {
+    if (!(Buffer.isBuffer(msg) || Array.isArray(msg) || msg instanceof Uint8Array) || msg.length === 0) return false;
+    if (Array.isArray(msg))
+      for (var i = 0; i < msg.length; i++) if ((msg[i] & 255) !== msg[i]) return false;
+    return true;
+  }
+  eng.verifyAsync = function verifyAsync(ec, msg, signature, key, enc, options) {
+    if (typeof enc === 'object' && enc !== null && options === undefined) { options = enc; enc = undefined; }
     var d = domain(ec.curve);
-    if (!d || ec.curve.type !== 'short' || !(Buffer.isBuffer(msg) || Array.isArray(msg) || msg instanceof Uint8Array)) {
+    if (!d || ec.curve.type !== 'short' || !byteMessage(msg)) {
       // outside the engine's batch domain: the (patched) synchronous path, as a Promise
-      return new Promise(function(resolve) { resolve(ec.verify(msg, signature, key, enc)); });
+      return new Promise(function(resolve) { resolve(ec.verify(msg, signature, key, enc, options)); });
     }
     return new Promise(function(resolve, reject) {
-      pendingVerify.push({ ec: ec, item: { msg: Buffer.from(msg), signature: signature, key: key, enc: enc },
-        resolve: resolve, reject: reject });
+      pendingVerify.push({ ec: ec, item: { msg: Buffer.from(msg), signature: signature, key: key, enc: enc,
+        options: options }, resolve: resolve, reject: reject });
       if (pendingVerify.length === 1) Promise.resolve().then(flushVerify);
     });
   };

@@ -32,9 +32,25 @@
  *     out_inf[i] = 1 with its x||y zeroed (the reference returns
  *     curve.point(null, null), short.js:253-256; for ed25519 the identity (0,1)
  *     is an ordinary point and out_inf mirrors Point#isInfinity()).
- *   - Input points are assumed to be on the curve, as in the reference
- *     (Point#mul does not validate).  Infinity as an INPUT is not representable;
- *     the JS layer short-circuits it exactly as short.js:424-425 does.
+ *   - DOMAIN: input points must lie ON the curve, and the callee CHECKS it, per item.
+ *     The reference does not validate on this path (ec/index.js:192 keyFromPublic,
+ *     ec/key.js:27-35, curve/short.js:422-432, curve/edwards.js:362-367): it runs its
+ *     formulas on any (x, y), and off the curve their outcome depends on the exact order of
+ *     its operations (wNAF / JSF digits, its GLV split, the window of G's shipped table) --
+ *     there is no group law to agree on.  The engine's ladders are different by design, so
+ *     an item with an operand that is not on the curve is OUTSIDE THE ENGINE'S DOMAIN and is
+ *     reported as such, never answered with a guess:
+ *         ELLGPU_STATUS_OFF_CURVE (= 2)  in out_inf[i] of ellgpu_mul_var / _mul_add2 (x||y
+ *                                        zeroed) and in out_ok[i] of ellgpu_ecdsa_verify and
+ *                                        ellgpu_ecdsa_verify_wire (there with out_err[i] = 5)
+ *     Callers that want the reference's answer for such an item run the reference on it
+ *     (elliptic_amd/js/index.js install() does exactly that; tests/golden/offcurve_*.json
+ *     pins what the reference answers).  ellgpu_point_add is the one exception: a single
+ *     chord / tangent formula, the reference's own, defined and equal off the curve too.
+ *     x-only ellgpu_x25519_ladder: every x is on the curve or its twist and the ladder is the
+ *     same function of (k, x) on both -- no such status.  Coordinates >= p are reduced mod p
+ *     first, as curve.point() does.  Infinity as an INPUT is not representable; the JS layer
+ *     short-circuits it exactly as short.js:424-425 does.
  *   - Per-item failures (bad r/s range, result at infinity) are per-item
  *     status bytes, never errors: EC#verify returns false, it does not throw
  *     (ec/index.js:199-202,222-223).
@@ -82,6 +98,9 @@ extern "C" {
 #define ELLGPU_E_HIP (-3)       /* HIP runtime error during the call */
 #define ELLGPU_E_NOMEM (-4)     /* device allocation failed */
 #define ELLGPU_E_UNSUPPORTED (-5) /* operation not defined for this curve (e.g. mulAdd on curve25519, mont.js:155) */
+
+/* per-item status in out_inf / out_ok: an operand is not on the curve (see DOMAIN above) */
+#define ELLGPU_STATUS_OFF_CURVE 2
 
 typedef struct ellgpu_ctx ellgpu_ctx;
 
@@ -152,14 +171,17 @@ int ellgpu_curve_define_edwards(ellgpu_ctx* ctx, const uint8_t* p, const uint8_t
 /* out[i] = k[i] * G */
 int ellgpu_mul_fixed(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
                      uint8_t* out_xy, uint8_t* out_inf);
-/* out[i] = k[i] * P[i] */
+/* out[i] = k[i] * P[i];  out_inf[i] = 0 finite, 1 infinity, 2 P[i] is not on the curve */
 int ellgpu_mul_var(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
                    const uint8_t* in_xy, uint8_t* out_xy, uint8_t* out_inf);
-/* out[i] = k1[i] * P1[i] + k2[i] * P2[i];  p1_xy == NULL means P1 = G */
+/* out[i] = k1[i] * P1[i] + k2[i] * P2[i];  p1_xy == NULL means P1 = G;
+ * out_inf[i] = 2 when P1[i] or P2[i] is not on the curve */
 int ellgpu_mul_add2(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1,
                     const uint8_t* p1_xy, const uint8_t* k2, const uint8_t* p2_xy,
                     uint8_t* out_xy, uint8_t* out_inf);
-/* out_ok[i] = EC#verify(hash[i], {r[i], s[i]}, pub[i]).
+/* out_ok[i] = EC#verify(hash[i], {r[i], s[i]}, pub[i]): 1 / 0, or 2 (ELLGPU_STATUS_OFF_CURVE)
+ * when r and s are in range but pub[i] is not on the curve -- the reference goes on to compute
+ * with such a key (and can answer true, tests/golden/offcurve_*.json), the engine does not guess.
  * hash: n x hash_len bytes, the message digest exactly as the caller would
  * pass it to EC#verify as an array (its length, not its value, drives the
  * truncation: ec/index.js:86-96).  msg_bits = 0 means hash_len*8; otherwise it
@@ -229,8 +251,8 @@ int ellgpu_validate_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy,
  * :279-309 for ed25519).  inf1 / inf2 (either may be NULL) flag operands that are the point at
  * infinity (the identity (0, 1) on ed25519); out_inf as for ellgpu_mul_var.  One launch of the
  * chord / tangent formula + the batched normalization, where the reference inverts once per
- * addition.  On the short curves the formulas are the reference's own, so off-curve operands give
- * the reference's coordinates as well. */
+ * addition.  The formulas are the reference's own, so off-curve operands give the reference's
+ * coordinates as well (add_*.json, offcurve_ed25519.json). */
 int ellgpu_point_add(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy1, const uint8_t* inf1,
                      const uint8_t* xy2, const uint8_t* inf2, uint8_t* out_xy, uint8_t* out_inf);
 int ellgpu_point_add_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy1, const uint8_t* inf1,
@@ -252,7 +274,9 @@ int ellgpu_point_add_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy
  *   decodePoint) and DER signatures as above; point decoding, DER parsing, the double-scalar
  *   multiplication and the x == r test all run on the device.  out_ok = 0/1; out_err (may be
  *   NULL) names the exception the reference throws, in its order: 1..3 = decodePoint's status
- *   for the key, 4 = 'Signature without r or s'; out_ok is 0 wherever out_err is not. */
+ *   for the key, 4 = 'Signature without r or s'; out_ok is 0 wherever out_err is 1..4.
+ *   out_err 5 is no exception: an uncompressed key that is not on the curve with r, s in range,
+ *   out_ok = 2 (ELLGPU_STATUS_OFF_CURVE) -- hand the item to the reference. */
 int ellgpu_sig_from_der(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* der, size_t stride,
                         const uint32_t* der_len, uint8_t* out_r, uint8_t* out_s, uint8_t* out_status);
 int ellgpu_sig_from_der_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* der, size_t stride,

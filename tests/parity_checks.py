@@ -100,7 +100,7 @@ def check_verify_golden(ctx, curve):
             continue                      # outside the C ABI's documented domain
         ok = ctx.ecdsa_verify(curve, hashes, r, s, pub, msg_bits=mbits)
         for i, c in enumerate(cs):
-            assert bool(ok[i]) == c["ok"], (curve, c)
+            assert ok[i] == (1 if c["ok"] else 0), (curve, c, int(ok[i]))
             n_checked += 1
     return n_checked
 
@@ -563,6 +563,18 @@ def check_custom_short_golden(ctx, spec):
     out, inf = ctx.mul_var(cid, ints_to_be([1 << c["pow"] for c in dbl], 32), xy([c["p"] for c in dbl]))
     for i, c in enumerate(dbl):
         assert _res_from(out, inf, i, 32) == want(c["r"]), ("dblp", spec["name"], c)
+    # operands off the curve are reported, not guessed: every multiplicand with y + 1 (never on the
+    # curve together with (x, y) unless y = (p - 1) / 2) -> out_inf = 2, result zeroed
+    off = xy([c["p"] for c in mul])
+    really_off = [(I(c["p"]["y"]) + 1) % p != (-I(c["p"]["y"])) % p for c in mul]
+    off[:, 32:] = ints_to_be([(I(c["p"]["y"]) + 1) % p for c in mul], 32)
+    out, inf = ctx.mul_var(cid, ints_to_be([I(c["k"]) for c in mul], 32), off)
+    for i, c in enumerate(mul):
+        if really_off[i]:
+            assert inf[i] == 2 and not out[i].any(), ("off-curve mul", spec["name"], c)
+    out, inf = ctx.mul_add2(cid, ints_to_be([I(c["k"]) for c in mul], 32), xy([c["p"] for c in mul]),
+                            ints_to_be([I(c["k"]) for c in mul], 32), off)
+    assert all(inf[i] == 2 and not out[i].any() for i in range(len(mul)) if really_off[i]), spec["name"]
     return len(mul) + len(madd) + len(add) + len(dbl)
 
 
@@ -609,6 +621,17 @@ def check_custom_edwards_golden(ctx, spec):
     got, _ = ctx.mul_add2(cid, ks[:m], xy([c["p"] for c in mul[:m]]), ks[m:2 * m], xy([c["p"] for c in mul[m:2 * m]]))
     want, _ = ctx.point_add(cid, xy([c["r"] for c in mul[:m]]), xy([c["r"] for c in mul[m:2 * m]]))
     assert np.array_equal(got, want)
+    # operands off the curve (x + 1 instead of x) are reported, not guessed
+    off = xy([c["p"] for c in mul])
+    off[:, :32] = ints_to_be([(I(c["p"]["x"]) + 1) % p for c in mul], 32)
+    offc = [(a * ((I(c["p"]["x"]) + 1) ** 2) + I(c["p"]["y"]) ** 2 - 1 - d * ((I(c["p"]["x"]) + 1) ** 2) * I(c["p"]["y"]) ** 2) % p != 0
+            for c in mul]
+    out, inf = ctx.mul_var(cid, ks, off)
+    assert any(offc)
+    for i in range(len(mul)):
+        assert (inf[i] == 2 and not out[i].any()) if offc[i] else inf[i] == 0, ("off-curve mul", spec["name"], i)
+    out, inf = ctx.mul_add2(cid, ks, xy([c["p"] for c in mul]), ks, off)
+    assert all(inf[i] == 2 for i in range(len(mul)) if offc[i])
     return len(mul) + len(add) + len(dbl) + m
 
 
@@ -632,3 +655,81 @@ def comb_boundary_scalars(bits, cb, count, seed=22):
             k |= v << (cb * w)
         out.append(k & ((1 << bits) - 1))
     return out
+
+
+def check_offcurve_golden(ctx, curve):
+    """offcurve_<curve>.json: operands that are NOT on the curve.  The reference computes with
+    them (the file holds what it answers); the engine's C ABI must report every such item as
+    outside its domain -- out_inf = 2 with a zeroed result, out_ok = 2 -- never a guess, and
+    must go on computing the on-curve items of the same batch.  Returns the number of items."""
+    from golden_util import load
+    B = FIELD_BYTES[curve]
+    cases = load("offcurve_%s.json" % curve)
+
+    def pts(cs, x, y):
+        return np.concatenate([ints_to_be([I(c[x]) for c in cs], B), ints_to_be([I(c[y]) for c in cs], B)], axis=1)
+
+    def point_results(out, inf, cs, what):
+        for i, c in enumerate(cs):
+            if c["on"]:
+                assert inf[i] in (0, 1) and _res_from(out, inf, i, B) == res_xy(c["r"]), (what, curve, c)
+            else:
+                assert inf[i] == 2 and not out[i].any(), (what, curve, c, int(inf[i]))
+
+    total = 0
+    var = [c for c in cases if c["op"] == "var"]
+    out, inf = ctx.mul_var(curve, ints_to_be([I(c["k"]) for c in var], B), pts(var, "px", "py"))
+    point_results(out, inf, var, "var")
+    assert sum(1 for c in var if c["on"]) >= 2 and sum(1 for c in var if not c["on"]) >= 10
+    total += len(var)
+    madd = [c for c in cases if c["op"] == "muladd"]
+    k1 = ints_to_be([I(c["k1"]) for c in madd], B)
+    k2 = ints_to_be([I(c["k2"]) for c in madd], B)
+    out, inf = ctx.mul_add2(curve, k1, pts(madd, "p1x", "p1y"), k2, pts(madd, "p2x", "p2y"))
+    point_results(out, inf, madd, "muladd")
+    gi = [i for i, c in enumerate(madd) if c["g1"]]
+    out, inf = ctx.mul_add2(curve, k1[gi], None, k2[gi], pts([madd[i] for i in gi], "p2x", "p2y"))
+    point_results(out, inf, [madd[i] for i in gi], "muladd-G")
+    total += len(madd) + len(gi)
+    add = [c for c in cases if c["op"] == "add"]
+    if add:                       # Point#add is one formula: equal off the curve too
+        p = np.frombuffer(b"".join(bytes.fromhex(c["p"]["x"] + c["p"]["y"]) for c in add), np.uint8).reshape(-1, 2 * B)
+        q = np.frombuffer(b"".join(bytes.fromhex(c["q"]["x"] + c["q"]["y"]) for c in add), np.uint8).reshape(-1, 2 * B)
+        out, inf = ctx.point_add(curve, p, q)
+        for i, c in enumerate(add):
+            assert out[i].tobytes().hex() == c["r"]["x"] + c["r"]["y"], ("add", c)
+        total += len(add)
+    ver = [c for c in cases if c["op"] == "verify"]
+    if not ver:
+        return total
+    NB = ORDER_BYTES[curve]
+    hl = len(ver[0]["z"]) // 2
+    from oracle import ec_oracle as O
+    n = O.get_curve(curve).n
+    z = ints_to_be([I(c["z"]) for c in ver], hl)
+    r = ints_to_be([I(c["r"]) for c in ver], NB)
+    s = ints_to_be([I(c["s"]) for c in ver], NB)
+    pub = pts(ver, "qx", "qy")
+    ok = ctx.ecdsa_verify(curve, z, r, s, pub)
+    n_dom = 0
+    for i, c in enumerate(ver):
+        in_range = 0 < I(c["r"]) < n and 0 < I(c["s"]) < n
+        if c["on"] or not in_range:
+            # on the curve, or rejected before the key is touched (ec/index.js:199-202): a verdict
+            assert ok[i] == (1 if c["ok"] else 0), (curve, c, int(ok[i]))
+        else:
+            assert ok[i] == 2, (curve, c, int(ok[i]))
+            n_dom += 1
+    assert n_dom >= 9 and sum(1 for c in ver if c["ok"] and not c["on"]) >= 8
+    # the same tuples through the wire form: DER signatures + uncompressed keys
+    inr = [i for i, c in enumerate(ver) if 0 < I(c["r"]) < n and 0 < I(c["s"]) < n]
+    ders = ctx.sig_to_der(curve, r[inr], s[inr])
+    keys = np.concatenate([np.full((len(inr), 1), 4, np.uint8), pub[inr]], axis=1)
+    wok, werr = ctx.ecdsa_verify_wire(curve, z[inr], ders, keys)
+    for j, i in enumerate(inr):
+        c = ver[i]
+        if c["on"]:
+            assert (wok[j], werr[j]) == (1 if c["ok"] else 0, 0), ("wire", curve, c)
+        else:
+            assert (wok[j], werr[j]) == (2, 5), ("wire", curve, c, int(wok[j]), int(werr[j]))
+    return total + len(ver) + len(inr)

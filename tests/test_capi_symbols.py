@@ -106,3 +106,32 @@ def test_product_does_not_reference_oracle():
                                 continue
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_reading_the_digest_does_not_map_the_library(tmp_path):
+    """build.library_digest() must not dlopen the library in the calling process: glibc matches
+    loaded objects by path, so a relinked file at the same path would later resolve to the OLD
+    mapping (build() then smoke() in one process).  Done with two toy libraries in a child process:
+    read the digest of the first, replace the file, load it -- the NEW code must answer."""
+    import subprocess
+    import sys
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    so = tmp_path / "libtoy.so"
+    for tag in ("old", "new"):
+        c = tmp_path / ("toy_%s.c" % tag)
+        c.write_text('const char* ellgpu_source_digest(void) { return "%s"; }\n' % tag)
+        subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(tmp_path / ("libtoy_%s.so" % tag)), str(c)], check=True)
+    code = (
+        "import ctypes, os, shutil, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from elliptic_amd import build as b\n"
+        "d, so = sys.argv[1], sys.argv[2]\n"
+        "shutil.copy(os.path.join(d, 'libtoy_old.so'), so)\n"
+        "assert b.library_digest(so) == 'old'\n"
+        "assert not any('libtoy' in l for l in open('/proc/self/maps'))\n"
+        "shutil.copy(os.path.join(d, 'libtoy_new.so'), so + '.tmp'); os.replace(so + '.tmp', so)\n"
+        "fn = ctypes.CDLL(so).ellgpu_source_digest; fn.restype = ctypes.c_char_p\n"
+        "assert fn() == b'new', fn()\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code, str(tmp_path), str(so)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr

@@ -35,6 +35,52 @@ def test_x25519_golden(ctx):
     assert PC.check_x25519_golden(ctx) > 30
 
 
+@pytest.mark.parametrize("curve", O.SHORT_CURVES + ["ed25519"])
+def test_offcurve_operands_are_reported_not_guessed(ctx, curve):
+    """offcurve_<curve>.json: points that are not on the curve get status 2 (out_inf / out_ok),
+    a zeroed result, and leave the on-curve items of the same batch untouched"""
+    assert PC.check_offcurve_golden(ctx, curve) >= 29
+
+
+def test_offcurve_keys_scattered_in_a_full_size_batch(ctx, monkeypatch):
+    """2^20 verifies with every 1000th key moved off the curve (y + 1): exactly those items -- minus
+    the ones whose r / s are out of range, which the reference rejects before it touches the key
+    -- answer 2, every other verdict is the expected mask; same for the small-grid tuning on a
+    131 072-item shard and for P*k through the host-buffer pipeline."""
+    n = 1 << 20
+    h, r, s, pub, expect = _make_sigs(ctx, n, "gpu-test-fullsize")
+    pub = pub.copy()
+    off = np.arange(7, n, 1000)
+    p = O.get_curve("secp256k1").p
+    for i in off:
+        y = (int.from_bytes(pub[i, 32:].tobytes(), "big") + 1) % p
+        pub[i, 32:] = np.frombuffer(y.to_bytes(32, "big"), np.uint8)
+    want = expect.copy()
+    want[off] = 2
+    nn = O.get_curve("secp256k1").n
+    for i in off:                        # corrupted r / s can leave [1, n): rejected first
+        ri, si = int.from_bytes(r[i].tobytes(), "big"), int.from_bytes(s[i].tobytes(), "big")
+        if not (0 < ri < nn and 0 < si < nn):
+            want[i] = 0
+    got = ctx.ecdsa_verify("secp256k1", h, r, s, pub)
+    assert np.array_equal(got, want)
+    m = 131072
+    assert np.array_equal(ctx.ecdsa_verify("secp256k1", h[:m], r[:m], s[:m], pub[:m]), want[:m])
+    monkeypatch.setenv("ELLGPU_SMALL_GRID", "0")            # the full-grid tuning on the same shard
+    assert np.array_equal(ctx.ecdsa_verify("secp256k1", h[:m], r[:m], s[:m], pub[:m]), want[:m])
+    monkeypatch.delenv("ELLGPU_SMALL_GRID")
+    m = 300000
+    xy, inf = ctx.mul_var("secp256k1", r[:m], pub[:m])
+    is_off = np.zeros(m, bool)
+    is_off[off[off < m]] = True
+    assert (inf[is_off] == 2).all() and not xy[is_off].any() and (inf[~is_off] == 0).all()
+    xy0, inf0 = ctx.mul_var("secp256k1", r[:2048], pub[:2048])
+    from oracle import c_oracle
+    wxy, winf = c_oracle.mul("secp256k1", r[:2048], pub[:2048])    # the oracle computes off-curve items too
+    on = ~is_off[:2048]
+    assert np.array_equal(xy0[on], wxy[on]) and np.array_equal(inf0[on], winf[on])
+
+
 @pytest.mark.parametrize("curve", O.SHORT_CURVES)
 def test_verify_golden(ctx, curve):
     assert PC.check_verify_golden(ctx, curve) > 15

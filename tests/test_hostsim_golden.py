@@ -246,6 +246,11 @@ def test_mul_golden(ctx, curve):
     assert PC.check_mul_golden(ctx, curve) > 50
 
 
+@pytest.mark.parametrize("curve", O.SHORT_CURVES + ["ed25519"])
+def test_offcurve_operands_are_reported_not_guessed(ctx, curve):
+    assert PC.check_offcurve_golden(ctx, curve) >= 29
+
+
 def test_x25519_golden(ctx):
     assert PC.check_x25519_golden(ctx) > 30
 

@@ -352,6 +352,10 @@ def test_ed25519_offcurve_matches_reference():
     for c in load("offcurve_ed25519.json"):
         if c["op"] == "var":
             R = cur.point(I(c["px"]), I(c["py"])).mul(I(c["k"]))
+        elif c["op"] == "add":
+            R = cur.point(I(c["p"]["x"]), I(c["p"]["y"])).add(cur.point(I(c["q"]["x"]), I(c["q"]["y"])))
+            assert R.normalized() == res_xy(c["r"]), c
+            continue
         else:
             R = cur.g.mul_add(I(c["k1"]), cur.point(I(c["p2x"]), I(c["p2y"])), I(c["k2"]))
         got = None if R.is_infinity() else R.normalized()

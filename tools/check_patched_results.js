@@ -1,7 +1,8 @@
 'use strict';
 // Differential check of the patched public API against the golden files (which were produced
 // by the unpatched reference): EC#recoverPubKey, EDDSA#sign, EDDSA#verify and pointFromX /
-// pointFromY through install(), including the MESSAGE of every exception the reference throws.
+// pointFromY through install(), including the MESSAGE of every exception the reference throws,
+// and the reference's answers on points that are not on the curve (offcurve_*.json).
 // Build container only (needs /root/reference).
 //
 //   ELLGPU_LIB=tests/hostsim/_build/libellgpu_hostsim.so node tools/check_patched_results.js
@@ -91,4 +92,64 @@ load('eddsa_verify_ed25519.json').forEach(function(c) {
     checked++;
   });
 })();
-console.log(JSON.stringify({ ok: true, checked: checked, thrown: thrown, engine: eng.stats }));
+// Points that are not on the curve (offcurve_<curve>.json): the reference computes with them, the
+// engine reports them with status 2, and install() hands those items to the reference's own
+// method -- so the patched library must return the reference's answer: Point#mul, mulAdd /
+// jmulAdd, EC#verify (incl. the tuples the reference answers TRUE on), verifyMany and the
+// coalescing verifyAsync.
+var pendingAsync = [];
+['secp256k1', 'p192', 'p224', 'p256', 'p384', 'p521', 'ed25519'].forEach(function(name) {
+  var pc = elliptic.curves[name];
+  var curve = pc.curve;
+  var L = curve.p.byteLength();
+  var before = eng.stats.offCurve;
+  var nOff = 0;
+  function same(pt, r) {
+    if (r.inf && r.x === undefined) return pt.isInfinity();
+    return !pt.isInfinity() || name === 'ed25519' ? (pt.getX().toString(16, 2 * L) === r.x &&
+      pt.getY().toString(16, 2 * L) === r.y) : false;
+  }
+  var ec = curve.type === 'short' ? new elliptic.ec(pc) : null;
+  if (!ec) curve.g.precompute(curve.n.bitLength() + 1);           // as EDDSA's constructor does
+  var items = [], wants = [];
+  load('offcurve_' + name + '.json').forEach(function(c) {
+    if (c.op === 'var') {
+      if (!same(curve.point(c.px, c.py).mul(new ref.BN(c.k, 16)), c.r)) throw new Error('off-curve mul mismatch: ' + name);
+      if (!c.on) nOff++;
+    } else if (c.op === 'muladd') {
+      var A = c.g1 ? curve.g : curve.point(c.p1x, c.p1y);
+      var B = curve.point(c.p2x, c.p2y);
+      if (!same(A.mulAdd(new ref.BN(c.k1, 16), B, new ref.BN(c.k2, 16)), c.r)) throw new Error('off-curve mulAdd mismatch: ' + name);
+      if (curve.type === 'short') {
+        var J = A.jmulAdd(new ref.BN(c.k1, 16), B, new ref.BN(c.k2, 16));
+        if (!same(J.toP ? J.toP() : J, c.r)) throw new Error('off-curve jmulAdd mismatch: ' + name);
+      }
+      if (!c.on) nOff++;
+    } else if (c.op === 'add') {
+      var S = curve.point(c.p.x, c.p.y).add(curve.point(c.q.x, c.q.y));
+      if (!same(S, c.r)) throw new Error('off-curve add mismatch: ' + name);
+    } else {
+      var key = { x: c.qx, y: c.qy };
+      if (ec.verify(c.z, { r: c.r, s: c.s }, key) !== c.ok) throw new Error('off-curve verify mismatch: ' + name + ' ' + c.note);
+      items.push({ msg: Buffer.from(c.z, 'hex'), signature: { r: c.r, s: c.s }, key: key });
+      wants.push(c.ok);
+    }
+    checked++;
+  });
+  if (eng.stats.offCurve - before < nOff) throw new Error('off-curve items did not reach the engine: ' + name);
+  if (!ec) return;
+  var got = eng.verifyMany(ec, items);
+  for (var i = 0; i < items.length; i++)
+    if (got[i] !== wants[i]) throw new Error('off-curve verifyMany mismatch: ' + name + ' #' + i);
+  checked += items.length;
+  pendingAsync.push(Promise.all(items.map(function(it) {
+    return eng.verifyAsync(ec, it.msg, it.signature, it.key);
+  })).then(function(res) {
+    for (var i = 0; i < items.length; i++)
+      if (res[i] !== wants[i]) throw new Error('off-curve verifyAsync mismatch: ' + name + ' #' + i);
+    checked += items.length;
+  }));
+});
+Promise.all(pendingAsync).then(function() {
+  console.log(JSON.stringify({ ok: true, checked: checked, thrown: thrown, engine: eng.stats }));
+}, function(e) { console.error(e.stack || e); process.exit(1); });

@@ -661,6 +661,7 @@ function genAdd(name) {
 //           (R = u1 G + u2 Q as the reference computes it, r = R.x mod n, s = r / u2,
 //           z = u1 s), plus corrupted ones it answers false, plus r / s out of range
 //   on      control items (on-curve points) mixed in: the engine must still compute those
+//   add     (ed25519) Point#add of off-curve operands: one formula, equal in the engine
 function genOffCurve(name) {
   var pc = elliptic.curves[name];
   var c = pc.curve;
@@ -717,7 +718,18 @@ function genOffCurve(name) {
     rec('muladd', { k1: hex(k1, L), p1x: aa.x, p1y: aa.y, k2: hex(k2, L), p2x: bb.x, p2y: bb.y,
       g1: kind === 0, on: kind === 4, r: affine(c, A.mulAdd(k1, B, k2)) });
   }
-  if (!short) return cases;
+  if (!short) {
+    // Point#add (edwards.js:350-360 -> _extAdd): ONE formula, so the engine's ellgpu_point_add
+    // has to give the reference's coordinates off the curve as well
+    for (i = 0; i < N; i++) {
+      var U = offPoint(), V = (i % 3 === 0) ? U : (i % 3 === 1 ? onPoint() : offPoint());
+      var S = U.add(V);
+      var ua = xy(U), va = xy(V);
+      rec('add', { p: { x: ua.x, y: ua.y }, q: { x: va.x, y: va.y },
+        r: { x: hex(S.getX(), L), y: hex(S.getY(), L) } });
+    }
+    return cases;
+  }
   // ECDSA over off-curve keys
   var ec = new elliptic.ec(pc);
   var NL = c.n.byteLength();
