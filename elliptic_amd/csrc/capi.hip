@@ -172,11 +172,14 @@ static int ell_backend_create(int device, ell::HipBackend* bk, std::string* err)
     return ell::E_NODEVICE;
   }
   bk->device = device;
+  if (prop.multiProcessorCount > 0) bk->cus = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&bk->own, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; return ell::E_HIP; }
   bk->cur = bk->own;
   if (hipStreamCreateWithFlags(&bk->copy, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&bk->copy_out, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&bk->own2, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; return ell::E_HIP; }
+      hipStreamCreateWithFlags(&bk->own2, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&bk->side[0], hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&bk->side[1], hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; return ell::E_HIP; }
   for (int i = 0; i < ell::HipBackend::RING; i++)
     if (hipEventCreateWithFlags(&bk->ring[i], hipEventDisableTiming) != hipSuccess) { *err = "hipEventCreate failed"; return ell::E_HIP; }
   if (hipEventCreateWithFlags(&bk->inflight_done, hipEventDisableTiming) != hipSuccess) { *err = "hipEventCreate failed"; return ell::E_HIP; }
@@ -191,6 +194,7 @@ static void ell_backend_destroy(ell::HipBackend* bk) {
   bk->copy_out = nullptr;
   if (bk->own2) (void)hipStreamDestroy(bk->own2);
   bk->copy = bk->own2 = nullptr;
+  for (int i = 0; i < 2; i++) { if (bk->side[i]) (void)hipStreamDestroy(bk->side[i]); bk->side[i] = nullptr; }
   for (int i = 0; i < ell::HipBackend::RING; i++)
     if (bk->ring[i]) { (void)hipEventDestroy(bk->ring[i]); bk->ring[i] = nullptr; }
   if (bk->inflight_done) { (void)hipEventDestroy(bk->inflight_done); bk->inflight_done = nullptr; }

@@ -58,9 +58,20 @@
 #ifndef ELL_ECDSA_MIN_WAVES
 #define ELL_ECDSA_MIN_WAVES 3
 #endif
-// batches of at most this many verifies (three waves on every SIMD) take the WIDE ecdsa_main
-#ifndef ELL_SMALL_GRID
-#define ELL_SMALL_GRID ((size_t)256 * 4 * 64 * 3)
+// (batches of at most three waves on every SIMD take the WIDE ecdsa_main: Engine::Tuning)
+// ecdsa_table (the window table of the small-grid verify, built beside ecdsa_prep): waves per
+// SIMD its register budget leaves room for
+#ifndef ELL_ECDSA_TABLE_MIN_WAVES
+#define ELL_ECDSA_TABLE_MIN_WAVES 4
+#endif
+// 1 (default): small-grid secp256k1 verifies run as prep || table -> ladder; 0: prep -> main
+#ifndef ELL_SPLIT_SMALL_VERIFY
+#define ELL_SPLIT_SMALL_VERIFY 1
+#endif
+// entries per slice of the fixed-base table build (Engine::ensure_comb); the CPU unit-test build
+// of these headers passes a small value so that its narrow combs are built in several slices too
+#ifndef ELL_COMB_SLICE
+#define ELL_COMB_SLICE (1u << 20)
 #endif
 #ifndef ELL_P521_MIN_WAVES
 #define ELL_P521_MIN_WAVES 1        // (the p521 ladders take 232-234 VGPRs: two waves either way; 3 waves spill 560 B)
@@ -200,10 +211,15 @@ struct FnEdcDomainMark {
     if (i < n) EdcWork::domain_mark(i, xy1, xy2, out_xy, out_inf);
   }
 };
-template <class CV>
+// MW != 0: a second instantiation held to 512 / MW registers (its own translation unit, default
+// scheduling strategy): the one that runs BESIDE ecdsa_table in the small-grid verify -- at 216
+// registers two waves of ecdsa_prep leave a SIMD no room for anything else, and the two kernels
+// would take turns instead of sharing it (profiles/r04_split_verify_ab.txt)
+template <class CV, int MW = 0>
 struct FnEcdsaPrep {
   static constexpr const char* NAME = "ecdsa_prep";
   typedef Work<CV> W;
+  static constexpr int MIN_WAVES = MW ? MW : 1;
   static constexpr int DS_PER_LANE = 0;
   size_t T; size_t n; int K; const u8* hash; int hash_len; int shift; const u8* r; const u8* s;
   u32* pre; u32* u12; u8* valid;
@@ -225,6 +241,31 @@ struct FnEcdsaMain {
   const typename W::A* comb; typename W::VT* tbl; u8* ok;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) W::template ecdsa_main<WIDE>(i, n, u12, valid, r, pub, comb, tbl, ds, ok);
+  }
+};
+// the small-grid verify in two kernels (Work::ecdsa_table / ecdsa_ladder): the table kernel runs
+// beside ecdsa_prep, the ladder after both
+template <class CV, bool WIDE = true>
+struct FnEcdsaTable {
+  static constexpr const char* NAME = "ecdsa_table";
+  typedef Work<CV> W;
+  static constexpr int MIN_WAVES = ELL_ECDSA_TABLE_MIN_WAVES;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* pub; typename W::VT* tbl;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::template ecdsa_table<WIDE>(i, n, pub, tbl);
+  }
+};
+template <class CV, bool WIDE = true>
+struct FnEcdsaLadder {
+  static constexpr const char* NAME = "ecdsa_main";      // the timing name of pass 2 in either form
+  typedef Work<CV> W;
+  static constexpr int MIN_WAVES = 3;
+  static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
+  size_t n; const u32* u12; const u8* valid; const u8* r; const u8* pub;
+  const typename W::A* comb; const typename W::VT* tbl; u8* ok;
+  ELL_HD void operator()(size_t i, const DigitStore& ds) const {
+    if (i < n) W::template ecdsa_ladder<WIDE>(i, n, u12, valid, r, pub, comb, tbl, ds, ok);
   }
 };
 
@@ -598,24 +639,43 @@ class Engine {
   // give every SIMD a wave (one inversion costs about what two items' other work does; a batch
   // of 131 072 verifies -- one GPU's share of 2^20 over eight -- ran its prep on 256 waves, one
   // per CU, at the lone-wave issue rate: 0.137 ms of a 1.52 ms pass).  ELLGPU_PREP_K overrides.
-  // largest batch that takes the small-grid (WIDE) kernels; ELLGPU_SMALL_GRID overrides (tests run
-  // both tunings of a kernel on the same inputs with it; 0 = never)
-  static size_t small_grid() {
+  // Batch-size dependent tuning, fixed when the context is created: the device's geometry comes
+  // from the backend (compute units of THIS device, not a constant), the developer / test
+  // overrides from the environment, read once here -- never at launch time:
+  //   ELLGPU_SMALL_GRID    largest batch that takes the small-grid (WIDE) kernels (0 = never);
+  //                        default: three waves on every SIMD of the device
+  //   ELLGPU_SPLIT_VERIFY  0 keeps small-grid verifies on prep -> ecdsa_main (default: prep ||
+  //                        table -> ladder)
+  //   ELLGPU_PREP_K        items per inversion in the scalar-field kernels (default: by batch size)
+  struct Tuning {
+    size_t wave_round;        // lanes of one wave on every SIMD of the device
+    size_t small_grid;
+    bool split_verify;
+    int prep_k;
+  };
+  Tuning tune_;
+  void init_tuning() {
+    tune_.wave_round = (size_t)bk.compute_units() * 4 * 64;
     const char* e = getenv("ELLGPU_SMALL_GRID");
-    return e ? (size_t)strtoull(e, nullptr, 10) : ELL_SMALL_GRID;
+    tune_.small_grid = e ? (size_t)strtoull(e, nullptr, 10) : 3 * tune_.wave_round;
+    e = getenv("ELLGPU_SPLIT_VERIFY");
+    tune_.split_verify = !(e && e[0] == '0');
+    e = getenv("ELLGPU_PREP_K");
+    tune_.prep_k = e ? atoi(e) : 0;
   }
-  static int inv_batch_for(size_t n, int kmax) {
-    static const int forced = []() { const char* e = getenv("ELLGPU_PREP_K"); return e ? atoi(e) : 0; }();
-    if (forced >= 1 && forced <= 64) return forced;
-    const size_t lanes = (size_t)256 * 4 * 64;             // one wave on every SIMD
+  size_t small_grid() const { return tune_.small_grid; }
+  bool split_small_verify() const { return tune_.split_verify; }
+  int inv_batch_for(size_t n, int kmax) const {
+    if (tune_.prep_k >= 1 && tune_.prep_k <= 64) return tune_.prep_k;
     int k = kmax;
-    while (k > 1 && n / (size_t)k < 2 * lanes) k >>= 1;
+    while (k > 1 && n / (size_t)k < 2 * tune_.wave_round) k >>= 1;
     return k;
   }
   static constexpr size_t CHUNK = 1u << 21;   // max items per launch (bounds the scratch arena)
 
   explicit Engine(const BK& b) : bk(b) {
     for (int i = 0; i < CURVE_COUNT; i++) comb_[i] = nullptr;
+    init_tuning();
   }
   ~Engine() {
     for (int i = 0; i < CURVE_COUNT; i++)
@@ -1763,7 +1823,7 @@ int Engine<BK>::ensure_comb() {
   // curves has 25 M entries = 1.6 GB; a slice needs 1 GB of window-table scratch).
   const size_t n = W::COMB_ENTRIES;
   const int B = W::BYTES;
-  const size_t slice = n < ((size_t)1 << 20) ? n : ((size_t)1 << 20);
+  const size_t slice = n < (size_t)ELL_COMB_SLICE ? n : (size_t)ELL_COMB_SLICE;
   void* comb = bk.alloc(n * sizeof(typename W::A));
   u8* dk = (u8*)bk.alloc(slice * B);
   u8* dp = (u8*)bk.alloc(slice * 2 * B);
@@ -1780,7 +1840,8 @@ int Engine<BK>::ensure_comb() {
     bk.launch(g, m);
     rc = mul_var_chunk<CV>(m, dk, dp, nullptr, nullptr, (typename W::A*)comb + first);
   }
-  bk.sync();
+  const int src = bk.sync();                     // a failed launch (comb_gen included) surfaces here
+  if (rc == E_OK && src != E_OK) rc = fail(src, "building the fixed-base table failed on the device");
   bk.free_(dk);
   bk.free_(dp);
   if (rc) { bk.free_(comb); return rc; }
@@ -1807,12 +1868,17 @@ template <class CV>
 int Engine<BK>::mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u8* out_inf,
                   typename Work<CV>::A* raw) {
   typedef Work<CV> W;
-  typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::VT));
+  // the window-table scratch is sized by the tuning that is launched (the small-grid tuning's
+  // 5-bit windows take twice the slots per item of the full-grid tuning's)
+  bool wide = false;
+  if constexpr (CV::ENDO && W::L <= 8) wide = n <= small_grid();
+  const size_t slots = wide ? (size_t)W::template stride<true>() : (size_t)W::template stride<false>();
+  typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * slots * sizeof(typename W::VT));
   u32* jac = (u32*)scratch(S_JAC, n * 3 * W::NS * 4);
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
   bool launched = false;
   if constexpr (CV::ENDO && W::L <= 8) {
-    if (n <= small_grid()) {                // at most three waves per SIMD: the register-rich tuning
+    if (wide) {                             // at most three waves per SIMD: the register-rich tuning
       FnMulVar<CV, 3, true> f{n, k, xy, tbl, jac};
       launch_fn(f, n);
       launched = true;
@@ -1876,7 +1942,7 @@ int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* 
                     u8* out_inf) {
   typedef Work<CV> W;
   u32* jac = (u32*)scratch(S_JAC, n * 3 * W::NS * 4);
-  typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::VT));
+  typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * (size_t)W::template stride<false>() * sizeof(typename W::VT));
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
   if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
     FnMulAddG<CV, (W::L > 12 ? 2 : 0)> f{n, k1, k2, xy2, (const typename W::A*)comb_[CV::ID], tbl, jac};
@@ -1934,7 +2000,10 @@ template <class CV>
 int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* r, const u8* s,
                 const u8* pub, u8* ok) {
   typedef Work<CV> W;
-  typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * W::TBL1 * sizeof(typename W::VT));
+  bool wide = false;
+  if constexpr (CV::ENDO && W::L <= 8) wide = n <= small_grid();
+  const size_t slots = wide ? (size_t)W::template stride<true>() : (size_t)W::template stride<false>();
+  typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * slots * sizeof(typename W::VT));
   u32* pre = (u32*)scratch(S_PRE, n * (W::LN > W::NS ? W::LN : W::NS) * 4);
   u32* u12 = (u32*)scratch(S_U12, n * 2 * W::LN * 4);
   u8* valid = (u8*)scratch(S_VALID, n);
@@ -1942,6 +2011,21 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
   const int K = inv_batch_for(n, INV_BATCH_N);
   size_t T = (n + K - 1) / K;
   FnEcdsaPrep<CV> f1{T, n, K, hash, hash_len, shift, r, s, pre, u12, valid};
+  if constexpr (CV::ENDO && W::L <= 8 && ELL_SPLIT_SMALL_VERIFY) {
+    if (wide && split_small_verify()) {
+      // latency-bound batch: the window table does not depend on s^-1, so it is built while
+      // ecdsa_prep runs on the side stream; the ladder waits for both
+      bk.fork_side();
+      FnEcdsaPrep<CV, ELL_ECDSA_TABLE_MIN_WAVES> fs{T, n, K, hash, hash_len, shift, r, s, pre, u12, valid};
+      launch_fn(fs, T);
+      bk.leave_side();
+      FnEcdsaTable<CV, true> ft{n, pub, tbl};
+      launch_fn(ft, n);
+      bk.join_side();
+      FnEcdsaLadder<CV, true> fl{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
+      return launch_fn(fl, n);
+    }
+  }
   launch_fn(f1, T);
   if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
     FnEcdsaMain<CV, (W::L > 12 ? 2 : 0)> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
@@ -1949,7 +2033,7 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
     return E_OK;
   }
   if constexpr (CV::ENDO && W::L <= 8) {
-    if (n <= small_grid()) {                // at most three waves per SIMD: the register-rich tuning
+    if (wide) {                             // at most three waves per SIMD: the register-rich tuning
       FnEcdsaMain<CV, 3, true> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
       return launch_fn(f2, n);
     }

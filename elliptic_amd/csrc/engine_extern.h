@@ -52,7 +52,13 @@ namespace ell {
   KW template int Engine<HipBackend>::launch_fn<FnEcdsaMain<CvSecp256k1, 3, true>>(                  \
       const FnEcdsaMain<CvSecp256k1, 3, true>&, size_t);                                             \
   KW template int Engine<HipBackend>::launch_fn<FnMulVar<CvSecp256k1, 3, true>>(                     \
-      const FnMulVar<CvSecp256k1, 3, true>&, size_t);
+      const FnMulVar<CvSecp256k1, 3, true>&, size_t);                                                \
+  KW template int Engine<HipBackend>::launch_fn<FnEcdsaPrep<CvSecp256k1, ELL_ECDSA_TABLE_MIN_WAVES>>(  \
+      const FnEcdsaPrep<CvSecp256k1, ELL_ECDSA_TABLE_MIN_WAVES>&, size_t);                             \
+  KW template int Engine<HipBackend>::launch_fn<FnEcdsaTable<CvSecp256k1, true>>(                    \
+      const FnEcdsaTable<CvSecp256k1, true>&, size_t);                                               \
+  KW template int Engine<HipBackend>::launch_fn<FnEcdsaLadder<CvSecp256k1, true>>(                   \
+      const FnEcdsaLadder<CvSecp256k1, true>&, size_t);
 // user-defined short curves (CvCustom): scalar multiplication and point addition only
 #define ELL_DECL_CUSTOM(KW)                                                                          \
   KW template int Engine<HipBackend>::mul_var_chunk<CvCustom>(size_t, const u8*, const u8*, u8*, u8*, \

@@ -1069,6 +1069,52 @@ struct Work {
     return F::eq(p.X, F::mul(F::from_plain(rn), zz));
   }
 
+  // ---- the small-grid form of pass 2, in two kernels (secp256k1) ---------------------------
+  // A batch that leaves two or three waves per SIMD resident (one GPU's share of BASELINE's 2^20
+  // over eight) is latency-bound: every lane is ONE dependent chain, s^-1 -> u2 -> digits ->
+  // ladder.  But the window table of Q -- a twentieth of the chain -- needs only the key, not
+  // u2: ecdsa_table builds it in a kernel of its own that runs CONCURRENTLY with ecdsa_prep (on
+  // a second stream, Engine::ecdsa_chunk), and ecdsa_ladder starts from the finished table.
+  // The table's common Z (zg) travels in the table's last scratch slot.
+  template <bool WIDE>
+  ELL_HD static void ecdsa_table(size_t i, size_t n, const u8* pub_xy, VT* tbl_all) {
+    static_assert(ENDO, "the split verify is the endomorphism curve's");
+    typedef Endo<WIDE> E;
+    A q = load_affine(pub_xy, i);
+    VT* tbl = tbl_all + i * stride<WIDE>();
+    El zg;
+    LD::template build_table_odd8<E::NE>(tbl, q, zg);
+    tbl[2 * E::NE - 1].x = zg;
+  }
+  template <bool WIDE>
+  ELL_HD static void ecdsa_ladder(size_t i, size_t n, const u32* u12, const u8* valid, const u8* rs,
+                                  const u8* pub_xy, const A* comb, const VT* tbl_all,
+                                  const DigitStore& ds, u8* out_ok) {
+    typedef Endo<WIDE> E;
+    u32 u1[L], u2[L], r[LN];
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) u2[l] = l < LN ? u12[(size_t)(1 * LN + l) * n + i] : 0u;
+    const VT* tbl = tbl_all + i * stride<WIDE>();
+    u32 k1[5], k2[5];
+    bool n1, n2;
+    glv_split<true>(u2, k1, n1, k2, n2);
+    recode_odd_w4<5, E::NW, E::WB>(k1, ds, 0, 2);
+    recode_odd_w4<5, E::NW, E::WB>(k2, ds, 1, 2);
+    const u32 negmask = (n1 ? 1u : 0u) | (n2 ? 2u : 0u);
+    El beta = load_beta();
+    bool inf;
+    J b = LD::template run_odd_w4<2, E::NW, true, WIDE, E::WB>(ds, tbl, negmask, 0u, inf, &beta);
+    b.Z = F::mul(b.Z, tbl[2 * E::NE - 1].x);             // back from the table's isomorphic curve
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) u1[l] = l < LN ? u12[(size_t)(0 * LN + l) * n + i] : 0u;
+    J p = LD::template comb_add<L, COMB_W, COMB_BITS, WIDE, COMB_SIGNED>(b, inf, u1, comb);
+    load_be<LN>(r, rs + i * NBYTES, NBYTES);
+    bool ok = !G::is_inf(p);
+    ok = ok && eq_x_to_p(p, r);
+    const bool on = on_curve(load_affine(pub_xy, i));      // see ecdsa_main
+    out_ok[i] = valid[i] == 0 ? (u8)0 : (!on ? (u8)DOMAIN_OFF_CURVE : (ok ? (u8)1 : (u8)0));
+  }
+
   // Pass 2: R = u1*G + u2*Q, accept iff R != O and R.x == r (mod n)
   template <bool WIDE = false>
   ELL_HD static void ecdsa_main(size_t i, size_t n, const u32* u12, const u8* valid,

@@ -18,7 +18,7 @@ def _digest():
     for f in src:
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(b"flags:-DELL_COMB_BITS_256=8 -DELL_BOUNDS_CHECK=1")
+    h.update(b"flags:-DELL_COMB_BITS_256=8 -DELL_BOUNDS_CHECK=1 -DELL_COMB_SLICE=1000")
     return h.hexdigest()
 
 
@@ -32,7 +32,8 @@ def build(force=False, lazy_k256=False):
     dig = _digest()
     if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read() == dig:
         return lib
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing", "-pthread", "-DELL_COMB_BITS_256=8", "-DELL_BOUNDS_CHECK=1"]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing", "-pthread", "-DELL_COMB_BITS_256=8", "-DELL_BOUNDS_CHECK=1",
+           "-DELL_COMB_SLICE=1000"]          # narrow combs built in several slices (ensure_comb's `first` offsets)
     if lazy_k256:
         cmd.append("-DELL_K256_LAZY=1")
     cmd += ["-o", lib, os.path.join(HERE, "hostsim.cpp")]

@@ -26,6 +26,7 @@ struct LoopBackend {
   void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
   int sync() { return 0; }
   int device_index() const { return 0; }
+  int compute_units() const { return 256; }
   void* own_stream() const { return nullptr; }
   void rt_upload(const RtField& f) { rt_host_block() = f; }
   void sync_all() {}
@@ -38,6 +39,9 @@ struct LoopBackend {
   int mark_compute() { return 0; }
   void copy_after(int) {}
   void select_lane(int) {}
+  void fork_side() {}
+  void leave_side() {}
+  void join_side() {}
   int sync_lanes() { return 0; }
   // "threads" of a launch are independent, so the loop is split over the host
   // cores (only to keep the CPU test-suite short)

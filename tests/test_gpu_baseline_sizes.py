@@ -119,19 +119,24 @@ def test_config3_strong_scaling_shards_both_tunings(ctx, monkeypatch):
             torch.cuda.synchronize()
             assert np.array_equal(ok.cpu().numpy(), expect[lo:hi]), (world, rank)
     lo, hi = shard_range(n, 3, 8)
-    masks = []
-    for forced in ("0", str(1 << 30)):                     # full-grid tuning, then small-grid tuning
-        monkeypatch.setenv("ELLGPU_SMALL_GRID", forced)
+    masks, outs = [], []
+    # full-grid tuning, small-grid tuning (prep || table -> ladder), small-grid tuning as prep ->
+    # ecdsa_main: the overrides are read when a context is created
+    for env in ({"ELLGPU_SMALL_GRID": "0"}, {"ELLGPU_SMALL_GRID": str(1 << 30)},
+                {"ELLGPU_SMALL_GRID": str(1 << 30), "ELLGPU_SPLIT_VERIFY": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c2 = elliptic_amd.Context(0)
+        for k in env:
+            monkeypatch.delenv(k)
         ok = torch.zeros(hi - lo, dtype=torch.uint8, device=dev)
-        ctx.ecdsa_verify_dev("secp256k1", *(x[lo:hi] for x in t), ok)
+        c2.ecdsa_verify_dev("secp256k1", *(x[lo:hi] for x in t), ok)
         torch.cuda.synchronize()
         masks.append(ok.cpu().numpy())
-    assert np.array_equal(masks[0], masks[1]) and np.array_equal(masks[0], expect[lo:hi])
-    # P*k on the same shard in both tunings: identical bytes, and the oracle's on a sample
-    outs = []
-    for forced in ("0", str(1 << 30)):
-        monkeypatch.setenv("ELLGPU_SMALL_GRID", forced)
-        outs.append(ctx.mul_var("secp256k1", r[lo:hi], pub[lo:hi]))
+        # P*k on the same shard: identical bytes in both tunings, and the oracle's on a sample
+        outs.append(c2.mul_var("secp256k1", r[lo:hi], pub[lo:hi]))
+        c2.close()
+    assert all(np.array_equal(m, expect[lo:hi]) for m in masks)
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     j = sample_idx(hi - lo, 1024)
     want, winf = C.mul_mt("secp256k1", r[lo:hi][j], pub[lo:hi][j], threads())

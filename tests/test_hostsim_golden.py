@@ -260,16 +260,36 @@ def test_verify_golden(ctx, curve):
     assert PC.check_verify_golden(ctx, curve) > 15
 
 
-def test_verify_golden_secp256k1_both_tunings(ctx, monkeypatch):
+def _fresh_ctx(hs, monkeypatch, **env):
+    """a context created under the given tuning overrides (they are read once, at creation)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = elliptic_amd.Context(0, lib_path=hs)
+    for k in env:
+        monkeypatch.delenv(k)
+    return c
+
+
+def test_verify_golden_secp256k1_both_tunings(hs, monkeypatch):
     """ecdsa_main exists in two tunings for secp256k1 (engine.h: FnEcdsaMain<.., WIDE>): the
     full-grid one (lean registers) and the small-grid one (entries requested one step ahead).
-    Small batches take the second by default; ELLGPU_SMALL_GRID=0 forces the first."""
-    monkeypatch.setenv("ELLGPU_SMALL_GRID", "0")
-    assert PC.check_verify_golden(ctx, "secp256k1") > 15
-    assert PC.check_mul_golden(ctx, "secp256k1") > 50          # mul_var has the two tunings too
-    monkeypatch.setenv("ELLGPU_SMALL_GRID", str(1 << 30))
-    assert PC.check_verify_golden(ctx, "secp256k1") > 15
-    assert PC.check_mul_golden(ctx, "secp256k1") > 50
+    Small batches take the second by default; ELLGPU_SMALL_GRID=0 (read when the context is
+    created) forces the first."""
+    c = _fresh_ctx(hs, monkeypatch, ELLGPU_SMALL_GRID="0")
+    assert PC.check_verify_golden(c, "secp256k1") > 15
+    assert PC.check_mul_golden(c, "secp256k1") > 50          # mul_var has the two tunings too
+    assert PC.check_offcurve_golden(c, "secp256k1") >= 29
+    c.close()
+    c = _fresh_ctx(hs, monkeypatch, ELLGPU_SMALL_GRID=str(1 << 30))
+    assert PC.check_verify_golden(c, "secp256k1") > 15
+    assert PC.check_mul_golden(c, "secp256k1") > 50
+    c.close()
+    # the small-grid verify itself has two forms: prep || table -> ladder (default, the two
+    # kernels of Work::ecdsa_table / ecdsa_ladder) and prep -> ecdsa_main (ELLGPU_SPLIT_VERIFY=0)
+    c = _fresh_ctx(hs, monkeypatch, ELLGPU_SPLIT_VERIFY="0")
+    assert PC.check_verify_golden(c, "secp256k1") > 15
+    assert PC.check_offcurve_golden(c, "secp256k1") >= 29
+    c.close()
 
 
 @pytest.mark.parametrize("curve", ["secp256k1", "p192", "p256", "p384", "p521", "ed25519"])
