@@ -665,6 +665,16 @@ class Engine {
   }
   size_t small_grid() const { return tune_.small_grid; }
   bool split_small_verify() const { return tune_.split_verify; }
+  // ... and for the ecdsa_prep that runs BESIDE ecdsa_table (small-grid verify): the two kernels
+  // share the SIMDs, so what counts is the work, not the latency of a lone chain -- the largest K
+  // that still leaves half a wave round of threads (131 072 items: K = 4, 1.332 -> 1.318 ms per
+  // pass; 65 536: K = 2; 16 384: K = 1; profiles/r04_split_verify_ab.txt)
+  int inv_batch_beside(size_t n, int kmax) const {
+    if (tune_.prep_k >= 1 && tune_.prep_k <= 64) return tune_.prep_k;
+    int k = kmax;
+    while (k > 1 && n / (size_t)k < tune_.wave_round / 2) k >>= 1;
+    return k;
+  }
   int inv_batch_for(size_t n, int kmax) const {
     if (tune_.prep_k >= 1 && tune_.prep_k <= 64) return tune_.prep_k;
     int k = kmax;
@@ -2016,8 +2026,10 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
       // latency-bound batch: the window table does not depend on s^-1, so it is built while
       // ecdsa_prep runs on the side stream; the ladder waits for both
       bk.fork_side();
-      FnEcdsaPrep<CV, ELL_ECDSA_TABLE_MIN_WAVES> fs{T, n, K, hash, hash_len, shift, r, s, pre, u12, valid};
-      launch_fn(fs, T);
+      const int Ks = inv_batch_beside(n, INV_BATCH_N);
+      const size_t Ts = (n + Ks - 1) / Ks;
+      FnEcdsaPrep<CV, ELL_ECDSA_TABLE_MIN_WAVES> fs{Ts, n, Ks, hash, hash_len, shift, r, s, pre, u12, valid};
+      launch_fn(fs, Ts);
       bk.leave_side();
       FnEcdsaTable<CV, true> ft{n, pub, tbl};
       launch_fn(ft, n);

@@ -121,3 +121,66 @@ class ShardedMul:
             xy = torch.from_numpy(np.ascontiguousarray(xy_np))
             inf = torch.from_numpy(np.ascontiguousarray(inf_np))
         return gather_results(xy, n, self.dist), gather_results(inf, n, self.dist)
+
+
+class OverlappedGather:
+    """The final gather off the compute stream, for a loop of batches (bench.py's strong-scaling
+    steps, a service that verifies block after block): step i's all_gather runs on the
+    collective's own stream WHILE step i + 1 computes.  Two result buffers alternate;
+    `async_op=True` orders the collective after the work already on the current stream, and
+    nothing on that stream waits for it until its buffer comes round again.
+
+        og = OverlappedGather(n, dist, device)            # n = rows of the GLOBAL batch
+        for step in ...:
+            out = og.begin()                              # this rank's shard rows to write (waits for the gather that last used them)
+            ctx.ecdsa_verify_dev(..., out)
+            og.submit()                                   # async all_gather of that buffer
+        og.drain()
+        mask = og.result(b)                               # the n-row gathered result of buffer b (0 / 1)
+
+    gather_device: where the collective runs (the compute device for backend "nccl" = RCCL; CPU
+    for "gloo", in which case submit() copies the shard to the host first)."""
+
+    def __init__(self, n, dist, device, gather_device=None, dtype=None):
+        import torch
+        self.n, self.dist = n, dist
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.lo, self.hi = shard_range(n, self.rank, self.world)
+        self.longest = (n + self.world - 1) // self.world
+        self.gdev = gather_device if gather_device is not None else device
+        dtype = dtype or torch.uint8
+        self.local = [torch.zeros(self.longest, dtype=dtype, device=device) for _ in range(2)]
+        self.full = [torch.zeros(self.world * self.longest, dtype=dtype, device=self.gdev) for _ in range(2)]
+        self.pending = [None, None]
+        self.turn = 0
+        self.cur = None
+
+    def begin(self):
+        b = self.turn
+        if self.pending[b] is not None:                   # the gather that last read local[b] / wrote full[b]
+            self.pending[b].wait()
+            self.pending[b] = None
+        self.cur = b
+        return self.local[b][: self.hi - self.lo]
+
+    def submit(self):
+        b = self.cur
+        src = self.local[b] if self.local[b].device == self.full[b].device else self.local[b].to(self.gdev)
+        self.pending[b] = self.dist.all_gather_into_tensor(self.full[b], src, async_op=True)
+        self.turn ^= 1
+
+    def drain(self):
+        for b in (0, 1):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+
+    def result(self, b):
+        """the n-row gathered result of buffer b: every rank's shard without its padding"""
+        import torch
+        parts = []
+        for r in range(self.world):
+            lo, hi = shard_range(self.n, r, self.world)
+            parts.append(self.full[b][r * self.longest: r * self.longest + (hi - lo)])
+        return torch.cat(parts)

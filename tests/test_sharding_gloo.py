@@ -130,3 +130,63 @@ def test_world2_sharded_mul_gathers_points():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res)
+
+
+def _overlap_worker(rank, world, port, lib_path, n, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import elliptic_amd
+        from elliptic_amd import _lib, ints_to_be
+        from elliptic_amd.sharding import OverlappedGather, shard_range
+        from golden_util import I, load
+        lib = _lib.load(lib_path, optional=("ellgpu_probe_valu", "ellgpu_ctx_set_timing", "ellgpu_ctx_get_timing", "ellgpu_debug_field_op"))
+        ctx = elliptic_amd.Context(0, lib_path=lib)
+        # the global batch: verify tuples of the reference, off-curve keys among them
+        cs = ([c for c in load("verify_secp256k1.json") if len(c["z"]) == 64] +
+              [c for c in load("offcurve_secp256k1.json") if c["op"] == "verify"])[:n]
+        assert len(cs) == n
+        h = ints_to_be([I(c["z"]) for c in cs], 32)
+        r = ints_to_be([I(c["r"]) for c in cs], 32)
+        s = ints_to_be([I(c["s"]) for c in cs], 32)
+        pub = np.concatenate([ints_to_be([I(c["qx"]) for c in cs], 32), ints_to_be([I(c["qy"]) for c in cs], 32)], axis=1)
+        cur_n = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+        want = np.array([(2 if (c.get("on") is False and 0 < I(c["r"]) < cur_n and 0 < I(c["s"]) < cur_n)
+                          else (1 if c["ok"] else 0)) for c in cs], np.uint8)
+        lo, hi = shard_range(n, rank, world)
+        og = OverlappedGather(n, dist, torch.device("cpu"))
+        good = True
+        for step in range(steps):
+            out = og.begin()
+            # (the hostsim build has no device pointers: compute into numpy, copy into the buffer)
+            out.copy_(torch.from_numpy(np.ascontiguousarray(ctx.ecdsa_verify("secp256k1", h[lo:hi], r[lo:hi], s[lo:hi], pub[lo:hi]))))
+            if step == 2:                                   # a step whose results differ: buffers must not mix
+                out.zero_()
+            og.submit()
+        og.drain()
+        last, prev = (steps - 1) & 1, (steps - 2) & 1
+        good = good and np.array_equal(og.result(last).numpy(), want) and np.array_equal(og.result(prev).numpy(), want)
+        q.put((rank, bool(good), int((want == 2).sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_overlapped_gather_of_verify_masks():
+    """bench.py's strong-scaling loop: step i's gather (async all_gather_into_tensor, two
+    alternating buffers) overlaps step i + 1's verifies; uneven shards; off-curve keys keep their
+    status 2 through the gather"""
+    from hostsim.build import build as build_hostsim
+    lib_path = build_hostsim()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_overlap_worker, args=(r, 2, port, lib_path, 91, 7, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res)
+    assert all(r[2] >= 10 for r in res)                     # the batch did contain off-curve keys
