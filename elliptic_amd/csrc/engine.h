@@ -260,7 +260,7 @@ template <class CV, bool WIDE = true>
 struct FnEcdsaLadder {
   static constexpr const char* NAME = "ecdsa_main";      // the timing name of pass 2 in either form
   typedef Work<CV> W;
-  static constexpr int MIN_WAVES = 3;
+  static constexpr int MIN_WAVES = WIDE ? 3 : ELL_ENDO_MIN_WAVES;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
   size_t n; const u32* u12; const u8* valid; const u8* r; const u8* pub;
   const typename W::A* comb; const typename W::VT* tbl; u8* ok;
@@ -2022,6 +2022,9 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
   size_t T = (n + K - 1) / K;
   FnEcdsaPrep<CV> f1{T, n, K, hash, hash_len, shift, r, s, pre, u12, valid};
   if constexpr (CV::ENDO && W::L <= 8 && ELL_SPLIT_SMALL_VERIFY) {
+    // (the two-kernel form on a FULL grid was measured too, round 4: 8.22 -> 8.37 ms per 2^20 --
+    // the table kernel alone takes 0.65 ms where building the table inside ecdsa_main costs
+    // 0.5 ms, and there is no latency to hide at four waves per SIMD; small grids only)
     if (wide && split_small_verify()) {
       // latency-bound batch: the window table does not depend on s^-1, so it is built while
       // ecdsa_prep runs on the side stream; the ladder waits for both

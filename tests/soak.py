@@ -85,7 +85,23 @@ def main():
             got = ctx.ecdsa_verify(curve, z, r, s, pts)
             assert np.array_equal(got, want), (curve, "verify")
             assert want[2::5].all() and not want[::5].any()
-            checked += 6 * n
+            # keys moved off the curve (the last byte of y flipped: still a field element): exactly
+            # those items come back with status 2 -- unless r / s are out of range, which wins --
+            # and every other item is untouched
+            bad = pts.copy()
+            off = np.arange(3, n, 41)
+            bad[off, 2 * B - 1] ^= 1
+            got2 = ctx.ecdsa_verify(curve, z, r, s, bad)
+            flagged = got2 == 2
+            assert np.array_equal(got2[~flagged], want[~flagged]), (curve, "verify beside off-curve keys")
+            assert not flagged[np.setdiff1d(np.arange(n), off)].any() and flagged[off].sum() >= len(off) - 2, (curve, "off-curve flags")
+            xy2, inf2 = ctx.mul_var(curve, k, bad)
+            assert (inf2[off] == 2).all() and not xy2[off].any(), (curve, "mul_var off-curve")
+            on = np.ones(n, bool)
+            on[off] = False
+            w_xy, w_inf = par(lambda kk, pp: c_oracle.mul(curve, kk, pp), n, threads, k, pts)
+            assert np.array_equal(xy2[on], w_xy[on]) and np.array_equal(inf2[on], w_inf[on]), (curve, "mul_var beside off-curve points")
+            checked += 8 * n
         # ed25519 (Edwards) and curve25519 (x-only Montgomery): variable base against the C oracle's
         # _extAdd / _extDbl and diffAdd / dbl; a user-defined curve (brainpoolP256r1) against its
         # generic-a _dbl path

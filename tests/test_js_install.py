@@ -147,7 +147,7 @@ def _run_coalescing(lib):
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     res = json.loads(p.stdout.strip().splitlines()[-1])
-    assert res["ok"] and res["calls"] == 99 and res["engine_calls"] <= 4 and res["rejected"] == 2
+    assert res["ok"] and res["calls"] == 103 and res["engine_calls"] <= 8 and res["rejected"] == 2
     return res
 
 
