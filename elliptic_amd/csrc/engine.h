@@ -652,6 +652,7 @@ class Engine {
     size_t small_grid;
     bool split_verify;
     int prep_k;
+    int norm_k;
   };
   Tuning tune_;
   void init_tuning() {
@@ -662,6 +663,8 @@ class Engine {
     tune_.split_verify = !(e && e[0] == '0');
     e = getenv("ELLGPU_PREP_K");
     tune_.prep_k = e ? atoi(e) : 0;
+    e = getenv("ELLGPU_NORM_K");
+    tune_.norm_k = e ? atoi(e) : 0;
   }
   size_t small_grid() const { return tune_.small_grid; }
   bool split_small_verify() const { return tune_.split_verify; }
@@ -675,6 +678,8 @@ class Engine {
     while (k > 1 && n / (size_t)k < tune_.wave_round / 2) k >>= 1;
     return k;
   }
+  // items per inversion in normalize (ELLGPU_NORM_K overrides)
+  int norm_batch_for(size_t) const { return tune_.norm_k >= 1 && tune_.norm_k <= 64 ? tune_.norm_k : INV_BATCH; }
   int inv_batch_for(size_t n, int kmax) const {
     if (tune_.prep_k >= 1 && tune_.prep_k <= 64) return tune_.prep_k;
     int k = kmax;
@@ -1866,8 +1871,9 @@ int Engine<BK>::normalize_chunk(size_t n, const u32* jac, u8* out_xy, u8* out_in
   typedef Work<CV> W;
   u32* pre = (u32*)scratch(S_PRE, n * W::NS * 4);
   if (!pre) return fail(E_NOMEM, "scratch allocation failed");
-  size_t T = (n + INV_BATCH - 1) / INV_BATCH;
-  FnNormalize<CV> f{T, n, INV_BATCH, jac, pre, out_xy, out_inf, raw};
+  const int K = norm_batch_for(n);
+  size_t T = (n + K - 1) / K;
+  FnNormalize<CV> f{T, n, K, jac, pre, out_xy, out_inf, raw};
   bk.launch(f, T);
   return E_OK;
 }

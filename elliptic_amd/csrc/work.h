@@ -602,14 +602,27 @@ struct Work {
   // form (used to build the comb tables).
   ELL_HD static void normalize(size_t t, size_t T, size_t n, int K, const u32* jac, u32* pre,
                                u8* out_xy, u8* out_inf, A* raw_aff) {
-    El acc = F::one();
-    ELL_NOUNROLL
-    for (int j = 0; j < K; j++) {
-      size_t i = t + (size_t)j * T;
-      if (i >= n) break;
+    // Both passes are software-pipelined by hand (round 4): item j + 1's words are requested
+    // before item j's multiplications, so that the thread's chain -- K items and one inversion,
+    // on a grid of n / K threads that leaves most SIMDs a single wave -- does not also wait for
+    // HBM once per item.
+    auto load_z = [&](size_t i) {
       El z;
       ELL_UNROLL
       for (int l = 0; l < NS; l++) z.v[l] = jac[(size_t)(2 * NS + l) * n + i];
+      return z;
+    };
+    // items of this thread: t, t + T, ... below n
+    int cnt = 0;
+    if (t < n) cnt = (int)((n - 1 - t) / T) + 1;
+    if (cnt > K) cnt = K;
+    El acc = F::one();
+    El znext = cnt > 0 ? load_z(t) : F::one();
+    ELL_NOUNROLL
+    for (int j = 0; j < cnt; j++) {
+      size_t i = t + (size_t)j * T;
+      El z = znext;
+      if (j + 1 < cnt) znext = load_z(i + T);
       bool inf = F::is_zero(z);
       z = fe_select<F>(inf, F::one(), z);
       ELL_UNROLL
@@ -617,16 +630,22 @@ struct Work {
       acc = F::mul(acc, z);
     }
     El inv = F::inv(acc);
-    ELL_NOUNROLL
-    for (int j = K - 1; j >= 0; j--) {
-      size_t i = t + (size_t)j * T;
-      if (i >= n) continue;
-      J p = load_jac(jac, n, i);
-      bool inf = F::is_zero(p.Z);
-      El z = fe_select<F>(inf, F::one(), p.Z);
-      El pr;
+    J pn;
+    El prn;
+    auto load_item = [&](size_t i, J& p, El& pr) {
+      p = load_jac(jac, n, i);
       ELL_UNROLL
       for (int l = 0; l < NS; l++) pr.v[l] = pre[(size_t)l * n + i];
+    };
+    if (cnt > 0) load_item(t + (size_t)(cnt - 1) * T, pn, prn);
+    ELL_NOUNROLL
+    for (int j = cnt - 1; j >= 0; j--) {
+      size_t i = t + (size_t)j * T;
+      J p = pn;
+      El pr = prn;
+      if (j > 0) load_item(i - T, pn, prn);
+      bool inf = F::is_zero(p.Z);
+      El z = fe_select<F>(inf, F::one(), p.Z);
       El zinv = F::mul(inv, pr);
       inv = F::mul(inv, z);
       El zi2 = F::sqr(zinv);
