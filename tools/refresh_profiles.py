@@ -36,6 +36,8 @@ MAP = {
     "latency.jsonl": "latency.jsonl",
     "bench_strong_two_ranks_one_gpu.jsonl": "bench_strong_two_ranks_one_gpu.jsonl",
     "bench_two_ranks_one_gpu.jsonl": "bench_two_ranks_one_gpu.jsonl",
+    "bench_selflaunch_two_ranks_one_gpu.jsonl": "bench_selflaunch_two_ranks_one_gpu.jsonl",
+    "bench_selflaunch_eight_ranks_one_gpu.jsonl": "bench_selflaunch_eight_ranks_one_gpu.jsonl",
     "rccl_selftest.jsonl": "rccl_selftest.jsonl",
 }
 

@@ -10,7 +10,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/refresh
 MODE="$1"
 rm -rf $O && mkdir -p $O
-ROUND="${ELL_ROUND:-r03}"
+ROUND="${ELL_ROUND:-r04}"
 ( time timeout 900 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
 tail -3 $O/pytest_gpu.log
 # the workload of the PMC passes: one pass of every benchmarked kernel (headline + configs), 2 timed steps
@@ -45,8 +45,11 @@ rm -rf /tmp/treecopy
 tail -c 600 $O/bench.json.log
 timeout 300 python tools/strong_proxy.py > $O/strong_proxy.jsonl 2> $O/strong_proxy.err
 timeout 300 python tools/bench_latency.py > $O/latency.jsonl 2> $O/latency.err
-( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 2 --scaling strong --dist-backend gloo --force-device 0 ) > $O/bench_strong_two_ranks_one_gpu.jsonl 2> $O/bench_strong2.err
-( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --steps 10 --warmup 2 --dist-backend gloo --force-device 0 ) > $O/bench_two_ranks_one_gpu.jsonl 2> $O/bench_weak2.err
+# the N > 1 flow on the one-GPU box, started as PLAIN python (bench.py launches itself under
+# torch.distributed.run): weak loop + configs[2] as written (`strong`) + the collective's census in
+# one line; two ranks, then eight ranks, all on device 0 over gloo (flow tests, not scaling points)
+( timeout 600 python3 bench.py --gpus 2 --steps 10 --warmup 2 --dist-backend gloo --force-device 0 ) > $O/bench_selflaunch_two_ranks_one_gpu.jsonl 2> $O/bench_selflaunch2.err
+( timeout 900 python3 bench.py --gpus 8 --steps 6 --warmup 2 --dist-backend gloo --force-device 0 --batch 131072 ) > $O/bench_selflaunch_eight_ranks_one_gpu.jsonl 2> $O/bench_selflaunch8.err
 ( timeout 300 python bench.py --rccl-selftest --steps 5 --warmup 2 --no-cpu --no-configs --no-live-counters ) > $O/rccl_selftest.jsonl 2> $O/rccl_selftest.err
 if [ "$MODE" != "quick" ]; then
   timeout 300 python tools/gpu_probe.py > $O/valu_probe.log 2>&1
