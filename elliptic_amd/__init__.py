@@ -6,7 +6,7 @@ include/ellgpu.h); this package is the thin Python host layer used by the
 tests and bench.py.  The JS host layer the reference's users switch to lives in
 elliptic_amd/js (N-API addon + install() patch).
 """
-from .engine import (CURVES, CURVE_ID, FIELD_BYTES, ORDER_BYTES, Context, be_to_ints,  # noqa: F401
+from .engine import (CURVES, CURVE_ID, FIELD_BYTES, ORDER_BYTES, STATUS_OFF_CURVE, Context, be_to_ints,  # noqa: F401
                      ints_to_be)
 from ._lib import EllgpuError  # noqa: F401
 

@@ -23,6 +23,10 @@ CURVE_ID = {n: i for i, n in enumerate(CURVES)}
 FIELD_BYTES = {"secp256k1": 32, "p192": 24, "p224": 28, "p256": 32, "p384": 48, "p521": 66,
                "ed25519": 32, "curve25519": 32}
 ORDER_BYTES = dict(FIELD_BYTES)
+# per-item status in the `inf` / `ok` results (include/ellgpu.h ELLGPU_STATUS_OFF_CURVE): a point
+# operand is not on the curve -- outside the engine's domain, reported instead of guessed (the
+# reference computes with such points, and its answer depends on the order of its own operations)
+STATUS_OFF_CURVE = 2
 # user-defined short curves (Context.define_short) are addressed by the integer id the library
 # hands out; their scalars and coordinates are 32 bytes wide whatever the prime's size
 CURVE_CUSTOM0 = 16

@@ -162,6 +162,10 @@ Engine.prototype.encodePointBatch = function encodePointBatch(curve, xy, compact
 // validateBatch: KeyPair#validate per point -> Buffer(n) of 0 ok / 1 'Invalid public key'
 // (o.inf[i] set) / 2 'Public key is not a point' / 3 'Public key * N != O' (skipped when
 // o.checkOrder === false)
+// status 2 in the `inf` result of mulBatch / mulAddBatch and in the verdicts of ecdsaVerifyBatch
+// (ELLGPU_STATUS_OFF_CURVE; ecdsaVerifyWireBatch: ok 2 with err 5): a point operand is not on the
+// curve -- outside the engine's domain, reported instead of guessed
+Engine.OFF_CURVE = 2;
 Engine.VALIDATE_REASON = [null, 'Invalid public key', 'Public key is not a point', 'Public key * N != O'];
 Engine.prototype.validateBatch = function validateBatch(curve, xy, o) {
   var id = this._id(curve);
@@ -208,7 +212,8 @@ Engine.prototype.sigToDerBatch = function sigToDerBatch(curve, r, s) {
 // keys Buffer(n x keyLen) of SEC1 encodings -> { ok, err: Buffer(n) }; err 1..3 = decodePoint's
 // exception for the key ('Unknown point format' / 'invalid point' / 'Assertion failed'),
 // 4 = 'Signature without r or s'
-Engine.WIRE_ERROR = [null, 'Unknown point format', 'invalid point', 'Assertion failed', 'Signature without r or s'];
+Engine.WIRE_ERROR = [null, 'Unknown point format', 'invalid point', 'Assertion failed', 'Signature without r or s',
+  null /* 5: no exception -- the key is not on the curve (ok = 2): run the reference on this item */];
 Engine.prototype.ecdsaVerifyWireBatch = function ecdsaVerifyWireBatch(curve, o) {
   var p = packRecords(o.sigs);
   this.stats.gpuCalls++; this.stats.gpuItems += o.sigs.length;
@@ -465,7 +470,7 @@ function install(elliptic, options) {
 
   // status 2 of the engine (ELLGPU_STATUS_OFF_CURVE): an operand is not on the curve.  The
   // reference computes with such points all the same; its own method gives its own answer.
-  var OFF_CURVE = 2;
+  var OFF_CURVE = Engine.OFF_CURVE;
   // > 0 while the reference's own method runs on such an item: the ladders it calls internally
   // (_endoWnafMulAdd -> _wnafMulAdd) are the patched ones, and must not ask the engine again
   var refOnly = 0;
