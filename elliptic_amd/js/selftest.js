@@ -63,6 +63,45 @@ function check(r, i, B, want, what) {
     });
   });
 });
+// points that are not on the curve (offcurve_<curve>.json): the batch API reports them with status
+// Engine.OFF_CURVE (2) and a zeroed result, and computes the on-curve items of the same batch
+['secp256k1', 'p192', 'p224', 'p256', 'p384', 'p521', 'ed25519'].forEach(function(name) {
+  var B = eng.addon.fieldBytes(eng.addon.curveId(name));
+  var OFF = ellgpu.Engine.OFF_CURVE;
+  var cases = JSON.parse(fs.readFileSync(path.join(GOLD, 'offcurve_' + name + '.json')));
+  function points(r, cs, what) {
+    cs.forEach(function(c, i) {
+      if (c.on) return check(r, i, B, c.r, name + ' ' + what + ' (on-curve control)');
+      if (r.inf[i] !== OFF) throw new Error(name + ' ' + what + ': off-curve item ' + i + ' has status ' + r.inf[i]);
+      for (var b = i * 2 * B; b < (i + 1) * 2 * B; b++)
+        if (r.xy[b] !== 0) throw new Error(name + ' ' + what + ': off-curve item ' + i + ' has a result');
+      checked++;
+    });
+  }
+  var vr = cases.filter(function(c) { return c.op === 'var'; });
+  points(eng.mulBatch(name, hexBuf(vr.map(function(c) { return c.k; }), B),
+    Buffer.concat(vr.map(function(c) { return hexBuf([c.px, c.py], B); }))), vr, 'mulBatch');
+  var ma = cases.filter(function(c) { return c.op === 'muladd'; });
+  points(eng.mulAddBatch(name, hexBuf(ma.map(function(c) { return c.k1; }), B),
+    Buffer.concat(ma.map(function(c) { return hexBuf([c.p1x, c.p1y], B); })),
+    hexBuf(ma.map(function(c) { return c.k2; }), B),
+    Buffer.concat(ma.map(function(c) { return hexBuf([c.p2x, c.p2y], B); }))), ma, 'mulAddBatch');
+  var vs = cases.filter(function(c) { return c.op === 'verify'; });
+  if (!vs.length) return;
+  var hl = vs[0].z.length / 2;
+  var ok = eng.ecdsaVerifyBatch(name, { hashes: hexBuf(vs.map(function(c) { return c.z; }), hl), hashLen: hl, msgBits: 0,
+    r: hexBuf(vs.map(function(c) { return c.r; }), B), s: hexBuf(vs.map(function(c) { return c.s; }), B),
+    pub: Buffer.concat(vs.map(function(c) { return hexBuf([c.qx, c.qy], B); })) });
+  var nOff = 0;
+  vs.forEach(function(c, i) {
+    var inRange = !/^0*$/.test(c.r) && !/^0*$/.test(c.s) && c.note.indexOf('s = n') < 0;
+    var want = (c.on || !inRange) ? (c.ok ? 1 : 0) : OFF;       // r / s out of range win, as in the reference
+    if (ok[i] !== want) throw new Error(name + ' ecdsaVerifyBatch: off-curve fixture ' + i + ' (' + c.note + ') -> ' + ok[i] + ', expected ' + want);
+    if (want === OFF) nOff++;
+    checked++;
+  });
+  if (nOff < 9) throw new Error(name + ': too few off-curve verify fixtures reached the engine');
+});
 ['secp256k1', 'p192', 'p256', 'p384', 'p521', 'ed25519'].forEach(function(name) {
   var B = eng.addon.fieldBytes(eng.addon.curveId(name));
   var cs = JSON.parse(fs.readFileSync(path.join(GOLD, 'decompress_' + name + '.json')));
