@@ -733,3 +733,75 @@ def check_offcurve_golden(ctx, curve):
         else:
             assert (wok[j], werr[j]) == (2, 5), ("wire", curve, c, int(wok[j]), int(werr[j]))
     return total + len(ver) + len(inr)
+
+
+def check_exceptional_keys(ctx, curve, seed=9):
+    """Directed ECDSA tuples whose double-scalar multiplication walks through the group law's
+    exceptional cases: keys that are multiples of G by 1, -1, 2, (for secp256k1) lambda, -lambda,
+    lambda^2, (n - 1) / 2, with (u1, u2) chosen so that u1 G + u2 Q is O, G, -G, 2G, Q, or that a GLV
+    half of u2 is 0 / 1 / a lattice vector, next to random ones.  Every tuple is built to VERIFY
+    (r = x(R) mod n, s = r / u2, z = u1 s) unless R = O; the engine's verdicts and its k1 G + k2 Q
+    results must equal the C port of the reference's algorithm item by item."""
+    import random
+    from oracle import c_oracle, ec_oracle as O
+    cur = O.get_curve(curve)
+    n, B = cur.n, FIELD_BYTES[curve]
+    NB = ORDER_BYTES[curve]
+    rnd = random.Random(seed)
+    ds = [1, n - 1, 2, (n - 1) // 2, 3, rnd.randrange(1, n)]
+    if cur.endo is not None:
+        lam = cur.endo["lambda"]
+        ds += [lam, n - lam, lam * lam % n, (lam + 1) % n, (lam - 1) % n]
+    tuples = []                                     # (d, u1, u2)
+    for d in ds:
+        dinv = pow(d, -1, n)
+        u2s = [1, 2, 3, n - 1, n - 2, rnd.randrange(1, n), rnd.randrange(1, 1 << 128), (1 << 128), (1 << 129) - 1]
+        if cur.endo is not None:
+            u2s += [lam, n - lam, (lam + 1) % n, lam * 2 % n]
+        for u2 in u2s:
+            for tgt in (0, 1, n - 1, 2, d % n, (n - d) % n, None):      # u1 + u2 d = tgt (None: random)
+                u1 = rnd.randrange(n) if tgt is None else (tgt - u2 * d) % n
+                tuples.append((d, u1, u2))
+    m = len(tuples)
+    dk = ints_to_be([t[0] for t in tuples], B)
+    keys, kinf = c_oracle.mul(curve, dk)            # Q = d G (the oracle's fixed-base path)
+    assert not kinf.any()
+    k1 = ints_to_be([t[1] for t in tuples], B)
+    k2 = ints_to_be([t[2] for t in tuples], B)
+    want_xy, want_inf = c_oracle.mul_add(curve, k1, None, k2, keys)
+    got_xy, got_inf = ctx.mul_add2(curve, k1, None, k2, keys)
+    assert np.array_equal(got_inf, want_inf) and np.array_equal(got_xy, want_xy), (curve, "k1 G + k2 Q on exceptional keys")
+    # the same (k1, k2, Q) with G passed as an ordinary point: the two-table ladder
+    g = np.tile(np.concatenate([ints_to_be([cur.g.x], B), ints_to_be([cur.g.y], B)], axis=1), (m, 1))
+    got2_xy, got2_inf = ctx.mul_add2(curve, k1, g, k2, keys)
+    assert np.array_equal(got2_inf, want_inf) and np.array_equal(got2_xy, want_xy), (curve, "k1 P1 + k2 P2 on exceptional keys")
+    # ECDSA tuples from them
+    zs, rs, ss, expect = [], [], [], []
+    for i, (d, u1, u2) in enumerate(tuples):
+        if want_inf[i]:
+            r = rnd.randrange(1, n)
+            ok = False
+        else:
+            r = int.from_bytes(want_xy[i, :B].tobytes(), "big") % n
+            ok = r != 0
+            if r == 0:
+                r = 1
+        s = r * pow(u2, -1, n) % n
+        z = u1 * s % n
+        if s == 0:
+            s, ok = 1, False
+        zs.append(z); rs.append(r); ss.append(s); expect.append(ok)
+    hl = NB if cur.n.bit_length() % 8 == 0 else NB - 1
+    keep = [i for i in range(m) if zs[i].bit_length() <= 8 * hl]      # digests the reference would not shift
+    z = ints_to_be([zs[i] for i in keep], hl)
+    r = ints_to_be([rs[i] for i in keep], NB)
+    s = ints_to_be([ss[i] for i in keep], NB)
+    pub = keys[keep]
+    want = c_oracle.verify(curve, z, r, s, pub)
+    got = ctx.ecdsa_verify(curve, z, r, s, pub)
+    assert np.array_equal(np.asarray(got), np.asarray(want)), (curve, "verify on exceptional keys")
+    # s == 1 substitutions aside, the construction's own verdicts hold as well
+    exp = np.array([1 if expect[i] else 0 for i in keep], np.uint8)
+    assert int((np.asarray(want) == exp).sum()) >= len(keep) - 4
+    assert int(exp.sum()) > len(keep) // 2 and int(np.asarray(want_inf).sum()) >= len(ds)
+    return 2 * m + len(keep)

@@ -31,6 +31,13 @@ def test_mul_golden(ctx, curve):
     assert PC.check_mul_golden(ctx, curve) > 50
 
 
+@pytest.mark.parametrize("curve", ["secp256k1", "p192", "p256", "p384", "p521"])
+def test_exceptional_keys_and_scalars(ctx, curve):
+    """keys +-G, 2G, +-lambda G ... with (u1, u2) that send u1 G + u2 Q through O, +-G, 2G, Q and GLV
+    halves of 0 / 1: k1 G + k2 Q, k1 P1 + k2 P2 and the verdicts against the C oracle"""
+    assert PC.check_exceptional_keys(ctx, curve) > 400
+
+
 def test_x25519_golden(ctx):
     assert PC.check_x25519_golden(ctx) > 30
 

@@ -251,6 +251,11 @@ def test_offcurve_operands_are_reported_not_guessed(ctx, curve):
     assert PC.check_offcurve_golden(ctx, curve) >= 29
 
 
+@pytest.mark.parametrize("curve", ["secp256k1", "p256", "p224"])
+def test_exceptional_keys_and_scalars(ctx, curve):
+    assert PC.check_exceptional_keys(ctx, curve) > 400
+
+
 def test_x25519_golden(ctx):
     assert PC.check_x25519_golden(ctx) > 30
 

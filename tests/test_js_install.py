@@ -151,6 +151,37 @@ def _run_coalescing(lib):
     return res
 
 
+def _run_eddsa_edges(lib):
+    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
+    if lib:
+        env["ELLGPU_LIB"] = lib
+    else:
+        env.pop("ELLGPU_LIB", None)
+    p = subprocess.run(["node", os.path.join(ROOT, "tools", "check_eddsa_edge_encodings.js")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["cases"] >= 2000 and res["accepted"] >= 10 and res["thrown"] >= 100
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_eddsa_verify_edge_encodings():
+    """EDDSA#verify on low-order and non-canonical encodings of A and R (y = 0, 1, p, p + 1, the
+    order-8 points ...), both sign bits, S in {0, 1, 5, n - 1, n}: patched library and batch API
+    against the unpatched reference, verdicts and throws"""
+    _addon()
+    from hostsim.build import build as build_hostsim
+    _run_eddsa_edges(build_hostsim())
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_eddsa_verify_edge_encodings_gpu():
+    from elliptic_amd.js import build as jb
+    jb.build()
+    _run_eddsa_edges(None)
+
+
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
 def test_verify_async_coalesces_concurrent_calls():
     """99 concurrent eng.verifyAsync calls (two curves, two digest lengths, corrupted tuples, two
