@@ -539,9 +539,27 @@ function install(elliptic, options) {
     if (refOnly) return orig.wnafMul.apply(this, arguments);
     return mul1(this, p, k, orig.wnafMul, arguments);
   };
+  // The reference's pairing loop (base.js:165-183) takes two points whose NAF window is 1 -- points
+  // without precomputed tables, `_getNAFPoints(defW = 1)` -- through `points[a].toJ()`, which
+  // Edwards points do not have: `fresh.mulAdd(k1, fresh2, k2)` on an Edwards curve THROWS
+  // "points[a].toJ is not a function" there (only a precomputed operand, e.g. EDDSA's G, makes
+  // it work).  Such calls go to the original method, so the caller sees that same TypeError.
+  function nafWindow(p, defW) {
+    return p && p.precomputed && p.precomputed.naf ? p.precomputed.naf.wnd : defW;
+  }
+  function referenceThrowsOnPair(points, len, defW) {
+    if (!points[0] || typeof points[0].toJ === 'function') return false;
+    for (var i = len - 1; i >= 1; i -= 2)
+      if (nafWindow(points[i - 1], defW) === 1 && nafWindow(points[i], defW) === 1) return true;
+    return false;
+  }
   base._wnafMulAdd = function _wnafMulAdd(defW, points, coeffs, len,
     jacobianResult) {
     if (refOnly) return orig.wnafMulAdd.apply(this, arguments);
+    if (referenceThrowsOnPair(points, len, defW)) {
+      eng.stats.passthrough++;
+      return orig.wnafMulAdd.apply(this, arguments);
+    }
     // (an odd len > 1 never worked in the reference: its pairing loop leaves naf[0] unset)
     if (len > 2 && len % 2 === 0)
       return mulAddMany(this, points, coeffs, len, !!jacobianResult, orig.wnafMulAdd, arguments);

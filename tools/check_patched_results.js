@@ -92,6 +92,25 @@ load('eddsa_verify_ed25519.json').forEach(function(c) {
     checked++;
   });
 })();
+// Edwards mulAdd / jmulAdd without a precomputed operand: the reference's pairing loop calls toJ(),
+// which Edwards points lack (base.js:174-183) -- it throws, and so must the patched library
+(function() {
+  var c = elliptic.curves.ed25519.curve;
+  var hadTables = c.g.precomputed;
+  c.g.precomputed = null;                               // (an EDDSA instance may have tabled G already)
+  var P = c.g.mul(new ref.BN(5)), Q = c.g.mul(new ref.BN(7));
+  var P2 = c.point(P.getX(), P.getY()), Q2 = c.point(Q.getX(), Q.getY());
+  expectThrow(function() { return P2.mulAdd(new ref.BN(3), Q2, new ref.BN(4)); }, 'points[a].toJ is not a function', 'edwards fresh.mulAdd(fresh)');
+  expectThrow(function() { return c.g.mulAdd(new ref.BN(3), Q2, new ref.BN(4)); }, 'points[a].toJ is not a function', 'edwards untabled g.mulAdd');
+  expectThrow(function() { return P2.jmulAdd(new ref.BN(3), Q2, new ref.BN(4)); }, 'points[a].toJ is not a function', 'edwards fresh.jmulAdd(fresh)');
+  c.g.precomputed = hadTables;
+  c.g.precompute(c.n.bitLength() + 1);
+  var R = c.g.mulAdd(new ref.BN(3), Q2, new ref.BN(4));   // with a tabled G it works, and on the device
+  var W = c.g.mul(new ref.BN(3)).add(Q2.mul(new ref.BN(4)));
+  if (R.getX().cmp(W.getX()) !== 0 || R.getY().cmp(W.getY()) !== 0) throw new Error('edwards g.mulAdd mismatch');
+  checked++;
+})();
+
 // Points that are not on the curve (offcurve_<curve>.json): the reference computes with them, the
 // engine reports them with status 2, and install() hands those items to the reference's own
 // method -- so the patched library must return the reference's answer: Point#mul, mulAdd /
