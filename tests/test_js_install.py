@@ -151,6 +151,40 @@ def _run_coalescing(lib):
     return res
 
 
+def _run_fuzz(lib, iterations, seed):
+    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
+    if lib:
+        env["ELLGPU_LIB"] = lib
+    else:
+        env.pop("ELLGPU_LIB", None)
+    p = subprocess.run(["node", os.path.join(ROOT, "tools", "fuzz_patched_vs_plain.js"), str(iterations), seed], env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["calls"] >= iterations and res["reference_threw"] > iterations // 10
+    assert res["engine"]["offCurve"] > 0 and res["engine"]["passthrough"] > 0
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_differential_fuzz_of_the_public_api():
+    """the same seeded sequence of public-API calls (mul / mulAdd / jmulAdd, ECDSA sign / verify /
+    recoverPubKey / derive, pointFromX / pointFromY, EdDSA sign / verify) with arguments on the seams
+    (edge, negative and over-wide scalars, infinity, tabled, off-curve and non-canonical points,
+    messages and signatures in every accepted form, corrupted ones) on an unpatched and a patched
+    copy of the reference: every result and every exception message equal"""
+    _addon()
+    from hostsim.build import build as build_hostsim
+    _run_fuzz(build_hostsim(), 200, "ci-1")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_differential_fuzz_of_the_public_api_gpu():
+    from elliptic_amd.js import build as jb
+    jb.build()
+    _run_fuzz(None, 600, "gpu-1")
+
+
 def _run_eddsa_edges(lib):
     env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
     if lib:

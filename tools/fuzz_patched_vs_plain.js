@@ -1,0 +1,174 @@
+'use strict';
+// Differential fuzz of the drop-in boundary: the SAME seeded sequence of public-API calls on an
+// unpatched copy of the reference and on a copy patched by install() -- results (canonical affine
+// coordinates, signatures, booleans) and exception MESSAGES must be identical.  Arguments are drawn
+// to sit on the seams: scalars 0, 1, n - 1, n, n + 1, 2^bits - 1, wider than the curve, negative,
+// numbers, hex strings; points that are G, fresh copies of G, -P, P itself twice, infinity, tabled
+// points, off-curve points, non-canonical coordinates; messages as arrays, hex strings, BNs, empty,
+// longer than n; signatures as objects, DER hex, DER arrays, corrupted; keys as points, hex, objects.
+//   ELLGPU_LIB=<hostsim or real library> node tools/fuzz_patched_vs_plain.js [iterations] [seed]
+var crypto = require('crypto');
+var loader = require('./ref_loader');
+var A = loader.load(), B = loader.load();
+var plain = A.elliptic, patched = B.elliptic;
+var eng = require('../elliptic_amd/js').install(patched, { libPath: process.env.ELLGPU_LIB });
+var ITER = +(process.argv[2] || 400), SEED = process.argv[3] || 'fuzz-1';
+
+function Prng(seed) { this.seed = seed; this.ctr = 0; }
+Prng.prototype.bytes = function(n) {
+  var out = [];
+  while (out.length < n) {
+    var h = crypto.createHash('sha256').update(this.seed + ':' + (this.ctr++)).digest();
+    for (var i = 0; i < h.length && out.length < n; i++) out.push(h[i]);
+  }
+  return out;
+};
+Prng.prototype.int = function(m) { var b = this.bytes(4); return (((b[0] << 24) | (b[1] << 16) | (b[2] << 8) | b[3]) >>> 0) % m; };
+Prng.prototype.pick = function(a) { return a[this.int(a.length)]; };
+
+function canon(v) {
+  // a comparable rendering of whatever a call returned
+  if (v === null || v === undefined || typeof v === 'boolean' || typeof v === 'number' || typeof v === 'string') return String(v);
+  if (Array.isArray(v)) return '[' + v.map(canon).join(',') + ']';
+  if (v.r && v.s && v.recoveryParam !== undefined) return 'sig(' + v.r.toString(16) + ',' + v.s.toString(16) + ',' + v.recoveryParam + ')';
+  if (typeof v.isInfinity === 'function') {
+    if (v.isInfinity() && v.curve.type !== 'edwards') return 'O';
+    if (typeof v.toP === 'function' && v.z !== undefined && v.curve.type === 'short') v = v.toP();
+    if (v.curve.type === 'mont') return 'x=' + v.getX().toString(16);
+    var q = v.curve.type === 'edwards' ? v.curve.point(v.x, v.y, v.z, v.t) : v;
+    return '(' + q.getX().toString(16) + ',' + q.getY().toString(16) + ')';
+  }
+  if (v.constructor && v.constructor.name === 'BN') return 'bn' + v.toString(16);
+  if (typeof v.toHex === 'function') return 'hex' + v.toHex();
+  return JSON.stringify(v);
+}
+function run(f) { try { return 'v:' + canon(f()); } catch (e) { return 'e:' + String(e && e.message); } }
+
+var SHORT = ['secp256k1', 'p192', 'p224', 'p256', 'p384', 'p521'];
+var rng = new Prng(SEED);
+var stats = { calls: 0, threw: 0, byOp: {} };
+var failures = [];
+
+function scalar(L, c, BN) {
+  var n = c.n, bits = c.p.bitLength();
+  var k = rng.int(16);
+  switch (k) {
+    case 0: return new BN(0);
+    case 1: return new BN(1);
+    case 2: return n.subn(1);
+    case 3: return n.clone();
+    case 4: return n.addn(1);
+    case 5: return new BN(1).ushln(8 * c.p.byteLength()).subn(1);
+    case 6: return new BN(rng.bytes(c.p.byteLength() + 3));            // wider than the curve
+    case 7: return new BN(rng.bytes(8)).neg();                        // negative
+    case 8: return new BN(rng.bytes(16));
+    case 9: return c.endo ? c.endo.lambda.clone() : new BN(2);
+    case 10: return new BN(1).ushln(bits - 1);
+    default: return new BN(rng.bytes(c.p.byteLength())).umod(n);
+  }
+}
+function pointOn(lib, name, which, seedScalar) {
+  // the same point on either library, built from the same recipe
+  var c = lib.curves[name].curve;
+  var BN = c.p.constructor;
+  var P = c.g.mul(new BN(seedScalar, 16));
+  switch (which) {
+    case 0: return c.g;
+    case 1: return c.type === 'mont' ? c.point(c.g.getX(), new BN(1)) : c.point(c.g.getX(), c.g.getY());
+    case 2: return P;
+    case 3: return c.type === 'short' ? P.neg() : P;
+    case 4: return c.type === 'short' ? c.point(null, null) : P;
+    case 5: if (c.type !== 'mont') { var T = c.point(P.getX(), P.getY()); T.precompute(c.n.bitLength() + 1); return T; } return P;
+    case 6: return c.type === 'mont' ? c.point(new BN(seedScalar, 16).umod(c.p), new BN(1)) :
+      c.point(new BN(seedScalar, 16).umod(c.p), new BN(seedScalar, 16).addn(7).umod(c.p));            // off the curve (w.h.p.)
+    case 7: return c.type === 'short' ? c.point(P.getX().add(c.p), P.getY()) : P;                    // non-canonical x (reduced by toRed)
+    default: return c.type === 'mont' ? P : c.point(P.getX(), P.getY());
+  }
+}
+
+function both(op, fa, fb) {
+  var a = run(fa), b = run(fb);
+  stats.calls++;
+  stats.byOp[op] = (stats.byOp[op] || 0) + 1;
+  if (a[0] === 'e') stats.threw++;
+  if (a !== b) failures.push({ op: op, reference: a.slice(0, 300), patched: b.slice(0, 300) });
+}
+
+for (var it = 0; it < ITER && failures.length < 5; it++) {
+  var name = rng.pick(SHORT.concat(['secp256k1', 'p256', 'ed25519', 'ed25519', 'curve25519']));
+  var ca = plain.curves[name].curve, cb = patched.curves[name].curve;
+  var BNa = ca.p.constructor, BNb = cb.p.constructor;
+  var kind = rng.int(10);
+  var s1 = Buffer.from(rng.bytes(20)).toString('hex'), s2 = Buffer.from(rng.bytes(20)).toString('hex');
+  var w1 = rng.int(9), w2 = rng.int(9);
+  if (ca.type === 'edwards') { ca.g.precompute(ca.n.bitLength() + 1); cb.g.precompute(cb.n.bitLength() + 1); }
+  (function() {
+    var rs = rng.ctr;                                 // scalars drawn identically for both libraries
+    function scal(c, BN) { var save = rng.ctr; rng.ctr = rs; var k = scalar(0, c, BN); rs = rng.ctr; rng.ctr = save; return k; }
+    if (kind <= 2 || ca.type === 'mont') {
+      var kA = scal(ca, BNa); rs -= (rng.ctr, 0);
+      var kh = kA.toString(16);
+      both(name + ' mul', function() { return pointOn(plain, name, w1, s1).mul(new BNa(kh, 16)); },
+        function() { return pointOn(patched, name, w1, s1).mul(new BNb(kh, 16)); });
+    } else if (kind <= 5) {
+      var k1 = scal(ca, BNa).toString(16), k2 = scal(ca, BNa).toString(16);
+      var jm = kind === 5 && ca.type === 'short';
+      both(name + (jm ? ' jmulAdd' : ' mulAdd'), function() {
+        var P = pointOn(plain, name, w1, s1), Q = pointOn(plain, name, w2, s2);
+        return jm ? P.jmulAdd(new BNa(k1, 16), Q, new BNa(k2, 16)) : P.mulAdd(new BNa(k1, 16), Q, new BNa(k2, 16));
+      }, function() {
+        var P = pointOn(patched, name, w1, s1), Q = pointOn(patched, name, w2, s2);
+        return jm ? P.jmulAdd(new BNb(k1, 16), Q, new BNb(k2, 16)) : P.mulAdd(new BNb(k1, 16), Q, new BNb(k2, 16));
+      });
+    } else if (ca.type === 'short') {
+      // ECDSA: sign with one library's key material on both, verify / recover variants
+      var eca = new plain.ec(name), ecb = new patched.ec(name);
+      var priv = new BNa(rng.bytes(ca.n.byteLength())).umod(ca.n.subn(1)).addn(1).toString(16);
+      var mlen = rng.pick([0, 1, 20, 32, 32, 32, 48, 64, 70]);
+      var mb = rng.bytes(mlen);
+      var mform = rng.int(5);
+      var msg = mform === 0 ? mb : mform === 1 ? Buffer.from(mb).toString('hex') : mform === 2 ? Buffer.from(mb) :
+        mform === 3 ? mb.map(function(x, i) { return i === 0 ? x + 256 : x; }) : mb;
+      var opts = rng.int(4) === 0 ? { canonical: true } : undefined;
+      both(name + ' sign', function() { return eca.sign(msg, priv, 'hex', opts); }, function() { return ecb.sign(msg, priv, 'hex', opts); });
+      var sig;
+      try { sig = eca.sign(mb, priv, 'hex'); } catch (e) { sig = null; }
+      if (sig) {
+        var form = rng.int(5);
+        var sg = form === 0 ? { r: sig.r.toString(16), s: sig.s.toString(16) } : form === 1 ? sig.toDER('hex') : form === 2 ? sig.toDER() :
+          form === 3 ? { r: sig.r.xor(new BNa(1)).toString(16), s: sig.s.toString(16) } : sig.toDER('hex').slice(0, -2);
+        var pubHex = eca.keyFromPrivate(priv, 'hex').getPublic(rng.int(2) === 0, 'hex');
+        var keyForm = rng.int(4);
+        var keyA = keyForm === 0 ? pubHex : keyForm === 1 ? pointOn(plain, name, 6, s1) : keyForm === 2 ? '05' + pubHex.slice(2) : pubHex;
+        var keyB = keyForm === 1 ? pointOn(patched, name, 6, s1) : keyA;
+        var mv = rng.int(3) === 0 ? Buffer.from(mb).toString('hex') : mb;
+        both(name + ' verify', function() { return eca.verify(mv, sg, keyA, 'hex'); }, function() { return ecb.verify(mv, sg, keyB, 'hex'); });
+        var j = rng.int(5);
+        both(name + ' recoverPubKey', function() { return eca.recoverPubKey(mb, sg, j); }, function() { return ecb.recoverPubKey(mb, sg, j); });
+        var xh = new BNa(rng.bytes(ca.p.byteLength())).toString(16);
+        both(name + ' pointFromX', function() { return ca.pointFromX(xh, rng.ctr % 2 === 0); }, function() { return cb.pointFromX(xh, rng.ctr % 2 === 0); });
+        both(name + ' derive', function() { return eca.keyFromPrivate(priv, 'hex').derive(eca.keyFromPublic(pubHex, 'hex').getPublic()); },
+          function() { return ecb.keyFromPrivate(priv, 'hex').derive(ecb.keyFromPublic(pubHex, 'hex').getPublic()); });
+      }
+    } else if (ca.type === 'edwards') {
+      var eda = new plain.eddsa('ed25519'), edb = new patched.eddsa('ed25519');
+      var secLen = rng.pick([32, 32, 32, 16, 40]);
+      var secret = Buffer.from(rng.bytes(secLen)).toString('hex');
+      var m2 = rng.bytes(rng.pick([0, 1, 3, 32, 100]));
+      both('eddsa sign', function() { return eda.sign(m2, secret).toHex(); }, function() { return edb.sign(m2, secret).toHex(); });
+      var sigh;
+      try { sigh = eda.sign(m2, secret).toHex(); } catch (e) { sigh = null; }
+      if (sigh) {
+        var pubh = eda.keyFromSecret(secret).getPublic('hex');
+        var tw = rng.int(4);
+        var sgh = tw === 1 ? (sigh.slice(0, 10) + (sigh[10] === 'a' ? 'b' : 'a') + sigh.slice(11)) : sigh;
+        var ph = tw === 2 ? ('ff' + pubh.slice(2)) : pubh;
+        both('eddsa verify', function() { return eda.verify(m2, sgh, ph); }, function() { return edb.verify(m2, sgh, ph); });
+        var yh = new BNa(rng.bytes(32)).toString(16);
+        both('ed pointFromY', function() { return ca.pointFromY(yh, false); }, function() { return cb.pointFromY(yh, false); });
+      }
+    }
+  })();
+}
+if (failures.length) { console.log(JSON.stringify({ ok: false, seed: SEED, failures: failures }, null, 1)); process.exit(1); }
+console.log(JSON.stringify({ ok: true, seed: SEED, calls: stats.calls, reference_threw: stats.threw, by_op: stats.byOp, engine: eng.stats }));
