@@ -661,7 +661,10 @@ function install(elliptic, options) {
       eng.stats.passthrough++;
       return orig.sign.apply(this, arguments);
     }
-    if (!SigCtor) SigCtor = orig.sign.call(new elliptic.ec('p192'), [ 1 ], '01', 'hex').constructor;
+    // (the Signature class is not exported: it is taken from a signature the CALLER's own EC
+    // instance makes with the original method -- constructing another EC here would give that
+    // preset's shared G its tables as a side effect, which the unpatched library does not do)
+    if (!SigCtor) SigCtor = orig.sign.call(this, [ 1 ], '01', 'hex').constructor;
     return new SigCtor({ r: new BN(res.r), s: new BN(res.s), recoveryParam: res.recid[0] });
   };
   orig.recoverPubKey = ecProto.recoverPubKey;

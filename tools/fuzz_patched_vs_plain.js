@@ -86,12 +86,13 @@ function pointOn(lib, name, which, seedScalar) {
   }
 }
 
+var context = '';
 function both(op, fa, fb) {
   var a = run(fa), b = run(fb);
   stats.calls++;
   stats.byOp[op] = (stats.byOp[op] || 0) + 1;
   if (a[0] === 'e') stats.threw++;
-  if (a !== b) failures.push({ op: op, reference: a.slice(0, 300), patched: b.slice(0, 300) });
+  if (a !== b) failures.push({ op: op, args: context, reference: a.slice(0, 300), patched: b.slice(0, 300) });
 }
 
 for (var it = 0; it < ITER && failures.length < 5; it++) {
@@ -113,6 +114,8 @@ for (var it = 0; it < ITER && failures.length < 5; it++) {
     } else if (kind <= 5) {
       var k1 = scal(ca, BNa).toString(16), k2 = scal(ca, BNa).toString(16);
       var jm = kind === 5 && ca.type === 'short';
+      context = JSON.stringify({ w1: w1, s1: s1, k1: k1, w2: w2, s2: s2, k2: k2,
+        gTablesRef: !!(ca.g.precomputed && ca.g.precomputed.naf), gTablesPatched: !!(cb.g.precomputed && cb.g.precomputed.naf) });
       both(name + (jm ? ' jmulAdd' : ' mulAdd'), function() {
         var P = pointOn(plain, name, w1, s1), Q = pointOn(plain, name, w2, s2);
         return jm ? P.jmulAdd(new BNa(k1, 16), Q, new BNa(k2, 16)) : P.mulAdd(new BNa(k1, 16), Q, new BNa(k2, 16));
@@ -170,5 +173,52 @@ for (var it = 0; it < ITER && failures.length < 5; it++) {
     }
   })();
 }
+// user-defined curves (run-time modulus kernels): the reference's own test curves and three others,
+// as tools/gen_golden_custom.js defines them -- Point#mul / mulAdd / jmulAdd / add with seam scalars,
+// infinity, off-curve points; scalars as numbers and hex strings on a preset (Point#mul converts them)
+(function() {
+  var fs = require('fs'), path = require('path');
+  var specs = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'tests', 'golden', 'custom_short.json')));
+  var eds = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'tests', 'golden', 'custom_edwards.json')));
+  function mkShort(lib, sp) {
+    return new lib.curve.short({ p: sp.p, a: sp.a, b: sp.b, n: sp.n, g: [sp.g.x, sp.g.y] });
+  }
+  function mkEd(lib, sp) {
+    return new lib.curve.edwards({ p: sp.p, a: sp.a, c: '1', d: sp.d, n: sp.n || null, g: [sp.g.x, sp.g.y] });
+  }
+  var made = [];
+  specs.forEach(function(sp) { made.push({ name: sp.name, a: mkShort(plain, sp), b: mkShort(patched, sp), type: 'short' }); });
+  eds.forEach(function(sp) { made.push({ name: sp.name, a: mkEd(plain, sp), b: mkEd(patched, sp), type: 'edwards' }); });
+  for (var it = 0; it < Math.ceil(ITER / 4) && failures.length < 5; it++) {
+    var m = rng.pick(made);
+    var BNa = m.a.p.constructor, BNb = m.b.p.constructor;
+    var nn = m.a.n || m.a.p;
+    var ks = [new BNa(0), new BNa(1), nn.subn(1), nn.clone(), nn.addn(1), new BNa(rng.bytes(m.a.p.byteLength())),
+      new BNa(rng.bytes(m.a.p.byteLength())).umod(nn), new BNa(rng.bytes(40)), new BNa(rng.bytes(4)).neg()];
+    var k1 = rng.pick(ks).toString(16), k2 = rng.pick(ks).toString(16);
+    var d1 = new BNa(rng.bytes(8)).toString(16), d2 = new BNa(rng.bytes(8)).toString(16);
+    var off = rng.int(6) === 0;
+    function pt(c, BN, d) {
+      var P = c.g.mul(new BN(d, 16));
+      if (c.type === 'edwards') return off ? c.point(P.getX().addn(1).umod(c.p), P.getY()) : c.point(P.getX(), P.getY());
+      if (P.isInfinity()) return P;
+      return off ? c.point(P.getX(), P.getY().addn(1).umod(c.p)) : P;
+    }
+    var op = rng.int(4);
+    if (op === 0) both(m.name + ' mul', function() { return pt(m.a, BNa, d1).mul(new BNa(k1, 16)); }, function() { return pt(m.b, BNb, d1).mul(new BNb(k1, 16)); });
+    else if (op === 1 && m.type === 'short') both(m.name + ' mulAdd', function() { return pt(m.a, BNa, d1).mulAdd(new BNa(k1, 16), pt(m.a, BNa, d2), new BNa(k2, 16)); },
+      function() { return pt(m.b, BNb, d1).mulAdd(new BNb(k1, 16), pt(m.b, BNb, d2), new BNb(k2, 16)); });
+    else if (op === 2 && m.type === 'short') both(m.name + ' jmulAdd', function() { return pt(m.a, BNa, d1).jmulAdd(new BNa(k1, 16), pt(m.a, BNa, d2), new BNa(k2, 16)); },
+      function() { return pt(m.b, BNb, d1).jmulAdd(new BNb(k1, 16), pt(m.b, BNb, d2), new BNb(k2, 16)); });
+    else both(m.name + ' add', function() { return pt(m.a, BNa, d1).add(pt(m.a, BNa, d2)); }, function() { return pt(m.b, BNb, d1).add(pt(m.b, BNb, d2)); });
+  }
+  // Point#mul with a number / a hex string (short.js:422: k = new BN(k, 16))
+  ['secp256k1', 'p256', 'ed25519'].forEach(function(name) {
+    [7, 0, 65537, 'ff', '0', 'deadbeefdeadbeefdeadbeefdeadbeefdeadbeefdeadbeefdeadbeefdeadbeef01'].forEach(function(k) {
+      both(name + ' mul(non-BN)', function() { return pointOn(plain, name, 8, 'abcdef').mul(k); }, function() { return pointOn(patched, name, 8, 'abcdef').mul(k); });
+      both(name + ' g.mul(non-BN)', function() { return plain.curves[name].curve.g.mul(k); }, function() { return patched.curves[name].curve.g.mul(k); });
+    });
+  });
+})();
 if (failures.length) { console.log(JSON.stringify({ ok: false, seed: SEED, failures: failures }, null, 1)); process.exit(1); }
 console.log(JSON.stringify({ ok: true, seed: SEED, calls: stats.calls, reference_threw: stats.threw, by_op: stats.byOp, engine: eng.stats }));
