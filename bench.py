@@ -413,6 +413,15 @@ def roofline_block(kernel_key, unit_key, n, kernel_ms, peak_gmads, clock_ghz, co
             waves_per_simd = (n / 64.0) / N_SIMD
             elapsed = kernel_ms * 1e-3 * clock_ghz * 1e9
             cpi = elapsed / (waves_per_simd * k["valu_per_unit"]) if waves_per_simd else None
+            # two-class issue model (profiles/r04_issue_runs.log): multiplies and
+            # carry / select / 64-bit instructions occupy a 4-cycle wave64 slot each, plain 32-bit moves,
+            # adds and logic ride behind them for free.  INT64 + INT32 is the PMC's upper bound of the
+            # slow class (INT32 also counts the plain adds), so this is the fraction of the kernel's
+            # SIMD cycles that such slots account for at the nominal clock (the part sustains ~8 % less)
+            slow = (k.get("mad_u64_per_unit") or 0) + (k.get("int32_per_unit") or 0)
+            out["issue_slots"] = {"slow_class_insts_per_unit_upper_bound": slow, "cycles_per_slot": 4,
+                                  "frac_of_elapsed_cycles_at_nominal_clock":
+                                      (waves_per_simd * slow * 4.0 / elapsed) if elapsed and slow else None}
             out["issue"] = {"valu_insts_per_wave": k["valu_per_unit"], "waves_per_simd": waves_per_simd,
                             "elapsed_cycles_at_nominal_clock": elapsed, "cycles_per_valu_inst": cpi,
                             "floor_cycles_per_valu_inst": 4.0,
