@@ -220,5 +220,34 @@ for (var it = 0; it < ITER && failures.length < 5; it++) {
     });
   });
 })();
+// uninstall() puts the reference's own functions back: every method install() replaces must read
+// exactly like the unpatched library's again
+(function() {
+  eng.uninstall();
+  var pairs = [
+    ['base._fixedNafMul', plain.curve.base.prototype._fixedNafMul, patched.curve.base.prototype._fixedNafMul],
+    ['base._wnafMul', plain.curve.base.prototype._wnafMul, patched.curve.base.prototype._wnafMul],
+    ['base._wnafMulAdd', plain.curve.base.prototype._wnafMulAdd, patched.curve.base.prototype._wnafMulAdd],
+    ['short._endoWnafMulAdd', plain.curve.short.prototype._endoWnafMulAdd, patched.curve.short.prototype._endoWnafMulAdd],
+    ['short.pointFromX', plain.curve.short.prototype.pointFromX, patched.curve.short.prototype.pointFromX],
+    ['edwards.pointFromY', plain.curve.edwards.prototype.pointFromY, patched.curve.edwards.prototype.pointFromY],
+    ['edwards.pointFromX', plain.curve.edwards.prototype.pointFromX, patched.curve.edwards.prototype.pointFromX],
+    ['ec.sign', plain.ec.prototype.sign, patched.ec.prototype.sign],
+    ['ec.recoverPubKey', plain.ec.prototype.recoverPubKey, patched.ec.prototype.recoverPubKey],
+    ['eddsa.verify', plain.eddsa.prototype.verify, patched.eddsa.prototype.verify],
+    ['eddsa.sign', plain.eddsa.prototype.sign, patched.eddsa.prototype.sign],
+    ['mont Point#mul', plain.curves.curve25519.curve.g.constructor.prototype.mul, patched.curves.curve25519.curve.g.constructor.prototype.mul],
+  ];
+  pairs.forEach(function(q) {
+    if (String(q[1]) !== String(q[2])) failures.push({ op: 'uninstall', args: q[0], reference: String(q[1]).slice(0, 80), patched: String(q[2]).slice(0, 80) });
+  });
+  // ... and the library works without the engine afterwards
+  var e1 = new plain.ec('secp256k1'), e2 = new patched.ec('secp256k1');
+  var k1 = e1.keyFromPrivate('0123456789abcdef', 'hex'), k2 = e2.keyFromPrivate('0123456789abcdef', 'hex');
+  var before = eng.stats.gpuCalls;
+  both('after uninstall: sign + verify', function() { var s = e1.sign([1, 2, 3], k1); return [s, e1.verify([1, 2, 3], s, k1)]; },
+    function() { var s = e2.sign([1, 2, 3], k2); return [s, e2.verify([1, 2, 3], s, k2)]; });
+  if (eng.stats.gpuCalls !== before) failures.push({ op: 'uninstall', args: 'engine still called', reference: '', patched: '' });
+})();
 if (failures.length) { console.log(JSON.stringify({ ok: false, seed: SEED, failures: failures }, null, 1)); process.exit(1); }
 console.log(JSON.stringify({ ok: true, seed: SEED, calls: stats.calls, reference_threw: stats.threw, by_op: stats.byOp, engine: eng.stats }));
