@@ -177,9 +177,7 @@ static int ell_backend_create(int device, ell::HipBackend* bk, std::string* err)
   bk->cur = bk->own;
   if (hipStreamCreateWithFlags(&bk->copy, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&bk->copy_out, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&bk->own2, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&bk->side[0], hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&bk->side[1], hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; return ell::E_HIP; }
+      hipStreamCreateWithFlags(&bk->own2, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; return ell::E_HIP; }
   for (int i = 0; i < ell::HipBackend::RING; i++)
     if (hipEventCreateWithFlags(&bk->ring[i], hipEventDisableTiming) != hipSuccess) { *err = "hipEventCreate failed"; return ell::E_HIP; }
   if (hipEventCreateWithFlags(&bk->inflight_done, hipEventDisableTiming) != hipSuccess) { *err = "hipEventCreate failed"; return ell::E_HIP; }
@@ -194,7 +192,6 @@ static void ell_backend_destroy(ell::HipBackend* bk) {
   bk->copy_out = nullptr;
   if (bk->own2) (void)hipStreamDestroy(bk->own2);
   bk->copy = bk->own2 = nullptr;
-  for (int i = 0; i < 2; i++) { if (bk->side[i]) (void)hipStreamDestroy(bk->side[i]); bk->side[i] = nullptr; }
   for (int i = 0; i < ell::HipBackend::RING; i++)
     if (bk->ring[i]) { (void)hipEventDestroy(bk->ring[i]); bk->ring[i] = nullptr; }
   if (bk->inflight_done) { (void)hipEventDestroy(bk->inflight_done); bk->inflight_done = nullptr; }

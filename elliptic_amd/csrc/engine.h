@@ -211,9 +211,9 @@ struct FnEdcDomainMark {
     if (i < n) EdcWork::domain_mark(i, xy1, xy2, out_xy, out_inf);
   }
 };
-// MW != 0: a second instantiation held to 512 / MW registers (its own translation unit, default
-// scheduling strategy): the one that runs BESIDE ecdsa_table in the small-grid verify -- at 216
-// registers two waves of ecdsa_prep leave a SIMD no room for anything else, and the two kernels
+// MW != 0: a second instantiation held to 512 / MW registers (default scheduling strategy): the
+// one that runs BESIDE ecdsa_table in the small-grid verify (FnEcdsaPrepTable) -- at 216
+// registers two waves of ecdsa_prep leave a SIMD no room for anything else, and the two jobs
 // would take turns instead of sharing it (profiles/r04_split_verify_ab.txt)
 template <class CV, int MW = 0>
 struct FnEcdsaPrep {
@@ -243,8 +243,8 @@ struct FnEcdsaMain {
     if (i < n) W::template ecdsa_main<WIDE>(i, n, u12, valid, r, pub, comb, tbl, ds, ok);
   }
 };
-// the small-grid verify in two kernels (Work::ecdsa_table / ecdsa_ladder): the table kernel runs
-// beside ecdsa_prep, the ladder after both
+// the small-grid verify in two kernels (Work::ecdsa_table / ecdsa_ladder): the tables are built
+// beside ecdsa_prep (FnEcdsaPrepTable), the ladder after both
 template <class CV, bool WIDE = true>
 struct FnEcdsaTable {
   static constexpr const char* NAME = "ecdsa_table";
@@ -266,6 +266,23 @@ struct FnEcdsaLadder {
   const typename W::A* comb; const typename W::VT* tbl; u8* ok;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
     if (i < n) W::template ecdsa_ladder<WIDE>(i, n, u12, valid, r, pub, comb, tbl, ds, ok);
+  }
+};
+
+// ecdsa_prep and ecdsa_table in ONE launch (horizontal fusion): workgroups below `tpad` threads
+// run the prep (the 104-register instantiation: at 216 registers two waves of prep would leave a
+// SIMD no room for the table workgroups), the others build window tables -- the two jobs share the
+// SIMDs without a second stream, without events and without a cross-queue wait before the ladder
+template <class CV>
+struct FnEcdsaPrepTable {
+  static constexpr const char* NAME = "ecdsa_prep_table";
+  typedef Work<CV> W;
+  static constexpr int MIN_WAVES = ELL_ECDSA_TABLE_MIN_WAVES;
+  static constexpr int DS_PER_LANE = 0;
+  FnEcdsaPrep<CV, ELL_ECDSA_TABLE_MIN_WAVES> prep; size_t tpad; FnEcdsaTable<CV, true> table;
+  ELL_HD void operator()(size_t tid, const DigitStore& ds) const {
+    if (tid < tpad) prep(tid, ds);
+    else table(tid - tpad, ds);
   }
 };
 
@@ -2032,17 +2049,16 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
     // the table kernel alone takes 0.65 ms where building the table inside ecdsa_main costs
     // 0.5 ms, and there is no latency to hide at four waves per SIMD; small grids only)
     if (wide && split_small_verify()) {
-      // latency-bound batch: the window table does not depend on s^-1, so it is built while
-      // ecdsa_prep runs on the side stream; the ladder waits for both
-      bk.fork_side();
+      // latency-bound batch: the window table does not depend on s^-1, so it is built BESIDE
+      // ecdsa_prep -- one launch whose first workgroups run the prep and whose others build the
+      // tables (FnEcdsaPrepTable); the ladder follows in stream order.  (Round 4 first ran the two
+      // as separate kernels on two streams with an event fork / join: 0.6-1.9 % slower than this
+      // fused launch, profiles/r04_split_verify_ab.txt.)
       const int Ks = inv_batch_beside(n, INV_BATCH_N);
       const size_t Ts = (n + Ks - 1) / Ks;
-      FnEcdsaPrep<CV, ELL_ECDSA_TABLE_MIN_WAVES> fs{Ts, n, Ks, hash, hash_len, shift, r, s, pre, u12, valid};
-      launch_fn(fs, Ts);
-      bk.leave_side();
-      FnEcdsaTable<CV, true> ft{n, pub, tbl};
-      launch_fn(ft, n);
-      bk.join_side();
+      const size_t tpad = (Ts + 127) & ~(size_t)127;          // whole workgroups of either kind
+      FnEcdsaPrepTable<CV> fpt{{Ts, n, Ks, hash, hash_len, shift, r, s, pre, u12, valid}, tpad, {n, pub, tbl}};
+      launch_fn(fpt, tpad + n);
       FnEcdsaLadder<CV, true> fl{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
       return launch_fn(fl, n);
     }

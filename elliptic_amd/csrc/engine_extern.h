@@ -53,10 +53,8 @@ namespace ell {
       const FnEcdsaMain<CvSecp256k1, 3, true>&, size_t);                                             \
   KW template int Engine<HipBackend>::launch_fn<FnMulVar<CvSecp256k1, 3, true>>(                     \
       const FnMulVar<CvSecp256k1, 3, true>&, size_t);                                                \
-  KW template int Engine<HipBackend>::launch_fn<FnEcdsaPrep<CvSecp256k1, ELL_ECDSA_TABLE_MIN_WAVES>>(  \
-      const FnEcdsaPrep<CvSecp256k1, ELL_ECDSA_TABLE_MIN_WAVES>&, size_t);                             \
-  KW template int Engine<HipBackend>::launch_fn<FnEcdsaTable<CvSecp256k1, true>>(                    \
-      const FnEcdsaTable<CvSecp256k1, true>&, size_t);                                               \
+  KW template int Engine<HipBackend>::launch_fn<FnEcdsaPrepTable<CvSecp256k1>>(                      \
+      const FnEcdsaPrepTable<CvSecp256k1>&, size_t);                                                 \
   KW template int Engine<HipBackend>::launch_fn<FnEcdsaLadder<CvSecp256k1, true>>(                   \
       const FnEcdsaLadder<CvSecp256k1, true>&, size_t);
 // user-defined short curves (CvCustom): scalar multiplication and point addition only

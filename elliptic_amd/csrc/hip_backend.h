@@ -60,9 +60,6 @@ struct HipBackend {
   hipStream_t own2 = nullptr;      // second compute lane of the host-buffer entry points
   hipStream_t copy = nullptr;      // H2D of the host-buffer entry points
   hipStream_t copy_out = nullptr;  // D2H of the host-buffer entry points
-  hipStream_t side[2] = {nullptr, nullptr};   // per compute lane: a kernel that runs BESIDE the lane's own (fork_side)
-  hipStream_t forked_from = nullptr;
-  int lane = 0;
   static constexpr int RING = 16;
   hipEvent_t ring[RING] = {};      // cross-stream dependencies (reused round-robin)
   unsigned ring_i = 0;
@@ -164,23 +161,7 @@ struct HipBackend {
   }
   void copy_after(int ev) { note(hipStreamWaitEvent(copy_out, ring[ev], 0)); }
   // compute lane 0 = the context's stream, lane 1 = a second stream for alternate chunks
-  void select_lane(int l) { lane = l ? 1 : 0; cur = lane ? own2 : own; }
-  // fork / join inside one call: launches between fork_side() and leave_side() go to the lane's
-  // side stream, ordered after everything the call's stream holds so far; join_side() makes the
-  // call's stream wait for them.  (Two independent kernels of one call then share the device.)
-  void fork_side() {
-    hipEvent_t e = ring[ring_i++ % RING];
-    note(hipEventRecord(e, cur));
-    note(hipStreamWaitEvent(side[lane], e, 0));
-    forked_from = cur;
-    cur = side[lane];
-  }
-  void leave_side() { cur = forked_from; }
-  void join_side() {
-    hipEvent_t e = ring[ring_i++ % RING];
-    note(hipEventRecord(e, side[lane]));
-    note(hipStreamWaitEvent(cur, e, 0));
-  }
+  void select_lane(int lane) { cur = lane ? own2 : own; }
   // wait for the copy stream and both lanes
   int sync_lanes() {
     note(hipStreamSynchronize(copy));

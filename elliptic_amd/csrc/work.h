@@ -1092,8 +1092,8 @@ struct Work {
   // A batch that leaves two or three waves per SIMD resident (one GPU's share of BASELINE's 2^20
   // over eight) is latency-bound: every lane is ONE dependent chain, s^-1 -> u2 -> digits ->
   // ladder.  But the window table of Q -- a twentieth of the chain -- needs only the key, not
-  // u2: ecdsa_table builds it in a kernel of its own that runs CONCURRENTLY with ecdsa_prep (on
-  // a second stream, Engine::ecdsa_chunk), and ecdsa_ladder starts from the finished table.
+  // u2: ecdsa_table builds it BESIDE ecdsa_prep -- other workgroups of the same launch
+  // (FnEcdsaPrepTable, Engine::ecdsa_chunk) -- and ecdsa_ladder starts from the finished table.
   // The table's common Z (zg) travels in the table's last scratch slot.
   template <bool WIDE>
   ELL_HD static void ecdsa_table(size_t i, size_t n, const u8* pub_xy, VT* tbl_all) {

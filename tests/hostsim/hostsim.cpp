@@ -39,9 +39,6 @@ struct LoopBackend {
   int mark_compute() { return 0; }
   void copy_after(int) {}
   void select_lane(int) {}
-  void fork_side() {}
-  void leave_side() {}
-  void join_side() {}
   int sync_lanes() { return 0; }
   // "threads" of a launch are independent, so the loop is split over the host
   // cores (only to keep the CPU test-suite short)
