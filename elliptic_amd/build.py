@@ -36,7 +36,7 @@ def units():
         for g in GROUPS:
             u.append(("inst_%s_g%d" % (c, g), "inst.hip",
                       ["-DELL_INST_CURVE=" + c, "-DELL_INST_GROUP=%d" % g] + GROUP_FLAGS.get(g, [])))
-    for g in (7, 10, 11, 12, 13, 14, 15, 16):
+    for g in (7, 8, 10, 11, 12, 13, 14, 15, 16):
         u.append(("inst_g%d" % g, "inst.hip", ["-DELL_INST_GROUP=%d" % g]))
     u.append(("capi", "capi.hip", []))
     return u
@@ -121,7 +121,7 @@ def build_dev_k256(verbose=True, curve="CvSecp256k1"):
     work = [("inst_%s_g%d" % (curve, g), "inst.hip", ["-DELL_INST_CURVE=" + curve, "-DELL_INST_GROUP=%d" % g,
                                                       dflag, tflag] + GROUP_FLAGS.get(g, []), digest,
              ["-Rpass-analysis=kernel-resource-usage"]) for g in GROUPS]
-    for g in (7, 10, 11, 12, 13, 14, 15, 16):   # ed25519 / x25519 units are referenced by the engine, keep them linkable
+    for g in (7, 8, 10, 11, 12, 13, 14, 15, 16):   # ed25519 / x25519 units are referenced by the engine, keep them linkable
         work.append(("inst_g%d" % g, "inst.hip", ["-DELL_INST_GROUP=%d" % g, dflag, tflag], digest, []))
     work.append(("capi_%s" % curve, "capi.hip", [dflag, tflag], digest, []))
     for f in os.listdir(OBJ):

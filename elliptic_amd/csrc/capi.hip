@@ -173,6 +173,8 @@ static int ell_backend_create(int device, ell::HipBackend* bk, std::string* err)
   }
   bk->device = device;
   if (prop.multiProcessorCount > 0) bk->cus = prop.multiProcessorCount;
+  bk->one_wave_groups = (size_t)bk->cus * 4 * 64 * 4;
+  if (const char* e = getenv("ELLGPU_ONE_WAVE_GROUPS")) bk->one_wave_groups = (size_t)strtoull(e, nullptr, 10);
   if (hipStreamCreateWithFlags(&bk->own, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; return ell::E_HIP; }
   bk->cur = bk->own;
   if (hipStreamCreateWithFlags(&bk->copy, hipStreamNonBlocking) != hipSuccess ||

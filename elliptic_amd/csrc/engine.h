@@ -286,6 +286,66 @@ struct FnEcdsaPrepTable {
   }
 };
 
+// The parted verify (Work::ecdsa_half / ecdsa_fixed / ecdsa_join): batches that leave most SIMDs
+// without a wave.  One launch of three regions of `npad` threads -- whole workgroups each, so a
+// wave belongs to ONE part -- runs the two half ladders and the comb of every item in different
+// waves; the join adds up.  256 registers per lane: a lone chain has no neighbour to make room for.
+template <class CV>
+struct FnEcdsaParts {
+  static constexpr const char* NAME = "ecdsa_parts";
+  typedef Work<CV> W;
+  static constexpr int MIN_WAVES = 2;
+  static constexpr int DS_PER_LANE = W::template Endo<true>::NW;
+  size_t n; size_t npad; const u32* u12; const typename W::A* comb; const typename W::VT* tbl; u32* jac;
+  ELL_HD void operator()(size_t tid, const DigitStore& ds) const {
+    const int part = tid >= 2 * npad ? 2 : (tid >= npad ? 1 : 0);
+    const size_t i = tid - (size_t)part * npad;
+    if (i >= n) return;
+    u32* out = jac + (size_t)part * 3 * W::NS * n;
+    if (part == 2) W::ecdsa_fixed(i, n, u12, comb, out);
+    else W::template ecdsa_half<true>(i, n, part, u12, tbl, ds, out);
+  }
+};
+template <class CV>
+struct FnEcdsaJoin {
+  static constexpr const char* NAME = "ecdsa_join";
+  typedef Work<CV> W;
+  static constexpr int MIN_WAVES = 2;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* valid; const u8* r; const u8* pub; const typename W::VT* tbl; const u32* jac; u8* ok;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::template ecdsa_join<true>(i, n, valid, r, pub, tbl, jac, ok);
+  }
+};
+
+// Point#mul in the parted form (Work::mul_half / mul_join)
+template <class CV>
+struct FnMulParts {
+  static constexpr const char* NAME = "mul_parts";
+  typedef Work<CV> W;
+  static constexpr int MIN_WAVES = 2;
+  static constexpr int DS_PER_LANE = W::template Endo<true>::NW;
+  size_t n; size_t npad; const u8* k; const u8* xy; typename W::VT* tbl; u32* jac;
+  ELL_HD void operator()(size_t tid, const DigitStore& ds) const {
+    const int half = tid >= npad ? 1 : 0;
+    const size_t i = tid - (size_t)half * npad;
+    if (i >= n) return;
+    W::template mul_half<true>(i, n, half, k, xy, tbl + (size_t)half * n * W::template stride<true>(), ds,
+                               jac + (size_t)half * 3 * W::NS * n);
+  }
+};
+template <class CV>
+struct FnMulJoin {
+  static constexpr const char* NAME = "mul_join";
+  typedef Work<CV> W;
+  static constexpr int MIN_WAVES = 2;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u32* jac; const u8* xy; u8* out_xy; u8* out_inf; typename W::A* raw;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::mul_join(i, n, jac, xy, out_xy, out_inf, raw);
+  }
+};
+
 template <class CV, int MW = 0>
 struct FnSignMul {
   static constexpr const char* NAME = "sign_mul";
@@ -663,11 +723,15 @@ class Engine {
   //                        default: three waves on every SIMD of the device
   //   ELLGPU_SPLIT_VERIFY  0 keeps small-grid verifies on prep -> ecdsa_main (default: prep ||
   //                        table -> ladder)
+  //   ELLGPU_PARTED_GRID   largest batch that takes the parted verify (FnEcdsaParts; 0 = never);
+  //                        default: half a wave round -- the two half ladders of every item find a
+  //                        SIMD of their own (the comb's waves are short)
   //   ELLGPU_PREP_K        items per inversion in the scalar-field kernels (default: by batch size)
   struct Tuning {
     size_t wave_round;        // lanes of one wave on every SIMD of the device
     size_t small_grid;
     bool split_verify;
+    size_t parted_grid;       // largest batch that takes the parted verify (three lanes per item)
     int prep_k;
     int norm_k;
   };
@@ -678,6 +742,8 @@ class Engine {
     tune_.small_grid = e ? (size_t)strtoull(e, nullptr, 10) : 3 * tune_.wave_round;
     e = getenv("ELLGPU_SPLIT_VERIFY");
     tune_.split_verify = !(e && e[0] == '0');
+    e = getenv("ELLGPU_PARTED_GRID");
+    tune_.parted_grid = e ? (size_t)strtoull(e, nullptr, 10) : tune_.wave_round / 2;
     e = getenv("ELLGPU_PREP_K");
     tune_.prep_k = e ? atoi(e) : 0;
     e = getenv("ELLGPU_NORM_K");
@@ -685,6 +751,7 @@ class Engine {
   }
   size_t small_grid() const { return tune_.small_grid; }
   bool split_small_verify() const { return tune_.split_verify; }
+  size_t parted_grid() const { return tune_.parted_grid; }
   // ... and for the ecdsa_prep that runs BESIDE ecdsa_table (small-grid verify): the two kernels
   // share the SIMDs, so what counts is the work, not the latency of a lone chain -- the largest K
   // that still leaves half a wave round of threads (131 072 items: K = 4, 1.332 -> 1.318 ms per
@@ -696,7 +763,13 @@ class Engine {
     return k;
   }
   // items per inversion in normalize (ELLGPU_NORM_K overrides)
-  int norm_batch_for(size_t) const { return tune_.norm_k >= 1 && tune_.norm_k <= 64 ? tune_.norm_k : INV_BATCH; }
+  // -- on a batch that leaves SIMDs idle the chain of K items per thread counts, not the inversions
+  int norm_batch_for(size_t n) const {
+    if (tune_.norm_k >= 1 && tune_.norm_k <= 64) return tune_.norm_k;
+    int k = INV_BATCH;
+    while (k > 1 && n / (size_t)k < tune_.wave_round / 2) k >>= 1;
+    return k;
+  }
   int inv_batch_for(size_t n, int kmax) const {
     if (tune_.prep_k >= 1 && tune_.prep_k <= 64) return tune_.prep_k;
     int k = kmax;
@@ -1906,12 +1979,20 @@ int Engine<BK>::mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u
   bool wide = false;
   if constexpr (CV::ENDO && W::L <= 8) wide = n <= small_grid();
   const size_t slots = wide ? (size_t)W::template stride<true>() : (size_t)W::template stride<false>();
-  typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * slots * sizeof(typename W::VT));
-  u32* jac = (u32*)scratch(S_JAC, n * 3 * W::NS * 4);
+  // (the parted form: a table and a result per half)
+  const bool parted = wide && n <= parted_grid();
+  typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, (parted ? 2 : 1) * n * slots * sizeof(typename W::VT));
+  u32* jac = (u32*)scratch(S_JAC, (parted ? 2 : 1) * n * 3 * W::NS * 4);
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");
   bool launched = false;
   if constexpr (CV::ENDO && W::L <= 8) {
-    if (wide) {                             // at most three waves per SIMD: the register-rich tuning
+    if (parted) {                           // most SIMDs would idle: two lanes per item, then the join
+      const size_t npad = (n + 127) & ~(size_t)127;            // whole workgroups per half
+      FnMulParts<CV> fp{n, npad, k, xy, tbl, jac};
+      launch_fn(fp, npad + n);
+      FnMulJoin<CV> fj{n, jac, xy, out_xy, out_inf, raw};      // ... to affine, and the domain test
+      return launch_fn(fj, n);
+    } else if (wide) {                      // at most three waves per SIMD: the register-rich tuning
       FnMulVar<CV, 3, true> f{n, k, xy, tbl, jac};
       launch_fn(f, n);
       launched = true;
@@ -2011,8 +2092,9 @@ int Engine<BK>::edc_chunk(int op, size_t n, const u8* k1, const u8* xy1, const u
     FnEdcPointAdd f{n, xy1, a, xy2, b, proj};
     bk.launch(f, n);
   }
-  size_t T = (n + INV_BATCH - 1) / INV_BATCH;
-  FnEdcNormalize g{T, n, INV_BATCH, proj, pre, out_xy, out_inf};
+  const int K = norm_batch_for(n);
+  size_t T = (n + K - 1) / K;
+  FnEdcNormalize g{T, n, K, proj, pre, out_xy, out_inf};
   bk.launch(g, T);
   if (op != 2 && out_inf) {                       // Point#add is one formula: the reference's own
     FnEdcDomainMark h{n, xy1, op == 1 ? xy2 : nullptr, out_xy, out_inf};
@@ -2059,6 +2141,16 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
       const size_t tpad = (Ts + 127) & ~(size_t)127;          // whole workgroups of either kind
       FnEcdsaPrepTable<CV> fpt{{Ts, n, Ks, hash, hash_len, shift, r, s, pre, u12, valid}, tpad, {n, pub, tbl}};
       launch_fn(fpt, tpad + n);
+      if (n <= parted_grid()) {
+        // most SIMDs would idle beside this batch: three lanes per item (FnEcdsaParts), then the join
+        u32* jac = (u32*)scratch(S_JAC, n * 3 * 3 * W::NS * 4);
+        if (!jac) return fail(E_NOMEM, "scratch allocation failed");
+        const size_t npad = (n + 127) & ~(size_t)127;          // whole workgroups per part
+        FnEcdsaParts<CV> fp{n, npad, u12, (const typename W::A*)comb_[CV::ID], tbl, jac};
+        launch_fn(fp, 2 * npad + n);
+        FnEcdsaJoin<CV> fj{n, valid, r, pub, tbl, jac, ok};
+        return launch_fn(fj, n);
+      }
       FnEcdsaLadder<CV, true> fl{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
       return launch_fn(fl, n);
     }
@@ -2122,8 +2214,9 @@ template <int U>
 int Engine<BK>::ed_normalize_chunk(size_t n, const u32* ext, u8* out_xy, u8* out_inf, EdWork::P* raw) {
   u32* pre = (u32*)scratch(S_PRE, n * 8 * 4);
   if (!pre) return fail(E_NOMEM, "scratch allocation failed");
-  size_t T = (n + INV_BATCH - 1) / INV_BATCH;
-  FnEdNormalize f{T, n, INV_BATCH, ext, pre, out_xy, out_inf, raw};
+  const int K = norm_batch_for(n);
+  size_t T = (n + K - 1) / K;
+  FnEdNormalize f{T, n, K, ext, pre, out_xy, out_inf, raw};
   bk.launch(f, T);
   return E_OK;
 }
@@ -2184,8 +2277,9 @@ int Engine<BK>::x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* 
   if (!xz || !pre) return fail(E_NOMEM, "scratch allocation failed");
   FnX25519 f{n, k, x, xz};
   bk.launch(f, n);
-  size_t T = (n + INV_BATCH - 1) / INV_BATCH;
-  FnX25519Normalize g{T, n, INV_BATCH, xz, pre, out_x, out_inf};
+  const int K = norm_batch_for(n);
+  size_t T = (n + K - 1) / K;
+  FnX25519Normalize g{T, n, K, xz, pre, out_x, out_inf};
   bk.launch(g, T);
   return E_OK;
 }
@@ -2295,8 +2389,9 @@ int Engine<BK>::recover_chunk(size_t n, const u8* hash, int hash_len, const u8* 
     u8* odd = flags;
     u8* dec_ok = flags + n;
     u8* inf = flags + 2 * n;
-    size_t T = (n + INV_BATCH_N - 1) / INV_BATCH_N;
-    FnRecoverPrep<CV> f1{T, n, INV_BATCH_N, hash, hash_len, r, s, recid, pre, xs, odd, s1, s2, out_status};
+    const int Kr = inv_batch_for(n, INV_BATCH_N);
+    size_t T = (n + Kr - 1) / Kr;
+    FnRecoverPrep<CV> f1{T, n, Kr, hash, hash_len, r, s, recid, pre, xs, odd, s1, s2, out_status};
     launch_fn(f1, T);
     int rc = decompress_chunk<CV>(n, xs, odd, rxy, dec_ok);
     if (rc) return rc;
@@ -2410,8 +2505,9 @@ int Engine<BK>::sign_chunk(size_t n, const u8* hash, int hash_len, int shift, co
   if (rc) return rc;
   u32* pre = (u32*)scratch(S_PRE, n * (W::LN > W::NS ? W::LN : W::NS) * 4);
   if (!pre) return fail(E_NOMEM, "scratch allocation failed");
-  size_t T = (n + INV_BATCH_N - 1) / INV_BATCH_N;
-  FnSignFinish<CV> f2{T, n, INV_BATCH_N, hash, hash_len, shift, priv, nonces, kg, kg_inf, canonical, pre,
+  const int Kf = inv_batch_for(n, INV_BATCH_N);
+  size_t T = (n + Kf - 1) / Kf;
+  FnSignFinish<CV> f2{T, n, Kf, hash, hash_len, shift, priv, nonces, kg, kg_inf, canonical, pre,
                       out_r, out_s, out_recid, out_ok};
   launch_fn(f2, T);
   return E_OK;

@@ -57,6 +57,16 @@ namespace ell {
       const FnEcdsaPrepTable<CvSecp256k1>&, size_t);                                                 \
   KW template int Engine<HipBackend>::launch_fn<FnEcdsaLadder<CvSecp256k1, true>>(                   \
       const FnEcdsaLadder<CvSecp256k1, true>&, size_t);
+// the parted verify (three lanes per item: batches that leave most of the device idle)
+#define ELL_DECL_G8(KW)                                                                              \
+  KW template int Engine<HipBackend>::launch_fn<FnEcdsaParts<CvSecp256k1>>(                          \
+      const FnEcdsaParts<CvSecp256k1>&, size_t);                                                     \
+  KW template int Engine<HipBackend>::launch_fn<FnEcdsaJoin<CvSecp256k1>>(                           \
+      const FnEcdsaJoin<CvSecp256k1>&, size_t);                                                      \
+  KW template int Engine<HipBackend>::launch_fn<FnMulParts<CvSecp256k1>>(                            \
+      const FnMulParts<CvSecp256k1>&, size_t);                                                       \
+  KW template int Engine<HipBackend>::launch_fn<FnMulJoin<CvSecp256k1>>(                             \
+      const FnMulJoin<CvSecp256k1>&, size_t);
 // user-defined short curves (CvCustom): scalar multiplication and point addition only
 #define ELL_DECL_CUSTOM(KW)                                                                          \
   KW template int Engine<HipBackend>::mul_var_chunk<CvCustom>(size_t, const u8*, const u8*, u8*, u8*, \
@@ -107,5 +117,6 @@ ELL_DECL_ED3(extern)
 ELL_DECL_ED4(extern)
 ELL_DECL_CUSTOM(extern)
 ELL_DECL_G7(extern)
+ELL_DECL_G8(extern)
 
 }  // namespace ell

@@ -36,10 +36,15 @@ struct MinWaves { static constexpr int value = 1; };
 template <class Fn>
 struct MinWaves<Fn, decltype((void)Fn::MIN_WAVES)> { static constexpr int value = Fn::MIN_WAVES; };
 
+// Workgroups are launched with BLOCK lanes on grids that fill the device and with ONE wave (64
+// lanes) on smaller ones (HipBackend::launch): the dispatcher places a workgroup's waves together,
+// and below about four waves per CU whole two-wave workgroups leave some SIMDs with two waves and
+// others with none -- 49 152 verifies took 1.23 ms where 32 768 took 0.95 (profiles/
+// r04_workgroup_size_ab.txt).  The LDS columns keep their BLOCK stride either way.
 template <class Fn>
 __global__ void __launch_bounds__(BLOCK, MinWaves<Fn>::value) k_run(const Fn f, size_t nthreads) {
   __shared__ signed char lds_digits[(Fn::DS_PER_LANE > 0 ? Fn::DS_PER_LANE : 1) * BLOCK];
-  size_t tid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   DigitStore ds{lds_digits + threadIdx.x, BLOCK};
   f(tid, ds);
 }
@@ -106,6 +111,9 @@ struct HipBackend {
   }
   int device_index() const { return device; }
   int cus = 256;                   // compute units of this device (hipDeviceProp_t::multiProcessorCount)
+  // launches of at most this many lanes take one-wave workgroups (see k_run): four waves per SIMD
+  // (ELLGPU_ONE_WAVE_GROUPS overrides, read when the context is created; 0 = never)
+  size_t one_wave_groups = (size_t)256 * 4 * 64 * 4;
   int compute_units() const { return cus; }
   void* own_stream() const { return (void*)own; }
   void rt_upload(const RtField& f) { note((hipError_t)rt_upload_device(&f)); }
@@ -174,14 +182,15 @@ struct HipBackend {
   template <class Fn>
   void launch(const Fn& f, size_t nthreads) {
     if (nthreads == 0) return;
-    unsigned blocks = (unsigned)((nthreads + BLOCK - 1) / BLOCK);
+    const unsigned B = nthreads <= one_wave_groups ? 64u : (unsigned)BLOCK;
+    unsigned blocks = (unsigned)((nthreads + B - 1) / B);
     TimedLaunch t{Fn::NAME, nullptr, nullptr};
     if (timing && timed) {
       note(hipEventCreate(&t.e0));
       note(hipEventCreate(&t.e1));
       note(hipEventRecord(t.e0, cur));
     }
-    hipLaunchKernelGGL(k_run<Fn>, dim3(blocks), dim3(BLOCK), 0, cur, f, nthreads);
+    hipLaunchKernelGGL(k_run<Fn>, dim3(blocks), dim3(B), 0, cur, f, nthreads);
     note(hipGetLastError());
     if (timing && timed) {
       note(hipEventRecord(t.e1, cur));

@@ -21,6 +21,8 @@ ELL_DECL_G5(ELL_NOKW, ELL_INST_CURVE)
 ELL_DECL_G6(ELL_NOKW, ELL_INST_CURVE)
 #elif ELL_INST_GROUP == 7
 ELL_DECL_G7(ELL_NOKW)
+#elif ELL_INST_GROUP == 8
+ELL_DECL_G8(ELL_NOKW)
 #elif ELL_INST_GROUP == 13
 ELL_DECL_ED2(ELL_NOKW)
 #elif ELL_INST_GROUP == 14

@@ -215,8 +215,10 @@ struct Ladder {
   // Halves the table bytes written per item and the region the gathers touch, for one more
   // field multiplication per addition of the second string (ELL_LAMBDA_AT_LOOKUP).
   template <int NS, int NW, bool LAMBDA_AT_LOOKUP = false, bool WIDE = false, int WB = 4>
+  // `lam_all` (NS = 1, the parted ladder of Work::ecdsa_half): this lane's ONE digit string is the
+  // lambda half's -- every entry it looks up takes the factor beta.
   ELL_HD static J run_odd_w4(const DigitStore& ds, const A* tbl, u32 negmask, u32 evenmask, bool& inf,
-                             const El* beta = nullptr) {
+                             const El* beta = nullptr, bool lam_all = false) {
     // table entry for digit string s at window w (digits are odd and non-zero); a function of
     // (w, s) only, so that the additions' rarely taken branch can fetch it again
     auto entry = [&](int w, int s) -> A {
@@ -224,7 +226,7 @@ struct Ladder {
       int ad = d < 0 ? -d : d;
       bool neg = (d < 0) != (((negmask >> s) & 1u) != 0);
       A q = tbl[(LAMBDA_AT_LOOKUP ? 0 : s * (1 << (WB - 1))) + ((ad - 1) >> 1)];
-      if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP, WIDE>(beta));
+      if (LAMBDA_AT_LOOKUP && (s == 1 || lam_all)) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP, WIDE>(beta));
       q.y = cneg_y(q.y, neg);
       return q;
     };
@@ -245,7 +247,7 @@ struct Ladder {
       return *at;
     };
     auto finish = [&](A q, int s, bool neg) -> A {
-      if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP, WIDE>(beta));
+      if (LAMBDA_AT_LOOKUP && (s == 1 || lam_all)) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP, WIDE>(beta));
       q.y = cneg_y(q.y, neg);
       return q;
     };
@@ -283,7 +285,7 @@ struct Ladder {
     for (int s = 0; s < NS; s++) {
       auto corr = [&]() -> A {
         A q = tbl[LAMBDA_AT_LOOKUP ? 0 : s * (1 << (WB - 1))];
-        if (LAMBDA_AT_LOOKUP && s == 1) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP, WIDE>(beta));
+        if (LAMBDA_AT_LOOKUP && (s == 1 || lam_all)) q.x = F::mul(q.x, lookup_beta<LAMBDA_AT_LOOKUP, WIDE>(beta));
         bool neg = ((negmask >> s) & 1u) == 0;        // subtract sign_s * P_s
         q.y = cneg_y(q.y, neg);
         return q;

@@ -1134,6 +1134,115 @@ struct Work {
     out_ok[i] = valid[i] == 0 ? (u8)0 : (!on ? (u8)DOMAIN_OFF_CURVE : (ok ? (u8)1 : (u8)0));
   }
 
+  // ---- the parted form of pass 2 (secp256k1): one verify on THREE lanes ---------------------
+  // A batch that does not give every SIMD of the device a wave -- a single EC#verify, the handful
+  // a server coalesces in one tick -- is one dependent chain per item and nothing else: the
+  // machine idles beside it.  R = u1*G + k1*Q + k2*(lambda Q) is a sum of three independent
+  // scalar multiplications, so the parted form runs them in three DIFFERENT waves (workgroups
+  // of the same launch, FnEcdsaParts): part 0 the ladder of k1 over Q's window table, part 1
+  // that of k2 over the same table with beta at every lookup, part 2 the comb of u1 -- and
+  // ecdsa_join adds the three Jacobian results and compares.  The chain per item falls from
+  // 125 doublings + 51 additions + 12 comb additions to 125 doublings + 25 additions + two full
+  // Jacobian additions; the total work rises by a tenth (which an idle machine does not feel).
+  // Parts 0 and 1 leave their sums on the table's isomorphic curve (Z not yet scaled by zg).
+  template <bool WIDE>
+  ELL_HD static void ecdsa_half(size_t i, size_t n, int half, const u32* u12, const VT* tbl_all,
+                                const DigitStore& ds, u32* jac) {
+    static_assert(ENDO, "the parted verify is the endomorphism curve's");
+    typedef Endo<WIDE> E;
+    u32 u2[L];
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) u2[l] = l < LN ? u12[(size_t)(1 * LN + l) * n + i] : 0u;
+    u32 k1[5], k2[5];
+    bool n1, n2;
+    glv_split<true>(u2, k1, n1, k2, n2);
+    const bool lam = half != 0;
+    ELL_UNROLL
+    for (int l = 0; l < 5; l++) k1[l] = lam ? k2[l] : k1[l];
+    recode_odd_w4<5, E::NW, E::WB>(k1, ds, 0, 1);
+    const u32 negmask = (lam ? n2 : n1) ? 1u : 0u;
+    El beta = load_beta();
+    bool inf;
+    J b = LD::template run_odd_w4<1, E::NW, true, WIDE, E::WB>(ds, tbl_all + i * stride<WIDE>(), negmask, 0u,
+                                                               inf, &beta, lam);
+    store_jac(jac, n, i, b);
+  }
+  ELL_HD static void ecdsa_fixed(size_t i, size_t n, const u32* u12, const A* comb, u32* jac) {
+    u32 u1[L];
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) u1[l] = l < LN ? u12[(size_t)(0 * LN + l) * n + i] : 0u;
+    J c = LD::template comb_mul<L, COMB_W, COMB_BITS, COMB_SIGNED>(u1, comb);
+    store_jac(jac, n, i, c);
+  }
+  // jac: the three parts' results, 3 * NS * n words each
+  template <bool WIDE>
+  ELL_HD static void ecdsa_join(size_t i, size_t n, const u8* valid, const u8* rs, const u8* pub_xy,
+                                const VT* tbl_all, const u32* jac, u8* out_ok) {
+    typedef Endo<WIDE> E;
+    const size_t part = (size_t)3 * NS * n;
+    J b = G::add(load_jac(jac, n, i), load_jac(jac + part, n, i));     // any of O, P = Q, P = -Q included
+    b.Z = F::mul(b.Z, tbl_all[i * stride<WIDE>() + 2 * E::NE - 1].x);   // back from the table's isomorphic curve
+    J p = G::add(b, load_jac(jac + 2 * part, n, i));
+    u32 r[LN];
+    load_be<LN>(r, rs + i * NBYTES, NBYTES);
+    bool ok = !G::is_inf(p);
+    ok = ok && eq_x_to_p(p, r);
+    const bool on = on_curve(load_affine(pub_xy, i));      // see ecdsa_main
+    out_ok[i] = valid[i] == 0 ? (u8)0 : (!on ? (u8)DOMAIN_OFF_CURVE : (ok ? (u8)1 : (u8)0));
+  }
+
+  // ... and Point#mul the same way: k*P = k1*P + k2*(lambda P) on two lanes.  Each half builds
+  // its own copy of P's window table (no launch in front of the ladder; an idle machine does not
+  // feel the second build) and returns its sum in true Jacobian coordinates; mul_join adds.
+  template <bool WIDE>
+  ELL_HD static void mul_half(size_t i, size_t n, int half, const u8* ks, const u8* xy, VT* tbl_all,
+                              const DigitStore& ds, u32* jac) {
+    static_assert(ENDO, "the parted ladder is the endomorphism curve's");
+    typedef Endo<WIDE> E;
+    u32 k[L];
+    load_be<L>(k, ks + i * BYTES, BYTES);
+    u32 k1[5], k2[5];
+    bool n1, n2;
+    glv_split<true>(k, k1, n1, k2, n2);
+    const bool lam = half != 0;
+    ELL_UNROLL
+    for (int l = 0; l < 5; l++) k1[l] = lam ? k2[l] : k1[l];
+    recode_odd_w4<5, E::NW, E::WB>(k1, ds, 0, 1);
+    const u32 negmask = (lam ? n2 : n1) ? 1u : 0u;
+    VT* tbl = tbl_all + i * stride<WIDE>();
+    El zg;
+    LD::template build_table_odd8<E::NE>(tbl, load_affine(xy, i), zg);
+    El beta = load_beta();
+    bool inf;
+    J b = LD::template run_odd_w4<1, E::NW, true, WIDE, E::WB>(ds, tbl, negmask, 0u, inf, &beta, lam);
+    b.Z = F::mul(b.Z, zg);
+    store_jac(jac, n, i, b);
+  }
+  // jac: the two halves' results (3 * NS * n words each).  The join is also the call's last
+  // kernel: the sum goes to affine coordinates with an inversion of its own (no Montgomery trick
+  // across items: on an idle machine the chain counts, not the work) and the operand is tested
+  // against the curve equation here (normalize + domain_mark of the one-lane form).
+  ELL_HD static void mul_join(size_t i, size_t n, const u32* jac, const u8* xy, u8* out_xy, u8* out_inf,
+                              A* raw_aff) {
+    const size_t part = (size_t)3 * NS * n;
+    J p = G::add(load_jac(jac, n, i), load_jac(jac + part, n, i));
+    const bool inf = F::is_zero(p.Z);
+    El zinv = F::inv(fe_select<F>(inf, F::one(), p.Z));
+    El zi2 = F::sqr(zinv);
+    El x = F::mul(p.X, zi2);
+    El y = F::mul(p.Y, F::mul(zi2, zinv));
+    if (inf) { x = F::zero(); y = F::zero(); }
+    if (raw_aff) { raw_aff[i].x = x; raw_aff[i].y = y; }
+    bool on = true;
+    if (out_inf) on = on_curve(load_affine(xy, i));            // (the comb build has no out_inf: its points are G)
+    if (!on) { x = F::zero(); y = F::zero(); }
+    if (out_xy) {
+      store_fe(out_xy + i * 2 * BYTES, x);
+      store_fe(out_xy + i * 2 * BYTES + BYTES, y);
+    }
+    if (out_inf) out_inf[i] = !on ? (u8)DOMAIN_OFF_CURVE : (inf ? (u8)1 : (u8)0);
+  }
+
   // Pass 2: R = u1*G + u2*Q, accept iff R != O and R.x == r (mod n)
   template <bool WIDE = false>
   ELL_HD static void ecdsa_main(size_t i, size_t n, const u32* u12, const u8* valid,

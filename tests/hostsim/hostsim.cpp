@@ -18,6 +18,9 @@
 #include "../../elliptic_amd/csrc/engine.h"
 
 namespace ell {
+// launches per kernel name since the last hs_launches_reset (white-box probe: which form of an
+// operation a batch was routed to)
+void hs_note_launch(const char* name);
 struct LoopBackend {
   void use_stream(void*) {}
   void* alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
@@ -44,6 +47,7 @@ struct LoopBackend {
   // cores (only to keep the CPU test-suite short)
   template <class Fn>
   void launch(const Fn& f, size_t nthreads) {
+    hs_note_launch(Fn::NAME);
     unsigned hw = std::thread::hardware_concurrency();
     size_t nw = hw ? hw : 1;
     if (nthreads < 64) nw = 1;
@@ -110,7 +114,27 @@ static void field_op(int op, const u32* a, const u32* b, u32* r) {
   for (int i = 0; i < F::L; i++) r[i] = tr[i];
 }
 
+#include <map>
+#include <mutex>
+namespace ell {
+static std::map<std::string, int>& hs_launch_map() { static std::map<std::string, int> m; return m; }
+static std::mutex hs_launch_mu;
+void hs_note_launch(const char* name) {
+  std::lock_guard<std::mutex> g(hs_launch_mu);
+  hs_launch_map()[name]++;
+}
+}  // namespace ell
+
 extern "C" {
+void hs_launches_reset() {
+  std::lock_guard<std::mutex> g(ell::hs_launch_mu);
+  ell::hs_launch_map().clear();
+}
+int hs_launches(const char* name) {
+  std::lock_guard<std::mutex> g(ell::hs_launch_mu);
+  auto it = ell::hs_launch_map().find(name);
+  return it == ell::hs_launch_map().end() ? 0 : it->second;
+}
 // field: 0 k256, 1 25519, 2.. mont(curve p): 10+curve -> base field, 20+curve -> order field
 int hs_field_limbs(int field) {
   switch (field) {

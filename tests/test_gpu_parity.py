@@ -392,6 +392,83 @@ def test_full_size_verify_mask_and_device_api(ctx):
         assert want == bool(expect[i])
 
 
+def test_parted_verify_and_mul_small_batches(monkeypatch):
+    """Batches that leave most SIMDs idle take the PARTED verify by default (three lanes per item:
+    the two GLV half ladders and the comb in different waves, then ecdsa_join -- engine.h
+    FnEcdsaParts); ELLGPU_PARTED_GRID=0 keeps them on the one-lane ladder.  Same verdicts from
+    both, equal to the construction's mask and (sampled) to the C port of the reference's
+    algorithm; off-curve keys, r / s out of range and the group law's exceptional cases included
+    (every wave of a part region full, half full, and a lone lane)."""
+    from oracle import c_oracle
+    monkeypatch.setenv("ELLGPU_PARTED_GRID", "0")
+    c0 = elliptic_amd.Context(0)
+    monkeypatch.setenv("ELLGPU_PARTED_GRID", str(1 << 30))
+    c1 = elliptic_amd.Context(0)
+    monkeypatch.delenv("ELLGPU_PARTED_GRID")
+    cd = elliptic_amd.Context(0)                       # the default threshold
+    n = 32768
+    h, r, s, pub, expect = _make_sigs(c0, n, "gpu-test-parted")
+    pub = pub.copy()
+    p = O.get_curve("secp256k1").p
+    want = expect.copy()
+    for i in range(5, n, 97):                          # keys off the curve: status 2
+        y = (int.from_bytes(pub[i, 32:].tobytes(), "big") + 1) % p
+        pub[i, 32:] = np.frombuffer(y.to_bytes(32, "big"), np.uint8)
+        want[i] = 2
+    r = r.copy()
+    r[11] = 0                                          # r = 0: rejected before the key is looked at
+    want[11] = 0
+    for m in (1, 2, 63, 64, 65, 127, 128, 129, 1000, 4096, 21845, 32768):
+        sl = (h[:m], r[:m], s[:m], pub[:m])
+        for c, parts in ((c0, False), (c1, True), (cd, True)):
+            c.set_timing(True)
+            got = c.ecdsa_verify("secp256k1", *sl)
+            tm = c.get_timing()
+            c.set_timing(False)
+            assert np.array_equal(got, want[:m]), (m, parts)
+            assert ("ecdsa_parts" in tm and "ecdsa_join" in tm) == parts, (m, parts, sorted(tm))
+    # above the default threshold: the one-lane small-grid ladder
+    h2, r2, s2, pub2, expect2 = _make_sigs(c0, 40000, "gpu-test-parted-2")
+    cd.set_timing(True)
+    assert np.array_equal(cd.ecdsa_verify("secp256k1", h2, r2, s2, pub2), expect2)
+    assert "ecdsa_parts" not in cd.get_timing()
+    cd.set_timing(False)
+    assert np.array_equal(c1.ecdsa_verify("secp256k1", h2, r2, s2, pub2), expect2)
+    j = np.arange(0, n, 11)
+    on = want[j] != 2
+    assert np.array_equal(np.asarray(c_oracle.verify("secp256k1", h[j], r[j], s[j], pub[j]))[on], want[j][on])
+    # Point#mul in the parted form (two lanes per item + mul_join): same bytes as the one-lane
+    # ladder, the C port's on a sample; off-curve points -> 2; k = 0, n, n + 1, 2^256 - 1 (the
+    # halves cancel / wrap) included
+    nn = O.get_curve("secp256k1").n
+    ks = r.copy()
+    for i, kv in enumerate((0, nn, nn + 1, (1 << 256) - 1, 1, 2, nn - 1)):
+        ks[20 + i] = np.frombuffer(kv.to_bytes(32, "big"), np.uint8)
+    for m in (1, 64, 65, 129, 4096, 32768):
+        outs = []
+        for c, parts in ((c0, False), (c1, True), (cd, True)):
+            c.set_timing(True)
+            outs.append(c.mul_var("secp256k1", ks[:m], pub[:m]))
+            tm = c.get_timing()
+            c.set_timing(False)
+            assert ("mul_parts" in tm and "mul_join" in tm) == parts, (m, parts, sorted(tm))
+        for xy, inf in outs[1:]:
+            assert np.array_equal(xy, outs[0][0]) and np.array_equal(inf, outs[0][1]), m
+    xy, inf = outs[1]
+    assert (inf[want[:m] == 2] == 2).all() and int((inf == 2).sum()) == int((want[:m] == 2).sum())
+    j = np.concatenate([np.arange(20, 27), np.arange(0, m, 23)])
+    j = j[want[j] != 2]
+    wxy, winf = c_oracle.mul("secp256k1", ks[j], pub[j])
+    assert np.array_equal(xy[j], wxy) and np.array_equal(inf[j], winf)
+    for c in (c0, c1):
+        assert PC.check_mul_golden(c, "secp256k1") > 50
+        assert PC.check_exceptional_keys(c, "secp256k1") > 400
+        assert PC.check_verify_golden(c, "secp256k1") > 15
+        assert PC.check_offcurve_golden(c, "secp256k1") >= 29
+    for c in (c0, c1, cd):
+        c.close()
+
+
 def test_full_size_group_properties(ctx):
     """size-independent properties on 2^18 items: (a*G)*b == (b*G)*a, fixed ==
     variable base on G, k1*G + k2*G == (k1+k2)*G."""

@@ -295,6 +295,21 @@ def test_verify_golden_secp256k1_both_tunings(hs, monkeypatch):
     assert PC.check_verify_golden(c, "secp256k1") > 15
     assert PC.check_offcurve_golden(c, "secp256k1") >= 29
     c.close()
+    # ... and batches far below one wave per SIMD take the PARTED form by default (three lanes per
+    # item: Work::ecdsa_half x 2, ecdsa_fixed, ecdsa_join); ELLGPU_PARTED_GRID=0 keeps them on the ladder
+    for grid, parts in (("0", False), (str(1 << 30), True)):
+        c = _fresh_ctx(hs, monkeypatch, ELLGPU_PARTED_GRID=grid)
+        hs.hs_launches_reset()
+        assert PC.check_verify_golden(c, "secp256k1") > 15
+        assert PC.check_offcurve_golden(c, "secp256k1") >= 29
+        assert PC.check_exceptional_keys(c, "secp256k1") > 400
+        assert (hs.hs_launches(b"ecdsa_parts") > 0) == parts and (hs.hs_launches(b"ecdsa_join") > 0) == parts
+        assert (hs.hs_launches(b"ecdsa_main") > 0) != parts
+        # Point#mul likewise (Work::mul_half x 2, mul_join); k1 G + k2 P stays on its one ladder
+        hs.hs_launches_reset()
+        assert PC.check_mul_golden(c, "secp256k1") > 50
+        assert (hs.hs_launches(b"mul_parts") > 0) == parts and (hs.hs_launches(b"mul_join") > 0) == parts
+        c.close()
 
 
 @pytest.mark.parametrize("curve", ["secp256k1", "p192", "p256", "p384", "p521", "ed25519"])
