@@ -281,8 +281,11 @@ struct FnEcdsaPrepTable {
   static constexpr int DS_PER_LANE = 0;
   FnEcdsaPrep<CV, ELL_ECDSA_TABLE_MIN_WAVES> prep; size_t tpad; FnEcdsaTable<CV, true> table;
   ELL_HD void operator()(size_t tid, const DigitStore& ds) const {
-    if (tid < tpad) prep(tid, ds);
-    else table(tid - tpad, ds);
+    if (tid < tpad) {
+      if (fill_lane(tid, prep.T)) prep(tid, ds);
+    } else {
+      table(tid - tpad, ds);                     // (the launch ends with this range: k_run fills its last wave)
+    }
   }
 };
 
@@ -299,8 +302,8 @@ struct FnEcdsaParts {
   size_t n; size_t npad; const u32* u12; const typename W::A* comb; const typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t tid, const DigitStore& ds) const {
     const int part = tid >= 2 * npad ? 2 : (tid >= npad ? 1 : 0);
-    const size_t i = tid - (size_t)part * npad;
-    if (i >= n) return;
+    size_t i = tid - (size_t)part * npad;
+    if (!fill_lane(i, n)) return;
     u32* out = jac + (size_t)part * 3 * W::NS * n;
     if (part == 2) W::ecdsa_fixed(i, n, u12, comb, out);
     else W::template ecdsa_half<true>(i, n, part, u12, tbl, ds, out);
@@ -328,8 +331,8 @@ struct FnMulParts {
   size_t n; size_t npad; const u8* k; const u8* xy; typename W::VT* tbl; u32* jac;
   ELL_HD void operator()(size_t tid, const DigitStore& ds) const {
     const int half = tid >= npad ? 1 : 0;
-    const size_t i = tid - (size_t)half * npad;
-    if (i >= n) return;
+    size_t i = tid - (size_t)half * npad;
+    if (!fill_lane(i, n)) return;
     W::template mul_half<true>(i, n, half, k, xy, tbl + (size_t)half * n * W::template stride<true>(), ds,
                                jac + (size_t)half * 3 * W::NS * n);
   }

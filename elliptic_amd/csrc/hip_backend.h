@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(BLOCK, MinWaves<Fn>::value) k_run(const Fn f, 
   __shared__ signed char lds_digits[(Fn::DS_PER_LANE > 0 ? Fn::DS_PER_LANE : 1) * BLOCK];
   size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   DigitStore ds{lds_digits + threadIdx.x, BLOCK};
+  if (!fill_lane(tid, nthreads)) return;       // the launch's last wave works with all its lanes
   f(tid, ds);
 }
 
