@@ -34,8 +34,7 @@ MAP = {
     "smoke.log": "smoke.log",
     "strong_proxy.jsonl": "strong_proxy.jsonl",
     "latency.jsonl": "latency.jsonl",
-    "bench_strong_two_ranks_one_gpu.jsonl": "bench_strong_two_ranks_one_gpu.jsonl",
-    "bench_two_ranks_one_gpu.jsonl": "bench_two_ranks_one_gpu.jsonl",
+    "parted_verify_ab.jsonl": "parted_verify_ab.jsonl",
     "bench_selflaunch_two_ranks_one_gpu.jsonl": "bench_selflaunch_two_ranks_one_gpu.jsonl",
     "bench_selflaunch_eight_ranks_one_gpu.jsonl": "bench_selflaunch_eight_ranks_one_gpu.jsonl",
     "rccl_selftest.jsonl": "rccl_selftest.jsonl",

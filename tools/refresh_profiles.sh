@@ -45,6 +45,8 @@ rm -rf /tmp/treecopy
 tail -c 600 $O/bench.json.log
 timeout 300 python tools/strong_proxy.py > $O/strong_proxy.jsonl 2> $O/strong_proxy.err
 timeout 300 python tools/bench_latency.py > $O/latency.jsonl 2> $O/latency.err
+# small batches: three lanes per item (the parted verify) against one, each leg its own process
+timeout 300 python tools/parted_ab.py --once --reps=100 > $O/parted_verify_ab.jsonl 2> $O/parted_ab.err
 # the N > 1 flow on the one-GPU box, started as PLAIN python (bench.py launches itself under
 # torch.distributed.run): weak loop + configs[2] as written (`strong`) + the collective's census in
 # one line; two ranks, then eight ranks, all on device 0 over gloo (flow tests, not scaling points)
