@@ -667,6 +667,34 @@ function install(elliptic, options) {
     if (!SigCtor) SigCtor = orig.sign.call(this, [ 1 ], '01', 'hex').constructor;
     return new SigCtor({ r: new BN(res.r), s: new BN(res.s), recoveryParam: res.recid[0] });
   };
+  // EC#verify (ec/index.js:188-229) as ONE engine call: s^-1, u1, u2, the double-scalar
+  // multiplication and the comparison on the device (ellgpu_ecdsa_verify; a lone call runs as
+  // three waves, csrc/work.h ecdsa_half) -- through the patched Point#mulAdd alone the inversion
+  // and the two products mod n stay in JavaScript and the call costs MORE than the unpatched
+  // library's (1.04 against 0.90 ms on the GPU box's host, profiles/r04_js_single_call.jsonl).
+  // Decoding is the reference's own (keyFromPublic, Signature); byte-array digests on the preset
+  // short curves only; whatever throws on the way, and a key that is not on the curve, goes to
+  // the original method, which throws / answers by itself.
+  orig.verify = ecProto.verify;
+  ecProto.verify = function verify(msg, signature, key, enc, options) {
+    var d = domain(this.curve);
+    if (refOnly || !d || d.custom || this.curve.type !== 'short' || !byteMessage(msg))
+      return orig.verify.apply(this, arguments);
+    var m, ok;
+    try {
+      var kp = this.keyFromPublic(key, enc);
+      var pub = kp.getPublic();
+      if (!pub || pub.isInfinity() || pub.curve !== this.curve) throw null;
+      var item = { msg: msg, signature: signature, key: kp, options: options || undefined };
+      m = marshalOne(this, d, item);
+      ok = eng.ecdsaVerifyBatch(d.id, packVerify([ m ], msg.length, msgBitsOf(item)).o)[0];
+    } catch (e) {
+      eng.stats.passthrough++;
+      return orig.verify.apply(this, arguments);
+    }
+    if (ok === OFF_CURVE) return offCurve(this, orig.verify, arguments);
+    return m.pre && ok === 1;
+  };
   orig.recoverPubKey = ecProto.recoverPubKey;
   ecProto.recoverPubKey = function recoverPubKey(msg, signature, j, enc) {
     var d = domain(this.curve);
@@ -761,6 +789,7 @@ function install(elliptic, options) {
     eddsaProto.verify = orig.eddsaVerify;
     eddsaProto.sign = orig.eddsaSign;
     ecProto.recoverPubKey = orig.recoverPubKey;
+    ecProto.verify = orig.verify;
     ecProto.sign = orig.sign;
     edw.pointFromY = orig.pointFromY;
     edw.pointFromX = orig.edPointFromX;

@@ -1,0 +1,73 @@
+'use strict';
+// What ONE call of the reference's public API costs, unpatched and patched (install()), on the
+// same host: EC#verify (ec/index.js:188-229), Point#mul (short.js:422-432), EC#sign
+// (ec/index.js:109-172), and eng.verifyAsync for 1 and for 64 concurrent calls.  GPU box.
+//   node tools/bench_js_single_call.js
+var loader = require('./ref_loader');
+var crypto = require('crypto');
+var plain = loader.load().elliptic;
+var patched = loader.load().elliptic;
+var eng = require('../elliptic_amd/js').install(patched, { libPath: process.env.ELLGPU_LIB });
+
+function stats(ts) {
+  ts.sort(function(a, b) { return a - b; });
+  return { median_us: +(ts[ts.length >> 1] / 1e3).toFixed(1), best_us: +(ts[0] / 1e3).toFixed(1) };
+}
+function timeSync(fn, reps) {
+  fn(); fn();
+  var ts = [];
+  for (var i = 0; i < reps; i++) {
+    var t0 = process.hrtime.bigint();
+    fn();
+    ts.push(Number(process.hrtime.bigint() - t0));
+  }
+  return stats(ts);
+}
+function out(op, which, st, extra) {
+  console.log(JSON.stringify(Object.assign({ op: op, library: which }, st, extra || {})));
+}
+
+var libs = [ [ 'reference (unpatched)', plain ], [ 'patched (install)', patched ] ];
+var msg = crypto.createHash('sha256').update('single call').digest();
+libs.forEach(function(l) {
+  var ec = new l[1].ec('secp256k1');
+  var kp = ec.genKeyPair({ entropy: crypto.createHash('sha512').update('k').digest() });
+  var sig = kp.sign(msg);
+  var der = sig.toDER('hex'), pub = kp.getPublic('hex');
+  if (ec.verify(msg, der, pub, 'hex') !== true) throw new Error('verify');
+  out('EC#verify (DER hex signature, hex key)', l[0], timeSync(function() { return ec.verify(msg, der, pub, 'hex'); }, 200));
+  var key = ec.keyFromPublic(pub, 'hex');
+  out('EC#verify (Signature object, KeyPair)', l[0], timeSync(function() { return ec.verify(msg, sig, key); }, 200));
+  var P = kp.getPublic(), k = kp.getPrivate();
+  out('Point#mul (variable base)', l[0], timeSync(function() { return P.mul(k).getX(); }, 200));
+  out('EC#sign', l[0], timeSync(function() { return ec.sign(msg, kp); }, 200));
+});
+
+// the engine's own asynchronous single call, alone and 64 at a time (one launch)
+var ecq = new patched.ec('secp256k1');
+var kps = [], jobs = [];
+for (var i = 0; i < 64; i++) {
+  var kp = ecq.genKeyPair({ entropy: crypto.createHash('sha512').update('a' + i).digest() });
+  var m = crypto.createHash('sha256').update('m' + i).digest();
+  jobs.push({ msg: m, sig: kp.sign(m).toDER('hex'), key: kp.getPublic('hex') });
+}
+function timeAsync(n, reps, done) {
+  var ts = [], i = 0;
+  function one() {
+    if (i++ === reps) return done(stats(ts));
+    var t0 = process.hrtime.bigint();
+    Promise.all(jobs.slice(0, n).map(function(j) { return eng.verifyAsync(ecq, j.msg, j.sig, j.key, 'hex'); }))
+      .then(function(v) {
+        if (v.indexOf(false) >= 0) throw new Error('verifyAsync');
+        ts.push(Number(process.hrtime.bigint() - t0));
+        one();
+      });
+  }
+  one();
+}
+timeAsync(1, 200, function(s1) {
+  out('eng.verifyAsync x 1', 'patched (install)', s1);
+  timeAsync(64, 100, function(s64) {
+    out('eng.verifyAsync x 64 concurrent (one launch)', 'patched (install)', s64, { per_verify_us: +(s64.median_us / 64).toFixed(1) });
+  });
+});

@@ -146,6 +146,27 @@ for (var it = 0; it < ITER && failures.length < 5; it++) {
         var keyB = keyForm === 1 ? pointOn(patched, name, 6, s1) : keyA;
         var mv = rng.int(3) === 0 ? Buffer.from(mb).toString('hex') : mb;
         both(name + ' verify', function() { return eca.verify(mv, sg, keyA, 'hex'); }, function() { return ecb.verify(mv, sg, keyB, 'hex'); });
+        // EC#verify itself is patched (one engine call): every form the reference takes for its
+        // key (KeyPair with / without a public half, {x, y}, a Point, O), its signature, its
+        // message (Buffer, Array, Uint8Array; any length) and options.msgBitLength
+        var kf2 = rng.int(6);
+        var xyA = eca.keyFromPrivate(priv, 'hex').getPublic();
+        function key2(ec, lib, c) {
+          return kf2 === 0 ? ec.keyFromPrivate(priv, 'hex') : kf2 === 1 ? ec.keyFromPublic(pubHex, 'hex') :
+            kf2 === 2 ? c.point(null, null) : kf2 === 3 ? { x: xyA.getX().toString(16), y: xyA.getY().toString(16) } :
+            kf2 === 4 ? pointOn(lib, name, rng.ctr % 7, s2) : ec.keyFromPrivate(priv, 'hex').getPublic();
+        }
+        var vopts = rng.int(3) === 0 ? { msgBitLength: rng.pick([8, 160, 255, 256, 260, 512]) } : undefined;
+        var mf2 = rng.int(3);
+        var mv2 = mf2 === 0 ? Buffer.from(mb) : mf2 === 1 ? Uint8Array.from(mb) : mb;
+        var sgf = rng.int(2);
+        var save2 = rng.ctr;
+        both(name + ' verify (key / options forms)', function() { rng.ctr = save2; return eca.verify(mv2, sgf ? sig : sg, key2(eca, plain, ca), undefined, vopts); },
+          function() {
+            rng.ctr = save2;
+            var sB = sgf ? { r: new BNb(sig.r.toString(16), 16), s: new BNb(sig.s.toString(16), 16) } : sg;
+            return ecb.verify(mv2, sB, key2(ecb, patched, cb), undefined, vopts);
+          });
         var j = rng.int(5);
         both(name + ' recoverPubKey', function() { return eca.recoverPubKey(mb, sg, j); }, function() { return ecb.recoverPubKey(mb, sg, j); });
         var xh = new BNa(rng.bytes(ca.p.byteLength())).toString(16);
@@ -234,6 +255,7 @@ for (var it = 0; it < ITER && failures.length < 5; it++) {
     ['edwards.pointFromX', plain.curve.edwards.prototype.pointFromX, patched.curve.edwards.prototype.pointFromX],
     ['ec.sign', plain.ec.prototype.sign, patched.ec.prototype.sign],
     ['ec.recoverPubKey', plain.ec.prototype.recoverPubKey, patched.ec.prototype.recoverPubKey],
+    ['ec.verify', plain.ec.prototype.verify, patched.ec.prototype.verify],
     ['eddsa.verify', plain.eddsa.prototype.verify, patched.eddsa.prototype.verify],
     ['eddsa.sign', plain.eddsa.prototype.sign, patched.eddsa.prototype.sign],
     ['mont Point#mul', plain.curves.curve25519.curve.g.constructor.prototype.mul, patched.curves.curve25519.curve.g.constructor.prototype.mul],

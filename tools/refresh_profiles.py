@@ -22,6 +22,7 @@ MAP = {
     "configs.jsonl": "configs.jsonl",
     "host_path.jsonl": "host_path.jsonl",
     "js_bench.jsonl": "js_bench.jsonl",
+    "js_single_call.jsonl": "js_single_call.jsonl",
     "soak.log": "soak.log",
     "custom_curve_bench.jsonl": "custom_curve_bench.jsonl",
     "bench_under_rocprof.log": "bench_under_rocprof.log",

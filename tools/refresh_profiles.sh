@@ -60,6 +60,7 @@ if [ "$MODE" != "quick" ]; then
   timeout 600 python tools/bench_configs.py 2>/dev/null | grep '"config"' > $O/configs.jsonl
   timeout 300 python tools/bench_host_path.py --reps 8 2>/dev/null | grep '"config"' > $O/host_path.jsonl
   timeout 120 node elliptic_amd/js/bench.js 2>/dev/null | grep '^{' > $O/js_bench.jsonl
+  timeout 120 node tools/bench_js_single_call.js 2>/dev/null | grep '^{' > $O/js_single_call.jsonl
   timeout 300 python tools/bench_custom.py 18 > $O/custom_curve_bench.jsonl 2>/dev/null
   timeout 300 python tests/soak.py --seconds 40 > $O/soak.log 2>&1
 fi
