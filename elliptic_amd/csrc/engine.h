@@ -328,13 +328,16 @@ struct FnMulParts {
   typedef Work<CV> W;
   static constexpr int MIN_WAVES = 2;
   static constexpr int DS_PER_LANE = W::template Endo<true>::NW;
+  // kg != null: k*P + kg*G -- a third range of lanes runs the comb of kg
   size_t n; size_t npad; const u8* k; const u8* xy; typename W::VT* tbl; u32* jac;
+  const u8* kg; const typename W::A* comb;
   ELL_HD void operator()(size_t tid, const DigitStore& ds) const {
-    const int half = tid >= npad ? 1 : 0;
-    size_t i = tid - (size_t)half * npad;
+    const int part = tid >= 2 * npad ? 2 : (tid >= npad ? 1 : 0);
+    size_t i = tid - (size_t)part * npad;
     if (!fill_lane(i, n)) return;
-    W::template mul_half<true>(i, n, half, k, xy, tbl + (size_t)half * n * W::template stride<true>(), ds,
-                               jac + (size_t)half * 3 * W::NS * n);
+    u32* out = jac + (size_t)part * 3 * W::NS * n;
+    if (part == 2) W::mul_fixed_part(i, n, kg, comb, out);
+    else W::template mul_half<true>(i, n, part, k, xy, tbl + (size_t)part * n * W::template stride<true>(), ds, out);
   }
 };
 template <class CV>
@@ -343,9 +346,9 @@ struct FnMulJoin {
   typedef Work<CV> W;
   static constexpr int MIN_WAVES = 2;
   static constexpr int DS_PER_LANE = 0;
-  size_t n; const u32* jac; const u8* xy; u8* out_xy; u8* out_inf; typename W::A* raw;
+  size_t n; const u32* jac; bool with_g; const u8* xy; u8* out_xy; u8* out_inf; typename W::A* raw;
   ELL_HD void operator()(size_t i, const DigitStore&) const {
-    if (i < n) W::mul_join(i, n, jac, xy, out_xy, out_inf, raw);
+    if (i < n) W::mul_join(i, n, jac, with_g, xy, out_xy, out_inf, raw);
   }
 };
 
@@ -1991,9 +1994,9 @@ int Engine<BK>::mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u
   if constexpr (CV::ENDO && W::L <= 8) {
     if (parted) {                           // most SIMDs would idle: two lanes per item, then the join
       const size_t npad = (n + 127) & ~(size_t)127;            // whole workgroups per half
-      FnMulParts<CV> fp{n, npad, k, xy, tbl, jac};
+      FnMulParts<CV> fp{n, npad, k, xy, tbl, jac, nullptr, nullptr};
       launch_fn(fp, npad + n);
-      FnMulJoin<CV> fj{n, jac, xy, out_xy, out_inf, raw};      // ... to affine, and the domain test
+      FnMulJoin<CV> fj{n, jac, false, xy, out_xy, out_inf, raw};   // ... to affine, and the domain test
       return launch_fn(fj, n);
     } else if (wide) {                      // at most three waves per SIMD: the register-rich tuning
       FnMulVar<CV, 3, true> f{n, k, xy, tbl, jac};
@@ -2058,6 +2061,18 @@ template <class CV>
 int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* xy2, u8* out_xy,
                     u8* out_inf) {
   typedef Work<CV> W;
+  if constexpr (CV::ENDO && W::L <= 8) {
+    if (n <= parted_grid()) {               // most SIMDs would idle: k2's halves and k1's comb in three waves
+      u32* pj = (u32*)scratch(S_JAC, 3 * n * 3 * W::NS * 4);
+      typename W::VT* pt = (typename W::VT*)scratch(S_TBL, 2 * n * (size_t)W::template stride<true>() * sizeof(typename W::VT));
+      if (!pt || !pj) return fail(E_NOMEM, "scratch allocation failed");
+      const size_t npad = (n + 127) & ~(size_t)127;
+      FnMulParts<CV> fp{n, npad, k2, xy2, pt, pj, k1, (const typename W::A*)comb_[CV::ID]};
+      launch_fn(fp, 2 * npad + n);
+      FnMulJoin<CV> fj{n, pj, true, xy2, out_xy, out_inf, nullptr};
+      return launch_fn(fj, n);
+    }
+  }
   u32* jac = (u32*)scratch(S_JAC, n * 3 * W::NS * 4);
   typename W::VT* tbl = (typename W::VT*)scratch(S_TBL, n * (size_t)W::template stride<false>() * sizeof(typename W::VT));
   if (!tbl || !jac) return fail(E_NOMEM, "scratch allocation failed");

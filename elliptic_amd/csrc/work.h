@@ -1218,14 +1218,22 @@ struct Work {
     b.Z = F::mul(b.Z, zg);
     store_jac(jac, n, i, b);
   }
+  // (third part of k1*G + k2*P in the parted form: the comb of k1)
+  ELL_HD static void mul_fixed_part(size_t i, size_t n, const u8* ks, const A* comb, u32* jac) {
+    u32 k[L];
+    load_be<L>(k, ks + i * BYTES, BYTES);
+    store_jac(jac, n, i, LD::template comb_mul<L, COMB_W, COMB_BITS, COMB_SIGNED>(k, comb));
+  }
   // jac: the two halves' results (3 * NS * n words each).  The join is also the call's last
   // kernel: the sum goes to affine coordinates with an inversion of its own (no Montgomery trick
   // across items: on an idle machine the chain counts, not the work) and the operand is tested
   // against the curve equation here (normalize + domain_mark of the one-lane form).
-  ELL_HD static void mul_join(size_t i, size_t n, const u32* jac, const u8* xy, u8* out_xy, u8* out_inf,
-                              A* raw_aff) {
+  // `with_g`: a third result, k1*G of k1*G + k2*P, follows the halves'.
+  ELL_HD static void mul_join(size_t i, size_t n, const u32* jac, bool with_g, const u8* xy, u8* out_xy,
+                              u8* out_inf, A* raw_aff) {
     const size_t part = (size_t)3 * NS * n;
     J p = G::add(load_jac(jac, n, i), load_jac(jac + part, n, i));
+    if (with_g) p = G::add(p, load_jac(jac + 2 * part, n, i));
     const bool inf = F::is_zero(p.Z);
     El zinv = F::inv(fe_select<F>(inf, F::one(), p.Z));
     El zi2 = F::sqr(zinv);

@@ -460,8 +460,24 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
     j = j[want[j] != 2]
     wxy, winf = c_oracle.mul("secp256k1", ks[j], pub[j])
     assert np.array_equal(xy[j], wxy) and np.array_equal(inf[j], winf)
+    # k1 G + k2 P (Point#mulAdd with G, EC#recoverPubKey) in three waves: the same bytes as the one
+    # ladder with the comb behind it
+    for m in (1, 65, 4096):
+        outs = []
+        for c, parts in ((c0, False), (c1, True)):
+            c.set_timing(True)
+            outs.append(c.mul_add2("secp256k1", s[:m], None, ks[:m], pub[:m]))
+            tm = c.get_timing()
+            c.set_timing(False)
+            assert ("mul_parts" in tm) == parts and ("mul_add_g" in tm) != parts, (m, parts, sorted(tm))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), m
+    j = np.arange(0, m, 37)
+    j = j[want[j] != 2]
+    wxy, winf = c_oracle.mul_add("secp256k1", s[j], None, ks[j], pub[j])
+    assert np.array_equal(outs[1][0][j], wxy) and np.array_equal(outs[1][1][j], winf)
     for c in (c0, c1):
         assert PC.check_mul_golden(c, "secp256k1") > 50
+        assert PC.check_recover_golden(c, "secp256k1") >= 30
         assert PC.check_exceptional_keys(c, "secp256k1") > 400
         assert PC.check_verify_golden(c, "secp256k1") > 15
         assert PC.check_offcurve_golden(c, "secp256k1") >= 29

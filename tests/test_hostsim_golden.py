@@ -309,6 +309,11 @@ def test_verify_golden_secp256k1_both_tunings(hs, monkeypatch):
         hs.hs_launches_reset()
         assert PC.check_mul_golden(c, "secp256k1") > 50
         assert (hs.hs_launches(b"mul_parts") > 0) == parts and (hs.hs_launches(b"mul_join") > 0) == parts
+        # k1 G + k2 P (Point#mulAdd with G, EC#recoverPubKey): the halves of k2 and the comb of k1
+        hs.hs_launches_reset()
+        assert PC.check_exceptional_keys(c, "secp256k1") > 400
+        assert PC.check_recover_golden(c, "secp256k1") >= 30
+        assert (hs.hs_launches(b"mul_add_g") > 0) != parts and (hs.hs_launches(b"mul_parts") > 0) == parts
         c.close()
 
 

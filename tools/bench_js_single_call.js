@@ -41,6 +41,18 @@ libs.forEach(function(l) {
   var P = kp.getPublic(), k = kp.getPrivate();
   out('Point#mul (variable base)', l[0], timeSync(function() { return P.mul(k).getX(); }, 200));
   out('EC#sign', l[0], timeSync(function() { return ec.sign(msg, kp); }, 200));
+  out('EC#recoverPubKey', l[0], timeSync(function() { return ec.recoverPubKey(msg, sig, sig.recoveryParam); }, 200));
+  var Q = ec.genKeyPair({ entropy: crypto.createHash('sha512').update('q').digest() }).getPublic();
+  out('Point#mulAdd (k1 G + k2 Q)', l[0], timeSync(function() { return ec.g.mulAdd(k, Q, sig.s).getX(); }, 200));
+  // a curve without the endomorphism
+  var e2 = new l[1].ec('p256');
+  var kp2 = e2.genKeyPair({ entropy: crypto.createHash('sha512').update('k2').digest() });
+  var der2 = kp2.sign(msg).toDER('hex'), pub2 = kp2.getPublic('hex');
+  out('p256 EC#verify (DER hex signature, hex key)', l[0], timeSync(function() { return e2.verify(msg, der2, pub2, 'hex'); }, 100));
+  var ed = new l[1].eddsa('ed25519');
+  var ek = ed.keyFromSecret(crypto.createHash('sha256').update('ed').digest());
+  var esig = ek.sign(msg).toHex(), epub = ek.getPublic('hex');
+  out('EDDSA#verify', l[0], timeSync(function() { return ed.verify(msg, esig, epub); }, 100));
 });
 
 // the engine's own asynchronous single call, alone and 64 at a time (one launch)
