@@ -182,7 +182,9 @@ static int ell_backend_create(int device, ell::HipBackend* bk, std::string* err)
       hipStreamCreateWithFlags(&bk->own2, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; return ell::E_HIP; }
   for (int i = 0; i < ell::HipBackend::RING; i++)
     if (hipEventCreateWithFlags(&bk->ring[i], hipEventDisableTiming) != hipSuccess) { *err = "hipEventCreate failed"; return ell::E_HIP; }
-  if (hipEventCreateWithFlags(&bk->inflight_done, hipEventDisableTiming) != hipSuccess) { *err = "hipEventCreate failed"; return ell::E_HIP; }
+  for (auto& l : bk->dlane)
+    if (hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess) { *err = "hipEventCreate failed"; return ell::E_HIP; }
+  if (const char* e = getenv("ELLGPU_DEV_LANES")) bk->one_dev_lane = atoi(e) == 1;
   bk->timed = new std::vector<ell::TimedLaunch>();
   return ell::E_OK;
 }
@@ -196,8 +198,11 @@ static void ell_backend_destroy(ell::HipBackend* bk) {
   bk->copy = bk->own2 = nullptr;
   for (int i = 0; i < ell::HipBackend::RING; i++)
     if (bk->ring[i]) { (void)hipEventDestroy(bk->ring[i]); bk->ring[i] = nullptr; }
-  if (bk->inflight_done) { (void)hipEventDestroy(bk->inflight_done); bk->inflight_done = nullptr; }
-  bk->inflight = nullptr;
+  for (auto& l : bk->dlane) {
+    if (l.done) { (void)hipEventDestroy(l.done); l.done = nullptr; }
+    l.stream = nullptr;
+    l.pending = false;
+  }
   if (bk->timed) {
     for (auto& t : *bk->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     delete bk->timed;

@@ -206,7 +206,13 @@ int ellgpu_curve_define_edwards(ellgpu_ctx* ctx, const uint8_t* p, const uint8_t
 #define ELL_ENTER(ctx, stream)                                      \
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");           \
   ctx->eng->err.clear();                                            \
-  ctx->eng->bk.use_stream(stream);
+  ctx->eng->bk.use_stream(stream);                                  \
+  ctx->eng->set_lane(0);
+// *_dev entry points: the call works in the scratch arena of its stream (HipBackend::use_stream_dev)
+#define ELL_ENTER_DEV(ctx, stream)                                  \
+  if (!ctx) return set_err(ELLGPU_E_ARG, "null context");           \
+  ctx->eng->err.clear();                                            \
+  ctx->eng->set_lane(ctx->eng->bk.use_stream_dev(stream));
 
 // byte widths of a curve's field elements and scalars (for slicing the flat buffers of a group call)
 static int curve_widths(int curve, size_t& B, size_t& NB) {
@@ -287,7 +293,7 @@ int ellgpu_decompress(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, co
 }
 int ellgpu_decompress_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, const uint8_t* odd,
                           uint8_t* out_xy, uint8_t* out_ok, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->decompress_dev(curve, n, v, odd, out_xy, out_ok), true);
 }
 
@@ -299,7 +305,7 @@ int ellgpu_decode_points(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* en
 }
 int ellgpu_decode_points_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* enc, size_t enc_len,
                              uint8_t* out_xy, uint8_t* out_status, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->decode_points_dev(curve, n, enc, enc_len, out_xy, out_status), true);
 }
 int ellgpu_encode_points(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, int compact,
@@ -309,7 +315,7 @@ int ellgpu_encode_points(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy
 }
 int ellgpu_encode_points_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, int compact,
                              uint8_t* out_enc, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->encode_points_dev(curve, n, xy, compact, out_enc), true);
 }
 int ellgpu_validate(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, const uint8_t* inf,
@@ -319,7 +325,7 @@ int ellgpu_validate(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, con
 }
 int ellgpu_validate_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy, const uint8_t* inf,
                         int check_order, uint8_t* out_status, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->validate_dev(curve, n, xy, inf, check_order, out_status), true);
 }
 
@@ -332,7 +338,7 @@ int ellgpu_point_add(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy1, c
 int ellgpu_point_add_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy1, const uint8_t* inf1,
                          const uint8_t* xy2, const uint8_t* inf2, uint8_t* out_xy, uint8_t* out_inf,
                          void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->point_add_dev(curve, n, xy1, inf1, xy2, inf2, out_xy, out_inf), true);
 }
 
@@ -345,7 +351,7 @@ int ellgpu_sig_from_der(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* der
 int ellgpu_sig_from_der_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* der, size_t stride,
                             const uint32_t* der_len, uint8_t* out_r, uint8_t* out_s, uint8_t* out_status,
                             void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->sig_from_der_dev(curve, n, der, stride, der_len, out_r, out_s, out_status), true);
 }
 int ellgpu_sig_to_der(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* r, const uint8_t* s,
@@ -355,7 +361,7 @@ int ellgpu_sig_to_der(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* r, co
 }
 int ellgpu_sig_to_der_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* r, const uint8_t* s,
                           uint8_t* out_der, size_t stride, uint32_t* out_len, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->sig_to_der_dev(curve, n, r, s, out_der, stride, out_len), true);
 }
 int ellgpu_ecdsa_verify_wire(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
@@ -369,7 +375,7 @@ int ellgpu_ecdsa_verify_wire_dev(ellgpu_ctx* ctx, int curve, size_t n, const uin
                                  int msg_bits, const uint8_t* der, size_t der_stride,
                                  const uint32_t* der_len, const uint8_t* pub_enc, size_t pub_len,
                                  uint8_t* out_ok, uint8_t* out_err, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->ecdsa_verify_wire_dev(curve, n, hash, hash_len, msg_bits, der, der_stride,
                                                      der_len, pub_enc, pub_len, out_ok, out_err), true);
 }
@@ -385,7 +391,7 @@ int ellgpu_ecdsa_sign_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* h
                           int msg_bits, const uint8_t* priv, const uint8_t* nonces, int canonical,
                           uint8_t* out_r, uint8_t* out_s, uint8_t* out_recid, uint8_t* out_ok,
                           void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->ecdsa_sign_dev(curve, n, hash, hash_len, msg_bits, priv, nonces, canonical,
                                               out_r, out_s, out_recid, out_ok), true);
 }
@@ -400,7 +406,7 @@ int ellgpu_eddsa_verify(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, const ui
 int ellgpu_eddsa_verify_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off,
                             size_t msg_len, const uint8_t* sigs, const uint8_t* pubs,
                             uint8_t* out_ok, uint8_t* out_err, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->eddsa_verify_dev(n, msgs, (const ell::u64*)msg_off, msg_len, sigs, pubs,
                                                 out_ok, out_err), true);
 }
@@ -415,7 +421,7 @@ int ellgpu_ecdsa_sign_det(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* h
 int ellgpu_ecdsa_sign_det_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
                               int msg_bits, const uint8_t* priv, int canonical, uint8_t* out_r,
                               uint8_t* out_s, uint8_t* out_recid, uint8_t* out_ok, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->ecdsa_sign_det_dev(curve, n, hash, hash_len, msg_bits, priv, canonical, out_r,
                                                   out_s, out_recid, out_ok), true);
 }
@@ -429,7 +435,7 @@ int ellgpu_ecdsa_recover(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* ha
 int ellgpu_ecdsa_recover_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
                              const uint8_t* r, const uint8_t* s, const uint8_t* recid, uint8_t* out_xy,
                              uint8_t* out_status, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->ecdsa_recover_dev(curve, n, hash, hash_len, r, s, recid, out_xy, out_status), true);
 }
 
@@ -442,37 +448,37 @@ int ellgpu_eddsa_sign(ellgpu_ctx* ctx, size_t n, const uint8_t* secrets, const u
 int ellgpu_eddsa_sign_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* secrets, const uint8_t* msgs,
                           const uint64_t* msg_off, size_t msg_len, uint8_t* out_sig, uint8_t* out_pub,
                           void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->eddsa_sign_dev(n, secrets, msgs, (const ell::u64*)msg_off, msg_len, out_sig,
                                               out_pub), true);
 }
 
 int ellgpu_mul_fixed_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, uint8_t* out_xy,
                          uint8_t* out_inf, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->mul_fixed_dev(curve, n, k, out_xy, out_inf), true);
 }
 int ellgpu_mul_var_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
                        const uint8_t* in_xy, uint8_t* out_xy, uint8_t* out_inf, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->mul_var_dev(curve, n, k, in_xy, out_xy, out_inf), true);
 }
 int ellgpu_mul_add2_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1,
                         const uint8_t* p1_xy, const uint8_t* k2, const uint8_t* p2_xy,
                         uint8_t* out_xy, uint8_t* out_inf, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->mul_add2_dev(curve, n, k1, p1_xy, k2, p2_xy, out_xy, out_inf), true);
 }
 int ellgpu_ecdsa_verify_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash,
                             int hash_len, int msg_bits, const uint8_t* r, const uint8_t* s,
                             const uint8_t* pub_xy, uint8_t* out_ok, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->ecdsa_verify_dev(curve, n, hash, hash_len, msg_bits, r, s, pub_xy,
                                                 out_ok), true);
 }
 int ellgpu_x25519_ladder_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* in_x,
                              uint8_t* out_x, uint8_t* out_inf, void* stream) {
-  ELL_ENTER(ctx, stream);
+  ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->x25519_dev(n, k, in_x, out_x, out_inf), true);
 }
 

@@ -1896,6 +1896,9 @@ class Engine {
     });
   }
 
+  // scratch arena of the current call (0 / 1: the compute lanes of pipelined(); a *_dev call takes
+  // the lane of its stream, HipBackend::use_stream_dev)
+  void set_lane(int l) { lane_ = l & 1; }
   int reserve(int curve, size_t n) {
     // run a dummy-sized allocation pass by touching the arena the way a verify /
     // mul_add2 batch of n items would
@@ -1906,9 +1909,16 @@ class Engine {
     size_t m = n < CHUNK ? n : CHUNK;
     size_t L = (size_t)(ci->field_bytes + 3) / 4 + 1;       // +1: the 29-bit secp256k1 field stores 9 limbs
     size_t ent = (curve == CURVE_ED25519) ? 16 * 4 * L * 4 : 32 * 3 * L * 4;
-    if (!scratch(S_TBL, m * ent) || !scratch(S_JAC, m * 4 * L * 4) || !scratch(S_PRE, m * L * 4) ||
-        !scratch(S_U12, m * 2 * L * 4) || !scratch(S_VALID, m))
-      return fail(E_NOMEM, "scratch allocation failed");
+    // both lanes: a caller that alternates two streams works in both arenas
+    for (int l = 0; l < 2; l++) {
+      lane_ = l;
+      if (!scratch(S_TBL, m * ent) || !scratch(S_JAC, m * 4 * L * 4) || !scratch(S_PRE, m * L * 4) ||
+          !scratch(S_U12, m * 2 * L * 4) || !scratch(S_VALID, m)) {
+        lane_ = 0;
+        return fail(E_NOMEM, "scratch allocation failed");
+      }
+    }
+    lane_ = 0;
     return E_OK;
   }
 

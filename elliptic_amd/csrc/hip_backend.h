@@ -73,40 +73,75 @@ struct HipBackend {
   bool timing = false;             // record HIP events around every launch
   std::vector<TimedLaunch>* timed = nullptr;
 
-  // The scratch arena (window tables, Jacobian results, batch-inversion prefixes ...) belongs to
-  // the context, not to a stream, and the *_dev entry points return without synchronising: a call
-  // on another stream than the previous one first waits (on the device) for the event the
-  // previous call recorded after its last launch.  Host-buffer calls synchronise before they
-  // return, so nothing is left in flight behind them.
+  // The scratch arenas (window tables, Jacobian results, batch-inversion prefixes ...) belong to
+  // the context, not to a stream, and the *_dev entry points return without synchronising.  The
+  // context has TWO arenas (the compute lanes of the host-buffer pipeline), and a *_dev call takes
+  // the arena of ITS stream: a caller that alternates two streams gets two passes in flight -- the
+  // latency-bound front of pass i + 1 (s^-1, window tables) runs beside the issue-bound ladder of
+  // pass i (131 072 verifies: 1.27 -> 1.08 ms per pass, 2^20: 8.08 -> 7.75 ms;
+  // profiles/r04_two_passes_in_flight.jsonl).  A call on a third stream takes the arena used
+  // longest ago and first waits (on the device) for the event its previous user recorded after
+  // its last launch.  Host-buffer calls use both arenas: they wait for everything the *_dev calls
+  // left in flight, and synchronise before they return.
   bool host_synced = false;        // the current call has synchronised `cur` on the host
-  hipStream_t inflight = nullptr;  // stream of the last call that may still be running
-  hipEvent_t inflight_done = nullptr;
-  void use_stream(void* s) {
+  struct DevLane {
+    hipStream_t stream = nullptr;  // stream of the lane's last *_dev call
+    hipEvent_t done = nullptr;     // recorded behind that call's last launch
+    bool pending = false;          // ... and possibly not reached yet
+  };
+  DevLane dlane[2];
+  int dcur = 0;                    // lane of the current call
+  int dlast = 1;                   // lane of the previous *_dev call
+  bool one_dev_lane = false;       // ELLGPU_DEV_LANES=1: every *_dev call takes lane 0 (the old ordering)
+  // host-buffer entry points (and anything else that runs on the context's own streams)
+  void use_stream(void*) {
+    (void)hipSetDevice(device);
+    cur = own;
+    last = 0;
+    host_synced = false;
+    dcur = 0;
+    for (auto& l : dlane)
+      if (l.pending && l.done) {
+        if (l.stream != own) note(hipStreamWaitEvent(own, l.done, 0));
+        note(hipStreamWaitEvent(own2, l.done, 0));
+      }
+  }
+  // *_dev entry points: returns the scratch lane of this call
+  int use_stream_dev(void* s) {
     (void)hipSetDevice(device);
     cur = s ? (hipStream_t)s : own;
     last = 0;
     host_synced = false;
+    int L;
+    if (one_dev_lane || dlane[0].stream == cur) L = 0;
+    else if (dlane[1].stream == cur) L = 1;
+    else L = !dlane[0].stream ? 0 : (!dlane[1].stream ? 1 : 1 - dlast);
 #ifndef ELL_NO_STREAM_ORDER          // (test switch: shows that test_dev_calls_on_alternating_streams fails without it)
-    if (inflight && inflight != cur && inflight_done) note(hipStreamWaitEvent(cur, inflight_done, 0));
+    if (dlane[L].pending && dlane[L].stream != cur && dlane[L].done) note(hipStreamWaitEvent(cur, dlane[L].done, 0));
 #endif
+    dlane[L].stream = cur;
+    dcur = dlast = L;
+    return L;
   }
   // end of an entry point: `async` = the call returned without synchronising `cur`
   void end_call(bool async) {
-    if (async && inflight_done) {
-      note(hipEventRecord(inflight_done, cur));
-      inflight = cur;
+    if (async && dlane[dcur].done) {
+      note(hipEventRecord(dlane[dcur].done, cur));
+      dlane[dcur].pending = true;
     } else if (host_synced) {
-      // the call waited for `cur` on the host, and `cur` had been ordered after whatever was in
+      // the call waited on the host for its streams, which had been ordered after whatever was in
       // flight (use_stream): nothing is left running
-      inflight = nullptr;
+      for (auto& l : dlane) l.pending = false;
     }
     // else: a call that neither launched asynchronously nor synchronised (ellgpu_ctx_reserve with
-    // nothing to grow): what was in flight before it still is -- keep its stream and event
+    // nothing to grow): what was in flight before it still is
   }
   // everything this context may have in flight, on whatever stream (before freeing scratch)
   void sync_all() {
-    if (inflight) note(hipStreamSynchronize(inflight));
-    inflight = nullptr;
+    for (auto& l : dlane) {
+      if (l.pending && l.stream) note(hipStreamSynchronize(l.stream));
+      l.pending = false;
+    }
     note(hipStreamSynchronize(cur ? cur : own));
     host_synced = true;
   }

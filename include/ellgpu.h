@@ -63,7 +63,15 @@
  *     The *_dev entry points take DEVICE pointers, enqueue on the given
  *     hipStream_t (passed as void*, NULL = the context's own non-blocking stream, which
  *     ellgpu_ctx_stream returns so that a caller can order other streams against it) and return
- *     without synchronising; outputs are valid once that stream is.
+ *     without synchronising; outputs are valid once that stream is.  The scratch belongs to the
+ *     context, which keeps TWO arenas and gives a *_dev call the arena of ITS stream: calls issued
+ *     alternately on two streams run side by side (two passes in flight -- the latency-bound front
+ *     of one beside the issue-bound ladder of the other: 131 072 verifies 1.27 -> 1.08 ms per pass,
+ *     2^20 8.08 -> 7.75 ms), without host synchronisation in between.  A call on a third stream
+ *     takes the arena used longest ago and is ordered, on the DEVICE, behind the event its previous
+ *     user recorded -- more streams serialise pairwise, they never race.  Host-buffer calls use
+ *     both arenas and wait for whatever the *_dev calls left in flight.  (ELLGPU_DEV_LANES=1,
+ *     read when the context is created: one arena for all *_dev calls, i.e. they serialise.)
  *     EXCEPTION: on a user-defined curve (ellgpu_curve_define_short / _edwards) a *_dev call is
  *     SYNCHRONOUS: the curve's parameter block lives in the device's constant memory, one block
  *     per device, so such a call takes a per-device lock, uploads the block, and waits for its

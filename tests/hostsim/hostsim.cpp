@@ -23,6 +23,7 @@ namespace ell {
 void hs_note_launch(const char* name);
 struct LoopBackend {
   void use_stream(void*) {}
+  int use_stream_dev(void*) { return 0; }
   void* alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
   void free_(void* p) { free(p); }
   void h2d(void* d, const void* h, size_t bytes) { memcpy(d, h, bytes); }

@@ -546,10 +546,12 @@ def test_user_defined_edwards_curves_gpu(ctx, idx):
 
 
 def test_dev_calls_on_alternating_streams(ctx):
-    """*_dev calls share the context's scratch arena: issued from two torch streams without any host
-    synchronisation in between (they used to race on the window tables), every call's
-    result must equal the one-stream result.  The library orders them on the device through the
-    event each call records (HipBackend::use_stream / end_call)."""
+    """*_dev calls work in the context's scratch arenas: issued from several torch streams without
+    any host synchronisation in between (they used to race on the window tables), every
+    call's result must equal the one-stream result.  Two streams get an arena each (two passes in
+    flight); a third stream takes the arena used longest ago, behind the event its previous user
+    recorded (HipBackend::use_stream_dev / end_call); a host-buffer call in between waits for all
+    of them."""
     import torch
     dev = torch.device("cuda", 0)
     n = 1 << 16
@@ -571,6 +573,29 @@ def test_dev_calls_on_alternating_streams(ctx):
         for i in range(len(ks)):
             assert np.array_equal(outs[i][0].cpu().numpy(), want[i][0]) and np.array_equal(outs[i][1].cpu().numpy(), want[i][1]), (rep, i)
             outs[i][0].zero_()
+    # three streams round-robin, batch sizes of every tuning (parted, small-grid, full-grid), a
+    # host-buffer call in the middle of the queue, and verifies between the multiplications
+    streams.append(torch.cuda.Stream(device=dev))
+    h, r, s, pub, expect = _make_sigs(ctx, n, "gpu-test-streams")
+    dv = [torch.from_numpy(x).to(dev) for x in (h, r, s, pub)]
+    sizes = [n, 100, 20000, n, 3000, 50000]
+    oks = [torch.zeros(m, dtype=torch.uint8, device=dev) for m in sizes]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i, k in enumerate(dk):
+            m = sizes[i]
+            with torch.cuda.stream(streams[i % 3]):
+                ctx.mul_var_dev("secp256k1", k[:m], dp[:m], outs[i][0][:m], outs[i][1][:m])
+                ctx.ecdsa_verify_dev("secp256k1", *(x[:m] for x in dv), oks[i])
+            if i == 2:
+                hx, hi = ctx.mul_var("secp256k1", ks[1][:777], pts[:777])          # host buffers: waits for the lanes
+                assert np.array_equal(hx, want[1][0][:777]) and np.array_equal(hi, want[1][1][:777])
+        torch.cuda.synchronize()
+        for i, m in enumerate(sizes):
+            assert np.array_equal(outs[i][0][:m].cpu().numpy(), want[i][0][:m]) and np.array_equal(outs[i][1][:m].cpu().numpy(), want[i][1][:m]), (rep, i)
+            assert np.array_equal(oks[i].cpu().numpy(), expect[:m]), (rep, i)
+            outs[i][0].zero_()
+            oks[i].zero_()
 
 
 def test_sharded_helpers_on_device(ctx):

@@ -27,6 +27,9 @@ MAP = {
     "custom_curve_bench.jsonl": "custom_curve_bench.jsonl",
     "bench_under_rocprof.log": "bench_under_rocprof.log",
     "rocprof_stats.txt": "rocprof_kernel_stats.txt",
+    "rocprof_stats2.txt": "rocprof_kernel_stats_two_in_flight.txt",
+    "bench_under_rocprof_two_in_flight.log": "bench_under_rocprof_two_in_flight.log",
+    "two_passes_in_flight.jsonl": "two_passes_in_flight.jsonl",
     "rocprof_fw.txt": "rocprof_pmc_fetch_write.txt",
     "rocprof_sqa.txt": "rocprof_pmc_sq_a.txt",
     "rocprof_sqb.txt": "rocprof_pmc_sq_b.txt",

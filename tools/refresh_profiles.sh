@@ -15,7 +15,10 @@ ROUND="${ELL_ROUND:-r04}"
 tail -3 $O/pytest_gpu.log
 # the workload of the PMC passes: one pass of every benchmarked kernel (headline + configs), 2 timed steps
 PROF="python bench.py --steps 2 --warmup 1 --no-cpu"
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o stats -- python bench.py --steps 30 --warmup 5 --no-cpu --no-configs > $O/bench_under_rocprof.log 2>&1
+# kernel durations: the kernels by themselves (--in-flight 1: what roofline.kernel_ms is) and as the
+# default command runs them (two passes in flight: spans of overlapping kernels, roofline.timed_region)
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o stats -- python bench.py --steps 30 --warmup 5 --no-cpu --no-configs --in-flight 1 > $O/bench_under_rocprof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats2 -o stats2 -- python bench.py --steps 30 --warmup 5 --no-cpu --no-configs > $O/bench_under_rocprof_two_in_flight.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $O/prof_sqa -o sqa -- $PROF > $O/pmc_sqa.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_ANY -d $O/prof_sqb -o sqb -- $PROF > $O/pmc_sqb.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fwa -o fwa -- $PROF > $O/pmc_fwa.log 2>&1
@@ -25,12 +28,12 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_fwb -o fwb -- $
 if [ -x tools/microbench/_build/gather_calib ]; then
   timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_gc -o gc -- tools/microbench/_build/gather_calib > $O/gather_calib.log 2>&1
 fi
-for t in stats sqa sqb fwa fwb gc; do
+for t in stats stats2 sqa sqb fwa fwb gc; do
   db=$(find $O/prof_$t -name "*_results.db" 2>/dev/null | head -1)
   [ -n "$db" ] && python tools/rocprof_summary.py "$db" > $O/rocprof_$t.txt 2>&1
 done
 cat $O/rocprof_fwa.txt $O/rocprof_fwb.txt > $O/rocprof_fw.txt 2>/dev/null
-rm -rf $O/prof_stats $O/prof_fwa $O/prof_fwb $O/prof_sqa $O/prof_sqb $O/prof_gc
+rm -rf $O/prof_stats $O/prof_stats2 $O/prof_fwa $O/prof_fwb $O/prof_sqa $O/prof_sqb $O/prof_gc
 # distil the counters HERE first (into this box's copy of profiles/), so that a bench.py run
 # without its own live passes prices its roofline with the instruction counts of these binaries
 python tools/refresh_profiles.py --round $ROUND --src $O > $O/distil.log 2>&1
@@ -44,6 +47,7 @@ rm -rf /tmp/treecopy
 ( time timeout 900 python bench.py --keep-counters $O/live_counters ) > $O/bench.json.log 2> $O/bench.err
 tail -c 600 $O/bench.json.log
 timeout 300 python tools/strong_proxy.py > $O/strong_proxy.jsonl 2> $O/strong_proxy.err
+timeout 300 python tools/two_stream_probe.py > $O/two_passes_in_flight.jsonl 2> $O/two_passes.err
 timeout 300 python tools/bench_latency.py > $O/latency.jsonl 2> $O/latency.err
 # small batches: three lanes per item (the parted verify) against one, each leg its own process
 timeout 300 python tools/parted_ab.py --once --reps=100 > $O/parted_verify_ab.jsonl 2> $O/parted_ab.err
