@@ -655,7 +655,7 @@ def main():
                 src = dok if args.dist_backend == "nccl" else dok.cpu()
                 full_mask = gather_results(src, args.batch, dist)
 
-    for _ in range(max(args.warmup, 2) if og_w is not None else args.warmup):
+    for _ in range(max(args.warmup, 2) if og_w is not None else max(args.warmup, flight)):     # every result buffer is written
         step()
     if og_w is not None:
         og_w.drain()
