@@ -198,6 +198,7 @@ static void ell_backend_destroy(ell::HipBackend* bk) {
   bk->copy = bk->own2 = nullptr;
   for (int i = 0; i < ell::HipBackend::RING; i++)
     if (bk->ring[i]) { (void)hipEventDestroy(bk->ring[i]); bk->ring[i] = nullptr; }
+  if (bk->pin_buf) { (void)hipHostFree(bk->pin_buf); bk->pin_buf = nullptr; bk->pin_cap = 0; }
   for (auto& l : bk->dlane) {
     if (l.done) { (void)hipEventDestroy(l.done); l.done = nullptr; }
     l.stream = nullptr;

@@ -156,6 +156,16 @@ struct HipBackend {
   void note(hipError_t e) {
     if (e != hipSuccess && !last) last = (int)e;
   }
+  // one grow-only pinned host buffer (staging of the small host-buffer calls, Engine::pipelined)
+  void* pin_buf = nullptr;
+  size_t pin_cap = 0;
+  void* pinned(size_t bytes) {
+    if (bytes <= pin_cap) return pin_buf;
+    if (pin_buf) { (void)hipHostFree(pin_buf); pin_buf = nullptr; pin_cap = 0; }
+    if (hipHostMalloc(&pin_buf, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pin_buf = nullptr; return nullptr; }
+    pin_cap = bytes;
+    return pin_buf;
+  }
   void* alloc(size_t bytes) {
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes ? bytes : 1);

@@ -25,6 +25,8 @@ struct LoopBackend {
   void use_stream(void*) {}
   int use_stream_dev(void*) { return 0; }
   void* alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+  std::vector<unsigned char> pin_;
+  void* pinned(size_t bytes) { if (pin_.size() < bytes) pin_.resize(bytes); return pin_.data(); }
   void free_(void* p) { free(p); }
   void h2d(void* d, const void* h, size_t bytes) { memcpy(d, h, bytes); }
   void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
