@@ -637,6 +637,14 @@ function install(elliptic, options) {
   // s = k^-1 (z + r d) in one call.  Byte-array digests only (the reference also takes hex
   // strings, numbers and BNs with their own length rules -- those, options.k / options.pers,
   // and anything the engine refuses go to the reference).
+  // options.msgBitLength as the engine takes it (0 = eight bits per byte).  _truncateToN
+  // (ec/index.js:81-108) uses ANY number it is given -- 0, a negative, a fraction, NaN: no shift, or
+  // an assertion inside bn.js -- so only positive integers go to the engine; anything else that is
+  // a number stays with the reference.
+  function plainMsgBits(options) {
+    if (!options || typeof options.msgBitLength !== 'number') return true;
+    return Number.isInteger(options.msgBitLength) && options.msgBitLength > 0 && options.msgBitLength < (1 << 30);
+  }
   var SigCtor = null;
   orig.sign = ecProto.sign;
   ecProto.sign = function sign(msg, key, enc, options) {
@@ -646,7 +654,7 @@ function install(elliptic, options) {
     var res = null;
     try {
       if (!d || options.k || options.pers !== undefined || typeof msg !== 'object' || BN.isBN(msg) ||
-          !msg || typeof msg.length !== 'number' || msg.length === 0) throw null;
+          !msg || typeof msg.length !== 'number' || msg.length === 0 || !plainMsgBits(options)) throw null;
       // new EC({ curve, hash }) may carry another DRBG hash than the preset's (ec/index.js:31)
       if (this.hash !== elliptic.curves[d.name].hash) throw null;
       for (var i = 0; i < msg.length; i++) if ((msg[i] & 255) !== msg[i]) throw null;
@@ -678,7 +686,7 @@ function install(elliptic, options) {
   orig.verify = ecProto.verify;
   ecProto.verify = function verify(msg, signature, key, enc, options) {
     var d = domain(this.curve);
-    if (refOnly || !d || d.custom || this.curve.type !== 'short' || !byteMessage(msg))
+    if (refOnly || !d || d.custom || this.curve.type !== 'short' || !byteMessage(msg) || !plainMsgBits(options))
       return orig.verify.apply(this, arguments);
     var m, ok;
     try {
@@ -914,7 +922,7 @@ function install(elliptic, options) {
   eng.verifyAsync = function verifyAsync(ec, msg, signature, key, enc, options) {
     if (typeof enc === 'object' && enc !== null && options === undefined) { options = enc; enc = undefined; }
     var d = domain(ec.curve);
-    if (!d || ec.curve.type !== 'short' || !byteMessage(msg)) {
+    if (!d || ec.curve.type !== 'short' || !byteMessage(msg) || !plainMsgBits(options)) {
       // outside the engine's batch domain: the (patched) synchronous path, as a Promise
       return new Promise(function(resolve) { resolve(ec.verify(msg, signature, key, enc, options)); });
     }

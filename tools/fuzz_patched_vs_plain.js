@@ -132,7 +132,7 @@ for (var it = 0; it < ITER && failures.length < 5; it++) {
       var mform = rng.int(5);
       var msg = mform === 0 ? mb : mform === 1 ? Buffer.from(mb).toString('hex') : mform === 2 ? Buffer.from(mb) :
         mform === 3 ? mb.map(function(x, i) { return i === 0 ? x + 256 : x; }) : mb;
-      var opts = rng.int(4) === 0 ? { canonical: true } : undefined;
+      var opts = rng.int(4) === 0 ? { canonical: true } : rng.int(6) === 0 ? { msgBitLength: rng.pick([0, 8, 260, -1, '256', 1.5]) } : undefined;
       both(name + ' sign', function() { return eca.sign(msg, priv, 'hex', opts); }, function() { return ecb.sign(msg, priv, 'hex', opts); });
       var sig;
       try { sig = eca.sign(mb, priv, 'hex'); } catch (e) { sig = null; }
@@ -156,7 +156,7 @@ for (var it = 0; it < ITER && failures.length < 5; it++) {
             kf2 === 2 ? c.point(null, null) : kf2 === 3 ? { x: xyA.getX().toString(16), y: xyA.getY().toString(16) } :
             kf2 === 4 ? pointOn(lib, name, rng.ctr % 7, s2) : ec.keyFromPrivate(priv, 'hex').getPublic();
         }
-        var vopts = rng.int(3) === 0 ? { msgBitLength: rng.pick([8, 160, 255, 256, 260, 512]) } : undefined;
+        var vopts = rng.int(3) === 0 ? { msgBitLength: rng.pick([8, 160, 255, 256, 260, 512, 0, -8, 100.5, '260', NaN]) } : undefined;
         var mf2 = rng.int(3);
         var mv2 = mf2 === 0 ? Buffer.from(mb) : mf2 === 1 ? Uint8Array.from(mb) : mb;
         var sgf = rng.int(2);
