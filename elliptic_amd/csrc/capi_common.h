@@ -12,6 +12,7 @@
 #include "../../include/ellgpu.h"
 #include "engine.h"
 
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -22,10 +23,20 @@
 // results straight into the caller's buffers -- no device-to-device traffic at all (SURVEY.md 8e:
 // "a direct per-device D2H is the zero-collective alternative").  Any other entry point called on
 // a group runs on member 0.
+// `mu` serialises the entry points of ONE context: the staging buffers, the scratch arenas, the
+// stream bookkeeping and `err` belong to the context, so two host threads inside it at once -- the
+// N-API addon's libuv worker running a Promise-form batch while the JS thread makes a synchronous
+// call -- would overwrite each other's staged inputs.  The second caller waits (host-buffer calls
+// hold the lock until their results are back; *_dev calls only while they enqueue).  Recursive:
+// an entry point may call another on the same context.  A group call locks the group, then every
+// member from its worker thread.
 struct ellgpu_ctx {
   ell::Engine<ELL_BACKEND>* eng;
   std::vector<ellgpu_ctx*> members;
+  std::recursive_mutex mu;
 };
+
+#define ELL_LOCK(ctx) std::lock_guard<std::recursive_mutex> ell_ctx_lock_((ctx)->mu)
 
 static thread_local std::string g_last_error;
 
@@ -139,6 +150,7 @@ void ellgpu_ctx_destroy(ellgpu_ctx* ctx) {
 }
 int ellgpu_ctx_synchronize(ellgpu_ctx* ctx) {
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  ELL_LOCK(ctx);
   if (!ctx->members.empty()) {                       // a group: every member's device
     for (ellgpu_ctx* m : ctx->members) {
       int rc = ellgpu_ctx_synchronize(m);
@@ -154,6 +166,7 @@ void* ellgpu_ctx_stream(ellgpu_ctx* ctx) {
 }
 int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n) {
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  ELL_LOCK(ctx);
   if (!ctx->members.empty()) {
     // a group: every member gets its shard's worth (tables and scratch are per device), so that
     // the first sharded call does not allocate and build tables inside its worker threads
@@ -169,6 +182,7 @@ int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n) {
 static int define_custom(ellgpu_ctx* ctx, int edwards, const uint8_t* p, const uint8_t* a, const uint8_t* b,
                          int* out_curve) {
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  ELL_LOCK(ctx);
   if (!ctx->members.empty()) {
     // all or nothing: a member that cannot take the curve (table full), or would give it another
     // id than member 0 (curves were defined on a member directly), is found BEFORE anything is
@@ -205,12 +219,14 @@ int ellgpu_curve_define_edwards(ellgpu_ctx* ctx, const uint8_t* p, const uint8_t
 
 #define ELL_ENTER(ctx, stream)                                      \
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");           \
+  ELL_LOCK(ctx);                                                    \
   ctx->eng->err.clear();                                            \
   ctx->eng->bk.use_stream(stream);                                  \
   ctx->eng->set_lane(0);
 // *_dev entry points: the call works in the scratch arena of its stream (HipBackend::use_stream_dev)
 #define ELL_ENTER_DEV(ctx, stream)                                  \
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");           \
+  ELL_LOCK(ctx);                                                    \
   ctx->eng->err.clear();                                            \
   ctx->eng->set_lane(ctx->eng->bk.use_stream_dev(stream));
 
@@ -226,6 +242,7 @@ static int curve_widths(int curve, size_t& B, size_t& NB) {
 int ellgpu_mul_fixed(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, uint8_t* out_xy,
                      uint8_t* out_inf) {
   if (ctx && !ctx->members.empty()) {
+    ELL_LOCK(ctx);
     size_t B, NB;
     if (curve_widths(curve, B, NB)) return ELLGPU_E_ARG;
     if (n && (!k || !out_xy)) return set_err(ELLGPU_E_ARG, "null buffer");
@@ -239,6 +256,7 @@ int ellgpu_mul_fixed(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, uin
 int ellgpu_mul_var(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, const uint8_t* in_xy,
                    uint8_t* out_xy, uint8_t* out_inf) {
   if (ctx && !ctx->members.empty()) {
+    ELL_LOCK(ctx);
     size_t B, NB;
     if (curve_widths(curve, B, NB)) return ELLGPU_E_ARG;
     if (n && (!k || !in_xy || !out_xy)) return set_err(ELLGPU_E_ARG, "null buffer");
@@ -253,6 +271,7 @@ int ellgpu_mul_var(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k, const
 int ellgpu_mul_add2(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1, const uint8_t* p1_xy,
                     const uint8_t* k2, const uint8_t* p2_xy, uint8_t* out_xy, uint8_t* out_inf) {
   if (ctx && !ctx->members.empty()) {
+    ELL_LOCK(ctx);
     size_t B, NB;
     if (curve_widths(curve, B, NB)) return ELLGPU_E_ARG;
     if (n && (!k1 || !k2 || !p2_xy || !out_xy)) return set_err(ELLGPU_E_ARG, "null buffer");
@@ -266,19 +285,21 @@ int ellgpu_mul_add2(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1, con
 }
 int ellgpu_ecdsa_verify(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash, int hash_len,
                         int msg_bits, const uint8_t* r, const uint8_t* s, const uint8_t* pub_xy,
-                        uint8_t* out_ok) {
+                        uint8_t* out_ok, uint8_t* out_status) {
   if (ctx && !ctx->members.empty()) {
+    ELL_LOCK(ctx);
     size_t B, NB;
     if (curve_widths(curve, B, NB)) return ELLGPU_E_ARG;
     if (n && (!hash || !r || !s || !pub_xy || !out_ok)) return set_err(ELLGPU_E_ARG, "null buffer");
     return group_shard(ctx, n, [=](ellgpu_ctx* m, size_t lo, size_t hi) {
       return ellgpu_ecdsa_verify(m, curve, hi - lo, hash + lo * (size_t)hash_len, hash_len, msg_bits, r + lo * NB,
-                                 s + lo * NB, pub_xy + lo * 2 * B, out_ok + lo);
+                                 s + lo * NB, pub_xy + lo * 2 * B, out_ok + lo,
+                                 out_status ? out_status + lo : nullptr);
     });
   }
   ELL_ENTER(ctx, nullptr);
   return finish(ctx, ctx->eng->ecdsa_verify_host(curve, n, hash, hash_len, msg_bits, r, s, pub_xy,
-                                                 out_ok));
+                                                 out_ok, out_status));
 }
 int ellgpu_x25519_ladder(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* in_x,
                          uint8_t* out_x, uint8_t* out_inf) {
@@ -471,10 +492,11 @@ int ellgpu_mul_add2_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1,
 }
 int ellgpu_ecdsa_verify_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash,
                             int hash_len, int msg_bits, const uint8_t* r, const uint8_t* s,
-                            const uint8_t* pub_xy, uint8_t* out_ok, void* stream) {
+                            const uint8_t* pub_xy, uint8_t* out_ok, uint8_t* out_status,
+                            void* stream) {
   ELL_ENTER_DEV(ctx, stream);
   return finish(ctx, ctx->eng->ecdsa_verify_dev(curve, n, hash, hash_len, msg_bits, r, s, pub_xy,
-                                                out_ok), true);
+                                                out_ok, out_status), true);
 }
 int ellgpu_x25519_ladder_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* in_x,
                              uint8_t* out_x, uint8_t* out_inf, void* stream) {

@@ -11,6 +11,7 @@
 // runs once per thread id with a DigitStore of Fn::DS_PER_LANE bytes per lane.
 #pragma once
 
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -238,9 +239,9 @@ struct FnEcdsaMain {
   static constexpr int MIN_WAVES = MW ? MW : (W::L <= 8 ? (CV::ENDO ? ELL_ENDO_MIN_WAVES : ELL_ECDSA_MIN_WAVES) : (W::L == 12 ? ELL_P384_MIN_WAVES : ELL_P521_MIN_WAVES));   // 128 VGPRs for secp256k1, <= 168 for the other 256-bit curves, <= 256 for p384
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
   size_t n; const u32* u12; const u8* valid; const u8* r; const u8* pub;
-  const typename W::A* comb; typename W::VT* tbl; u8* ok;
+  const typename W::A* comb; typename W::VT* tbl; u8* ok; u8* st;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
-    if (i < n) W::template ecdsa_main<WIDE>(i, n, u12, valid, r, pub, comb, tbl, ds, ok);
+    if (i < n) W::template ecdsa_main<WIDE>(i, n, u12, valid, r, pub, comb, tbl, ds, ok, st);
   }
 };
 // the small-grid verify in two kernels (Work::ecdsa_table / ecdsa_ladder): the tables are built
@@ -263,9 +264,9 @@ struct FnEcdsaLadder {
   static constexpr int MIN_WAVES = WIDE ? 3 : ELL_ENDO_MIN_WAVES;
   static constexpr int DS_PER_LANE = W::NWIN * W::NSV;
   size_t n; const u32* u12; const u8* valid; const u8* r; const u8* pub;
-  const typename W::A* comb; const typename W::VT* tbl; u8* ok;
+  const typename W::A* comb; const typename W::VT* tbl; u8* ok; u8* st;
   ELL_HD void operator()(size_t i, const DigitStore& ds) const {
-    if (i < n) W::template ecdsa_ladder<WIDE>(i, n, u12, valid, r, pub, comb, tbl, ds, ok);
+    if (i < n) W::template ecdsa_ladder<WIDE>(i, n, u12, valid, r, pub, comb, tbl, ds, ok, st);
   }
 };
 
@@ -315,9 +316,9 @@ struct FnEcdsaJoin {
   typedef Work<CV> W;
   static constexpr int MIN_WAVES = 2;
   static constexpr int DS_PER_LANE = 0;
-  size_t n; const u8* valid; const u8* r; const u8* pub; const typename W::VT* tbl; const u32* jac; u8* ok;
+  size_t n; const u8* valid; const u8* r; const u8* pub; const typename W::VT* tbl; const u32* jac; u8* ok; u8* st;
   ELL_HD void operator()(size_t i, const DigitStore&) const {
-    if (i < n) W::template ecdsa_join<true>(i, n, valid, r, pub, tbl, jac, ok);
+    if (i < n) W::template ecdsa_join<true>(i, n, valid, r, pub, tbl, jac, ok, st);
   }
 };
 
@@ -484,9 +485,9 @@ struct FnWireStatus {
   static constexpr const char* NAME = "wire_status";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = 0;
-  size_t n; const u8* key_st; const u8* sig_st; u8* ok; u8* err;
+  size_t n; const u8* key_st; const u8* sig_st; const u8* ver_st; u8* ok; u8* err;
   ELL_HD void operator()(size_t i, const DigitStore&) const {
-    if (i < n) W::wire_status(i, key_st, sig_st, ok, err);
+    if (i < n) W::wire_status(i, key_st, sig_st, ver_st, ok, err);
   }
 };
 template <class CV>
@@ -836,7 +837,7 @@ class Engine {
                       u8* out_inf);
   template <class CV>
   int ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* r, const u8* s,
-                  const u8* pub, u8* ok);
+                  const u8* pub, u8* ok, u8* st);
   // launch of a scalar-field kernel (ecdsa_prep, sign_finish, recover_prep: batched inversion
   // and Montgomery arithmetic mod n, long dependent chains).  A member of its own so that these
   // kernels are instantiated in their own translation units (inst.hip group 6), which are
@@ -1096,6 +1097,9 @@ class Engine {
     return E_OK;
   }
 
+  static bool overlap(const u8* a, const u8* b, size_t bytes) {
+    return a && b && bytes && (uintptr_t)a < (uintptr_t)b + bytes && (uintptr_t)b < (uintptr_t)a + bytes;
+  }
   int mul_var_dev(int curve, size_t n, const u8* k, const u8* xy, u8* out_xy, u8* out_inf) {
     const CurveInfo* ci = curve_info(curve);
     if (!ci) return fail(E_ARG, "unknown curve id");
@@ -1103,6 +1107,9 @@ class Engine {
       return fail(E_UNSUPPORTED, "curve25519 is x-only; use x25519_ladder");
     if (n && (!k || !xy || !out_xy || !out_inf)) return fail(E_ARG, "null pointer");
     const size_t B = ci->field_bytes;
+    // the operands are read again AFTER the results are written (the curve test of
+    // Work::domain_mark / mul_join): a result written over its own operand would be tested in its place
+    if (overlap(xy, out_xy, n * 2 * B)) return fail(E_ARG, "in_xy and out_xy must not overlap");
     int rc = E_OK;
     CustomScope sc(this, curve);
     if (sc.rc) return sc.rc;
@@ -1134,6 +1141,8 @@ class Engine {
       return fail(E_UNSUPPORTED, "user-defined curves have no fixed-base table: pass the generator as p1");
     if (!xy1) { rc = prepare_curve(curve); if (rc) return rc; }
     const size_t B = ci->field_bytes;
+    if (overlap(xy2, out_xy, n * 2 * B) || (xy1 && overlap(xy1, out_xy, n * 2 * B)))   // see mul_var_dev
+      return fail(E_ARG, "p1_xy / p2_xy and out_xy must not overlap");
     CustomScope sc(this, curve);
     if (sc.rc) return sc.rc;
     for (size_t o = 0; o < n; o += CHUNK) {
@@ -1160,8 +1169,10 @@ class Engine {
     return E_OK;
   }
 
+  // ok: the verdicts, strictly 0 / 1.  st (may be null): the domain status per item -- 2 where the
+  // key is not on the curve (verdict 0 there), else 0 (Work::store_verdict)
   int ecdsa_verify_dev(int curve, size_t n, const u8* hash, int hash_len, int msg_bits,
-                       const u8* r, const u8* s, const u8* pub, u8* ok) {
+                       const u8* r, const u8* s, const u8* pub, u8* ok, u8* st) {
     const CurveInfo* ci = curve_info(curve);
     if (!ci) return fail(E_ARG, "unknown curve id");
     if (curve >= CURVE_ED25519)
@@ -1182,7 +1193,7 @@ class Engine {
       size_t m = n - o < CHUNK ? n - o : CHUNK;
       ELL_SHORT_DISPATCH(curve, rc = ecdsa_chunk<CV>(m, hash + o * hash_len, hash_len, shift,
                                                      r + o * NB, s + o * NB, pub + o * 2 * B,
-                                                     ok + o));
+                                                     ok + o, st ? st + o : nullptr));
       if (rc) return rc;
     }
     return E_OK;
@@ -1673,21 +1684,22 @@ class Engine {
     const size_t B = ci->field_bytes, NB = ci->order_bytes, HL = (size_t)hash_len;
     for (size_t o = 0; o < n; o += CHUNK) {
       size_t m = n - o < CHUNK ? n - o : CHUNK;
-      u8* tmp = (u8*)scratch(S_WIRE, m * (2 * NB + 2 * B + 2));
+      u8* tmp = (u8*)scratch(S_WIRE, m * (2 * NB + 2 * B + 3));
       if (!tmp) return fail(E_NOMEM, "scratch allocation failed");
       u8* r = tmp;
       u8* s = r + m * NB;
       u8* xy = s + m * NB;
       u8* kst = xy + m * 2 * B;
       u8* sst = kst + m;
+      u8* vst = sst + m;
       rc = decode_points_dev(curve, m, pub_enc + o * pub_len, pub_len, xy, kst);
       if (rc) return rc;
       rc = sig_from_der_dev(curve, m, der + o * der_stride, der_stride, der_len + o, r, s, sst);
       if (rc) return rc;
-      rc = ecdsa_verify_dev(curve, m, hash + o * HL, hash_len, msg_bits, r, s, xy, ok + o);
+      rc = ecdsa_verify_dev(curve, m, hash + o * HL, hash_len, msg_bits, r, s, xy, ok + o, vst);
       if (rc) return rc;
       ELL_SHORT_DISPATCH(curve, rc = der_chunk<CV>(OP_WIRE_STATUS, m, kst, sst, 0, nullptr, ok + o,
-                                                   err ? err + o : nullptr, nullptr));
+                                                   err ? err + o : nullptr, vst));
       if (rc) return rc;
     }
     return E_OK;
@@ -1899,7 +1911,7 @@ class Engine {
     });
   }
   int ecdsa_verify_host(int curve, size_t n, const u8* hash, int hash_len, int msg_bits,
-                        const u8* r, const u8* s, const u8* pub, u8* ok) {
+                        const u8* r, const u8* s, const u8* pub, u8* ok, u8* st) {
     const CurveInfo* ci = curve_info(curve);
     if (!ci) return fail(E_ARG, "unknown curve id");
     if (n && (!hash || !r || !s || !pub || !ok)) return fail(E_ARG, "null pointer");
@@ -1911,12 +1923,13 @@ class Engine {
     u8* dsg = out_buf(G_IN2, n * NB);
     u8* dq = out_buf(G_IN3, n * 2 * B);
     u8* dok = out_buf(G_OUT0, n);
-    if (!dh || !dr || !dsg || !dq || !dok) return fail(E_NOMEM, "staging allocation failed");
+    u8* dst = st ? out_buf(G_OUT1, n) : nullptr;
+    if (!dh || !dr || !dsg || !dq || !dok || (st && !dst)) return fail(E_NOMEM, "staging allocation failed");
     HostIn ins[4] = {{dh, hash, HL}, {dr, r, NB}, {dsg, s, NB}, {dq, pub, 2 * B}};
-    HostOut outs[1] = {{ok, dok, 1}};
-    return pipelined(n, ins, 4, outs, 1, [&](size_t o, size_t m) {
+    HostOut outs[2] = {{ok, dok, 1}, {st, dst, 1}};
+    return pipelined(n, ins, 4, outs, st ? 2 : 1, [&](size_t o, size_t m) {
       return ecdsa_verify_dev(curve, m, dh + o * HL, hash_len, msg_bits, dr + o * NB, dsg + o * NB,
-                              dq + o * 2 * B, dok + o);
+                              dq + o * 2 * B, dok + o, dst ? dst + o : nullptr);
     });
   }
   int x25519_host(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf) {
@@ -2109,7 +2122,9 @@ int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* 
                     u8* out_inf) {
   typedef Work<CV> W;
   if constexpr (CV::ENDO && W::L <= 8) {
-    if (n <= parted_grid()) {               // most SIMDs would idle: k2's halves and k1's comb in three waves
+    // (both gates, as in mul_var_chunk / ecdsa_chunk: ELLGPU_SMALL_GRID=0 keeps the call on the
+    // full-grid tuning whatever the parted threshold says)
+    if (n <= small_grid() && n <= parted_grid()) {   // most SIMDs would idle: k2's halves and k1's comb in three waves
       u32* pj = (u32*)scratch(S_JAC, 3 * n * 3 * W::NS * 4);
       typename W::VT* pt = (typename W::VT*)scratch(S_TBL, 2 * n * (size_t)W::template stride<true>() * sizeof(typename W::VT));
       if (!pt || !pj) return fail(E_NOMEM, "scratch allocation failed");
@@ -2178,7 +2193,7 @@ int Engine<BK>::launch_fn(const Fn& f, size_t nthreads) {
 template <class BK>
 template <class CV>
 int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, const u8* r, const u8* s,
-                const u8* pub, u8* ok) {
+                const u8* pub, u8* ok, u8* st) {
   typedef Work<CV> W;
   bool wide = false;
   if constexpr (CV::ENDO && W::L <= 8) wide = n <= small_grid();
@@ -2213,26 +2228,26 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
         const size_t npad = (n + 127) & ~(size_t)127;          // whole workgroups per part
         FnEcdsaParts<CV> fp{n, npad, u12, (const typename W::A*)comb_[CV::ID], tbl, jac};
         launch_fn(fp, 2 * npad + n);
-        FnEcdsaJoin<CV> fj{n, valid, r, pub, tbl, jac, ok};
+        FnEcdsaJoin<CV> fj{n, valid, r, pub, tbl, jac, ok, st};
         return launch_fn(fj, n);
       }
-      FnEcdsaLadder<CV, true> fl{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
+      FnEcdsaLadder<CV, true> fl{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok, st};
       return launch_fn(fl, n);
     }
   }
   launch_fn(f1, T);
   if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
-    FnEcdsaMain<CV, (W::L > 12 ? 2 : 0)> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
+    FnEcdsaMain<CV, (W::L > 12 ? 2 : 0)> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok, st};
     bk.launch(f2, n);
     return E_OK;
   }
   if constexpr (CV::ENDO && W::L <= 8) {
     if (wide) {                             // at most three waves per SIMD: the register-rich tuning
-      FnEcdsaMain<CV, 3, true> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
+      FnEcdsaMain<CV, 3, true> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok, st};
       return launch_fn(f2, n);
     }
   }
-  FnEcdsaMain<CV> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok};
+  FnEcdsaMain<CV> f2{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok, st};
   bk.launch(f2, n);
   return E_OK;
 }
@@ -2415,7 +2430,7 @@ int Engine<BK>::der_chunk(int op, size_t n, const u8* a, const u8* b, size_t str
     FnSigToDer<CV> f{n, a, b, o1, stride, lens};
     bk.launch(f, n);
   } else {
-    FnWireStatus<CV> f{n, a, b, o1, o2};
+    FnWireStatus<CV> f{n, a, b, o3, o1, o2};
     bk.launch(f, n);
   }
   return E_OK;

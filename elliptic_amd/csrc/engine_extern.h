@@ -25,7 +25,7 @@ namespace ell {
                                                           const u8*, u8*, u8*);
 #define ELL_DECL_G4(KW, CV)                                                                       \
   KW template int Engine<HipBackend>::ecdsa_chunk<CV>(size_t, const u8*, int, int, const u8*,     \
-                                                      const u8*, const u8*, u8*);
+                                                      const u8*, const u8*, u8*, u8*);
 
 #define ELL_DECL_G5(KW, CV)                                                                       \
   KW template int Engine<HipBackend>::decompress_chunk<CV>(size_t, const u8*, const u8*, u8*, u8*); \

@@ -40,7 +40,13 @@ struct MinWaves<Fn, decltype((void)Fn::MIN_WAVES)> { static constexpr int value 
 // lanes) on smaller ones (HipBackend::launch): the dispatcher places a workgroup's waves together,
 // and below about four waves per CU whole two-wave workgroups leave some SIMDs with two waves and
 // others with none -- 49 152 verifies took 1.23 ms where 32 768 took 0.95 (profiles/
-// r04_workgroup_size_ab.txt).  The LDS columns keep their BLOCK stride either way.
+// r04_workgroup_size_ab.txt).  The LDS columns keep their BLOCK stride either way: a one-wave
+// workgroup allocates twice the columns it uses (<= 8.4 KB for the ladders) -- nothing on gfx950,
+// the only target (160 KB of LDS per CU: 16 such workgroups take 134 KB); a part with 64 KB per CU
+// would want k_run instantiated per lane count.
+// CONTRACT for every functor: f(tid, ds) must be IDEMPOTENT per item and free of side effects
+// other than its own item's outputs (no atomics, no counters) -- fill_lane makes the idle lanes of
+// the launch's last wave repeat the last item's work instead of sitting masked off.
 template <class Fn>
 __global__ void __launch_bounds__(BLOCK, MinWaves<Fn>::value) k_run(const Fn f, size_t nthreads) {
   __shared__ signed char lds_digits[(Fn::DS_PER_LANE > 0 ? Fn::DS_PER_LANE : 1) * BLOCK];

@@ -374,10 +374,21 @@ struct Work {
   // reference's operations (its wNAF / JSF digits, its GLV split, the window of G's shipped
   // table), which the ladders here deliberately do not share.  So an off-curve operand is
   // OUTSIDE the engine's domain: it is detected (one squaring more than ShortCurve#validate,
-  // short.js:205-216) and reported per item -- out_inf = 2 / out_ok = 2 at the C ABI -- never
-  // answered with a guess; the JS layer hands such items to the reference's own method.
+  // short.js:205-216) and reported per item -- out_inf = 2, or out_status = 2 beside a verdict
+  // of 0, at the C ABI -- never answered with a guess; the JS layer hands such items to the
+  // reference's own method.
   enum { DOMAIN_OFF_CURVE = 2 };
   ELL_HD static bool on_curve(const A& a) { return F::eq(F::sqr(a.y), curve_rhs(a.x)); }
+  // EC#verify's answer for item i.  out_ok is a MASK, strictly 0 / 1: anything the engine cannot
+  // vouch for is 0 there, so a caller that reads it as a boolean never accepts a signature over a
+  // key that is no curve point.  The domain status goes to out_st (may be null): 2 where r and s
+  // are in range but the key is not on the curve (the reference computes with such a key, and can
+  // even answer true -- a caller that wants ITS answer runs it on those items), else 0.
+  ELL_HD static void store_verdict(size_t i, u8 valid, bool on, bool ok, u8* out_ok, u8* out_st) {
+    const bool in_range = valid != 0;
+    out_ok[i] = (in_range && on && ok) ? (u8)1 : (u8)0;
+    if (out_st) out_st[i] = (in_range && !on) ? (u8)DOMAIN_OFF_CURVE : (u8)0;
+  }
   // after the ladder + normalization of a point-valued call: items with an operand that is not
   // on the curve get out_inf = 2 and a zeroed result (xy1 / xy2: the call's point operands,
   // either may be null)
@@ -568,12 +579,13 @@ struct Work {
   }
   // EC#verify on wire formats: exceptions in the reference's order (keyFromPublic first, then
   // the Signature constructor); err 1..3 = decodePoint's status, 4 = 'Signature without r or s'
-  // err 5 (with ok = 2): an uncompressed key that is not on the curve -- no exception of the
-  // reference's, it computes with such keys; outside the engine's domain (on_curve below)
-  ELL_HD static void wire_status(size_t i, const u8* key_st, const u8* sig_st, u8* ok, u8* err) {
+  // err 5 (ok = 0 like every other err): an uncompressed key that is not on the curve -- no
+  // exception of the reference's, it computes with such keys; outside the engine's domain
+  // (on_curve below; ver_st = the verify's status array, Work::store_verdict)
+  ELL_HD static void wire_status(size_t i, const u8* key_st, const u8* sig_st, const u8* ver_st, u8* ok, u8* err) {
     u32 e = key_st[i] ? key_st[i] : (sig_st[i] == DER_MALFORMED ? 4u : 0u);
     if (e || sig_st[i] == DER_TOO_WIDE) ok[i] = 0;
-    else if (ok[i] == 2) e = 5u;
+    else if (ver_st[i] == (u8)DOMAIN_OFF_CURVE) e = 5u;
     if (err) err[i] = (u8)e;
   }
 
@@ -1108,7 +1120,7 @@ struct Work {
   template <bool WIDE>
   ELL_HD static void ecdsa_ladder(size_t i, size_t n, const u32* u12, const u8* valid, const u8* rs,
                                   const u8* pub_xy, const A* comb, const VT* tbl_all,
-                                  const DigitStore& ds, u8* out_ok) {
+                                  const DigitStore& ds, u8* out_ok, u8* out_st) {
     typedef Endo<WIDE> E;
     u32 u1[L], u2[L], r[LN];
     ELL_UNROLL
@@ -1131,7 +1143,7 @@ struct Work {
     bool ok = !G::is_inf(p);
     ok = ok && eq_x_to_p(p, r);
     const bool on = on_curve(load_affine(pub_xy, i));      // see ecdsa_main
-    out_ok[i] = valid[i] == 0 ? (u8)0 : (!on ? (u8)DOMAIN_OFF_CURVE : (ok ? (u8)1 : (u8)0));
+    store_verdict(i, valid[i], on, ok, out_ok, out_st);
   }
 
   // ---- the parted form of pass 2 (secp256k1): one verify on THREE lanes ---------------------
@@ -1177,7 +1189,7 @@ struct Work {
   // jac: the three parts' results, 3 * NS * n words each
   template <bool WIDE>
   ELL_HD static void ecdsa_join(size_t i, size_t n, const u8* valid, const u8* rs, const u8* pub_xy,
-                                const VT* tbl_all, const u32* jac, u8* out_ok) {
+                                const VT* tbl_all, const u32* jac, u8* out_ok, u8* out_st) {
     typedef Endo<WIDE> E;
     const size_t part = (size_t)3 * NS * n;
     J b = G::add(load_jac(jac, n, i), load_jac(jac + part, n, i));     // any of O, P = Q, P = -Q included
@@ -1188,7 +1200,7 @@ struct Work {
     bool ok = !G::is_inf(p);
     ok = ok && eq_x_to_p(p, r);
     const bool on = on_curve(load_affine(pub_xy, i));      // see ecdsa_main
-    out_ok[i] = valid[i] == 0 ? (u8)0 : (!on ? (u8)DOMAIN_OFF_CURVE : (ok ? (u8)1 : (u8)0));
+    store_verdict(i, valid[i], on, ok, out_ok, out_st);
   }
 
   // ... and Point#mul the same way: k*P = k1*P + k2*(lambda P) on two lanes.  Each half builds
@@ -1255,7 +1267,7 @@ struct Work {
   template <bool WIDE = false>
   ELL_HD static void ecdsa_main(size_t i, size_t n, const u32* u12, const u8* valid,
                                 const u8* rs, const u8* pub_xy, const A* comb, VT* tbl_all,
-                                const DigitStore& ds, u8* out_ok) {
+                                const DigitStore& ds, u8* out_ok, u8* out_st) {
     u32 u1[L], u2[L], r[LN];
     ELL_UNROLL
     for (int l = 0; l < L; l++) u2[l] = l < LN ? u12[(size_t)(1 * LN + l) * n + i] : 0u;
@@ -1280,12 +1292,12 @@ struct Work {
     // nothing but the verdict is live (a flag carried across the ladder would cost the
     // 128-register build a spill): r or s out of range -> 0 as in the reference, which returns
     // false before it touches the key (ec/index.js:199-202); a key that is not on the curve ->
-    // 2, outside the engine's domain (see on_curve above); else the verdict.
+    // verdict 0 with status 2, outside the engine's domain (see on_curve above); else the verdict.
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" ::: "memory");
 #endif
     const bool on = on_curve(load_affine(pub_xy, i));
-    out_ok[i] = valid[i] == 0 ? (u8)0 : (!on ? (u8)DOMAIN_OFF_CURVE : (ok ? (u8)1 : (u8)0));
+    store_verdict(i, valid[i], on, ok, out_ok, out_st);
   }
 };
 

@@ -179,7 +179,11 @@ class Context:
                                               inf.ctypes.data))
         return out, inf
 
-    def ecdsa_verify(self, curve, hashes, r, s, pub, msg_bits=0):
+    def ecdsa_verify(self, curve, hashes, r, s, pub, msg_bits=0, status=False):
+        """EC#verify per item -> ok, a mask of strictly 0 / 1.  status=True -> (ok, st): st[i] = 2
+        (ELLGPU_STATUS_OFF_CURVE) where r and s are in range but pub[i] is not on the curve -- ok[i]
+        is 0 there, the safe answer; the reference computes with such keys, run it on those items
+        if its answer is wanted -- else 0."""
         B, NB = FIELD_BYTES[curve], ORDER_BYTES[curve]
         hashes = _u8(hashes)
         if hashes.ndim != 2:
@@ -189,10 +193,12 @@ class Context:
         s = _u8(s, (n, NB))                     # make the library read past a buffer
         pub = _u8(pub, (n, 2 * B))
         ok = np.zeros(n, np.uint8)
+        st = np.zeros(n, np.uint8) if status else None
         self._check(self._lib.ellgpu_ecdsa_verify(self._ctx, self._cid(curve), n, hashes.ctypes.data,
                                                   hash_len, int(msg_bits), r.ctypes.data,
-                                                  s.ctypes.data, pub.ctypes.data, ok.ctypes.data))
-        return ok
+                                                  s.ctypes.data, pub.ctypes.data, ok.ctypes.data,
+                                                  st.ctypes.data if status else None))
+        return (ok, st) if status else ok
 
     def decompress(self, curve, v, odd):
         """pointFromX (short curves, v = x) / pointFromY (ed25519, v = y) -> (xy, ok)"""
@@ -554,12 +560,16 @@ class Context:
                                                   k2.data_ptr(), p2.data_ptr(), out_xy.data_ptr(),
                                                   out_inf.data_ptr(), self._stream()))
 
-    def ecdsa_verify_dev(self, curve, hashes, r, s, pub, out_ok, msg_bits=0):
+    def ecdsa_verify_dev(self, curve, hashes, r, s, pub, out_ok, msg_bits=0, out_status=None):
+        """out_ok: uint8 CUDA tensor (n), strictly 0 / 1; out_status (optional, same shape): 2 where
+        the key is not on the curve (out_ok 0 there), else 0 -- see ecdsa_verify"""
         n, hash_len = hashes.shape
         self._check(self._lib.ellgpu_ecdsa_verify_dev(self._ctx, self._cid(curve), n,
                                                       hashes.data_ptr(), hash_len, int(msg_bits),
                                                       r.data_ptr(), s.data_ptr(), pub.data_ptr(),
-                                                      out_ok.data_ptr(), self._stream()))
+                                                      out_ok.data_ptr(),
+                                                      None if out_status is None else out_status.data_ptr(),
+                                                      self._stream()))
 
     def x25519_dev(self, k, x, out_x, out_inf):
         n = k.shape[0]

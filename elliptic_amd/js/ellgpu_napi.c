@@ -16,7 +16,7 @@
  *           mulFixed(ctx, curve, k) -> {xy, inf}
  *           mulVar(ctx, curve, k, xy) -> {xy, inf}
  *           mulAdd2(ctx, curve, k1, p1|null, k2, p2) -> {xy, inf}
- *           ecdsaVerify(ctx, curve, hash, hashLen, msgBits, r, s, pub) -> Buffer(ok)
+ *           ecdsaVerify(ctx, curve, hash, hashLen, msgBits, r, s, pub) -> {ok, status}
  *           x25519(ctx, k, x) -> {x, inf}
  *           decompress(ctx, curve, v, odd) -> {xy, ok}
  *           ecdsaSign(ctx, curve, hash, hashLen, msgBits, priv, nonces, canonical)
@@ -72,7 +72,7 @@ static struct {
   int (*mul_add2)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, const uint8_t*,
                   const uint8_t*, uint8_t*, uint8_t*);
   int (*ecdsa_verify)(ellgpu_ctx*, int, size_t, const uint8_t*, int, int, const uint8_t*,
-                      const uint8_t*, const uint8_t*, uint8_t*);
+                      const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
   int (*x25519)(ellgpu_ctx*, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
   int (*decompress)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
   int (*ecdsa_sign)(ellgpu_ctx*, int, size_t, const uint8_t*, int, int, const uint8_t*, const uint8_t*,
@@ -359,9 +359,11 @@ static napi_value fn_verify(napi_env env, napi_callback_info info) {
   if (lh % (size_t)hl) THROW(env, "hash buffer length is not a multiple of hashLen");
   size_t n = lh / (size_t)hl;
   if (lr != n * (size_t)NB || ls != n * (size_t)NB || lq != n * 2 * (size_t)B) THROW(env, "buffer length mismatch");
-  napi_value bok; void* dok; CHECK(env, result_buffer(env, n, &dok, &bok));
-  if (L.ecdsa_verify(c, curve, n, h, hl, mb, r, s, q, (uint8_t*)dok) != 0) return lib_error(env);
-  return bok;
+  napi_value bok, bst; void *dok, *dst;
+  CHECK(env, result_buffer(env, n, &dok, &bok));
+  CHECK(env, result_buffer(env, n, &dst, &bst));
+  if (L.ecdsa_verify(c, curve, n, h, hl, mb, r, s, q, (uint8_t*)dok, (uint8_t*)dst) != 0) return lib_error(env);
+  return mk_result(env, "ok", bok, "status", bst);
 }
 static napi_value fn_x25519(napi_env env, napi_callback_info info) {
   if (!need_lib(env)) return NULL;
@@ -714,7 +716,7 @@ static void job_execute(napi_env env, void* data) {
     case 0: j->rc = L.mul_fixed(j->ctx, j->curve, j->n, j->in[0], j->out0, j->out1); break;
     case 1: j->rc = L.mul_var(j->ctx, j->curve, j->n, j->in[0], j->in[1], j->out0, j->out1); break;
     case 2: j->rc = L.mul_add2(j->ctx, j->curve, j->n, j->in[0], j->in[1], j->in[2], j->in[3], j->out0, j->out1); break;
-    case 3: j->rc = L.ecdsa_verify(j->ctx, j->curve, j->n, j->in[0], j->hash_len, j->msg_bits, j->in[1], j->in[2], j->in[3], j->out0); break;
+    case 3: j->rc = L.ecdsa_verify(j->ctx, j->curve, j->n, j->in[0], j->hash_len, j->msg_bits, j->in[1], j->in[2], j->in[3], j->out0, j->out1); break;
     case 4: j->rc = L.x25519(j->ctx, j->n, j->in[0], j->in[1], j->out0, j->out1); break;
     case 5: j->rc = L.ecdsa_sign_det(j->ctx, j->curve, j->n, j->in[0], j->hash_len, j->msg_bits, j->in[1], j->i0,
                                      j->out0, j->out1, j->out2, j->out3); break;
@@ -736,23 +738,16 @@ static void job_complete(napi_env env, napi_status status, void* data) {
   if (status == napi_ok && j->rc == 0) {
     /* result property names per op, in output order */
     static const char* const names[9][4] = {
-      {"xy", "inf", 0, 0}, {"xy", "inf", 0, 0}, {"xy", "inf", 0, 0}, {0, 0, 0, 0}, {"x", "inf", 0, 0},
+      {"xy", "inf", 0, 0}, {"xy", "inf", 0, 0}, {"xy", "inf", 0, 0}, {"ok", "status", 0, 0}, {"x", "inf", 0, 0},
       {"r", "s", "recid", "ok"}, {"xy", "status", 0, 0}, {"ok", "err", 0, 0}, {"xy", "status", 0, 0}};
     uint8_t** outs[4] = {&j->out0, &j->out1, &j->out2, &j->out3};
     size_t lens[4] = {j->out0_len, j->out1_len, j->out2_len, j->out3_len};
-    napi_value b0;
-    if (j->op == 3) {
-      napi_create_external_buffer(env, j->out0_len, j->out0, free_cb, NULL, &b0);
-      j->out0 = NULL;
-      result = b0;
-    } else {
-      napi_create_object(env, &result);
-      for (int k = 0; k < 4 && names[j->op][k]; k++) {
-        napi_value b;
-        napi_create_external_buffer(env, lens[k], *outs[k], free_cb, NULL, &b);
-        *outs[k] = NULL;
-        napi_set_named_property(env, result, names[j->op][k], b);
-      }
+    napi_create_object(env, &result);
+    for (int k = 0; k < 4 && names[j->op][k]; k++) {
+      napi_value b;
+      napi_create_external_buffer(env, lens[k], *outs[k], free_cb, NULL, &b);
+      *outs[k] = NULL;
+      napi_set_named_property(env, result, names[j->op][k], b);
     }
     napi_resolve_deferred(env, j->deferred, result);
   } else {
@@ -828,7 +823,7 @@ static napi_value fn_call_async(napi_env env, napi_callback_info info) {
     THROW(env, "callAsync: buffer length mismatch");
   }
   j->out0_len = op == 3 || op == 7 ? j->n : op == 4 ? j->n * 32 : op == 5 ? j->n * NB : j->n * 2 * B;
-  j->out1_len = op == 3 ? 0 : op == 5 ? j->n * NB : j->n;
+  j->out1_len = op == 5 ? j->n * NB : j->n;
   j->out2_len = op == 5 ? j->n : 0;
   j->out3_len = op == 5 ? j->n : 0;
   j->out0 = (uint8_t*)malloc(j->out0_len ? j->out0_len : 1);

@@ -95,12 +95,18 @@ Engine.prototype.mulAddBatch = function mulAddBatch(curve, k1, points1, k2,
   return this.addon.mulAdd2(this.ctx, id, k1, points1 || null, k2, points2);
 };
 // o = { hashes: Buffer(n x hashLen), hashLen, msgBits (0 = hashLen*8),
-//       r: Buffer(n x NB), s: Buffer(n x NB), pub: Buffer(n x 2B) } -> Buffer(n) of 0/1
+//       r: Buffer(n x NB), s: Buffer(n x NB), pub: Buffer(n x 2B) } -> Buffer(n), strictly 0 / 1:
+// a mask.  o.status (optional Buffer(n)) receives the domain status per item: 2
+// (Engine.OFF_CURVE) where r and s are in range but the key is not on the curve -- the verdict is
+// 0 there, the safe answer; the reference computes with such keys and can answer true, and
+// install() runs the reference on exactly those items -- else 0.
 Engine.prototype.ecdsaVerifyBatch = function ecdsaVerifyBatch(curve, o) {
   var id = this._id(curve);
   this.stats.gpuCalls++; this.stats.gpuItems += o.hashes.length / o.hashLen;
-  return this.addon.ecdsaVerify(this.ctx, id, o.hashes, o.hashLen,
+  var res = this.addon.ecdsaVerify(this.ctx, id, o.hashes, o.hashLen,
     o.msgBits | 0, o.r, o.s, o.pub);
+  if (o.status) res.status.copy(o.status);
+  return res.ok;
 };
 Engine.prototype.x25519Batch = function x25519Batch(scalars, xs) {
   this.stats.gpuCalls++; this.stats.gpuItems += scalars.length / 32;
@@ -162,9 +168,9 @@ Engine.prototype.encodePointBatch = function encodePointBatch(curve, xy, compact
 // validateBatch: KeyPair#validate per point -> Buffer(n) of 0 ok / 1 'Invalid public key'
 // (o.inf[i] set) / 2 'Public key is not a point' / 3 'Public key * N != O' (skipped when
 // o.checkOrder === false)
-// status 2 in the `inf` result of mulBatch / mulAddBatch and in the verdicts of ecdsaVerifyBatch
-// (ELLGPU_STATUS_OFF_CURVE; ecdsaVerifyWireBatch: ok 2 with err 5): a point operand is not on the
-// curve -- outside the engine's domain, reported instead of guessed
+// status 2 in the `inf` result of mulBatch / mulAddBatch and in the `status` of ecdsaVerifyBatch
+// (ELLGPU_STATUS_OFF_CURVE; ecdsaVerifyWireBatch: err 5): a point operand is not on the curve --
+// outside the engine's domain, reported instead of guessed.  Verdicts (`ok`) stay 0 / 1.
 Engine.OFF_CURVE = 2;
 Engine.VALIDATE_REASON = [null, 'Invalid public key', 'Public key is not a point', 'Public key * N != O'];
 Engine.prototype.validateBatch = function validateBatch(curve, xy, o) {
@@ -211,9 +217,9 @@ Engine.prototype.sigToDerBatch = function sigToDerBatch(curve, r, s) {
 // EC#verify(msg, derSignature, encodedKey): hashes Buffer(n x hashLen), sigs array of DER Buffers,
 // keys Buffer(n x keyLen) of SEC1 encodings -> { ok, err: Buffer(n) }; err 1..3 = decodePoint's
 // exception for the key ('Unknown point format' / 'invalid point' / 'Assertion failed'),
-// 4 = 'Signature without r or s'
+// 4 = 'Signature without r or s'; ok is 0 wherever err is not 0
 Engine.WIRE_ERROR = [null, 'Unknown point format', 'invalid point', 'Assertion failed', 'Signature without r or s',
-  null /* 5: no exception -- the key is not on the curve (ok = 2): run the reference on this item */];
+  null /* 5: no exception -- the key is not on the curve: run the reference on this item if its answer is wanted */];
 Engine.prototype.ecdsaVerifyWireBatch = function ecdsaVerifyWireBatch(curve, o) {
   var p = packRecords(o.sigs);
   this.stats.gpuCalls++; this.stats.gpuItems += o.sigs.length;
@@ -289,7 +295,10 @@ Engine.prototype.mulAddBatchAsync = function(curve, k1, points1, k2, points2) {
   return this._async(2, curve, 0, 0, k1, points1 || null, k2, points2);
 };
 Engine.prototype.ecdsaVerifyBatchAsync = function(curve, o) {
-  return this._async(3, curve, o.hashLen, o.msgBits | 0, o.hashes, o.r, o.s, o.pub);
+  return this._async(3, curve, o.hashLen, o.msgBits | 0, o.hashes, o.r, o.s, o.pub).then(function(res) {
+    if (o.status) res.status.copy(o.status);
+    return res.ok;
+  });
 };
 Engine.prototype.ecdsaSignDetBatchAsync = function(curve, o) {
   return this._async(5, curve, o.hashLen, o.msgBits | 0, o.hashes, o.priv, null, null, o.canonical ? 1 : 0, 0);
@@ -431,10 +440,18 @@ function install(elliptic, options) {
   }
   // affine (x, y) of a point without mutating it; null for infinity
   function affineBuf(curve, p, B) {
-    if (p.isInfinity()) return null;
+    // (a point of ANOTHER curve object -- the public half of a KeyPair made by another EC instance:
+    // the reference's field operations throw 'red works only with red numbers' on it, its own to throw)
+    if (!p || p.curve !== curve || p.isInfinity()) return null;
     var x, y;
     if (curve.type === 'short') { x = p.getX(); y = p.getY(); }
     else {
+      // extended coordinates carry T = X Y / Z, which the reference's _extAdd / _extDbl USE
+      // (edwards.js:279-309): a point built with any other T (curve.point(x, y, z, t) takes what
+      // it is given) is not the point its (x, y) says -- the reference's own, like a point that is
+      // off the curve
+      // (curves with a != -1 use the projective formulas, which never look at T)
+      if (curve.extended && (!p.t || !p.x.red || !p.t.red || p.t.redMul(p.z).cmp(p.x.redMul(p.y)) !== 0)) return null;
       var q = curve.point(p.x, p.y, p.z, p.t);        // clone: getX() normalizes in place
       x = q.getX(); y = q.getY();
     }
@@ -660,7 +677,14 @@ function install(elliptic, options) {
       for (var i = 0; i < msg.length; i++) if ((msg[i] & 255) !== msg[i]) throw null;
       var priv = this.keyFromPrivate(key, enc).getPrivate();
       var NB = this.n.byteLength();
-      if (priv.isNeg() || priv.byteLength() > NB) throw null;
+      // a KeyPair is taken as it is (ec/key.js:31-32), so one made by ANOTHER EC instance may carry
+      // a private key that was reduced by another order: the reference seeds its DRBG with those
+      // bytes unreduced (ec/index.js:133), the engine reduces mod n first -- the reference's own
+      if (priv.isNeg() || priv.cmp(this.n) >= 0) throw null;
+      // the reference writes the truncated digest on n.byteLength() bytes (ec/index.js:136) and
+      // throws 'byte array longer than desired length' when it does not fit -- p521 with a 67- or
+      // 68-byte digest and an options.msgBitLength that shifts it by less than its excess
+      if (this._truncateToN(msg, false, options.msgBitLength).byteLength() > NB) throw null;
       res = eng.ecdsaSignDetBatch(d.id, { hashes: Buffer.from(msg), hashLen: msg.length,
         msgBits: typeof options.msgBitLength === 'number' ? options.msgBitLength : 0,
         priv: Buffer.from(priv.toArray('be', NB)), canonical: !!options.canonical });
@@ -695,7 +719,10 @@ function install(elliptic, options) {
       if (!pub || pub.isInfinity() || pub.curve !== this.curve) throw null;
       var item = { msg: msg, signature: signature, key: kp, options: options || undefined };
       m = marshalOne(this, d, item);
-      ok = eng.ecdsaVerifyBatch(d.id, packVerify([ m ], msg.length, msgBitsOf(item)).o)[0];
+      var pk = packVerify([ m ], msg.length, msgBitsOf(item)).o;
+      pk.status = Buffer.alloc(1);
+      ok = eng.ecdsaVerifyBatch(d.id, pk)[0];
+      if (pk.status[0] === OFF_CURVE) ok = OFF_CURVE;
     } catch (e) {
       eng.stats.passthrough++;
       return orig.verify.apply(this, arguments);
@@ -736,16 +763,55 @@ function install(elliptic, options) {
   // reference throws (an undecodable R or A) its own method is run to throw the same Error.
   var eddsaProto = elliptic.eddsa.prototype;
   orig.eddsaVerify = eddsaProto.verify;
+  // The reference computes with the OBJECTS it is given: a point passed as the key or as R is used
+  // as it is (eddsa/key.js:20-23, eddsa/signature.js:33-38, eddsa/index.js:60-62) -- on the curve
+  // or not, normalised or not -- a BN passed as S is S whatever `Sencoded` says, and `Rencoded` is
+  // what gets hashed whatever R is.  The engine decodes R and A from their 32-byte encodings, so it
+  // answers for the reference only when every object agrees with the encoding the engine is given:
+  // same curve object, Z = 1, T = X Y, on the curve, and encodePoint(point) equal to the bytes.
+  // Anything else is the reference's own.
+  function sameBytes(a, b) {
+    if (!a || !b || a.length !== b.length) return false;
+    for (var i = 0; i < a.length; i++) if (a[i] !== b[i]) return false;
+    return true;
+  }
+  function byteArray(a, len) {
+    if (!a || typeof a.length !== 'number' || (len !== undefined && a.length !== len)) return false;
+    for (var i = 0; i < a.length; i++) if ((a[i] & 255) !== a[i]) return false;
+    return true;
+  }
+  function pointIsItsEncoding(eddsa, P, enc) {
+    if (!P || P.curve !== eddsa.curve || !P.zOne || !P.x || !P.y || !P.t) return false;
+    if (!P.x.red || !P.y.red || !P.t.red || P.t.cmp(P.x.redMul(P.y)) !== 0) return false;
+    return eddsa.curve.validate(P) && sameBytes(eddsa.encodePoint(P), enc);
+  }
   eddsaProto.verify = function verify(message, sig, pub) {
     var d = domain(this.curve);
     var utils = elliptic.utils;
+    var m, sb, pb;
     try {
       if (!d || d.name !== 'ed25519') throw null;
-      var m = Buffer.from(utils.parseBytes(message));
+      var mm = utils.parseBytes(message);
+      // (hash.js takes array elements as they are; Buffer.from would reduce them mod 256)
+      if (!byteArray(mm)) throw null;
+      m = Buffer.from(mm);
       var sg = this.makeSignature(sig);
-      var sb = Buffer.from(sg.toBytes());
-      var pb = Buffer.from(this.keyFromPublic(pub).pubBytes());
-      if (sb.length !== 64 || pb.length !== 32) throw null;
+      if (sg.eddsa !== this && (!sg.eddsa || sg.eddsa.curve !== this.curve)) throw null;
+      var S = sg.S();
+      // eddsa/index.js:55-57, before the key is looked at
+      if (!BN.isBN(S)) throw null;
+      if (S.gte(this.curve.n) || S.isNeg()) return false;
+      var key = this.keyFromPublic(pub);
+      if (key.eddsa !== this && (!key.eddsa || key.eddsa.curve !== this.curve)) throw null;
+      var renc = sg.Rencoded(), aenc = key.pubBytes();
+      // (true Arrays only: EDDSA#decodePoint does bytes.slice(...).concat(...), eddsa/index.js:103,
+      // which a Buffer or a Uint8Array does not have -- the reference throws a TypeError there)
+      if (!Array.isArray(renc) || !Array.isArray(aenc) || !byteArray(renc, 32) || !byteArray(aenc, 32)) throw null;
+      // point objects (given, or cached by an earlier call): the reference adds / multiplies THEM
+      if (sg._R !== undefined && !pointIsItsEncoding(this, sg._R, renc)) throw null;
+      if (key._pub !== undefined && !pointIsItsEncoding(this, key._pub, aenc)) throw null;
+      sb = Buffer.concat([Buffer.from(renc), Buffer.from(S.toArray('le', 32))]);
+      pb = Buffer.from(aenc);
     } catch (e) {
       eng.stats.passthrough++;
       return orig.eddsaVerify.apply(this, arguments);
@@ -762,9 +828,12 @@ function install(elliptic, options) {
     var d = domain(this.curve);
     try {
       if (!d || d.name !== 'ed25519') throw null;
-      var m = Buffer.from(elliptic.utils.parseBytes(message));
-      var sec = Buffer.from(this.keyFromSecret(secret).secret());
-      if (sec.length !== 32) throw null;
+      var mm = elliptic.utils.parseBytes(message);
+      var ss = this.keyFromSecret(secret).secret();
+      // (hash.js takes array elements as they are; Buffer.from would reduce them mod 256)
+      if (!byteArray(mm) || !byteArray(ss, 32)) throw null;
+      var m = Buffer.from(mm);
+      var sec = Buffer.from(ss);
     } catch (e) {
       eng.stats.passthrough++;
       return orig.eddsaSign.apply(this, arguments);
@@ -810,8 +879,9 @@ function install(elliptic, options) {
     var d = domain(ec.curve);
     if (!d || ec.curve.type !== 'short') throw new Error('verifyMany: unsupported curve');
     var m = marshalVerify(ec, d, items);
+    m.o.status = Buffer.alloc(items.length);
     var ok = eng.ecdsaVerifyBatch(d.id, m.o);
-    return items.map(function(it, i) { return verdict(ec, it, m.pre[i], ok[i]); });
+    return items.map(function(it, i) { return verdict(ec, it, m.pre[i], m.o.status[i] === OFF_CURVE ? OFF_CURVE : ok[i]); });
   };
   // a key that is not on the curve (status 2): the reference computes with it -- and can answer
   // true -- so that item goes through EC#verify itself, with the reference's own ladders
@@ -868,8 +938,9 @@ function install(elliptic, options) {
     var m;
     try { m = marshalVerify(ec, d, items); } catch (e) { return Promise.reject(e); }
     if (!items.length) return Promise.resolve([]);
+    m.o.status = Buffer.alloc(items.length);
     return eng.ecdsaVerifyBatchAsync(d.id, m.o).then(function(ok) {
-      return items.map(function(it, i) { return verdict(ec, it, m.pre[i], ok[i]); });
+      return items.map(function(it, i) { return verdict(ec, it, m.pre[i], m.o.status[i] === OFF_CURVE ? OFF_CURVE : ok[i]); });
     });
   };
   // One verification as a Promise -- and the answer to "one ec.verify is one launch of one lane"
@@ -903,9 +974,10 @@ function install(elliptic, options) {
       eng.stats.coalescedBatches = (eng.stats.coalescedBatches || 0) + 1;
       eng.stats.coalescedItems = (eng.stats.coalescedItems || 0) + good.length;
       var m = packVerify(ms, g.hl, g.mb);
+      m.o.status = Buffer.alloc(good.length);
       eng.ecdsaVerifyBatchAsync(d.id, m.o).then(function(ok) {
         good.forEach(function(p, i) {
-          try { p.resolve(verdict(g.ec, p.item, m.pre[i], ok[i])); } catch (e) { p.reject(e); }
+          try { p.resolve(verdict(g.ec, p.item, m.pre[i], m.o.status[i] === OFF_CURVE ? OFF_CURVE : ok[i])); } catch (e) { p.reject(e); }
         });
       }, function(e) { good.forEach(function(p) { p.reject(e); }); });
     });

@@ -89,15 +89,18 @@ function check(r, i, B, want, what) {
   var vs = cases.filter(function(c) { return c.op === 'verify'; });
   if (!vs.length) return;
   var hl = vs[0].z.length / 2;
+  var vst = Buffer.alloc(vs.length, 9);
   var ok = eng.ecdsaVerifyBatch(name, { hashes: hexBuf(vs.map(function(c) { return c.z; }), hl), hashLen: hl, msgBits: 0,
     r: hexBuf(vs.map(function(c) { return c.r; }), B), s: hexBuf(vs.map(function(c) { return c.s; }), B),
-    pub: Buffer.concat(vs.map(function(c) { return hexBuf([c.qx, c.qy], B); })) });
+    pub: Buffer.concat(vs.map(function(c) { return hexBuf([c.qx, c.qy], B); })), status: vst });
   var nOff = 0;
   vs.forEach(function(c, i) {
     var inRange = !/^0*$/.test(c.r) && !/^0*$/.test(c.s) && c.note.indexOf('s = n') < 0;
-    var want = (c.on || !inRange) ? (c.ok ? 1 : 0) : OFF;       // r / s out of range win, as in the reference
-    if (ok[i] !== want) throw new Error(name + ' ecdsaVerifyBatch: off-curve fixture ' + i + ' (' + c.note + ') -> ' + ok[i] + ', expected ' + want);
-    if (want === OFF) nOff++;
+    var off = !(c.on || !inRange);                              // r / s out of range win, as in the reference
+    var want = off ? 0 : (c.ok ? 1 : 0);                        // the verdicts are a mask: 0 / 1, 0 for a key off the curve
+    if (ok[i] !== want || vst[i] !== (off ? OFF : 0))
+      throw new Error(name + ' ecdsaVerifyBatch: off-curve fixture ' + i + ' (' + c.note + ') -> ok ' + ok[i] + ' status ' + vst[i] + ', expected ' + want + ' / ' + (off ? OFF : 0));
+    if (off) nOff++;
     checked++;
   });
   if (nOff < 9) throw new Error(name + ': too few off-curve verify fixtures reached the engine');

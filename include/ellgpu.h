@@ -41,8 +41,10 @@
  *     an item with an operand that is not on the curve is OUTSIDE THE ENGINE'S DOMAIN and is
  *     reported as such, never answered with a guess:
  *         ELLGPU_STATUS_OFF_CURVE (= 2)  in out_inf[i] of ellgpu_mul_var / _mul_add2 (x||y
- *                                        zeroed) and in out_ok[i] of ellgpu_ecdsa_verify and
- *                                        ellgpu_ecdsa_verify_wire (there with out_err[i] = 5)
+ *                                        zeroed), in out_status[i] of ellgpu_ecdsa_verify
+ *                                        (out_err[i] = 5 for ellgpu_ecdsa_verify_wire)
+ *     A verdict array (out_ok) is a MASK, strictly 0 / 1, and it is 0 for such an item: a caller
+ *     that reads it as a boolean never accepts a signature over a key that is no curve point.
  *     Callers that want the reference's answer for such an item run the reference on it
  *     (elliptic_amd/js/index.js install() does exactly that; tests/golden/offcurve_*.json
  *     pins what the reference answers).  ellgpu_point_add is the one exception: a single
@@ -57,9 +59,13 @@
  *   - Every function returns 0 on success or a negative ELLGPU_E_* code;
  *     ellgpu_last_error() gives a thread-local message.  There is NO CPU
  *     fallback: without a usable gfx950 device ellgpu_ctx_create fails.
- *   - A context is bound to one device and owns one HIP stream; calls on one
- *     context are serialised by the caller (one process / thread per GPU, see
- *     DESIGN.md multi-GPU).  Host-buffer entry points are synchronous.
+ *   - A context is bound to one device and owns its HIP streams, staging buffers and scratch
+ *     arenas.  Entry points on ONE context take turns: every call holds the context's mutex --
+ *     host-buffer calls until their results are back, *_dev calls while they enqueue -- so a
+ *     second host thread (the N-API addon's libuv worker beside the JS thread) waits instead
+ *     of overwriting the first one's staged inputs.  Throughput comes from one context per
+ *     GPU (one process / thread per GPU, see DESIGN.md multi-GPU), not from threads inside a
+ *     context.  Host-buffer entry points are synchronous.
  *     The *_dev entry points take DEVICE pointers, enqueue on the given
  *     hipStream_t (passed as void*, NULL = the context's own non-blocking stream, which
  *     ellgpu_ctx_stream returns so that a caller can order other streams against it) and return
@@ -107,7 +113,7 @@ extern "C" {
 #define ELLGPU_E_NOMEM (-4)     /* device allocation failed */
 #define ELLGPU_E_UNSUPPORTED (-5) /* operation not defined for this curve (e.g. mulAdd on curve25519, mont.js:155) */
 
-/* per-item status in out_inf / out_ok: an operand is not on the curve (see DOMAIN above) */
+/* per-item status in out_inf / out_status: an operand is not on the curve (see DOMAIN above) */
 #define ELLGPU_STATUS_OFF_CURVE 2
 
 typedef struct ellgpu_ctx ellgpu_ctx;
@@ -187,9 +193,12 @@ int ellgpu_mul_var(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
 int ellgpu_mul_add2(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1,
                     const uint8_t* p1_xy, const uint8_t* k2, const uint8_t* p2_xy,
                     uint8_t* out_xy, uint8_t* out_inf);
-/* out_ok[i] = EC#verify(hash[i], {r[i], s[i]}, pub[i]): 1 / 0, or 2 (ELLGPU_STATUS_OFF_CURVE)
- * when r and s are in range but pub[i] is not on the curve -- the reference goes on to compute
- * with such a key (and can answer true, tests/golden/offcurve_*.json), the engine does not guess.
+/* out_ok[i] = EC#verify(hash[i], {r[i], s[i]}, pub[i]): strictly 1 / 0.
+ * out_status (may be NULL): out_status[i] = 2 (ELLGPU_STATUS_OFF_CURVE) when r and s are in range
+ * but pub[i] is not on the curve, else 0.  out_ok[i] is 0 for such an item -- the safe answer;
+ * the reference goes on to compute with such a key (and can answer true,
+ * tests/golden/offcurve_*.json), the engine does not guess: a caller that wants the reference's
+ * own answer runs the reference on the items out_status marks.
  * hash: n x hash_len bytes, the message digest exactly as the caller would
  * pass it to EC#verify as an array (its length, not its value, drives the
  * truncation: ec/index.js:86-96).  msg_bits = 0 means hash_len*8; otherwise it
@@ -198,7 +207,7 @@ int ellgpu_mul_add2(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1,
  * 32 bits. */
 int ellgpu_ecdsa_verify(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash,
                         int hash_len, int msg_bits, const uint8_t* r, const uint8_t* s,
-                        const uint8_t* pub_xy, uint8_t* out_ok);
+                        const uint8_t* pub_xy, uint8_t* out_ok, uint8_t* out_status);
 /* x-only Montgomery ladder on curve25519: out_x[i] = x(k[i] * (in_x[i], .));
  * out_inf[i] = 1 when the result is the point at infinity (Z == 0), where the
  * reference's getX() would throw. */
@@ -282,9 +291,9 @@ int ellgpu_point_add_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* xy
  *   decodePoint) and DER signatures as above; point decoding, DER parsing, the double-scalar
  *   multiplication and the x == r test all run on the device.  out_ok = 0/1; out_err (may be
  *   NULL) names the exception the reference throws, in its order: 1..3 = decodePoint's status
- *   for the key, 4 = 'Signature without r or s'; out_ok is 0 wherever out_err is 1..4.
- *   out_err 5 is no exception: an uncompressed key that is not on the curve with r, s in range,
- *   out_ok = 2 (ELLGPU_STATUS_OFF_CURVE) -- hand the item to the reference. */
+ *   for the key, 4 = 'Signature without r or s'; out_ok is 0 wherever out_err is not 0.
+ *   out_err 5 is no exception: an uncompressed key that is not on the curve with r, s in range
+ *   (ELLGPU_STATUS_OFF_CURVE) -- hand the item to the reference if its answer is wanted. */
 int ellgpu_sig_from_der(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* der, size_t stride,
                         const uint32_t* der_len, uint8_t* out_r, uint8_t* out_s, uint8_t* out_status);
 int ellgpu_sig_from_der_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* der, size_t stride,
@@ -378,7 +387,9 @@ int ellgpu_eddsa_sign_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* secrets, con
                           const uint64_t* msg_off, size_t msg_len, uint8_t* out_sig, uint8_t* out_pub,
                           void* stream);
 
-/* ---- device-buffer entry points (inputs/outputs resident in HBM) -------- */
+/* ---- device-buffer entry points (inputs/outputs resident in HBM) --------
+ * Point operands and results must not overlap (in_xy / p1_xy / p2_xy against out_xy): the
+ * operands are read again, for the curve test, after the results are written -- ELLGPU_E_ARG. */
 int ellgpu_mul_fixed_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
                          uint8_t* out_xy, uint8_t* out_inf, void* stream);
 int ellgpu_mul_var_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k,
@@ -388,7 +399,8 @@ int ellgpu_mul_add2_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* k1,
                         uint8_t* out_xy, uint8_t* out_inf, void* stream);
 int ellgpu_ecdsa_verify_dev(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* hash,
                             int hash_len, int msg_bits, const uint8_t* r, const uint8_t* s,
-                            const uint8_t* pub_xy, uint8_t* out_ok, void* stream);
+                            const uint8_t* pub_xy, uint8_t* out_ok, uint8_t* out_status,
+                            void* stream);
 int ellgpu_x25519_ladder_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* in_x,
                              uint8_t* out_x, uint8_t* out_inf, void* stream);
 

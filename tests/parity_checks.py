@@ -710,15 +710,18 @@ def check_offcurve_golden(ctx, curve):
     r = ints_to_be([I(c["r"]) for c in ver], NB)
     s = ints_to_be([I(c["s"]) for c in ver], NB)
     pub = pts(ver, "qx", "qy")
-    ok = ctx.ecdsa_verify(curve, z, r, s, pub)
+    ok, st = ctx.ecdsa_verify(curve, z, r, s, pub, status=True)
+    assert np.array_equal(ok, ctx.ecdsa_verify(curve, z, r, s, pub))       # the status is optional
+    assert set(np.unique(ok).tolist()) <= {0, 1}                           # a mask, whatever the keys are
     n_dom = 0
     for i, c in enumerate(ver):
         in_range = 0 < I(c["r"]) < n and 0 < I(c["s"]) < n
         if c["on"] or not in_range:
             # on the curve, or rejected before the key is touched (ec/index.js:199-202): a verdict
-            assert ok[i] == (1 if c["ok"] else 0), (curve, c, int(ok[i]))
+            assert (ok[i], st[i]) == (1 if c["ok"] else 0, 0), (curve, c, int(ok[i]), int(st[i]))
         else:
-            assert ok[i] == 2, (curve, c, int(ok[i]))
+            # outside the engine's domain: verdict 0 (never "accept"), status 2
+            assert (ok[i], st[i]) == (0, 2), (curve, c, int(ok[i]), int(st[i]))
             n_dom += 1
     assert n_dom >= 9 and sum(1 for c in ver if c["ok"] and not c["on"]) >= 8
     # the same tuples through the wire form: DER signatures + uncompressed keys
@@ -731,7 +734,7 @@ def check_offcurve_golden(ctx, curve):
         if c["on"]:
             assert (wok[j], werr[j]) == (1 if c["ok"] else 0, 0), ("wire", curve, c)
         else:
-            assert (wok[j], werr[j]) == (2, 5), ("wire", curve, c, int(wok[j]), int(werr[j]))
+            assert (wok[j], werr[j]) == (0, 5), ("wire", curve, c, int(wok[j]), int(werr[j]))
     return total + len(ver) + len(inr)
 
 

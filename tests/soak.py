@@ -91,8 +91,9 @@ def main():
             bad = pts.copy()
             off = np.arange(3, n, 41)
             bad[off, 2 * B - 1] ^= 1
-            got2 = ctx.ecdsa_verify(curve, z, r, s, bad)
-            flagged = got2 == 2
+            got2, st2 = ctx.ecdsa_verify(curve, z, r, s, bad, status=True)
+            flagged = st2 == 2
+            assert got2.max() <= 1 and not got2[flagged].any(), (curve, "verdicts are a mask")
             assert np.array_equal(got2[~flagged], want[~flagged]), (curve, "verify beside off-curve keys")
             assert not flagged[np.setdiff1d(np.arange(n), off)].any() and flagged[off].sum() >= len(off) - 2, (curve, "off-curve flags")
             xy2, inf2 = ctx.mul_var(curve, k, bad)

@@ -52,7 +52,7 @@ def test_offcurve_operands_are_reported_not_guessed(ctx, curve):
 def test_offcurve_keys_scattered_in_a_full_size_batch(ctx, monkeypatch):
     """2^20 verifies with every 1000th key moved off the curve (y + 1): exactly those items -- minus
     the ones whose r / s are out of range, which the reference rejects before it touches the key
-    -- answer 2, every other verdict is the expected mask; same for the small-grid tuning on a
+    -- have status 2 beside a verdict of 0, every other verdict is the expected mask; same for the small-grid tuning on a
     131 072-item shard and for P*k through the host-buffer pipeline."""
     n = 1 << 20
     h, r, s, pub, expect = _make_sigs(ctx, n, "gpu-test-fullsize")
@@ -63,21 +63,34 @@ def test_offcurve_keys_scattered_in_a_full_size_batch(ctx, monkeypatch):
         y = (int.from_bytes(pub[i, 32:].tobytes(), "big") + 1) % p
         pub[i, 32:] = np.frombuffer(y.to_bytes(32, "big"), np.uint8)
     want = expect.copy()
-    want[off] = 2
+    want[off] = 0                        # the verdicts are a mask: 0 for a key that is no curve point
+    wst = np.zeros(n, np.uint8)
+    wst[off] = 2
     nn = O.get_curve("secp256k1").n
     for i in off:                        # corrupted r / s can leave [1, n): rejected first
         ri, si = int.from_bytes(r[i].tobytes(), "big"), int.from_bytes(s[i].tobytes(), "big")
         if not (0 < ri < nn and 0 < si < nn):
-            want[i] = 0
-    got = ctx.ecdsa_verify("secp256k1", h, r, s, pub)
-    assert np.array_equal(got, want)
+            wst[i] = 0
+    got, gst = ctx.ecdsa_verify("secp256k1", h, r, s, pub, status=True)
+    assert np.array_equal(got, want) and np.array_equal(gst, wst)
+    assert np.array_equal(ctx.ecdsa_verify("secp256k1", h, r, s, pub), want)      # without the status array
     m = 131072
-    assert np.array_equal(ctx.ecdsa_verify("secp256k1", h[:m], r[:m], s[:m], pub[:m]), want[:m])
+    got, gst = ctx.ecdsa_verify("secp256k1", h[:m], r[:m], s[:m], pub[:m], status=True)
+    assert np.array_equal(got, want[:m]) and np.array_equal(gst, wst[:m])
     monkeypatch.setenv("ELLGPU_SMALL_GRID", "0")            # the full-grid tuning on the same shard
     c2 = elliptic_amd.Context(0)                            # (tuning overrides are read at creation)
     monkeypatch.delenv("ELLGPU_SMALL_GRID")
-    assert np.array_equal(c2.ecdsa_verify("secp256k1", h[:m], r[:m], s[:m], pub[:m]), want[:m])
+    got, gst = c2.ecdsa_verify("secp256k1", h[:m], r[:m], s[:m], pub[:m], status=True)
+    assert np.array_equal(got, want[:m]) and np.array_equal(gst, wst[:m])
     c2.close()
+    # device-resident form: the status array is optional there too
+    import torch
+    dv = [torch.from_numpy(x[:m]).cuda() for x in (h, r, s, pub)]
+    dok = torch.full((m,), 9, dtype=torch.uint8, device="cuda")
+    dst = torch.full((m,), 9, dtype=torch.uint8, device="cuda")
+    ctx.ecdsa_verify_dev("secp256k1", *dv, dok, out_status=dst)
+    ctx.synchronize()
+    assert np.array_equal(dok.cpu().numpy(), want[:m]) and np.array_equal(dst.cpu().numpy(), wst[:m])
     m = 300000
     xy, inf = ctx.mul_var("secp256k1", r[:m], pub[:m])
     is_off = np.zeros(m, bool)
@@ -422,10 +435,12 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
         sl = (h[:m], r[:m], s[:m], pub[:m])
         for c, parts in ((c0, False), (c1, True), (cd, True)):
             c.set_timing(True)
-            got = c.ecdsa_verify("secp256k1", *sl)
+            got, gst = c.ecdsa_verify("secp256k1", *sl, status=True)
             tm = c.get_timing()
             c.set_timing(False)
-            assert np.array_equal(got, want[:m]), (m, parts)
+            # (`want` marks off-curve keys with 2: verdict 0 and status 2 at the C ABI)
+            assert got.max(initial=0) <= 1 and not got[gst == 2].any(), (m, parts)
+            assert np.array_equal(np.where(gst == 2, 2, got), want[:m]), (m, parts)
             assert ("ecdsa_parts" in tm and "ecdsa_join" in tm) == parts, (m, parts, sorted(tm))
     # above the default threshold: the one-lane small-grid ladder
     h2, r2, s2, pub2, expect2 = _make_sigs(c0, 40000, "gpu-test-parted-2")

@@ -516,6 +516,68 @@ def test_error_paths(ctx, hs):
     assert out.shape == (0, 64)
 
 
+def test_one_context_entered_from_several_threads(ctx):
+    """The N-API addon runs Promise-form batches on a libuv worker while the JS thread makes
+    synchronous calls on the SAME context: entry points of one context take turns (a
+    mutex in the C ABI), so concurrent callers get their own results, not each other's staged
+    inputs.  ctypes releases the GIL around the calls: the threads really are inside together."""
+    import threading
+    from golden_util import I, verify_cases
+    from elliptic_amd import ints_to_be
+    cs = [c for c in verify_cases("secp256k1") if len(c["z"]) == 64]
+    h = ints_to_be([I(c["z"]) for c in cs], 32)
+    r = ints_to_be([I(c["r"]) for c in cs], 32)
+    s = ints_to_be([I(c["s"]) for c in cs], 32)
+    q = np.concatenate([ints_to_be([I(c["qx"]) for c in cs], 32), ints_to_be([I(c["qy"]) for c in cs], 32)], axis=1)
+    want = np.array([1 if c["ok"] else 0 for c in cs], np.uint8)
+    rng = random.Random(11)
+    ks = np.frombuffer(bytes(rng.getrandbits(8) for _ in range(24 * 32)), np.uint8).reshape(24, 32)
+    want_xy, want_inf = ctx.mul_fixed("secp256k1", ks)
+    errors = []
+
+    def verifier(t):
+        try:
+            for it in range(6):
+                lo = (t * 7 + it * 3) % (len(cs) - 8)
+                m = 8 + (t + it) % 5
+                got = ctx.ecdsa_verify("secp256k1", h[lo:lo + m], r[lo:lo + m], s[lo:lo + m], q[lo:lo + m])
+                if not np.array_equal(got, want[lo:lo + m]):
+                    errors.append(("verify", t, it))
+        except Exception as e:                      # noqa: BLE001
+            errors.append(("verify raised", t, repr(e)))
+
+    def multiplier(t):
+        try:
+            for it in range(6):
+                lo = (t + it) % 12
+                xy, inf = ctx.mul_fixed("secp256k1", ks[lo:lo + 12])
+                if not (np.array_equal(xy, want_xy[lo:lo + 12]) and np.array_equal(inf, want_inf[lo:lo + 12])):
+                    errors.append(("mul_fixed", t, it))
+        except Exception as e:                      # noqa: BLE001
+            errors.append(("mul raised", t, repr(e)))
+
+    th = [threading.Thread(target=verifier if t % 2 == 0 else multiplier, args=(t,)) for t in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:5]
+
+
+def test_point_operands_and_results_must_not_overlap(ctx, hs):
+    """*_dev entry points read the operands again after the results are written (the curve test):
+    an out_xy over its own in_xy is refused, loudly"""
+    n = 4
+    buf = np.zeros((n, 64), np.uint8)
+    k = np.zeros((n, 32), np.uint8)
+    inf = np.zeros(n, np.uint8)
+    rc = hs.ellgpu_mul_var_dev(ctx._ctx, 0, n, k.ctypes.data, buf.ctypes.data, buf.ctypes.data, inf.ctypes.data, None)
+    assert rc == -2 and b"overlap" in hs.ellgpu_last_error()
+    rc = hs.ellgpu_mul_add2_dev(ctx._ctx, 0, n, k.ctypes.data, None, k.ctypes.data, buf.ctypes.data,
+                                buf[1:].ctypes.data, inf.ctypes.data, None)
+    assert rc == -2 and b"overlap" in hs.ellgpu_last_error()
+
+
 def test_device_group_shards_match_single_context():
     """ellgpu_group_create: the sharded host entry points (one host thread per member, results
     written straight into the caller's buffers) give exactly the single-context results, for
@@ -561,7 +623,7 @@ def test_device_group_shards_match_single_context():
     grp.synchronize()
     import ctypes
     assert lib.ellgpu_mul_fixed(grp._ctx, 0, 4, None, None, None) == -2
-    assert lib.ellgpu_ecdsa_verify(grp._ctx, 0, 4, None, 32, 0, None, None, None, None) == -2
+    assert lib.ellgpu_ecdsa_verify(grp._ctx, 0, 4, None, 32, 0, None, None, None, None, None) == -2
     # a user-defined curve is registered with all members or with none: fill ONE member's table
     # behind the group's back, then the group definition must fail and leave member 0 untouched
     members = grp.group_size()

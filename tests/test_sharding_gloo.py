@@ -152,8 +152,10 @@ def _overlap_worker(rank, world, port, lib_path, n, steps, q):
         s = ints_to_be([I(c["s"]) for c in cs], 32)
         pub = np.concatenate([ints_to_be([I(c["qx"]) for c in cs], 32), ints_to_be([I(c["qy"]) for c in cs], 32)], axis=1)
         cur_n = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
-        want = np.array([(2 if (c.get("on") is False and 0 < I(c["r"]) < cur_n and 0 < I(c["s"]) < cur_n)
-                          else (1 if c["ok"] else 0)) for c in cs], np.uint8)
+        # a key that is not on the curve (r, s in range): verdict 0 -- the gathered array is a MASK,
+        # strictly 0 / 1 (the domain status is a separate, optional array of the C ABI)
+        off = np.array([c.get("on") is False and 0 < I(c["r"]) < cur_n and 0 < I(c["s"]) < cur_n for c in cs])
+        want = np.array([(0 if off[i] else (1 if c["ok"] else 0)) for i, c in enumerate(cs)], np.uint8)
         lo, hi = shard_range(n, rank, world)
         og = OverlappedGather(n, dist, torch.device("cpu"))
         good = True
@@ -167,15 +169,16 @@ def _overlap_worker(rank, world, port, lib_path, n, steps, q):
         og.drain()
         last, prev = (steps - 1) & 1, (steps - 2) & 1
         good = good and np.array_equal(og.result(last).numpy(), want) and np.array_equal(og.result(prev).numpy(), want)
-        q.put((rank, bool(good), int((want == 2).sum())))
+        good = good and int(og.result(last).max()) <= 1
+        q.put((rank, bool(good), int(off.sum())))
     finally:
         dist.destroy_process_group()
 
 
 def test_world2_overlapped_gather_of_verify_masks():
     """bench.py's strong-scaling loop: step i's gather (async all_gather_into_tensor, two
-    alternating buffers) overlaps step i + 1's verifies; uneven shards; off-curve keys keep their
-    status 2 through the gather"""
+    alternating buffers) overlaps step i + 1's verifies; uneven shards; off-curve keys are 0 in
+    the gathered mask (never "accept")"""
     from hostsim.build import build as build_hostsim
     lib_path = build_hostsim()
     ctxm = mp.get_context("spawn")

@@ -169,6 +169,21 @@ var pendingAsync = [];
     checked += items.length;
   }));
 });
+// api_forms.json (tools/api_forms.js): arguments that are objects of the library -- the patched
+// library must answer, or throw, exactly what the unpatched reference did when the file was made
+(function() {
+  var forms = require('./api_forms');
+  var byOp = {};
+  load('api_forms.json').forEach(function(o, i) {
+    var got = forms.run(elliptic, o);
+    if (got !== o.want) throw new Error('api_forms #' + i + ' ' + JSON.stringify(o).slice(0, 300) + ': patched ' + got + ', reference ' + o.want);
+    if (o.want[0] === 'e') thrown++;
+    byOp[o.op] = (byOp[o.op] || 0) + 1;
+    checked++;
+  });
+  if ((byOp['eddsa-verify'] || 0) < 200 || (byOp['sign-width'] || 0) < 300 || (byOp['foreign-sign'] || 0) < 25)
+    throw new Error('api_forms.json is not the file tools/gen_golden.js writes: ' + JSON.stringify(byOp));
+})();
 Promise.all(pendingAsync).then(function() {
   console.log(JSON.stringify({ ok: true, checked: checked, thrown: thrown, engine: eng.stats }));
 }, function(e) { console.error(e.stack || e); process.exit(1); });

@@ -241,6 +241,158 @@ for (var it = 0; it < ITER && failures.length < 5; it++) {
     });
   });
 })();
+// ---- the forms of the public API that carry OBJECTS (round-4 review: three mismatches hid here) ----
+// EDDSA#verify computes with the point objects it is given -- the key's, the signature's R -- and
+// with a BN S, whatever their encodings say (eddsa/index.js:52-63, eddsa/key.js:20-23,
+// eddsa/signature.js:33-38): off-curve twins that encode like the true point, points with Z != 1
+// or a wrong T, a negative S, S + n, an `Rencoded` / `Sencoded` that belongs to another signature.
+(function() {
+  function build(L, o) {
+    var ed = new L.eddsa('ed25519'), c = ed.curve, BN = c.p.constructor;
+    var sig = ed.sign(o.msg, o.secret), other = ed.sign(o.msg.concat([ 7 ]), o.secret);
+    var A = ed.keyFromSecret(o.secret).pub();
+    function twin(P) { return c.point(P.getX().addn(2).umod(c.p), P.getY()); }              // same encoding, off the curve
+    function scaled(P) { var z = new BN(o.z, 16).toRed(c.red); return c.point(P.x.redMul(z), P.y.redMul(z), z, P.t.redMul(z)); }
+    function badT(P) { return c.point(P.getX(), P.getY(), null, P.t.redAdd(c.one)); }
+    function fresh(P) { return c.point(P.getX(), P.getY()); }
+    var pub;
+    switch (o.pubForm) {
+      case 0: pub = ed.keyFromSecret(o.secret).getPublic('hex'); break;
+      case 1: pub = ed.keyFromSecret(o.secret).getPublic(); break;
+      case 2: pub = fresh(A); break;
+      case 3: pub = twin(A); break;
+      case 4: pub = scaled(A); break;
+      case 5: pub = badT(A); break;
+      case 6: pub = ed.keyFromPublic(fresh(A)); break;
+      case 7: pub = ed.keyFromPublic(twin(A)); break;
+      case 8: pub = ed.keyFromPublic(ed.keyFromSecret(o.secret).getPublic()); break;
+      case 9: pub = ed.keyFromSecret(o.secret); break;
+      case 10: pub = ed.keyFromPublic(fresh(A)); pub.pubBytes(); pub.pub(); break;           // caches filled
+      case 11: pub = new L.eddsa('ed25519').keyFromPublic(fresh(A)); break;                  // another EDDSA instance
+      default: pub = Buffer.from(ed.keyFromSecret(o.secret).getPublic());                    // a Buffer is no Array
+    }
+    var R = sig.R(), S = sig.S(), sg;
+    switch (o.sigForm) {
+      case 0: sg = sig.toHex(); break;
+      case 1: sg = sig.toBytes(); break;
+      case 2: sg = { R: sig.Rencoded(), S: sig.Sencoded() }; break;
+      case 3: sg = { R: fresh(R), S: S.clone() }; break;
+      case 4: sg = { R: twin(R), S: S.clone() }; break;
+      case 5: sg = { R: fresh(R), S: S.neg() }; break;
+      case 6: sg = { R: fresh(R), S: S.add(c.n) }; break;
+      case 7: sg = { R: scaled(R), S: S.clone() }; break;
+      case 8: sg = { R: badT(R), S: S.clone() }; break;
+      case 9: sg = { R: fresh(other.R()), S: S.clone(), Rencoded: sig.Rencoded() }; break;
+      case 10: sg = { R: sig.Rencoded(), S: other.S(), Sencoded: sig.Sencoded() }; break;
+      case 11: sg = sig; break;
+      case 12: sg = ed.makeSignature({ R: twin(R), S: S.clone() }); break;
+      case 13: sg = { R: fresh(R), S: sig.Sencoded() }; break;
+      case 14: sg = { R: sig.Rencoded(), S: S.clone() }; break;
+      case 15: sg = { R: fresh(R), S: new BN(1).ushln(300) }; break;
+      case 16: sg = { R: twin(R), S: S.clone(), Rencoded: sig.Rencoded() }; break;
+      default: sg = new L.eddsa('ed25519').makeSignature(sig.toHex());                       // a Signature of another instance
+    }
+    var msg = o.msgForm === 0 ? o.msg : o.msgForm === 1 ? Buffer.from(o.msg).toString('hex') :
+      o.msgForm === 2 ? o.msg.map(function(x, i) { return i === 1 ? x + 256 : x; }) : Buffer.from(o.msg);
+    return { ed: ed, msg: msg, sig: sg, pub: pub };
+  }
+  for (var it = 0; it < Math.ceil(ITER / 2) && failures.length < 5; it++) {
+    var o = { secret: Buffer.from(rng.bytes(32)).toString('hex'), msg: rng.bytes(rng.pick([ 2, 3, 32, 64 ])),
+      z: Buffer.from(rng.bytes(31)).toString('hex') + '01', pubForm: rng.int(13), sigForm: rng.int(18), msgForm: rng.int(8) > 5 ? rng.int(4) : 0 };
+    context = JSON.stringify(o);
+    both('eddsa verify (object forms)', function() { var b = build(plain, o); return b.ed.verify(b.msg, b.sig, b.pub); },
+      function() { var b = build(patched, o); return b.ed.verify(b.msg, b.sig, b.pub); });
+    // ... and twice on the same objects (the reference caches decoded points / encodings on them)
+    both('eddsa verify (object forms, same objects twice)', function() { var b = build(plain, o); b.ed.verify(b.msg, b.sig, b.pub); return b.ed.verify(b.msg, b.sig, b.pub); },
+      function() { var b = build(patched, o); b.ed.verify(b.msg, b.sig, b.pub); return b.ed.verify(b.msg, b.sig, b.pub); });
+    if (it % 4 === 0) {
+      var sform = rng.int(4);
+      both('eddsa sign (secret / message forms)', function() {
+        var ed = new plain.eddsa('ed25519');
+        var sec = sform === 0 ? o.secret : sform === 1 ? ed.keyFromSecret(o.secret) : sform === 2 ? Buffer.from(o.secret, 'hex') :
+          Array.prototype.slice.call(Buffer.from(o.secret, 'hex')).map(function(x, i) { return i === 3 ? x + 256 : x; });
+        return ed.sign(build(plain, o).msg, sec).toHex();
+      }, function() {
+        var ed = new patched.eddsa('ed25519');
+        var sec = sform === 0 ? o.secret : sform === 1 ? ed.keyFromSecret(o.secret) : sform === 2 ? Buffer.from(o.secret, 'hex') :
+          Array.prototype.slice.call(Buffer.from(o.secret, 'hex')).map(function(x, i) { return i === 3 ? x + 256 : x; });
+        return ed.sign(build(patched, o).msg, sec).toHex();
+      });
+      // Edwards Point#mul / mulAdd on points whose coordinates are not what a decoder makes
+      var kk = Buffer.from(rng.bytes(32)).toString('hex'), pf = rng.int(4);
+      both('ed25519 mul (Z != 1 / wrong T / off-curve twin)', function() {
+        var c = plain.curves.ed25519.curve, BN = c.p.constructor, A = c.g.mul(new BN(o.secret, 16));
+        var z = new BN(o.z, 16).toRed(c.red);
+        var P = pf === 0 ? c.point(A.x.redMul(z), A.y.redMul(z), z, A.t.redMul(z)) : pf === 1 ? c.point(A.getX(), A.getY(), null, A.t.redAdd(c.one)) :
+          pf === 2 ? c.point(A.getX().addn(2).umod(c.p), A.getY()) : c.point(A.getX(), A.getY(), new BN(1));
+        return P.mul(new BN(kk, 16).umod(c.n));
+      }, function() {
+        var c = patched.curves.ed25519.curve, BN = c.p.constructor, A = c.g.mul(new BN(o.secret, 16));
+        A = c.point(A.getX(), A.getY());
+        var z = new BN(o.z, 16).toRed(c.red);
+        var P = pf === 0 ? c.point(A.x.redMul(z), A.y.redMul(z), z, A.t.redMul(z)) : pf === 1 ? c.point(A.getX(), A.getY(), null, A.t.redAdd(c.one)) :
+          pf === 2 ? c.point(A.getX().addn(2).umod(c.p), A.getY()) : c.point(A.getX(), A.getY(), new BN(1));
+        return P.mul(new BN(kk, 16).umod(c.n));
+      });
+    }
+  }
+})();
+// EC#sign / EC#verify with digests of NB - 1 .. NB + 4 bytes and an explicit options.msgBitLength
+// on every curve: the reference writes the truncated digest on n.byteLength() bytes
+// (ec/index.js:133-139) and throws when it does not fit -- p521, 67 / 68 bytes
+(function() {
+  SHORT.forEach(function(name) {
+    var eca = new plain.ec(name), ecb = new patched.ec(name);
+    var NB = eca.n.byteLength(), bits = eca.n.bitLength();
+    var priv = Buffer.from(rng.bytes(NB - 1)).toString('hex');
+    for (var len = NB - 1; len <= NB + 4 && failures.length < 5; len++) {
+      var mb = rng.bytes(len);
+      mb[0] |= 0x80;                                  // a digest that really is `len` bytes wide
+      var full;
+      try { full = eca.sign(mb, priv, 'hex'); } catch (e) { full = null; }
+      [ undefined, 1, 8, bits - 1, bits, bits + 1, 8 * len - 1, 8 * len, 8 * len + 8 ].forEach(function(mbl) {
+        var opts = mbl === undefined ? undefined : { msgBitLength: mbl };
+        context = JSON.stringify({ curve: name, len: len, msgBitLength: mbl });
+        both(name + ' sign (digest length x msgBitLength)', function() { return eca.sign(mb, priv, 'hex', opts); }, function() { return ecb.sign(mb, priv, 'hex', opts); });
+        var sg;
+        try { sg = eca.sign(mb, priv, 'hex', opts); } catch (e) { sg = full; }
+        if (!sg) return;
+        var sh = { r: sg.r.toString(16), s: sg.s.toString(16) };
+        var pubHex = eca.keyFromPrivate(priv, 'hex').getPublic('hex');
+        both(name + ' verify (digest length x msgBitLength)', function() { return eca.verify(mb, sh, pubHex, 'hex', opts); }, function() { return ecb.verify(mb, sh, pubHex, 'hex', opts); });
+      });
+    }
+  });
+})();
+// A KeyPair is used as it is (ec/key.js:23-24, 31-32), whichever EC instance made it: its private
+// half was reduced by ITS curve's order, its public half lives on ITS curve
+(function() {
+  [ [ 'secp256k1', 'p256' ], [ 'p256', 'secp256k1' ], [ 'p384', 'p256' ], [ 'p224', 'p192' ], [ 'p521', 'p384' ], [ 'p256', 'p256' ] ].forEach(function(pr) {
+    function mk(L) { return { from: new L.ec(pr[0]), to: new L.ec(pr[1]) }; }
+    var a = mk(plain), b = mk(patched);
+    var n2 = a.to.n;
+    [ '07', n2.addn(5).toString(16), n2.subn(1).toString(16), n2.toString(16), Buffer.from(rng.bytes(a.from.n.byteLength())).toString('hex') ].forEach(function(ph) {
+      if (failures.length >= 5) return;
+      var msg = rng.bytes(32);
+      context = JSON.stringify({ from: pr[0], to: pr[1], priv: ph });
+      both('sign with a KeyPair of another EC instance', function() { return a.to.sign(msg, a.from.keyFromPrivate(ph, 'hex')); },
+        function() { return b.to.sign(msg, b.from.keyFromPrivate(ph, 'hex')); });
+      both('KeyPair#sign of another EC instance', function() { return a.from.keyFromPrivate(ph, 'hex').sign(msg); },
+        function() { return b.from.keyFromPrivate(ph, 'hex').sign(msg); });
+      var sg;
+      try { sg = a.to.sign(msg, '0b', 'hex'); } catch (e) { return; }
+      var sh = { r: sg.r.toString(16), s: sg.s.toString(16) };
+      both('verify with a KeyPair of another EC instance', function() { return a.to.verify(msg, sh, a.from.keyFromPrivate(ph, 'hex')); },
+        function() { return b.to.verify(msg, sh, b.from.keyFromPrivate(ph, 'hex')); });
+      both('verify with a public-only KeyPair of another EC instance', function() { return a.to.verify(msg, sh, a.from.keyFromPublic(a.from.keyFromPrivate(ph, 'hex').getPublic('hex'), 'hex')); },
+        function() { return b.to.verify(msg, sh, b.from.keyFromPublic(b.from.keyFromPrivate(ph, 'hex').getPublic('hex'), 'hex')); });
+      both('derive across EC instances', function() { return a.to.keyFromPrivate('0d', 'hex').derive(a.from.keyFromPrivate(ph, 'hex').getPublic()); },
+        function() { return b.to.keyFromPrivate('0d', 'hex').derive(b.from.keyFromPrivate(ph, 'hex').getPublic()); });
+      both('derive with a private key of another EC instance', function() { return a.from.keyFromPrivate(ph, 'hex').derive(a.from.keyFromPrivate('11', 'hex').getPublic()); },
+        function() { return b.from.keyFromPrivate(ph, 'hex').derive(b.from.keyFromPrivate('11', 'hex').getPublic()); });
+    });
+  });
+})();
 // uninstall() puts the reference's own functions back: every method install() replaces must read
 // exactly like the unpatched library's again
 (function() {

@@ -8,6 +8,9 @@
 //   mul_<curve>.json        seeded + edge cases for Point.mul / mulAdd
 //   verify_<curve>.json     ECDSA verify tuples (valid + corrupted)
 //   offcurve_<curve>.json   points that are not on the curve: what the reference answers
+//   api_forms.json          calls whose arguments are library OBJECTS (points, KeyPairs, Signatures):
+//                           EDDSA#verify over every key form x signature form, EC#sign / verify over
+//                           digest widths x options.msgBitLength, KeyPairs of another EC instance
 //   captured_<curve>.json   every call the reference's OWN mocha suite makes
 //                           into the hot path (Point.mul / mulAdd / jmulAdd /
 //                           ec.verify), captured at the prototype boundary
@@ -1207,6 +1210,13 @@ SHORT.concat(['ed25519']).forEach(function(name) {
 });
 write('eddsa_verify_ed25519.json', genEddsa());
 write('eddsa_sign_ed25519.json', genEddsaSign());
+// public-API calls whose arguments are objects of the library (tools/api_forms.js): recipe + what
+// the reference answers (a value or the message of the Error it throws)
+(function() {
+  var forms = require('./api_forms');
+  var rng = new Prng('golden:api_forms');
+  write('api_forms.json', forms.recipes(rng, elliptic).map(function(o) { o.want = forms.run(elliptic, o); return o; }));
+})();
 write('mul_ed25519.json', genEdwardsMul());
 write('mul_curve25519.json', genMontMul());
 if (ONLY && !ONLY.test('captured_')) process.exit(0);
