@@ -308,7 +308,7 @@ def live_counters(batch, per_pass_timeout=90, keep=None, total_budget=240):
     os.makedirs(tmp, exist_ok=True)
     summ = _tool("rocprof_summary")
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu",
-             "--no-live-counters", "--batch", str(batch)]
+             "--no-live-counters", "--sustain", "0", "--batch", str(batch)]
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -558,6 +558,8 @@ def main():
                     help="self-test only: every rank uses this device (lets the N>1 flow run on a 1-GPU box)")
     ap.add_argument("--rccl-selftest", action="store_true",
                     help="N = 1: initialise a 1-rank RCCL group and run the gather through it once")
+    ap.add_argument("--sustain", type=float, default=5.0,
+                    help="seconds of the same step loop AFTER the timed region, reported as `sustained` (0 = skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -686,6 +688,8 @@ def main():
         rccl_selftest = {"backend": args.dist_backend, "world": 1, "all_gather_ok": bool(torch.equal(gathered[0], dok)),
                          "ms": (time.perf_counter() - t0) * 1e3}
 
+    own_dt = [0.0]
+
     def timed(fn, steps, finish=None):
         """exactly `steps` calls of fn (+ finish(): whatever they left in flight) between barrier +
         synchronize on both sides -> max over ranks"""
@@ -701,6 +705,7 @@ def main():
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        own_dt[0] = dt                              # this rank's own wall time of the region (see per_rank)
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -711,6 +716,8 @@ def main():
     dt = timed(step, args.steps, og_w.drain if og_w is not None else None)
     timing = ctx.get_timing()
     ctx.set_timing(False)
+    own_dt = [own_dt[0]]                            # (kept: later regions write their own)
+    own_main = own_dt[0]
     # with two passes in flight the HIP events around a launch also span the time the kernel
     # shares the device with the other pass's kernels: the kernels BY THEMSELVES are timed in a
     # short one-stream loop outside the timed region
@@ -722,6 +729,34 @@ def main():
         torch.cuda.synchronize()
         timing_alone = ctx.get_timing()
         ctx.set_timing(False)
+
+    # SUSTAINED rate (never `value`): the timed region above is --steps passes, a fraction of a second,
+    # on a kernel that runs into the part's power limit -- so the same step loop (same streams, same
+    # synchronisation, max over ranks) is run again for at least --sustain seconds
+    sustained = None
+    if args.sustain > 0:
+        sus_steps = max(args.steps, int(np.ceil(args.sustain / (dt / args.steps))))
+        sdt_s = timed(step, sus_steps, og_w.drain if og_w is not None else None)
+        sustained = {"seconds": sdt_s, "steps": sus_steps, "value": n_global * sus_steps / sdt_s, "unit": "verifies/s",
+                     "ms_per_step": sdt_s / sus_steps * 1e3,
+                     "ratio_to_value": (n_global * sus_steps / sdt_s) / (n_global * args.steps / dt),
+                     "how": "the timed region's step loop again (same passes in flight, barrier + synchronize on both "
+                            "sides, max over ranks), for at least --sustain seconds"}
+        # every result buffer still holds the expected mask
+        for d in (doks if og_w is None else []):
+            if not np.array_equal(d.cpu().numpy(), expect):
+                raise SystemExit("PARITY FAILURE: a result buffer differs from the expected mask after the sustained loop")
+
+    # per-rank view of the timed region (a slow rank must be visible): this rank's own wall time
+    # per step and its dominant kernel's mean duration between HIP events
+    per_rank = None
+    if world > 1:
+        cnt_r, main_r = timing.get("ecdsa_main", (0, 0.0))
+        mine = torch.tensor([float(rank), own_main / args.steps * 1e3, main_r / max(cnt_r, 1)], dtype=torch.float64,
+                            device=dev if args.dist_backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": int(t[0].item()), "ms_per_step": float(t[1].item()), "ecdsa_main_ms": float(t[2].item())} for t in allr]
 
     rccl = None
     strong_block = None
@@ -874,6 +909,15 @@ def main():
                        "library_digest": lib_digest()},
             "roofline": roof,
         }
+        if sustained is not None:
+            vb = ((counters or {}).get("kernels", {}).get("ecdsa_main<secp256k1>", {}) or {}).get("valu_busy") or {}
+            sustained["clock_ghz_effective"] = vb.get("clock_ghz_effective")
+            sustained["clock_note"] = ("GRBM_GUI_ACTIVE / 8 XCDs / the dominant kernel's wall time, both from the live PMC pass of "
+                                       "this run (profiled passes clock a few per cent below un-profiled ones: MI355X_MICROARCH.md)"
+                                       if vb.get("clock_ghz_effective") else "no live PMC pass in this run")
+            out["sustained"] = sustained
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if rccl is not None:
             out["rccl"] = rccl
         if strong_block is not None:

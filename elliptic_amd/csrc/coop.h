@@ -1,0 +1,416 @@
+// ellgpu -- the LANES-PER-ITEM layer for batches that leave the machine idle: one secp256k1
+// field element spread over the lanes of ONE 16-lane DPP row, a whole wavefront per item.
+//
+// Why (profiles/r05_coop_field_microbench.json).  The reference's API is one
+// item per call (curve/short.js:422-432, ec/index.js:188-229): a lone EC#verify or Point#mul is
+// ONE dependent chain of field operations, and the device idles beside it.  An instruction costs
+// a wave its ~5 SIMD cycles whether one lane is active or sixty-four, so what the single call
+// waits for is INSTRUCTIONS PER FIELD OPERATION on its critical path: the one-item-per-lane
+// product (fp.h / mul_asm.h) is 72 multiply-adds + ~100 carry and move instructions, an addition
+// a 13-instruction carry chain.  Here limb l of an element (29 bits, signed: the radix and the
+// lazy algebra of fpk256l.h) lives in lane l of the row:
+//   * a product's nine partial-product rows are nine v_mad_i64_i32 of ALL lanes at once -- column
+//     l accumulates in lane l; operand a's limbs arrive as SGPRs (v_readlane), operand b shifted
+//     along the row by DPP row_shr -- column 16 (a8 b8) falls off the row onto the scalar unit;
+//   * carries travel one lane up by DPP, twice, and the high columns fold back through
+//     2^261 = 256 * 2^29 + 31264 (mod p) with three more multiply-adds and one carry pass;
+//   * an addition or subtraction is ONE instruction, a normalisation eight.
+// Measured on a lone wave (MI355X): product 184 ns against 439, square 180 against 362, Jacobian
+// doubling 1.43 us against 3.21 -- 2.2-2.4x per operation.  Throughput per INSTRUCTION is
+// the same, so this layer only serves batches of at most a few hundred items
+// (Engine::Tuning::coop_grid); everything larger stays one item per lane.
+//
+// The group law and the ladders are the SAME templates the one-lane kernels instantiate
+// (short.h dbl_lazy / add_mixed_lazy, ladder.h build_table_odd8 / run_odd_w4): FpK256C offers
+// FpK256L's interface, with `El` holding this lane's limb.  All control flow is wave-uniform
+// (one item per wave); zero tests reduce across the row through the scalar unit.
+//
+// Host passes (hipcc's host side, tests/hostsim) simulate the row: El holds all sixteen lanes
+// and every primitive is a loop over them -- the CPU suite runs the same code, bounds checks
+// (ELL_BOUNDS_CHECK) included.
+//
+// Replaces, for one item per wave: JPoint#dbl / mixedAdd (short.js:569-603, 668-737) and the
+// bn.js Red / K256 arithmetic under them (dist/elliptic.js:6888-6931, 7078-7302).
+#pragma once
+
+#include "curves.h"
+
+namespace ell {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ELL_COOP_LANES 1
+#else
+#define ELL_COOP_LANES 16
+#endif
+
+struct FpK256C {
+  static constexpr int CL = ELL_COOP_LANES;        // lanes of the row held by one El: 1 = the hardware lane
+  static constexpr int ROW = 16;
+  static constexpr int L = 8;                      // 32-bit words of a plain value
+  static constexpr bool LAZY = true;
+  static constexpr bool HAS_SQRT = false;
+  typedef Fe<CL> El;                               // v[t]: the two's complement bits of lane t's signed limb
+  struct W64 { i64 w[CL]; };
+  static constexpr u32 M = (1u << 29) - 1;
+  static constexpr i32 R0 = 31264, R1 = 256;       // 2^261 = R1 * 2^29 + R0  (mod p)
+
+  ELL_HD static i32 s(u32 x) { return (i32)x; }
+  ELL_HD static void get_p(u32 (&p)[8]) { FpK256::get_p(p); }
+
+  // ---- the row: lane index, per-lane constants, movement along it ---------------------------------
+  ELL_HD static int lane_of(int t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)t;
+    return (int)(threadIdx.x & 15u);
+#else
+    return t;
+#endif
+  }
+  // per-lane constant f(lane)
+  template <class Fn>
+  ELL_HD static El each(const Fn& f) {
+    El r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) r.v[t] = (u32)f(lane_of(t));
+    return r;
+  }
+  // lane l <- lane l - N, zeros shifted in (DPP row_shr:N bound_ctrl:0)
+  template <int N>
+  ELL_HD static El up(const El& x) {
+    El r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    r.v[0] = (u32)__builtin_amdgcn_update_dpp(0, (int)x.v[0], 0x110 + N, 0xF, 0xF, true);
+#else
+    for (int t = 0; t < CL; t++) r.v[t] = t >= N ? x.v[t - N] : 0u;
+#endif
+    return r;
+  }
+  // lane l <- lane l + N, zeros shifted in (row_shl:N)
+  template <int N>
+  ELL_HD static El down(const El& x) {
+    El r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    r.v[0] = (u32)__builtin_amdgcn_update_dpp(0, (int)x.v[0], 0x100 + N, 0xF, 0xF, true);
+#else
+    for (int t = 0; t < CL; t++) r.v[t] = t + N < CL ? x.v[t + N] : 0u;
+#endif
+    return r;
+  }
+  // the (wave-uniform) value of lane l
+  ELL_HD static i32 at(const El& x, int l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readlane((int)x.v[0], l);
+#else
+    return s(x.v[l]);
+#endif
+  }
+  // lane LANE <- the wave-uniform value sv
+  template <int LANE>
+  ELL_HD static El put(El x, i32 sv) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int v = (int)x.v[0];
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(sv), "n"(LANE));
+    x.v[0] = (u32)v;
+#else
+    x.v[LANE] = (u32)sv;
+#endif
+    return x;
+  }
+  template <int N>
+  ELL_HD static W64 up64(const W64& x) {
+    W64 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)x.w[0], 0x110 + N, 0xF, 0xF, true);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)((u64)x.w[0] >> 32), 0x110 + N, 0xF, 0xF, true);
+    r.w[0] = (i64)(((u64)hi << 32) | lo);
+#else
+    for (int t = 0; t < CL; t++) r.w[t] = t >= N ? x.w[t - N] : 0;
+#endif
+    return r;
+  }
+  ELL_HD static i64 at64(const W64& x, int l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)x.w[0], l);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)((u64)x.w[0] >> 32), l);
+    return (i64)(((u64)hi << 32) | lo);
+#else
+    return x.w[l];
+#endif
+  }
+  // per-lane constants of the algebra (loop-invariant registers on the device)
+  ELL_HD static El c_live() { return each([](int l) { return l <= 8 ? -1 : 0; }); }
+  ELL_HD static El c_mask() { return each([](int l) { return l < 8 ? (i32)M : (l == 8 ? -1 : 0); }); }   // a carry pass keeps these bits
+  ELL_HD static El c_kp() { return each([](int l) { return l == 0 ? -977 : (l == 1 ? -8 : (l == 8 ? (1 << 24) : 0)); }); }   // p - 2^256's part, limb by limb: K p = K * this (+ K 2^256 at limb 8)
+  ELL_HD static El c_kf() { return each([](int l) { return l == 0 ? 977 : (l == 1 ? 8 : 0); }); }       // one unit of limb 8's bit 24 (2^256 = 2^32 + 977)
+  ELL_HD static El c_rr() { return each([](int l) { return l == 0 ? R0 : (l == 1 ? R1 : 0); }); }        // one unit of column 9
+  ELL_HD static El c_r1() { return each([](int l) { return (l >= 1 && l <= 8) ? R1 : 0; }); }
+  ELL_HD static El c_rrr() { return each([](int l) { return l == 0 ? R1 * R0 : (l == 1 ? R1 * R1 : 0); }); }   // one unit of column 17's R1 part (column 9 again)
+  ELL_HD static El c_p() {
+    return each([](int l) { return l == 0 ? (i32)((1u << 29) - 977u) : (l == 1 ? (i32)((1u << 29) - 9u) : (l < 8 ? (i32)M : (l == 8 ? (1 << 24) - 1 : 0))); });
+  }
+
+  ELL_HD static El zero() { return each([](int) { return 0; }); }
+  ELL_HD static El one() { return each([](int l) { return l == 0 ? 1 : 0; }); }
+
+  // ---- conversions ----------------------------------------------------------------------------------
+  // the row <-> the one-lane 29-bit field (cold paths: canonical tests, stores)
+  ELL_HD static FpK256L::El gather(const El& a) {
+    FpK256L::El r;
+    ELL_UNROLL
+    for (int i = 0; i < 9; i++) r.v[i] = (u32)at(a, i);
+    return r;
+  }
+  ELL_HD static El scatter(const FpK256L::El& a) {
+    return each([&](int l) {
+      u32 v = 0;
+      ELL_UNROLL
+      for (int i = 0; i < 9; i++) v = l == i ? a.v[i] : v;
+      return (i32)v;
+    });
+  }
+  // wave-uniform plain words -> exact 29-bit digits (N form; the value may be >= p)
+  ELL_HD static El from_plain(const u32 (&a)[8]) { return scatter(FpK256L::from_plain(a)); }
+  // eight plain words IN MEMORY (an entry of the one-lane kernels' tables: fp.h FpK256 values,
+  // 32-bit words little-endian) -> the row: lane l reads the two words its 29 bits straddle
+  ELL_HD static El load_words(const u32* w) {
+    return each([&](int l) {
+      const int ll = l > 8 ? 8 : l;
+      const int bit = 29 * ll, k = bit >> 5, sh = bit & 31;
+      const u64 two = (u64)w[k] | ((u64)(k + 1 < 8 ? w[k + 1] : 0u) << 32);
+      return l > 8 ? 0 : (i32)((u32)(two >> sh) & (l == 8 ? 0xFFFFFFu : M));
+    });
+  }
+  // canonical residue in [0, p) as eight 32-bit words (wave-uniform)
+  ELL_HD static void to_plain(u32 (&out)[8], const El& a) { FpK256L::to_plain(out, gather(a)); }
+  ELL_HD static bool is_zero(const El& a) { return FpK256L::is_zero(gather(a)); }
+  ELL_HD static bool eq(const El& a, const El& b) { return FpK256L::eq(gather(a), gather(b)); }
+  ELL_HD static bool is_odd(const El& a) { return FpK256L::is_odd(gather(a)); }
+  // Exact zero test for a DIRECT mul / sqr / mul2 output, whose value V lies in (-2^205, 2^256 +
+  // 2^222): V = 0 (mod p) iff V is 0 or p, and V = limb 0 (mod 2^29) -- so unless limb 0's low 29
+  // bits are those of 0 or of p (one output in 2^28), V is not zero; the canonical test decides
+  // the rest.
+  ELL_HD static bool is_zero_w(const El& a) {
+    const u32 r0 = (u32)at(a, 0) & M;
+    if (ELL_UNLIKELY(r0 == 0u || r0 == M - 976u)) return is_zero(a);
+    return false;
+  }
+
+  // ---- lazy primitives (fpk256l.h's, lane by lane) ------------------------------------------------------
+  ELL_HD static El add_l(const El& a, const El& b) {
+    El r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) r.v[t] = a.v[t] + b.v[t];
+    return r;
+  }
+  // a - b + K p
+  template <int K>
+  ELL_HD static El sub_l(const El& a, const El& b) {
+    const El kp = c_kp();
+    El r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) r.v[t] = a.v[t] - b.v[t] + (u32)K * kp.v[t];
+    return r;
+  }
+  template <int K>
+  ELL_HD static El neg_l(const El& a) { return sub_l<K>(zero(), a); }
+  // c ? K p - a : a
+  template <int K>
+  ELL_HD static El cneg_l(const El& a, bool c) {
+    const El n = neg_l<K>(a);
+    El r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) r.v[t] = c ? n.v[t] : a.v[t];
+    return r;
+  }
+  // parallel carry pass + top fold (fpk256l.h norm): any lazy value with |limbs| < 2^31 -> N form
+  ELL_HD static El norm(const El& a) {
+    const El mk = c_mask(), kf = c_kf(), live = c_live();
+    El c;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) c.v[t] = (u32)(s(a.v[t]) >> 29);
+    const El cin = up<1>(c);
+    i32 r8;
+    const i32 f = FpK256L::top_fold(at(a, 8), r8);
+    El r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) {
+      u32 v = (a.v[t] & mk.v[t]) + cin.v[t] + (u32)f * kf.v[t];
+      if (lane_of(t) == 8) v -= (u32)f << 24;
+      r.v[t] = v & live.v[t];                          // (lane 9 received limb 8's carry: limb 8 keeps it)
+    }
+    return r;
+  }
+  // (a << K) in N form, a in N form (K <= 3)
+  template <int K>
+  ELL_HD static El shl_norm(const El& a) {
+    const El mk = c_mask(), kf = c_kf(), live = c_live();
+    El c;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) c.v[t] = (u32)(s(a.v[t]) >> (29 - K));
+    const El cin = up<1>(c);
+    i32 r8;
+    const i32 f = FpK256L::top_fold(at(a, 8) << K, r8);
+    El r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) {
+      u32 v = ((a.v[t] << K) & mk.v[t]) + cin.v[t] + (u32)f * kf.v[t];
+      if (lane_of(t) == 8) v -= (u32)f << 24;
+      r.v[t] = v & live.v[t];
+    }
+    return r;
+  }
+  // a / 2 mod p for a lazy value with |limbs| < 2^30 (fpk256l.h half_l)
+  ELL_HD static El half_l(const El& a) {
+    const El pv = c_p();
+    const u32 odd = 0u - ((u32)at(a, 0) & 1u);
+    El tt;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) tt.v[t] = a.v[t] + (odd & pv.v[t]);
+    const El nx = down<1>(tt);                         // (lane 8 sees lane 9: zero)
+    El r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) r.v[t] = (u32)(s(tt.v[t]) >> 1) + ((nx.v[t] & 1u) << 28);
+    return r;
+  }
+
+  // ---- products -------------------------------------------------------------------------------------------
+#if defined(ELL_BOUNDS_CHECK)
+  static void check(const El& a, const El& b, __int128 (&col)[17], const char* what) {
+    FpK256L::check_operands(gather(a), gather(b), col);
+    for (int t = 9; t < CL; t++)
+      if (a.v[t] != 0 || b.v[t] != 0) { fprintf(stderr, "fpk256c %s: dead lane %d is not zero\n", what, t); assert(0); }
+  }
+#endif
+  // columns 0..15 of a * b onto acc (one per lane), column 16 onto col16
+  ELL_HD static void columns(W64& acc, i64& col16, const El& a, const El& b) {
+    const i32 a0 = at(a, 0), a1 = at(a, 1), a2 = at(a, 2), a3 = at(a, 3), a4 = at(a, 4), a5 = at(a, 5),
+              a6 = at(a, 6), a7 = at(a, 7), a8 = at(a, 8);
+    const El b1 = up<1>(b), b2 = up<2>(b), b3 = up<3>(b), b4 = up<4>(b), b5 = up<5>(b), b6 = up<6>(b),
+             b7 = up<7>(b), b8 = up<8>(b);
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) {
+      i64 c = acc.w[t];
+      c += (i64)a0 * s(b.v[t]);
+      c += (i64)a1 * s(b1.v[t]);
+      c += (i64)a2 * s(b2.v[t]);
+      c += (i64)a3 * s(b3.v[t]);
+      c += (i64)a4 * s(b4.v[t]);
+      c += (i64)a5 * s(b5.v[t]);
+      c += (i64)a6 * s(b6.v[t]);
+      c += (i64)a7 * s(b7.v[t]);
+      c += (i64)a8 * s(b8.v[t]);
+      acc.w[t] = c;
+    }
+    col16 += (i64)a8 * (i64)at(b, 8);
+  }
+  // carries and the fold of columns 9.. -> N form
+  // (bounds, for column sums below 2^63: pass 1 leaves limbs below 2^29 + 2^35, pass 2 below 2^29 +
+  // 2^6; column 16 splits into a 29-bit digit and a part below 2^24; the folded limbs stay below
+  // 2^47, their carries below 2^18; limb 0 ends below 2^29 + 2^25, the others below 2^29 + 2^19,
+  // limb 8 in [0, 2^24) -- see DESIGN.md section 4)
+  ELL_HD static El tail(const W64& acc, i64 col16) {
+    const El r1 = c_r1(), rr = c_rr(), rrr = c_rrr(), kf = c_kf(), live = c_live();
+    // first carry pass, 64-bit carries
+    W64 c1;
+    El lo1;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) { c1.w[t] = acc.w[t] >> 29; lo1.v[t] = (u32)acc.w[t] & M; }
+    const W64 cin1 = up64<1>(c1);
+    W64 v1;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) v1.w[t] = (i64)lo1.v[t] + cin1.w[t];
+    col16 += at64(c1, 15);
+    // second pass: the carries fit a word
+    El c2, v2;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) c2.v[t] = (u32)(i32)(v1.w[t] >> 29);
+    const El cin2 = up<1>(c2);
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) v2.v[t] = ((u32)v1.w[t] & M) + cin2.v[t];
+    col16 += (i64)at(c2, 15);
+    const i32 p16 = (i32)((u32)col16 & M);
+    const i32 p17 = (i32)(col16 >> 29);
+    // fold: column 9 + j -> R0 at limb j, R1 at limb j + 1; column 17's R1 part is column 9 again
+    El h0 = down<9>(v2);                               // lane j <- column 9 + j   (j <= 6)
+    h0 = put<7>(h0, p16);
+    h0 = put<8>(h0, p17);
+    El h1 = down<8>(v2);                               // lane j <- column 8 + j   (lane 0: times 0 below)
+    h1 = put<8>(h1, p16);
+    W64 tt;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) {
+      i64 x = (i64)s(v2.v[t]);
+      x += (i64)s(h0.v[t]) * R0;
+      x += (i64)s(h1.v[t]) * s(r1.v[t]);
+      x += (i64)p17 * s(rrr.v[t]);
+      tt.w[t] = x;
+    }
+    // carry pass over the folded limbs
+    El c3, v3;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) c3.v[t] = (u32)(i32)(tt.w[t] >> 29);
+    const El cin3 = up<1>(c3);
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) v3.v[t] = ((u32)tt.w[t] & M) + cin3.v[t];
+    // limb 8: its carry is column 9 once more (small now), its bits above 2^24 fold through 2^256
+    const i32 c9 = at(c3, 8);
+    const i32 x8 = at(v3, 8);
+    const i32 hi = x8 >> 24;
+    El r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) {
+      u32 v = v3.v[t] + (u32)c9 * rr.v[t] + (u32)hi * kf.v[t];
+      if (lane_of(t) == 8) v -= (u32)hi << 24;
+      r.v[t] = v & live.v[t];
+    }
+    return r;
+  }
+  ELL_HD static W64 zero64() {
+    W64 z;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) z.w[t] = 0;
+    return z;
+  }
+  ELL_HD static El mul(const El& a, const El& b) {
+#if defined(ELL_BOUNDS_CHECK)
+    { __int128 col[17] = {0}; check(a, b, col, "mul"); FpK256L::check_cols(col); }
+#endif
+    W64 acc = zero64();
+    i64 col16 = 0;
+    columns(acc, col16, a, b);
+    return tail(acc, col16);
+  }
+  ELL_HD static El sqr(const El& a) { return mul(a, a); }
+  // a * b + e * f with one reduction
+  ELL_HD static El mul2(const El& a, const El& b, const El& e, const El& f) {
+#if defined(ELL_BOUNDS_CHECK)
+    { __int128 col[17] = {0}; check(a, b, col, "mul2"); check(e, f, col, "mul2"); FpK256L::check_cols(col); }
+#endif
+    W64 acc = zero64();
+    i64 col16 = 0;
+    columns(acc, col16, a, b);
+    columns(acc, col16, e, f);
+    return tail(acc, col16);
+  }
+
+  // ---- generic interface: N form in, N form out --------------------------------------------------------
+  ELL_HD static El add(const El& a, const El& b) { return norm(add_l(a, b)); }
+  ELL_HD static El sub(const El& a, const El& b) { return norm(sub_l<4>(a, b)); }
+  ELL_HD static El neg(const El& a) { return norm(neg_l<4>(a)); }
+  ELL_HD static El dbl(const El& a) { return shl_norm<1>(a); }
+  template <int K>
+  ELL_HD static El mul_pow2(const El& a) { return shl_norm<K>(a); }
+};
+
+// the curve as the group-law templates see it (short.h ShortOps, ladder.h Ladder)
+struct CvSecp256k1C {
+  typedef FpK256C F;
+  typedef FpMont<consts::SECP256K1_N> Fn;
+  typedef consts::SECP256K1_C C;
+  static constexpr int A_KIND = 0;
+  static constexpr bool ENDO = true;
+  static constexpr bool JTABLE = false;
+  static constexpr int ID = CURVE_SECP256K1;
+};
+
+}  // namespace ell

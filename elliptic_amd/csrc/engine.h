@@ -322,6 +322,41 @@ struct FnEcdsaJoin {
   }
 };
 
+// The parts of the parted verify / Point#mul on the LANES-PER-ITEM layer (coop.h, coop_work.h):
+// one unit = one part of one item on a wave of its own, its field elements spread over a 16-lane
+// row -- 2.2 x fewer instructions on the item's critical path.  Launched through BK::launch_coop
+// (k_run_coop: one unit per workgroup) for batches of at most Tuning::coop_grid items; the join
+// kernels are the one-lane ones.  secp256k1 only.
+struct FnEcdsaPartsC {
+  static constexpr const char* NAME = "ecdsa_parts_c";
+  typedef Work<CvSecp256k1> W;
+  static constexpr int DS_PER_LANE = CoopK256::E::NW;
+  static constexpr int ROW_BYTES = CoopK256::ROW_BYTES;
+  size_t n; const u32* u12; const typename W::A* comb; const typename W::VT* tbl; u32* jac;
+  ELL_HD void operator()(size_t unit, const DigitStore& ds, void* row_mem) const {
+    const int part = (int)(unit / n);
+    const size_t i = unit - (size_t)part * n;
+    u32* out = jac + (size_t)part * 3 * W::NS * n;
+    if (part == 2) CoopK256::ecdsa_fixed(i, n, u12, comb, out);
+    else CoopK256::ecdsa_half(i, n, part, u12, tbl, ds, out, row_mem);
+  }
+};
+struct FnMulPartsC {
+  static constexpr const char* NAME = "mul_parts_c";
+  typedef Work<CvSecp256k1> W;
+  static constexpr int DS_PER_LANE = CoopK256::E::NW;
+  static constexpr int ROW_BYTES = CoopK256::ROW_BYTES;
+  // kg != null: k*P + kg*G -- the units of a third range run the comb of kg
+  size_t n; const u8* k; const u8* xy; u32* jac; const u8* kg; const typename W::A* comb;
+  ELL_HD void operator()(size_t unit, const DigitStore& ds, void* row_mem) const {
+    const int part = (int)(unit / n);
+    const size_t i = unit - (size_t)part * n;
+    u32* out = jac + (size_t)part * 3 * W::NS * n;
+    if (part == 2) CoopK256::mul_fixed_part(i, n, kg, comb, out);
+    else CoopK256::mul_half(i, n, part, k, xy, ds, out, row_mem);
+  }
+};
+
 // Point#mul in the parted form (Work::mul_half / mul_join)
 template <class CV>
 struct FnMulParts {
@@ -739,6 +774,7 @@ class Engine {
     size_t small_grid;
     bool split_verify;
     size_t parted_grid;       // largest batch that takes the parted verify (three lanes per item)
+    size_t coop_grid;         // largest batch whose parts run on the lanes-per-item layer (a wave per part)
     int prep_k;
     int norm_k;
   };
@@ -751,6 +787,11 @@ class Engine {
     tune_.split_verify = !(e && e[0] == '0');
     e = getenv("ELLGPU_PARTED_GRID");
     tune_.parted_grid = e ? (size_t)strtoull(e, nullptr, 10) : tune_.wave_round / 2;
+    // ELLGPU_COOP_GRID  largest batch whose parts take a WAVE each (coop.h; 0 = never); default:
+    //                   the three parts of every item find a SIMD of their own, twice over -- above
+    //                   that the waves share SIMDs and the one-lane parts (64 items per wave) win
+    e = getenv("ELLGPU_COOP_GRID");
+    tune_.coop_grid = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)bk.compute_units() * 4 * 2 / 3;
     e = getenv("ELLGPU_PREP_K");
     tune_.prep_k = e ? atoi(e) : 0;
     e = getenv("ELLGPU_NORM_K");
@@ -759,6 +800,7 @@ class Engine {
   size_t small_grid() const { return tune_.small_grid; }
   bool split_small_verify() const { return tune_.split_verify; }
   size_t parted_grid() const { return tune_.parted_grid; }
+  size_t coop_grid() const { return CoopK256::AVAILABLE ? tune_.coop_grid : 0; }
   // ... and for the ecdsa_prep that runs BESIDE ecdsa_table (small-grid verify): the two kernels
   // share the SIMDs, so what counts is the work, not the latency of a lone chain -- the largest K
   // that still leaves half a wave round of threads (131 072 items: K = 4, 1.332 -> 1.318 ms per
@@ -2053,9 +2095,14 @@ int Engine<BK>::mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u
   bool launched = false;
   if constexpr (CV::ENDO && W::L <= 8) {
     if (parted) {                           // most SIMDs would idle: two lanes per item, then the join
+      if (n <= coop_grid()) {               // ... or two WAVES per item (coop.h)
+        FnMulPartsC fc{n, k, xy, jac, nullptr, nullptr};
+        bk.launch_coop(fc, 2 * n);
+      } else {
       const size_t npad = (n + 127) & ~(size_t)127;            // whole workgroups per half
       FnMulParts<CV> fp{n, npad, k, xy, tbl, jac, nullptr, nullptr};
       launch_fn(fp, npad + n);
+      }
       FnMulJoin<CV> fj{n, jac, false, xy, out_xy, out_inf, raw};   // ... to affine, and the domain test
       return launch_fn(fj, n);
     } else if (wide) {                      // at most three waves per SIMD: the register-rich tuning
@@ -2128,9 +2175,14 @@ int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* 
       u32* pj = (u32*)scratch(S_JAC, 3 * n * 3 * W::NS * 4);
       typename W::VT* pt = (typename W::VT*)scratch(S_TBL, 2 * n * (size_t)W::template stride<true>() * sizeof(typename W::VT));
       if (!pt || !pj) return fail(E_NOMEM, "scratch allocation failed");
+      if (n <= coop_grid()) {
+        FnMulPartsC fc{n, k2, xy2, pj, k1, (const typename W::A*)comb_[CV::ID]};
+        bk.launch_coop(fc, 3 * n);
+      } else {
       const size_t npad = (n + 127) & ~(size_t)127;
       FnMulParts<CV> fp{n, npad, k2, xy2, pt, pj, k1, (const typename W::A*)comb_[CV::ID]};
       launch_fn(fp, 2 * npad + n);
+      }
       FnMulJoin<CV> fj{n, pj, true, xy2, out_xy, out_inf, nullptr};
       return launch_fn(fj, n);
     }
@@ -2225,9 +2277,15 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
         // most SIMDs would idle beside this batch: three lanes per item (FnEcdsaParts), then the join
         u32* jac = (u32*)scratch(S_JAC, n * 3 * 3 * W::NS * 4);
         if (!jac) return fail(E_NOMEM, "scratch allocation failed");
+        if (n <= coop_grid()) {
+          // a handful of items: every part on a wave of its own, lanes-per-item arithmetic
+          FnEcdsaPartsC fc{n, u12, (const typename W::A*)comb_[CV::ID], tbl, jac};
+          bk.launch_coop(fc, 3 * n);
+        } else {
         const size_t npad = (n + 127) & ~(size_t)127;          // whole workgroups per part
         FnEcdsaParts<CV> fp{n, npad, u12, (const typename W::A*)comb_[CV::ID], tbl, jac};
         launch_fn(fp, 2 * npad + n);
+        }
         FnEcdsaJoin<CV> fj{n, valid, r, pub, tbl, jac, ok, st};
         return launch_fn(fj, n);
       }

@@ -56,6 +56,18 @@ __global__ void __launch_bounds__(BLOCK, MinWaves<Fn>::value) k_run(const Fn f, 
   f(tid, ds);
 }
 
+// The lanes-per-item layer (coop.h): ONE unit per workgroup of one wave; lanes 0..15 -- one DPP
+// row -- carry the unit's field elements, the other three rows sit the kernel out.  LDS: the digit
+// columns and Fn::ROW_BYTES of row memory (every lane's own window table).
+template <class Fn>
+__global__ void __launch_bounds__(64) k_run_coop(const Fn f, size_t units) {
+  __shared__ signed char lds_digits[(Fn::DS_PER_LANE > 0 ? Fn::DS_PER_LANE : 1) * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_rows[Fn::ROW_BYTES];
+  if (threadIdx.x >= 16u || (size_t)blockIdx.x >= units) return;
+  DigitStore ds{lds_digits + threadIdx.x, 64};
+  f((size_t)blockIdx.x, ds, (void*)lds_rows);
+}
+
 struct TimedLaunch {
   const char* name;
   hipEvent_t e0, e1;
@@ -243,6 +255,22 @@ struct HipBackend {
       note(hipEventRecord(t.e0, cur));
     }
     hipLaunchKernelGGL(k_run<Fn>, dim3(blocks), dim3(B), 0, cur, f, nthreads);
+    note(hipGetLastError());
+    if (timing && timed) {
+      note(hipEventRecord(t.e1, cur));
+      timed->push_back(t);
+    }
+  }
+  template <class Fn>
+  void launch_coop(const Fn& f, size_t units) {
+    if (units == 0) return;
+    TimedLaunch t{Fn::NAME, nullptr, nullptr};
+    if (timing && timed) {
+      note(hipEventCreate(&t.e0));
+      note(hipEventCreate(&t.e1));
+      note(hipEventRecord(t.e0, cur));
+    }
+    hipLaunchKernelGGL(k_run_coop<Fn>, dim3((unsigned)units), dim3(64), 0, cur, f, units);
     note(hipGetLastError());
     if (timing && timed) {
       note(hipEventRecord(t.e1, cur));

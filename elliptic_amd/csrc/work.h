@@ -1302,3 +1302,5 @@ struct Work {
 };
 
 }  // namespace ell
+
+#include "coop_work.h"

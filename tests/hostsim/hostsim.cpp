@@ -66,6 +66,28 @@ struct LoopBackend {
     }
     for (auto& th : pool) th.join();
   }
+  // the lanes-per-item layer: one unit per wave on the device, one call per unit here -- the
+  // host build of coop.h holds all sixteen lanes of the row in every field element
+  template <class Fn>
+  void launch_coop(const Fn& f, size_t units) {
+    hs_note_launch(Fn::NAME);
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nw = hw ? hw : 1;
+    if (units < 8) nw = 1;
+    if (nw > units) nw = units;
+    std::vector<std::thread> pool;
+    for (size_t w = 0; w < nw; w++) {
+      size_t lo = units * w / nw, hi = units * (w + 1) / nw;
+      auto body = [&f, lo, hi]() {
+        signed char digits[Fn::DS_PER_LANE > 0 ? Fn::DS_PER_LANE : 1];
+        alignas(16) unsigned char rows[Fn::ROW_BYTES];
+        DigitStore ds{digits, 1};
+        for (size_t t = lo; t < hi; t++) f(t, ds, (void*)rows);
+      };
+      if (nw == 1) body(); else pool.emplace_back(body);
+    }
+    for (auto& th : pool) th.join();
+  }
 };
 }  // namespace ell
 
@@ -95,7 +117,7 @@ static void field_op(int op, const u32* a, const u32* b, u32* r) {
     case 1: z = F::sub(x, y); break;
     case 2: z = F::mul(x, y); break;
     case 3: z = F::sqr(x); break;
-    case 4: z = F::inv(x); break;
+    case 4: if constexpr (!std::is_same<F, FpK256C>::value) z = F::inv(x); else z = x; break;
     case 5: z = F::neg(x); break;
     case 6: z = F::template mul_pow2<1>(x); break;
     case 7: z = F::template mul_pow2<2>(x); break;
@@ -109,9 +131,16 @@ static void field_op(int op, const u32* a, const u32* b, u32* r) {
       z = F::reduce_wide(w);
     }
   }
-  if constexpr (std::is_same<F, FpK256L>::value) {
+  if constexpr (std::is_same<F, FpK256L>::value || std::is_same<F, FpK256C>::value) {
     if (op == 11) z = F::mul2(x, y, F::template neg_l<4>(x), F::template sub_l<4>(x, y));
     if (op == 12) { typename F::El a = F::sqr(x); z = F::norm(F::add_l(a, F::half_l(a))); }
+  }
+  if constexpr (std::is_same<F, FpK256C>::value) {
+    // the row layer's own corners: the exact zero test of a product, a lazy difference through a
+    // product, an entry read from the one-lane tables' memory format
+    if (op == 14) { z = F::mul(x, y); z = F::is_zero_w(z) == F::is_zero(z) ? z : F::one(); }
+    if (op == 15) z = F::mul(F::template sub_l<4>(x, y), F::add_l(x, y));
+    if (op == 16) z = F::norm(F::template cneg_l<2>(F::load_words(ta), (tb[0] & 1u) != 0));
   }
   F::to_plain(tr, z);
   for (int i = 0; i < F::L; i++) r[i] = tr[i];
@@ -141,7 +170,7 @@ int hs_launches(const char* name) {
 // field: 0 k256, 1 25519, 2.. mont(curve p): 10+curve -> base field, 20+curve -> order field
 int hs_field_limbs(int field) {
   switch (field) {
-    case 0: case 1: case 2: return 8;
+    case 0: case 1: case 2: case 3: return 8;
     case 10: return 8; case 11: return 6; case 12: return 7; case 13: return 8; case 14: return 12; case 15: return 17;
     case 20: return 8; case 21: return 6; case 22: return 7; case 23: return 8; case 24: return 12; case 25: return 17;
     case 26: return 8;
@@ -152,6 +181,7 @@ int hs_field_op(int field, int op, const u32* a, const u32* b, u32* r) {
   switch (field) {
     case 0: field_op<FpK256>(op, a, b, r); break;
     case 2: field_op<FpK256L>(op, a, b, r); break;
+    case 3: field_op<FpK256C>(op, a, b, r); break;
     case 1:
       if (op == 10) {                      // mul_u32 by the one-limb constant b[0]
         u32 ta[8];

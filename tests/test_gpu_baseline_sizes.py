@@ -7,6 +7,7 @@ whole batch included so that every region of the launch is sampled, and size-ind
 properties over ALL items where the domain offers one.  Bounded: the oracle legs are ~1-3 s each
 on the GPU box's 16 usable threads."""
 import hashlib
+import json
 import os
 import sys
 
@@ -237,6 +238,63 @@ def test_device_group_on_gpu(ctx):
         fx1, fi1 = ctx.mul_fixed("secp256k1", s)
         assert np.array_equal(fx, fx1) and np.array_equal(fi, fi1)
         g.close()
+
+
+def test_device_group_over_distinct_gpus(ctx):
+    """A group over DISTINCT ordinals -- every GPU of the box, at least two -- on an uneven batch:
+    verify / P*k / G*k / k1*G + k2*P bytes equal the single-context ones, each member built its own
+    tables on its own device, and the N-API engine does the same through `new Engine({devices})`.
+    Skipped on a one-GPU box (the 8-GPU node of the round-end scaling run executes it)."""
+    import shutil
+    import subprocess
+    import bench
+    from elliptic_amd import _lib
+    ndev = _lib.load().ellgpu_device_count()
+    if ndev < 2:
+        pytest.skip("one GPU on this box (ellgpu_device_count() = %d)" % ndev)
+    devs = list(range(min(ndev, 8)))
+    n = 300001 + len(devs)                               # never a multiple of the group size
+    h, r, s, pub, expect = bench.cached_signatures(ctx, 1 << 20, "ellgpu-bench-v1:3:rank0")
+    h, r, s, pub, expect = h[:n], r[:n], s[:n], pub[:n], expect[:n]
+    pub = pub.copy()
+    pub[7::1001, 63] ^= 1                                # keys off the curve: status 2 beside a verdict of 0
+    g = elliptic_amd.Context(devices=devs)
+    assert g.group_size() == len(devs)
+    ok1, st1 = ctx.ecdsa_verify("secp256k1", h, r, s, pub, status=True)
+    ok, st = g.ecdsa_verify("secp256k1", h, r, s, pub, status=True)
+    assert np.array_equal(ok, ok1) and np.array_equal(st, st1) and (st == 2).sum() > 200
+    on = st1 == 0
+    assert np.array_equal(ok[on], expect[on])
+    for got, want in ((g.mul_var("secp256k1", r, pub), ctx.mul_var("secp256k1", r, pub)),
+                      (g.mul_fixed("secp256k1", s), ctx.mul_fixed("secp256k1", s)),
+                      (g.mul_add2("secp256k1", s, None, r, pub), ctx.mul_add2("secp256k1", s, None, r, pub))):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # a small batch too: fewer items than members' waves, and fewer items than members
+    for m in (1, len(devs) - 1, len(devs) + 1, 1000):
+        assert np.array_equal(g.ecdsa_verify("secp256k1", h[:m], r[:m], s[:m], pub[:m]), ok1[:m]), m
+    g.close()
+    # every member alone, on its own ordinal, gives the same bytes (replicated tables)
+    for d in devs[1:]:
+        c = elliptic_amd.Context(d)
+        assert np.array_equal(c.ecdsa_verify("secp256k1", h[:4099], r[:4099], s[:4099], pub[:4099]), ok1[:4099]), d
+        c.close()
+    if shutil.which("node"):
+        import os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        js = ("var e=new (require('%s/elliptic_amd/js').Engine)({devices:%s});var c=require('crypto');"
+              "var k=c.createHash('sha512').update('grp').digest().slice(0,32);var n=1003;"
+              "var ks=Buffer.concat(Array.from({length:n},function(_,i){var b=Buffer.from(k);b.writeUInt32BE(i+1,28);return b;}));"
+              "var one=new (require('%s/elliptic_amd/js').Engine)({device:0});"
+              "var a=e.mulBatch('secp256k1',ks,null),b=one.mulBatch('secp256k1',ks,null);"
+              "var p=e.mulBatch('secp256k1',ks,a.xy),q=one.mulBatch('secp256k1',ks,b.xy);"
+              "console.log(JSON.stringify({fixed:a.xy.equals(b.xy)&&a.inf.equals(b.inf),vari:p.xy.equals(q.xy)&&p.inf.equals(q.inf),n:n}));"
+              % (root, json.dumps(devs), root))
+        from elliptic_amd.js import build as jb
+        if jb.build() is not None:
+            pr = subprocess.run(["node", "-e", js], capture_output=True, text=True, timeout=600)
+            assert pr.returncode == 0, pr.stderr[-2000:]
+            res = json.loads(pr.stdout.strip().splitlines()[-1])
+            assert res["fixed"] and res["vari"], res
 
 
 def test_user_defined_curve_large_batch(ctx):

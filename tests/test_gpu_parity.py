@@ -411,14 +411,27 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
     FnEcdsaParts); ELLGPU_PARTED_GRID=0 keeps them on the one-lane ladder.  Same verdicts from
     both, equal to the construction's mask and (sampled) to the C port of the reference's
     algorithm; off-curve keys, r / s out of range and the group law's exceptional cases included
-    (every wave of a part region full, half full, and a lone lane)."""
+    (every wave of a part region full, half full, and a lone lane).
+    The parts run in two forms: one item per lane (work.h) and, for batches of at most
+    ELLGPU_COOP_GRID items (default: two waves per SIMD's worth), one item per WAVE with its field
+    elements spread over a 16-lane row (coop.h: DPP / readlane arithmetic, 2.2 x fewer instructions
+    on the critical path).  Every form must give the same bytes."""
     from oracle import c_oracle
     monkeypatch.setenv("ELLGPU_PARTED_GRID", "0")
-    c0 = elliptic_amd.Context(0)
+    c0 = elliptic_amd.Context(0)                       # the whole ladder on one lane
     monkeypatch.setenv("ELLGPU_PARTED_GRID", str(1 << 30))
-    c1 = elliptic_amd.Context(0)
+    monkeypatch.setenv("ELLGPU_COOP_GRID", "0")
+    c1 = elliptic_amd.Context(0)                       # parts, one item per lane
+    monkeypatch.setenv("ELLGPU_COOP_GRID", str(1 << 30))
+    c2 = elliptic_amd.Context(0)                       # parts, one item per wave (the row layer), whatever the batch
     monkeypatch.delenv("ELLGPU_PARTED_GRID")
-    cd = elliptic_amd.Context(0)                       # the default threshold
+    monkeypatch.delenv("ELLGPU_COOP_GRID")
+    cd = elliptic_amd.Context(0)                       # the default thresholds
+    coop_default = 256 * 4 * 2 // 3                    # engine.h Tuning::coop_grid on 256 CUs
+
+    def forms(m):
+        """(context, kernel of the parts or None) for a batch of m items"""
+        return ((c0, None), (c1, ""), (c2, "_c"), (cd, "_c" if m <= coop_default else ""))
     n = 32768
     h, r, s, pub, expect = _make_sigs(c0, n, "gpu-test-parted")
     pub = pub.copy()
@@ -431,9 +444,11 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
     r = r.copy()
     r[11] = 0                                          # r = 0: rejected before the key is looked at
     want[11] = 0
-    for m in (1, 2, 63, 64, 65, 127, 128, 129, 1000, 4096, 21845, 32768):
+    for m in (1, 2, 3, 63, 64, 65, 127, 128, 129, 682, 683, 1000, 4096, 21845, 32768):
         sl = (h[:m], r[:m], s[:m], pub[:m])
-        for c, parts in ((c0, False), (c1, True), (cd, True)):
+        for c, parts in forms(m):
+            if c is c2 and m > 4096:
+                continue                               # (a wave per part: 3 m workgroups -- small batches are its job)
             c.set_timing(True)
             got, gst = c.ecdsa_verify("secp256k1", *sl, status=True)
             tm = c.get_timing()
@@ -441,7 +456,9 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
             # (`want` marks off-curve keys with 2: verdict 0 and status 2 at the C ABI)
             assert got.max(initial=0) <= 1 and not got[gst == 2].any(), (m, parts)
             assert np.array_equal(np.where(gst == 2, 2, got), want[:m]), (m, parts)
-            assert ("ecdsa_parts" in tm and "ecdsa_join" in tm) == parts, (m, parts, sorted(tm))
+            assert ("ecdsa_join" in tm) == (parts is not None), (m, parts, sorted(tm))
+            for suffix in ("", "_c"):
+                assert ("ecdsa_parts" + suffix in tm) == (parts == suffix), (m, parts, sorted(tm))
     # above the default threshold: the one-lane small-grid ladder
     h2, r2, s2, pub2, expect2 = _make_sigs(c0, 40000, "gpu-test-parted-2")
     cd.set_timing(True)
@@ -459,14 +476,18 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
     ks = r.copy()
     for i, kv in enumerate((0, nn, nn + 1, (1 << 256) - 1, 1, 2, nn - 1)):
         ks[20 + i] = np.frombuffer(kv.to_bytes(32, "big"), np.uint8)
-    for m in (1, 64, 65, 129, 4096, 32768):
+    for m in (1, 27, 64, 65, 129, 683, 4096, 32768):
         outs = []
-        for c, parts in ((c0, False), (c1, True), (cd, True)):
+        for c, parts in forms(m):
+            if c is c2 and m > 4096:
+                continue
             c.set_timing(True)
             outs.append(c.mul_var("secp256k1", ks[:m], pub[:m]))
             tm = c.get_timing()
             c.set_timing(False)
-            assert ("mul_parts" in tm and "mul_join" in tm) == parts, (m, parts, sorted(tm))
+            assert ("mul_join" in tm) == (parts is not None), (m, parts, sorted(tm))
+            for suffix in ("", "_c"):
+                assert ("mul_parts" + suffix in tm) == (parts == suffix), (m, parts, sorted(tm))
         for xy, inf in outs[1:]:
             assert np.array_equal(xy, outs[0][0]) and np.array_equal(inf, outs[0][1]), m
     xy, inf = outs[1]
@@ -479,24 +500,27 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
     # ladder with the comb behind it
     for m in (1, 65, 4096):
         outs = []
-        for c, parts in ((c0, False), (c1, True)):
+        for c, parts in ((c0, None), (c1, ""), (c2, "_c")):
             c.set_timing(True)
             outs.append(c.mul_add2("secp256k1", s[:m], None, ks[:m], pub[:m]))
             tm = c.get_timing()
             c.set_timing(False)
-            assert ("mul_parts" in tm) == parts and ("mul_add_g" in tm) != parts, (m, parts, sorted(tm))
-        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), m
+            assert ("mul_add_g" in tm) == (parts is None), (m, parts, sorted(tm))
+            for suffix in ("", "_c"):
+                assert ("mul_parts" + suffix in tm) == (parts == suffix), (m, parts, sorted(tm))
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]), m
     j = np.arange(0, m, 37)
     j = j[want[j] != 2]
     wxy, winf = c_oracle.mul_add("secp256k1", s[j], None, ks[j], pub[j])
     assert np.array_equal(outs[1][0][j], wxy) and np.array_equal(outs[1][1][j], winf)
-    for c in (c0, c1):
+    for c in (c0, c1, c2):
         assert PC.check_mul_golden(c, "secp256k1") > 50
         assert PC.check_recover_golden(c, "secp256k1") >= 30
         assert PC.check_exceptional_keys(c, "secp256k1") > 400
         assert PC.check_verify_golden(c, "secp256k1") > 15
         assert PC.check_offcurve_golden(c, "secp256k1") >= 29
-    for c in (c0, c1, cd):
+    for c in (c0, c1, c2, cd):
         c.close()
 
 

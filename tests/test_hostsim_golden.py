@@ -36,6 +36,7 @@ def ctx(hs):
 
 FIELDS = {
     0: int(O.get_curve("secp256k1", False).p), 1: 2 ** 255 - 19, 2: int(O.get_curve("secp256k1", False).p),
+    3: int(O.get_curve("secp256k1", False).p),        # the lanes-per-item field (csrc/coop.h), host simulation of the row
     10: O.get_curve("secp256k1", False).p, 11: O.get_curve("p192", False).p,
     12: O.get_curve("p224", False).p, 13: O.get_curve("p256", False).p,
     14: O.get_curve("p384", False).p, 15: O.get_curve("p521", False).p,
@@ -79,7 +80,7 @@ def test_field_ops(hs, field):
                 assert hs.hs_field_op(field, op, _limbs(a, L), _limbs(b, L), r) == 0
                 assert _val(r) == fn(a % p, b % p), (field, op, hex(a), hex(b))
     for a in vals[:20]:
-        if a % p == 0:
+        if a % p == 0 or field == 3:                  # (the row layer has no inversion: the join kernels invert)
             continue
         r = (ctypes.c_uint32 * L)()
         hs.hs_field_op(field, 4, _limbs(a, L), _limbs(0, L), r)
@@ -99,6 +100,8 @@ def _inv_values(p, rnd, count):
 def test_field_inversion(hs, field):
     """division-step inversion (csrc/safegcd.h) in every field: edge values, powers of two,
     operands with long zero runs, random; inv(0) = 0 as bn.js `invm` callers expect"""
+    if field == 3:
+        pytest.skip("the lanes-per-item field has no inversion")
     p = FIELDS[field]
     L = hs.hs_field_limbs(field)
     rnd = random.Random(31337 + field)
@@ -296,25 +299,41 @@ def test_verify_golden_secp256k1_both_tunings(hs, monkeypatch):
     assert PC.check_offcurve_golden(c, "secp256k1") >= 29
     c.close()
     # ... and batches far below one wave per SIMD take the PARTED form by default (three lanes per
-    # item: Work::ecdsa_half x 2, ecdsa_fixed, ecdsa_join); ELLGPU_PARTED_GRID=0 keeps them on the ladder
-    for grid, parts in (("0", False), (str(1 << 30), True)):
-        c = _fresh_ctx(hs, monkeypatch, ELLGPU_PARTED_GRID=grid)
+    # item: Work::ecdsa_half x 2, ecdsa_fixed, ecdsa_join); ELLGPU_PARTED_GRID=0 keeps them on the
+    # ladder.  The parts themselves have two forms: one item per lane (work.h) and, for batches of
+    # at most ELLGPU_COOP_GRID items, one item per WAVE with its field elements spread over a
+    # 16-lane row (coop.h / coop_work.h; here the host simulation of the row) -- same join kernels.
+    for grid, coop, parts in (("0", "0", None), (str(1 << 30), "0", b"ecdsa_parts"), (str(1 << 30), str(1 << 30), b"ecdsa_parts_c")):
+        c = _fresh_ctx(hs, monkeypatch, ELLGPU_PARTED_GRID=grid, ELLGPU_COOP_GRID=coop)
+        mparts = {None: None, b"ecdsa_parts": b"mul_parts", b"ecdsa_parts_c": b"mul_parts_c"}[parts]
         hs.hs_launches_reset()
         assert PC.check_verify_golden(c, "secp256k1") > 15
         assert PC.check_offcurve_golden(c, "secp256k1") >= 29
         assert PC.check_exceptional_keys(c, "secp256k1") > 400
-        assert (hs.hs_launches(b"ecdsa_parts") > 0) == parts and (hs.hs_launches(b"ecdsa_join") > 0) == parts
-        assert (hs.hs_launches(b"ecdsa_main") > 0) != parts
+        for name in (b"ecdsa_parts", b"ecdsa_parts_c"):
+            assert (hs.hs_launches(name) > 0) == (name == parts), name
+        assert (hs.hs_launches(b"ecdsa_join") > 0) == (parts is not None)
+        assert (hs.hs_launches(b"ecdsa_main") > 0) == (parts is None)
         # Point#mul likewise (Work::mul_half x 2, mul_join); k1 G + k2 P stays on its one ladder
         hs.hs_launches_reset()
         assert PC.check_mul_golden(c, "secp256k1") > 50
-        assert (hs.hs_launches(b"mul_parts") > 0) == parts and (hs.hs_launches(b"mul_join") > 0) == parts
+        for name in (b"mul_parts", b"mul_parts_c"):
+            assert (hs.hs_launches(name) > 0) == (name == mparts), name
+        assert (hs.hs_launches(b"mul_join") > 0) == (parts is not None)
         # k1 G + k2 P (Point#mulAdd with G, EC#recoverPubKey): the halves of k2 and the comb of k1
         hs.hs_launches_reset()
         assert PC.check_exceptional_keys(c, "secp256k1") > 400
         assert PC.check_recover_golden(c, "secp256k1") >= 30
-        assert (hs.hs_launches(b"mul_add_g") > 0) != parts and (hs.hs_launches(b"mul_parts") > 0) == parts
+        assert (hs.hs_launches(b"mul_add_g") > 0) == (parts is None)
+        for name in (b"mul_parts", b"mul_parts_c"):
+            assert (hs.hs_launches(name) > 0) == (name == mparts), name
         c.close()
+    # the default context routes the lone call to the row layer
+    c = elliptic_amd.Context(0, lib_path=hs)
+    hs.hs_launches_reset()
+    assert PC.check_verify_golden(c, "secp256k1") > 15
+    assert hs.hs_launches(b"ecdsa_parts_c") > 0 and hs.hs_launches(b"ecdsa_parts") == 0
+    c.close()
 
 
 @pytest.mark.parametrize("curve", ["secp256k1", "p192", "p256", "p384", "p521", "ed25519"])
@@ -658,11 +677,13 @@ def test_secp256k1_on_the_lazy_field():
     c.close()
 
 
-def test_lazy_field_two_product_and_half(hs):
-    """FpK256L's lazy forms (field id 2): x*y + (4p - x)*(x - y + 4p) through mul2 and 3/2 x^2
-    through half_l, edge and random operands, incl. p - 1 (whose products fold to a slightly
-    NEGATIVE value: the canonicalisation must cope)"""
-    p = FIELDS[2]
+@pytest.mark.parametrize("field", [2, 3])
+def test_lazy_field_two_product_and_half(hs, field):
+    """FpK256L's lazy forms (field id 2) and the same algebra across a 16-lane row (FpK256C, field
+    id 3): x*y + (4p - x)*(x - y + 4p) through mul2 and 3/2 x^2 through half_l, edge and random
+    operands, incl. p - 1 (whose products fold to a slightly NEGATIVE value: the canonicalisation
+    must cope)"""
+    p = FIELDS[field]
     rnd = random.Random(77)
     edge = [0, 1, 2, p - 1, p - 2, p, p + 1, 2 ** 256 - 1, 2 ** 255, 2 ** 232, 2 ** 232 - 1, 2 ** 29, 2 ** 29 - 1, (p + 1) // 2]
     vals = [(x, y) for x in edge for y in edge] + [(rnd.getrandbits(256), rnd.getrandbits(256)) for _ in range(400)]
@@ -670,7 +691,27 @@ def test_lazy_field_two_product_and_half(hs):
     for x, y in vals:
         for op, want in ((11, (2 * x * y - x * x) % p), (12, 3 * x * x * inv2 % p), (2, x * y % p), (1, (x - y) % p)):
             r = (ctypes.c_uint32 * 8)()
-            assert hs.hs_field_op(2, op, _limbs(x, 8), _limbs(y, 8), r) == 0
+            assert hs.hs_field_op(field, op, _limbs(x, 8), _limbs(y, 8), r) == 0
+            assert _val(r) == want, (op, hex(x), hex(y))
+
+
+def test_row_field_corners(hs):
+    """FpK256C (csrc/coop.h) on the host simulation of its 16-lane row: the exact zero test of a
+    product (factors whose product is 0 or p exactly, and near misses), a lazy difference times a
+    lazy sum, entries read from the one-lane tables' memory format with and without the lazy
+    negation -- against Python integers"""
+    p = FIELDS[3]
+    rnd = random.Random(1234)
+    import math
+    rt = math.isqrt(p)
+    pairs = [(0, 5), (5, 0), (1, p), (p, 1), (p, p), (2, (p + 1) // 2), (p - 1, p - 1), (1, 0), (rt, rt), (rt + 1, rt + 1),
+             (1 << 29, 1 << 227), (1 << 128, 1 << 128), ((1 << 256) - 1, (1 << 256) - 1), (977, 1 << 29), (p - 977, 3)]
+    # products that are small multiples of 2^29 (limb 0 of the unreduced product is zero)
+    pairs += [(1 << 29, k) for k in (1, 2, 3, 1 << 29, (1 << 58) + 1)] + [(rnd.getrandbits(256), rnd.getrandbits(256)) for _ in range(300)]
+    for x, y in pairs:
+        for op, want in ((14, x * y % p), (15, (x - y) * (x + y) % p), (16, (-x if y & 1 else x) % p)):
+            r = (ctypes.c_uint32 * 8)()
+            assert hs.hs_field_op(3, op, _limbs(x, 8), _limbs(y, 8), r) == 0
             assert _val(r) == want, (op, hex(x), hex(y))
 
 

@@ -74,6 +74,15 @@ def calls(txt):
     return out
 
 
+def totals(txt):
+    """{kernel: total microseconds over all its dispatches} from the kernel-stats table of a summary"""
+    out = {}
+    sec = txt.split("## durations per dispatch")[0]
+    for m in re.finditer(r"^(\S.*?)\s{2,}(\d+)\s+(\d+)\s+(\d+)\s+([\d.]+)\s*$", sec, re.M):
+        out[m.group(1).strip()] = int(m.group(3))
+    return out
+
+
 def grids(txt):
     """{kernel: total work-items over all dispatches} from the dispatch table (first grid only per kernel)"""
     out = {}
@@ -89,6 +98,7 @@ def distil(src, digest):
     sqa, sqb, fw, gc = read("rocprof_sqa.txt"), read("rocprof_sqb.txt"), read("rocprof_fw.txt"), read("rocprof_gc.txt")
     ca, cb, cf = counters(sqa), counters(sqb), counters(fw)
     na, nb = calls(sqa), calls(sqb)
+    ta = totals(sqa)
     out = {"source_digest": digest, "how": "rocprofv3 --kernel-trace --pmc (separate passes) over "
            "`python bench.py --steps 2 --warmup 1 --no-cpu`; tools/refresh_profiles.sh",
            "kernels": {}}
@@ -132,6 +142,11 @@ def distil(src, digest):
                 # with the counters summed over the 32 SEs' SQs and GRBM over 8 XCDs as this summary has them:
                 "valu_busy_pct_gfx94x_formula": (100.0 * act * 4 / 1024 / (gui / 8.0)) if gui else None,
                 "active_inst_valu_over_busy_cycles": act / busy if busy else None,
+                # effective clock of the kernel IN THE PROFILED PASS (MI355X_MICROARCH.md, DVFS note):
+                # GRBM_GUI_ACTIVE (per XCD: the sum over the 8 XCDs / 8) / the kernel's wall time in the
+                # same pass (the kernel trace of the pass that collected the counter)
+                "kernel_total_us_in_pass": ta.get(kname),
+                "clock_ghz_effective": (gui / 8.0 / ta[kname] / 1e3) if gui and ta.get(kname) else None,
             }
         if "FETCH_SIZE" in f and "WRITE_SIZE" in f:
             lanes = waves * 64.0

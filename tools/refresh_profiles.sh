@@ -14,11 +14,11 @@ ROUND="${ELL_ROUND:-r04}"
 ( time timeout 900 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
 tail -3 $O/pytest_gpu.log
 # the workload of the PMC passes: one pass of every benchmarked kernel (headline + configs), 2 timed steps
-PROF="python bench.py --steps 2 --warmup 1 --no-cpu"
+PROF="python bench.py --steps 2 --warmup 1 --no-cpu --sustain 0"
 # kernel durations: the kernels by themselves (--in-flight 1: what roofline.kernel_ms is) and as the
 # default command runs them (two passes in flight: spans of overlapping kernels, roofline.timed_region)
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o stats -- python bench.py --steps 30 --warmup 5 --no-cpu --no-configs --in-flight 1 > $O/bench_under_rocprof.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats2 -o stats2 -- python bench.py --steps 30 --warmup 5 --no-cpu --no-configs > $O/bench_under_rocprof_two_in_flight.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o stats -- python bench.py --steps 30 --warmup 5 --no-cpu --no-configs --in-flight 1 --sustain 0 > $O/bench_under_rocprof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats2 -o stats2 -- python bench.py --steps 30 --warmup 5 --no-cpu --no-configs --sustain 0 > $O/bench_under_rocprof_two_in_flight.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $O/prof_sqa -o sqa -- $PROF > $O/pmc_sqa.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_ANY -d $O/prof_sqb -o sqb -- $PROF > $O/pmc_sqb.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fwa -o fwa -- $PROF > $O/pmc_fwa.log 2>&1
@@ -54,9 +54,9 @@ timeout 300 python tools/parted_ab.py --once --reps=100 > $O/parted_verify_ab.js
 # the N > 1 flow on the one-GPU box, started as PLAIN python (bench.py launches itself under
 # torch.distributed.run): weak loop + configs[2] as written (`strong`) + the collective's census in
 # one line; two ranks, then eight ranks, all on device 0 over gloo (flow tests, not scaling points)
-( timeout 600 python3 bench.py --gpus 2 --steps 10 --warmup 2 --dist-backend gloo --force-device 0 ) > $O/bench_selflaunch_two_ranks_one_gpu.jsonl 2> $O/bench_selflaunch2.err
-( timeout 900 python3 bench.py --gpus 8 --steps 6 --warmup 2 --dist-backend gloo --force-device 0 --batch 131072 ) > $O/bench_selflaunch_eight_ranks_one_gpu.jsonl 2> $O/bench_selflaunch8.err
-( timeout 300 python bench.py --rccl-selftest --steps 5 --warmup 2 --no-cpu --no-configs --no-live-counters ) > $O/rccl_selftest.jsonl 2> $O/rccl_selftest.err
+( timeout 600 python3 bench.py --gpus 2 --steps 10 --warmup 2 --dist-backend gloo --force-device 0 --sustain 1 ) > $O/bench_selflaunch_two_ranks_one_gpu.jsonl 2> $O/bench_selflaunch2.err
+( timeout 900 python3 bench.py --gpus 8 --steps 6 --warmup 2 --dist-backend gloo --force-device 0 --batch 131072 --sustain 1 ) > $O/bench_selflaunch_eight_ranks_one_gpu.jsonl 2> $O/bench_selflaunch8.err
+( timeout 300 python bench.py --rccl-selftest --steps 5 --warmup 2 --no-cpu --no-configs --no-live-counters --sustain 0 ) > $O/rccl_selftest.jsonl 2> $O/rccl_selftest.err
 if [ "$MODE" != "quick" ]; then
   timeout 300 python tools/gpu_probe.py > $O/valu_probe.log 2>&1
   timeout 200 tools/microbench/_build/valu_patterns > $O/valu_patterns.log 2>&1
