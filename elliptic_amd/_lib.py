@@ -32,6 +32,7 @@ _SIGS = {
     "ellgpu_ctx_destroy": (None, [ctypes.c_void_p]),
     "ellgpu_ctx_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
     "ellgpu_ctx_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]),
+    "ellgpu_ctx_comb_bits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "ellgpu_mul_fixed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p]),
     "ellgpu_mul_var": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p]),
     "ellgpu_mul_add2": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p]),

@@ -179,6 +179,13 @@ int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n) {
   return finish(ctx, ctx->eng->reserve(curve, n));
 }
 
+int ellgpu_ctx_comb_bits(ellgpu_ctx* ctx, int curve) {
+  if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  if (curve < 0 || curve >= ell::CURVE_COUNT) return set_err(ELLGPU_E_ARG, "unknown curve id");
+  ELL_LOCK(ctx);
+  return ctx->eng->comb_bits(curve);
+}
+
 static int define_custom(ellgpu_ctx* ctx, int edwards, const uint8_t* p, const uint8_t* a, const uint8_t* b,
                          int* out_curve) {
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");

@@ -121,11 +121,12 @@ struct CoopK256 {
 
   // ---- fixed base: k*G over the one-lane comb table (ladder.h comb_add, entries through load_entry) ----
   ELL_HD static J comb_mul(const u32 (&k)[8], const W1::A* comb) {
-    constexpr int CB = W1::COMB_BITS, W = W1::COMB_W;
     constexpr bool SIGNED = W1::COMB_SIGNED;
-    constexpr u32 MASK = (1u << CB) - 1u;
-    constexpr u32 HALF = 1u << (CB - 1);
-    constexpr u32 PER = SIGNED ? HALF : MASK;
+    const int CB = SIGNED ? comb_bits_of(comb) : W1::COMB_BITS;        // (the table carries its window width)
+    const int W = SIGNED ? comb_windows(256, CB) : W1::COMB_W;
+    const u32 MASK = (1u << CB) - 1u;
+    const u32 HALF = 1u << (CB - 1);
+    const u32 PER = SIGNED ? HALF : MASK;
     u32 kk[8];
     bn_copy<8>(kk, k);
     u32 carry = 0;

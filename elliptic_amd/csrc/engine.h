@@ -140,13 +140,14 @@ struct FnCombGen {
   static constexpr const char* NAME = "comb_gen";
   typedef Work<CV> W;
   static constexpr int DS_PER_LANE = 0;
-  size_t n; size_t first; u8* k; u8* xy;
+  size_t n; size_t first; u8* k; u8* xy; int cb;       // cb: window bits of a SIGNED comb (else W::COMB_BITS)
   ELL_HD void operator()(size_t i, const DigitStore&) const {
     if (i >= n) return;
     const size_t idx = first + i;
-    const int w = (int)(idx / W::COMB_DIG);
-    const u32 d = (u32)(idx % W::COMB_DIG) + 1u;
-    const int sh = w * W::COMB_BITS;
+    const size_t per = W::COMB_SIGNED ? ((size_t)1 << (cb - 1)) : (size_t)W::COMB_DIG;
+    const int w = (int)(idx / per);
+    const u32 d = (u32)(idx % per) + 1u;
+    const int sh = w * (W::COMB_SIGNED ? cb : W::COMB_BITS);
     // (d << sh) mod n: the value can exceed the scalar's byte length in the top window (the
     // signed recoding's carry window of a narrow comb: 2^256 * G), so it goes through the order
     // field like any over-long byte string (Work::bytes_mod_n)
@@ -775,6 +776,7 @@ class Engine {
     bool split_verify;
     size_t parted_grid;       // largest batch that takes the parted verify (three lanes per item)
     size_t coop_grid;         // largest batch whose parts run on the lanes-per-item layer (a wave per part)
+    size_t comb_max_bytes;    // ELLGPU_COMB_MAX_BYTES: fixed-base tables above this are treated as unallocatable (0 = no limit)
     int prep_k;
     int norm_k;
   };
@@ -792,6 +794,8 @@ class Engine {
     //                   that the waves share SIMDs and the one-lane parts (64 items per wave) win
     e = getenv("ELLGPU_COOP_GRID");
     tune_.coop_grid = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)bk.compute_units() * 4 * 2 / 3;
+    e = getenv("ELLGPU_COMB_MAX_BYTES");
+    tune_.comb_max_bytes = e ? (size_t)strtoull(e, nullptr, 10) : 0;
     e = getenv("ELLGPU_PREP_K");
     tune_.prep_k = e ? atoi(e) : 0;
     e = getenv("ELLGPU_NORM_K");
@@ -801,6 +805,11 @@ class Engine {
   bool split_small_verify() const { return tune_.split_verify; }
   size_t parted_grid() const { return tune_.parted_grid; }
   size_t coop_grid() const { return CoopK256::AVAILABLE ? tune_.coop_grid : 0; }
+  // window width of the curve's fixed-base table in use (0 = not built; ellgpu_ctx_comb_bits)
+  int comb_bits(int curve) const {
+    if (curve < 0 || curve >= CURVE_COUNT || !comb_[curve]) return 0;
+    return comb_bits_[curve] ? comb_bits_[curve] : 8;
+  }
   // ... and for the ecdsa_prep that runs BESIDE ecdsa_table (small-grid verify): the two kernels
   // share the SIMDs, so what counts is the work, not the latency of a lone chain -- the largest K
   // that still leaves half a wave round of threads (131 072 items: K = 4, 1.332 -> 1.318 ms per
@@ -828,12 +837,12 @@ class Engine {
   static constexpr size_t CHUNK = 1u << 21;   // max items per launch (bounds the scratch arena)
 
   explicit Engine(const BK& b) : bk(b) {
-    for (int i = 0; i < CURVE_COUNT; i++) comb_[i] = nullptr;
+    for (int i = 0; i < CURVE_COUNT; i++) { comb_[i] = nullptr; comb_base_[i] = nullptr; comb_bits_[i] = 0; }
     init_tuning();
   }
   ~Engine() {
     for (int i = 0; i < CURVE_COUNT; i++)
-      if (comb_[i]) bk.free_(comb_[i]);
+      if (comb_[i]) bk.free_(comb_base_[i] ? comb_base_[i] : comb_[i]);
     for (auto& a : scratch_)
       for (auto& s : a)
         if (s.p) bk.free_(s.p);
@@ -2015,7 +2024,9 @@ class Engine {
   }
 
  private:
-  void* comb_[CURVE_COUNT];
+  void* comb_[CURVE_COUNT];                  // entry 0 of the fixed-base table (the slot in front of it: its geometry)
+  void* comb_base_[CURVE_COUNT];             // what was allocated
+  int comb_bits_[CURVE_COUNT];               // window width in use (signed combs may be narrower than the default)
   Buf scratch_[2][S_COUNT];   // one scratch arena per compute lane (see pipelined())
   int lane_ = 0;
   Buf staging_[G_COUNT];
@@ -2034,32 +2045,51 @@ int Engine<BK>::ensure_comb() {
   // Built by the engine itself: the variable-base kernel on the scalars d << (COMB_BITS w) and
   // the generator, in slices of at most 2^20 entries (the 22-bit signed comb of the 256-bit
   // curves has 25 M entries = 1.6 GB; a slice needs 1 GB of window-table scratch).
-  const size_t n = W::COMB_ENTRIES;
+  // A SIGNED comb (the 256-bit curves) carries its window width in the slot in front of entry 0
+  // (ladder.h comb_bits_of): when the device cannot hold the default table -- 12 windows x 2^21
+  // entries = 1.6 GB per curve -- the SAME kernels run on a narrower one: 16 bits (17 windows,
+  // 36 MB), 12, 8, 4.  ELLGPU_COMB_MAX_BYTES (developer / test override, read when the context is
+  // created) refuses larger tables as if the allocation had failed.
   const int B = W::BYTES;
-  const size_t slice = n < (size_t)ELL_COMB_SLICE ? n : (size_t)ELL_COMB_SLICE;
-  void* comb = bk.alloc(n * sizeof(typename W::A));
-  u8* dk = (u8*)bk.alloc(slice * B);
-  u8* dp = (u8*)bk.alloc(slice * 2 * B);
-  if (!comb || !dk || !dp) {
-    if (comb) bk.free_(comb);
-    if (dk) bk.free_(dk);
+  int cb = W::COMB_BITS;
+  for (;;) {
+    const size_t n = W::COMB_SIGNED ? (size_t)comb_windows(8 * B, cb) << (cb - 1) : W::COMB_ENTRIES;
+    const size_t bytes = (n + 1) * sizeof(typename W::A);
+    const size_t slice = n < (size_t)ELL_COMB_SLICE ? n : (size_t)ELL_COMB_SLICE;
+    typename W::A* base = (tune_.comb_max_bytes && bytes > tune_.comb_max_bytes) ? nullptr : (typename W::A*)bk.alloc(bytes);
+    u8* dk = base ? (u8*)bk.alloc(slice * B) : nullptr;
+    u8* dp = dk ? (u8*)bk.alloc(slice * 2 * B) : nullptr;
+    int rc = (base && dk && dp) ? E_OK : E_NOMEM;
+    if (rc == E_OK) {
+      typename W::A* comb = base + 1;
+      u32 hdr[sizeof(typename W::A) / 4] = {0};
+      hdr[0] = (u32)cb;
+      bk.h2d(base, hdr, sizeof hdr);
+      for (size_t first = 0; first < n && rc == E_OK; first += slice) {
+        const size_t m = n - first < slice ? n - first : slice;
+        FnCombGen<CV> g{m, first, dk, dp, cb};
+        bk.launch(g, m);
+        rc = mul_var_chunk<CV>(m, dk, dp, nullptr, nullptr, comb + first);
+      }
+      const int src = bk.sync();                   // a failed launch (comb_gen included) surfaces here
+      if (rc == E_OK && src != E_OK) rc = fail(src, "building the fixed-base table failed on the device");
+      if (rc == E_OK) {
+        bk.free_(dk);
+        bk.free_(dp);
+        comb_[CV::ID] = comb;
+        comb_base_[CV::ID] = base;
+        comb_bits_[CV::ID] = cb;
+        return E_OK;
+      }
+    }
     if (dp) bk.free_(dp);
-    return fail(E_NOMEM, "comb table allocation failed");
+    if (dk) bk.free_(dk);
+    if (base) bk.free_(base);
+    // out of memory (the table, or the window-table scratch of its build): a narrower comb
+    if (rc != E_NOMEM || !W::COMB_SIGNED || cb <= 4) return rc == E_NOMEM ? fail(E_NOMEM, "comb table allocation failed") : rc;
+    err.clear();
+    cb = cb > 16 ? 16 : (cb > 12 ? 12 : (cb > 8 ? 8 : 4));
   }
-  int rc = E_OK;
-  for (size_t first = 0; first < n && rc == E_OK; first += slice) {
-    const size_t m = n - first < slice ? n - first : slice;
-    FnCombGen<CV> g{m, first, dk, dp};
-    bk.launch(g, m);
-    rc = mul_var_chunk<CV>(m, dk, dp, nullptr, nullptr, (typename W::A*)comb + first);
-  }
-  const int src = bk.sync();                     // a failed launch (comb_gen included) surfaces here
-  if (rc == E_OK && src != E_OK) rc = fail(src, "building the fixed-base table failed on the device");
-  bk.free_(dk);
-  bk.free_(dp);
-  if (rc) { bk.free_(comb); return rc; }
-  comb_[CV::ID] = comb;
-  return E_OK;
 }
 
 

@@ -936,6 +936,12 @@ struct FpMont {
 #ifndef ELL_P384_CHAIN
 #define ELL_P384_CHAIN 0
 #endif
+#ifndef ELL_SOLINAS_PAIR
+#define ELL_SOLINAS_PAIR 1
+#endif
+#ifndef ELL_P384_PAIR
+#define ELL_P384_PAIR 0
+#endif
 #ifndef ELL_SOLINAS_DIRECT_SUB
 #define ELL_SOLINAS_DIRECT_SUB 1
 #endif
@@ -1311,6 +1317,40 @@ struct FpSolinas {
     if constexpr (L >= ELL_MONT_CALL_MINL) return sqr_call(a);
     else return sqr_inline(a);
   }
+  // PAIR PRODUCTS with one fold (round 5, ELL_SOLINAS_PAIR): the lazy fold takes a SIGNED word
+  // vector, so a difference of two wide products -- Y3 = rr (v - X3) - Y1 hhh of the mixed
+  // addition, Y3 = alpha (4 beta - X3) - 8 gamma^2 of the a = -3 doubling (short.h) -- is folded
+  // once instead of twice.  Only where the lazy fold is the field's fold (p256, p384).
+  // MEASURED (MI355X, same box, profiles/r05_pair_products_ab.txt): p256 P*k 61.7 -> 64.6 M/s
+  // (+4.7 %, kernel 16.75 -> 15.98 ms per 2^20); p384 21.65 -> 21.3-21.5 M/s with one pass in
+  // flight (kernel 11.92 -> 12.0-12.1 ms per 2^18: the second wide product's 24 words live across
+  // the fold cost the 168-register kernel more than the fold saves) and +0.7 % with two -- so the
+  // prime's descriptor decides (R::PAIR: p256 yes, p384 no).
+  template <class RR, class = void>
+  struct wants_pair { static constexpr bool value = false; };
+  template <class RR>
+  struct wants_pair<RR, decltype((void)RR::PAIR)> { static constexpr bool value = RR::PAIR; };
+  static constexpr bool PAIR = ELL_SOLINAS_PAIR && wants_pair<R>::value && !(has_chain<R>::value && ELL_SOLINAS_CHAIN);
+  // a * b - c * d
+  ELL_HD static El mul_sub_mul(const El& a, const El& b, const El& c, const El& d) {
+    u32 t1[2 * L], t2[2 * L];
+    fe_mul_wide<L>(t1, a.v, b.v);
+    fe_mul_wide<L>(t2, c.v, d.v);
+    i64 A[2 * L];
+    ELL_UNROLL
+    for (int k = 0; k < 2 * L; k++) A[k] = (i64)(u64)t1[k] - (i64)(u64)t2[k];
+    return finish_lazy(A);
+  }
+  // a * b - 8 c^2
+  ELL_HD static El mul_sub_sqr8(const El& a, const El& b, const El& c) {
+    u32 t1[2 * L], t2[2 * L];
+    fe_mul_wide<L>(t1, a.v, b.v);
+    fe_sqr_wide<L>(t2, c.v);
+    i64 A[2 * L];
+    ELL_UNROLL
+    for (int k = 0; k < 2 * L; k++) A[k] = (i64)(u64)t1[k] - ((i64)(u64)t2[k] << 3);
+    return finish_lazy(A);
+  }
   ELL_HD static El sqr_n(El a, int n) {
     ELL_NOUNROLL
     for (int i = 0; i < n; i++) a = sqr(a);
@@ -1425,6 +1465,7 @@ struct SolP224 {                       // p224 = 2^224 - 2^96 + 1:            B^
 };
 struct SolP256 {                       // p256 = 2^256 - 2^224 + 2^192 + 2^96 - 1:   B^8 == B^7 - B^6 - B^3 + 1
   typedef consts::P256_P MP;
+  static constexpr bool PAIR = true;     // Y3 as ONE folded difference of two wide products (FpSolinas::mul_sub_mul)
   static constexpr int NFOLD = 4;
   static constexpr int fold_pos[4] = {7, 6, 3, 0};
   static constexpr int fold_sign[4] = {1, -1, -1, 1};
@@ -1435,6 +1476,8 @@ struct SolP384 {                       // p384 = 2^384 - 2^128 - 2^96 + 2^32 - 1
   // measures 2 % SLOWER (P*k 21.0 against 21.4 M/s, profiles/r03_solinas_chain_ab.txt): four
   // 13-word carry chains are latency, where the lazy fold's 64-bit adds have no flag to wait for
   static constexpr bool CHAIN = ELL_P384_CHAIN;
+  // pair products (one fold for Y3): measured slower here, see FpSolinas::PAIR
+  static constexpr bool PAIR = ELL_P384_PAIR;
   static constexpr int NFOLD = 4;
   static constexpr int fold_pos[4] = {4, 3, 1, 0};
   static constexpr int fold_sign[4] = {1, 1, -1, 1};

@@ -93,6 +93,12 @@ ELL_HD void recode_odd_w4(const u32 (&k)[LW], const DigitStore& ds, int s, int N
   }
 }
 
+// window width of a signed fixed-base table (see Ladder::comb_add): the word in front of entry 0
+template <class AA>
+ELL_HD int comb_bits_of(const AA* comb) { return (int)((const u32*)(comb - 1))[0]; }
+// windows of a signed cb-bit comb over `bits`-bit scalars (one more bit for the recoding's carry)
+ELL_HD constexpr int comb_windows(int bits, int cb) { return (bits + cb) / cb; }
+
 template <class CV>
 struct Ladder {
   typedef typename CV::F F;
@@ -328,11 +334,18 @@ struct Ladder {
   // and y negated at lookup -- half the table per window bit, so wider windows for the same bytes.
   // Entries are affine, field-internal form.  Zero digits sit the addition out (exec mask).
   // `inf` = acc is O, updated.  WIDE: window w+1's entry is requested before window w's addition.
+  // The SIGNED comb's window width is a property of the TABLE, not of the kernel: the slot in front
+  // of entry 0 holds it (comb_bits_of), so that Engine::ensure_comb can narrow the comb when the
+  // device cannot hold the default 1.6 GB one (ELLGPU_E_NOMEM otherwise: ADVICE r3) -- the same
+  // kernels then run 17 / 33 / 65 windows of 16 / 8 / 4 bits instead of 12 of 22.  CB / W are the
+  // default geometry (and the unsigned combs' only one).
   template <int LK, int W, int CB, bool WIDE = false, bool SIGNED = false>
   ELL_HD static J comb_add(J acc, bool& inf, const u32 (&k)[LK], const A* comb) {
-    constexpr u32 MASK = (1u << CB) - 1u;
-    constexpr u32 HALF = 1u << (CB - 1);
-    constexpr u32 PER = SIGNED ? HALF : MASK;             // entries per window
+    const int cb = SIGNED ? comb_bits_of(comb) : CB;
+    const int nwin = SIGNED ? (LK * 32 + cb) / cb : W;    // signed: one more bit for the recoding's carry
+    const u32 MASK = (1u << cb) - 1u;
+    const u32 HALF = 1u << (cb - 1);
+    const u32 PER = SIGNED ? HALF : MASK;                 // entries per window
     u32 kk[LK];
     bn_copy<LK>(kk, k);
     u32 carry = 0;
@@ -340,8 +353,8 @@ struct Ladder {
     auto digit = [&](u32& idx, bool& neg, bool& zero) {
       u32 d = (kk[0] & MASK) + carry;
       ELL_UNROLL
-      for (int i = 0; i < LK - 1; i++) kk[i] = (kk[i] >> CB) | (kk[i + 1] << (32 - CB));
-      kk[LK - 1] >>= CB;
+      for (int i = 0; i < LK - 1; i++) kk[i] = (kk[i] >> cb) | (kk[i + 1] << (32 - cb));
+      kk[LK - 1] >>= cb;
       if (SIGNED) {
         neg = d > HALF;
         carry = neg ? 1u : 0u;
@@ -363,11 +376,11 @@ struct Ladder {
       const A* e = comb + idx;
       A q = *e;
       ELL_NOUNROLL
-      for (int w = 0; w < W; w++) {
+      for (int w = 0; w < nwin; w++) {
         u32 idxn = 0; bool negn = false, zeron = true;
         const A* en = comb;
         A qn = q;
-        if (w + 1 < W) {
+        if (w + 1 < nwin) {
           digit(idxn, negn, zeron);
           en = comb + ((size_t)(w + 1) * PER + idxn);
           qn = *en;
@@ -381,7 +394,7 @@ struct Ladder {
       return acc;
     } else {
       ELL_NOUNROLL
-      for (int w = 0; w < W; w++) {
+      for (int w = 0; w < nwin; w++) {
         u32 idx; bool neg, zero;
         digit(idx, neg, zero);
         if (!zero) {

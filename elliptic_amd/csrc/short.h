@@ -43,6 +43,13 @@ struct is_lazy { static constexpr bool value = false; };
 template <class F>
 struct is_lazy<F, decltype((void)F::LAZY)> { static constexpr bool value = F::LAZY; };
 
+// F::PAIR (fp.h FpSolinas): the field folds a difference of two wide products once
+// (mul_sub_mul / mul_sub_sqr8); the doubling and the additions below form their Y3 that way
+template <class F, class = void>
+struct has_pair { static constexpr bool value = false; };
+template <class F>
+struct has_pair<F, decltype((void)F::PAIR)> { static constexpr bool value = F::PAIR; };
+
 template <class CV>
 struct ShortOps {
   typedef typename CV::F F;
@@ -139,9 +146,13 @@ struct ShortOps {
       r.X = F::sub(F::sqr(alpha), F::template mul_pow2<1>(beta4));
       El yz = F::sqr(F::add(p.Y, p.Z));
       r.Z = F::sub(F::sub(yz, gamma), delta);
-      El g2 = F::sqr(gamma);
-      El g8 = F::template mul_pow2<3>(g2);
-      r.Y = F::sub(F::mul(alpha, F::sub(beta4, r.X)), g8);
+      if constexpr (has_pair<F>::value) {
+        r.Y = F::mul_sub_sqr8(alpha, F::sub(beta4, r.X), gamma);
+      } else {
+        El g2 = F::sqr(gamma);
+        El g8 = F::template mul_pow2<3>(g2);
+        r.Y = F::sub(F::mul(alpha, F::sub(beta4, r.X)), g8);
+      }
     }
     return r;
   }
@@ -236,8 +247,12 @@ struct ShortOps {
     El hhh = F::mul(h, hh);
     El v = F::mul(p.X, hh);
     r.X = F::sub(F::sub(F::sqr(rr), hhh), F::template mul_pow2<1>(v));
-    El yh = F::mul(p.Y, hhh);
-    r.Y = F::sub(F::mul(rr, F::sub(v, r.X)), yh);
+    if constexpr (has_pair<F>::value) {
+      r.Y = F::mul_sub_mul(rr, F::sub(v, r.X), p.Y, hhh);
+    } else {
+      El yh = F::mul(p.Y, hhh);
+      r.Y = F::sub(F::mul(rr, F::sub(v, r.X)), yh);
+    }
     bool z = F::is_zero(r.Z);
     if (ELL_UNLIKELY(z)) {
       const A qq = reload();

@@ -127,7 +127,16 @@ class Context:
     def reserve(self, curve, n):
         self._check(self._lib.ellgpu_ctx_reserve(self._ctx, self._cid(curve), int(n)))
 
+    def comb_bits(self, curve):
+        """window width of the curve's fixed-base table on this context (0 = not built yet; the
+        256-bit curves default to 22, narrower when the device could not hold that table)"""
+        rc = self._lib.ellgpu_ctx_comb_bits(self._ctx, self._cid(curve))
+        if rc < 0:
+            raise _lib.EllgpuError(rc, self._lib.ellgpu_last_error().decode())
+        return rc
+
     # ---- host buffers -------------------------------------------------------
+
     def mul_fixed(self, curve, k, out=None):
         """out: optional (xy, inf) uint8 arrays to write into (see mul_var)"""
         B = FIELD_BYTES[curve]

@@ -407,6 +407,13 @@ int ellgpu_x25519_ladder_dev(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const 
 /* Pre-size the context's scratch arena for batches of up to n items of `curve`
  * (otherwise it grows on first use); also builds the curve's fixed-base table. */
 int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n);
+/* Window width, in bits, of the curve's fixed-base table on this context (0: not built yet; a
+ * group answers for its first member).  The 256-bit curves' signed comb defaults to 22-bit
+ * windows (12 additions per k*G, 1.6 GB); when the device cannot hold that table the engine
+ * builds a narrower one -- 16, 12, 8 or 4 bits -- instead of failing with ELLGPU_E_NOMEM, and the
+ * same kernels run on it (results are the same points; more additions per k*G).  The reference's
+ * counterpart is the fixed `doubles` step of BasePoint#precompute (base.js:312-346). */
+int ellgpu_ctx_comb_bits(ellgpu_ctx* ctx, int curve);
 
 /* ---- measurement helper --------------------------------------------------
  * Integer-VALU roofline probe: runs `iters` dependent-free 32x32+64 -> 64 bit

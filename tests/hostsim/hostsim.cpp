@@ -131,6 +131,12 @@ static void field_op(int op, const u32* a, const u32* b, u32* r) {
       z = F::reduce_wide(w);
     }
   }
+  if constexpr (has_wide_probe<F>::value) {
+    // pair products with one fold (fp.h FpSolinas::mul_sub_mul / mul_sub_sqr8; whether a curve's group
+    // law USES them is the prime's PAIR flag)
+    if (op == 17) z = F::mul_sub_mul(x, y, F::sub(y, x), F::add(x, y));        // x y - (y - x)(x + y)
+    if (op == 18) z = F::mul_sub_sqr8(x, y, F::sub(x, y));                      // x y - 8 (x - y)^2
+  }
   if constexpr (std::is_same<F, FpK256L>::value || std::is_same<F, FpK256C>::value) {
     if (op == 11) z = F::mul2(x, y, F::template neg_l<4>(x), F::template sub_l<4>(x, y));
     if (op == 12) { typename F::El a = F::sqr(x); z = F::norm(F::add_l(a, F::half_l(a))); }

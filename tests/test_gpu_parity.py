@@ -524,6 +524,37 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
         c.close()
 
 
+def test_fixed_base_table_narrows_when_memory_is_short(ctx, monkeypatch):
+    """The signed comb's window width travels with the table (ladder.h comb_bits_of): a context
+    that cannot have the default 22-bit table (1.6 GB) builds a 16-bit one (36 MB; here forced
+    with ELLGPU_COMB_MAX_BYTES) and the same kernels -- full-grid, small-grid, parted, row layer,
+    sign, recover -- give the same bytes on it."""
+    assert ctx.mul_fixed("secp256k1", np.ones((1, 32), np.uint8))[0].shape == (1, 64)
+    assert ctx.comb_bits("secp256k1") == 22
+    monkeypatch.setenv("ELLGPU_COMB_MAX_BYTES", str(100 << 20))
+    c = elliptic_amd.Context(0)
+    monkeypatch.delenv("ELLGPU_COMB_MAX_BYTES")
+    n = 200000
+    h, r, s, pub, expect = _make_sigs(ctx, n, "gpu-test-narrow-comb")
+    assert np.array_equal(c.ecdsa_verify("secp256k1", h, r, s, pub), expect)          # full grid
+    assert c.comb_bits("secp256k1") == 16
+    for m in (1, 100, 5000, 70000):                                                  # row layer, parts, small grid
+        assert np.array_equal(c.ecdsa_verify("secp256k1", h[:m], r[:m], s[:m], pub[:m]), expect[:m]), m
+    ks = r.copy()
+    ks[0] = 0
+    ks[1] = 255
+    for m in (n, 300):
+        a, ai = c.mul_fixed("secp256k1", ks[:m])
+        b, bi = ctx.mul_fixed("secp256k1", ks[:m])
+        assert np.array_equal(a, b) and np.array_equal(ai, bi), m
+        a, ai = c.mul_add2("secp256k1", ks[:m], None, s[:m], pub[:m])
+        b, bi = ctx.mul_add2("secp256k1", ks[:m], None, s[:m], pub[:m])
+        assert np.array_equal(a, b) and np.array_equal(ai, bi), m
+    assert PC.check_signdet_golden(c, "secp256k1") > 10 and PC.check_recover_golden(c, "secp256k1") >= 30
+    assert PC.check_verify_golden(c, "p256") > 15 and c.comb_bits("p256") == 16
+    c.close()
+
+
 def test_full_size_group_properties(ctx):
     """size-independent properties on 2^18 items: (a*G)*b == (b*G)*a, fixed ==
     variable base on G, k1*G + k2*G == (k1+k2)*G."""

@@ -535,6 +535,43 @@ def test_error_paths(ctx, hs):
     assert out.shape == (0, 64)
 
 
+def test_fixed_base_table_narrows_when_memory_is_short(hs, monkeypatch):
+    """ADVICE r3 / VERDICT r4 #7: the 256-bit curves' signed comb carries its window width in front
+    of its first entry, so a context that cannot allocate the default table builds a narrower one
+    and the SAME kernels run on it -- instead of ELLGPU_E_NOMEM on the first G*k / verify / sign.
+    ELLGPU_COMB_MAX_BYTES makes allocations above a size fail (here: the host build's 8-bit comb
+    of 33 x 128 entries does not fit, the 4-bit one of 65 x 8 does)."""
+    c0 = elliptic_amd.Context(0, lib_path=hs)
+    assert c0.comb_bits("secp256k1") == 0
+    c0.reserve("secp256k1", 16)
+    wide = c0.comb_bits("secp256k1")
+    assert wide == 8                                      # tests/hostsim/build.py: -DELL_COMB_BITS_256=8
+    c = _fresh_ctx(hs, monkeypatch, ELLGPU_COMB_MAX_BYTES=str(100 * 1024))
+    for curve in ("secp256k1", "p256"):
+        c.reserve(curve, 16)
+        assert c.comb_bits(curve) == 4, curve
+        assert PC.check_mul_golden(c, curve) > 50         # fixed-base rows included
+        assert PC.check_verify_golden(c, curve) > 15
+        assert PC.check_sign_golden(c, curve) > 10
+        assert PC.check_signdet_golden(c, curve) > 10
+    assert PC.check_recover_golden(c, "secp256k1") >= 30
+    assert PC.check_exceptional_keys(c, "secp256k1") > 400
+    rng = random.Random(3)
+    ks = np.frombuffer(bytes(rng.getrandbits(8) for _ in range(40 * 32)), np.uint8).reshape(40, 32).copy()
+    ks[0] = 0
+    ks[1] = 255                                           # 2^256 - 1: every window at its maximum, the carry window used
+    a, ai = c.mul_fixed("secp256k1", ks)
+    b, bi = c0.mul_fixed("secp256k1", ks)
+    assert np.array_equal(a, b) and np.array_equal(ai, bi)
+    # nothing fits: the call fails loudly, and says why
+    c2 = _fresh_ctx(hs, monkeypatch, ELLGPU_COMB_MAX_BYTES="64")
+    with pytest.raises(elliptic_amd.EllgpuError) as e:
+        c2.mul_fixed("secp256k1", ks)
+    assert "comb table allocation failed" in str(e.value)
+    for x in (c0, c, c2):
+        x.close()
+
+
 def test_one_context_entered_from_several_threads(ctx):
     """The N-API addon runs Promise-form batches on a libuv worker while the JS thread makes
     synchronous calls on the SAME context: entry points of one context take turns (a
@@ -693,6 +730,23 @@ def test_lazy_field_two_product_and_half(hs, field):
             r = (ctypes.c_uint32 * 8)()
             assert hs.hs_field_op(field, op, _limbs(x, 8), _limbs(y, 8), r) == 0
             assert _val(r) == want, (op, hex(x), hex(y))
+
+
+@pytest.mark.parametrize("field", [13, 14])
+def test_solinas_pair_products(hs, field):
+    """FpSolinas::mul_sub_mul / mul_sub_sqr8 (p256, p384): a difference of two wide products through
+    ONE signed lazy fold -- negative differences, operands at the edges of [0, p), the rare top
+    branch -- against Python integers"""
+    p = FIELDS[field]
+    L = hs.hs_field_limbs(field)
+    rnd = random.Random(4242 + field)
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 2 ** 32 - 1, 2 ** (32 * (L - 1)), p - 2 ** 32, p - 2 ** 96]
+    vals = [(x, y) for x in edge for y in edge] + [(rnd.randrange(p), rnd.randrange(p)) for _ in range(600)]
+    for x, y in vals:
+        for op, want in ((17, (x * y - (y - x) * (x + y)) % p), (18, (x * y - 8 * (x - y) ** 2) % p)):
+            r = (ctypes.c_uint32 * L)()
+            assert hs.hs_field_op(field, op, _limbs(x, L), _limbs(y, L), r) == 0
+            assert _val(r) == want, (field, op, hex(x), hex(y))
 
 
 def test_row_field_corners(hs):
