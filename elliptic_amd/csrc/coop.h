@@ -393,6 +393,15 @@ struct FpK256C {
     return tail(acc, col16);
   }
 
+  // a^-1 (0 for 0): canonical words -> the division steps of the saturated field -> back (cold: once
+  // per item, where a result leaves the row layer in affine form)
+  static ELL_HD_NOINLINE El inv(const El& a) {
+    FpK256::El t;
+    to_plain(t.v, a);
+    FpK256::El r = FpK256::inv(t);
+    return from_plain(r.v);
+  }
+
   // ---- generic interface: N form in, N form out --------------------------------------------------------
   ELL_HD static El add(const El& a, const El& b) { return norm(add_l(a, b)); }
   ELL_HD static El sub(const El& a, const El& b) { return norm(sub_l<4>(a, b)); }

@@ -1,0 +1,293 @@
+// ellgpu -- the lanes-per-item layer (coop.h) for the NIST primes up to 256 bits: a Montgomery
+// field over nine signed 29-bit limbs, one limb per lane of a 16-lane row, R = 2^261.
+//
+// Same idea as coop.h's FpK256C -- a product's partial-product rows are nine multiply-adds of the
+// whole row, additions are one instruction -- with a reduction that does not depend on the shape
+// of the prime: word-serial REDC.  Column i of the 17-column product (lane i; column 16 on the
+// scalar unit) is made divisible by 2^29 by adding m_i * p shifted up i lanes, m_i = column i *
+// (-p^-1) mod 2^29 computed on the scalar unit from a v_readlane of the running column; after
+// nine steps the low nine columns are zero and columns 9..17 ARE the result (one DPP shift down).
+// Signed limbs throughout (no offsets K p anywhere): REDC works on two's complement columns, and
+// because R is 2^5 times larger than 2^256 a product of two values below ~1.01 p comes out below
+// 1.04 p -- nothing is ever conditionally subtracted on the fast path.  Additions, subtractions
+// and small multiples fold the VALUE back with one estimate from the top limb (norm): every value
+// the interface returns lies in (-2^(PBITS-23), 2^PBITS + 2^(PBITS-23)), limbs below 2^29 + 2^7.
+//
+// Used for single calls and small batches on p256 / p224 / p192 (coop_work.h CoopNist): the
+// reference's JPoint arithmetic (short.js:532-603, 739-800) over bn.js `Mont` (dist/elliptic.js:
+// 7308-7381), one item per wave.  Elements are in MONTGOMERY form inside this layer; the one-lane
+// kernels' tables and results are plain words (fp.h FpSolinas), converted at the boundary.
+#pragma once
+
+#include "coop.h"
+#include "coop_consts.h"
+
+namespace ell {
+
+// MC: consts::COOP_P* (nine 29-bit digits of p, n0, R, R^2); F1: the curve's one-lane field (plain
+// words <-> elements, the inversion)
+template <class MC, class F1>
+struct FpMontC {
+  typedef FpK256C R_;                                // the row primitives (lane index, DPP moves, readlane)
+  static constexpr int CL = ELL_COOP_LANES;
+  static constexpr int L = F1::L;                    // 32-bit words of a plain value
+  static constexpr bool HAS_SQRT = false;
+  typedef Fe<CL> El;
+  typedef FpK256C::W64 W64;
+  static constexpr u32 M = (1u << 29) - 1;
+  static constexpr int TL = (MC::PBITS - 1) / 29;    // the limb that holds bit PBITS - 1 ...
+  static constexpr int TB = MC::PBITS - 29 * TL;     // ... and how many bits of it belong to a value below 2^PBITS
+
+  ELL_HD static i32 s(u32 x) { return (i32)x; }
+  template <class Fn> ELL_HD static El each(const Fn& f) { return R_::each(f); }
+  template <int N> ELL_HD static El up(const El& x) { return R_::template up<N>(x); }
+  template <int N> ELL_HD static El down(const El& x) { return R_::template down<N>(x); }
+  ELL_HD static i32 at(const El& x, int l) { return R_::at(x, l); }
+  ELL_HD static int lane_of(int t) { return R_::lane_of(t); }
+
+  ELL_HD static El c_p() { return by_lane<0>(MC::p29); }
+  // digits of a compile-time table by lane: a select chain (an indexed read would be a memory table)
+  template <int I, class Tab>
+  ELL_HD static El by_lane(const Tab& tab) {
+    return each([&](int l) {
+      i32 v = 0;
+      ELL_UNROLL
+      for (int j = 0; j < 9; j++) v = (l == j + I) ? (i32)tab[j] : v;
+      return v;
+    });
+  }
+  template <int I>
+  ELL_HD static El c_pshift() { return by_lane<I>(MC::p29); }
+  ELL_HD static El c_live() { return R_::c_live(); }
+  ELL_HD static El c_mask() { return each([](int l) { return l < 8 ? (i32)M : (l == 8 ? -1 : 0); }); }
+  ELL_HD static El zero() { return each([](int) { return 0; }); }
+  ELL_HD static El one() { return by_lane<0>(MC::one29); }     // R mod p
+  ELL_HD static El c_rr() { return by_lane<0>(MC::rr29); }      // R^2 mod p
+  ELL_HD static El plain_one() { return each([](int l) { return l == 0 ? 1 : 0; }); }
+
+  // ---- lazy limb-wise forms -----------------------------------------------------------------------
+  ELL_HD static El add_l(const El& a, const El& b) {
+    El r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) r.v[t] = a.v[t] + b.v[t];
+    return r;
+  }
+  ELL_HD static El sub_l(const El& a, const El& b) {
+    El r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) r.v[t] = a.v[t] - b.v[t];
+    return r;
+  }
+  // Carry pass + value fold: a lazy value with |limbs| < 2^30 and |value| < 3 * 2^PBITS comes back
+  // with limbs in (-2^7, 2^29 + 2^7) and its value in (-2^(PBITS-23), 2^PBITS + 2^(PBITS-23)).
+  // The fold subtracts k p for k = floor(value / 2^PBITS) as limb TL shows it (limbs above TL are
+  // carry-sized), k in [-2, 2]: |limb - k p_l| stays below 2^31.
+  ELL_HD static El norm(const El& a) {
+    const El pv = c_p(), mk = c_mask(), live = c_live();
+    i64 top = (i64)at(a, TL);
+    ELL_UNROLL
+    for (int j = TL + 1; j <= 8; j++) top += (i64)at(a, j) << (29 * (j - TL));        // (carry-sized limbs above TL)
+    const i64 k64 = top >> TB;
+    const i32 k = k64 < -2 ? -2 : (k64 > 2 ? 2 : (i32)k64);
+    El d, c;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) d.v[t] = a.v[t] - (u32)k * pv.v[t];
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) c.v[t] = (u32)(s(d.v[t]) >> 29);
+    const El cin = up<1>(c);
+    El r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) r.v[t] = ((d.v[t] & mk.v[t]) + cin.v[t]) & live.v[t];
+    return r;
+  }
+
+  // ---- products: nine multiply-adds of the row, then word-serial REDC -----------------------------
+#if defined(ELL_BOUNDS_CHECK)
+  static void check(const El& a, const El& b, const char* what) {
+    __int128 col[17] = {0};
+    FpK256L::check_operands(R_::gather(a), R_::gather(b), col);
+    // + the reduction's own rows: nine m_i p, |m_i| < 2^29
+    const __int128 lim = ((__int128)1 << 63) - ((__int128)1 << 50);
+    for (int k = 0; k < 17; k++) {
+      __int128 red = 0;
+      for (int i = 0; i <= 8; i++) { int j = k - i; if (j >= 0 && j <= 8) red += ((__int128)1 << 29) * MC::p29[j]; }
+      if (col[k] + red >= lim) { fprintf(stderr, "fpmontc %s: column %d exceeds 63 bits\n", what, k); assert(0); }
+    }
+    for (int t = 9; t < CL; t++) assert(a.v[t] == 0 && b.v[t] == 0 && "fpmontc: dead lane not zero");
+  }
+#endif
+  ELL_HD static El redc(W64 acc, i64 col16) {
+    // p shifted up i lanes, as per-lane CONSTANTS (a DPP move is a convergent operation the
+    // compiler will not hoist out of the ladder's loops; a select chain on the lane index it does)
+    const El live = c_live();
+    const El pv = c_pshift<0>(), p1 = c_pshift<1>(), p2 = c_pshift<2>(), p3 = c_pshift<3>(), p4 = c_pshift<4>(),
+             p5 = c_pshift<5>(), p6 = c_pshift<6>(), p7 = c_pshift<7>(), p8 = c_pshift<8>();
+    const El* const ps[9] = {&pv, &p1, &p2, &p3, &p4, &p5, &p6, &p7, &p8};
+    const i64 p0 = (i64)MC::p29[0], p8s = (i64)MC::p29[8];
+    i64 carry = 0;
+    ELL_UNROLL
+    for (int i = 0; i <= 8; i++) {
+      const i64 v = R_::at64(acc, i) + carry;                      // column i as it stands
+      const i32 m = (i32)(((u32)v * MC::n0) & M);                  // v + m p_0 = 0 (mod 2^29)
+      ELL_UNROLL
+      for (int t = 0; t < CL; t++) acc.w[t] += (i64)m * (i64)s(ps[i]->v[t]);
+      if (i == 8) col16 += (i64)m * p8s;                           // (lane 16 is off the row)
+      // p = -1 (mod 2^29) (p256, p192): m is v's low digit and v + m (2^29 - 1) = ((v >> 29) + m) 2^29
+      if constexpr (MC::n0 == 1u && MC::p29[0] == (int)M) carry = (v >> 29) + (i64)m;
+      else carry = (v + (i64)m * p0) >> 29;
+    }
+    // columns 9..15 (lanes 9..15), 16 (scalar) and the carry into column 9 are the result's limbs 0..7
+    W64 res;
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+      const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)acc.w[0], 0x100 + 9, 0xF, 0xF, true);
+      const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)((u64)acc.w[0] >> 32), 0x100 + 9, 0xF, 0xF, true);
+      i64 x = (i64)(((u64)hi << 32) | lo);
+      const int l = lane_of(0);
+      x = l == 7 ? col16 : x;
+      x += l == 0 ? carry : 0;
+      res.w[0] = x;
+    }
+#else
+    for (int t = 0; t < CL; t++) res.w[t] = t + 9 < CL ? acc.w[t + 9] : 0;
+    res.w[7] = col16;
+    res.w[0] += carry;
+#endif
+    // two carry passes (64-bit, then 32-bit): limbs below 2^29 + 2^7; limb 8 takes limb 7's carries
+    W64 c1;
+    El lo1;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) { c1.w[t] = res.w[t] >> 29; lo1.v[t] = (u32)res.w[t] & M; }
+    const W64 cin1 = R_::template up64<1>(c1);
+    W64 v1;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) v1.w[t] = (i64)lo1.v[t] + cin1.w[t];
+    El c2, r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) c2.v[t] = lane_of(t) < 8 ? (u32)(i32)(v1.w[t] >> 29) : 0u;
+    const El cin2 = up<1>(c2);
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++)
+      r.v[t] = ((lane_of(t) < 8 ? ((u32)v1.w[t] & M) : (u32)v1.w[t]) + cin2.v[t]) & live.v[t];
+    return r;
+  }
+  ELL_HD static El mul(const El& a, const El& b) {
+#if defined(ELL_BOUNDS_CHECK)
+    check(a, b, "mul");
+#endif
+    W64 acc = R_::zero64();
+    i64 col16 = 0;
+    R_::columns(acc, col16, a, b);
+    return redc(acc, col16);
+  }
+  ELL_HD static El sqr(const El& a) { return mul(a, a); }
+
+  // ---- the field interface of short.h's generic (non-lazy) formulas --------------------------------
+  ELL_HD static El add(const El& a, const El& b) { return norm(add_l(a, b)); }
+  ELL_HD static El sub(const El& a, const El& b) { return norm(sub_l(a, b)); }
+  ELL_HD static El neg(const El& a) { return norm(sub_l(zero(), a)); }
+  ELL_HD static El dbl(const El& a) { return norm(add_l(a, a)); }
+  template <int K>
+  ELL_HD static El mul_pow2(const El& a) {
+    El r = a;
+    ELL_UNROLL
+    for (int i = 0; i < K; i++) r = norm(add_l(r, r));
+    return r;
+  }
+
+  // ---- conversions, tests (cold paths: through the scalar unit and the one-lane field) -------------
+  // the value's canonical residue in [0, p) as nine exact 29-bit digits -> eight plain words
+  ELL_HD static void canon(u32 (&out)[8], const El& a) {
+    i64 d[9];
+    ELL_UNROLL
+    for (int i = 0; i < 9; i++) d[i] = (i64)at(a, i);
+    // value in (-p, 2p): + p, sequential carry, then up to two conditional subtractions of p
+    i64 c = 0;
+    u32 dig[9];
+    ELL_UNROLL
+    for (int i = 0; i < 9; i++) {
+      i64 t = d[i] + (i64)MC::p29[i] + c;
+      dig[i] = (u32)t & M;
+      c = t >> 29;
+    }
+    // (c is 0 here: the value + p lies in (0, 3p) < 2^261)
+    ELL_NOUNROLL
+    for (int it = 0; it < 2; it++) {
+      u32 sub[9];
+      i32 br = 0;
+      ELL_UNROLL
+      for (int i = 0; i < 9; i++) {
+        i32 t = (i32)dig[i] - MC::p29[i] + br;
+        sub[i] = (u32)t & M;
+        br = t >> 29;
+      }
+      const bool take = br == 0;                       // dig >= p
+      ELL_UNROLL
+      for (int i = 0; i < 9; i++) dig[i] = take ? sub[i] : dig[i];
+    }
+    u32 w[9];
+    ELL_UNROLL
+    for (int j = 0; j < 9; j++) w[j] = 0;
+    ELL_UNROLL
+    for (int i = 0; i < 9; i++) {
+      const int bit = 29 * i, k = bit >> 5, sh = bit & 31;
+      const u64 v = (u64)dig[i] << sh;
+      w[k] |= (u32)v;
+      if (k + 1 < 9) w[k + 1] |= (u32)(v >> 32);
+    }
+    ELL_UNROLL
+    for (int j = 0; j < 8; j++) out[j] = w[j];
+  }
+  // plain words of the element (out of Montgomery form): REDC of a * 1, canonical
+  ELL_HD static void to_plain(u32 (&out)[L], const El& a) {
+    u32 w[8];
+    canon(w, mul(a, plain_one()));
+    ELL_UNROLL
+    for (int j = 0; j < L; j++) out[j] = w[j];
+  }
+  // wave-uniform plain words -> the element: digits times R^2, reduced
+  ELL_HD static El from_plain(const u32 (&a)[L]) {
+    u32 w[8];
+    ELL_UNROLL
+    for (int j = 0; j < 8; j++) w[j] = j < L ? a[j] : 0u;
+    return mul(R_::scatter(FpK256L::from_plain(w)), c_rr());
+  }
+  // L plain words in memory (an entry of the one-lane kernels' tables) -> the element
+  ELL_HD static El load_words(const u32* w) {
+    const El digs = each([&](int l) {
+      const int ll = l > 8 ? 8 : l;
+      const int bit = 29 * ll;
+      int k = bit >> 5;
+      const int sh = bit & 31;
+      const u32 lo = k < L ? w[k] : 0u;
+      const u32 hi = k + 1 < L ? w[k + 1] : 0u;
+      const u64 two = (u64)lo | ((u64)hi << 32);
+      return l > 8 ? 0 : (i32)((u32)(two >> sh) & M);
+    });
+    return mul(digs, c_rr());
+  }
+  // Zero test.  Every value of the interface lies in (-p, 2p): it is 0 (mod p) iff it is 0 or p, and
+  // then limb 0's low 29 bits are 0's or p's -- anything else (all but one value in 2^28) is not zero;
+  // the canonical digits decide the rest.  (Montgomery form keeps 0 at 0.)
+  ELL_HD static bool is_zero(const El& a) {
+    const u32 r0 = (u32)at(a, 0) & M;
+    if (ELL_UNLIKELY(r0 == 0u || r0 == ((u32)MC::p29[0] & M))) {
+      u32 w[8];
+      canon(w, a);
+      return bn_is_zero<8>(w);
+    }
+    return false;
+  }
+  ELL_HD static bool eq(const El& a, const El& b) { return is_zero(sub(a, b)); }
+  // a^-1 (0 for 0): through the one-lane field's division steps
+  static ELL_HD_NOINLINE El inv(const El& a) {
+    u32 w[L];
+    to_plain(w, a);
+    typename F1::El y = F1::inv(F1::from_plain(w));
+    u32 v[L];
+    F1::to_plain(v, y);
+    return from_plain(v);
+  }
+};
+
+}  // namespace ell

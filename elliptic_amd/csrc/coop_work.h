@@ -11,8 +11,82 @@
 #pragma once
 
 #include "coop.h"
+#include "coop_mont.h"
 
 namespace ell {
+
+// k*G over the one-lane kernels' comb table (ladder.h comb_add with the entries read through
+// CW::load_entry): CW = the row layer's work struct (CoopK256 / CoopNist<...>)
+template <class CW, int LK>
+ELL_HD typename CW::J coop_comb_mul(const u32 (&k)[LK], const typename CW::W1::A* comb) {
+  typedef typename CW::W1 W1;
+  typedef typename CW::A A;
+  typedef typename CW::G G;
+  typedef typename CW::LD LD;
+  constexpr bool SIGNED = W1::COMB_SIGNED;
+  const int CB = SIGNED ? comb_bits_of(comb) : W1::COMB_BITS;        // (a signed table carries its window width)
+  const int W = SIGNED ? comb_windows(32 * LK, CB) : W1::COMB_W;
+  const u32 MASK = (1u << CB) - 1u;
+  const u32 HALF = 1u << (CB - 1);
+  const u32 PER = SIGNED ? HALF : MASK;
+  u32 kk[LK];
+  bn_copy<LK>(kk, k);
+  u32 carry = 0;
+  typename CW::J acc = G::infinity();
+  bool inf = true;
+  ELL_NOUNROLL
+  for (int w = 0; w < W; w++) {
+    u32 d = (kk[0] & MASK) + carry;
+    ELL_UNROLL
+    for (int j = 0; j < LK - 1; j++) kk[j] = (kk[j] >> CB) | (kk[j + 1] << (32 - CB));
+    kk[LK - 1] >>= CB;
+    bool neg = false;
+    if (SIGNED) {
+      neg = d > HALF;
+      carry = neg ? 1u : 0u;
+      d = neg ? (MASK + 1u) - d : d;
+    }
+    if (d != 0) {                                        // wave-uniform: one item per wave
+      const typename W1::A* e = comb + ((size_t)w * PER + (d - 1u));
+      auto fetch = [&]() -> A {
+        A q = CW::load_entry(e);
+        if (SIGNED) q.y = LD::cneg_y(q.y, neg);
+        return q;
+      };
+      acc = G::add_mixed_lean(acc, fetch(), inf, fetch);
+    }
+  }
+  return acc;
+}
+
+// EC#sign's k*G for a handful of items (work.h sign_mul + normalize in one unit): the comb on the
+// row layer, then THIS item's own inversion -- no Montgomery trick across items, on an idle machine
+// the chain counts -- and the affine point as the one-lane sign_finish reads it (big-endian x || y,
+// infinity flag).  CW = CoopK256 / CoopNist<...>.
+template <class CW>
+ELL_HD void coop_sign_point(size_t i, const u8* nonces, const typename CW::W1::A* comb, u8* kg_xy, u8* kg_inf) {
+  typedef typename CW::W1 W1;
+  typedef typename CW::F F;
+  constexpr int L = W1::L, LN = W1::LN, BYTES = W1::BYTES;
+  u32 k[LN], kk[L];
+  W1::load_nonce(k, nonces + i * W1::NBYTES);
+  ELL_UNROLL
+  for (int l = 0; l < L; l++) kk[l] = l < LN ? k[l] : 0u;
+  typename CW::J r = coop_comb_mul<CW>(kk, comb);
+  const bool inf = F::is_zero(r.Z);
+  typename F::El zi = F::inv(r.Z);                      // inv(0) = 0
+  typename F::El zi2 = F::sqr(zi);
+  u32 x[L], y[L];
+  F::to_plain(x, F::mul(r.X, zi2));
+  F::to_plain(y, F::mul(r.Y, F::mul(zi2, zi)));
+  if (CW::writer()) {
+    u8* o = kg_xy + i * 2 * BYTES;
+    if (inf) { ELL_UNROLL for (int l = 0; l < L; l++) { x[l] = 0; y[l] = 0; } }
+    store_be<L>(o, x, BYTES);
+    store_be<L>(o + BYTES, y, BYTES);
+    kg_inf[i] = inf ? 1 : 0;
+  }
+}
 
 struct CoopK256 {
   typedef CvSecp256k1C CV;
@@ -119,43 +193,8 @@ struct CoopK256 {
     store_jac(jac, n, i, b);
   }
 
-  // ---- fixed base: k*G over the one-lane comb table (ladder.h comb_add, entries through load_entry) ----
-  ELL_HD static J comb_mul(const u32 (&k)[8], const W1::A* comb) {
-    constexpr bool SIGNED = W1::COMB_SIGNED;
-    const int CB = SIGNED ? comb_bits_of(comb) : W1::COMB_BITS;        // (the table carries its window width)
-    const int W = SIGNED ? comb_windows(256, CB) : W1::COMB_W;
-    const u32 MASK = (1u << CB) - 1u;
-    const u32 HALF = 1u << (CB - 1);
-    const u32 PER = SIGNED ? HALF : MASK;
-    u32 kk[8];
-    bn_copy<8>(kk, k);
-    u32 carry = 0;
-    J acc = G::infinity();
-    bool inf = true;
-    ELL_NOUNROLL
-    for (int w = 0; w < W; w++) {
-      u32 d = (kk[0] & MASK) + carry;
-      ELL_UNROLL
-      for (int j = 0; j < 7; j++) kk[j] = (kk[j] >> CB) | (kk[j + 1] << (32 - CB));
-      kk[7] >>= CB;
-      bool neg = false;
-      if (SIGNED) {
-        neg = d > HALF;
-        carry = neg ? 1u : 0u;
-        d = neg ? (MASK + 1u) - d : d;
-      }
-      if (d != 0) {                                      // wave-uniform: one item per wave
-        const W1::A* e = comb + ((size_t)w * PER + (d - 1u));
-        auto fetch = [&]() -> A {
-          A q = load_entry(e);
-          if (SIGNED) q.y = LD::cneg_y(q.y, neg);
-          return q;
-        };
-        acc = G::add_mixed_lean(acc, fetch(), inf, fetch);
-      }
-    }
-    return acc;
-  }
+  // ---- fixed base: k*G over the one-lane comb table ----
+  ELL_HD static J comb_mul(const u32 (&k)[8], const W1::A* comb) { return coop_comb_mul<CoopK256>(k, comb); }
   // EC#verify, part 2: u1*G
   ELL_HD static void ecdsa_fixed(size_t i, size_t n, const u32* u12, const W1::A* comb, u32* jac) {
     u32 u1[8];
@@ -185,6 +224,133 @@ struct CoopK256 {
     u32 k[8];
     load_be<8>(k, ks + i * 32, 32);
     store_jac(jac, n, i, comb_mul(k, comb));
+  }
+};
+
+
+// ---- the NIST curves up to 256 bits on the row layer (coop_mont.h) --------------------------------
+// No endomorphism: a verify is TWO parts -- u2*Q by the odd-digit ladder over a table of its own
+// (work.h var_ladder's plain branch: co-Z table on the isomorphic curves, one inversion to map it
+// back to the curve whose a = -3 doubling the ladder needs) and u1*G by the comb -- joined by the
+// one-lane ecdsa_join2; Point#mul is the ladder alone, normalised by the one-lane kernel.
+template <class CV1>
+struct CoopConsts { static constexpr bool AVAILABLE = false; typedef consts::COOP_P256 MC; };
+template <> struct CoopConsts<CvP192> { static constexpr bool AVAILABLE = true; typedef consts::COOP_P192 MC; };
+template <> struct CoopConsts<CvP224> { static constexpr bool AVAILABLE = true; typedef consts::COOP_P224 MC; };
+template <> struct CoopConsts<CvP256> { static constexpr bool AVAILABLE = true; typedef consts::COOP_P256 MC; };
+
+template <class CV1>
+struct CoopNist {
+  typedef typename CoopConsts<CV1>::MC MC;
+  static constexpr bool AVAILABLE = CoopConsts<CV1>::AVAILABLE;
+  struct CV {
+    typedef FpMontC<MC, typename CV1::F> F;
+    typedef typename CV1::Fn Fn;
+    typedef typename CV1::C C;
+    static constexpr int A_KIND = CV1::A_KIND;
+    static constexpr bool ENDO = false;
+    static constexpr bool JTABLE = false;
+    static constexpr int ID = CV1::ID;
+  };
+  typedef typename CV::F F;
+  typedef typename F::El El;
+  typedef ShortOps<CV> G;
+  typedef Ladder<CV> LD;
+  typedef Jac<F> J;
+  typedef Aff<F> A;
+  typedef Work<CV1> W1;
+  static constexpr int L = W1::L;
+  static constexpr int NE = W1::PLAIN_NE, NW = W1::PLAIN_NW, WB = W1::PLAIN_WB;
+  static constexpr int SLOTS = 2 * NE;
+  static constexpr int ROW_BYTES = SLOTS * FpK256C::ROW * 16;
+
+  ELL_HD static A* lane_table(void* row_mem) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (A*)row_mem + (size_t)(threadIdx.x & 15u) * SLOTS;
+#else
+    return (A*)row_mem;
+#endif
+  }
+  ELL_HD static bool writer() { return CoopK256::writer(); }
+  ELL_HD static A load_entry(const typename W1::A* e) {
+    A q;
+    q.x = F::load_words(e->x.v);
+    q.y = F::load_words(e->y.v);
+    return q;
+  }
+  ELL_HD static A load_affine(const u8* xy, size_t i) {
+    u32 tx[L], ty[L];
+    load_be<L>(tx, xy + i * 2 * W1::BYTES, W1::BYTES);
+    load_be<L>(ty, xy + i * 2 * W1::BYTES + W1::BYTES, W1::BYTES);
+    A q;
+    q.x = F::from_plain(tx);
+    q.y = F::from_plain(ty);
+    return q;
+  }
+  // -> the one-lane kernels' format (W1::store_jac: the field's words, limb-major; FpSolinas: plain)
+  ELL_HD static void store_jac(u32* jac, size_t n, size_t i, const J& p) {
+    u32 x[L], y[L], z[L];
+    F::to_plain(x, p.X);
+    F::to_plain(y, p.Y);
+    F::to_plain(z, p.Z);
+    if (CoopK256::writer()) {
+      ELL_UNROLL
+      for (int l = 0; l < L; l++) {
+        jac[(size_t)(0 * L + l) * n + i] = x[l];
+        jac[(size_t)(1 * L + l) * n + i] = y[l];
+        jac[(size_t)(2 * L + l) * n + i] = z[l];
+      }
+    }
+  }
+  // k*P (work.h var_ladder, the curves without an endomorphism)
+  ELL_HD static J ladder(const u32 (&k)[L], const A& p, const DigitStore& ds, A* tbl) {
+    u32 kk[L];
+    bn_copy<L>(kk, k);
+    const u32 evenmask = (k[0] & 1u) ? 0u : 1u;
+    kk[0] |= 1u;                                    // k even -> k + 1, P subtracted at the end
+    recode_odd_w4<L, NW, WB>(kk, ds, 0, 1);
+    El zg;
+    LD::template build_table_odd8<NE>(tbl, p, zg);
+    El zi = F::inv(zg);
+    El zi2 = F::sqr(zi);
+    El zi3 = F::mul(zi2, zi);
+    ELL_NOUNROLL
+    for (int e = 0; e < NE; e++) {
+      A t = tbl[e];
+      t.x = F::mul(t.x, zi2);
+      t.y = F::mul(t.y, zi3);
+      tbl[e] = t;
+    }
+    bool inf;
+    return LD::template run_odd_w4<1, NW, false, false, WB>(ds, tbl, 0u, evenmask, inf);
+  }
+  // EC#verify part 0: u2*Q
+  ELL_HD static void ecdsa_var(size_t i, size_t n, const u32* u12, const u8* pub_xy, const DigitStore& ds,
+                               u32* jac, void* row_mem) {
+    u32 u2[L];
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) u2[l] = l < W1::LN ? u12[(size_t)(1 * W1::LN + l) * n + i] : 0u;
+    store_jac(jac, n, i, ladder(u2, load_affine(pub_xy, i), ds, lane_table(row_mem)));
+  }
+  // EC#verify part 1: u1*G
+  ELL_HD static void ecdsa_fixed(size_t i, size_t n, const u32* u12, const typename W1::A* comb, u32* jac) {
+    u32 u1[L];
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) u1[l] = l < W1::LN ? u12[(size_t)(0 * W1::LN + l) * n + i] : 0u;
+    store_jac(jac, n, i, coop_comb_mul<CoopNist<CV1>>(u1, comb));
+  }
+  // Point#mul
+  ELL_HD static void mul_var(size_t i, size_t n, const u8* ks, const u8* xy, const DigitStore& ds, u32* jac,
+                             void* row_mem) {
+    u32 k[L];
+    load_be<L>(k, ks + i * W1::BYTES, W1::BYTES);
+    store_jac(jac, n, i, ladder(k, load_affine(xy, i), ds, lane_table(row_mem)));
+  }
+  // the comb of k1 in k1*G + k2*P
+  ELL_HD static void mul_fixed_part(size_t i, size_t n, const u8* ks, const typename W1::A* comb, u32* jac) {
+    u32 k[L];
+    load_be<L>(k, ks + i * W1::BYTES, W1::BYTES);
+    store_jac(jac, n, i, coop_comb_mul<CoopNist<CV1>>(k, comb));
   }
 };
 

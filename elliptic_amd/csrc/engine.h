@@ -358,6 +358,53 @@ struct FnMulPartsC {
   }
 };
 
+// ... and for the NIST curves up to 256 bits (coop_mont.h, coop_work.h CoopNist): a verify is two
+// units (u2*Q ladder, u1*G comb), a Point#mul one, k1*G + k2*P two
+template <class CV>
+struct FnEcdsaPartsN {
+  static constexpr const char* NAME = "ecdsa_parts_c";
+  typedef Work<CV> W;
+  typedef CoopNist<CV> CW;
+  static constexpr int DS_PER_LANE = CW::NW;
+  static constexpr int ROW_BYTES = CW::ROW_BYTES;
+  size_t n; const u32* u12; const u8* pub; const typename W::A* comb; u32* jac;
+  ELL_HD void operator()(size_t unit, const DigitStore& ds, void* row_mem) const {
+    const int part = (int)(unit / n);
+    const size_t i = unit - (size_t)part * n;
+    u32* out = jac + (size_t)part * 3 * W::NS * n;
+    if (part == 1) CW::ecdsa_fixed(i, n, u12, comb, out);
+    else CW::ecdsa_var(i, n, u12, pub, ds, out, row_mem);
+  }
+};
+template <class CV>
+struct FnMulPartsN {
+  static constexpr const char* NAME = "mul_parts_c";
+  typedef Work<CV> W;
+  typedef CoopNist<CV> CW;
+  static constexpr int DS_PER_LANE = CW::NW;
+  static constexpr int ROW_BYTES = CW::ROW_BYTES;
+  // kg != null: k*P + kg*G -- the units of a second range run the comb of kg
+  size_t n; const u8* k; const u8* xy; u32* jac; const u8* kg; const typename W::A* comb;
+  ELL_HD void operator()(size_t unit, const DigitStore& ds, void* row_mem) const {
+    const int part = (int)(unit / n);
+    const size_t i = unit - (size_t)part * n;
+    u32* out = jac + (size_t)part * 3 * W::NS * n;
+    if (part == 1) CW::mul_fixed_part(i, n, kg, comb, out);
+    else CW::mul_var(i, n, k, xy, ds, out, row_mem);
+  }
+};
+template <class CV>
+struct FnEcdsaJoin2 {
+  static constexpr const char* NAME = "ecdsa_join";
+  typedef Work<CV> W;
+  static constexpr int MIN_WAVES = 2;
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* valid; const u8* r; const u8* pub; const u32* jac; u8* ok; u8* st;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) W::ecdsa_join2(i, n, valid, r, pub, jac, ok, st);
+  }
+};
+
 // Point#mul in the parted form (Work::mul_half / mul_join)
 template <class CV>
 struct FnMulParts {
@@ -407,10 +454,26 @@ struct FnSignFinish {
   static constexpr int DS_PER_LANE = 0;
   size_t T; size_t n; int K; const u8* hash; int hash_len; int shift; const u8* priv;
   const u8* nonces; const u8* kg_xy; const u8* kg_inf; int canonical; u32* pre;
-  u8* out_r; u8* out_s; u8* out_recid; u8* out_ok;
+  u8* out_r; u8* out_s; u8* out_recid; u8* out_ok; const u32* kinv;
   ELL_HD void operator()(size_t t, const DigitStore&) const {
     if (t < T) W::sign_finish(t, T, n, K, hash, hash_len, shift, priv, nonces, kg_xy, kg_inf, canonical,
-                              pre, out_r, out_s, out_recid, out_ok);
+                              pre, out_r, out_s, out_recid, out_ok, kinv);
+  }
+};
+// EC#sign's middle for a handful of items, ONE launch of the row layer (k_run_coop): unit i < n
+// computes k_i*G on a wave of its own and leaves it affine (coop_work.h coop_sign_point), unit
+// n + i inverts k_i mod n beside it (Work::sign_kinv) -- sign_mul, normalize and the inversion of
+// sign_finish were three dependent one-lane launches.  CW: CoopK256 / CoopNist<CV>.
+template <class CV, class CW>
+struct FnSignPartsC {
+  static constexpr const char* NAME = "sign_parts_c";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  static constexpr int ROW_BYTES = 16;
+  size_t n; const u8* nonces; const typename W::A* comb; u8* kg_xy; u8* kg_inf; u32* kinv;
+  ELL_HD void operator()(size_t unit, const DigitStore&, void*) const {
+    if (unit < n) coop_sign_point<CW>(unit, nonces, comb, kg_xy, kg_inf);
+    else W::sign_kinv(unit - n, n, nonces, kinv, CW::writer());
   }
 };
 template <class CV>
@@ -2141,6 +2204,15 @@ int Engine<BK>::mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u
       launched = true;
     }
   }
+  if constexpr (!CV::ENDO && CoopNist<CV>::AVAILABLE) {
+    // a handful of items: the ladder of every item on a wave of its own (the row layer); the
+    // normalisation and the domain test below are the one-lane kernels'
+    if (!launched && n <= coop_grid() && out_inf) {
+      FnMulPartsN<CV> fc{n, k, xy, jac, nullptr, nullptr};
+      bk.launch_coop(fc, n);
+      launched = true;
+    }
+  }
   if (launched) {
   } else if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
     FnMulVar<CV, (W::L > 12 ? 2 : 0)> f{n, k, xy, tbl, jac};
@@ -2214,6 +2286,16 @@ int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* 
       launch_fn(fp, 2 * npad + n);
       }
       FnMulJoin<CV> fj{n, pj, true, xy2, out_xy, out_inf, nullptr};
+      return launch_fn(fj, n);
+    }
+  }
+  if constexpr (!CV::ENDO && CoopNist<CV>::AVAILABLE) {
+    if (n <= coop_grid()) {                 // the ladder of k2 and the comb of k1 on a wave each, joined on one lane
+      u32* pj = (u32*)scratch(S_JAC, 2 * n * 3 * W::NS * 4);
+      if (!pj) return fail(E_NOMEM, "scratch allocation failed");
+      FnMulPartsN<CV> fc{n, k2, xy2, pj, k1, (const typename W::A*)comb_[CV::ID]};
+      bk.launch_coop(fc, 2 * n);
+      FnMulJoin<CV> fj{n, pj, false, xy2, out_xy, out_inf, nullptr};
       return launch_fn(fj, n);
     }
   }
@@ -2321,6 +2403,21 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
       }
       FnEcdsaLadder<CV, true> fl{n, u12, valid, r, pub, (const typename W::A*)comb_[CV::ID], tbl, ok, st};
       return launch_fn(fl, n);
+    }
+  }
+  if constexpr (!CV::ENDO && CoopNist<CV>::AVAILABLE) {
+    if (n <= coop_grid()) {
+      // a handful of items on a curve without an endomorphism: the scalar-field prep as it is
+      // (one inversion per item), then the ladder and the comb of every item on a WAVE each (the
+      // row layer, coop_mont.h), and the one-lane join
+      FnEcdsaPrep<CV> fp1{n, n, 1, hash, hash_len, shift, r, s, pre, u12, valid};
+      launch_fn(fp1, n);
+      u32* jac = (u32*)scratch(S_JAC, n * 2 * 3 * W::NS * 4);
+      if (!jac) return fail(E_NOMEM, "scratch allocation failed");
+      FnEcdsaPartsN<CV> fc{n, u12, pub, (const typename W::A*)comb_[CV::ID], jac};
+      bk.launch_coop(fc, 2 * n);
+      FnEcdsaJoin2<CV> fj{n, valid, r, pub, jac, ok, st};
+      return launch_fn(fj, n);
     }
   }
   launch_fn(f1, T);
@@ -2662,6 +2759,23 @@ int Engine<BK>::sign_chunk(size_t n, const u8* hash, int hash_len, int shift, co
   u8* kg = (u8*)scratch(S_U12, n * (2 * W::BYTES + 1));          // k*G affine + infinity flags
   if (!jac || !kg) return fail(E_NOMEM, "scratch allocation failed");
   u8* kg_inf = kg + n * 2 * W::BYTES;
+  // a handful of items: k*G (comb + its own inversion) and k^-1 mod n on a wave each, one launch;
+  // then the finish without an inversion of its own
+  constexpr bool row_k256 = CV::ENDO && W::L <= 8 && CoopK256::AVAILABLE;
+  constexpr bool row_nist = !CV::ENDO && CoopNist<CV>::AVAILABLE;
+  if constexpr (row_k256 || row_nist) {
+    if (n <= coop_grid()) {
+      u32* kinv = (u32*)scratch(S_PRE, n * 2 * (W::LN > W::NS ? W::LN : W::NS) * 4);
+      if (!kinv) return fail(E_NOMEM, "scratch allocation failed");
+      u32* pre2 = kinv + n * (W::LN > W::NS ? W::LN : W::NS);
+      typedef typename std::conditional<row_k256, CoopK256, CoopNist<CV>>::type CW;
+      FnSignPartsC<CV, CW> fc{n, nonces, (const typename W::A*)comb_[CV::ID], kg, kg_inf, kinv};
+      bk.launch_coop(fc, 2 * n);
+      FnSignFinish<CV> f2{n, n, 1, hash, hash_len, shift, priv, nonces, kg, kg_inf, canonical, pre2,
+                          out_r, out_s, out_recid, out_ok, kinv};
+      return launch_fn(f2, n);
+    }
+  }
   if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
     FnSignMul<CV, (W::L > 12 ? 2 : 0)> f1{n, nonces, (const typename W::A*)comb_[CV::ID], jac};
     bk.launch(f1, n);
@@ -2676,7 +2790,7 @@ int Engine<BK>::sign_chunk(size_t n, const u8* hash, int hash_len, int shift, co
   const int Kf = inv_batch_for(n, INV_BATCH_N);
   size_t T = (n + Kf - 1) / Kf;
   FnSignFinish<CV> f2{T, n, Kf, hash, hash_len, shift, priv, nonces, kg, kg_inf, canonical, pre,
-                      out_r, out_s, out_recid, out_ok};
+                      out_r, out_s, out_recid, out_ok, nullptr};
   launch_fn(f2, T);
   return E_OK;
 }

@@ -59,8 +59,10 @@ __global__ void __launch_bounds__(BLOCK, MinWaves<Fn>::value) k_run(const Fn f, 
 // The lanes-per-item layer (coop.h): ONE unit per workgroup of one wave; lanes 0..15 -- one DPP
 // row -- carry the unit's field elements, the other three rows sit the kernel out.  LDS: the digit
 // columns and Fn::ROW_BYTES of row memory (every lane's own window table).
+// (at most two waves per SIMD are ever resident: the register allocator may keep every
+// loop-invariant row constant -- the shifted copies of p, the lane masks -- in registers)
 template <class Fn>
-__global__ void __launch_bounds__(64) k_run_coop(const Fn f, size_t units) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_run_coop(const Fn f, size_t units) {
   __shared__ signed char lds_digits[(Fn::DS_PER_LANE > 0 ? Fn::DS_PER_LANE : 1) * 64];
   __shared__ __attribute__((aligned(16))) unsigned char lds_rows[Fn::ROW_BYTES];
   if (threadIdx.x >= 16u || (size_t)blockIdx.x >= units) return;

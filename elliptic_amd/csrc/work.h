@@ -997,13 +997,30 @@ struct Work {
     J r = LD::template comb_mul<L, COMB_W, COMB_BITS, COMB_SIGNED>(kk, comb);
     store_jac(jac, n, i, r);
   }
+  // k^-1 R mod n for item i (1 where the nonce is outside [2, n - 2]: sign_finish rejects it),
+  // limb-major -- the parted sign's inversion, on a wave beside the one that computes k*G
+  ELL_HD static void sign_kinv(size_t i, size_t n, const u8* nonces, u32* kinv, bool writer) {
+    u32 nn[LN], nm1[LN], one1[LN], k[LN];
+    ELL_UNROLL
+    for (int l = 0; l < LN; l++) { nn[l] = C::n[l]; one1[l] = l == 0 ? 1u : 0u; }
+    bn_sub<LN>(nm1, nn, one1);
+    load_nonce(k, nonces + i * NBYTES);
+    const bool ok = !bn_is_zero<LN>(k) && !bn_eq<LN>(k, one1) && !bn_geq<LN>(k, nm1);
+    Nl v = Fn::inv(fe_select<Fn>(ok, Fn::from_plain(k), Fn::one()));
+    if (writer) {
+      ELL_UNROLL
+      for (int l = 0; l < LN; l++) kinv[(size_t)l * n + i] = v.v[l];
+    }
+  }
   // pass B: thread t finishes items t, t+T, ...: r = x mod n, s = k^-1 (z + r d) mod n with
   // one inversion per K items, recovery parameter, optional low-s form.  ok = 0 where the
   // reference would go on to its next nonce (k <= 1, k >= n-1, k*G = O, r = 0, s = 0).
   ELL_HD static void sign_finish(size_t t, size_t T, size_t n, int K, const u8* hash, int hash_len,
                                  int shift, const u8* priv, const u8* nonces, const u8* kg_xy,
                                  const u8* kg_inf, int canonical, u32* pre, u8* out_r, u8* out_s,
-                                 u8* out_recid, u8* out_ok) {
+                                 u8* out_recid, u8* out_ok, const u32* kinv_in = nullptr) {
+    // kinv_in (small batches, K = 1): k^-1 R mod n per item (limb-major), computed BESIDE k*G by a
+    // wave of its own (sign_kinv below) -- the inversion is then off this kernel's chain
     u32 nn[LN], nm1[LN], one1[LN];
     ELL_UNROLL
     for (int l = 0; l < LN; l++) { nn[l] = C::n[l]; one1[l] = l == 0 ? 1u : 0u; }
@@ -1022,7 +1039,13 @@ struct Work {
       for (int l = 0; l < LN; l++) pre[(size_t)l * n + i] = acc.v[l];
       acc = Fn::mul(acc, km);
     }
-    Nl inv = Fn::inv(acc);
+    Nl inv = Fn::one();
+    if (kinv_in) {
+      ELL_UNROLL
+      for (int l = 0; l < LN; l++) inv.v[l] = kinv_in[(size_t)l * n + t];      // (K = 1: item t, prefix = one)
+    } else {
+      inv = Fn::inv(acc);
+    }
     ELL_NOUNROLL
     for (int j = K - 1; j >= 0; j--) {
       size_t i = t + (size_t)j * T;
@@ -1200,6 +1223,20 @@ struct Work {
     bool ok = !G::is_inf(p);
     ok = ok && eq_x_to_p(p, r);
     const bool on = on_curve(load_affine(pub_xy, i));      // see ecdsa_main
+    store_verdict(i, valid[i], on, ok, out_ok, out_st);
+  }
+
+  // The join of the curves without an endomorphism (two parts: u2*Q and u1*G, computed by the
+  // row layer's waves, coop_work.h CoopNist): their sum, the x test, the verdict.
+  ELL_HD static void ecdsa_join2(size_t i, size_t n, const u8* valid, const u8* rs, const u8* pub_xy,
+                                 const u32* jac, u8* out_ok, u8* out_st) {
+    const size_t part = (size_t)3 * NS * n;
+    J p = G::add(load_jac(jac, n, i), load_jac(jac + part, n, i));     // any of O, P = Q, P = -Q included
+    u32 r[LN];
+    load_be<LN>(r, rs + i * NBYTES, NBYTES);
+    bool ok = !G::is_inf(p);
+    ok = ok && eq_x_to_p(p, r);
+    const bool on = on_curve(load_affine(pub_xy, i));
     store_verdict(i, valid[i], on, ok, out_ok, out_st);
   }
 

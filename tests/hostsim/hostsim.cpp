@@ -178,6 +178,7 @@ int hs_field_limbs(int field) {
   switch (field) {
     case 0: case 1: case 2: case 3: return 8;
     case 10: return 8; case 11: return 6; case 12: return 7; case 13: return 8; case 14: return 12; case 15: return 17;
+    case 31: return 6; case 32: return 7; case 33: return 8;
     case 20: return 8; case 21: return 6; case 22: return 7; case 23: return 8; case 24: return 12; case 25: return 17;
     case 26: return 8;
   }
@@ -188,6 +189,10 @@ int hs_field_op(int field, int op, const u32* a, const u32* b, u32* r) {
     case 0: field_op<FpK256>(op, a, b, r); break;
     case 2: field_op<FpK256L>(op, a, b, r); break;
     case 3: field_op<FpK256C>(op, a, b, r); break;
+    // the row layer's Montgomery fields (csrc/coop_mont.h), host simulation of the row
+    case 31: field_op<CoopNist<CvP192>::F>(op, a, b, r); break;
+    case 32: field_op<CoopNist<CvP224>::F>(op, a, b, r); break;
+    case 33: field_op<CoopNist<CvP256>::F>(op, a, b, r); break;
     case 1:
       if (op == 10) {                      // mul_u32 by the one-limb constant b[0]
         u32 ta[8];

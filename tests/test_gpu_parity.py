@@ -524,6 +524,99 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("curve", ["p256", "p224", "p192"])
+def test_nist_small_batches_on_the_row_layer(monkeypatch, curve):
+    """Batches of at most ELLGPU_COOP_GRID items on the NIST curves up to 256 bits run every item's
+    ladder and comb on a wave of its own (csrc/coop_mont.h: a Montgomery field of nine 29-bit limbs
+    across a 16-lane DPP row; coop_work.h CoopNist), joined by one-lane kernels.  Same bytes as the
+    one-item-per-lane kernels (ELLGPU_COOP_GRID=0) for verify (valid, corrupted, off-curve keys, r
+    or s out of range), P*k (k = 0, 1, n - 1, n, n + 1, 2^(8B) - 1 included), k1*G + k2*P, and the
+    reference's fixtures through both."""
+    B = elliptic_amd.FIELD_BYTES[curve]
+    monkeypatch.setenv("ELLGPU_COOP_GRID", "0")
+    c0 = elliptic_amd.Context(0)
+    monkeypatch.setenv("ELLGPU_COOP_GRID", str(1 << 30))
+    c1 = elliptic_amd.Context(0)
+    monkeypatch.delenv("ELLGPU_COOP_GRID")
+    cd = elliptic_amd.Context(0)
+    cur = O.get_curve(curve)
+    n = 1500
+    raw = np.frombuffer(hashlib.shake_256(("row-layer:" + curve).encode()).digest(n * 4 * B), dtype=np.uint8).reshape(n, 4 * B)
+    d, k, z, e = (np.ascontiguousarray(raw[:, i * B:(i + 1) * B]) for i in range(4))
+    for i, kv in enumerate((0, 1, 2, cur.n - 1, cur.n, cur.n + 1, (1 << (8 * B)) - 1)):
+        k[10 + i] = np.frombuffer(int(kv).to_bytes(B, "big"), np.uint8)
+    pts, _ = c0.mul_fixed(curve, d)
+    r, s_, rec, okk = c0.ecdsa_sign_det(curve, z, d)
+    assert okk.all()
+    zz = z.copy()
+    zz[::7, 0] ^= 1                                      # corrupted digests
+    rr = r.copy()
+    rr[3] = 0                                            # r = 0
+    bad = pts.copy()
+    bad[5::11, 2 * B - 1] ^= 1                           # keys off the curve
+    for m in (1, 2, 17, 64, 65, 300, 682, 683, 1500):
+        outs = []
+        for c, rowk in ((c0, False), (c1, True), (cd, m <= 682)):
+            c.set_timing(True)
+            v = c.ecdsa_verify(curve, zz[:m], rr[:m], s_[:m], bad[:m], status=True)
+            tm = c.get_timing()
+            assert ("ecdsa_parts_c" in tm) == rowk and ("ecdsa_main" in tm) != rowk, (curve, m, rowk, sorted(tm))
+            mv = c.mul_var(curve, k[:m], pts[:m])
+            tm = c.get_timing()
+            assert ("mul_parts_c" in tm) == rowk, (curve, m, rowk, sorted(tm))
+            ma = c.mul_add2(curve, e[:m], None, k[:m], pts[:m])
+            c.set_timing(False)
+            outs.append((v, mv, ma))
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (curve, m)
+    ok, st = outs[0][0]
+    assert ok[1::7][:50].sum() > 30 and not ok[::7].any() and (st[5::11] == 2).sum() > 100 and ok[3] == 0
+    for c in (c0, c1):
+        assert PC.check_verify_golden(c, curve) > 15 and PC.check_mul_golden(c, curve) > 50
+        assert PC.check_offcurve_golden(c, curve) >= 29
+        if curve != "p192":
+            assert PC.check_exceptional_keys(c, curve) > 400
+    for c in (c0, c1, cd):
+        c.close()
+
+
+@pytest.mark.parametrize("curve", ["secp256k1", "p256", "p224", "p192"])
+def test_small_batch_sign_on_the_row_layer(monkeypatch, curve):
+    """EC#sign for a handful of items: k*G (comb + the item's own inversion) and k^-1 mod n on a
+    wave each in ONE launch of the row layer (sign_parts_c), then sign_finish without an inversion
+    -- instead of sign_mul -> normalize -> sign_finish with its inversion.  Same (r, s, recovery
+    parameter, ok) as the one-lane pipeline: deterministic nonces, supplied nonces incl. k = 0, 1,
+    n - 1 (rejected), canonical form."""
+    B, NB = elliptic_amd.FIELD_BYTES[curve], elliptic_amd.ORDER_BYTES[curve]
+    monkeypatch.setenv("ELLGPU_COOP_GRID", "0")
+    c0 = elliptic_amd.Context(0)
+    monkeypatch.delenv("ELLGPU_COOP_GRID")
+    c1 = elliptic_amd.Context(0)
+    cur = O.get_curve(curve)
+    n = 700
+    raw = np.frombuffer(hashlib.shake_256(("row-sign:" + curve).encode()).digest(n * 3 * NB), dtype=np.uint8).reshape(n, 3 * NB)
+    d, z, kn = (np.ascontiguousarray(raw[:, i * NB:(i + 1) * NB]) for i in range(3))
+    for i, kv in enumerate((0, 1, cur.n - 1, 2, cur.n - 2)):
+        kn[20 + i] = np.frombuffer(int(kv).to_bytes(NB, "big"), np.uint8)
+    for m in (1, 3, 64, 300, 682, 700):
+        for canonical in (False, True):
+            c1.set_timing(True)
+            a = c1.ecdsa_sign_det(curve, z[:m], d[:m], canonical=canonical)
+            tm = c1.get_timing()
+            c1.set_timing(False)
+            assert ("sign_parts_c" in tm) == (m <= 682) and ("sign_mul" in tm) == (m > 682), (curve, m, sorted(tm))
+            b = c0.ecdsa_sign_det(curve, z[:m], d[:m], canonical=canonical)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), (curve, m, canonical)
+        a = c1.ecdsa_sign(curve, z[:m], d[:m], kn[:m])
+        b = c0.ecdsa_sign(curve, z[:m], d[:m], kn[:m])
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), (curve, m)
+    assert not a[3][20:23].any() and a[3][23:25].all()           # k = 0, 1, n - 1 rejected; 2 and n - 2 signed
+    assert PC.check_sign_golden(c1, curve) > 10 and PC.check_signdet_golden(c1, curve) > 10
+    c0.close()
+    c1.close()
+
+
 def test_fixed_base_table_narrows_when_memory_is_short(ctx, monkeypatch):
     """The signed comb's window width travels with the table (ladder.h comb_bits_of): a context
     that cannot have the default 22-bit table (1.6 GB) builds a 16-bit one (36 MB; here forced

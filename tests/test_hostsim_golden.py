@@ -44,6 +44,8 @@ FIELDS = {
     22: O.get_curve("p224", False).n, 23: O.get_curve("p256", False).n,
     24: O.get_curve("p384", False).n, 25: O.get_curve("p521", False).n,
     26: O.get_curve("ed25519", False).n,
+    # the row layer's Montgomery fields (csrc/coop_mont.h: nine 29-bit limbs across a 16-lane row, R = 2^261)
+    31: O.get_curve("p192", False).p, 32: O.get_curve("p224", False).p, 33: O.get_curve("p256", False).p,
 }
 
 
@@ -334,6 +336,29 @@ def test_verify_golden_secp256k1_both_tunings(hs, monkeypatch):
     assert PC.check_verify_golden(c, "secp256k1") > 15
     assert hs.hs_launches(b"ecdsa_parts_c") > 0 and hs.hs_launches(b"ecdsa_parts") == 0
     c.close()
+
+
+@pytest.mark.parametrize("curve", ["p192", "p224", "p256"])
+def test_nist_curves_one_lane_and_row_layer(hs, monkeypatch, curve):
+    """Small batches on the NIST curves up to 256 bits run their ladder and comb on the row layer
+    (csrc/coop_mont.h: a Montgomery field of nine 29-bit limbs across a 16-lane row, one item per
+    wave; work: coop_work.h CoopNist, joined by the one-lane ecdsa_join2 / mul_join);
+    ELLGPU_COOP_GRID=0 keeps them on the one-item-per-lane kernels.  Same results from both."""
+    for coop, rowk in (("0", False), (str(1 << 30), True)):
+        c = _fresh_ctx(hs, monkeypatch, ELLGPU_COOP_GRID=coop)
+        hs.hs_launches_reset()
+        assert PC.check_verify_golden(c, curve) > 15
+        assert PC.check_offcurve_golden(c, curve) >= 29
+        if curve != "p192":
+            assert PC.check_exceptional_keys(c, curve) > 400
+        assert (hs.hs_launches(b"ecdsa_parts_c") > 0) == rowk and (hs.hs_launches(b"ecdsa_main") > 0) != rowk
+        hs.hs_launches_reset()
+        assert PC.check_mul_golden(c, curve) > 50
+        assert (hs.hs_launches(b"mul_parts_c") > 0) == rowk
+        if curve != "p224":
+            assert PC.check_recover_golden(c, curve) >= 30
+        assert PC.check_sign_golden(c, curve) > 10
+        c.close()
 
 
 @pytest.mark.parametrize("curve", ["secp256k1", "p192", "p256", "p384", "p521", "ed25519"])
