@@ -853,10 +853,12 @@ class Engine {
     e = getenv("ELLGPU_PARTED_GRID");
     tune_.parted_grid = e ? (size_t)strtoull(e, nullptr, 10) : tune_.wave_round / 2;
     // ELLGPU_COOP_GRID  largest batch whose parts take a WAVE each (coop.h; 0 = never); default:
-    //                   the three parts of every item find a SIMD of their own, twice over -- above
+    //                   four waves per SIMD's worth of verify parts (1 365 items on 256 CUs) --
+    //                   measured (profiles/r05_small_batch_forms.jsonl): a pass of 1 365 verifies
+    //                   0.64 ms on waves against 0.72 on lanes, of 2 048 0.75 against 0.73; above
     //                   that the waves share SIMDs and the one-lane parts (64 items per wave) win
     e = getenv("ELLGPU_COOP_GRID");
-    tune_.coop_grid = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)bk.compute_units() * 4 * 2 / 3;
+    tune_.coop_grid = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)bk.compute_units() * 4 * 4 / 3;
     e = getenv("ELLGPU_COMB_MAX_BYTES");
     tune_.comb_max_bytes = e ? (size_t)strtoull(e, nullptr, 10) : 0;
     e = getenv("ELLGPU_PREP_K");

@@ -427,7 +427,7 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
     monkeypatch.delenv("ELLGPU_PARTED_GRID")
     monkeypatch.delenv("ELLGPU_COOP_GRID")
     cd = elliptic_amd.Context(0)                       # the default thresholds
-    coop_default = 256 * 4 * 2 // 3                    # engine.h Tuning::coop_grid on 256 CUs
+    coop_default = 256 * 4 * 4 // 3                    # engine.h Tuning::coop_grid on 256 CUs
 
     def forms(m):
         """(context, kernel of the parts or None) for a batch of m items"""
@@ -444,7 +444,7 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
     r = r.copy()
     r[11] = 0                                          # r = 0: rejected before the key is looked at
     want[11] = 0
-    for m in (1, 2, 3, 63, 64, 65, 127, 128, 129, 682, 683, 1000, 4096, 21845, 32768):
+    for m in (1, 2, 3, 63, 64, 65, 127, 128, 129, 1000, 1365, 1366, 4096, 21845, 32768):
         sl = (h[:m], r[:m], s[:m], pub[:m])
         for c, parts in forms(m):
             if c is c2 and m > 4096:
@@ -476,7 +476,7 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
     ks = r.copy()
     for i, kv in enumerate((0, nn, nn + 1, (1 << 256) - 1, 1, 2, nn - 1)):
         ks[20 + i] = np.frombuffer(kv.to_bytes(32, "big"), np.uint8)
-    for m in (1, 27, 64, 65, 129, 683, 4096, 32768):
+    for m in (1, 27, 64, 65, 129, 1366, 4096, 32768):
         outs = []
         for c, parts in forms(m):
             if c is c2 and m > 4096:
@@ -554,9 +554,9 @@ def test_nist_small_batches_on_the_row_layer(monkeypatch, curve):
     rr[3] = 0                                            # r = 0
     bad = pts.copy()
     bad[5::11, 2 * B - 1] ^= 1                           # keys off the curve
-    for m in (1, 2, 17, 64, 65, 300, 682, 683, 1500):
+    for m in (1, 2, 17, 64, 65, 300, 1365, 1366, 1500):
         outs = []
-        for c, rowk in ((c0, False), (c1, True), (cd, m <= 682)):
+        for c, rowk in ((c0, False), (c1, True), (cd, m <= 1365)):
             c.set_timing(True)
             v = c.ecdsa_verify(curve, zz[:m], rr[:m], s_[:m], bad[:m], status=True)
             tm = c.get_timing()
@@ -594,18 +594,18 @@ def test_small_batch_sign_on_the_row_layer(monkeypatch, curve):
     monkeypatch.delenv("ELLGPU_COOP_GRID")
     c1 = elliptic_amd.Context(0)
     cur = O.get_curve(curve)
-    n = 700
+    n = 1400
     raw = np.frombuffer(hashlib.shake_256(("row-sign:" + curve).encode()).digest(n * 3 * NB), dtype=np.uint8).reshape(n, 3 * NB)
     d, z, kn = (np.ascontiguousarray(raw[:, i * NB:(i + 1) * NB]) for i in range(3))
     for i, kv in enumerate((0, 1, cur.n - 1, 2, cur.n - 2)):
         kn[20 + i] = np.frombuffer(int(kv).to_bytes(NB, "big"), np.uint8)
-    for m in (1, 3, 64, 300, 682, 700):
+    for m in (1, 3, 64, 300, 1365, 1400):
         for canonical in (False, True):
             c1.set_timing(True)
             a = c1.ecdsa_sign_det(curve, z[:m], d[:m], canonical=canonical)
             tm = c1.get_timing()
             c1.set_timing(False)
-            assert ("sign_parts_c" in tm) == (m <= 682) and ("sign_mul" in tm) == (m > 682), (curve, m, sorted(tm))
+            assert ("sign_parts_c" in tm) == (m <= 1365) and ("sign_mul" in tm) == (m > 1365), (curve, m, sorted(tm))
             b = c0.ecdsa_sign_det(curve, z[:m], d[:m], canonical=canonical)
             assert all(np.array_equal(x, y) for x, y in zip(a, b)), (curve, m, canonical)
         a = c1.ecdsa_sign(curve, z[:m], d[:m], kn[:m])

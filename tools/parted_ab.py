@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the parted verify (three lanes per item, engine.h FnEcdsaParts) against the one-lane
-ladder at small batch sizes, on ONE GPU box (developer tool; the override is read when a context
+"""A/B of the parted verify (three lanes per item, engine.h FnEcdsaParts; three WAVES per item on
+the row layer, FnEcdsaPartsC) against the one-lane ladder at small batch sizes, on ONE GPU box (developer tool; the override is read when a context
 is created, so each leg is its own process).
 
     python tools/parted_ab.py [--sizes=1,64,1024,...] [--reps=200]
@@ -17,7 +17,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SIZES = [1, 16, 64, 256, 1024, 4096, 8192, 16384, 21760, 32768, 49152, 65536]
+SIZES = [1, 16, 64, 128, 256, 341, 512, 682, 1024, 1365, 2048, 4096, 16384, 32768, 65536]
 
 
 def child(sizes, reps):
@@ -32,6 +32,7 @@ def child(sizes, reps):
     dh, dr, dsg, dq = (torch.from_numpy(x).to(dev) for x in (h, r, s, pub))
     ctx.reserve("secp256k1", n0)
     grid = os.environ.get("ELLGPU_PARTED_GRID")
+    coop = os.environ.get("ELLGPU_COOP_GRID")
     for n in sizes:
         dok = torch.zeros(n, dtype=torch.uint8, device=dev)
         args = (dh[:n], dr[:n], dsg[:n], dq[:n], dok)
@@ -47,7 +48,7 @@ def child(sizes, reps):
         dt = (time.perf_counter() - t0) / reps
         tm = ctx.get_timing()
         ctx.set_timing(False)
-        out = {"lib": os.path.basename(os.environ.get("ELLGPU_LIB", "default")), "parted_grid": grid, "n": n, "mask_ok": ok, "pass_ms": round(dt * 1e3, 4),
+        out = {"lib": os.path.basename(os.environ.get("ELLGPU_LIB", "default")), "parted_grid": grid, "coop_grid": coop, "n": n, "mask_ok": ok, "pass_ms": round(dt * 1e3, 4),
                "kernels_ms": {k: round(v[1] / max(v[0], 1), 4) for k, v in tm.items()}}
         if n <= 4096:
             z, rr, ss, q = h[:n].copy(), r[:n].copy(), s[:n].copy(), pub[:n].copy()
@@ -73,8 +74,11 @@ def main():
     if "--child" in sys.argv:
         child(sizes, reps)
         return
-    for grid in ("0", str(1 << 30)) * (1 if "--once" in sys.argv else 2):
-        env = dict(os.environ, ELLGPU_PARTED_GRID=grid)
+    # three forms of a small batch: the whole ladder on one lane; the parts one item per lane; the
+    # parts one item per WAVE (the row layer, csrc/coop.h) -- each leg its own process
+    big = str(1 << 30)
+    for grid, coop in (("0", "0"), (big, "0"), (big, big)) * (1 if "--once" in sys.argv else 2):
+        env = dict(os.environ, ELLGPU_PARTED_GRID=grid, ELLGPU_COOP_GRID=coop)
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--sizes=" + ",".join(map(str, sizes)),
                             "--reps=%d" % reps], env=env, capture_output=True, text=True, timeout=900)
         lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
