@@ -101,6 +101,35 @@ __global__ void __launch_bounds__(64) k_probe_field(u32* out, int iters, u32 see
   out[(size_t)blockIdx.x * 64 + threadIdx.x] = acc ^ (inf ? 1u : 0u);
 }
 
+// the same chains on the lanes-per-item layer (coop.h; one item per wave): kind 20 product chain,
+// 24 Jacobian doublings, 25 mixed additions -- what ONE item's critical path pays per operation
+template <int KIND>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_probe_row(u32* out, int iters, u32 seed) {
+  typedef FpK256C F;
+  typedef ShortOps<CvSecp256k1C> G;
+  u32 xs[8], ys[8], zs[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    xs[i] = seed * (i + 1) + blockIdx.x * 2654435761u;
+    ys[i] = (seed ^ 0x9E3779B9u) * (i + 3) + blockIdx.x;
+    zs[i] = seed + i * 0x1234567u + blockIdx.x * 7u;
+  }
+  xs[7] &= 0x7FFFFFFFu; ys[7] &= 0x7FFFFFFFu; zs[7] &= 0x7FFFFFFFu;
+  F::El x = F::from_plain(xs), y = F::from_plain(ys), z = F::from_plain(zs);
+  G::J p;
+  p.X = x; p.Y = y; p.Z = z;
+  G::A q;
+  q.x = y; q.y = z;
+  bool inf = false;
+#pragma nounroll
+  for (int it = 0; it < iters; it++) {
+    if (KIND == 20) x = F::mul(x, y);
+    else if (KIND == 24) p = G::dbl(p);
+    else p = G::add_mixed_lean(p, q, inf, [&]() { return q; });
+  }
+  out[(size_t)blockIdx.x * 64 + threadIdx.x] = x.v[0] ^ p.X.v[0] ^ p.Y.v[0] ^ p.Z.v[0] ^ (inf ? 1u : 0u);
+}
+
 // ---- white-box probe: one field operation per lane (tests/test_gpu_field.py) ----
 template <class F, class = void>
 struct ell_has_wide_probe { static constexpr bool value = false; };
@@ -239,6 +268,9 @@ extern "C" int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iter
       case 16: hipLaunchKernelGGL(ell::k_probe_field<16>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       case 17: hipLaunchKernelGGL(ell::k_probe_field<17>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       case 18: hipLaunchKernelGGL(ell::k_probe_field<18>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 20: hipLaunchKernelGGL(ell::k_probe_row<20>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 24: hipLaunchKernelGGL(ell::k_probe_row<24>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 25: hipLaunchKernelGGL(ell::k_probe_row<25>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       default: bk.free_(out); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
                return set_err(ELLGPU_E_ARG, "unknown probe kind");
     }

@@ -72,6 +72,11 @@ struct FpK256C {
     El r;
     ELL_UNROLL
     for (int t = 0; t < CL; t++) r.v[t] = (u32)f(lane_of(t));
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (an opaque register: without it the compiler folds a constant's lane cases into its users
+    // and re-derives them, with branches, inside the ladders' loops)
+    asm("" : "+v"(r.v[0]));
+#endif
     return r;
   }
   // lane l <- lane l - N, zeros shifted in (DPP row_shr:N bound_ctrl:0)
@@ -104,13 +109,24 @@ struct FpK256C {
     return s(x.v[l]);
 #endif
   }
-  // lane LANE <- the wave-uniform value sv
+  // limb I as every lane of the row sees it.  RW = false: the element is the same in the four rows
+  // of the wave (every value outside a `Q` is), lane I of row 0 arrives as a scalar register
+  // (v_readlane); RW = true: each row holds an element of its own, lane I of THIS row is broadcast
+  // along it (DPP row_newbcast) -- the value is a vector register, the arithmetic around it the same
+  template <bool RW, int I>
+  ELL_HD static i32 ln(const El& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (RW) return __builtin_amdgcn_update_dpp(0, (int)x.v[0], 0x150 + I, 0xF, 0xF, false);
+    else return __builtin_amdgcn_readlane((int)x.v[0], I);
+#else
+    return s(x.v[I]);
+#endif
+  }
+  // lane LANE <- sv (in every row of the wave: the rows stay copies of each other)
   template <int LANE>
   ELL_HD static El put(El x, i32 sv) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    int v = (int)x.v[0];
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(sv), "n"(LANE));
-    x.v[0] = (u32)v;
+    x.v[0] = lane_of(0) == LANE ? (u32)sv : x.v[0];
 #else
     x.v[LANE] = (u32)sv;
 #endif
@@ -137,20 +153,95 @@ struct FpK256C {
     return x.w[l];
 #endif
   }
-  // per-lane constants of the algebra (loop-invariant registers on the device)
-  ELL_HD static El c_live() { return each([](int l) { return l <= 8 ? -1 : 0; }); }
-  ELL_HD static El c_mask() { return each([](int l) { return l < 8 ? (i32)M : (l == 8 ? -1 : 0); }); }   // a carry pass keeps these bits
-  ELL_HD static El c_kp() { return each([](int l) { return l == 0 ? -977 : (l == 1 ? -8 : (l == 8 ? (1 << 24) : 0)); }); }   // p - 2^256's part, limb by limb: K p = K * this (+ K 2^256 at limb 8)
-  ELL_HD static El c_kf() { return each([](int l) { return l == 0 ? 977 : (l == 1 ? 8 : 0); }); }       // one unit of limb 8's bit 24 (2^256 = 2^32 + 977)
-  ELL_HD static El c_rr() { return each([](int l) { return l == 0 ? R0 : (l == 1 ? R1 : 0); }); }        // one unit of column 9
-  ELL_HD static El c_r1() { return each([](int l) { return (l >= 1 && l <= 8) ? R1 : 0; }); }
-  ELL_HD static El c_rrr() { return each([](int l) { return l == 0 ? R1 * R0 : (l == 1 ? R1 * R1 : 0); }); }   // one unit of column 17's R1 part (column 9 again)
+  template <bool RW, int I>
+  ELL_HD static i64 ln64(const W64& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (RW) {
+      const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)x.w[0], 0x150 + I, 0xF, 0xF, false);
+      const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)((u64)x.w[0] >> 32), 0x150 + I, 0xF, 0xF, false);
+      return (i64)(((u64)hi << 32) | lo);
+    } else {
+      return at64(x, I);
+    }
+#else
+    return x.w[I];
+#endif
+  }
+
+  // ---- four elements side by side: one per ROW of the wavefront ----------------------------------------
+  // A wave has four 16-lane rows and the item needs one.  Every element outside a Q is held by all
+  // four rows alike (the same instruction computes it four times); a Q holds four DIFFERENT
+  // elements, row j its own, so that ONE product instruction stream multiplies four independent
+  // pairs (mulq) -- the group law below runs its independent products of a step that way
+  // (short.h dbl_lazy / add_mixed_lazy).  On the device a Q is one register; host passes keep the
+  // four rows as four elements.
+  static constexpr bool QUAD = true;
+  static constexpr int QR = CL == 1 ? 1 : 4;
+  struct Q { El r[QR]; };
+  // rows (a, b, a, b)
+  ELL_HD static Q pack2(const El& a, const El& b) {
+    Q q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    q.r[0].v[0] = (threadIdx.x & 16u) ? b.v[0] : a.v[0];
+#else
+    q.r[0] = a; q.r[1] = b; q.r[2] = a; q.r[3] = b;
+#endif
+    return q;
+  }
+  // rows (a, b, c, c)
+  ELL_HD static Q pack3(const El& a, const El& b, const El& c) {
+    Q q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 ab = (threadIdx.x & 16u) ? b.v[0] : a.v[0];
+    q.r[0].v[0] = (threadIdx.x & 32u) ? c.v[0] : ab;
+#else
+    q.r[0] = a; q.r[1] = b; q.r[2] = c; q.r[3] = c;
+#endif
+    return q;
+  }
+  // every row <- rows 0 and 1 of a (.., .., same, same) Q: v_permlane16_swap trades the odd rows
+  // of its first operand for the even rows of its second
+  ELL_HD static void unpack2(const Q& q, El& a, El& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto p = __builtin_amdgcn_permlane16_swap(q.r[0].v[0], q.r[0].v[0], false, false);
+    a.v[0] = p[0];
+    b.v[0] = p[1];
+#else
+    a = q.r[0]; b = q.r[1];
+#endif
+  }
+  // every row <- rows 0, 1, 2: v_permlane32_swap trades the upper half of its first operand for the
+  // lower half of its second, then the row swap within each half
+  ELL_HD static void unpack3(const Q& q, El& a, El& b, El& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto h = __builtin_amdgcn_permlane32_swap(q.r[0].v[0], q.r[0].v[0], false, false);   // (r0 r1 r0 r1), (r2 r3 r2 r3)
+    const auto p = __builtin_amdgcn_permlane16_swap(h[0], h[0], false, false);
+    const auto t = __builtin_amdgcn_permlane16_swap(h[1], h[1], false, false);
+    a.v[0] = p[0];
+    b.v[0] = p[1];
+    c.v[0] = t[0];
+#else
+    a = q.r[0]; b = q.r[1]; c = q.r[2];
+#endif
+  }
+  // per-lane constants of the algebra (loop-invariant registers on the device).  Written as masks,
+  // not as ?: chains: a chain reaches the loop optimiser as control flow, which it does not hoist
+  ELL_HD static u32 m_eq(int l, int i) { return 0u - (u32)(l == i); }
+  ELL_HD static u32 m_lt(int l, int i) { return 0u - (u32)(l < i); }
+  ELL_HD static El c_live() { return each([](int l) { return m_lt(l, 9); }); }
+  ELL_HD static El c_mask() { return each([](int l) { return (m_lt(l, 8) & M) | m_eq(l, 8); }); }   // a carry pass keeps these bits
+  // p - 2^256's part, limb by limb: K p = K * this (+ K 2^256 at limb 8)
+  ELL_HD static El c_kp() { return each([](int l) { return (m_eq(l, 0) & (u32)-977) | (m_eq(l, 1) & (u32)-8) | (m_eq(l, 8) & (1u << 24)); }); }
+  ELL_HD static El c_kf() { return each([](int l) { return (m_eq(l, 0) & 977u) | (m_eq(l, 1) & 8u); }); }       // one unit of limb 8's bit 24 (2^256 = 2^32 + 977)
+  ELL_HD static El c_rr() { return each([](int l) { return (m_eq(l, 0) & (u32)R0) | (m_eq(l, 1) & (u32)R1); }); }        // one unit of column 9
+  ELL_HD static El c_r1() { return each([](int l) { return m_lt(l, 9) & ~m_eq(l, 0) & (u32)R1; }); }
+  ELL_HD static El c_rrr() { return each([](int l) { return (m_eq(l, 0) & (u32)(R1 * R0)) | (m_eq(l, 1) & (u32)(R1 * R1)); }); }   // one unit of column 17's R1 part (column 9 again)
   ELL_HD static El c_p() {
-    return each([](int l) { return l == 0 ? (i32)((1u << 29) - 977u) : (l == 1 ? (i32)((1u << 29) - 9u) : (l < 8 ? (i32)M : (l == 8 ? (1 << 24) - 1 : 0))); });
+    return each([](int l) { return (m_eq(l, 0) & ((1u << 29) - 977u)) | (m_eq(l, 1) & ((1u << 29) - 9u)) | (m_lt(l, 8) & ~m_lt(l, 2) & M) | (m_eq(l, 8) & ((1u << 24) - 1u)); });
   }
 
   ELL_HD static El zero() { return each([](int) { return 0; }); }
-  ELL_HD static El one() { return each([](int l) { return l == 0 ? 1 : 0; }); }
+  ELL_HD static El one() { return each([](int l) { return m_eq(l, 0) & 1u; }); }
 
   // ---- conversions ----------------------------------------------------------------------------------
   // the row <-> the one-lane 29-bit field (cold paths: canonical tests, stores)
@@ -282,9 +373,11 @@ struct FpK256C {
   }
 #endif
   // columns 0..15 of a * b onto acc (one per lane), column 16 onto col16
+  // (RW: a and b differ from row to row -- see ln)
+  template <bool RW = false>
   ELL_HD static void columns(W64& acc, i64& col16, const El& a, const El& b) {
-    const i32 a0 = at(a, 0), a1 = at(a, 1), a2 = at(a, 2), a3 = at(a, 3), a4 = at(a, 4), a5 = at(a, 5),
-              a6 = at(a, 6), a7 = at(a, 7), a8 = at(a, 8);
+    const i32 a0 = ln<RW, 0>(a), a1 = ln<RW, 1>(a), a2 = ln<RW, 2>(a), a3 = ln<RW, 3>(a), a4 = ln<RW, 4>(a),
+              a5 = ln<RW, 5>(a), a6 = ln<RW, 6>(a), a7 = ln<RW, 7>(a), a8 = ln<RW, 8>(a);
     const El b1 = up<1>(b), b2 = up<2>(b), b3 = up<3>(b), b4 = up<4>(b), b5 = up<5>(b), b6 = up<6>(b),
              b7 = up<7>(b), b8 = up<8>(b);
     ELL_UNROLL
@@ -301,13 +394,14 @@ struct FpK256C {
       c += (i64)a8 * s(b8.v[t]);
       acc.w[t] = c;
     }
-    col16 += (i64)a8 * (i64)at(b, 8);
+    col16 += (i64)a8 * (i64)ln<RW, 8>(b);
   }
   // carries and the fold of columns 9.. -> N form
   // (bounds, for column sums below 2^63: pass 1 leaves limbs below 2^29 + 2^35, pass 2 below 2^29 +
   // 2^6; column 16 splits into a 29-bit digit and a part below 2^24; the folded limbs stay below
   // 2^47, their carries below 2^18; limb 0 ends below 2^29 + 2^25, the others below 2^29 + 2^19,
   // limb 8 in [0, 2^24) -- see DESIGN.md section 4)
+  template <bool RW = false>
   ELL_HD static El tail(const W64& acc, i64 col16) {
     const El r1 = c_r1(), rr = c_rr(), rrr = c_rrr(), kf = c_kf(), live = c_live();
     // first carry pass, 64-bit carries
@@ -319,7 +413,7 @@ struct FpK256C {
     W64 v1;
     ELL_UNROLL
     for (int t = 0; t < CL; t++) v1.w[t] = (i64)lo1.v[t] + cin1.w[t];
-    col16 += at64(c1, 15);
+    col16 += ln64<RW, 15>(c1);
     // second pass: the carries fit a word
     El c2, v2;
     ELL_UNROLL
@@ -327,7 +421,7 @@ struct FpK256C {
     const El cin2 = up<1>(c2);
     ELL_UNROLL
     for (int t = 0; t < CL; t++) v2.v[t] = ((u32)v1.w[t] & M) + cin2.v[t];
-    col16 += (i64)at(c2, 15);
+    col16 += (i64)ln<RW, 15>(c2);
     const i32 p16 = (i32)((u32)col16 & M);
     const i32 p17 = (i32)(col16 >> 29);
     // fold: column 9 + j -> R0 at limb j, R1 at limb j + 1; column 17's R1 part is column 9 again
@@ -353,8 +447,8 @@ struct FpK256C {
     ELL_UNROLL
     for (int t = 0; t < CL; t++) v3.v[t] = ((u32)tt.w[t] & M) + cin3.v[t];
     // limb 8: its carry is column 9 once more (small now), its bits above 2^24 fold through 2^256
-    const i32 c9 = at(c3, 8);
-    const i32 x8 = at(v3, 8);
+    const i32 c9 = ln<RW, 8>(c3);
+    const i32 x8 = ln<RW, 8>(v3);
     const i32 hi = x8 >> 24;
     El r;
     ELL_UNROLL
@@ -381,6 +475,19 @@ struct FpK256C {
     return tail(acc, col16);
   }
   ELL_HD static El sqr(const El& a) { return mul(a, a); }
+  // row j of the result = row j of a * row j of b: four products for the instructions of one
+  ELL_HD static Q mulq(const Q& a, const Q& b) {
+    Q r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    W64 acc = zero64();
+    i64 col16 = 0;
+    columns<true>(acc, col16, a.r[0], b.r[0]);
+    r.r[0] = tail<true>(acc, col16);
+#else
+    for (int j = 0; j < QR; j++) r.r[j] = mul(a.r[j], b.r[j]);
+#endif
+    return r;
+  }
   // a * b + e * f with one reduction
   ELL_HD static El mul2(const El& a, const El& b, const El& e, const El& f) {
 #if defined(ELL_BOUNDS_CHECK)

@@ -56,16 +56,18 @@ __global__ void __launch_bounds__(BLOCK, MinWaves<Fn>::value) k_run(const Fn f, 
   f(tid, ds);
 }
 
-// The lanes-per-item layer (coop.h): ONE unit per workgroup of one wave; lanes 0..15 -- one DPP
-// row -- carry the unit's field elements, the other three rows sit the kernel out.  LDS: the digit
-// columns and Fn::ROW_BYTES of row memory (every lane's own window table).
+// The lanes-per-item layer (coop.h): ONE unit per workgroup of one wave.  A field element is one
+// DPP row (16 lanes); the wave's four rows hold the same element, or -- inside a step of the group
+// law -- four different ones whose products run together (coop.h Q / mulq).  LDS: the digit
+// columns and Fn::ROW_BYTES of row memory (every lane's own window table; the rows write the
+// same bytes to the same places).
 // (at most two waves per SIMD are ever resident: the register allocator may keep every
 // loop-invariant row constant -- the shifted copies of p, the lane masks -- in registers)
 template <class Fn>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_run_coop(const Fn f, size_t units) {
   __shared__ signed char lds_digits[(Fn::DS_PER_LANE > 0 ? Fn::DS_PER_LANE : 1) * 64];
   __shared__ __attribute__((aligned(16))) unsigned char lds_rows[Fn::ROW_BYTES];
-  if (threadIdx.x >= 16u || (size_t)blockIdx.x >= units) return;
+  if ((size_t)blockIdx.x >= units) return;
   DigitStore ds{lds_digits + threadIdx.x, 64};
   f((size_t)blockIdx.x, ds, (void*)lds_rows);
 }

@@ -50,6 +50,14 @@ struct has_pair { static constexpr bool value = false; };
 template <class F>
 struct has_pair<F, decltype((void)F::PAIR)> { static constexpr bool value = F::PAIR; };
 
+// F::QUAD (coop.h): a wave holds four field elements side by side and multiplies them in one
+// instruction stream (F::mulq over F::pack* / F::unpack*); the lazy doubling and mixed addition
+// below then take the independent products of a step together
+template <class F, class = void>
+struct has_quad { static constexpr bool value = false; };
+template <class F>
+struct has_quad<F, decltype((void)F::QUAD)> { static constexpr bool value = F::QUAD; };
+
 template <class CV>
 struct ShortOps {
   typedef typename CV::F F;
@@ -90,6 +98,17 @@ struct ShortOps {
   ELL_HD static J dbl_lazy(const J& p) {
     J r;
     ELL_K256L_AT("dbl_lazy");
+    if constexpr (has_quad<FF>::value) {
+      // the same products in three steps: {Y^2, Y Z, X^2}, {X S, L^2}, the two-product Y3
+      El s, a, t, l2;
+      FF::unpack3(FF::mulq(FF::pack3(p.Y, p.Y, p.X), FF::pack3(p.Y, p.Z, p.X)), s, r.Z, a);
+      El l = FF::norm(FF::add_l(a, FF::half_l(a)));
+      FF::unpack2(FF::mulq(FF::pack2(p.X, l), FF::pack2(s, l)), t, l2);
+      r.X = FF::norm(FF::template sub_l<4>(l2, FF::add_l(t, t)));
+      El w = FF::template sub_l<4>(t, r.X);
+      r.Y = FF::mul2(l, w, FF::template neg_l<2>(s), s);
+      return r;
+    }
     El s = FF::sqr(p.Y);                                             // N x N
     r.Z = FF::mul(p.Y, p.Z);
     El a = FF::sqr(p.X);
@@ -197,6 +216,25 @@ struct ShortOps {
   template <class FF = F>
   ELL_HD static J add_mixed_lazy(const J& p, const A& q, El* h_out, El* rr_out = nullptr) {
     ELL_K256L_AT("add_mixed_lazy");
+    if constexpr (has_quad<FF>::value) {
+      // five steps for the ten products: {Z^2, y2 Z}, {x2 Z^2, (y2 Z) Z^2}, {Z h, h^2, rr^2},
+      // {h h^2, X h^2}, the two-product Y3  (s2 = (y2 Z) Z^2: the association differs from the
+      // chain below, the value does not)
+      El z1z1, yz, u2, s2, hh, r2, hhh, v;
+      J r;
+      FF::unpack2(FF::mulq(FF::pack2(p.Z, q.y), FF::pack2(p.Z, p.Z)), z1z1, yz);
+      FF::unpack2(FF::mulq(FF::pack2(q.x, yz), FF::pack2(z1z1, z1z1)), u2, s2);
+      El h = FF::template sub_l<4>(u2, p.X);
+      El rr = FF::template sub_l<4>(s2, p.Y);
+      FF::unpack3(FF::mulq(FF::pack3(p.Z, h, rr), FF::pack3(h, h, rr)), r.Z, hh, r2);
+      FF::unpack2(FF::mulq(FF::pack2(h, p.X), FF::pack2(hh, hh)), hhh, v);
+      r.X = FF::norm(FF::template sub_l<4>(r2, FF::add_l(hhh, FF::add_l(v, v))));
+      El w = FF::template sub_l<4>(v, r.X);
+      r.Y = FF::mul2(rr, w, FF::template neg_l<4>(p.Y), hhh);
+      if (h_out) *h_out = FF::norm(h);
+      if (rr_out) *rr_out = rr;
+      return r;
+    }
     El z1z1 = FF::sqr(p.Z);
     El u2 = FF::mul(q.x, z1z1);
     El s2 = FF::mul(q.y, FF::mul(p.Z, z1z1));

@@ -425,6 +425,8 @@ int ellgpu_ctx_comb_bits(ellgpu_ctx* ctx, int curve);
  * dependent operations per lane (blocks = 1024 * w puts w waves on every SIMD): 10 field mul,
  * 11 field sqr, 12 two interleaved mul chains, 13 add + sub, 14 Jacobian doubling,
  * 15 mixed addition, 16 wide product only, 17 wide square only, 18 reduction only;
+ * 20 / 24 / 25: product / doubling / mixed addition of the lanes-per-item layer (one item per
+ * wavefront: blocks items);
  * ops_out = lane-operations. */
 int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iters, double* ms_out,
                       double* ops_out);

@@ -1,0 +1,11 @@
+import json, elliptic_amd
+ctx = elliptic_amd.Context(0)
+out = {}
+for blocks in (1, 256):
+    row = {}
+    for name, kind, iters in (("one_lane_mul", 10, 20000), ("one_lane_dbl", 14, 3000), ("one_lane_madd", 15, 3000),
+                              ("row_mul", 20, 20000), ("row_dbl", 24, 3000), ("row_madd", 25, 3000)):
+        best = min(ctx.probe_valu(kind, blocks, iters)[0] for _ in range(3))
+        row[name] = round(best * 1e6 / iters, 1)
+    out[str(blocks)] = row
+print(json.dumps({"ns_per_op": out}))
