@@ -59,11 +59,11 @@ struct FpMontC {
   template <int I>
   ELL_HD static El c_pshift() { return by_lane<I>(MC::p29); }
   ELL_HD static El c_live() { return R_::c_live(); }
-  ELL_HD static El c_mask() { return each([](int l) { return l < 8 ? (i32)M : (l == 8 ? -1 : 0); }); }
+  ELL_HD static El c_mask() { return R_::c_mask(); }
   ELL_HD static El zero() { return each([](int) { return 0; }); }
   ELL_HD static El one() { return by_lane<0>(MC::one29); }     // R mod p
   ELL_HD static El c_rr() { return by_lane<0>(MC::rr29); }      // R^2 mod p
-  ELL_HD static El plain_one() { return each([](int l) { return l == 0 ? 1 : 0; }); }
+  ELL_HD static El plain_one() { return R_::one(); }
 
   // ---- lazy limb-wise forms -----------------------------------------------------------------------
   ELL_HD static El add_l(const El& a, const El& b) {
@@ -116,26 +116,36 @@ struct FpMontC {
     for (int t = 9; t < CL; t++) assert(a.v[t] == 0 && b.v[t] == 0 && "fpmontc: dead lane not zero");
   }
 #endif
-  ELL_HD static El redc(W64 acc, i64 col16) {
-    // p shifted up i lanes, as per-lane CONSTANTS (a DPP move is a convergent operation the
+  // one step of the reduction: column I made divisible by 2^29 (RW: every row reduces a product of
+  // its own -- coop.h ln -- and m, the carry and column 16 are per-row values)
+  template <bool RW, int I>
+  ELL_HD static void redc_step(W64& acc, i64& col16, i64& carry) {
+    // p shifted up I lanes, as a per-lane CONSTANT (a DPP move is a convergent operation the
     // compiler will not hoist out of the ladder's loops; a select chain on the lane index it does)
-    const El live = c_live();
-    const El pv = c_pshift<0>(), p1 = c_pshift<1>(), p2 = c_pshift<2>(), p3 = c_pshift<3>(), p4 = c_pshift<4>(),
-             p5 = c_pshift<5>(), p6 = c_pshift<6>(), p7 = c_pshift<7>(), p8 = c_pshift<8>();
-    const El* const ps[9] = {&pv, &p1, &p2, &p3, &p4, &p5, &p6, &p7, &p8};
+    const El ps = c_pshift<I>();
     const i64 p0 = (i64)MC::p29[0], p8s = (i64)MC::p29[8];
-    i64 carry = 0;
+    const i64 v = R_::template ln64<RW, I>(acc) + carry;            // column I as it stands
+    const i32 m = (i32)(((u32)v * MC::n0) & M);                    // v + m p_0 = 0 (mod 2^29)
     ELL_UNROLL
-    for (int i = 0; i <= 8; i++) {
-      const i64 v = R_::at64(acc, i) + carry;                      // column i as it stands
-      const i32 m = (i32)(((u32)v * MC::n0) & M);                  // v + m p_0 = 0 (mod 2^29)
-      ELL_UNROLL
-      for (int t = 0; t < CL; t++) acc.w[t] += (i64)m * (i64)s(ps[i]->v[t]);
-      if (i == 8) col16 += (i64)m * p8s;                           // (lane 16 is off the row)
-      // p = -1 (mod 2^29) (p256, p192): m is v's low digit and v + m (2^29 - 1) = ((v >> 29) + m) 2^29
-      if constexpr (MC::n0 == 1u && MC::p29[0] == (int)M) carry = (v >> 29) + (i64)m;
-      else carry = (v + (i64)m * p0) >> 29;
-    }
+    for (int t = 0; t < CL; t++) acc.w[t] += (i64)m * (i64)s(ps.v[t]);
+    if (I == 8) col16 += (i64)m * p8s;                             // (lane 16 is off the row)
+    // p = -1 (mod 2^29) (p256, p192): m is v's low digit and v + m (2^29 - 1) = ((v >> 29) + m) 2^29
+    if constexpr (MC::n0 == 1u && MC::p29[0] == (int)M) carry = (v >> 29) + (i64)m;
+    else carry = (v + (i64)m * p0) >> 29;
+  }
+  template <bool RW = false>
+  ELL_HD static El redc(W64 acc, i64 col16) {
+    const El live = c_live();
+    i64 carry = 0;
+    redc_step<RW, 0>(acc, col16, carry);
+    redc_step<RW, 1>(acc, col16, carry);
+    redc_step<RW, 2>(acc, col16, carry);
+    redc_step<RW, 3>(acc, col16, carry);
+    redc_step<RW, 4>(acc, col16, carry);
+    redc_step<RW, 5>(acc, col16, carry);
+    redc_step<RW, 6>(acc, col16, carry);
+    redc_step<RW, 7>(acc, col16, carry);
+    redc_step<RW, 8>(acc, col16, carry);
     // columns 9..15 (lanes 9..15), 16 (scalar) and the carry into column 9 are the result's limbs 0..7
     W64 res;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -181,6 +191,25 @@ struct FpMontC {
     return redc(acc, col16);
   }
   ELL_HD static El sqr(const El& a) { return mul(a, a); }
+  // four products side by side, one per row of the wave (coop.h Q / mulq)
+  static constexpr bool QUAD = true;
+  typedef FpK256C::Q Q;
+  ELL_HD static Q pack2(const El& a, const El& b) { return R_::pack2(a, b); }
+  ELL_HD static Q pack3(const El& a, const El& b, const El& c) { return R_::pack3(a, b, c); }
+  ELL_HD static void unpack2(const Q& q, El& a, El& b) { R_::unpack2(q, a, b); }
+  ELL_HD static void unpack3(const Q& q, El& a, El& b, El& c) { R_::unpack3(q, a, b, c); }
+  ELL_HD static Q mulq(const Q& a, const Q& b) {
+    Q r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    W64 acc = R_::zero64();
+    i64 col16 = 0;
+    R_::template columns<true>(acc, col16, a.r[0], b.r[0]);
+    r.r[0] = redc<true>(acc, col16);
+#else
+    for (int j = 0; j < R_::QR; j++) r.r[j] = mul(a.r[j], b.r[j]);
+#endif
+    return r;
+  }
 
   // ---- the field interface of short.h's generic (non-lazy) formulas --------------------------------
   ELL_HD static El add(const El& a, const El& b) { return norm(add_l(a, b)); }

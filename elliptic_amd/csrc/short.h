@@ -156,6 +156,19 @@ struct ShortOps {
       r.Y = F::sub(F::mul(e, F::sub(d, r.X)), F::template mul_pow2<3>(c));
     } else {
       // dbl-2001-b, a = -3: 3M + 5S
+      if constexpr (has_quad<F>::value) {
+        // the eight products in four steps: {Z^2, Y^2, (Y+Z)^2}, {X gamma, (X-delta)(X+delta), gamma^2}, alpha^2, Y3's
+        El delta, gamma, yz, beta, t, g2;
+        const El ypz = F::add(p.Y, p.Z);
+        F::unpack3(F::mulq(F::pack3(p.Z, p.Y, ypz), F::pack3(p.Z, p.Y, ypz)), delta, gamma, yz);
+        r.Z = F::sub(F::sub(yz, gamma), delta);
+        F::unpack3(F::mulq(F::pack3(p.X, F::sub(p.X, delta), gamma), F::pack3(gamma, F::add(p.X, delta), gamma)), beta, t, g2);
+        El alpha = F::add(F::template mul_pow2<1>(t), t);
+        El beta4 = F::template mul_pow2<2>(beta);
+        r.X = F::sub(F::sqr(alpha), F::template mul_pow2<1>(beta4));
+        r.Y = F::sub(F::mul(alpha, F::sub(beta4, r.X)), F::template mul_pow2<3>(g2));
+        return r;
+      }
       El delta = F::sqr(p.Z);
       El gamma = F::sqr(p.Y);
       El beta = F::mul(p.X, gamma);
@@ -256,6 +269,23 @@ struct ShortOps {
     return r;
   }
 
+  // the eleven products of the mixed addition in five steps (fields with F::QUAD, normalising
+  // interface): {Z^2, y2 Z}, {x2 Z^2, (y2 Z) Z^2}, {Z h, h^2, rr^2}, {h h^2, X h^2}, {rr (v - X3), Y h^3}
+  ELL_HD static J add_mixed_quad(const J& p, const A& q, El& h, El& rr) {
+    El z1z1, yz, u2, s2, hh, r2, hhh, v, ya, yb;
+    J r;
+    F::unpack2(F::mulq(F::pack2(p.Z, q.y), F::pack2(p.Z, p.Z)), z1z1, yz);
+    F::unpack2(F::mulq(F::pack2(q.x, yz), F::pack2(z1z1, z1z1)), u2, s2);
+    h = F::sub(u2, p.X);
+    rr = F::sub(s2, p.Y);
+    F::unpack3(F::mulq(F::pack3(p.Z, h, rr), F::pack3(h, h, rr)), r.Z, hh, r2);
+    F::unpack2(F::mulq(F::pack2(h, p.X), F::pack2(hh, hh)), hhh, v);
+    r.X = F::sub(F::sub(r2, hhh), F::template mul_pow2<1>(v));
+    F::unpack2(F::mulq(F::pack2(rr, p.Y), F::pack2(F::sub(v, r.X), hhh)), ya, yb);
+    r.Y = F::sub(ya, yb);
+    return r;
+  }
+
   template <class Reload>
   ELL_HD static J add_mixed_lean(const J& p, const A& q, bool& pinf, const Reload& reload) {
     if constexpr (is_lazy<F>::value) {
@@ -274,22 +304,28 @@ struct ShortOps {
       pinf = z;
       return r;
     }
-    El z1z1 = F::sqr(p.Z);
-    El u2 = F::mul(q.x, z1z1);
-    El s2 = F::mul(q.y, F::mul(p.Z, z1z1));
-    El h = F::sub(u2, p.X);
     J r;
-    r.Z = F::mul(p.Z, h);
-    El rr = F::sub(s2, p.Y);
-    El hh = F::sqr(h);
-    El hhh = F::mul(h, hh);
-    El v = F::mul(p.X, hh);
-    r.X = F::sub(F::sub(F::sqr(rr), hhh), F::template mul_pow2<1>(v));
-    if constexpr (has_pair<F>::value) {
-      r.Y = F::mul_sub_mul(rr, F::sub(v, r.X), p.Y, hhh);
+    El rr;
+    if constexpr (has_quad<F>::value) {
+      El h;
+      r = add_mixed_quad(p, q, h, rr);
     } else {
-      El yh = F::mul(p.Y, hhh);
-      r.Y = F::sub(F::mul(rr, F::sub(v, r.X)), yh);
+      El z1z1 = F::sqr(p.Z);
+      El u2 = F::mul(q.x, z1z1);
+      El s2 = F::mul(q.y, F::mul(p.Z, z1z1));
+      El h = F::sub(u2, p.X);
+      r.Z = F::mul(p.Z, h);
+      rr = F::sub(s2, p.Y);
+      El hh = F::sqr(h);
+      El hhh = F::mul(h, hh);
+      El v = F::mul(p.X, hh);
+      r.X = F::sub(F::sub(F::sqr(rr), hhh), F::template mul_pow2<1>(v));
+      if constexpr (has_pair<F>::value) {
+        r.Y = F::mul_sub_mul(rr, F::sub(v, r.X), p.Y, hhh);
+      } else {
+        El yh = F::mul(p.Y, hhh);
+        r.Y = F::sub(F::mul(rr, F::sub(v, r.X)), yh);
+      }
     }
     bool z = F::is_zero(r.Z);
     if (ELL_UNLIKELY(z)) {
@@ -307,6 +343,10 @@ struct ShortOps {
   // prime-order curve), returns the ratio h with Z3 = Z1 * h.  8M + 3S.
   ELL_HD static J add_mixed_zr(const J& p, const A& q, El& h) {
     if constexpr (is_lazy<F>::value) return add_mixed_lazy<F>(p, q, &h);
+    if constexpr (has_quad<F>::value) {
+      El rr;
+      return add_mixed_quad(p, q, h, rr);
+    }
     El z1z1 = F::sqr(p.Z);
     El u2 = F::mul(q.x, z1z1);
     El s2 = F::mul(q.y, F::mul(p.Z, z1z1));

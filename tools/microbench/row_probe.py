@@ -1,4 +1,16 @@
-import json, elliptic_amd
+#!/usr/bin/env python3
+"""GPU box: what ONE item's critical path pays per field / group operation -- the one-item-per-lane
+secp256k1 field (fp.h; probe kinds 10 / 14 / 15 of ellgpu_probe_valu) against the lanes-per-item
+layer (coop.h; kinds 20 / 24 / 25), on a lone wave (blocks = 1) and on 256 one-wave workgroups.
+
+  python tools/microbench/row_probe.py > profiles/rNN_row_probe.json"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import elliptic_amd
+
 ctx = elliptic_amd.Context(0)
 out = {}
 for blocks in (1, 256):
