@@ -199,6 +199,18 @@ struct FpK256C {
 #endif
     return q;
   }
+  // rows (a, b, c, d)
+  ELL_HD static Q pack4(const El& a, const El& b, const El& c, const El& d) {
+    Q q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 ab = (threadIdx.x & 16u) ? b.v[0] : a.v[0];
+    const u32 cd = (threadIdx.x & 16u) ? d.v[0] : c.v[0];
+    q.r[0].v[0] = (threadIdx.x & 32u) ? cd : ab;
+#else
+    q.r[0] = a; q.r[1] = b; q.r[2] = c; q.r[3] = d;
+#endif
+    return q;
+  }
   // every row <- rows 0 and 1 of a (.., .., same, same) Q: v_permlane16_swap trades the odd rows
   // of its first operand for the even rows of its second
   ELL_HD static void unpack2(const Q& q, El& a, El& b) {
@@ -224,6 +236,20 @@ struct FpK256C {
     a = q.r[0]; b = q.r[1]; c = q.r[2];
 #endif
   }
+  ELL_HD static void unpack4(const Q& q, El& a, El& b, El& c, El& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto h = __builtin_amdgcn_permlane32_swap(q.r[0].v[0], q.r[0].v[0], false, false);
+    const auto p = __builtin_amdgcn_permlane16_swap(h[0], h[0], false, false);
+    const auto t = __builtin_amdgcn_permlane16_swap(h[1], h[1], false, false);
+    a.v[0] = p[0];
+    b.v[0] = p[1];
+    c.v[0] = t[0];
+    d.v[0] = t[1];
+#else
+    a = q.r[0]; b = q.r[1]; c = q.r[2]; d = q.r[3];
+#endif
+  }
+
   // per-lane constants of the algebra (loop-invariant registers on the device).  Written as masks,
   // not as ?: chains: a chain reaches the loop optimiser as control flow, which it does not hoist
   ELL_HD static u32 m_eq(int l, int i) { return 0u - (u32)(l == i); }

@@ -89,6 +89,12 @@ struct FpMontC {
     for (int j = TL + 1; j <= 8; j++) top += (i64)at(a, j) << (29 * (j - TL));        // (carry-sized limbs above TL)
     const i64 k64 = top >> TB;
     const i32 k = k64 < -2 ? -2 : (k64 > 2 ? 2 : (i32)k64);
+#if defined(ELL_BOUNDS_CHECK)
+    for (int t = 0; t < CL; t++) {
+      const i64 dd = (i64)s(a.v[t]) - (i64)k * (i64)s(pv.v[t]);
+      if (dd >= ((i64)1 << 31) || dd < -((i64)1 << 31)) { fprintf(stderr, "fpmontc norm: limb %d leaves 32 bits\n", t); assert(0); }
+    }
+#endif
     El d, c;
     ELL_UNROLL
     for (int t = 0; t < CL; t++) d.v[t] = a.v[t] - (u32)k * pv.v[t];

@@ -526,6 +526,23 @@ struct EdWork {
     if (out_err) out_err[i] = bad ? 1 : 0;
   }
 
+  // the comparison of EDDSA#verify for the items whose two sides came from the lanes-per-item layer
+  // (coop_ed.h verify_part): ext holds h*A (point i) and S*G - R (point n + i) as canonical X, Y, Z
+  // words; flags as verify_part writes them.  Point#eq (edwards.js:409-413), projectively.
+  ELL_HD static void eddsa_join(size_t i, size_t n, const u32* ext, const u8* flags, u8* out_ok, u8* out_err) {
+    El c[6];
+    ELL_UNROLL
+    for (int k = 0; k < 6; k++) {
+      const size_t slot = (k < 3 ? 0 : n) + i;
+      ELL_UNROLL
+      for (int l = 0; l < 8; l++) c[k].v[l] = ext[(size_t)((k % 3) * 8 + l) * (2 * n) + slot];
+    }
+    const bool same = F::eq(F::mul(c[0], c[5]), F::mul(c[3], c[2])) && F::eq(F::mul(c[1], c[5]), F::mul(c[4], c[2]));
+    const bool a_ok = (flags[i] & 1u) != 0, r_ok = (flags[n + i] & 1u) != 0, s_ok = (flags[n + i] & 2u) != 0;
+    out_ok[i] = (s_ok && a_ok && r_ok && same) ? 1 : 0;
+    if (out_err) out_err[i] = (s_ok && !(a_ok && r_ok)) ? 1 : 0;
+  }
+
   // (X:Y:Z) -> affine (x, y) with one inversion per K items (normalize,
   // edwards.js:377-390).  out_inf mirrors Point#isInfinity (edwards.js:167-172):
   // x == 0 && y == 1.  raw != null stores cached(x, y, 1, xy) for the comb.

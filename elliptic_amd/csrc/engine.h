@@ -23,6 +23,7 @@
 #include "edcustom.h"
 #include "mont.h"
 #include "work.h"
+#include "coop_ed.h"
 
 #ifndef ELL_INV_BATCH
 #define ELL_INV_BATCH 16
@@ -655,6 +656,31 @@ struct FnEddsaVerify {
     const u8* m = off ? msgs + off[i] : msgs + i * msg_len;
     u64 len = off ? off[i + 1] - off[i] : (u64)msg_len;
     EdWork::eddsa_verify(i, m, len, sigs + i * 64, pubs + i * 32, comb, tbl, ds, ok, err);
+  }
+};
+
+// EDDSA#verify for a handful of items: the two sides of the equation on a wave each (coop_ed.h),
+// then the one-lane comparison
+struct FnEddsaPartsC {
+  static constexpr const char* NAME = "eddsa_parts_c";
+  static constexpr int DS_PER_LANE = EdWork::NWIN;
+  static constexpr int ROW_BYTES = CoopEd::ROW_BYTES;
+  size_t n; const u8* msgs; const u64* off; size_t msg_len; const u8* sigs; const u8* pubs;
+  const EdWork::P* comb; u32* ext; u8* flags;
+  ELL_HD void operator()(size_t unit, const DigitStore& ds, void* row_mem) const {
+    const int part = (int)(unit / n);
+    const size_t i = unit - (size_t)part * n;
+    const u8* m = off ? msgs + off[i] : msgs + i * msg_len;
+    const u64 len = off ? off[i + 1] - off[i] : (u64)msg_len;
+    CoopEd::verify_part(i, n, part, m, len, sigs + i * 64, pubs + i * 32, comb, ds, ext, flags, row_mem);
+  }
+};
+struct FnEddsaJoin {
+  static constexpr const char* NAME = "eddsa_join";
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u32* ext; const u8* flags; u8* ok; u8* err;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) EdWork::eddsa_join(i, n, ext, flags, ok, err);
   }
 };
 
@@ -2723,6 +2749,17 @@ template <class BK>
 template <int U>
 int Engine<BK>::eddsa_chunk(size_t n, size_t o, const u8* msgs, const u64* off, size_t msg_len,
                             const u8* sigs, const u8* pubs, u8* ok, u8* err) {
+  if (n <= coop_grid()) {
+    u32* ext = (u32*)scratch(S_JAC, 2 * n * 3 * 8 * 4);
+    u8* flags = (u8*)scratch(S_VALID, 2 * n);
+    if (!ext || !flags) return fail(E_NOMEM, "scratch allocation failed");
+    FnEddsaPartsC fc{n, off ? msgs : msgs + o * msg_len, off ? off + o : nullptr, msg_len, sigs + o * 64,
+                     pubs + o * 32, (const EdWork::P*)comb_[CURVE_ED25519], ext, flags};
+    bk.launch_coop(fc, 2 * n);
+    FnEddsaJoin fj{n, ext, flags, ok + o, err ? err + o : nullptr};
+    bk.launch(fj, n);
+    return E_OK;
+  }
   EdWork::P* tbl = (EdWork::P*)scratch(S_TBL, n * 8 * sizeof(EdWork::P));
   if (!tbl) return fail(E_NOMEM, "scratch allocation failed");
   FnEddsaVerify f{n, off ? msgs : msgs + o * msg_len, off ? off + o : nullptr, msg_len,

@@ -581,6 +581,57 @@ def test_nist_small_batches_on_the_row_layer(monkeypatch, curve):
         c.close()
 
 
+def test_eddsa_verify_small_batches_on_the_row_layer(monkeypatch):
+    """EDDSA#verify of at most ELLGPU_COOP_GRID items: the two sides of the equation on a wave each
+    (csrc/coop_ed.h; eddsa_parts_c), compared by the one-lane eddsa_join -- against the one-kernel
+    form (ELLGPU_COOP_GRID=0) on signatures of this library (messages of 0..200 bytes), corrupted
+    messages / R / S / keys, S >= n, encodings that do not decode (the reference throws: err = 1),
+    non-canonical y, and the reference's vectors through both."""
+    monkeypatch.setenv("ELLGPU_COOP_GRID", "0")
+    c0 = elliptic_amd.Context(0)
+    monkeypatch.setenv("ELLGPU_COOP_GRID", str(1 << 30))
+    c1 = elliptic_amd.Context(0)
+    monkeypatch.delenv("ELLGPU_COOP_GRID")
+    cd = elliptic_amd.Context(0)
+    n = 1500
+    raw = hashlib.shake_256(b"row-layer:eddsa").digest(n * 32 + n * 200)
+    sec = np.frombuffer(raw[:n * 32], np.uint8).reshape(n, 32)
+    msgs = [raw[n * 32 + 200 * i: n * 32 + 200 * i + (i * 7) % 201] for i in range(n)]
+    sig, pub = c0.eddsa_sign(msgs, sec)
+    sig, pub, msgs = sig.copy(), pub.copy(), list(msgs)
+    L_ORDER = 2 ** 252 + 27742317777372353535851937790883648493
+    for i in range(0, n, 9):                              # one defect per ninth item, by kind
+        kind = (i // 9) % 8
+        if kind == 0: msgs[i] = msgs[i] + b"x"
+        elif kind == 1: sig[i, 3] ^= 0x10                 # R: another point, or no point at all
+        elif kind == 2: sig[i, 40] ^= 1                   # S
+        elif kind == 3: pub[i, 7] ^= 0x20                 # A
+        elif kind == 4:                                   # S + n (still 32 bytes): S >= n -> false, nothing decoded
+            S = int.from_bytes(sig[i, 32:].tobytes(), "little") + L_ORDER
+            if S < 1 << 256: sig[i, 32:] = np.frombuffer(S.to_bytes(32, "little"), np.uint8)
+        elif kind == 5: sig[i, :32] = np.frombuffer((2).to_bytes(32, "little"), np.uint8)       # y = 2: not on the curve
+        elif kind == 6: pub[i] = np.frombuffer((2 ** 255 - 19 + 1).to_bytes(32, "little"), np.uint8)   # y = p + 1: non-canonical 1
+        else: pub[i, 31] ^= 0x80                          # the other x
+    for m in (1, 2, 33, 300, 1365, 1366, 1500):
+        outs = []
+        for c, rowk in ((c0, False), (c1, True), (cd, m <= 1365)):
+            c.set_timing(True)
+            outs.append(c.eddsa_verify(msgs[:m], sig[:m], pub[:m]))
+            tm = c.get_timing()
+            c.set_timing(False)
+            assert ("eddsa_parts_c" in tm) == rowk and ("eddsa_verify" in tm) != rowk, (m, rowk, sorted(tm))
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]), m
+    ok, err = outs[0]
+    good = np.ones(n, bool)
+    good[::9] = False
+    assert ok[good].all() and not ok[::9].any() and not err[good].any() and err[::9].sum() > 10
+    for c in (c0, c1):
+        assert PC.check_eddsa_golden(c) > 200
+    for c in (c0, c1, cd):
+        c.close()
+
+
 @pytest.mark.parametrize("curve", ["secp256k1", "p256", "p224", "p192"])
 def test_small_batch_sign_on_the_row_layer(monkeypatch, curve):
     """EC#sign for a handful of items: k*G (comb + the item's own inversion) and k^-1 mod n on a

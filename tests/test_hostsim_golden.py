@@ -361,6 +361,21 @@ def test_nist_curves_one_lane_and_row_layer(hs, monkeypatch, curve):
         c.close()
 
 
+def test_eddsa_verify_one_lane_and_row_layer(hs, monkeypatch):
+    """EDDSA#verify of at most ELLGPU_COOP_GRID items runs the two sides of its equation on a wave
+    each (csrc/coop_ed.h: 2^255 - 19 as nine signed limbs across a DPP row, the four products of a
+    step of the extended-coordinate formulas side by side in the wave's four rows) and compares them
+    in the one-lane eddsa_join; ELLGPU_COOP_GRID=0 keeps the one-kernel form.  Same verdicts and
+    'reference throws' flags from both, on the reference's vectors and on the edge encodings."""
+    for coop, rowk in (("0", False), (str(1 << 30), True)):
+        c = _fresh_ctx(hs, monkeypatch, ELLGPU_COOP_GRID=coop)
+        hs.hs_launches_reset()
+        assert PC.check_eddsa_golden(c) > 200
+        assert (hs.hs_launches(b"eddsa_parts_c") > 0) == rowk and (hs.hs_launches(b"eddsa_verify") > 0) != rowk
+        assert (hs.hs_launches(b"eddsa_join") > 0) == rowk
+        c.close()
+
+
 @pytest.mark.parametrize("curve", ["secp256k1", "p192", "p256", "p384", "p521", "ed25519"])
 def test_decompress_golden(ctx, curve):
     assert PC.check_decompress_golden(ctx, curve) > 40
