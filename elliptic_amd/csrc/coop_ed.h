@@ -184,11 +184,12 @@ struct CoopEd {
   static constexpr bool AVAILABLE = true;
   // (X, Y, Z, T), or a table entry's cached form (Y+X, Y-X, 2Z, 2dT)
   struct P { El a, b, c, d; };
-  static constexpr int ROW_BYTES = 8 * (int)sizeof(P) * (FpK256C::CL == 1 ? 16 : 1);
+  static constexpr int ROW_BYTES = 8 * (int)sizeof(P) * (FpK256C::CL == 1 ? 16 : 1);     // one window table of every lane
+  static constexpr int ROW_BYTES2 = 2 * ROW_BYTES;                                         // two (k1*P1 + k2*P2)
 
   ELL_HD static P* lane_table(void* row_mem) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return (P*)row_mem + (size_t)(threadIdx.x & 15u) * 8;
+    return (P*)row_mem + (size_t)(threadIdx.x & 15u) * 16;
 #else
     return (P*)row_mem;
 #endif
@@ -261,7 +262,8 @@ struct CoopEd {
     ELL_NOUNROLL
     for (int j = 0; j < 8; j++) tbl[j] = to_cached(tbl[j]);
   }
-  // signed 4-bit windows (edwards.h run_w4)
+  // signed 4-bit windows over NS tables of eight (edwards.h run_w4)
+  template <int NS = 1>
   ELL_HD static P run_w4(const DigitStore& ds, const P* tbl) {
     P acc = identity();
     ELL_NOUNROLL
@@ -270,9 +272,12 @@ struct CoopEd {
         ELL_NOUNROLL
         for (int j = 0; j < 4; j++) acc = dbl(acc);
       }
-      const int d = ds.get(w);
-      const int ad = d < 0 ? -d : d;
-      if (ad != 0) acc = add(acc, cached_cneg(tbl[ad - 1], d < 0));       // wave-uniform: one item per wave
+      ELL_UNROLL
+      for (int s = 0; s < NS; s++) {
+        const int d = ds.get(w * NS + s);
+        const int ad = d < 0 ? -d : d;
+        if (ad != 0) acc = add(acc, cached_cneg(tbl[s * 8 + ad - 1], d < 0));   // wave-uniform: one item per wave
+      }
     }
     return acc;
   }
@@ -332,6 +337,43 @@ struct CoopEd {
         ext[(size_t)(1 * 8 + l) * n2 + slot] = y[l];
         ext[(size_t)(2 * 8 + l) * n2 + slot] = z[l];
       }
+    }
+  }
+
+  ELL_HD static P load_affine(const u8* xy, size_t i) {
+    u32 tx[8], ty[8];
+    load_be<8>(tx, xy + i * 64, 32);
+    load_be<8>(ty, xy + i * 64 + 32, 32);
+    return from_affine(F::from_plain(tx), F::from_plain(ty));
+  }
+  // Point#mul (edwards.js:362-364) of one item -> ed_normalize's input (edwards.h store_ext's layout)
+  ELL_HD static void mul_var(size_t i, size_t n, const u8* ks, const u8* xy, const DigitStore& ds, u32* ext,
+                             void* row_mem) {
+    u32 k[8];
+    load_be<8>(k, ks + i * 32, 32);
+    P* tbl = lane_table(row_mem);
+    build_table8(tbl, load_affine(xy, i));
+    recode_w4<8, W1::NNIB, true>(k, ds, 0, 1);
+    store_point(ext, n, i, run_w4<1>(ds, tbl));
+  }
+  // Point#mulAdd (edwards.js:366-368): k1*P1 + k2*P2, or k1*G over the comb when xy1 is null
+  ELL_HD static void mul_add(size_t i, size_t n, const u8* k1s, const u8* xy1, const u8* k2s, const u8* xy2,
+                             const W1::P* comb, const DigitStore& ds, u32* ext, void* row_mem) {
+    u32 k1[8], k2[8];
+    load_be<8>(k1, k1s + i * 32, 32);
+    load_be<8>(k2, k2s + i * 32, 32);
+    P* tbl = lane_table(row_mem);
+    if (xy1) {
+      build_table8(tbl, load_affine(xy1, i));
+      build_table8(tbl + 8, load_affine(xy2, i));
+      recode_w4<8, W1::NNIB, true>(k1, ds, 0, 2);
+      recode_w4<8, W1::NNIB, true>(k2, ds, 1, 2);
+      store_point(ext, n, i, run_w4<2>(ds, tbl));
+    } else {
+      build_table8(tbl, load_affine(xy2, i));
+      recode_w4<8, W1::NNIB, true>(k2, ds, 0, 1);
+      const P b = run_w4<1>(ds, tbl);
+      store_point(ext, n, i, add(comb_mul(k1, comb), to_cached(b)));
     }
   }
 

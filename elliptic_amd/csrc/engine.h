@@ -664,7 +664,7 @@ struct FnEddsaVerify {
 struct FnEddsaPartsC {
   static constexpr const char* NAME = "eddsa_parts_c";
   static constexpr int DS_PER_LANE = EdWork::NWIN;
-  static constexpr int ROW_BYTES = CoopEd::ROW_BYTES;
+  static constexpr int ROW_BYTES = CoopEd::ROW_BYTES2;      // (lane_table strides by sixteen entries)
   size_t n; const u8* msgs; const u64* off; size_t msg_len; const u8* sigs; const u8* pubs;
   const EdWork::P* comb; u32* ext; u8* flags;
   ELL_HD void operator()(size_t unit, const DigitStore& ds, void* row_mem) const {
@@ -673,6 +673,19 @@ struct FnEddsaPartsC {
     const u8* m = off ? msgs + off[i] : msgs + i * msg_len;
     const u64 len = off ? off[i + 1] - off[i] : (u64)msg_len;
     CoopEd::verify_part(i, n, part, m, len, sigs + i * 64, pubs + i * 32, comb, ds, ext, flags, row_mem);
+  }
+};
+// edwards Point#mul / mulAdd for a handful of items: one item per wave (coop_ed.h), then the
+// one-lane normalisation
+struct FnEdMulC {
+  static constexpr const char* NAME = "ed_mul_c";
+  static constexpr int DS_PER_LANE = 2 * EdWork::NWIN;
+  static constexpr int ROW_BYTES = CoopEd::ROW_BYTES2;
+  // k1 == null: k2*P2; xy1 == null: k1*G + k2*P2
+  size_t n; const u8* k1; const u8* xy1; const u8* k2; const u8* xy2; const EdWork::P* comb; u32* ext;
+  ELL_HD void operator()(size_t i, const DigitStore& ds, void* row_mem) const {
+    if (!k1) CoopEd::mul_var(i, n, k2, xy2, ds, ext, row_mem);
+    else CoopEd::mul_add(i, n, k1, xy1, k2, xy2, comb, ds, ext, row_mem);
   }
 };
 struct FnEddsaJoin {
@@ -2520,8 +2533,13 @@ int Engine<BK>::ed_mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy
   EdWork::P* tbl = (EdWork::P*)scratch(S_TBL, n * 8 * sizeof(EdWork::P));
   u32* ext = (u32*)scratch(S_JAC, n * 4 * 8 * 4);
   if (!tbl || !ext) return fail(E_NOMEM, "scratch allocation failed");
-  FnEdMulVar f{n, k, xy, tbl, ext};
-  bk.launch(f, n);
+  if (n <= coop_grid()) {
+    FnEdMulC fc{n, nullptr, nullptr, k, xy, nullptr, ext};
+    bk.launch_coop(fc, n);
+  } else {
+    FnEdMulVar f{n, k, xy, tbl, ext};
+    bk.launch(f, n);
+  }
   int rc = ed_normalize_chunk(n, ext, out_xy, out_inf, raw);
   if (rc == E_OK && out_inf) {
     FnEdDomainMark g{n, xy, nullptr, out_xy, out_inf};
@@ -2547,7 +2565,10 @@ int Engine<BK>::ed_mul_add2_chunk(size_t n, const u8* k1, const u8* xy1, const u
   u32* ext = (u32*)scratch(S_JAC, n * 4 * 8 * 4);
   EdWork::P* tbl = (EdWork::P*)scratch(S_TBL, n * 16 * sizeof(EdWork::P));
   if (!tbl || !ext) return fail(E_NOMEM, "scratch allocation failed");
-  if (xy1) {
+  if (n <= coop_grid()) {
+    FnEdMulC fc{n, k1, xy1, k2, xy2, (const EdWork::P*)comb_[CURVE_ED25519], ext};
+    bk.launch_coop(fc, n);
+  } else if (xy1) {
     FnEdMulAdd2 f{n, k1, xy1, k2, xy2, tbl, ext};
     bk.launch(f, n);
   } else {

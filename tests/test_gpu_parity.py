@@ -626,8 +626,28 @@ def test_eddsa_verify_small_batches_on_the_row_layer(monkeypatch):
     good = np.ones(n, bool)
     good[::9] = False
     assert ok[good].all() and not ok[::9].any() and not err[good].any() and err[::9].sum() > 10
+    # edwards Point#mul / mulAdd of a handful of items: one item per wave (ed_mul_c)
+    kk = np.frombuffer(hashlib.shake_256(b"row-layer:edmul").digest(n * 64), np.uint8).reshape(n, 64)
+    k1, k2 = np.ascontiguousarray(kk[:, :32]), np.ascontiguousarray(kk[:, 32:])
+    for i, kv in enumerate((0, 1, 2, L_ORDER - 1, L_ORDER, L_ORDER + 1, (1 << 256) - 1)):
+        k2[20 + i] = np.frombuffer(int(kv).to_bytes(32, "big"), np.uint8)
+    pts, _ = c0.mul_fixed("ed25519", sec)
+    pts2, _ = c0.mul_fixed("ed25519", k1)
+    for m in (1, 3, 64, 1365, 1366):
+        outs = []
+        for c, rowk in ((c0, False), (c1, True), (cd, m <= 1365)):
+            c.set_timing(True)
+            r = (c.mul_var("ed25519", k2[:m], pts[:m]), c.mul_add2("ed25519", k1[:m], pts2[:m], k2[:m], pts[:m]),
+                 c.mul_add2("ed25519", k1[:m], None, k2[:m], pts[:m]))
+            tm = c.get_timing()
+            c.set_timing(False)
+            assert ("ed_mul_c" in tm) == rowk and ("ed_mul_var" in tm) != rowk, (m, rowk, sorted(tm))
+            outs.append(r)
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), m
     for c in (c0, c1):
-        assert PC.check_eddsa_golden(c) > 200
+        assert PC.check_eddsa_golden(c) > 200 and PC.check_mul_golden(c, "ed25519") > 50
     for c in (c0, c1, cd):
         c.close()
 

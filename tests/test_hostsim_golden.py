@@ -373,6 +373,11 @@ def test_eddsa_verify_one_lane_and_row_layer(hs, monkeypatch):
         assert PC.check_eddsa_golden(c) > 200
         assert (hs.hs_launches(b"eddsa_parts_c") > 0) == rowk and (hs.hs_launches(b"eddsa_verify") > 0) != rowk
         assert (hs.hs_launches(b"eddsa_join") > 0) == rowk
+        # edwards Point#mul / mulAdd (all three forms) of a handful of items: one item per wave
+        hs.hs_launches_reset()
+        assert PC.check_mul_golden(c, "ed25519") > 50
+        assert PC.check_offcurve_golden(c, "ed25519") >= 29
+        assert (hs.hs_launches(b"ed_mul_c") > 0) == rowk and (hs.hs_launches(b"ed_mul_var") > 0) != rowk
         c.close()
 
 
