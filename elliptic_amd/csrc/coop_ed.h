@@ -16,6 +16,7 @@
 
 #include "coop_mont.h"
 #include "edwards.h"
+#include "mont.h"
 
 namespace ell {
 
@@ -53,7 +54,7 @@ struct Fp25519C : FpMontC<consts::COOP_P25519, Fp25519> {
   // Result: limbs below 2^29 + 2^13, limb 8 below 2^23 + 2^11.
   template <bool RW = false>
   ELL_HD static El fold(const W64& acc, i64 col16) {
-    const El live = B::c_live(), sh = c_sh(), m3 = c_m3(), k19 = c_19();
+    const El live = B::c_live();
     W64 c1;
     El lo1;
     ELL_UNROLL
@@ -78,6 +79,13 @@ struct Fp25519C : FpMontC<consts::COOP_P25519, Fp25519> {
     W64 tt;
     ELL_UNROLL
     for (int t = 0; t < CL; t++) tt.w[t] = (i64)B::s(v2.v[t] & live.v[t]) + (i64)B::s(h0.v[t]) * FOLD;
+    return carry3<RW>(tt);
+  }
+  // the last carry pass: nine limbs below 2^63 -> 29-bit digits + carries, limb 8 cut at bit 23 and
+  // its carry folded by 19 onto limb 0
+  template <bool RW = false>
+  ELL_HD static El carry3(const W64& tt) {
+    const El live = B::c_live(), sh = c_sh(), m3 = c_m3(), k19 = c_19();
     El c3, lo3;
     ELL_UNROLL
     for (int t = 0; t < CL; t++) {
@@ -90,6 +98,13 @@ struct Fp25519C : FpMontC<consts::COOP_P25519, Fp25519> {
     ELL_UNROLL
     for (int t = 0; t < CL; t++) r.v[t] = (lo3.v[t] + cin3.v[t] + (u32)hi * k19.v[t]) & live.v[t];
     return r;
+  }
+  // a * k for a small constant k (a in the interface's range, 0 < k < 2^20): limbs below 2^29 + 2^25
+  ELL_HD static El mul_small(const El& a, i32 k) {
+    W64 tt;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) tt.w[t] = (i64)B::s(a.v[t]) * (i64)k;
+    return carry3<false>(tt);
   }
   ELL_HD static El mul(const El& a, const El& b) {
 #if defined(ELL_BOUNDS_CHECK)
@@ -410,6 +425,57 @@ struct CoopEd {
       const P sg = comb_mul(S, comb);
       store_point(ext, 2 * n, n + i, add(sg, to_cached(R)));
       if (CoopK256::writer()) flags[n + i] = (u8)((r_ok ? 1 : 0) | (s_ok ? 2 : 0));
+    }
+  }
+};
+
+// curve25519's x-only ladder for a handful of items (mont.h MontWork::ladder: mont.js:82-153), one
+// item per wave.  A step is the differential addition and the doubling together: their first four
+// products side by side, then three of the next four with the small-constant multiple in between,
+// then x1 * (da - cb)^2.
+struct CoopX25519 {
+  typedef Fp25519C F;
+  typedef F::El El;
+  typedef MontWork W1;
+  static constexpr int ROW_BYTES = 16;
+  struct XZ { El x, z; };
+
+  ELL_HD static void ladder(size_t i, size_t n, const u8* ks, const u8* xs, u32* xz) {
+    u32 k[8], t[8];
+    load_be<8>(k, ks + i * 32, 32);
+    load_be<8>(t, xs + i * 32, 32);
+    const El x1 = F::from_plain(t);
+    XZ a, b;
+    a.x = x1; a.z = F::one();
+    b.x = F::one(); b.z = F::zero();
+    ELL_NOUNROLL
+    for (int w = 0; w < 256; w++) {
+      const bool bit = (k[7] >> 31) != 0;                 // wave-uniform: one item per wave
+      ELL_UNROLL
+      for (int l = 7; l > 0; l--) k[l] = (k[l] << 1) | (k[l - 1] >> 31);
+      k[0] <<= 1;
+      const El as = F::norm(F::add_l(a.x, a.z)), ad = F::norm(F::sub_l(a.x, a.z));
+      const El bs = F::norm(F::add_l(b.x, b.z)), bd = F::norm(F::sub_l(b.x, b.z));
+      El da, cb, aa, bb;
+      F::unpack4(F::mulq(F::pack4(bd, bs, bit ? as : bs, bit ? ad : bd), F::pack4(as, ad, bit ? as : bs, bit ? ad : bd)), da, cb, aa, bb);
+      const El e = F::norm(F::sub_l(aa, bb));
+      const El f = F::add_l(bb, F::mul_small(e, (i32)W1::C::a24[0]));      // lazy: limbs below 2^30 + 2^26
+      const El sp = F::norm(F::add_l(da, cb)), sm = F::norm(F::sub_l(da, cb));
+      El sx, t2, dx, dz;
+      F::unpack4(F::mulq(F::pack4(sp, sm, aa, e), F::pack4(sp, sm, bb, f)), sx, t2, dx, dz);
+      const El sz = F::mul(x1, t2);
+      a.x = bit ? dx : sx; a.z = bit ? dz : sz;
+      b.x = bit ? sx : dx; b.z = bit ? sz : dz;
+    }
+    u32 ox[8], oz[8];
+    F::to_plain(ox, b.x);
+    F::to_plain(oz, b.z);
+    if (CoopK256::writer()) {
+      ELL_UNROLL
+      for (int l = 0; l < 8; l++) {
+        xz[(size_t)(0 * 8 + l) * n + i] = ox[l];
+        xz[(size_t)(1 * 8 + l) * n + i] = oz[l];
+      }
     }
   }
 };

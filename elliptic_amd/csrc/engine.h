@@ -688,6 +688,13 @@ struct FnEdMulC {
     else CoopEd::mul_add(i, n, k1, xy1, k2, xy2, comb, ds, ext, row_mem);
   }
 };
+struct FnX25519C {
+  static constexpr const char* NAME = "x25519_c";
+  static constexpr int DS_PER_LANE = 0;
+  static constexpr int ROW_BYTES = CoopX25519::ROW_BYTES;
+  size_t n; const u8* k; const u8* x; u32* xz;
+  ELL_HD void operator()(size_t i, const DigitStore&, void*) const { CoopX25519::ladder(i, n, k, x, xz); }
+};
 struct FnEddsaJoin {
   static constexpr const char* NAME = "eddsa_join";
   static constexpr int DS_PER_LANE = 0;
@@ -2589,8 +2596,13 @@ int Engine<BK>::x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* 
   u32* xz = (u32*)scratch(S_JAC, n * 2 * 8 * 4);
   u32* pre = (u32*)scratch(S_PRE, n * 8 * 4);
   if (!xz || !pre) return fail(E_NOMEM, "scratch allocation failed");
-  FnX25519 f{n, k, x, xz};
-  bk.launch(f, n);
+  if (n <= coop_grid()) {
+    FnX25519C fc{n, k, x, xz};
+    bk.launch_coop(fc, n);
+  } else {
+    FnX25519 f{n, k, x, xz};
+    bk.launch(f, n);
+  }
   const int K = norm_batch_for(n);
   size_t T = (n + K - 1) / K;
   FnX25519Normalize g{T, n, K, xz, pre, out_x, out_inf};

@@ -646,8 +646,25 @@ def test_eddsa_verify_small_batches_on_the_row_layer(monkeypatch):
         for o in outs[1:]:
             for a, b in zip(outs[0], o):
                 assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), m
+    # curve25519 Point#mul (x only), one item per wave (x25519_c): unclamped scalars incl. 0, 1 and
+    # 2^256 - 1, u = 0, 1, p - 1 and a point of small order
+    xs = np.ascontiguousarray(kk[:, :32]).copy()
+    xs[:, 0] &= 0x7F
+    for i, xv in enumerate((0, 1, 2 ** 255 - 20, 9, 325606250916557431795983626356110631294008115727848805560023387167927233504)):
+        xs[30 + i] = np.frombuffer(int(xv).to_bytes(32, "big"), np.uint8)
+    for m in (1, 40, 1365, 1366):
+        outs = []
+        for c, rowk in ((c0, False), (c1, True), (cd, m <= 1365)):
+            c.set_timing(True)
+            outs.append(c.x25519(k2[:m], xs[:m]))
+            tm = c.get_timing()
+            c.set_timing(False)
+            assert ("x25519_c" in tm) == rowk and ("x25519_ladder" in tm) != rowk, (m, rowk, sorted(tm))
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]), m
     for c in (c0, c1):
         assert PC.check_eddsa_golden(c) > 200 and PC.check_mul_golden(c, "ed25519") > 50
+        assert PC.check_x25519_golden(c) > 30
     for c in (c0, c1, cd):
         c.close()
 

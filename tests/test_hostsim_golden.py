@@ -378,6 +378,10 @@ def test_eddsa_verify_one_lane_and_row_layer(hs, monkeypatch):
         assert PC.check_mul_golden(c, "ed25519") > 50
         assert PC.check_offcurve_golden(c, "ed25519") >= 29
         assert (hs.hs_launches(b"ed_mul_c") > 0) == rowk and (hs.hs_launches(b"ed_mul_var") > 0) != rowk
+        # curve25519's x-only ladder, one item per wave (coop_ed.h CoopX25519)
+        hs.hs_launches_reset()
+        assert PC.check_x25519_golden(c) > 30
+        assert (hs.hs_launches(b"x25519_c") > 0) == rowk and (hs.hs_launches(b"x25519_ladder") > 0) != rowk
         c.close()
 
 

@@ -53,6 +53,16 @@ libs.forEach(function(l) {
   var ek = ed.keyFromSecret(crypto.createHash('sha256').update('ed').digest());
   var esig = ek.sign(msg).toHex(), epub = ek.getPublic('hex');
   out('EDDSA#verify', l[0], timeSync(function() { return ed.verify(msg, esig, epub); }, 100));
+  // the other two curve families' own Point#mul
+  var eA = ek.pub(), ekk = kp.getPrivate();
+  out('ed25519 Point#mul', l[0], timeSync(function() { return eA.mul(ekk).getX(); }, 100));
+  var c25 = new l[1].ec('curve25519');
+  var mk = c25.keyFromPrivate(crypto.createHash('sha256').update('m').digest());
+  var mP = c25.keyFromPrivate(crypto.createHash('sha256').update('n').digest()).getPublic();
+  var mkk = mk.getPrivate();
+  out('curve25519 Point#mul (x only)', l[0], timeSync(function() { return mP.mul(mkk).getX(); }, 100));
+  // (KeyPair#derive = MontCurve#validate -- a square root in JavaScript, not patched -- + this mul)
+  out('curve25519 KeyPair#derive', l[0], timeSync(function() { return mk.derive(mP); }, 100));
 });
 
 // the engine's own asynchronous single call, alone and 64 at a time (one launch)
