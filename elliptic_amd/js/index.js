@@ -414,15 +414,25 @@ function install(elliptic, options) {
         writable: true });
       return null;
     }
+    // A singular cubic (4 a^3 + 27 b^2 = 0) has no group law at its singular point, and an Edwards
+    // curve whose addition law is not complete (complete: a a square, d not -- Bernstein et al.,
+    // "Twisted Edwards curves", section 6) has pairs of points on which the projective formulas give
+    // Z = 0: there the reference's result depends on the order in which ITS ladder adds, and is not
+    // the engine's.  Such curves (exhaustive search over F_5, F_7, F_11: the only disagreements) stay
+    // on the reference's own code.
+    var red = curve.red, fe = function(v) { return new BN(v).toRed(red); };
     if (curve.type === 'short' && curve.a && curve.b && curve.p.bitLength() <= 256 &&
-        curve.p.isOdd() && curve.p.cmpn(3) > 0) {
+        curve.p.isOdd() && curve.p.cmpn(3) > 0 &&
+        curve.a.redSqr().redMul(curve.a).redMul(fe(4)).redAdd(curve.b.redSqr().redMul(fe(27))).cmpn(0) !== 0) {
       try {
         d = { name: 'custom', custom: true, B: 32,
           id: eng.defineShort(curve.p, curve.a.fromRed(), curve.b.fromRed()) };
       } catch (e) { d = null; }
     } else if (curve.type === 'edwards' && curve.a && curve.d && curve.c &&
         curve.c.fromRed().cmpn(1) === 0 && curve.p.bitLength() <= 256 && curve.p.isOdd() &&
-        curve.p.cmpn(3) > 0) {
+        curve.p.cmpn(3) > 0 && curve.a.cmp(curve.d) !== 0 &&
+        curve.a.redPow(curve.p.subn(1).ushrn(1)).cmp(fe(1)) === 0 &&
+        curve.d.redPow(curve.p.subn(1).ushrn(1)).cmp(fe(1).redNeg()) === 0) {
       // (twisted) Edwards curves other than ed25519, c = 1: projective ladder on the device
       // (the reference's _projDbl / _projAdd for a != -1, its extended forms for a = -1)
       try {
@@ -444,7 +454,8 @@ function install(elliptic, options) {
     // the reference's field operations throw 'red works only with red numbers' on it, its own to throw)
     if (!p || p.curve !== curve || p.isInfinity()) return null;
     var x, y;
-    if (curve.type === 'short') { x = p.getX(); y = p.getY(); }
+    // (the reference's _wnafMulAdd also takes Jacobian points, base.js:158-183, 222-233: its own)
+    if (curve.type === 'short') { if (p.type !== 'affine') return null; x = p.getX(); y = p.getY(); }
     else {
       // extended coordinates carry T = X Y / Z, which the reference's _extAdd / _extDbl USE
       // (edwards.js:279-309): a point built with any other T (curve.point(x, y, z, t) takes what
@@ -463,6 +474,144 @@ function install(elliptic, options) {
     if (curve.type === 'short')
       return !p.inf && p.x.cmp(curve.g.x) === 0 && p.y.cmp(curve.g.y) === 0;
     return p === curve.g;
+  }
+  // ---- inputs the reference TRUSTS: precomputed tables and the endomorphism's constants --------
+  // A point's `precomputed` tables are input to the reference's ladders: _fixedNafMul adds
+  // doubles.points[j] (base.js:44-94), _wnafMul / _wnafMulAdd add naf.points[(z - 1) >> 1]
+  // (base.js:96-253, through _getNAFPoints, base.js:342-360), _endoWnafMulAdd takes
+  // precomputed.beta for lambda * P (short.js:282-310) -- whatever they hold.  precompute() fills
+  // them with the true multiples, but curve.pointFromJSON([x, y, { doubles, naf }])
+  // (short.js:332-359, edwards.js the same way) takes them from the caller, and a table that is
+  // not the point's multiples makes the reference return something else than k * P.  The engine
+  // computes k * P from (x, y) alone, so it answers only for points whose tables ARE their
+  // multiples: each table is checked once (the reference's Jacobian / projective dbl() and add(), a
+  // few milliseconds per curve), and the verdict
+  // is remembered on the table object; anything else is left to the reference's own ladders.
+  function hide(o, k, v) {
+    try { Object.defineProperty(o, k, { value: v, enumerable: false, writable: true, configurable: true }); }
+    catch (e) { /* a frozen object: checked again next time */ }
+  }
+  function canonical(curve, v) { return !!v && v.red === curve.red && !v.isNeg() && v.cmp(curve.p) < 0; }
+  function entryOK(curve, e) {
+    if (!e || e.curve !== curve || !canonical(curve, e.x) || !canonical(curve, e.y)) return false;
+    if (curve.type === 'short') return e.type === 'affine' && e.inf === false;
+    if (!canonical(curve, e.z) || e.z.cmpn(0) === 0) return false;
+    if (e.zOne && e.z.cmp(curve.one) !== 0) return false;
+    // extended coordinates: _extAdd multiplies the entries' T (edwards.js:279-309)
+    if (curve.extended && (!canonical(curve, e.t) || e.t.redMul(e.z).cmp(e.x.redMul(e.y)) !== 0)) return false;
+    return true;
+  }
+  // a table entry against the multiple it should be (q: a Jacobian point on a short curve -- no
+  // inversions -- a projective / extended one on an Edwards curve): cross-multiplied coordinates
+  function samePoint(curve, e, q) {
+    if (!entryOK(curve, e) || !q) return false;
+    if (curve.type === 'short') return !q.isInfinity() && q.eq(e);
+    return e.x.redMul(q.z).cmp(q.x.redMul(e.z)) === 0 && e.y.redMul(q.z).cmp(q.y.redMul(e.z)) === 0;
+  }
+  function checkTable(curve, p, tbl, kind) {
+    var pts = tbl.points, w = kind === 'naf' ? tbl.wnd : tbl.step;
+    if (!Array.isArray(pts) || !Number.isInteger(w) || w < 1 || w > 12 || !entryOK(curve, p)) return false;
+    var i, q = curve.type === 'short' ? p.toJ() : p;
+    if (!samePoint(curve, pts[0], q)) return false;
+    if (kind === 'naf') {
+      // entry i is (2 i + 1) * P; a digit of getNAF(k, wnd) reaches index 2^(wnd-1) - 1 at most
+      var need = 1 << (w - 1);
+      if (pts.length < need) return false;
+      var two = need > 1 ? q.dbl() : null;
+      for (i = 1; i < need; i++) {
+        q = q.add(two);
+        if (!samePoint(curve, pts[i], q)) return false;
+      }
+      return true;
+    }
+    // doubles: entry j is 2^(step j) * P, every one of them within reach of _hasDoubles
+    for (i = 1; i < pts.length; i++) {
+      for (var s = 0; s < w; s++) q = q.dbl();
+      if (!samePoint(curve, pts[i], q)) return false;
+    }
+    return true;
+  }
+  function tableOK(curve, p, tbl, kind) {
+    if (!tbl) return true;
+    var c = tbl._ellgpuOK;
+    var w = kind === 'naf' ? tbl.wnd : tbl.step;
+    if (c && c.p === p && c.pts === tbl.points && c.len === (tbl.points && tbl.points.length) && c.w === w) return c.ok;
+    var ok = false;
+    refOnly++;
+    try { ok = typeof tbl === 'object' && checkTable(curve, p, tbl, kind); } catch (e) { ok = false; } finally { refOnly--; }
+    hide(tbl, '_ellgpuOK', { p: p, pts: tbl.points, len: tbl.points && tbl.points.length, w: w, ok: ok });
+    return ok;
+  }
+  function tablesOK(curve, p, inner) {
+    var pre = p && p.precomputed;
+    if (!pre) return true;
+    if (typeof pre !== 'object') return false;
+    if (!tableOK(curve, p, pre.naf, 'naf') || !tableOK(curve, p, pre.doubles, 'doubles')) return false;
+    if (pre.beta && curve.type === 'short' && curve.endo) {
+      // lambda * P as _getBeta caches it: (beta x, y), with the tables of THAT point
+      var b = pre.beta;
+      if (inner || !entryOK(curve, b) || b.x.cmp(p.x.redMul(curve.endo.beta)) !== 0 || b.y.cmp(p.y) !== 0) return false;
+      if (!tablesOK(curve, b, true)) return false;
+    }
+    return true;
+  }
+  // The GLV ladder of the reference (short.js:168-249) is k * P only if its constants are what
+  // _getEndomorphism would compute: conf.beta / conf.lambda / conf.basis are taken as given
+  // (short.js:36-67), and k1 + k2 lambda = k (mod n) says nothing about a point outside <G> -- on a
+  // curve whose group is larger than n the reference's result for such a point is not k * P.  The
+  // engine answers for a curve with an endomorphism only when it can see that the two agree on
+  // EVERY point of the curve: beta^3 = 1, n prime with n * G = O and lambda * G = (beta x_G, y_G), n
+  // the only multiple of itself in the Hasse interval (so the group IS <G>), both basis vectors in
+  // the lattice a + b lambda = 0 (mod n).  Checked once per curve object (two multiplications by
+  // the reference's plain w-NAF ladder).
+  function checkEndo(curve) {
+    var e = curve.endo, n = curve.n, g = curve.g, p = curve.p;
+    if (!e.beta || e.beta.red !== curve.red || !BN.isBN(e.lambda) || e.lambda.red || !Array.isArray(e.basis) || e.basis.length !== 2) return false;
+    if (!n || !g || g.inf !== false || n.isNeg() || n.cmpn(3) < 0) return false;
+    var one = new BN(1).toRed(curve.red);
+    if (e.beta.cmp(one) === 0 || e.beta.redSqr().redMul(e.beta).cmp(one) !== 0) return false;
+    // #E(F_p) = n: n is prime, lies in the Hasse interval and is wider than the interval
+    var t = n.sub(p).isubn(1);
+    if (t.sqr().cmp(p.muln(4)) > 0 || n.sqr().cmp(p.muln(16)) <= 0 || !probablyPrime(n)) return false;
+    for (var i = 0; i < 2; i++) {
+      var v = e.basis[i];
+      if (!v || !BN.isBN(v.a) || !BN.isBN(v.b) || v.a.add(v.b.mul(e.lambda)).umod(n).cmpn(0) !== 0) return false;
+    }
+    var g0 = curve.point(g.x, g.y);                       // no tables: the plain ladder builds its own
+    if (!curve.validate(g0)) return false;
+    if (!orig.wnafMul.call(curve, g0, n).isInfinity()) return false;
+    var lg = orig.wnafMul.call(curve, g0, e.lambda.umod(n));
+    return !lg.isInfinity() && lg.x.cmp(g.x.redMul(e.beta)) === 0 && lg.y.cmp(g.y) === 0;
+  }
+  function endoOK(curve) {
+    var e = curve.endo;
+    if (!e) return true;
+    var c = curve._ellgpuEndo;
+    if (c && c.endo === e && c.beta === e.beta && c.lambda === e.lambda && c.basis === e.basis && c.n === curve.n && c.g === curve.g) return c.ok;
+    var ok = false;
+    refOnly++;
+    try { ok = checkEndo(curve); } catch (x) { ok = false; } finally { refOnly--; }
+    hide(curve, '_ellgpuEndo', { endo: e, beta: e.beta, lambda: e.lambda, basis: e.basis, n: curve.n, g: curve.g, ok: ok });
+    return ok;
+  }
+  // the engine's domain for the ladders of this curve, or null: the reference's own code
+  function ladderDomain(curve) {
+    if (curve.type === 'mont') return null;
+    var d = domain(curve) || customDomain(curve);
+    if (d && curve.type === 'short' && curve.endo && !endoOK(curve)) return null;
+    return d;
+  }
+  // ... and for the protocol calls, which also multiply the curve's own G (with ITS tables)
+  function protocolDomain(curve) {
+    var d = domain(curve);
+    if (!d) return null;
+    if (curve.type === 'short' && curve.endo && !endoOK(curve)) return null;
+    return tablesOK(curve, curve.g) ? d : null;
+  }
+  // an operand as the engine takes it, or null where the reference must compute by itself
+  function operandBuf(curve, p, B) {
+    var b = affineBuf(curve, p, B);
+    return b && tablesOK(curve, p) ? b : null;
   }
   function resultPoint(curve, d, r, jacobian) {
     var B = d.B;
@@ -497,20 +646,20 @@ function install(elliptic, options) {
     try { return origFn.apply(curve, origArgs); } finally { refOnly--; }
   }
   function mul1(curve, p, k, origFn, origArgs) {
-    var d = curve.type === 'mont' ? null : (domain(curve) || customDomain(curve));
+    var d = ladderDomain(curve);
     var kb = d && scalarBuf(k, d.B);
-    var pb = kb && affineBuf(curve, p, d.B);
+    var pb = kb && operandBuf(curve, p, d.B);
     if (!d || !kb || !pb) { eng.stats.passthrough++; return origFn.apply(curve, origArgs); }
     var r = isG(curve, d, p) ? eng.mulBatch(d.id, kb, null) : eng.mulBatch(d.id, kb, pb);
     if (r.inf[0] === OFF_CURVE) return offCurve(curve, origFn, origArgs);
     return resultPoint(curve, d, r, false);
   }
   function mulAdd(curve, p1, k1, p2, k2, jacobian, origFn, origArgs) {
-    var d = curve.type === 'mont' ? null : (domain(curve) || customDomain(curve));
+    var d = ladderDomain(curve);
     var b1 = d && scalarBuf(k1, d.B);
     var b2 = b1 && scalarBuf(k2, d.B);
-    var q1 = b2 && affineBuf(curve, p1, d.B);
-    var q2 = q1 && affineBuf(curve, p2, d.B);
+    var q1 = b2 && operandBuf(curve, p1, d.B);
+    var q2 = q1 && operandBuf(curve, p2, d.B);
     if (!q2) { eng.stats.passthrough++; return origFn.apply(curve, origArgs); }
     var r = eng.mulAddBatch(d.id, b1, isG(curve, d, p1) ? null : q1, b2, q2);
     if (r.inf[0] === OFF_CURVE) return offCurve(curve, origFn, origArgs);
@@ -523,14 +672,14 @@ function install(elliptic, options) {
   // are paired up, every pair is one item of ONE k1*P1 + k2*P2 launch, and the partial sums are
   // added with the reference's Point#add.
   function mulAddMany(curve, points, coeffs, len, jacobian, origFn, origArgs) {
-    var d = curve.type === 'mont' ? null : (domain(curve) || customDomain(curve));
+    var d = ladderDomain(curve);
     var k1 = [], p1 = [], k2 = [], p2 = [];
     var ok = !!d && len >= 3 && len <= 8;
     for (var i = 0; ok && i < len; i += 2) {
       var j = i + 1 < len ? i + 1 : i;               // odd tail: k * P + 0 * P
-      var a = scalarBuf(coeffs[i], d.B), pa = affineBuf(curve, points[i], d.B);
+      var a = scalarBuf(coeffs[i], d.B), pa = operandBuf(curve, points[i], d.B);
       var b = j === i ? Buffer.alloc(d.B) : scalarBuf(coeffs[j], d.B);
-      var pb = affineBuf(curve, points[j], d.B);
+      var pb = operandBuf(curve, points[j], d.B);
       if (!a || !pa || !b || !pb) { ok = false; break; }
       k1.push(a); p1.push(pa); k2.push(b); p2.push(pb);
     }
@@ -549,7 +698,8 @@ function install(elliptic, options) {
   }
 
   base._fixedNafMul = function _fixedNafMul(p, k) {
-    if (refOnly) return orig.fixedNafMul.apply(this, arguments);
+    // (base.js:44-46: the reference asserts p.precomputed and reads its doubles)
+    if (refOnly || !p || !p.precomputed || !p.precomputed.doubles) return orig.fixedNafMul.apply(this, arguments);
     return mul1(this, p, k, orig.fixedNafMul, arguments);
   };
   base._wnafMul = function _wnafMul(p, k) {
@@ -667,7 +817,7 @@ function install(elliptic, options) {
   ecProto.sign = function sign(msg, key, enc, options) {
     if (typeof enc === 'object') { options = enc; enc = null; }
     if (!options) options = {};
-    var d = domain(this.curve);
+    var d = protocolDomain(this.curve);
     var res = null;
     try {
       if (!d || options.k || options.pers !== undefined || typeof msg !== 'object' || BN.isBN(msg) ||
@@ -709,8 +859,8 @@ function install(elliptic, options) {
   // the original method, which throws / answers by itself.
   orig.verify = ecProto.verify;
   ecProto.verify = function verify(msg, signature, key, enc, options) {
-    var d = domain(this.curve);
-    if (refOnly || !d || d.custom || this.curve.type !== 'short' || !byteMessage(msg) || !plainMsgBits(options))
+    var d = refOnly ? null : protocolDomain(this.curve);
+    if (!d || d.custom || this.curve.type !== 'short' || !byteMessage(msg) || !plainMsgBits(options))
       return orig.verify.apply(this, arguments);
     var m, ok;
     try {
@@ -719,6 +869,7 @@ function install(elliptic, options) {
       if (!pub || pub.isInfinity() || pub.curve !== this.curve) throw null;
       var item = { msg: msg, signature: signature, key: kp, options: options || undefined };
       m = marshalOne(this, d, item);
+      if (m.ref) throw null;                   // a key with tables of its own that are not its multiples
       var pk = packVerify([ m ], msg.length, msgBitsOf(item)).o;
       pk.status = Buffer.alloc(1);
       ok = eng.ecdsaVerifyBatch(d.id, pk)[0];
@@ -732,7 +883,7 @@ function install(elliptic, options) {
   };
   orig.recoverPubKey = ecProto.recoverPubKey;
   ecProto.recoverPubKey = function recoverPubKey(msg, signature, j, enc) {
-    var d = domain(this.curve);
+    var d = protocolDomain(this.curve);
     var e, r, s, NB;
     try {
       if (!d || (3 & j) !== j) throw null;
@@ -783,10 +934,10 @@ function install(elliptic, options) {
   function pointIsItsEncoding(eddsa, P, enc) {
     if (!P || P.curve !== eddsa.curve || !P.zOne || !P.x || !P.y || !P.t) return false;
     if (!P.x.red || !P.y.red || !P.t.red || P.t.cmp(P.x.redMul(P.y)) !== 0) return false;
-    return eddsa.curve.validate(P) && sameBytes(eddsa.encodePoint(P), enc);
+    return eddsa.curve.validate(P) && tablesOK(eddsa.curve, P) && sameBytes(eddsa.encodePoint(P), enc);
   }
   eddsaProto.verify = function verify(message, sig, pub) {
-    var d = domain(this.curve);
+    var d = protocolDomain(this.curve);
     var utils = elliptic.utils;
     var m, sb, pb;
     try {
@@ -825,7 +976,7 @@ function install(elliptic, options) {
   // S = r + h*a in one call; other secrets (any length is legal for the reference) pass through.
   orig.eddsaSign = eddsaProto.sign;
   eddsaProto.sign = function sign(message, secret) {
-    var d = domain(this.curve);
+    var d = protocolDomain(this.curve);
     try {
       if (!d || d.name !== 'ed25519') throw null;
       var mm = elliptic.utils.parseBytes(message);
@@ -875,13 +1026,20 @@ function install(elliptic, options) {
   // EC#verify over many signatures with the reference's own decoding
   // (keyFromPublic, Signature, _truncateToN's length rule) and ONE launch.
   // items: [{ msg: Buffer|Array, signature, key, enc? }] -> [bool]
+  // a preset whose G carries tables that are not G's multiples, or whose endomorphism constants are
+  // not the curve's (protocolDomain): every item through EC#verify, whose ladders decide by themselves
+  function untrusted(ec, d) { return d && !protocolDomain(ec.curve); }
+  function verifyEach(ec, items) {
+    return items.map(function(it) { return ec.verify(it.msg, it.signature, it.key, it.enc, it.options); });
+  }
   eng.verifyMany = function verifyMany(ec, items) {
     var d = domain(ec.curve);
     if (!d || ec.curve.type !== 'short') throw new Error('verifyMany: unsupported curve');
+    if (untrusted(ec, d)) return verifyEach(ec, items);
     var m = marshalVerify(ec, d, items);
     m.o.status = Buffer.alloc(items.length);
     var ok = eng.ecdsaVerifyBatch(d.id, m.o);
-    return items.map(function(it, i) { return verdict(ec, it, m.pre[i], m.o.status[i] === OFF_CURVE ? OFF_CURVE : ok[i]); });
+    return items.map(function(it, i) { return verdict(ec, it, m.pre[i], m.ref[i] || m.o.status[i] === OFF_CURVE ? OFF_CURVE : ok[i]); });
   };
   // a key that is not on the curve (status 2): the reference computes with it -- and can answer
   // true -- so that item goes through EC#verify itself, with the reference's own ladders
@@ -908,16 +1066,19 @@ function install(elliptic, options) {
     var key = ec.keyFromPublic(it.key, it.enc);
     var sig = new Signature(it.signature, 'hex');
     var bad = sig.r.isNeg() || sig.s.isNeg() || sig.r.byteLength() > NB || sig.s.byteLength() > NB;
+    // (a key whose own precomputed tables are not its multiples: the reference's ladder reads
+    // them -- that item is the reference's, like a key that is not on the curve)
+    var q = operandBuf(ec.curve, key.getPublic(), d.B);
     return { pre: !bad, h: Buffer.from(it.msg),
       r: Buffer.from((bad ? new BN(0) : sig.r).toArray('be', NB)),
       s: Buffer.from((bad ? new BN(0) : sig.s).toArray('be', NB)),
-      q: affineBuf(ec.curve, key.getPublic(), d.B) };
+      q: q || Buffer.alloc(2 * d.B), ref: !q };
   }
   function msgBitsOf(it) {
     return it.options && typeof it.options.msgBitLength === 'number' ? it.options.msgBitLength : 0;
   }
   function packVerify(ms, hl, msgBits) {
-    return { pre: ms.map(function(m) { return m.pre; }),
+    return { pre: ms.map(function(m) { return m.pre; }), ref: ms.map(function(m) { return m.ref; }),
       o: { hashes: Buffer.concat(ms.map(function(m) { return m.h; })), hashLen: hl, msgBits: msgBits | 0,
         r: Buffer.concat(ms.map(function(m) { return m.r; })), s: Buffer.concat(ms.map(function(m) { return m.s; })),
         pub: Buffer.concat(ms.map(function(m) { return m.q; })) } };
@@ -935,12 +1096,13 @@ function install(elliptic, options) {
     var d = domain(ec.curve);
     if (!d || ec.curve.type !== 'short')
       return Promise.reject(new Error('verifyMany: unsupported curve'));
+    if (untrusted(ec, d)) return new Promise(function(resolve) { resolve(verifyEach(ec, items)); });
     var m;
     try { m = marshalVerify(ec, d, items); } catch (e) { return Promise.reject(e); }
     if (!items.length) return Promise.resolve([]);
     m.o.status = Buffer.alloc(items.length);
     return eng.ecdsaVerifyBatchAsync(d.id, m.o).then(function(ok) {
-      return items.map(function(it, i) { return verdict(ec, it, m.pre[i], m.o.status[i] === OFF_CURVE ? OFF_CURVE : ok[i]); });
+      return items.map(function(it, i) { return verdict(ec, it, m.pre[i], m.ref[i] || m.o.status[i] === OFF_CURVE ? OFF_CURVE : ok[i]); });
     });
   };
   // One verification as a Promise -- and the answer to "one ec.verify is one launch of one lane"
@@ -977,7 +1139,7 @@ function install(elliptic, options) {
       m.o.status = Buffer.alloc(good.length);
       eng.ecdsaVerifyBatchAsync(d.id, m.o).then(function(ok) {
         good.forEach(function(p, i) {
-          try { p.resolve(verdict(g.ec, p.item, m.pre[i], m.o.status[i] === OFF_CURVE ? OFF_CURVE : ok[i])); } catch (e) { p.reject(e); }
+          try { p.resolve(verdict(g.ec, p.item, m.pre[i], m.ref[i] || m.o.status[i] === OFF_CURVE ? OFF_CURVE : ok[i])); } catch (e) { p.reject(e); }
         });
       }, function(e) { good.forEach(function(p) { p.reject(e); }); });
     });
@@ -993,7 +1155,7 @@ function install(elliptic, options) {
   }
   eng.verifyAsync = function verifyAsync(ec, msg, signature, key, enc, options) {
     if (typeof enc === 'object' && enc !== null && options === undefined) { options = enc; enc = undefined; }
-    var d = domain(ec.curve);
+    var d = protocolDomain(ec.curve);
     if (!d || ec.curve.type !== 'short' || !byteMessage(msg) || !plainMsgBits(options)) {
       // outside the engine's batch domain: the (patched) synchronous path, as a Promise
       return new Promise(function(resolve) { resolve(ec.verify(msg, signature, key, enc, options)); });

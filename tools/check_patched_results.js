@@ -184,6 +184,22 @@ var pendingAsync = [];
   if ((byOp['eddsa-verify'] || 0) < 200 || (byOp['sign-width'] || 0) < 300 || (byOp['foreign-sign'] || 0) < 25)
     throw new Error('api_forms.json is not the file tools/gen_golden.js writes: ' + JSON.stringify(byOp));
 })();
+// trusted_inputs.json (tools/trusted_inputs.js): precomputed tables that are not the point's
+// multiples, endomorphism constants that are not the curve's, curves without a (complete) group law
+// -- the reference computes with what it is given, and so must the patched library
+(function() {
+  var trusted = require('./trusted_inputs');
+  var byOp = {};
+  load('trusted_inputs.json').forEach(function(o, i) {
+    var got = trusted.run(elliptic, o);
+    if (got !== o.want) throw new Error('trusted_inputs #' + i + ' ' + JSON.stringify(o).slice(0, 300) + ': patched ' + got + ', reference ' + o.want);
+    if (o.want[0] === 'e') thrown++;
+    byOp[o.op] = (byOp[o.op] || 0) + 1;
+    checked++;
+  });
+  if ((byOp.tables || 0) < 500 || (byOp['g-tables'] || 0) < 30 || (byOp.endo || 0) < 20 || (byOp.toy || 0) < 25 || (byOp['toy-endo'] || 0) < 6)
+    throw new Error('trusted_inputs.json is not the file tools/gen_golden.js writes: ' + JSON.stringify(byOp));
+})();
 Promise.all(pendingAsync).then(function() {
   console.log(JSON.stringify({ ok: true, checked: checked, thrown: thrown, engine: eng.stats }));
 }, function(e) { console.error(e.stack || e); process.exit(1); });

@@ -393,6 +393,37 @@ for (var it = 0; it < ITER && failures.length < 5; it++) {
     });
   });
 })();
+// Inputs the reference trusts (tools/trusted_inputs.js): points carrying precomputed tables -- right
+// ones and tampered ones -- the curve's own G with such tables, endomorphism constants given in the
+// curve's conf, toy curves over F_5 .. F_13 with any coefficients (singular cubics, Edwards curves
+// without a complete addition law included), drawn at random
+(function() {
+  var T = require('./trusted_inputs');
+  function hex(n) { return Buffer.from(rng.bytes(n)).toString('hex'); }
+  var draws = Math.max(12, ITER >> 3);
+  for (var i = 0; i < draws && failures.length < 5; i++) {
+    var o, kind = rng.int(10);
+    if (kind < 6) {
+      var curve = rng.pick([ 'secp256k1', 'secp256k1', 'p256', 'p224', 'p384', 'ed25519' ]);
+      o = { op: 'tables', curve: curve, mult: 1 + rng.int(9), tamper: rng.pick(T.TAMPER), at: rng.int(250),
+        call: rng.pick(curve === 'ed25519' ? [ 'mul', 'mulAdd', 'mulAddRev' ] : [ 'mul', 'mulAdd', 'mulAddRev', 'jmulAdd', 'derive', 'verify' ]),
+        k: hex(1 + rng.int(plain.curves[curve].curve.n.byteLength())), k2: hex(1 + rng.int(32)), msg: rng.bytes(32) };
+    } else if (kind < 7) {
+      o = { op: 'g-tables', curve: rng.pick([ 'secp256k1', 'p256', 'ed25519' ]), tamper: rng.pick(T.TAMPER), at: rng.int(250),
+        k: hex(20), k2: hex(31), msg: rng.bytes(32) };
+    } else if (kind < 8) {
+      o = { op: 'endo', variant: rng.pick(T.ENDO), mult: hex(8), k: hex(1 + rng.int(32)), k2: hex(1 + rng.int(32)) };
+    } else {
+      var P = rng.pick([ 5, 7, 7, 11, 13 ]);
+      o = { op: 'toy', type: rng.pick([ 'short', 'edwards' ]), p: P, a: rng.int(P), b: rng.int(P), big: hex(32) };
+      if (o.type === 'edwards' && (o.a === 0 || o.b === 0 || o.a === o.b)) { o.a = 1; o.b = 2; }
+    }
+    context = JSON.stringify(o).slice(0, 400);
+    (function(o) {
+      both('trusted inputs: ' + o.op, function() { return T.run(plain, o); }, function() { return T.run(patched, o); });
+    })(o);
+  }
+})();
 // uninstall() puts the reference's own functions back: every method install() replaces must read
 // exactly like the unpatched library's again
 (function() {

@@ -8,6 +8,9 @@
 //   mul_<curve>.json        seeded + edge cases for Point.mul / mulAdd
 //   verify_<curve>.json     ECDSA verify tuples (valid + corrupted)
 //   offcurve_<curve>.json   points that are not on the curve: what the reference answers
+//   trusted_inputs.json     points with precomputed tables of their own (right and wrong), curves with
+//                           given endomorphism constants, singular / incomplete toy curves, the
+//                           private ladders with Jacobian operands (tools/trusted_inputs.js)
 //   api_forms.json          calls whose arguments are library OBJECTS (points, KeyPairs, Signatures):
 //                           EDDSA#verify over every key form x signature form, EC#sign / verify over
 //                           digest widths x options.msgBitLength, KeyPairs of another EC instance
@@ -1216,6 +1219,13 @@ write('eddsa_sign_ed25519.json', genEddsaSign());
   var forms = require('./api_forms');
   var rng = new Prng('golden:api_forms');
   write('api_forms.json', forms.recipes(rng, elliptic).map(function(o) { o.want = forms.run(elliptic, o); return o; }));
+})();
+// inputs the reference trusts (tools/trusted_inputs.js): precomputed tables, endomorphism constants,
+// degenerate curve equations -- recipe + what the reference answers
+(function() {
+  var trusted = require('./trusted_inputs');
+  var rng = new Prng('golden:trusted_inputs');
+  write('trusted_inputs.json', trusted.recipes(rng).map(function(o) { o.want = trusted.run(elliptic, o); return o; }));
 })();
 write('mul_ed25519.json', genEdwardsMul());
 write('mul_curve25519.json', genMontMul());
