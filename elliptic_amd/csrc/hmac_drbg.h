@@ -59,8 +59,9 @@ struct HmacDrbg {
     for (int i = 0; i < OUT; i++) { K[i] = 0x00; V[i] = 0x01; }
     update(seed, elen + nlen);
   }
-  // :91-113 generate(len) without additional input
-  ELL_HD void generate(u8* out, int len) {
+  // :91-113 generate(len) without additional input, in two halves (hmac_drbg256.h): draw = the
+  // output blocks, reseed = the _update() that ends generate, run only in front of a further draw
+  ELL_HD void draw(u8* out, int len) {
     int have = 0;
     ELL_NOUNROLL
     while (have < len) {
@@ -73,8 +74,8 @@ struct HmacDrbg {
       }
       have += OUT;
     }
-    update(nullptr, 0);
   }
+  ELL_HD void reseed() { update(nullptr, 0); }
 };
 
 }  // namespace ell

@@ -1,7 +1,7 @@
 // ellgpu -- HMAC_DRBG over SHA-256, word-oriented: the generator EC#sign draws its nonces from
 // on secp256k1 / p192 / p224 / p256 (hmac_drbg.h is the generic byte-wise form and documents the
 // algorithm; this one keeps K, V, the two keyed SHA-256 states and every message block in
-// registers -- no byte buffers, 24 compressions per signature instead of ~32 byte-gathered ones).
+// registers -- no byte buffers, 16 compressions per signature instead of ~32 byte-gathered ones).
 // SEEDW = words of entropy || nonce (2 * n.byteLength() / 4).
 #pragma once
 
@@ -155,20 +155,27 @@ struct HmacDrbg256 {
     for (int i = 0; i < 8; i++) Vw[i] = t[i];
   }
   // :37-48 _init, seed = entropy || nonce as SEEDW big-endian words
+  // (the two keyed states of the all-zero K the generator starts from are constants: the SHA-256
+  // states after a block of 0x36 / of 0x5c bytes -- tests/hostsim hs_drbg_draws checks them against
+  // Python's hmac through whole draws)
   ELL_HD void init(const u32 (&seed)[SEEDW]) {
+    const u32 zi[8] = {0xf454deadu, 0x9725214fu, 0x90daf2a0u, 0xdf1228eau, 0x64e5750fu, 0xa3924181u, 0x824a932bu, 0xf8e04e32u};
+    const u32 zo[8] = {0xd385480fu, 0x7abb6477u, 0x37c9c538u, 0x5dd82467u, 0x8e043a72u, 0x753434b0u, 0xdeb82818u, 0x361d45a6u};
     ELL_UNROLL
-    for (int i = 0; i < 8; i++) { Kw[i] = 0; Vw[i] = 0x01010101u; }
-    key_states();
+    for (int i = 0; i < 8; i++) { Kw[i] = 0; Vw[i] = 0x01010101u; si[i] = zi[i]; so[i] = zo[i]; }
     update<SEEDW>(seed);
   }
-  // :91-113 generate(len <= 32 bytes): the first `words` words of the new V
-  ELL_HD void generate(u32 (&out)[8]) {
+  // :91-113 generate(len <= 32 bytes) in two halves.  draw: V = HMAC(K, V), the new V is the output;
+  // reseed: the _update() that ends generate (:109) -- it only matters to the NEXT draw, so the
+  // caller runs it in front of a second draw instead of behind every first one (EC#sign takes its
+  // first candidate in all but ~2^-128 of the cases: 16 compressions per signature instead of 24)
+  ELL_HD void draw(u32 (&out)[8]) {
     u32 t[8];
     hmac_v(t);
     ELL_UNROLL
     for (int i = 0; i < 8; i++) { Vw[i] = t[i]; out[i] = t[i]; }
-    update<0>(nullptr);
   }
+  ELL_HD void reseed() { update<0>(nullptr); }
 };
 
 }  // namespace ell

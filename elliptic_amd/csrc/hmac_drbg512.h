@@ -216,14 +216,15 @@ struct HmacDrbg512 {
     key_states();
     update<SEEDW>(seed);
   }
-  // generate(len <= 8 OUTW bytes): the new V
-  ELL_HD void generate(u64 (&out)[OUTW]) {
+  // generate(len <= 8 OUTW bytes) in two halves (hmac_drbg256.h): draw = the new V, reseed = the
+  // _update() that ends generate, run by the caller only in front of a further draw
+  ELL_HD void draw(u64 (&out)[OUTW]) {
     u64 t[OUTW];
     hmac_v(t);
     ELL_UNROLL
     for (int i = 0; i < OUTW; i++) { Vw[i] = t[i]; out[i] = t[i]; }
-    update<0>(nullptr);
   }
+  ELL_HD void reseed() { update<0>(nullptr); }
 };
 
 // HMAC_DRBG over SHA-512 for seeds and draws that are not whole words (p521: 66-byte entropy,
@@ -287,7 +288,8 @@ struct HmacDrbg512Bytes {
     update(buf, seedlen);
   }
   // :91-113 generate(len), 64 < len <= 128: two V blocks, the first `len` bytes as big-endian words
-  ELL_HD void generate2(u64 (&out)[16], u8* sepbuf) {
+  // (draw2 / reseed: the two halves of generate, hmac_drbg256.h)
+  ELL_HD void draw2(u64 (&out)[16]) {
     u64 t[8];
     hmac_v_tail(t, nullptr, 0);
     ELL_UNROLL
@@ -295,8 +297,8 @@ struct HmacDrbg512Bytes {
     hmac_v_tail(t, nullptr, 0);
     ELL_UNROLL
     for (int i = 0; i < 8; i++) { Vw[i] = t[i]; out[8 + i] = t[i]; }
-    update(sepbuf, 0);
   }
+  ELL_HD void reseed(u8* sepbuf) { update(sepbuf, 0); }
 };
 
 }  // namespace ell

@@ -887,7 +887,8 @@ struct Work {
       bool done = false;
       ELL_NOUNROLL
       for (int it = 0; it < 16 && !done; it++) {
-        g.generate(v);
+        if (it) g.reseed();
+        g.draw(v);
         ELL_UNROLL
         for (int w = 0; w < LN; w++) k[w] = w < NW ? v[NW - 1 - w] : 0u;      // no shift: 8 NBYTES == bit length of n
         done = !bn_is_zero<LN>(k) && !bn_eq<LN>(k, one1) && !bn_geq<LN>(k, nm1);
@@ -912,7 +913,8 @@ struct Work {
       bool done = false;
       ELL_NOUNROLL
       for (int it = 0; it < 16 && !done; it++) {
-        g.generate(v);
+        if (it) g.reseed();
+        g.draw(v);
         ELL_UNROLL
         for (int w = 0; w < 6; w++) { k[11 - 2 * w] = (u32)(v[w] >> 32); k[10 - 2 * w] = (u32)v[w]; }
         done = !bn_is_zero<LN>(k) && !bn_eq<LN>(k, one1) && !bn_geq<LN>(k, nm1);
@@ -935,7 +937,8 @@ struct Work {
       ELL_NOUNROLL
       for (int it = 0; it < 16 && !done; it++) {
         u64 v[16];
-        g.generate2(v, sb);
+        if (it) g.reseed(sb);
+        g.draw2(v);
         ELL_UNROLL
         for (int b = 0; b < NBYTES; b++) kb[b] = (u8)(v[b >> 3] >> (56 - 8 * (b & 7)));
         u32 k[LN];
@@ -957,7 +960,8 @@ struct Work {
       bool done = false;
       ELL_NOUNROLL
       for (int it = 0; it < 16 && !done; it++) {
-        g.generate(kb, NBYTES);
+        if (it) g.reseed();
+        g.draw(kb, NBYTES);
         u32 k[LN];
         load_nonce(k, kb);
         done = !bn_is_zero<LN>(k) && !bn_eq<LN>(k, one1) && !bn_geq<LN>(k, nm1);

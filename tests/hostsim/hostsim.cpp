@@ -163,6 +163,24 @@ void hs_note_launch(const char* name) {
 }
 }  // namespace ell
 
+// EC#sign's nonce generators, several draws in a row (the reseed in front of a second draw is the
+// path no real signature takes): kind 0 = HmacDrbg256 (seed = 2 * nbytes, nbytes in {24, 28, 32}),
+// 1 = HmacDrbg512<6, 12> (SHA-384, nbytes 48), 2 = HmacDrbg512Bytes (SHA-512, nbytes 66),
+// 3 = the generic byte-wise HmacDrbg<Sha256>.  out: ndraws * nbytes bytes.
+template <int NW>
+static void drbg256_draws(const u8* seed, int ndraws, u8* out) {
+  u32 sw[2 * NW];
+  for (int w = 0; w < 2 * NW; w++)
+    sw[w] = ((u32)seed[4 * w] << 24) | ((u32)seed[4 * w + 1] << 16) | ((u32)seed[4 * w + 2] << 8) | seed[4 * w + 3];
+  HmacDrbg256<2 * NW> g;
+  g.init(sw);
+  for (int d = 0; d < ndraws; d++) {
+    u32 v[8];
+    if (d) g.reseed();
+    g.draw(v);
+    for (int b = 0; b < 4 * NW; b++) out[d * 4 * NW + b] = (u8)(v[b >> 2] >> (24 - 8 * (b & 3)));
+  }
+}
 extern "C" {
 void hs_launches_reset() {
   std::lock_guard<std::mutex> g(ell::hs_launch_mu);
@@ -219,6 +237,47 @@ int hs_field_op(int field, int op, const u32* a, const u32* b, u32* r) {
     default: return -1;
   }
   return 0;
+}
+int hs_drbg_draws(int kind, const u8* seed, int nbytes, int ndraws, u8* out) {
+  if (kind == 0 && nbytes == 24) { drbg256_draws<6>(seed, ndraws, out); return 0; }
+  if (kind == 0 && nbytes == 28) { drbg256_draws<7>(seed, ndraws, out); return 0; }
+  if (kind == 0 && nbytes == 32) { drbg256_draws<8>(seed, ndraws, out); return 0; }
+  if (kind == 1 && nbytes == 48) {
+    u64 sw[12];
+    for (int w = 0; w < 12; w++) { sw[w] = 0; for (int b = 0; b < 8; b++) sw[w] = (sw[w] << 8) | seed[8 * w + b]; }
+    HmacDrbg512<6, 12> g;
+    g.init(sw);
+    for (int d = 0; d < ndraws; d++) {
+      u64 v[6];
+      if (d) g.reseed();
+      g.draw(v);
+      for (int b = 0; b < 48; b++) out[d * 48 + b] = (u8)(v[b >> 3] >> (56 - 8 * (b & 7)));
+    }
+    return 0;
+  }
+  if (kind == 2 && nbytes == 66) {
+    u8 sb[1 + 132];
+    for (int b = 0; b < 132; b++) sb[1 + b] = seed[b];
+    HmacDrbg512Bytes g;
+    g.init(sb, 132);
+    for (int d = 0; d < ndraws; d++) {
+      u64 v[16];
+      if (d) g.reseed(sb);
+      g.draw2(v);
+      for (int b = 0; b < 66; b++) out[d * 66 + b] = (u8)(v[b >> 3] >> (56 - 8 * (b & 7)));
+    }
+    return 0;
+  }
+  if (kind == 3 && nbytes <= 66) {
+    HmacDrbg<Sha256> g;
+    g.init(seed, nbytes, seed + nbytes, nbytes);
+    for (int d = 0; d < ndraws; d++) {
+      if (d) g.reseed();
+      g.draw(out + d * nbytes, nbytes);
+    }
+    return 0;
+  }
+  return -1;
 }
 // GLV split of a 256-bit k (8 LE limbs): k1, k2 as 5 LE limbs + sign flags
 void hs_glv_split(const u32* k, u32* k1, int* neg1, u32* k2, int* neg2) {

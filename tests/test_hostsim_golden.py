@@ -182,6 +182,52 @@ def test_p521_from_plain_overrange(hs):
         assert _val(r) == a * a % p, hex(a)
 
 
+def _py_hmac_drbg(hname, entropy, nonce):
+    """hmac-drbg 1.0.1 (lib/hmac-drbg.js:37-113) in Python: a generator of generate(len) calls"""
+    import hashlib
+    import hmac as pyhmac
+    H = getattr(hashlib, hname)
+    outlen = H().digest_size
+    state = {"K": b"\x00" * outlen, "V": b"\x01" * outlen}
+
+    def upd(seed):
+        state["K"] = pyhmac.new(state["K"], state["V"] + b"\x00" + seed, H).digest()
+        state["V"] = pyhmac.new(state["K"], state["V"], H).digest()
+        if seed:
+            state["K"] = pyhmac.new(state["K"], state["V"] + b"\x01" + seed, H).digest()
+            state["V"] = pyhmac.new(state["K"], state["V"], H).digest()
+
+    upd(entropy + nonce)
+
+    def generate(n):
+        out = b""
+        while len(out) < n:
+            state["V"] = pyhmac.new(state["K"], state["V"], H).digest()
+            out += state["V"]
+        upd(b"")
+        return out[:n]
+    return generate
+
+
+@pytest.mark.parametrize("kind,hname,nbytes", [(0, "sha256", 24), (0, "sha256", 28), (0, "sha256", 32), (1, "sha384", 48),
+                                               (2, "sha512", 66), (3, "sha256", 32), (3, "sha256", 21)])
+def test_drbg_draws_in_a_row(hs, kind, hname, nbytes):
+    """EC#sign's nonce generators (ec/index.js:141-158 -> hmac-drbg.js), FIVE draws in a row: a
+    signature takes the first candidate in all but ~2^-128 of the cases, so the reseed in front of
+    a further draw (the _update() that ends generate, deferred to where it is needed) and the
+    constant key states of the all-zero K are checked here, against Python's hmac"""
+    import random
+    hs.hs_drbg_draws.restype = ctypes.c_int
+    rnd = random.Random(1000 * kind + nbytes)
+    for _ in range(4):
+        seed = bytes(rnd.randrange(256) for _ in range(2 * nbytes))
+        gen = _py_hmac_drbg(hname, seed[:nbytes], seed[nbytes:])
+        want = b"".join(gen(nbytes) for _ in range(5))
+        out = (ctypes.c_ubyte * (5 * nbytes))()
+        assert hs.hs_drbg_draws(kind, (ctypes.c_ubyte * len(seed))(*seed), nbytes, 5, out) == 0
+        assert bytes(out) == want
+
+
 def test_glv_split(hs):
     cur = O.get_curve("secp256k1", False)
     lam, n = cur.endo["lambda"], cur.n
