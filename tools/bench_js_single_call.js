@@ -49,6 +49,19 @@ libs.forEach(function(l) {
   var kp2 = e2.genKeyPair({ entropy: crypto.createHash('sha512').update('k2').digest() });
   var der2 = kp2.sign(msg).toDER('hex'), pub2 = kp2.getPublic('hex');
   out('p256 EC#verify (DER hex signature, hex key)', l[0], timeSync(function() { return e2.verify(msg, der2, pub2, 'hex'); }, 100));
+  out('p256 EC#sign', l[0], timeSync(function() { return e2.sign(msg, kp2); }, 100));
+  // the wide NIST curves (one item per lane also for a lone call: their fields do not fit a 16-lane row)
+  [ 'p384', 'p521' ].forEach(function(name) {
+    var e3 = new l[1].ec(name);
+    var kp3 = e3.genKeyPair({ entropy: crypto.createHash('sha512').update('k3' + name).digest() });
+    var m3 = crypto.createHash(name === 'p384' ? 'sha384' : 'sha512').update('single call').digest();
+    var der3 = kp3.sign(m3).toDER('hex'), pub3 = kp3.getPublic('hex');
+    if (e3.verify(m3, der3, pub3, 'hex') !== true) throw new Error('verify ' + name);
+    out(name + ' EC#verify (DER hex signature, hex key)', l[0], timeSync(function() { return e3.verify(m3, der3, pub3, 'hex'); }, 40));
+    out(name + ' EC#sign', l[0], timeSync(function() { return e3.sign(m3, kp3); }, 40));
+    var P3 = kp3.getPublic(), k3 = kp3.getPrivate();
+    out(name + ' Point#mul (variable base)', l[0], timeSync(function() { return P3.mul(k3).getX(); }, 40));
+  });
   var ed = new l[1].eddsa('ed25519');
   var ek = ed.keyFromSecret(crypto.createHash('sha256').update('ed').digest());
   var esig = ek.sign(msg).toHex(), epub = ek.getPublic('hex');
