@@ -455,8 +455,13 @@ function install(elliptic, options) {
     if (!p || p.curve !== curve || p.isInfinity()) return null;
     var x, y;
     // (the reference's _wnafMulAdd also takes Jacobian points, base.js:158-183, 222-233: its own)
+    // (coordinates that live in ANOTHER reduction context -- curve.point(Q.x, Q.y) with Q from another
+    // curve object over the same field, which is also what ec.keyFromPublic(Q) does, ec/key.js:96 --
+    // make bn.js throw 'red works only with red numbers' in the reference's first field operation)
+    if (!p.x || !p.y || p.x.red !== curve.red || p.y.red !== curve.red) return null;
     if (curve.type === 'short') { if (p.type !== 'affine') return null; x = p.getX(); y = p.getY(); }
     else {
+      if (!p.z || p.z.red !== curve.red || (p.t && p.t.red !== curve.red)) return null;
       // extended coordinates carry T = X Y / Z, which the reference's _extAdd / _extDbl USE
       // (edwards.js:279-309): a point built with any other T (curve.point(x, y, z, t) takes what
       // it is given) is not the point its (x, y) says -- the reference's own, like a point that is
@@ -756,8 +761,9 @@ function install(elliptic, options) {
   short.pointFromX = function pointFromX(x, odd) {
     var d = domain(this);
     var xb = new BN(x, 16);
+    var foreign = !!xb.red && xb.red !== this.red;      // the reference's first mixed operation throws
     if (xb.red) xb = xb.fromRed();
-    if (!d || xb.isNeg() || xb.byteLength() > d.B) {
+    if (!d || foreign || xb.isNeg() || xb.byteLength() > d.B) {
       eng.stats.passthrough++;
       return orig.pointFromX.apply(this, arguments);
     }
@@ -770,8 +776,9 @@ function install(elliptic, options) {
   edw.pointFromY = function pointFromY(y, odd) {
     var d = domain(this);
     var yb = new BN(y, 16);
+    var foreign = !!yb.red && yb.red !== this.red;      // the reference's first mixed operation throws
     if (yb.red) yb = yb.fromRed();
-    if (!d || yb.isNeg() || yb.byteLength() > d.B) {
+    if (!d || foreign || yb.isNeg() || yb.byteLength() > d.B) {
       eng.stats.passthrough++;
       return orig.pointFromY.apply(this, arguments);
     }
@@ -785,8 +792,9 @@ function install(elliptic, options) {
   edw.pointFromX = function pointFromX(x, odd) {
     var d = domain(this);
     var xb = new BN(x, 16);
+    var foreign = !!xb.red && xb.red !== this.red;      // the reference's first mixed operation throws
     if (xb.red) xb = xb.fromRed();
-    if (!d || xb.isNeg() || xb.byteLength() > d.B) {
+    if (!d || foreign || xb.isNeg() || xb.byteLength() > d.B) {
       eng.stats.passthrough++;
       return orig.edPointFromX.apply(this, arguments);
     }
@@ -893,6 +901,7 @@ function install(elliptic, options) {
       r = new BN(signature.r, 16);
       s = new BN(signature.s, 16);
       e = new BN(msg);
+      if (r.red || s.red || e.red) throw null;
       NB = this.n.byteLength();
       if (e.isNeg() || r.isNeg() || s.isNeg() || r.byteLength() > NB || s.byteLength() > NB ||
           e.byteLength() > 2 * NB) throw null;
@@ -1000,7 +1009,10 @@ function install(elliptic, options) {
   montProto.mul = function mul(k) {
     var d = domain(this.curve);
     var kb = d && scalarBuf(k, 32);
-    if (!kb || this.isInfinity()) { eng.stats.passthrough++; return orig.montMul.apply(this, arguments); }
+    if (!kb || this.isInfinity() || this.x.red !== this.curve.red || this.z.red !== this.curve.red) {
+      eng.stats.passthrough++;
+      return orig.montMul.apply(this, arguments);
+    }
     var x = this.curve.point(this.x, this.z).getX();
     var r = eng.x25519Batch(kb, Buffer.from(x.toArray('be', 32)));
     if (r.inf[0]) return this.curve.point(null, null);
@@ -1065,14 +1077,16 @@ function install(elliptic, options) {
     var Signature = signatureClass(ec);
     var key = ec.keyFromPublic(it.key, it.enc);
     var sig = new Signature(it.signature, 'hex');
+    // (r or s in a reduction context: eqXToP's r.toRed throws 'toRed works only with numbers')
+    var redSig = !!(sig.r.red || sig.s.red);              // -- that item is the reference's
     var bad = sig.r.isNeg() || sig.s.isNeg() || sig.r.byteLength() > NB || sig.s.byteLength() > NB;
     // (a key whose own precomputed tables are not its multiples: the reference's ladder reads
     // them -- that item is the reference's, like a key that is not on the curve)
-    var q = operandBuf(ec.curve, key.getPublic(), d.B);
+    var q = redSig ? null : operandBuf(ec.curve, key.getPublic(), d.B);
     return { pre: !bad, h: Buffer.from(it.msg),
       r: Buffer.from((bad ? new BN(0) : sig.r).toArray('be', NB)),
       s: Buffer.from((bad ? new BN(0) : sig.s).toArray('be', NB)),
-      q: q || Buffer.alloc(2 * d.B), ref: !q };
+      q: q || Buffer.alloc(2 * d.B), ref: !q };   // ref: EC#verify itself, with the reference's own ladders (verdict)
   }
   function msgBitsOf(it) {
     return it.options && typeof it.options.msgBitLength === 'number' ? it.options.msgBitLength : 0;

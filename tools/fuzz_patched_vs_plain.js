@@ -411,6 +411,9 @@ for (var it = 0; it < ITER && failures.length < 5; it++) {
     } else if (kind < 7) {
       o = { op: 'g-tables', curve: rng.pick([ 'secp256k1', 'p256', 'ed25519' ]), tamper: rng.pick(T.TAMPER), at: rng.int(250),
         k: hex(20), k2: hex(31), msg: rng.bytes(32) };
+    } else if (kind < 8 && rng.int(2)) {
+      o = { op: 'foreign-red', curve: rng.pick([ 'secp256k1', 'p256', 'p224', 'ed25519', 'curve25519' ]), mult: hex(12), k: hex(1 + rng.int(32)),
+        msg: rng.bytes(32), secret: hex(32) };
     } else if (kind < 8) {
       o = { op: 'endo', variant: rng.pick(T.ENDO), mult: hex(8), k: hex(1 + rng.int(32)), k2: hex(1 + rng.int(32)) };
     } else {

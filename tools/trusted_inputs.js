@@ -234,6 +234,44 @@ function run(L, o) {
       default: throw new Error('unknown call ' + o.call);
     }
   });
+  if (o.op === 'foreign-red') return render(function() {
+    // coordinates / signature halves that live in the reduction context of ANOTHER curve object over
+    // the same field: ec.keyFromPublic(Q) builds curve.point(Q.x, Q.y) from them as they are
+    // (ec/key.js:85-97), and bn.js throws 'red works only with red numbers' in the first mixed operation
+    var name = o.curve, c = L.curves[name].curve, c2 = c.type === 'mont' ? null : cloneCurve(L, name);
+    var k = new BN(o.k, 16);
+    if (c.type === 'mont') {
+      var c3 = new L.curve.mont({ p: c.p.toString(16), a: c.a.fromRed().toString(16), b: '1', g: [ '9' ] });
+      var M2 = c3.g.mul(new BN(7));
+      return [ render(function() { return c.point(M2.x, M2.z).mul(k); }), render(function() { return c.point(M2.getX(), new BN(1)).mul(k); }) ];
+    }
+    var P2 = c2.g.mul(new BN(o.mult, 16));
+    if (c.type === 'edwards') {
+      var ed = new L.eddsa('ed25519');
+      var sig = ed.sign(o.msg, o.secret), A = ed.keyFromSecret(o.secret).pub();
+      var A2 = c2.point(A.getX(), A.getY());
+      return [ render(function() { return ed.verify(o.msg, sig, A2); }), render(function() { return c.point(P2.x, P2.y).mul(k); }),
+        render(function() { return c.point(P2.x, P2.y, P2.z, P2.t).mul(k); }), render(function() { return c.g.mulAdd(k, c.point(P2.x, P2.y, P2.z, P2.t), k); }),
+        render(function() { return c.pointFromY(P2.y, true); }), render(function() { return c.pointFromX(P2.x, false); }),
+        render(function() { return c.point(P2.getX(), P2.getY()).mul(k); }) ];
+    }
+    var ec = new L.ec(name);
+    var kp = ec.keyFromPrivate(o.mult, 'hex');
+    var sg = ec.sign(o.msg, kp);
+    return [ render(function() { return ec.verify(o.msg, sg, P2); }), render(function() { return ec.verify(o.msg, sg, { x: P2.x, y: P2.y }); }),
+      render(function() { return ec.verify(o.msg, sg, { x: P2.getX(), y: P2.getY() }); }),
+      render(function() { return ec.keyFromPrivate('0d', 'hex').derive(P2); }),
+      render(function() { return ec.keyFromPublic(P2).getPublic().mul(k); }),
+      render(function() { return c.g.mulAdd(k, c.point(P2.x, P2.y), k); }),
+      render(function() { return c.point(P2.x, P2.y).mul(k); }),
+      render(function() { return c.point(P2.x, P2.y, true).mul(k); }),
+      render(function() { return ec.recoverPubKey(o.msg, { r: sg.r.toRed(c2.red), s: sg.s }, sg.recoveryParam); }),
+      render(function() { return ec.recoverPubKey(o.msg, { r: sg.r, s: sg.s.toRed(c.red) }, sg.recoveryParam); }),
+      render(function() { return ec.verify(o.msg, { r: sg.r.toRed(c2.red), s: sg.s }, kp); }),
+      render(function() { return ec.verify(o.msg, { r: sg.r, s: sg.s.toRed(c.red) }, kp); }),
+      render(function() { return c.pointFromX(P2.x, true); }), render(function() { return c.pointFromX(kp.getPublic().x, true); }),
+      render(function() { return kp.getPublic().mul(k.toRed(c.red)); }), render(function() { return kp.getPublic().mul(k.toRed(c2.red)); }) ];
+  });
   throw new Error('unknown op ' + o.op);
 }
 
@@ -289,6 +327,10 @@ function recipes(rng) {
       if (curve === 'p256' && call.slice(0, 4) === 'endo') return;
       out.push({ op: 'private', curve: curve, call: call, k: hex(31), k2: hex(16) });
     });
+  });
+  [ 'secp256k1', 'p256', 'p384', 'ed25519', 'curve25519' ].forEach(function(curve) {
+    for (var i = 0; i < 2; i++)
+      out.push({ op: 'foreign-red', curve: curve, mult: hex(12), k: hex(20 + 11 * i), msg: arr(32), secret: hex(32) });
   });
   return out;
 }
