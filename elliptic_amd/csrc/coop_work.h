@@ -225,6 +225,77 @@ struct CoopK256 {
     load_be<8>(k, ks + i * 32, 32);
     store_jac(jac, n, i, comb_mul(k, comb));
   }
+
+  // ---- ShortCurve#pointFromX (short.js:187-204) of one item on a wave ----
+  // a^((p+1)/4) with FpK256::sqrt's addition chain (253 S + 13 M; bn.js Red#sqrt takes the same
+  // power): every step is a product of the row field, 2.2-2.4 x shorter than the one-lane one
+  ELL_HD static El sqr_n(El a, int n) {
+    ELL_NOUNROLL
+    for (int i = 0; i < n; i++) a = F::sqr(a);
+    return a;
+  }
+  ELL_HD static El sqrt(const El& a) {
+    El x2 = F::mul(F::sqr(a), a);
+    El x3 = F::mul(F::sqr(x2), a);
+    El x6 = F::mul(sqr_n(x3, 3), x3);
+    El x9 = F::mul(sqr_n(x6, 3), x3);
+    El x11 = F::mul(sqr_n(x9, 2), x2);
+    El x22 = F::mul(sqr_n(x11, 11), x11);
+    El x44 = F::mul(sqr_n(x22, 22), x22);
+    El x88 = F::mul(sqr_n(x44, 44), x44);
+    El x176 = F::mul(sqr_n(x88, 88), x88);
+    El x220 = F::mul(sqr_n(x176, 44), x44);
+    El x223 = F::mul(sqr_n(x220, 3), x3);
+    El t = F::mul(sqr_n(x223, 23), x22);
+    t = F::mul(sqr_n(t, 6), x2);
+    return sqr_n(t, 2);
+  }
+  // (work.h lift_x / decompress: the same results -- x reduced, y with the requested parity, zeros
+  // and ok = 0 where x is no abscissa of the curve); xw: the wave-uniform plain words of x
+  ELL_HD static void decompress_words(size_t i, const u32 (&xw)[8], bool want_odd, u8* out_xy, u8* out_ok) {
+    const El x = F::from_plain(xw);
+    u32 seven[8] = {7u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    const El rhs = F::add(F::mul(F::sqr(x), x), F::from_plain(seven));
+    const El y = sqrt(rhs);
+    const bool ok = F::eq(F::sqr(y), rhs);
+    u32 xp[8], yp[8], yn[8], pp[8];
+    F::to_plain(xp, x);
+    F::to_plain(yp, y);
+    FpK256::get_p(pp);
+    bn_sub<8>(yn, pp, yp);                              // p - y (y = 0 has no negative to take: no such point on this curve)
+    const bool flip = ((yp[0] & 1u) != 0) != want_odd && !bn_is_zero<8>(yp);
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++) {
+      yp[l] = flip ? yn[l] : yp[l];
+      if (!ok) { xp[l] = 0; yp[l] = 0; }
+    }
+    if (writer()) {
+      store_be<8>(out_xy + i * 64, xp, 32);
+      store_be<8>(out_xy + i * 64 + 32, yp, 32);
+      out_ok[i] = ok ? 1 : 0;
+    }
+  }
+  ELL_HD static void decompress(size_t i, const u8* xs, const u8* odd, u8* out_xy, u8* out_ok) {
+    u32 xw[8];
+    load_be<8>(xw, xs + i * 32, 32);
+    decompress_words(i, xw, odd[i] != 0, out_xy, out_ok);
+  }
+  // EC#recoverPubKey's R (ec/index.js:243-250) straight from (r, j): x = r, or r + n for the second
+  // candidate -- what recover_prep writes into xs / odd, so that the square root does not wait for
+  // the inversion of r beside it.  (Where recover_prep's status is not RECOVER_POINT the result is
+  // not looked at.)
+  ELL_HD static void recover_point(size_t i, const u8* rs, const u8* recid, u8* out_xy, u8* out_ok) {
+    u32 r[8], rn[8], nn[8];
+    load_be<8>(r, rs + i * 32, 32);
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++) nn[l] = consts::SECP256K1_C::n[l];
+    bn_add<8>(rn, r, nn);
+    const u32 jj = recid[i];
+    const bool second = (jj >> 1) != 0;
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++) r[l] = second ? rn[l] : r[l];
+    decompress_words(i, r, (jj & 1u) != 0, out_xy, out_ok);
+  }
 };
 
 

@@ -477,6 +477,48 @@ struct FnSignPartsC {
     else W::sign_kinv(unit - n, n, nonces, kinv, CW::writer());
   }
 };
+// Point#mul on G / KeyPair#getPublic for a handful of items on the row layer: the comb and the
+// item's own inversion on a wave (coop_work.h coop_sign_point -- the point half of sign_parts_c);
+// mul_fixed + normalize were two dependent one-lane launches.  The scalar is any BYTES-byte value
+// (the comb's windows cover 8 BYTES bits and their carry, as in the one-lane mul_fixed).
+template <class CV, class CW>
+struct FnMulFixedC {
+  static constexpr const char* NAME = "mul_fixed_c";
+  typedef Work<CV> W;
+  static constexpr int DS_PER_LANE = 0;
+  static constexpr int ROW_BYTES = 16;
+  size_t n; const u8* k; const typename W::A* comb; u8* out_xy; u8* out_inf;
+  ELL_HD void operator()(size_t unit, const DigitStore&, void*) const {
+    if (unit < n) coop_sign_point<CW>(unit, k, comb, out_xy, out_inf);
+  }
+};
+// ShortCurve#pointFromX of a handful of secp256k1 abscissas: the square root's 266 products on a
+// wave per item (coop_work.h CoopK256::decompress); FnDecompress is the one-lane form.
+struct FnDecompressC {
+  static constexpr const char* NAME = "decompress_c";
+  static constexpr int DS_PER_LANE = 0;
+  static constexpr int ROW_BYTES = 16;
+  size_t n; const u8* xs; const u8* odd; u8* out_xy; u8* out_ok;
+  ELL_HD void operator()(size_t unit, const DigitStore&, void*) const {
+    if (unit < n) CoopK256::decompress(unit, xs, odd, out_xy, out_ok);
+  }
+};
+// EC#recoverPubKey's front for a handful of items, ONE launch: unit i < n lifts R from (r, j) on
+// a wave (the square root), unit n + i runs recover_prep for item i beside it (range checks, r^-1,
+// both scalars) -- recover_prep and decompress were two dependent one-lane launches, 62 + 103 us.
+struct FnRecoverPartsC {
+  static constexpr const char* NAME = "recover_parts_c";
+  typedef Work<CvSecp256k1> W;
+  static constexpr int DS_PER_LANE = 0;
+  static constexpr int ROW_BYTES = 16;
+  size_t n; const u8* hash; int hash_len; const u8* r; const u8* s; const u8* recid;
+  u32* pre; u8* xs; u8* odd; u8* s1; u8* s2; u8* status; u8* rxy; u8* dec_ok;
+  ELL_HD void operator()(size_t unit, const DigitStore&, void*) const {
+    if (unit < n) CoopK256::recover_point(unit, r, recid, rxy, dec_ok);
+    // (every lane of the wave runs the one-lane code on the same item and stores the same values)
+    else W::recover_prep(unit - n, n, n, 1, hash, hash_len, r, s, recid, pre, xs, odd, s1, s2, status);
+  }
+};
 template <class CV>
 struct FnDetNonce {
   static constexpr const char* NAME = "det_nonce";
@@ -2282,6 +2324,18 @@ template <class BK>
 template <class CV>
 int Engine<BK>::mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf) {
   typedef Work<CV> W;
+  // a handful of items: the comb and the item's own inversion on a wave, one launch (the scalar's
+  // byte width is the order's on these curves, which is what coop_sign_point reads)
+  constexpr bool row_k256 = CV::ENDO && W::L <= 8 && CoopK256::AVAILABLE;
+  constexpr bool row_nist = !CV::ENDO && CoopNist<CV>::AVAILABLE;
+  if constexpr ((row_k256 || row_nist) && W::NBYTES == W::BYTES) {
+    if (n <= coop_grid() && out_inf) {
+      typedef typename std::conditional<row_k256, CoopK256, CoopNist<CV>>::type CW;
+      FnMulFixedC<CV, CW> fc{n, k, (const typename W::A*)comb_[CV::ID], out_xy, out_inf};
+      bk.launch_coop(fc, n);
+      return E_OK;
+    }
+  }
   u32* jac = (u32*)scratch(S_JAC, n * 3 * W::NS * 4);
   if (!jac) return fail(E_NOMEM, "scratch allocation failed");
   if (W::L > 12 && n > ELL_P521_PAIR_MIN) {
@@ -2617,6 +2671,13 @@ int Engine<BK>::decompress_chunk(size_t n, const u8* x, const u8* odd, u8* out_x
   if constexpr (!CV::F::HAS_SQRT) {
     return fail(E_UNSUPPORTED, "point decompression is not available in this field");
   } else {
+    if constexpr (CV::ID == CURVE_SECP256K1 && CoopK256::AVAILABLE) {
+      if (n <= coop_grid()) {                          // a handful of items: the square root on a wave each
+        FnDecompressC fc{n, x, odd, out_xy, out_ok};
+        bk.launch_coop(fc, n);
+        return E_OK;
+      }
+    }
     FnDecompress<CV> f{n, x, odd, out_xy, out_ok};
     bk.launch(f, n);
     return E_OK;
@@ -2715,12 +2776,23 @@ int Engine<BK>::recover_chunk(size_t n, const u8* hash, int hash_len, const u8* 
     u8* odd = flags;
     u8* dec_ok = flags + n;
     u8* inf = flags + 2 * n;
-    const int Kr = inv_batch_for(n, INV_BATCH_N);
-    size_t T = (n + Kr - 1) / Kr;
-    FnRecoverPrep<CV> f1{T, n, Kr, hash, hash_len, r, s, recid, pre, xs, odd, s1, s2, out_status};
-    launch_fn(f1, T);
-    int rc = decompress_chunk<CV>(n, xs, odd, rxy, dec_ok);
-    if (rc) return rc;
+    int rc = E_OK;
+    bool front = false;
+    if constexpr (CV::ID == CURVE_SECP256K1 && CoopK256::AVAILABLE) {
+      if (n <= coop_grid()) {                          // a handful of items: R's square root beside r^-1, one launch
+        FnRecoverPartsC fc{n, hash, hash_len, r, s, recid, pre, xs, odd, s1, s2, out_status, rxy, dec_ok};
+        bk.launch_coop(fc, 2 * n);
+        front = true;
+      }
+    }
+    if (!front) {
+      const int Kr = inv_batch_for(n, INV_BATCH_N);
+      size_t T = (n + Kr - 1) / Kr;
+      FnRecoverPrep<CV> f1{T, n, Kr, hash, hash_len, r, s, recid, pre, xs, odd, s1, s2, out_status};
+      launch_fn(f1, T);
+      rc = decompress_chunk<CV>(n, xs, odd, rxy, dec_ok);
+      if (rc) return rc;
+    }
     rc = mul_add_g_chunk<CV>(n, s1, s2, rxy, out_xy, inf);         // s1 * G + s2 * R
     if (rc) return rc;
     FnRecoverFinish<CV> f2{n, dec_ok, inf, out_xy, out_status};

@@ -70,13 +70,13 @@ def main():
             # the row layer (csrc/coop.h, coop_mont.h: one item per wave) serves batches of at most
             # 1 365 items on secp256k1 / p256 / p224 / p192: the same items again in slices of that size
             ROW = 1300 if curve in ("secp256k1", "p256", "p224", "p192") else 0
-            for lo in range(0, n if ROW else 0, 4 * ROW):
+            for lo in (range(0, n, 4 * ROW) if ROW else ()):
                 g2 = ctx.mul_var(curve, k[lo:lo + ROW], pts[lo:lo + ROW])
                 assert np.array_equal(g2[1], want[1][lo:lo + ROW]) and np.array_equal(g2[0], want[0][lo:lo + ROW]), (curve, "mul_var, row layer", lo)
             want = par(lambda a1, a2, pp: c_oracle.mul_add(curve, a1, None, a2, pp), n, threads, k, k2, pts)
             got = ctx.mul_add2(curve, k, None, k2, pts)
             assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]), (curve, "mul_add_g")
-            for lo in range(0, n if ROW else 0, 4 * ROW):
+            for lo in (range(0, n, 4 * ROW) if ROW else ()):
                 g2 = ctx.mul_add2(curve, k[lo:lo + ROW], None, k2[lo:lo + ROW], pts[lo:lo + ROW])
                 assert np.array_equal(g2[1], want[1][lo:lo + ROW]) and np.array_equal(g2[0], want[0][lo:lo + ROW]), (curve, "mul_add_g, row layer", lo)
             p1 = np.roll(pts, 1, axis=0)
@@ -88,7 +88,7 @@ def main():
             z = rnd(tag + ":z", n, min(NB, 32) if curve != "p521" else 64)
             r, s, rec, ok = ctx.ecdsa_sign_det(curve, z, d[:, :NB] if NB == B else d)
             assert ok.all(), (curve, "sign_det")
-            for lo in range(0, n if ROW else 0, 4 * ROW):       # EC#sign's middle on the row layer: the same signatures
+            for lo in (range(0, n, 4 * ROW) if ROW else ()):       # EC#sign's middle on the row layer: the same signatures
                 g2 = ctx.ecdsa_sign_det(curve, z[lo:lo + ROW], (d[:, :NB] if NB == B else d)[lo:lo + ROW])
                 assert all(np.array_equal(x, y[lo:lo + ROW]) for x, y in zip(g2, (r, s, rec, ok))), (curve, "sign_det, row layer", lo)
             z[::5, 0] ^= 1
@@ -96,7 +96,7 @@ def main():
             want = c_oracle.verify(curve, z, r, s, pts, threads=threads)
             got = ctx.ecdsa_verify(curve, z, r, s, pts)
             assert np.array_equal(got, want), (curve, "verify")
-            for lo in range(0, n if ROW else 0, 4 * ROW):
+            for lo in (range(0, n, 4 * ROW) if ROW else ()):
                 g2 = ctx.ecdsa_verify(curve, z[lo:lo + ROW], r[lo:lo + ROW], s[lo:lo + ROW], pts[lo:lo + ROW])
                 assert np.array_equal(g2, want[lo:lo + ROW]), (curve, "verify, row layer", lo)
             assert want[2::5].all() and not want[::5].any()

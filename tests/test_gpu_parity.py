@@ -432,6 +432,11 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
     def forms(m):
         """(context, kernel of the parts or None) for a batch of m items"""
         return ((c0, None), (c1, ""), (c2, "_c"), (cd, "_c" if m <= coop_default else ""))
+
+    def row(c, m):
+        """do the calls that have no parted one-lane form (fixed base, decompression, the front of
+        the recovery) run on the row layer?  ELLGPU_COOP_GRID alone decides"""
+        return c is c2 or (c is not c1 and m <= coop_default)
     n = 32768
     h, r, s, pub, expect = _make_sigs(c0, n, "gpu-test-parted")
     pub = pub.copy()
@@ -492,6 +497,23 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
             assert np.array_equal(xy, outs[0][0]) and np.array_equal(inf, outs[0][1]), m
     xy, inf = outs[1]
     assert (inf[want[:m] == 2] == 2).all() and int((inf == 2).sum()) == int((want[:m] == 2).sum())
+    # Point#mul on G (KeyPair#getPublic): a handful of items run the comb and the item's own inversion
+    # on a wave (mul_fixed_c); same bytes as mul_fixed -> normalize, k = 0, n, n + 1, 2^256 - 1 included
+    for m in (1, 27, 64, 65, 1365, 1366, 4096):
+        outs_f = []
+        for c, parts in forms(m):
+            if c is c2 and m > 4096:
+                continue
+            c.set_timing(True)
+            outs_f.append(c.mul_fixed("secp256k1", ks[:m]))
+            tm = c.get_timing()
+            c.set_timing(False)
+            assert ("mul_fixed_c" in tm) == row(c, m) and ("mul_fixed" in tm) != row(c, m), (m, parts, sorted(tm))
+        for fxy, finf in outs_f[1:]:
+            assert np.array_equal(fxy, outs_f[0][0]) and np.array_equal(finf, outs_f[0][1]), m
+    jf = np.concatenate([np.arange(20, 27), np.arange(0, m, 41)])
+    wxy, winf = c_oracle.mul("secp256k1", ks[jf])
+    assert np.array_equal(outs_f[0][0][jf], wxy) and np.array_equal(outs_f[0][1][jf], winf)
     j = np.concatenate([np.arange(20, 27), np.arange(0, m, 23)])
     j = j[want[j] != 2]
     wxy, winf = c_oracle.mul("secp256k1", ks[j], pub[j])
@@ -514,8 +536,39 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
     j = j[want[j] != 2]
     wxy, winf = c_oracle.mul_add("secp256k1", s[j], None, ks[j], pub[j])
     assert np.array_equal(outs[1][0][j], wxy) and np.array_equal(outs[1][1][j], winf)
+    # ShortCurve#pointFromX and EC#recoverPubKey of a handful of items: the square root on a wave per
+    # item (decompress_c; recover_parts_c runs it beside r^-1 in one launch) -- same bytes as the
+    # one-lane kernels on abscissas with and without a point, x >= p, every recovery id, r = 0, r >= n
+    xs_ = pub[:, :32].copy()
+    xs_[1::3, 31] ^= 0x55                              # mostly no points any more
+    xs_[7] = 0xFF                                      # x >= p
+    odd_ = (np.arange(n) % 2).astype(np.uint8)
+    rec_ = (np.arange(n) % 5).astype(np.uint8)         # 4: more than two bits
+    rr_ = r.copy()
+    rr_[13] = 0xFF                                     # r >= n
+    for m in (1, 3, 64, 65, 1365, 1366, 4096):
+        outs_d, outs_r = [], []
+        for c, parts in forms(m):
+            if c is c2 and m > 4096:
+                continue
+            c.set_timing(True)
+            outs_d.append(c.decompress("secp256k1", xs_[:m], odd_[:m]))
+            tm = c.get_timing()
+            assert ("decompress_c" in tm) == row(c, m) and ("decompress" in tm) != row(c, m), (m, parts, sorted(tm))
+            c.set_timing(True)
+            outs_r.append(c.ecdsa_recover("secp256k1", h[:m], rr_[:m], s[:m], rec_[:m]))
+            tm = c.get_timing()
+            c.set_timing(False)
+            assert ("recover_parts_c" in tm) == row(c, m) and ("recover_prep" in tm) != row(c, m), (m, parts, sorted(tm))
+        for o in outs_d[1:]:
+            assert all(np.array_equal(a, b) for a, b in zip(outs_d[0], o)), ("decompress", m)
+        for o in outs_r[1:]:
+            assert all(np.array_equal(a, b) for a, b in zip(outs_r[0], o)), ("recover", m)
+    okd = outs_d[0][1]
+    assert 0 < int(okd.sum()) < m and okd[0] == 1
     for c in (c0, c1, c2):
         assert PC.check_mul_golden(c, "secp256k1") > 50
+        assert PC.check_decompress_golden(c, "secp256k1") > 40
         assert PC.check_recover_golden(c, "secp256k1") >= 30
         assert PC.check_exceptional_keys(c, "secp256k1") > 400
         assert PC.check_verify_golden(c, "secp256k1") > 15
@@ -565,8 +618,12 @@ def test_nist_small_batches_on_the_row_layer(monkeypatch, curve):
             tm = c.get_timing()
             assert ("mul_parts_c" in tm) == rowk, (curve, m, rowk, sorted(tm))
             ma = c.mul_add2(curve, e[:m], None, k[:m], pts[:m])
+            c.set_timing(True)                             # (a fresh recording)
+            mf = c.mul_fixed(curve, k[:m])                 # the comb + the item's own inversion on a wave
+            tm = c.get_timing()
+            assert ("mul_fixed_c" in tm) == rowk and ("mul_fixed" in tm) != rowk, (curve, m, rowk, sorted(tm))
             c.set_timing(False)
-            outs.append((v, mv, ma))
+            outs.append((v, mv, ma, mf))
         for o in outs[1:]:
             for a, b in zip(outs[0], o):
                 assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (curve, m)

@@ -368,6 +368,9 @@ def test_verify_golden_secp256k1_both_tunings(hs, monkeypatch):
         for name in (b"mul_parts", b"mul_parts_c"):
             assert (hs.hs_launches(name) > 0) == (name == mparts), name
         assert (hs.hs_launches(b"mul_join") > 0) == (parts is not None)
+        # fixed base: the comb and the item's own inversion on a wave (mul_fixed_c), or mul_fixed -> normalize
+        assert (hs.hs_launches(b"mul_fixed_c") > 0) == (parts == b"ecdsa_parts_c")
+        assert (hs.hs_launches(b"mul_fixed") > 0) == (parts != b"ecdsa_parts_c")
         # k1 G + k2 P (Point#mulAdd with G, EC#recoverPubKey): the halves of k2 and the comb of k1
         hs.hs_launches_reset()
         assert PC.check_exceptional_keys(c, "secp256k1") > 400
@@ -375,6 +378,14 @@ def test_verify_golden_secp256k1_both_tunings(hs, monkeypatch):
         assert (hs.hs_launches(b"mul_add_g") > 0) == (parts is None)
         for name in (b"mul_parts", b"mul_parts_c"):
             assert (hs.hs_launches(name) > 0) == (name == mparts), name
+        # ... whose front -- R's square root and r^-1 -- is one launch of the row layer, side by side
+        assert (hs.hs_launches(b"recover_parts_c") > 0) == (parts == b"ecdsa_parts_c")
+        assert (hs.hs_launches(b"recover_prep") > 0) == (parts != b"ecdsa_parts_c")
+        # ShortCurve#pointFromX of a handful of abscissas: the square root on a wave per item
+        hs.hs_launches_reset()
+        assert PC.check_decompress_golden(c, "secp256k1") > 40
+        assert (hs.hs_launches(b"decompress_c") > 0) == (parts == b"ecdsa_parts_c")
+        assert (hs.hs_launches(b"decompress") > 0) == (parts != b"ecdsa_parts_c")
         c.close()
     # the default context routes the lone call to the row layer
     c = elliptic_amd.Context(0, lib_path=hs)
@@ -401,6 +412,7 @@ def test_nist_curves_one_lane_and_row_layer(hs, monkeypatch, curve):
         hs.hs_launches_reset()
         assert PC.check_mul_golden(c, curve) > 50
         assert (hs.hs_launches(b"mul_parts_c") > 0) == rowk
+        assert (hs.hs_launches(b"mul_fixed_c") > 0) == rowk and (hs.hs_launches(b"mul_fixed") > 0) != rowk
         if curve != "p224":
             assert PC.check_recover_golden(c, curve) >= 30
         assert PC.check_sign_golden(c, curve) > 10
