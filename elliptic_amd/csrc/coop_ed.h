@@ -361,6 +361,28 @@ struct CoopEd {
     load_be<8>(ty, xy + i * 64 + 32, 32);
     return from_affine(F::from_plain(tx), F::from_plain(ty));
   }
+  // Point#mul on G (EDDSA's a*G and r*G, KeyPair#getPublic) of one item: the comb and the item's own
+  // inversion on a wave -> affine big-endian (x, y) and Point#isInfinity's flag, as edwards.h
+  // normalize writes them (ed_mul_fixed + ed_normalize were two dependent one-lane launches)
+  ELL_HD static void mul_fixed(size_t i, const u8* ks, const W1::P* comb, u8* out_xy, u8* out_inf) {
+    u32 k[8];
+    load_be<8>(k, ks + i * 32, 32);
+    const P r = comb_mul(k, comb);
+    // (Z = 0 cannot happen on the curve -- complete formulas; normalize puts 1 in its place)
+    const El z = F::is_zero(r.c) ? F::one() : r.c;
+    const El zi = F::inv(z);
+    u32 x[8], y[8];
+    F::to_plain(x, F::mul(r.a, zi));
+    F::to_plain(y, F::mul(r.b, zi));
+    bool ident = y[0] == 1u;
+    ELL_UNROLL
+    for (int l = 0; l < 8; l++) ident = ident && x[l] == 0u && (l == 0 || y[l] == 0u);
+    if (CoopK256::writer()) {
+      store_be<8>(out_xy + i * 64, x, 32);
+      store_be<8>(out_xy + i * 64 + 32, y, 32);
+      if (out_inf) out_inf[i] = ident ? 1 : 0;
+    }
+  }
   // Point#mul (edwards.js:362-364) of one item -> ed_normalize's input (edwards.h store_ext's layout)
   ELL_HD static void mul_var(size_t i, size_t n, const u8* ks, const u8* xy, const DigitStore& ds, u32* ext,
                              void* row_mem) {

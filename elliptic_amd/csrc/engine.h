@@ -730,6 +730,16 @@ struct FnEdMulC {
     else CoopEd::mul_add(i, n, k1, xy1, k2, xy2, comb, ds, ext, row_mem);
   }
 };
+// edwards Point#mul on G for a handful of items: the comb and the inversion on a wave, one launch
+struct FnEdMulFixedC {
+  static constexpr const char* NAME = "ed_mul_fixed_c";
+  static constexpr int DS_PER_LANE = 0;
+  static constexpr int ROW_BYTES = 16;
+  size_t n; const u8* k; const EdWork::P* comb; u8* out_xy; u8* out_inf;
+  ELL_HD void operator()(size_t i, const DigitStore&, void*) const {
+    if (i < n) CoopEd::mul_fixed(i, k, comb, out_xy, out_inf);
+  }
+};
 struct FnX25519C {
   static constexpr const char* NAME = "x25519_c";
   static constexpr int DS_PER_LANE = 0;
@@ -2612,6 +2622,11 @@ int Engine<BK>::ed_mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy
 template <class BK>
 template <int U>
 int Engine<BK>::ed_mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf) {
+  if (n <= coop_grid() && out_xy) {                    // a handful of items: one item per wave, one launch
+    FnEdMulFixedC fc{n, k, (const EdWork::P*)comb_[CURVE_ED25519], out_xy, out_inf};
+    bk.launch_coop(fc, n);
+    return E_OK;
+  }
   u32* ext = (u32*)scratch(S_JAC, n * 4 * 8 * 4);
   if (!ext) return fail(E_NOMEM, "scratch allocation failed");
   FnEdMulFixed f{n, k, (const EdWork::P*)comb_[CURVE_ED25519], ext};

@@ -703,6 +703,26 @@ def test_eddsa_verify_small_batches_on_the_row_layer(monkeypatch):
         for o in outs[1:]:
             for a, b in zip(outs[0], o):
                 assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), m
+    # edwards Point#mul on G (the comb + the item's own inversion on a wave: ed_mul_fixed_c) and
+    # EDDSA#sign, whose a*G and r*G are two such items: same bytes as ed_mul_fixed -> ed_normalize
+    for m in (1, 3, 64, 682, 683, 1365, 1366):
+        outs = []
+        for c, rowk in ((c0, False), (c1, True), (cd, m <= 1365)):
+            c.set_timing(True)
+            mf = c.mul_fixed("ed25519", k2[:m])
+            tm = c.get_timing()
+            assert ("ed_mul_fixed_c" in tm) == rowk and ("ed_mul_fixed" in tm) != rowk, (m, rowk, sorted(tm))
+            c.set_timing(True)
+            sg = c.eddsa_sign(msgs[:m], sec[:m])
+            tm = c.get_timing()
+            c.set_timing(False)
+            rows = rowk if c is not cd else 2 * m <= 1365
+            assert ("ed_mul_fixed_c" in tm) == rows and ("ed_mul_fixed" in tm) != rows, (m, rowk, sorted(tm))
+            outs.append((mf, sg))
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), m
+    assert outs[0][0][1][20] == 1 and outs[0][0][1][24] == 1 and outs[0][0][1][:20].sum() == 0   # k = 0 and k = n: the identity
     # curve25519 Point#mul (x only), one item per wave (x25519_c): unclamped scalars incl. 0, 1 and
     # 2^256 - 1, u = 0, 1, p - 1 and a point of small order
     xs = np.ascontiguousarray(kk[:, :32]).copy()

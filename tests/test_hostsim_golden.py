@@ -436,6 +436,11 @@ def test_eddsa_verify_one_lane_and_row_layer(hs, monkeypatch):
         assert PC.check_mul_golden(c, "ed25519") > 50
         assert PC.check_offcurve_golden(c, "ed25519") >= 29
         assert (hs.hs_launches(b"ed_mul_c") > 0) == rowk and (hs.hs_launches(b"ed_mul_var") > 0) != rowk
+        # ... on G: the comb and the item's own inversion on a wave (EDDSA#sign's a*G and r*G too)
+        assert (hs.hs_launches(b"ed_mul_fixed_c") > 0) == rowk and (hs.hs_launches(b"ed_mul_fixed") > 0) != rowk
+        hs.hs_launches_reset()
+        assert PC.check_eddsa_sign_golden(c) > 100
+        assert (hs.hs_launches(b"ed_mul_fixed_c") > 0) == rowk and (hs.hs_launches(b"ed_mul_fixed") > 0) != rowk
         # curve25519's x-only ladder, one item per wave (coop_ed.h CoopX25519)
         hs.hs_launches_reset()
         assert PC.check_x25519_golden(c) > 30

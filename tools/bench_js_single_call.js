@@ -40,6 +40,11 @@ libs.forEach(function(l) {
   out('EC#verify (Signature object, KeyPair)', l[0], timeSync(function() { return ec.verify(msg, sig, key); }, 200));
   var P = kp.getPublic(), k = kp.getPrivate();
   out('Point#mul (variable base)', l[0], timeSync(function() { return P.mul(k).getX(); }, 200));
+  out('Point#mul (fixed base: G.mul(k), KeyPair#getPublic)', l[0], timeSync(function() { return ec.g.mul(k).getX(); }, 200));
+  var xh = P.getX().toString(16, 64), yOdd = P.getY().isOdd();
+  out('ShortCurve#pointFromX', l[0], timeSync(function() { return ec.curve.pointFromX(xh, yOdd).getY(); }, 200));
+  var pubc = kp.getPublic(true, 'hex');
+  out('EC#verify (DER hex signature, COMPRESSED hex key)', l[0], timeSync(function() { return ec.verify(msg, der, pubc, 'hex'); }, 200));
   out('EC#sign', l[0], timeSync(function() { return ec.sign(msg, kp); }, 200));
   out('EC#recoverPubKey', l[0], timeSync(function() { return ec.recoverPubKey(msg, sig, sig.recoveryParam); }, 200));
   var Q = ec.genKeyPair({ entropy: crypto.createHash('sha512').update('q').digest() }).getPublic();
@@ -66,6 +71,7 @@ libs.forEach(function(l) {
   var ek = ed.keyFromSecret(crypto.createHash('sha256').update('ed').digest());
   var esig = ek.sign(msg).toHex(), epub = ek.getPublic('hex');
   out('EDDSA#verify', l[0], timeSync(function() { return ed.verify(msg, esig, epub); }, 100));
+  out('EDDSA#sign', l[0], timeSync(function() { return ed.sign(msg, ek).toHex(); }, 100));
   // the other two curve families' own Point#mul
   var eA = ek.pub(), ekk = kp.getPrivate();
   out('ed25519 Point#mul', l[0], timeSync(function() { return eA.mul(ekk).getX(); }, 100));
