@@ -490,7 +490,7 @@ function install(elliptic, options) {
   // not the point's multiples makes the reference return something else than k * P.  The engine
   // computes k * P from (x, y) alone, so it answers only for points whose tables ARE their
   // multiples: each table is checked once (the reference's Jacobian / projective dbl() and add(), a
-  // few milliseconds per curve), and the verdict
+  // few milliseconds per curve -- 6 for secp256k1, 65 for p521 --), and the verdict
   // is remembered on the table object; anything else is left to the reference's own ladders.
   function hide(o, k, v) {
     try { Object.defineProperty(o, k, { value: v, enumerable: false, writable: true, configurable: true }); }
