@@ -482,11 +482,11 @@ function install(elliptic, options) {
   }
   // ---- inputs the reference TRUSTS: precomputed tables and the endomorphism's constants --------
   // A point's `precomputed` tables are input to the reference's ladders: _fixedNafMul adds
-  // doubles.points[j] (base.js:44-94), _wnafMul / _wnafMulAdd add naf.points[(z - 1) >> 1]
-  // (base.js:96-253, through _getNAFPoints, base.js:342-360), _endoWnafMulAdd takes
+  // doubles.points[j] (base.js:52-84), _wnafMul / _wnafMulAdd add naf.points[(z - 1) >> 1]
+  // (base.js:86-253, through _getNAFPoints, base.js:357-374), _endoWnafMulAdd takes
   // precomputed.beta for lambda * P (short.js:282-310) -- whatever they hold.  precompute() fills
   // them with the true multiples, but curve.pointFromJSON([x, y, { doubles, naf }])
-  // (short.js:332-359, edwards.js the same way) takes them from the caller, and a table that is
+  // (short.js:328-355, edwards.js the same way) takes them from the caller, and a table that is
   // not the point's multiples makes the reference return something else than k * P.  The engine
   // computes k * P from (x, y) alone, so it answers only for points whose tables ARE their
   // multiples: each table is checked once (the reference's Jacobian / projective dbl() and add(), a
@@ -703,7 +703,7 @@ function install(elliptic, options) {
   }
 
   base._fixedNafMul = function _fixedNafMul(p, k) {
-    // (base.js:44-46: the reference asserts p.precomputed and reads its doubles)
+    // (base.js:52-54: the reference asserts p.precomputed and reads its doubles)
     if (refOnly || !p || !p.precomputed || !p.precomputed.doubles) return orig.fixedNafMul.apply(this, arguments);
     return mul1(this, p, k, orig.fixedNafMul, arguments);
   };

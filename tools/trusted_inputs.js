@@ -1,10 +1,10 @@
 'use strict';
 // Inputs the reference TRUSTS.  Its ladders read a point's precomputed tables
-// (lib/elliptic/curve/base.js:44-94 doubles, :96-253 naf, short.js:282-310 beta), the constants of
+// (lib/elliptic/curve/base.js:52-84 doubles, :96-253 naf, short.js:282-310 beta), the constants of
 // the GLV endomorphism (short.js:28-75: conf.beta / conf.lambda / conf.basis are taken as given,
 // :168-249 split and ladder) and the curve equation itself as they are handed in.  When those are
 // not what precompute() / _getEndomorphism() would have made of the curve -- tables through
-// curve.pointFromJSON, short.js:332-359; an order n smaller than the group; a singular cubic; an
+// curve.pointFromJSON, short.js:328-355; an order n smaller than the group; a singular cubic; an
 // Edwards curve whose addition law is not complete -- the reference still answers, with a value
 // that is not k * P.  install() answers from (x, y) and k alone, so it must leave every such call
 // to the reference's own code (elliptic_amd/js/index.js: tablesOK, endoOK, customDomain).
@@ -286,7 +286,7 @@ function recipes(rng) {
     TAMPER.forEach(function(tamper, ti) {
       var calls = curve === 'ed25519' ? [ 'mul', 'mulAdd', 'mulAddRev' ] : [ 'mul', 'mulAdd', 'mulAddRev', 'jmulAdd', 'derive', 'verify' ];
       calls.forEach(function(call, ci) {
-        // the table a ladder reads depends on the width of k (_hasDoubles, base.js:333-340): narrow and wide
+        // the table a ladder reads depends on the width of k (_hasDoubles, base.js:329-338): narrow and wide
         [ hex(1 + (ti + ci) % 3), hex(NB - 1) ].forEach(function(k) {
           out.push({ op: 'tables', curve: curve, mult: 1 + (ti + ci) % 2 * 6, tamper: tamper, at: small(), call: call,
             k: k, k2: hex(NB - 1), msg: arr(32) });
