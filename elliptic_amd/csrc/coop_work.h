@@ -193,6 +193,32 @@ struct CoopK256 {
     store_jac(jac, n, i, b);
   }
 
+  // ---- EC#verify, in front of the parts: the window table of Q on a wave (work.h ecdsa_table) ----
+  // The same table -- build_table_odd8 is the same template, its entries and the common Z are the
+  // same field values -- written in the one-lane kernels' format (plain words; zg in the table's
+  // last scratch slot), where ecdsa_half / ecdsa_join read it.  Runs BESIDE the scalar-field prep
+  // (FnEcdsaPrepTableC): the one-lane table build was the longer of the two (86 against 55 us).
+  ELL_HD static void store_words(u32 (&dst)[8], const El& a) {
+    u32 w[8];
+    F::to_plain(w, a);
+    if (writer()) {
+      ELL_UNROLL
+      for (int l = 0; l < 8; l++) dst[l] = w[l];
+    }
+  }
+  ELL_HD static void ecdsa_table(size_t i, const u8* pub_xy, W1::VT* tbl_all, void* row_mem) {
+    A* tbl = lane_table(row_mem);
+    El zg;
+    LD::template build_table_odd8<E::NE>(tbl, load_affine(pub_xy, i), zg);
+    W1::VT* dst = tbl_all + i * W1::stride<true>();
+    ELL_NOUNROLL
+    for (int e = 0; e < E::NE; e++) {
+      store_words(dst[e].x.v, tbl[e].x);
+      store_words(dst[e].y.v, tbl[e].y);
+    }
+    store_words(dst[2 * E::NE - 1].x.v, zg);
+  }
+
   // ---- fixed base: k*G over the one-lane comb table ----
   ELL_HD static J comb_mul(const u32 (&k)[8], const W1::A* comb) { return coop_comb_mul<CoopK256>(k, comb); }
   // EC#verify, part 2: u1*G

@@ -343,6 +343,23 @@ struct FnEcdsaPartsC {
     else CoopK256::ecdsa_half(i, n, part, u12, tbl, ds, out, row_mem);
   }
 };
+// ... and in front of them, ONE launch: unit i < n runs the scalar-field prep of item i (the
+// one-lane code on a wave of its own: range checks, s^-1, u1, u2), unit n + i builds the window
+// table of Q_i on the row layer (coop_work.h CoopK256::ecdsa_table) -- the one-lane
+// FnEcdsaPrepTable took as long as its table build (86 us against the prep's 55).
+struct FnEcdsaPrepTableC {
+  static constexpr const char* NAME = "ecdsa_prep_table_c";
+  typedef Work<CvSecp256k1> W;
+  static constexpr int DS_PER_LANE = 0;
+  static constexpr int ROW_BYTES = CoopK256::ROW_BYTES;
+  size_t n; const u8* hash; int hash_len; int shift; const u8* r; const u8* s;
+  u32* pre; u32* u12; u8* valid; const u8* pub; typename W::VT* tbl;
+  ELL_HD void operator()(size_t unit, const DigitStore&, void* row_mem) const {
+    // (every lane of the prep's wave runs the one-lane code on the same item and stores the same values)
+    if (unit < n) W::ecdsa_prep(unit, n, n, 1, hash, hash_len, shift, r, s, pre, u12, valid);
+    else CoopK256::ecdsa_table(unit - n, pub, tbl, row_mem);
+  }
+};
 struct FnMulPartsC {
   static constexpr const char* NAME = "mul_parts_c";
   typedef Work<CvSecp256k1> W;
@@ -2495,8 +2512,14 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
       const int Ks = inv_batch_beside(n, INV_BATCH_N);
       const size_t Ts = (n + Ks - 1) / Ks;
       const size_t tpad = (Ts + 127) & ~(size_t)127;          // whole workgroups of either kind
-      FnEcdsaPrepTable<CV> fpt{{Ts, n, Ks, hash, hash_len, shift, r, s, pre, u12, valid}, tpad, {n, pub, tbl}};
-      launch_fn(fpt, tpad + n);
+      if (n <= parted_grid() && n <= coop_grid()) {
+        // a handful of items: the prep on a wave per item, the table on another (row layer), one launch
+        FnEcdsaPrepTableC fptc{n, hash, hash_len, shift, r, s, pre, u12, valid, pub, tbl};
+        bk.launch_coop(fptc, 2 * n);
+      } else {
+        FnEcdsaPrepTable<CV> fpt{{Ts, n, Ks, hash, hash_len, shift, r, s, pre, u12, valid}, tpad, {n, pub, tbl}};
+        launch_fn(fpt, tpad + n);
+      }
       if (n <= parted_grid()) {
         // most SIMDs would idle beside this batch: three lanes per item (FnEcdsaParts), then the join
         u32* jac = (u32*)scratch(S_JAC, n * 3 * 3 * W::NS * 4);

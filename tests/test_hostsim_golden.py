@@ -362,6 +362,9 @@ def test_verify_golden_secp256k1_both_tunings(hs, monkeypatch):
             assert (hs.hs_launches(name) > 0) == (name == parts), name
         assert (hs.hs_launches(b"ecdsa_join") > 0) == (parts is not None)
         assert (hs.hs_launches(b"ecdsa_main") > 0) == (parts is None)
+        # (the row layer also builds Q's window table, beside the prep: one launch)
+        assert (hs.hs_launches(b"ecdsa_prep_table_c") > 0) == (parts == b"ecdsa_parts_c")
+        assert (hs.hs_launches(b"ecdsa_prep_table") > 0) == (parts != b"ecdsa_parts_c")
         # Point#mul likewise (Work::mul_half x 2, mul_join); k1 G + k2 P stays on its one ladder
         hs.hs_launches_reset()
         assert PC.check_mul_golden(c, "secp256k1") > 50
