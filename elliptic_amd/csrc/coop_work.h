@@ -198,12 +198,15 @@ struct CoopK256 {
   // same field values -- written in the one-lane kernels' format (plain words; zg in the table's
   // last scratch slot), where ecdsa_half / ecdsa_join read it.  Runs BESIDE the scalar-field prep
   // (FnEcdsaPrepTableC): the one-lane table build was the longer of the two (86 against 55 us).
-  ELL_HD static void store_words(u32 (&dst)[8], const El& a) {
+  // (N = 8: the saturated field's words.  The ELL_K256_LAZY build's nine-limb elements keep their
+  // small batches off the row layer -- AVAILABLE is false there -- but this must still compile)
+  template <int N>
+  ELL_HD static void store_words(u32 (&dst)[N], const El& a) {
     u32 w[8];
     F::to_plain(w, a);
     if (writer()) {
       ELL_UNROLL
-      for (int l = 0; l < 8; l++) dst[l] = w[l];
+      for (int l = 0; l < N; l++) dst[l] = l < 8 ? w[l] : 0u;
     }
   }
   ELL_HD static void ecdsa_table(size_t i, const u8* pub_xy, W1::VT* tbl_all, void* row_mem) {
