@@ -252,3 +252,37 @@ def test_js_batch_api_gpu():
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert json.loads(p.stdout.strip().splitlines()[-1])["checked"] > 1000
+
+
+def _run_toy_probe(lib, p, kind, min_calls):
+    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
+    if lib:
+        env["ELLGPU_LIB"] = lib
+    else:
+        env.pop("ELLGPU_LIB", None)
+    q = subprocess.run(["node", os.path.join(ROOT, "tools", "probe_toy_curves.js"), str(p), kind], env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert q.returncode == 0, q.stdout[-2000:] + q.stderr[-2000:]
+    res = json.loads(q.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["mismatches"] == 0 and res["calls"] >= min_calls and res["engine_calls"] > 0, res
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+@pytest.mark.parametrize("p,kind,min_calls", [(5, "short", 3000), (5, "edwards", 1500), (7, "edwards", 6000)])
+def test_every_toy_curve_every_point(p, kind, min_calls):
+    """EVERY curve over F_p in the given model (singular cubics and Edwards curves without a complete
+    addition law included), every point on it, k = 0 .. 2p + 3, mulAdd / jmulAdd grids: the patched
+    library against the unpatched reference (tools/probe_toy_curves.js) -- the curves whose equation
+    gives no (complete) group law must stay on the reference's own code"""
+    _addon()
+    from hostsim.build import build as build_hostsim
+    _run_toy_probe(build_hostsim(), p, kind, min_calls)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_every_toy_curve_every_point_gpu():
+    from elliptic_amd.js import build as jb
+    jb.build()
+    _run_toy_probe(None, 7, "short", 12000)
+    _run_toy_probe(None, 7, "edwards", 6000)
