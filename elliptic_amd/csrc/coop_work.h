@@ -402,13 +402,9 @@ struct CoopNist {
       }
     }
   }
-  // k*P (work.h var_ladder, the curves without an endomorphism)
-  ELL_HD static J ladder(const u32 (&k)[L], const A& p, const DigitStore& ds, A* tbl) {
-    u32 kk[L];
-    bn_copy<L>(kk, k);
-    const u32 evenmask = (k[0] & 1u) ? 0u : 1u;
-    kk[0] |= 1u;                                    // k even -> k + 1, P subtracted at the end
-    recode_odd_w4<L, NW, WB>(kk, ds, 0, 1);
+  // the odd multiples of P on the curve itself (co-Z table on the isomorphic curves, one inversion
+  // to map it back to the curve whose a = -3 doubling the ladder needs): the first half of var_ladder
+  ELL_HD static void build_table(A* tbl, const A& p) {
     El zg;
     LD::template build_table_odd8<NE>(tbl, p, zg);
     El zi = F::inv(zg);
@@ -421,16 +417,65 @@ struct CoopNist {
       t.y = F::mul(t.y, zi3);
       tbl[e] = t;
     }
+  }
+  // the digits of k over such a table (k even -> k + 1, P subtracted at the end)
+  ELL_HD static J run_table(const u32 (&k)[L], const DigitStore& ds, const A* tbl) {
+    u32 kk[L];
+    bn_copy<L>(kk, k);
+    const u32 evenmask = (k[0] & 1u) ? 0u : 1u;
+    kk[0] |= 1u;
+    recode_odd_w4<L, NW, WB>(kk, ds, 0, 1);
     bool inf;
     return LD::template run_odd_w4<1, NW, false, false, WB>(ds, tbl, 0u, evenmask, inf);
   }
+  // k*P (work.h var_ladder, the curves without an endomorphism)
+  ELL_HD static J ladder(const u32 (&k)[L], const A& p, const DigitStore& ds, A* tbl) {
+    build_table(tbl, p);
+    return run_table(k, ds, tbl);
+  }
+  // A unit's table in global memory, in the ROW's own format (nothing is converted): the table of an
+  // EC#verify's key does not depend on s^-1, so a unit of the launch in front builds it beside the
+  // scalar-field prep (FnEcdsaPrepTableN) and the ladder's unit starts from it.  GROW lane-entries
+  // per table entry (the device keeps a limb per lane, host passes a whole row per element).
+  static constexpr int GROW = FpK256C::CL == 1 ? 16 : 1;
+  static constexpr size_t TABLE_BYTES = (size_t)NE * GROW * sizeof(A);
+  ELL_HD static void table_out(A* g, const A* tbl) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x < 16u) {
+      ELL_NOUNROLL
+      for (int e = 0; e < NE; e++) g[e * 16 + threadIdx.x] = tbl[e];
+    }
+#else
+    for (int e = 0; e < NE; e++) g[e] = tbl[e];
+#endif
+  }
+  ELL_HD static void table_in(A* tbl, const A* g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    ELL_NOUNROLL
+    for (int e = 0; e < NE; e++) tbl[e] = g[e * 16 + (threadIdx.x & 15u)];
+#else
+    for (int e = 0; e < NE; e++) tbl[e] = g[e];
+#endif
+  }
+  ELL_HD static void ecdsa_table(size_t i, const u8* pub_xy, A* gtbl, void* row_mem) {
+    A* tbl = lane_table(row_mem);
+    build_table(tbl, load_affine(pub_xy, i));
+    table_out(gtbl + i * (size_t)NE * GROW, tbl);
+  }
   // EC#verify part 0: u2*Q
+  // (gtbl != null: over the table ecdsa_table built in the launch in front)
   ELL_HD static void ecdsa_var(size_t i, size_t n, const u32* u12, const u8* pub_xy, const DigitStore& ds,
-                               u32* jac, void* row_mem) {
+                               u32* jac, void* row_mem, const A* gtbl) {
     u32 u2[L];
     ELL_UNROLL
     for (int l = 0; l < L; l++) u2[l] = l < W1::LN ? u12[(size_t)(1 * W1::LN + l) * n + i] : 0u;
-    store_jac(jac, n, i, ladder(u2, load_affine(pub_xy, i), ds, lane_table(row_mem)));
+    A* tbl = lane_table(row_mem);
+    if (gtbl) {
+      table_in(tbl, gtbl + i * (size_t)NE * GROW);
+      store_jac(jac, n, i, run_table(u2, ds, tbl));
+    } else {
+      store_jac(jac, n, i, ladder(u2, load_affine(pub_xy, i), ds, tbl));
+    }
   }
   // EC#verify part 1: u1*G
   ELL_HD static void ecdsa_fixed(size_t i, size_t n, const u32* u12, const typename W1::A* comb, u32* jac) {

@@ -385,13 +385,31 @@ struct FnEcdsaPartsN {
   typedef CoopNist<CV> CW;
   static constexpr int DS_PER_LANE = CW::NW;
   static constexpr int ROW_BYTES = CW::ROW_BYTES;
-  size_t n; const u32* u12; const u8* pub; const typename W::A* comb; u32* jac;
+  size_t n; const u32* u12; const u8* pub; const typename W::A* comb; u32* jac; const typename CW::A* gtbl;
   ELL_HD void operator()(size_t unit, const DigitStore& ds, void* row_mem) const {
     const int part = (int)(unit / n);
     const size_t i = unit - (size_t)part * n;
     u32* out = jac + (size_t)part * 3 * W::NS * n;
     if (part == 1) CW::ecdsa_fixed(i, n, u12, comb, out);
-    else CW::ecdsa_var(i, n, u12, pub, ds, out, row_mem);
+    else CW::ecdsa_var(i, n, u12, pub, ds, out, row_mem, gtbl);
+  }
+};
+// ... in front of them, ONE launch: unit i < n runs the scalar-field prep of item i (the one-lane
+// code on a wave), unit n + i builds the window table of Q_i -- co-Z chain, the inversion that maps
+// it back to the curve, 60 us of the ladder's chain that do not depend on s^-1 -- and leaves it in
+// global memory in the row's own format (CoopNist::ecdsa_table)
+template <class CV>
+struct FnEcdsaPrepTableN {
+  static constexpr const char* NAME = "ecdsa_prep_table_c";
+  typedef Work<CV> W;
+  typedef CoopNist<CV> CW;
+  static constexpr int DS_PER_LANE = 0;
+  static constexpr int ROW_BYTES = CW::ROW_BYTES;
+  size_t n; const u8* hash; int hash_len; int shift; const u8* r; const u8* s;
+  u32* pre; u32* u12; u8* valid; const u8* pub; typename CW::A* gtbl;
+  ELL_HD void operator()(size_t unit, const DigitStore&, void* row_mem) const {
+    if (unit < n) W::ecdsa_prep(unit, n, n, 1, hash, hash_len, shift, r, s, pre, u12, valid);
+    else CW::ecdsa_table(unit - n, pub, gtbl, row_mem);
   }
 };
 template <class CV>
@@ -2545,11 +2563,15 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
       // a handful of items on a curve without an endomorphism: the scalar-field prep as it is
       // (one inversion per item), then the ladder and the comb of every item on a WAVE each (the
       // row layer, coop_mont.h), and the one-lane join
-      FnEcdsaPrep<CV> fp1{n, n, 1, hash, hash_len, shift, r, s, pre, u12, valid};
-      launch_fn(fp1, n);
+      typedef CoopNist<CV> CW;
       u32* jac = (u32*)scratch(S_JAC, n * 2 * 3 * W::NS * 4);
-      if (!jac) return fail(E_NOMEM, "scratch allocation failed");
-      FnEcdsaPartsN<CV> fc{n, u12, pub, (const typename W::A*)comb_[CV::ID], jac};
+      typename CW::A* gt = (typename CW::A*)scratch(S_TBL, n * CW::TABLE_BYTES);
+      if (!jac || !gt) return fail(E_NOMEM, "scratch allocation failed");
+      // the prep on a wave per item, the window table of the key on another, one launch ...
+      FnEcdsaPrepTableN<CV> fpt{n, hash, hash_len, shift, r, s, pre, u12, valid, pub, gt};
+      bk.launch_coop(fpt, 2 * n);
+      // ... then the ladder over that table and the comb
+      FnEcdsaPartsN<CV> fc{n, u12, pub, (const typename W::A*)comb_[CV::ID], jac, gt};
       bk.launch_coop(fc, 2 * n);
       FnEcdsaJoin2<CV> fj{n, valid, r, pub, jac, ok, st};
       return launch_fn(fj, n);

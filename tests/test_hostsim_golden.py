@@ -412,6 +412,8 @@ def test_nist_curves_one_lane_and_row_layer(hs, monkeypatch, curve):
         if curve != "p192":
             assert PC.check_exceptional_keys(c, curve) > 400
         assert (hs.hs_launches(b"ecdsa_parts_c") > 0) == rowk and (hs.hs_launches(b"ecdsa_main") > 0) != rowk
+        # (the key's window table is built beside the scalar-field prep, one launch in front)
+        assert (hs.hs_launches(b"ecdsa_prep_table_c") > 0) == rowk and (hs.hs_launches(b"ecdsa_prep") > 0) != rowk
         hs.hs_launches_reset()
         assert PC.check_mul_golden(c, curve) > 50
         assert (hs.hs_launches(b"mul_parts_c") > 0) == rowk
