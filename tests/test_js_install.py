@@ -286,3 +286,35 @@ def test_every_toy_curve_every_point_gpu():
     jb.build()
     _run_toy_probe(None, 7, "short", 12000)
     _run_toy_probe(None, 7, "edwards", 6000)
+
+
+def _run_api_walk(lib):
+    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
+    if lib:
+        env["ELLGPU_LIB"] = lib
+    else:
+        env.pop("ELLGPU_LIB", None)
+    q = subprocess.run(["node", os.path.join(ROOT, "tools", "probe_api_walk.js")], env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert q.returncode == 0, q.stdout[-2000:] + q.stderr[-2000:]
+    res = json.loads(q.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["calls"] >= 600 and res["reference_threw"] >= 150 and res["engine"]["gpuCalls"] >= 400, res
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_public_api_walk_every_input_form():
+    """One set of inputs in every form the reference accepts -- keys, signatures, messages, recovery
+    ids, pointFromX / decodePoint forms on four curves, EdDSA keys / signatures / secrets / messages
+    -- on an unpatched and on a patched copy (tools/probe_api_walk.js): 635 calls, every result and
+    every exception message identical"""
+    _addon()
+    from hostsim.build import build as build_hostsim
+    _run_api_walk(build_hostsim())
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_public_api_walk_every_input_form_gpu():
+    from elliptic_amd.js import build as jb
+    jb.build()
+    _run_api_walk(None)
