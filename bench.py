@@ -64,6 +64,7 @@ N_SIMD = 256 * 4
 ORACLE_SAMPLE = 10240                 # tuples checked against the oracle in every run
 
 SECP_N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+SECP_P = (1 << 256) - (1 << 32) - 977
 
 
 def xof(seed: str, nbytes: int) -> np.ndarray:
@@ -73,8 +74,11 @@ def xof(seed: str, nbytes: int) -> np.ndarray:
 def make_signatures(ctx, n, seed, corrupt_every=100):
     """n synthetic secp256k1 signatures, all distinct keys/nonces, built without
     any modular inversion: pick d, k, s; r = x(kG) mod n; z = s*k - r*d mod n.
-    Every `corrupt_every`-th tuple gets one bit flipped in z, r or s.
-    Returns (hash, r, s, pub, expected_ok) as numpy arrays.  (The public keys and the
+    Every `corrupt_every`-th tuple is corrupted ("flip a bit of r, s, z or Q"): in
+    turn one bit of z, of r, of s, and the key Q -- alternately x + 1 (a point that is NOT on the
+    curve: the engine reports status 2 beside a verdict of 0) and the next tuple's key (on the
+    curve, the wrong key).  Returns (hash, r, s, pub, expected_ok) as numpy arrays;
+    expected_status(pub) gives the status array that goes with them.  (The public keys and the
     nonce points come from the engine's own fixed-base kernel; bench.py checks a sample of
     the tuples with the oracle in every run, so a wrong comb table cannot hide.)"""
     from elliptic_amd import ints_to_be
@@ -100,17 +104,40 @@ def make_signatures(ctx, n, seed, corrupt_every=100):
     ok = np.ones(n, np.uint8)
     ok[np.array(rs) == 0] = 0
     idx = np.arange(0, n, corrupt_every)
+    pub = np.array(pub, copy=True)
     for j, i in enumerate(idx):
-        which = (h, r, s)[j % 3]
-        which[i, 31 - (j % 8)] ^= 1 << (j % 7)
+        if j % 4 == 3:
+            if (j // 4) % 2 == 0:
+                x = (int.from_bytes(pub[i, :32].tobytes(), "big") + 1) % SECP_P
+                pub[i, :32] = np.frombuffer(x.to_bytes(32, "big"), np.uint8)
+            else:
+                pub[i] = pub[(i + 1) % n]
+        else:
+            which = (h, r, s)[j % 4]
+            which[i, 31 - (j % 8)] ^= 1 << (j % 7)
         ok[i] = 0
     return h, r, s, pub, ok
+
+
+def expected_status(pub, r=None, s=None):
+    """the status array ellgpu_ecdsa_verify reports beside the verdicts: 2 (ELLGPU_STATUS_OFF_CURVE)
+    where the key does not satisfy y^2 = x^3 + 7 (and r, s are in range), else 0 -- computed here
+    with Python integers, independently of the device"""
+    x = [int.from_bytes(row[:32].tobytes(), "big") for row in pub]
+    y = [int.from_bytes(row[32:].tobytes(), "big") for row in pub]
+    st = np.array([2 if (yy * yy - xx * xx * xx - 7) % SECP_P else 0 for xx, yy in zip(x, y)], np.uint8)
+    if r is not None and s is not None:
+        for i in np.nonzero(st)[0]:
+            ri, si = int.from_bytes(r[i].tobytes(), "big"), int.from_bytes(s[i].tobytes(), "big")
+            if not (0 < ri < SECP_N and 0 < si < SECP_N):
+                st[i] = 0
+    return st
 
 
 def cached_signatures(ctx, n, seed):
     """make_signatures with a /tmp cache (the generator is ~10 s of Python big-int work per 2^20
     tuples; the profiling passes call bench.py several times on one box)"""
-    key = hashlib.sha256(("%s:%d:v2" % (seed, n)).encode()).hexdigest()[:16]
+    key = hashlib.sha256(("%s:%d:v3" % (seed, n)).encode()).hexdigest()[:16]
     path = os.path.join(tempfile.gettempdir(), "ellgpu_bench_%s.npz" % key)
     if os.path.exists(path):
         try:
@@ -700,6 +727,19 @@ def main():
         if not np.array_equal(got, expect):
             bad = int((got != expect).sum())
             raise SystemExit("PARITY FAILURE: %d of %d verify results differ from the expected mask" % (bad, n))
+    # ... and the STATUS array beside it: 2 exactly where the (corrupted) key is not on the curve --
+    # one pass of the same entry point with out_status, compared with a host-side curve test
+    dst = torch.zeros(n, dtype=torch.uint8, device=dev)
+    dok_st = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ctx.ecdsa_verify_dev("secp256k1", dh, dr, dsg, dq, dok_st, out_status=dst)
+    torch.cuda.synchronize()
+    want_st = expected_status(pub, r, s)
+    got_st = dst.cpu().numpy()
+    if not np.array_equal(got_st, want_st) or not np.array_equal(dok_st.cpu().numpy(), expect):
+        raise SystemExit("PARITY FAILURE: status array differs from the host-side curve test on %d of %d tuples"
+                         % (int((got_st != want_st).sum()), n))
+    off_curve_tuples = int((want_st == 2).sum())
+    del dst, dok_st
     if strong and world > 1:
         # the gathered mask is the global batch's expected mask on every rank
         _, _, _, _, expect_all = cached_signatures(ctx, args.batch, "ellgpu-bench-v1:3:rank0")
@@ -748,13 +788,25 @@ def main():
     # shares the device with the other pass's kernels: the kernels BY THEMSELVES are timed in a
     # short one-stream loop outside the timed region
     timing_alone = None
+    one_in_flight = None
+    alone_steps = min(args.steps, 20)
     if flight > 1 and og_w is None:
         ctx.set_timing(True)
-        for _ in range(min(args.steps, 10)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(alone_steps):
             ctx.ecdsa_verify_dev("secp256k1", dh, dr, dsg, dq, dok)
         torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t0
         timing_alone = ctx.get_timing()
         ctx.set_timing(False)
+        # the cross-check the line carries with it: with ONE pass in flight a step cannot be shorter
+        # than its kernels (kernel_ms + prep_kernel_ms <= one_in_flight.ms_per_step); `value` is the
+        # two-in-flight rate, in which the front of pass i + 1 runs beside the ladder of pass i
+        one_in_flight = {"value": n * alone_steps / dt1, "unit": "verifies/s", "ms_per_step": dt1 / alone_steps * 1e3,
+                         "steps": alone_steps,
+                         "how": "this rank's batch in a ONE-stream loop right after the timed region, wall clock "
+                                "between synchronisations; never `value`"}
 
     # SUSTAINED rate (never `value`): the timed region above is --steps passes, a fraction of a second,
     # on a kernel that runs into the part's power limit -- so the same step loop (same streams, same
@@ -893,7 +945,7 @@ def main():
         roof["prep_kernel_ms"] = prep_alone
         if timing_alone is not None:
             roof["kernel_ms_measured"] = ("HIP events around the kernel's launches in a one-stream loop of %d passes right "
-                                          "after the timed region (the kernel by itself)" % min(args.steps, 10))
+                                          "after the timed region (the kernel by itself)" % alone_steps)
             roof["timed_region"] = {"passes_in_flight": flight, "kernel_ms_between_events": k_timed,
                                     "prep_kernel_ms_between_events": prep_timed,
                                     "note": "HIP events around the same kernels inside the timed region: two passes "
@@ -931,10 +983,16 @@ def main():
                        "batch_per_gpu": n, "global_batch": n_global, "parallelism": "shard%d" % world,
                        "parity": "ok-mask == expected mask on all %d tuples; expected mask == oracle on the "
                                  "first %d (%s)" % (n, checked["tuples"], checked["by"]),
+                       "corrupted": "every 100th tuple: one bit of z / r / s in turn, every fourth of them the key Q "
+                                    "(x + 1: off the curve, %d tuples, status 2 checked against a host-side curve "
+                                    "test before timing; or the next tuple's key)" % off_curve_tuples,
                        "passes_in_flight": flight,
+                       "comb_bits": ctx.comb_bits("secp256k1"),
                        "library_digest": lib_digest()},
             "roofline": roof,
         }
+        if one_in_flight is not None:
+            out["one_in_flight"] = one_in_flight
         if sustained is not None:
             vb = ((counters or {}).get("kernels", {}).get("ecdsa_main<secp256k1>", {}) or {}).get("valu_busy") or {}
             sustained["clock_ghz_effective"] = vb.get("clock_ghz_effective")

@@ -25,6 +25,8 @@ _SIGS = {
     "ellgpu_group_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "ellgpu_group_size": (ctypes.c_int, [ctypes.c_void_p]),
     "ellgpu_ctx_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "ellgpu_ctx_defer": (ctypes.c_int, [ctypes.c_void_p]),
+    "ellgpu_ctx_collect": (ctypes.c_int, [ctypes.c_void_p]),
     "ellgpu_curve_define_short": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
                                                  ctypes.POINTER(ctypes.c_int)]),
     "ellgpu_curve_define_edwards": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
@@ -78,6 +80,11 @@ _SIGS = {
 # every symbol include/ellgpu.h declares (tests check the .so exports them all)
 SYMBOLS = sorted(_SIGS)
 
+# ELLGPU_VERSION of the include/ellgpu.h this table was written against: load() refuses any other
+# library (a prototype changed -- e.g. ellgpu_ecdsa_verify's out_status -- and a stale table would
+# pass garbage for the added arguments)
+ABI_VERSION = 0x000200
+
 
 class EllgpuError(RuntimeError):
     def __init__(self, code, msg):
@@ -92,6 +99,11 @@ def load(path=None, optional=()):
             "libellgpu.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
     lib = ctypes.CDLL(path)
+    lib.ellgpu_version.restype = ctypes.c_int
+    got = lib.ellgpu_version()
+    if got != ABI_VERSION:
+        raise ImportError("%s reports ABI version 0x%06x, this binding was written for 0x%06x (include/ellgpu.h "
+                          "ELLGPU_VERSION): rebuild the library from this tree" % (path, got, ABI_VERSION))
     for name, (res, args) in _SIGS.items():
         try:
             fn = getattr(lib, name)

@@ -294,6 +294,7 @@ extern "C" int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iter
 // "<name> <launches> <total_ms>\n".  Returns the number of bytes written.
 extern "C" int ellgpu_ctx_set_timing(ellgpu_ctx* ctx, int on) {
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  ELL_LOCK(ctx);                                   // launch() appends to bk.timed under the same lock
   ell::HipBackend& bk = ctx->eng->bk;
   for (auto& t : *bk.timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   bk.timed->clear();
@@ -302,6 +303,7 @@ extern "C" int ellgpu_ctx_set_timing(ellgpu_ctx* ctx, int on) {
 }
 extern "C" int ellgpu_ctx_get_timing(ellgpu_ctx* ctx, char* buf, size_t cap) {
   if (!ctx || !buf || !cap) return set_err(ELLGPU_E_ARG, "bad arguments");
+  ELL_LOCK(ctx);
   ell::HipBackend& bk = ctx->eng->bk;
   (void)hipDeviceSynchronize();
   std::map<std::string, std::pair<int, double>> acc;

@@ -34,9 +34,19 @@ struct ellgpu_ctx {
   ell::Engine<ELL_BACKEND>* eng;
   std::vector<ellgpu_ctx*> members;
   std::recursive_mutex mu;
+  int deferred_rc = 0;             // status of a deferred call that something else completed
+  std::string deferred_msg;
 };
 
-#define ELL_LOCK(ctx) std::lock_guard<std::recursive_mutex> ell_ctx_lock_((ctx)->mu)
+// (entering a context also completes a call that ellgpu_ctx_defer left in flight: its results sit
+// in the context's one pinned buffer, which the next small call would overwrite)
+static void ell_complete_deferred(ellgpu_ctx* ctx) {
+  if (!ctx->members.empty() || !ctx->eng || !ctx->eng->defer_pending()) return;
+  const int rc = ctx->eng->defer_collect();
+  if (rc && !ctx->deferred_rc) { ctx->deferred_rc = rc; ctx->deferred_msg = ctx->eng->err; }
+  ctx->eng->bk.end_call(false);
+}
+#define ELL_LOCK(ctx) std::lock_guard<std::recursive_mutex> ell_ctx_lock_((ctx)->mu); ell_complete_deferred(ctx)
 
 static thread_local std::string g_last_error;
 
@@ -162,7 +172,23 @@ int ellgpu_ctx_synchronize(ellgpu_ctx* ctx) {
 }
 void* ellgpu_ctx_stream(ellgpu_ctx* ctx) {
   if (!ctx) return nullptr;
+  ELL_LOCK(ctx);
   return ctx->eng->bk.own_stream();
+}
+int ellgpu_ctx_defer(ellgpu_ctx* ctx) {
+  if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  ELL_LOCK(ctx);
+  if (ctx->members.empty()) ctx->eng->defer_arm();          // (a group's calls are never deferred)
+  return ELLGPU_OK;
+}
+int ellgpu_ctx_collect(ellgpu_ctx* ctx) {
+  if (!ctx) return set_err(ELLGPU_E_ARG, "null context");
+  ELL_LOCK(ctx);                                             // completes the pending call, if any
+  if (ctx->members.empty()) ctx->eng->defer_collect();       // disarms
+  const int rc = ctx->deferred_rc;
+  ctx->deferred_rc = 0;
+  if (rc) return set_err(rc, ctx->deferred_msg.empty() ? "device error in a deferred call" : ctx->deferred_msg);
+  return ELLGPU_OK;
 }
 int ellgpu_ctx_reserve(ellgpu_ctx* ctx, int curve, size_t n) {
   if (!ctx) return set_err(ELLGPU_E_ARG, "null context");

@@ -1630,6 +1630,22 @@ class Engine {
         if (off[i] > off[i + 1]) return fail(E_ARG, "message offsets must be non-decreasing");
     size_t total = off ? (size_t)off[n] : n * msg_len;
     if (total && !msgs) return fail(E_ARG, "null message pointer");
+    if (n && n <= bk.pipeline_quantum()) {
+      // a few items: through the pinned buffer, one synchronisation (or none: ellgpu_ctx_defer)
+      u8* dm = out_buf(G_IN0, total);
+      u64* doff = off ? (u64*)out_buf(G_IN1, (n + 1) * sizeof(u64)) : nullptr;
+      u8* dsg = out_buf(G_IN2, n * 64);
+      u8* dpk = out_buf(G_IN3, n * 32);
+      u8* dok = out_buf(G_OUT0, n);
+      u8* derr = out_buf(G_OUT1, n);
+      if (!dm || !dsg || !dpk || !dok || !derr || (off && !doff)) return fail(E_NOMEM, "staging allocation failed");
+      SpanIn si[4] = {{dm, msgs ? msgs : (const u8*)"", total}, {(u8*)doff, (const u8*)off, off ? (n + 1) * sizeof(u64) : 0},
+                      {dsg, sigs, n * 64}, {dpk, pubs, n * 32}};
+      SpanOut so[2] = {{ok, dok, n}, {err, derr, n}};
+      int rc = E_OK;
+      if (small_call(si, 4, so, 2, [&]() { return eddsa_verify_dev(n, dm, doff, msg_len, dsg, dpk, dok, derr); }, &rc)) return rc;
+    }
+    defer_.armed = false;
     u8* dm = put(G_IN0, msgs ? msgs : (const u8*)"", total);
     u64* doff = off ? (u64*)put(G_IN1, off, (n + 1) * sizeof(u64)) : nullptr;
     u8* dsg = put(G_IN2, sigs, n * 64);
@@ -1667,6 +1683,20 @@ class Engine {
         if (off[i] > off[i + 1]) return fail(E_ARG, "message offsets must be non-decreasing");
     size_t total = off ? (size_t)off[n] : n * msg_len;
     if (total && !msgs) return fail(E_ARG, "null message pointer");
+    if (n && n <= bk.pipeline_quantum()) {
+      u8* dm = out_buf(G_IN0, total);
+      u64* doff = off ? (u64*)out_buf(G_IN1, (n + 1) * sizeof(u64)) : nullptr;
+      u8* dsec = out_buf(G_IN2, n * 32);
+      u8* dsig = out_buf(G_OUT0, n * 64);
+      u8* dpub = out_buf(G_OUT1, n * 32);
+      if (!dm || !dsec || !dsig || !dpub || (off && !doff)) return fail(E_NOMEM, "staging allocation failed");
+      SpanIn si[3] = {{dm, msgs ? msgs : (const u8*)"", total}, {(u8*)doff, (const u8*)off, off ? (n + 1) * sizeof(u64) : 0},
+                      {dsec, secrets, n * 32}};
+      SpanOut so[2] = {{sig, dsig, n * 64}, {pub, dpub, n * 32}};
+      int rc = E_OK;
+      if (small_call(si, 3, so, 2, [&]() { return eddsa_sign_dev(n, dsec, dm, doff, msg_len, dsig, dpub); }, &rc)) return rc;
+    }
+    defer_.armed = false;
     u8* dm = put(G_IN0, msgs ? msgs : (const u8*)"", total);
     u64* doff = off ? (u64*)put(G_IN1, off, (n + 1) * sizeof(u64)) : nullptr;
     u8* dsec = put(G_IN2, secrets, n * 32);
@@ -2035,40 +2065,95 @@ class Engine {
   // stream, with one synchronisation (no copy streams, no events, no pageable-memory copies that
   // each block the host: 60 -> ~25 us of overhead per call).
   static constexpr size_t SMALL_HOST_BYTES = 256 * 1024;
+  // The SPLIT form of such a call (ellgpu_ctx_defer / ellgpu_ctx_collect): an armed context's next
+  // small call returns as soon as its copies and kernels are enqueued; the synchronisation and the
+  // copy into the caller's result buffers happen in defer_collect().  The host thread is free in
+  // between -- the JavaScript layer re-validates what it took on trust (the reference's
+  // precomputed tables, elliptic_amd/js/index.js) while the device works.  Anything else that
+  // enters the context first completes the pending call (capi_common.h ELL_LOCK).
+  struct Deferred {
+    bool armed = false, on = false;
+    struct Out { u8* host; size_t bytes; } outs[4];
+    int nout = 0;
+    size_t out0 = 0;
+    u8* pin = nullptr;
+  } defer_;
+  void defer_arm() { defer_.armed = true; }
+  bool defer_pending() const { return defer_.on; }
+  static size_t pad64(size_t b) { return (b + 63) & ~(size_t)63; }
+  int defer_collect() {
+    defer_.armed = false;
+    if (!defer_.on) return E_OK;
+    defer_.on = false;
+    bk.select_lane(0);
+    const int rs = bk.sync();
+    size_t off = defer_.out0;
+    for (int i = 0; i < defer_.nout; i++)
+      if (defer_.outs[i].host) {
+        if (!rs) memcpy(defer_.outs[i].host, defer_.pin + off, defer_.outs[i].bytes);
+        off += pad64(defer_.outs[i].bytes);
+      }
+    if (rs) fail(rs, "device error in a deferred call");
+    return rs;
+  }
+  // the few-item call itself: operands (host -> pinned -> device), body, results (device -> pinned
+  // [-> host, now or in defer_collect]).  Returns false when the call does not fit the pinned buffer.
+  struct SpanIn { u8* dev; const u8* host; size_t bytes; };
+  struct SpanOut { u8* host; const u8* dev; size_t bytes; };
+  template <class Body>
+  bool small_call(const SpanIn* ins, int nin, const SpanOut* outs, int nout, Body body, int* result) {
+    const bool defer = defer_.armed;
+    size_t tot = 0;
+    for (int i = 0; i < nin; i++) if (ins[i].host) tot += pad64(ins[i].bytes);
+    for (int i = 0; i < nout; i++) if (outs[i].host) tot += pad64(outs[i].bytes);
+    u8* pin = tot <= SMALL_HOST_BYTES ? (u8*)bk.pinned(SMALL_HOST_BYTES) : nullptr;
+    if (!pin) return false;
+    defer_.armed = false;
+    size_t off = 0;
+    for (int i = 0; i < nin; i++)
+      if (ins[i].host) {
+        memcpy(pin + off, ins[i].host, ins[i].bytes);
+        if (ins[i].bytes) bk.h2d(ins[i].dev, pin + off, ins[i].bytes);
+        off += pad64(ins[i].bytes);
+      }
+    lane_ = 0;
+    const int rc = body();
+    const size_t out0 = off;
+    for (int i = 0; i < nout; i++)
+      if (outs[i].host) {
+        if (outs[i].bytes) bk.d2h(pin + off, outs[i].dev, outs[i].bytes);
+        off += pad64(outs[i].bytes);
+      }
+    if (defer && !rc && nout <= 4 && !custom_active_) {
+      defer_.on = true;
+      defer_.nout = nout;
+      for (int i = 0; i < nout; i++) defer_.outs[i] = {outs[i].host, outs[i].bytes};
+      defer_.out0 = out0;
+      defer_.pin = pin;
+      *result = E_OK;
+      return true;
+    }
+    const int rs = bk.sync();
+    off = out0;
+    for (int i = 0; i < nout; i++)
+      if (outs[i].host) {
+        if (!rc && !rs) memcpy(outs[i].host, pin + off, outs[i].bytes);
+        off += pad64(outs[i].bytes);
+      }
+    *result = rc ? rc : rs;
+    return true;
+  }
   template <class Body>
   int pipelined(size_t n, const HostIn* ins, int nin, const HostOut* outs, int nout, Body body) {
-    {
-      auto pad = [](size_t b) { return (b + 63) & ~(size_t)63; };
-      size_t tot = 0;
-      for (int i = 0; i < nin; i++) if (ins[i].host) tot += pad(n * ins[i].stride);
-      for (int i = 0; i < nout; i++) if (outs[i].host) tot += pad(n * outs[i].stride);
-      u8* pin = (n && tot <= SMALL_HOST_BYTES && n <= bk.pipeline_quantum()) ? (u8*)bk.pinned(SMALL_HOST_BYTES) : nullptr;
-      if (pin) {
-        size_t off = 0;
-        for (int i = 0; i < nin; i++)
-          if (ins[i].host) {
-            memcpy(pin + off, ins[i].host, n * ins[i].stride);
-            bk.h2d(ins[i].dev, pin + off, n * ins[i].stride);
-            off += pad(n * ins[i].stride);
-          }
-        lane_ = 0;
-        int rc = body(0, n);
-        const size_t out0 = off;
-        for (int i = 0; i < nout; i++)
-          if (outs[i].host) {
-            bk.d2h(pin + off, outs[i].dev, n * outs[i].stride);
-            off += pad(n * outs[i].stride);
-          }
-        int rs = bk.sync();
-        off = out0;
-        for (int i = 0; i < nout; i++)
-          if (outs[i].host) {
-            if (!rc && !rs) memcpy(outs[i].host, pin + off, n * outs[i].stride);
-            off += pad(n * outs[i].stride);
-          }
-        return rc ? rc : rs;
-      }
+    if (n && n <= bk.pipeline_quantum() && nin <= 4 && nout <= 4) {
+      SpanIn si[4];
+      SpanOut so[4];
+      for (int i = 0; i < nin; i++) si[i] = {ins[i].dev, ins[i].host, n * ins[i].stride};
+      for (int i = 0; i < nout; i++) so[i] = {outs[i].host, outs[i].dev, n * outs[i].stride};
+      int rc = E_OK;
+      if (small_call(si, nin, so, nout, [&]() { return body(0, n); }, &rc)) return rc;
     }
+    defer_.armed = false;
     size_t q = bk.pipeline_quantum(), step = q;
     size_t o = 0, po = 0, pm = 0;
     int pev = -1, rc = E_OK;

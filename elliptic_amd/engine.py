@@ -135,6 +135,15 @@ class Context:
             raise _lib.EllgpuError(rc, self._lib.ellgpu_last_error().decode())
         return rc
 
+    def defer(self):
+        """the next few-item host-buffer call on this context returns once its work is enqueued;
+        its result arrays are filled by collect() (ellgpu_ctx_defer / ellgpu_ctx_collect: the
+        split form behind install()'s table re-validation).  Keep the result arrays alive."""
+        self._check(self._lib.ellgpu_ctx_defer(self._ctx))
+
+    def collect(self):
+        self._check(self._lib.ellgpu_ctx_collect(self._ctx))
+
     # ---- host buffers -------------------------------------------------------
 
     def mul_fixed(self, curve, k, out=None):

@@ -12,6 +12,11 @@
  * Exports:  open(path) -> true
  *           createContext(device) -> external
  *           destroyContext(ctx)
+ *           combBits(ctx, curve) -> width of the fixed-base table in use (ellgpu_ctx_comb_bits)
+ *           defer(ctx): the next few-item call on ctx returns once it is enqueued (ellgpu_ctx_defer);
+ *           collect(ctx): waits for it and fills the result Buffers that call returned
+ *             (ellgpu_ctx_collect; throws the library's error) -- index.js validates the
+ *             reference's precomputed tables in between, while the device works
  *           curveId(name), fieldBytes(id), orderBytes(id), deviceCount(), defineShort(ctx, p, a, b), defineEdwards(ctx, p, a, d)
  *           mulFixed(ctx, curve, k) -> {xy, inf}
  *           mulVar(ctx, curve, k, xy) -> {xy, inf}
@@ -54,8 +59,15 @@
 #include <sys/mman.h>
 
 typedef struct ellgpu_ctx ellgpu_ctx;
+/* ELLGPU_VERSION of the include/ellgpu.h this file was written against: open() refuses a library
+ * that reports another one (a prototype changed; dlsym would still find the name) */
+#define ELLGPU_ABI_VERSION 0x000200
 static struct {
   void* h;
+  int (*version)(void);
+  int (*ctx_defer)(ellgpu_ctx*);
+  int (*ctx_comb_bits)(ellgpu_ctx*, int);
+  int (*ctx_collect)(ellgpu_ctx*);
   const char* (*last_error)(void);
   int (*curve_id)(const char*);
   int (*field_bytes)(int);
@@ -120,6 +132,15 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   if (!h) { char msg[4400]; snprintf(msg, sizeof msg, "ellgpu: cannot load %s: %s", path, dlerror()); THROW(env, msg); }
 #define SYM(field, name) do { *(void**)(&L.field) = dlsym(h, name); if (!L.field) { char m_[256]; \
     snprintf(m_, sizeof m_, "ellgpu: %s missing from library", name); dlclose(h); THROW(env, m_); } } while (0)
+  SYM(version, "ellgpu_version");
+  if (L.version() != ELLGPU_ABI_VERSION) {
+    char m_[256];
+    snprintf(m_, sizeof m_, "ellgpu: library reports ABI version 0x%06x, this addon was built for 0x%06x (include/ellgpu.h)",
+             L.version(), ELLGPU_ABI_VERSION);
+    dlclose(h); THROW(env, m_);
+  }
+  SYM(ctx_defer, "ellgpu_ctx_defer"); SYM(ctx_collect, "ellgpu_ctx_collect");
+  SYM(ctx_comb_bits, "ellgpu_ctx_comb_bits");
   SYM(last_error, "ellgpu_last_error"); SYM(curve_id, "ellgpu_curve_id");
   SYM(field_bytes, "ellgpu_curve_field_bytes"); SYM(order_bytes, "ellgpu_curve_order_bytes");
   SYM(device_count, "ellgpu_device_count"); SYM(ctx_create, "ellgpu_ctx_create");
@@ -293,6 +314,31 @@ static napi_value fn_define_edwards(napi_env e, napi_callback_info i) { return d
 static napi_value fn_destroy(napi_env env, napi_callback_info info) {
   /* contexts are released by the GC finalizer; explicit destroy is a no-op hook */
   (void)info; napi_value u; napi_get_undefined(env, &u); return u;
+}
+
+/* defer(ctx) / collect(ctx): the split form of a few-item call (ellgpu_ctx_defer / _collect) */
+static napi_value defer_common(napi_env env, napi_callback_info info, int collect) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 1; napi_value argv[1];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  if ((collect ? L.ctx_collect : L.ctx_defer)(c) != 0) return lib_error(env);
+  napi_value u; napi_get_undefined(env, &u); return u;
+}
+static napi_value fn_defer(napi_env e, napi_callback_info i) { return defer_common(e, i, 0); }
+static napi_value fn_collect(napi_env e, napi_callback_info i) { return defer_common(e, i, 1); }
+
+/* combBits(ctx, curve) -> window width of the curve's fixed-base table on this context (0: not
+ * built yet; narrower than the default when the device could not hold it: ellgpu_ctx_comb_bits) */
+static napi_value fn_comb_bits(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 2; napi_value argv[2]; int32_t curve = 0;
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  if (argc < 2 || napi_get_value_int32(env, argv[1], &curve) != napi_ok) THROW(env, "combBits(ctx, curve)");
+  int v = L.ctx_comb_bits(c, curve);
+  if (v < 0) return lib_error(env);
+  napi_value r; CHECK(env, napi_create_int32(env, v, &r)); return r;
 }
 
 /* mulFixed / mulVar / mulAdd2 share the output shape */
@@ -846,6 +892,7 @@ static napi_value fn_call_async(napi_env env, napi_callback_info info) {
 static napi_value init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
     {"open", fn_open}, {"createContext", fn_create}, {"destroyContext", fn_destroy},
+    {"defer", fn_defer}, {"collect", fn_collect}, {"combBits", fn_comb_bits},
     {"curveId", fn_curve_id}, {"fieldBytes", fn_field_bytes}, {"orderBytes", fn_order_bytes},
     {"deviceCount", fn_device_count}, {"groupSize", fn_group_size}, {"defineShort", fn_define_short}, {"defineEdwards", fn_define_edwards}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
     {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519},

@@ -53,6 +53,13 @@ Engine.prototype._id = function _id(curve) {
   return id;
 };
 
+// Window width of the curve's fixed-base table on this engine's (first) device: 0 before the first
+// k*G, 22 on the 256-bit curves by default, 16 / 12 / 8 / 4 when the device could not hold that
+// table (up to ~5x more additions per k*G: a crowded device shows up here, not only in the timings)
+Engine.prototype.combBits = function combBits(curve) {
+  return this.addon.combBits(this.ctx, this._id(curve));
+};
+
 // Register y^2 = x^3 + a x + b over an odd prime p < 2^256 that is none of the presets
 // (`new elliptic.curve.short({p, a, b})`, lib/elliptic/curve/short.js:11-24) and return its curve
 // id: usable with mulBatch (points given), mulAddBatch (both points given) and pointAddBatch, with
@@ -350,8 +357,95 @@ function install(elliptic, options) {
     for (var i = 0; i < a.length; i++) if (a[i].cmp(b[i]) !== 0) return false;
     return true;
   }
+  function hide(o, k, v) {
+    try { Object.defineProperty(o, k, { value: v, enumerable: false, writable: true, configurable: true }); }
+    catch (e) { /* a frozen object: checked again next time */ }
+  }
+  // ---- witnesses: what a remembered verdict stands on ---------------------------------------------
+  // install() remembers what it has established about the caller's objects -- "this curve object is
+  // the preset", "these are the curve's GLV constants", "this table holds its point's multiples" --
+  // because establishing it costs up to tens of milliseconds.  But the objects stay the caller's, and
+  // the reference reads them afresh on every call: a table entry replaced in place, an entry's
+  // coordinate edited, `curve.n` or a basis vector changed after the first call change the
+  // reference's answer and must change the patched library's.  A remembered verdict therefore carries
+  // a WITNESS -- a flat copy of every number it depended on -- and is used only while the live objects
+  // still hold exactly those numbers (an exact comparison, not a hash); otherwise the check is made
+  // again.  Re-reading a secp256k1 G's 388 table entries costs ~10 us of host time; the one-item calls
+  // hide it behind the device's work (`guarded`, below).  What is NOT re-read is stated in
+  // INTEGRATION.md section 2 ("what install() treats as immutable").
+  // a BN as [negative, length, words...]; anything that is no BN as a marker no BN compares equal to
+  function snapBN(v, b) {
+    if (!b || typeof b !== 'object' || !Array.isArray(b.words) || !(b.length >= 0 && b.length <= b.words.length)) { v.push(-2); return; }
+    v.push(b.negative | 0, b.length);
+    for (var i = 0; i < b.length; i++) v.push(b.words[i] | 0);
+  }
+  // -> position behind the BN in the snapshot, or -1: another value, or not in reduction context `red`
+  function sameBN(s, pos, b, red) {
+    if (s[pos] === -2) return b === undefined || b === null ? pos + 1 : -1;
+    if (!b || b.red !== red || b.negative !== s[pos]) return -1;
+    var l = b.length, w = b.words;
+    if (s[pos + 1] !== l || !w) return -1;
+    pos += 2;
+    for (var j = 0; j < l; j++) if (w[j] !== s[pos + j]) return -1;
+    return pos + l;
+  }
+  // a table entry / an operand with the fields the reference's formulas read (short.js:365-412,
+  // 569-603: x, y, inf; edwards.js:174-348: x, y, z, t, zOne)
+  function snapEntry(curve, v, e) {
+    if (!e || typeof e !== 'object') { v.push(-3); return; }
+    if (curve.type === 'short') { snapBN(v, e.x); snapBN(v, e.y); return; }
+    v.push(e.zOne ? 1 : 0);
+    snapBN(v, e.x); snapBN(v, e.y); snapBN(v, e.z);
+    if (curve.extended) snapBN(v, e.t);
+  }
+  function sameEntry(curve, s, pos, e) {
+    if (s[pos] === -3) return e === undefined || e === null ? pos + 1 : -1;
+    if (!e || e.curve !== curve) return -1;
+    var red = curve.red;
+    if (curve.type === 'short') {
+      if (e.inf !== false || e.type !== 'affine') return -1;
+      pos = sameBN(s, pos, e.x, red);
+      return pos < 0 ? -1 : sameBN(s, pos, e.y, red);
+    }
+    if (s[pos] !== (e.zOne ? 1 : 0)) return -1;
+    pos = sameBN(s, pos + 1, e.x, red);
+    if (pos >= 0) pos = sameBN(s, pos, e.y, red);
+    if (pos >= 0) pos = sameBN(s, pos, e.z, red);
+    if (pos >= 0 && curve.extended) pos = sameBN(s, pos, e.t, red);
+    return pos;
+  }
+  // the numbers a curve object is recognised by: p, its coefficients, n and the generator
+  function coeffs(curve) {
+    return curve.type === 'edwards' ? [curve.a, curve.d, curve.c] : [curve.a, curve.b];
+  }
+  function snapCurve(curve, withGen) {
+    var v = [];
+    snapBN(v, curve.p);
+    coeffs(curve).forEach(function(c) { snapBN(v, c); });
+    if (withGen) {
+      snapBN(v, curve.n);
+      var g = curve.g;
+      if (!g || typeof g !== 'object') v.push(-3);
+      else if (curve.type === 'mont') { snapBN(v, g.x); snapBN(v, g.z); }
+      else snapEntry(curve, v, g);
+    }
+    return Int32Array.from(v);
+  }
+  function sameCurve(curve, s, withGen) {
+    var red = curve.red, pos = sameBN(s, 0, curve.p, null), cs = coeffs(curve);
+    for (var i = 0; pos >= 0 && i < cs.length; i++) pos = sameBN(s, pos, cs[i], red);
+    if (pos >= 0 && withGen) {
+      pos = sameBN(s, pos, curve.n, null);
+      var g = curve.g;
+      if (pos >= 0 && !g) pos = -1;
+      else if (pos >= 0 && curve.type === 'mont') { pos = sameBN(s, pos, g.x, red); if (pos >= 0) pos = sameBN(s, pos, g.z, red); }
+      else if (pos >= 0) pos = sameEntry(curve, s, pos, g);
+    }
+    return pos === s.length;
+  }
   function domain(curve) {
-    if (curve._ellgpu !== undefined) return curve._ellgpu;
+    var c = curve._ellgpu;
+    if (c !== undefined && c.red === curve.red && sameCurve(curve, c.snap, true)) return c.d;
     var d = presets[curve.type + ':' + curve.p.toString(16)] || null;
     // (methods of a curve under construction -- ShortCurve#_getEndomorphism multiplies g before
     // the constructor returns -- see every field this test reads: p, n, g, a, b are set first)
@@ -368,17 +462,20 @@ function install(elliptic, options) {
         d = null;
     }
     if (d && !sameGenerator(curve, elliptic.curves[d.name].curve)) d = null;
-    Object.defineProperty(curve, '_ellgpu', { value: d, enumerable: false,
-      writable: true });
+    var snap = null;
+    try { snap = snapCurve(curve, true); } catch (e) { snap = null; }
+    if (snap) hide(curve, '_ellgpu', { d: d, red: curve.red, snap: snap });
     return d;
   }
   // A short curve that is no preset still gets its Point#mul / mulAdd / jmulAdd from the device:
   // run-time prime (<= 256 bits), arbitrary a (the generic `_dbl` / `dblp` of short.js:802-830,
   // 605-654), no fixed-base table.  options.customCurves === false keeps such curves on the
   // reference's own code, as do primes wider than 256 bits and a seventeenth distinct curve.
-  // Miller-Rabin to twelve prime bases: the device inverts by Fermat's a^(p-2), which equals the
-  // reference's extended-Euclid BN#invm only for a prime modulus -- a composite `p` (which the
-  // reference accepts) stays on the reference's own code
+  // Miller-Rabin to twelve prime bases and eight RANDOM ones (composites that pass any fixed set of
+  // bases can be constructed -- Arnault 1995 -- but not ones that pass bases drawn after the number
+  // was chosen: error < 4^-8 per call, for adversarial input only): the device inverts by Fermat's
+  // a^(p-2), which equals the reference's extended-Euclid BN#invm only for a prime modulus -- a
+  // composite `p` (which the reference accepts) stays on the reference's own code
   function probablyPrime(p) {
     var small = [2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37];
     for (var i = 0; i < small.length; i++) {
@@ -392,8 +489,16 @@ function install(elliptic, options) {
     while (dd.isEven()) { dd = dd.shrn(1); s++; }
     var one = new BN(1).toRed(red);
     var m1 = pm1.toRed(red);
-    for (i = 0; i < small.length; i++) {
-      var x = new BN(small[i]).toRed(red).redPow(dd);
+    var bases = small.map(function(b) { return new BN(b); });
+    if (p.bitLength() > 48) {
+      var rb = require('crypto').randomBytes(8 * p.byteLength());
+      for (i = 0; i < 8; i++) {
+        var a = new BN(rb.slice(i * p.byteLength(), (i + 1) * p.byteLength())).umod(p.subn(3)).iaddn(2);   // [2, p - 2]
+        bases.push(a);
+      }
+    }
+    for (i = 0; i < bases.length; i++) {
+      var x = bases[i].toRed(red).redPow(dd);
       if (x.cmp(one) === 0 || x.cmp(m1) === 0) continue;
       var composite = true;
       for (var r = 1; r < s; r++) {
@@ -405,15 +510,18 @@ function install(elliptic, options) {
     return true;
   }
   function customDomain(curve) {
-    if (curve._ellgpuCustom !== undefined) return curve._ellgpuCustom;
+    var cc = curve._ellgpuCustom;
+    if (cc !== undefined && cc.red === curve.red && sameCurve(curve, cc.snap, false)) return cc.d;
     var d = null;
     if (options && options.customCurves === false) return null;
-    if (curve.p && curve.p.bitLength() <= 256 && curve.p.isOdd() && curve.p.cmpn(3) > 0 &&
-        !probablyPrime(curve.p)) {
-      Object.defineProperty(curve, '_ellgpuCustom', { value: null, enumerable: false,
-        writable: true });
-      return null;
+    function remember(v) {
+      var snap = null;
+      try { snap = snapCurve(curve, false); } catch (e) { snap = null; }
+      if (snap) hide(curve, '_ellgpuCustom', { d: v, red: curve.red, snap: snap });
+      return v;
     }
+    if (curve.p && curve.p.bitLength() <= 256 && curve.p.isOdd() && curve.p.cmpn(3) > 0 &&
+        !probablyPrime(curve.p)) return remember(null);
     // A singular cubic (4 a^3 + 27 b^2 = 0) has no group law at its singular point, and an Edwards
     // curve whose addition law is not complete (complete: a a square, d not -- Bernstein et al.,
     // "Twisted Edwards curves", section 6) has pairs of points on which the projective formulas give
@@ -440,9 +548,7 @@ function install(elliptic, options) {
           id: eng.defineEdwards(curve.p, curve.a.fromRed(), curve.d.fromRed()) };
       } catch (e) { d = null; }
     }
-    Object.defineProperty(curve, '_ellgpuCustom', { value: d, enumerable: false,
-      writable: true });
-    return d;
+    return remember(d);
   }
   function scalarBuf(k, B) {
     if (!BN.isBN(k) || k.isNeg() || k.byteLength() > B) return null;
@@ -492,10 +598,6 @@ function install(elliptic, options) {
   // multiples: each table is checked once (the reference's Jacobian / projective dbl() and add(), a
   // few milliseconds per curve -- 6 for secp256k1, 65 for p521 --), and the verdict
   // is remembered on the table object; anything else is left to the reference's own ladders.
-  function hide(o, k, v) {
-    try { Object.defineProperty(o, k, { value: v, enumerable: false, writable: true, configurable: true }); }
-    catch (e) { /* a frozen object: checked again next time */ }
-  }
   function canonical(curve, v) { return !!v && v.red === curve.red && !v.isNeg() && v.cmp(curve.p) < 0; }
   function entryOK(curve, e) {
     if (!e || e.curve !== curve || !canonical(curve, e.x) || !canonical(curve, e.y)) return false;
@@ -515,7 +617,7 @@ function install(elliptic, options) {
   }
   function checkTable(curve, p, tbl, kind) {
     var pts = tbl.points, w = kind === 'naf' ? tbl.wnd : tbl.step;
-    if (!Array.isArray(pts) || !Number.isInteger(w) || w < 1 || w > 12 || !entryOK(curve, p)) return false;
+    if (!Array.isArray(pts) || pts.length > 4096 || !Number.isInteger(w) || w < 1 || w > 12 || !entryOK(curve, p)) return false;
     var i, q = curve.type === 'short' ? p.toJ() : p;
     if (!samePoint(curve, pts[0], q)) return false;
     if (kind === 'naf') {
@@ -536,15 +638,34 @@ function install(elliptic, options) {
     }
     return true;
   }
+  // the table's witness: the point itself and every entry of `points` (all of them: _getBeta and
+  // neg(true), short.js:282-310, 437-462, map the whole array)
+  function snapTable(curve, p, pts) {
+    var v = [];
+    snapEntry(curve, v, p);
+    for (var i = 0; i < pts.length; i++) snapEntry(curve, v, pts[i]);
+    return Int32Array.from(v);
+  }
+  function sameTable(curve, p, pts, c) {
+    if (pts.length !== c.len) return false;
+    var s = c.snap, pos = sameEntry(curve, s, 0, p);
+    for (var i = 0, n = c.len; pos >= 0 && i < n; i++) pos = sameEntry(curve, s, pos, pts[i]);
+    return pos === s.length;
+  }
   function tableOK(curve, p, tbl, kind) {
     if (!tbl) return true;
     var c = tbl._ellgpuOK;
     var w = kind === 'naf' ? tbl.wnd : tbl.step;
-    if (c && c.p === p && c.pts === tbl.points && c.len === (tbl.points && tbl.points.length) && c.w === w) return c.ok;
+    if (c && c.p === p && c.pts === tbl.points && c.w === w && sameTable(curve, p, c.pts, c)) return c.ok;
     var ok = false;
     refOnly++;
     try { ok = typeof tbl === 'object' && checkTable(curve, p, tbl, kind); } catch (e) { ok = false; } finally { refOnly--; }
-    hide(tbl, '_ellgpuOK', { p: p, pts: tbl.points, len: tbl.points && tbl.points.length, w: w, ok: ok });
+    // (a table that is not even an array of a sane length is looked at again next time: that is cheap)
+    if (typeof tbl === 'object' && Array.isArray(tbl.points) && tbl.points.length <= 4096) {
+      var snap = null;
+      try { snap = snapTable(curve, p, tbl.points); } catch (e) { snap = null; }
+      if (snap) hide(tbl, '_ellgpuOK', { p: p, pts: tbl.points, len: tbl.points.length, w: w, ok: ok, snap: snap });
+    }
     return ok;
   }
   function tablesOK(curve, p, inner) {
@@ -588,15 +709,40 @@ function install(elliptic, options) {
     var lg = orig.wnafMul.call(curve, g0, e.lambda.umod(n));
     return !lg.isInfinity() && lg.x.cmp(g.x.redMul(e.beta)) === 0 && lg.y.cmp(g.y) === 0;
   }
+  // the witness of that verdict: beta, lambda, both basis vectors, and n and G once more (the
+  // verdict is about THIS generator and order)
+  function snapEndo(curve) {
+    var e = curve.endo, v = [];
+    snapBN(v, e.beta); snapBN(v, e.lambda);
+    for (var i = 0; i < 2; i++) { var b = Array.isArray(e.basis) ? e.basis[i] : null; snapBN(v, b && b.a); snapBN(v, b && b.b); }
+    snapBN(v, curve.n);
+    snapEntry(curve, v, curve.g);
+    return Int32Array.from(v);
+  }
+  function sameEndo(curve, s) {
+    var e = curve.endo, pos = sameBN(s, 0, e.beta, curve.red);
+    if (pos >= 0) pos = sameBN(s, pos, e.lambda, null);
+    if (pos >= 0 && (!Array.isArray(e.basis) || e.basis.length !== 2)) pos = -1;
+    for (var i = 0; pos >= 0 && i < 2; i++) {
+      var b = e.basis[i];
+      pos = b ? sameBN(s, pos, b.a, null) : -1;
+      if (pos >= 0) pos = sameBN(s, pos, b.b, null);
+    }
+    if (pos >= 0) pos = sameBN(s, pos, curve.n, null);
+    if (pos >= 0) pos = sameEntry(curve, s, pos, curve.g);
+    return pos === s.length;
+  }
   function endoOK(curve) {
     var e = curve.endo;
     if (!e) return true;
     var c = curve._ellgpuEndo;
-    if (c && c.endo === e && c.beta === e.beta && c.lambda === e.lambda && c.basis === e.basis && c.n === curve.n && c.g === curve.g) return c.ok;
+    if (c && c.red === curve.red && sameEndo(curve, c.snap)) return c.ok;
     var ok = false;
     refOnly++;
     try { ok = checkEndo(curve); } catch (x) { ok = false; } finally { refOnly--; }
-    hide(curve, '_ellgpuEndo', { endo: e, beta: e.beta, lambda: e.lambda, basis: e.basis, n: curve.n, g: curve.g, ok: ok });
+    var snap = null;
+    try { snap = snapEndo(curve); } catch (x) { snap = null; }
+    if (snap) hide(curve, '_ellgpuEndo', { red: curve.red, snap: snap, ok: ok });
     return ok;
   }
   // the engine's domain for the ladders of this curve, or null: the reference's own code
@@ -608,10 +754,45 @@ function install(elliptic, options) {
   }
   // ... and for the protocol calls, which also multiply the curve's own G (with ITS tables)
   function protocolDomain(curve) {
+    var d = protocolDomainLazy(curve);
+    return d && tablesOK(curve, curve.g) ? d : null;
+  }
+  // (the same without G's tables: the one-item calls look at those while the device works -- guarded)
+  function protocolDomainLazy(curve) {
     var d = domain(curve);
     if (!d) return null;
     if (curve.type === 'short' && curve.endo && !endoOK(curve)) return null;
-    return tablesOK(curve, curve.g) ? d : null;
+    return d;
+  }
+  // an EC / EDDSA instance multiplies ITS g and reduces by ITS n (ec/index.js:37-45, eddsa/index.js:
+  // 17-20): they are the curve's unless somebody replaced them
+  function ecOK(ec) {
+    var c = ec.curve;
+    if (ec.g !== c.g) return false;
+    if (ec.n === undefined) return true;                       // EDDSA keeps no n of its own
+    if (ec.n !== c.n || !ec.nh || ec.nh.red || ec.nh.isNeg()) return false;
+    return ec.nh.ushln(1).iaddn(1).cmp(c.n) === 0;              // nh = n >> 1, n odd
+  }
+  // ---- the one-item calls: validate the tables WHILE the device computes ------------------------
+  // call() is ONE engine call of a few items.  When any of `pts` carries precomputed tables, the
+  // call is issued in its split form (ellgpu_ctx_defer: it returns once its work is enqueued), the
+  // tables are compared with their witnesses (or checked from scratch the first time) while the
+  // device works, and ellgpu_ctx_collect fetches the result -- which is DISCARDED (null: the caller
+  // runs the reference's own method) when a table is not its point's multiples.
+  var canDefer = typeof addon.defer === 'function' && typeof addon.collect === 'function' && !eng.devices;
+  function guarded(curve, pts, call) {
+    var any = false;
+    for (var i = 0; i < pts.length; i++) if (pts[i] && pts[i].precomputed) any = true;
+    if (!any) return call();
+    function ok() {
+      for (var j = 0; j < pts.length; j++) if (pts[j] && pts[j].precomputed && !tablesOK(curve, pts[j])) return false;
+      return true;
+    }
+    if (!canDefer) return ok() ? call() : null;
+    var r = null, good = false;
+    addon.defer(eng.ctx);
+    try { r = call(); good = ok(); } finally { addon.collect(eng.ctx); }
+    return good ? r : null;
   }
   // an operand as the engine takes it, or null where the reference must compute by itself
   function operandBuf(curve, p, B) {
@@ -653,9 +834,11 @@ function install(elliptic, options) {
   function mul1(curve, p, k, origFn, origArgs) {
     var d = ladderDomain(curve);
     var kb = d && scalarBuf(k, d.B);
-    var pb = kb && operandBuf(curve, p, d.B);
-    if (!d || !kb || !pb) { eng.stats.passthrough++; return origFn.apply(curve, origArgs); }
-    var r = isG(curve, d, p) ? eng.mulBatch(d.id, kb, null) : eng.mulBatch(d.id, kb, pb);
+    var pb = kb && affineBuf(curve, p, d.B);
+    var r = pb && guarded(curve, [p], function() {
+      return isG(curve, d, p) ? eng.mulBatch(d.id, kb, null) : eng.mulBatch(d.id, kb, pb);
+    });
+    if (!r) { eng.stats.passthrough++; return origFn.apply(curve, origArgs); }
     if (r.inf[0] === OFF_CURVE) return offCurve(curve, origFn, origArgs);
     return resultPoint(curve, d, r, false);
   }
@@ -663,10 +846,12 @@ function install(elliptic, options) {
     var d = ladderDomain(curve);
     var b1 = d && scalarBuf(k1, d.B);
     var b2 = b1 && scalarBuf(k2, d.B);
-    var q1 = b2 && operandBuf(curve, p1, d.B);
-    var q2 = q1 && operandBuf(curve, p2, d.B);
-    if (!q2) { eng.stats.passthrough++; return origFn.apply(curve, origArgs); }
-    var r = eng.mulAddBatch(d.id, b1, isG(curve, d, p1) ? null : q1, b2, q2);
+    var q1 = b2 && affineBuf(curve, p1, d.B);
+    var q2 = q1 && affineBuf(curve, p2, d.B);
+    var r = q2 && guarded(curve, [p1, p2], function() {
+      return eng.mulAddBatch(d.id, b1, isG(curve, d, p1) ? null : q1, b2, q2);
+    });
+    if (!r) { eng.stats.passthrough++; return origFn.apply(curve, origArgs); }
     if (r.inf[0] === OFF_CURVE) return offCurve(curve, origFn, origArgs);
     return resultPoint(curve, d, r, jacobian);
   }
@@ -825,10 +1010,10 @@ function install(elliptic, options) {
   ecProto.sign = function sign(msg, key, enc, options) {
     if (typeof enc === 'object') { options = enc; enc = null; }
     if (!options) options = {};
-    var d = protocolDomain(this.curve);
-    var res = null;
+    var d = protocolDomainLazy(this.curve);
+    var res = null, self = this;
     try {
-      if (!d || options.k || options.pers !== undefined || typeof msg !== 'object' || BN.isBN(msg) ||
+      if (!d || !ecOK(this) || options.k || options.pers !== undefined || typeof msg !== 'object' || BN.isBN(msg) ||
           !msg || typeof msg.length !== 'number' || msg.length === 0 || !plainMsgBits(options)) throw null;
       // new EC({ curve, hash }) may carry another DRBG hash than the preset's (ec/index.js:31)
       if (this.hash !== elliptic.curves[d.name].hash) throw null;
@@ -843,10 +1028,12 @@ function install(elliptic, options) {
       // throws 'byte array longer than desired length' when it does not fit -- p521 with a 67- or
       // 68-byte digest and an options.msgBitLength that shifts it by less than its excess
       if (this._truncateToN(msg, false, options.msgBitLength).byteLength() > NB) throw null;
-      res = eng.ecdsaSignDetBatch(d.id, { hashes: Buffer.from(msg), hashLen: msg.length,
-        msgBits: typeof options.msgBitLength === 'number' ? options.msgBitLength : 0,
-        priv: Buffer.from(priv.toArray('be', NB)), canonical: !!options.canonical });
-      if (!res.ok[0]) throw null;
+      res = guarded(this.curve, [this.curve.g], function() {
+        return eng.ecdsaSignDetBatch(d.id, { hashes: Buffer.from(msg), hashLen: msg.length,
+          msgBits: typeof options.msgBitLength === 'number' ? options.msgBitLength : 0,
+          priv: Buffer.from(priv.toArray('be', NB)), canonical: !!options.canonical });
+      });
+      if (!res || !res.ok[0]) throw null;
     } catch (e) {
       eng.stats.passthrough++;
       return orig.sign.apply(this, arguments);
@@ -867,8 +1054,8 @@ function install(elliptic, options) {
   // the original method, which throws / answers by itself.
   orig.verify = ecProto.verify;
   ecProto.verify = function verify(msg, signature, key, enc, options) {
-    var d = refOnly ? null : protocolDomain(this.curve);
-    if (!d || d.custom || this.curve.type !== 'short' || !byteMessage(msg) || !plainMsgBits(options))
+    var d = refOnly ? null : protocolDomainLazy(this.curve);
+    if (!d || d.custom || this.curve.type !== 'short' || !ecOK(this) || !byteMessage(msg) || !plainMsgBits(options))
       return orig.verify.apply(this, arguments);
     var m, ok;
     try {
@@ -876,11 +1063,14 @@ function install(elliptic, options) {
       var pub = kp.getPublic();
       if (!pub || pub.isInfinity() || pub.curve !== this.curve) throw null;
       var item = { msg: msg, signature: signature, key: kp, options: options || undefined };
-      m = marshalOne(this, d, item);
-      if (m.ref) throw null;                   // a key with tables of its own that are not its multiples
+      m = marshalOne(this, d, item, true);
+      if (m.ref) throw null;                   // a key the engine does not take (see marshalOne)
       var pk = packVerify([ m ], msg.length, msgBitsOf(item)).o;
       pk.status = Buffer.alloc(1);
-      ok = eng.ecdsaVerifyBatch(d.id, pk)[0];
+      // G's tables, and the key's if it has any: looked at while the device works
+      var res = guarded(this.curve, [this.curve.g, pub], function() { return eng.ecdsaVerifyBatch(d.id, pk); });
+      if (!res) throw null;                    // a table that is not its point's multiples
+      ok = res[0];
       if (pk.status[0] === OFF_CURVE) ok = OFF_CURVE;
     } catch (e) {
       eng.stats.passthrough++;
@@ -891,10 +1081,10 @@ function install(elliptic, options) {
   };
   orig.recoverPubKey = ecProto.recoverPubKey;
   ecProto.recoverPubKey = function recoverPubKey(msg, signature, j, enc) {
-    var d = protocolDomain(this.curve);
+    var d = protocolDomainLazy(this.curve);
     var e, r, s, NB;
     try {
-      if (!d || (3 & j) !== j) throw null;
+      if (!d || !ecOK(this) || (3 & j) !== j) throw null;
       // the reference's Signature class is not exported; {r, s} objects (which include its own
       // instances) are decoded as it does (signature.js:20-21), DER input goes to the reference
       if (!signature || signature.r === undefined || signature.s === undefined) throw null;
@@ -910,8 +1100,11 @@ function install(elliptic, options) {
       return orig.recoverPubKey.apply(this, arguments);
     }
     var hl = Math.max(e.byteLength(), 1);
-    var res = eng.ecdsaRecoverBatch(d.id, { hashes: Buffer.from(e.toArray('be', hl)), hashLen: hl,
-      r: Buffer.from(r.toArray('be', NB)), s: Buffer.from(s.toArray('be', NB)), recid: Buffer.from([j]) });
+    var res = guarded(this.curve, [this.curve.g], function() {
+      return eng.ecdsaRecoverBatch(d.id, { hashes: Buffer.from(e.toArray('be', hl)), hashLen: hl,
+        r: Buffer.from(r.toArray('be', NB)), s: Buffer.from(s.toArray('be', NB)), recid: Buffer.from([j]) });
+    });
+    if (!res) { eng.stats.passthrough++; return orig.recoverPubKey.apply(this, arguments); }
     // status 2 / 3: the reference throws, or inverts an unreduced r -- let it
     if (res.status[0] >= 2) return orig.recoverPubKey.apply(this, arguments);
     if (res.status[0] === 1) return this.curve.point(null, null);
@@ -946,11 +1139,11 @@ function install(elliptic, options) {
     return eddsa.curve.validate(P) && tablesOK(eddsa.curve, P) && sameBytes(eddsa.encodePoint(P), enc);
   }
   eddsaProto.verify = function verify(message, sig, pub) {
-    var d = protocolDomain(this.curve);
+    var d = protocolDomainLazy(this.curve);
     var utils = elliptic.utils;
     var m, sb, pb;
     try {
-      if (!d || d.name !== 'ed25519') throw null;
+      if (!d || d.name !== 'ed25519' || !ecOK(this)) throw null;
       var mm = utils.parseBytes(message);
       // (hash.js takes array elements as they are; Buffer.from would reduce them mod 256)
       if (!byteArray(mm)) throw null;
@@ -976,7 +1169,8 @@ function install(elliptic, options) {
       eng.stats.passthrough++;
       return orig.eddsaVerify.apply(this, arguments);
     }
-    var r = eng.eddsaVerifyBatch([m], sb, pb);
+    var r = guarded(this.curve, [this.curve.g], function() { return eng.eddsaVerifyBatch([m], sb, pb); });
+    if (!r) { eng.stats.passthrough++; return orig.eddsaVerify.apply(this, arguments); }
     if (r.err[0]) return orig.eddsaVerify.apply(this, arguments);      // throws as the reference does
     return r.ok[0] === 1;
   };
@@ -985,9 +1179,9 @@ function install(elliptic, options) {
   // S = r + h*a in one call; other secrets (any length is legal for the reference) pass through.
   orig.eddsaSign = eddsaProto.sign;
   eddsaProto.sign = function sign(message, secret) {
-    var d = protocolDomain(this.curve);
+    var d = protocolDomainLazy(this.curve);
     try {
-      if (!d || d.name !== 'ed25519') throw null;
+      if (!d || d.name !== 'ed25519' || !ecOK(this)) throw null;
       var mm = elliptic.utils.parseBytes(message);
       var ss = this.keyFromSecret(secret).secret();
       // (hash.js takes array elements as they are; Buffer.from would reduce them mod 256)
@@ -998,7 +1192,8 @@ function install(elliptic, options) {
       eng.stats.passthrough++;
       return orig.eddsaSign.apply(this, arguments);
     }
-    var r = eng.eddsaSignBatch([m], sec);
+    var r = guarded(this.curve, [this.curve.g], function() { return eng.eddsaSignBatch([m], sec); });
+    if (!r) { eng.stats.passthrough++; return orig.eddsaSign.apply(this, arguments); }
     return this.makeSignature(Array.prototype.slice.call(r.sig, 0, 64));
   };
 
@@ -1040,7 +1235,7 @@ function install(elliptic, options) {
   // items: [{ msg: Buffer|Array, signature, key, enc? }] -> [bool]
   // a preset whose G carries tables that are not G's multiples, or whose endomorphism constants are
   // not the curve's (protocolDomain): every item through EC#verify, whose ladders decide by themselves
-  function untrusted(ec, d) { return d && !protocolDomain(ec.curve); }
+  function untrusted(ec, d) { return d && !(protocolDomain(ec.curve) && ecOK(ec)); }
   function verifyEach(ec, items) {
     return items.map(function(it) { return ec.verify(it.msg, it.signature, it.key, it.enc, it.options); });
   }
@@ -1072,7 +1267,7 @@ function install(elliptic, options) {
     return SignatureClass;
   }
   // one (msg, signature, key) as the engine's fixed-width fields; throws what EC#verify throws
-  function marshalOne(ec, d, it) {
+  function marshalOne(ec, d, it, lazyTables) {
     var NB = ec.n.byteLength();
     var Signature = signatureClass(ec);
     var key = ec.keyFromPublic(it.key, it.enc);
@@ -1082,7 +1277,8 @@ function install(elliptic, options) {
     var bad = sig.r.isNeg() || sig.s.isNeg() || sig.r.byteLength() > NB || sig.s.byteLength() > NB;
     // (a key whose own precomputed tables are not its multiples: the reference's ladder reads
     // them -- that item is the reference's, like a key that is not on the curve)
-    var q = redSig ? null : operandBuf(ec.curve, key.getPublic(), d.B);
+    // (lazyTables: the caller looks at the key's tables itself, while the device works -- guarded)
+    var q = redSig ? null : (lazyTables ? affineBuf : operandBuf)(ec.curve, key.getPublic(), d.B);
     return { pre: !bad, h: Buffer.from(it.msg),
       r: Buffer.from((bad ? new BN(0) : sig.r).toArray('be', NB)),
       s: Buffer.from((bad ? new BN(0) : sig.s).toArray('be', NB)),
@@ -1169,7 +1365,7 @@ function install(elliptic, options) {
   }
   eng.verifyAsync = function verifyAsync(ec, msg, signature, key, enc, options) {
     if (typeof enc === 'object' && enc !== null && options === undefined) { options = enc; enc = undefined; }
-    var d = protocolDomain(ec.curve);
+    var d = ecOK(ec) ? protocolDomain(ec.curve) : null;
     if (!d || ec.curve.type !== 'short' || !byteMessage(msg) || !plainMsgBits(options)) {
       // outside the engine's batch domain: the (patched) synchronous path, as a Promise
       return new Promise(function(resolve) { resolve(ec.verify(msg, signature, key, enc, options)); });

@@ -94,7 +94,12 @@
 extern "C" {
 #endif
 
-#define ELLGPU_VERSION 0x000100
+/* ABI version: bumped whenever a prototype below changes (0x000200: ellgpu_ecdsa_verify and
+ * ellgpu_ecdsa_verify_dev gained out_status and their out_ok became a strict 0 / 1 mask;
+ * ellgpu_ctx_defer / ellgpu_ctx_collect).  Both loaders in this repo -- elliptic_amd/_lib.py and
+ * elliptic_amd/js/ellgpu_napi.c -- refuse a library whose ellgpu_version() differs from the value
+ * they were written against: a stale binding would pass garbage for the added arguments. */
+#define ELLGPU_VERSION 0x000200
 
 /* curve ids (names are the reference's preset names, lib/elliptic/curves.js) */
 #define ELLGPU_SECP256K1 0
@@ -148,6 +153,20 @@ int ellgpu_ctx_synchronize(ellgpu_ctx* ctx);
 /* the context's own stream (a hipStream_t; a group: its first member's): what a NULL `stream`
  * argument of the *_dev entry points means */
 void* ellgpu_ctx_stream(ellgpu_ctx* ctx);
+/* The SPLIT form of a small host-buffer call.  The reference's API is one item per synchronous
+ * call (lib/elliptic/ec/index.js:188-229, curve/short.js:422-432) and takes a point's precomputed
+ * tables on trust (curve/base.js:52-126); a patched call must find them unchanged on EVERY call
+ * (elliptic_amd/js/index.js, INTEGRATION.md "what install() treats as immutable") -- a walk over a
+ * few hundred table entries on the host.  ellgpu_ctx_defer(ctx) arms the context: its NEXT
+ * host-buffer call, if it is one of the few-item calls that travel through the context's pinned
+ * buffer (<= 256 KB of operands and results; not a group, not a user-defined curve), returns as
+ * soon as its copies and kernels are enqueued, and the caller's result buffers are written by
+ * ellgpu_ctx_collect(ctx), which waits for the device and returns the call's status -- the host
+ * validates while the device computes.  The result buffers must stay valid until then.  A call
+ * that cannot be deferred runs to completion as usual and ellgpu_ctx_collect has nothing to do;
+ * any other entry point on the context completes a pending call first.  collect also disarms. */
+int ellgpu_ctx_defer(ellgpu_ctx* ctx);
+int ellgpu_ctx_collect(ellgpu_ctx* ctx);
 
 /* User-defined short Weierstrass curve y^2 = x^3 + a x + b over an odd prime p < 2^256 -- the
  * reference's `new elliptic.curve.short({p, a, b, ...})` (lib/elliptic/curve/short.js:11-24) with

@@ -808,3 +808,68 @@ def check_exceptional_keys(ctx, curve, seed=9):
     assert int((np.asarray(want) == exp).sum()) >= len(keep) - 4
     assert int(exp.sum()) > len(keep) // 2 and int(np.asarray(want_inf).sum()) >= len(ds)
     return 2 * m + len(keep)
+
+
+def check_deferred_calls(ctx):
+    """ellgpu_ctx_defer / ellgpu_ctx_collect: a deferred few-item call gives the same bytes as the
+    plain call -- after collect(), or after ANY other entry point on the context (which completes
+    it first); collect() without a pending call, and defer() in front of a call too large for the
+    pinned buffer, are harmless."""
+    import random
+    from oracle import ec_oracle as O
+    rnd = random.Random(606)
+    cur = O.get_curve("secp256k1")
+    n = 5
+    ks = ints_to_be([rnd.randrange(1, 1 << 256) for _ in range(n)], 32)
+    pts, _ = ctx.mul_fixed("secp256k1", ints_to_be([rnd.randrange(1, cur.n) for _ in range(n)], 32))
+    want, winf = ctx.mul_var("secp256k1", ks, pts)
+    assert want.any()
+    # 1. defer -> call -> collect
+    ctx.defer()
+    got, ginf = ctx.mul_var("secp256k1", ks, pts)
+    ctx.collect()
+    assert np.array_equal(got, want) and np.array_equal(ginf, winf)
+    # 2. another entry point in between completes the pending call before it runs
+    ctx.defer()
+    got2, ginf2 = ctx.mul_var("secp256k1", ks, pts)
+    other, _ = ctx.mul_fixed("secp256k1", ks)               # would overwrite the pinned buffer
+    assert np.array_equal(got2, want) and np.array_equal(ginf2, winf)
+    ctx.collect()                                           # nothing left to do
+    assert np.array_equal(got2, want)
+    fx, _ = ctx.mul_fixed("secp256k1", ks)
+    assert np.array_equal(fx, other)
+    # 3. collect() with nothing pending; defer() is consumed by the next call only
+    ctx.collect()
+    ctx.defer()
+    ctx.collect()                                           # disarms
+    got3, _ = ctx.mul_var("secp256k1", ks, pts)             # a plain call again
+    assert np.array_equal(got3, want)
+    # 4. a verify and an EdDSA call in the split form
+    zs = ints_to_be([rnd.randrange(1 << 256) for _ in range(n)], 32)
+    rs = ints_to_be([rnd.randrange(1, cur.n) for _ in range(n)], 32)
+    ok0 = ctx.ecdsa_verify("secp256k1", zs, rs, rs, pts)
+    ctx.defer()
+    ok1 = ctx.ecdsa_verify("secp256k1", zs, rs, rs, pts)
+    ctx.collect()
+    assert np.array_equal(ok0, ok1)
+    secrets = np.frombuffer(bytes(rnd.randrange(256) for _ in range(32 * 3)), np.uint8).reshape(3, 32)
+    msgs = [b"", b"abc", bytes(range(200))]
+    sig0, pub0 = ctx.eddsa_sign(msgs, secrets)
+    ctx.defer()
+    sig1, pub1 = ctx.eddsa_sign(msgs, secrets)
+    ctx.collect()
+    assert np.array_equal(sig0, sig1) and np.array_equal(pub0, pub1)
+    ok2, err2 = ctx.eddsa_verify(msgs, sig0, pub0)
+    ctx.defer()
+    ok3, err3 = ctx.eddsa_verify(msgs, sig0, pub0)
+    ctx.collect()
+    assert ok2.all() and np.array_equal(ok2, ok3) and np.array_equal(err2, err3)
+    # 5. a batch that does not fit the pinned buffer is simply not deferred
+    m = 6000
+    kk = np.tile(ks, (m // n, 1))
+    pp = np.tile(pts, (m // n, 1))
+    ctx.defer()
+    big, _ = ctx.mul_var("secp256k1", kk, pp)
+    assert np.array_equal(big[:n], want)                    # complete already
+    ctx.collect()
+    assert np.array_equal(big[-n:], want)

@@ -41,7 +41,7 @@ def test_header_symbols_all_exported(lib_path):
 def test_metadata_calls_work_without_gpu(lib_path):
     from elliptic_amd import _lib
     lib = _lib.load(lib_path)
-    assert lib.ellgpu_version() == 0x000100
+    assert lib.ellgpu_version() == 0x000200 == _lib.ABI_VERSION
     for i, (name, fb) in enumerate([("secp256k1", 32), ("p192", 24), ("p224", 28), ("p256", 32),
                                     ("p384", 48), ("p521", 66), ("ed25519", 32), ("curve25519", 32)]):
         assert lib.ellgpu_curve_id(name.encode()) == i

@@ -947,3 +947,10 @@ def test_sharded_helpers_on_device(ctx):
     xy, inf = ShardedMul(ctx, "secp256k1", dist=None, device=dev).mul(k)
     wxy, winf = ctx.mul_fixed("secp256k1", k)
     assert np.array_equal(xy.cpu().numpy(), wxy) and np.array_equal(inf.cpu().numpy(), winf)
+
+
+@pytest.mark.gpu
+def test_deferred_small_calls_gpu(ctx):
+    """ellgpu_ctx_defer / ellgpu_ctx_collect on the device: the call returns with its work in flight,
+    collect() -- or any other entry point -- completes it; same bytes as the plain call"""
+    PC.check_deferred_calls(ctx)

@@ -915,3 +915,8 @@ def test_user_defined_edwards_curves(ctx, idx):
     (a != -1) and extended (a = -1) curves of the reference against the device's run-time-prime
     projective ladder (EdcWork)"""
     assert PC.check_custom_edwards_golden(ctx, PC.custom_edwards_curves()[idx]) > 80
+
+
+def test_deferred_small_calls(ctx):
+    """the split form of a few-item call (ellgpu_ctx_defer / ellgpu_ctx_collect), CPU build"""
+    PC.check_deferred_calls(ctx)

@@ -59,7 +59,8 @@ function same(a, b, what) {
     throw new Error(name + ': a custom-generator curve reached the engine');
   if (CUSTOM && eng.stats.gpuCalls === before)
     throw new Error(name + ': the user-defined curve did not reach the engine');
-  if (CUSTOM && (cq._ellgpu !== null || !cq._ellgpuCustom || cq._ellgpuCustom.id < 16))
+  // (the remembered verdicts, each beside its witness: { d, red, snap } -- index.js `domain`, `customDomain`)
+  if (CUSTOM && (!cq._ellgpu || cq._ellgpu.d !== null || !cq._ellgpuCustom || !cq._ellgpuCustom.d || cq._ellgpuCustom.d.id < 16))
     throw new Error(name + ': a custom-generator curve was taken for the preset');
 });
 // the general forms of _wnafMulAdd / _endoWnafMulAdd: 3 and 4 points (paired up on the device)

@@ -402,8 +402,14 @@ for (var it = 0; it < ITER && failures.length < 5; it++) {
   function hex(n) { return Buffer.from(rng.bytes(n)).toString('hex'); }
   var draws = Math.max(12, ITER >> 3);
   for (var i = 0; i < draws && failures.length < 5; i++) {
-    var o, kind = rng.int(10);
-    if (kind < 6) {
+    var o, kind = rng.int(12);
+    if (kind >= 10) {
+      // ... and the same objects changed AFTER their first use (a remembered verdict must not outlive the change)
+      o = { op: 'mutate', curve: rng.pick([ 'secp256k1', 'secp256k1', 'p256', 'p224', 'ed25519' ]), subject: rng.pick([ 'P', 'G' ]),
+        mutation: rng.pick(T.MUTATE), table: rng.pick([ 'naf', 'doubles' ]), at: rng.int(250), mult: 2 + rng.int(9),
+        k: hex(1 + rng.int(32)), k2: hex(1 + rng.int(32)), d: hex(1 + rng.int(24)), msg: rng.bytes(32) };
+      if (o.mutation === 'self-x' && o.subject === 'G') o.subject = 'P';
+    } else if (kind < 6) {
       var curve = rng.pick([ 'secp256k1', 'secp256k1', 'p256', 'p224', 'p384', 'ed25519' ]);
       o = { op: 'tables', curve: curve, mult: 1 + rng.int(9), tamper: rng.pick(T.TAMPER), at: rng.int(250),
         call: rng.pick(curve === 'ed25519' ? [ 'mul', 'mulAdd', 'mulAddRev' ] : [ 'mul', 'mulAdd', 'mulAddRev', 'jmulAdd', 'derive', 'verify' ]),

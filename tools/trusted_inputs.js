@@ -98,6 +98,11 @@ function cloneCurve(L, name, extra) {
   return c.type === 'short' ? new L.curve.short(conf) : new L.curve.edwards(conf);
 }
 
+// an EC instance over a curve OBJECT (ec/index.js:24-45 reads options.curve.curve / .g / .n and a hash)
+function ecOn(L, c, name) {
+  return new L.ec({ curve: { curve: c, g: c.g, n: c.n, hash: L.curves[name].hash } });
+}
+
 var ENDO = [ 'auto', 'given', 'beta-other', 'lambda-other', 'basis-off', 'basis-other', 'basis-swapped' ];
 function endoCurve(L, variant) {
   var c = L.curves.secp256k1.curve, e = c.endo, BN = c.p.constructor;
@@ -170,7 +175,7 @@ function run(L, o) {
       out.push(c.g.mulAdd(new BN(o.k, 16), c.g.mul(new BN(5)), new BN(o.k2, 16)));
       return out;
     }
-    var ec = new L.ec({ curve: { curve: c, hash: L.curves[o.curve].hash } });
+    var ec = ecOn(L, c, o.curve);
     var key = ec.keyFromPrivate(o.k, 'hex');
     var sg = ec.sign(o.msg, key);
     var good = new L.ec(o.curve).sign(o.msg, new L.ec(o.curve).keyFromPrivate(o.k, 'hex'));
@@ -272,7 +277,87 @@ function run(L, o) {
       render(function() { return c.pointFromX(P2.x, true); }), render(function() { return c.pointFromX(kp.getPublic().x, true); }),
       render(function() { return kp.getPublic().mul(k.toRed(c.red)); }), render(function() { return kp.getPublic().mul(k.toRed(c2.red)); }) ];
   });
+  if (o.op === 'mutate') return render(function() { return mutateAfterUse(L, o); });
   throw new Error('unknown op ' + o.op);
+}
+
+// ---- the same objects, changed AFTER their first use -----------------------------------------------
+// The reference reads a point's tables, the endomorphism's constants, the curve's n and g and an EC
+// instance's n / nh / g afresh on every call; whatever install() remembered about them after the
+// first call must not outlive a change.  One recipe: the calls once (first use), the change, the
+// calls again, the change undone, the calls a third time -- all three renderings are the result.
+var MUTATE = [ 'entry', 'coord', 'words', 'y-words', 'width', 'beta-entry', 'beta-words', 'self-x', 'endo-basis', 'endo-beta',
+  'endo-lambda', 'curve-n-words', 'curve-n-replace', 'curve-g', 'curve-b-words', 'ec-g', 'ec-n', 'ec-nh', 'none' ];
+function mutateAfterUse(L, o) {
+  var BN = L.curves.secp256k1.curve.p.constructor;
+  var c = o.curve === 'secp256k1' ? endoCurve(L, 'auto') : cloneCurve(L, o.curve);
+  var k = new BN(o.k, 16), k2 = new BN(o.k2, 16), one = new BN(1);
+  var ec = c.type === 'short' ? ecOn(L, c, o.curve) : null;
+  if (!ec) c.g.precompute(c.n.bitLength() + 1);
+  var S, other = c.g.mul(new BN(11));
+  if (o.subject === 'G') S = c.g;
+  else {
+    var b = c.g.mul(new BN(o.mult));
+    S = c.type === 'short' ? c.point(b.getX(), b.getY()) : c.point(b.getX(), b.getY());
+    S.precompute(c.n.bitLength() + 1);
+  }
+  var wrong = c.g.mul(new BN(3));
+  wrong = c.point(wrong.getX(), wrong.getY());
+  var key = ec && ec.keyFromPrivate(o.d, 'hex'), good = ec && new L.ec(o.curve).sign(o.msg, o.d, 'hex');
+  function calls() {
+    var out = [ render(function() { return S.mul(k); }), render(function() { return S.mul(k2); }),
+      render(function() { return other.mulAdd(k, S, k2); }), render(function() { return c.g.mulAdd(k2, other, k); }),
+      render(function() { return c.validate(S); }) ];
+    if (ec) {
+      out.push(render(function() { return ec.sign(o.msg, key, { canonical: true }); }));
+      out.push(render(function() { return ec.verify(o.msg, good, key.getPublic()); }));
+      out.push(render(function() { return ec.verify(o.msg, good, S); }));
+      out.push(render(function() { return ec.keyFromPrivate(o.d, 'hex').getPublic(); }));
+      out.push(render(function() { return ec.recoverPubKey(o.msg, good, good.recoveryParam); }));
+      out.push(render(function() { return key.derive(S); }));
+    }
+    return out;
+  }
+  var pre = S.precomputed, tbl = pre[o.table] || pre.naf, at = 1 + o.at % (Math.min(tbl.points.length, 120) - 1);
+  var undo = function() {};
+  function swap(obj, prop, val) { var old = obj[prop]; obj[prop] = val; var prev = undo; undo = function() { obj[prop] = old; prev(); }; }
+  function flip(bn, word, bit) { bn.words[word] ^= bit; var prev = undo; undo = function() { bn.words[word] ^= bit; prev(); }; }
+  var first = calls();
+  switch (o.mutation) {
+    case 'none': break;
+    case 'entry': swap(tbl.points, at, wrong); break;
+    case 'coord': swap(tbl.points[at], 'x', tbl.points[at].x.redAdd(c.one || one.toRed(c.red))); break;
+    case 'words': flip(tbl.points[at].x, 0, 1); break;
+    case 'y-words': flip(tbl.points[at].y, 1, 4); break;
+    case 'width': if (tbl === pre.doubles) swap(tbl, 'step', 3); else swap(tbl, 'wnd', tbl.wnd + 1); break;
+    // (precompute() leaves lambda * P WITHOUT tables -- base.js:312-327 calls _getBeta before it sets
+    // this.precomputed; the G of a preset ships them, precomputed/secp256k1.js + short.js:282-310)
+    case 'beta-entry':
+      if (pre.beta && pre.beta.precomputed && pre.beta.precomputed.naf) swap(pre.beta.precomputed.naf.points, at, wrong);
+      else if (pre.beta) swap(pre, 'beta', wrong);
+      else swap(tbl.points, at, wrong);
+      break;
+    case 'beta-words':
+      if (pre.beta && pre.beta.precomputed && pre.beta.precomputed.naf) flip(pre.beta.precomputed.naf.points[at].x, 2, 8);
+      else if (pre.beta) flip(pre.beta.x, 2, 8);
+      else flip(tbl.points[at].x, 2, 8);
+      break;
+    case 'self-x': swap(S, 'x', wrong.x); break;
+    case 'endo-basis': if (c.endo) flip(c.endo.basis[o.at % 2].a, 0, 1); else flip(tbl.points[at].x, 0, 1); break;
+    case 'endo-beta': if (c.endo) swap(c.endo, 'beta', c.endo.beta.redSqr()); else swap(tbl.points, at, wrong); break;
+    case 'endo-lambda': if (c.endo) swap(c.endo, 'lambda', c.endo.lambda.sqr().umod(c.n)); else swap(tbl.points, at, wrong); break;
+    case 'curve-n-words': flip(c.n, 0, 2); break;
+    case 'curve-n-replace': swap(c, 'n', c.n.subn(2)); break;
+    case 'curve-g': wrong.precompute(c.n.bitLength() + 1); swap(c, 'g', wrong); break;
+    case 'curve-b-words': flip(c.type === 'short' ? c.b : c.d, 0, 1); break;
+    case 'ec-g': wrong.precompute(c.n.bitLength() + 1); if (ec) swap(ec, 'g', wrong); else swap(c, 'g', wrong); break;
+    case 'ec-n': if (ec) swap(ec, 'n', ec.n.subn(2)); else flip(c.n, 0, 2); break;
+    case 'ec-nh': if (ec) swap(ec, 'nh', ec.nh.ushrn(3)); else flip(c.n, 0, 2); break;
+    default: throw new Error('unknown mutation ' + o.mutation);
+  }
+  var second = calls();
+  undo();
+  return [ first, second, calls() ];
 }
 
 // the recipes; rng: { bytes(n) -> Buffer | Array }
@@ -332,7 +417,17 @@ function recipes(rng) {
     for (var i = 0; i < 2; i++)
       out.push({ op: 'foreign-red', curve: curve, mult: hex(12), k: hex(20 + 11 * i), msg: arr(32), secret: hex(32) });
   });
+  // the same objects changed after their first use (mutateAfterUse)
+  [ 'secp256k1', 'p256', 'ed25519' ].forEach(function(curve, ci) {
+    MUTATE.forEach(function(mutation, mi) {
+      [ 'P', 'G' ].forEach(function(subject, si) {
+        if (mutation === 'self-x' && subject === 'G') return;
+        out.push({ op: 'mutate', curve: curve, subject: subject, mutation: mutation, table: (ci + mi + si) % 2 ? 'naf' : 'doubles',
+          at: small(), mult: 5 + (mi % 3), k: hex(31), k2: hex(1 + mi % 2 * 15), d: hex(20), msg: arr(32) });
+      });
+    });
+  });
   return out;
 }
 
-module.exports = { run: run, recipes: recipes, TAMPER: TAMPER, ENDO: ENDO };
+module.exports = { run: run, recipes: recipes, TAMPER: TAMPER, ENDO: ENDO, MUTATE: MUTATE };
