@@ -71,14 +71,16 @@ def xof(seed: str, nbytes: int) -> np.ndarray:
     return np.frombuffer(hashlib.shake_256(seed.encode()).digest(nbytes), dtype=np.uint8)
 
 
-def make_signatures(ctx, n, seed, corrupt_every=100):
+def make_signatures(ctx, n, seed, corrupt_every=100, corrupt_q=False):
     """n synthetic secp256k1 signatures, all distinct keys/nonces, built without
     any modular inversion: pick d, k, s; r = x(kG) mod n; z = s*k - r*d mod n.
     Every `corrupt_every`-th tuple is corrupted ("flip a bit of r, s, z or Q"): in
     turn one bit of z, of r, of s, and the key Q -- alternately x + 1 (a point that is NOT on the
     curve: the engine reports status 2 beside a verdict of 0) and the next tuple's key (on the
-    curve, the wrong key).  Returns (hash, r, s, pub, expected_ok) as numpy arrays;
-    expected_status(pub) gives the status array that goes with them.  (The public keys and the
+    curve, the wrong key) when corrupt_q is set -- the bench's own batches (cached_signatures) set
+    it; with corrupt_q off every fourth corrupted tuple takes a bit flip in z, r or s like the
+    others.  Returns (hash, r, s, pub, expected_ok) as numpy arrays; expected_status(pub) gives the
+    status array that goes with them.  (The public keys and the
     nonce points come from the engine's own fixed-base kernel; bench.py checks a sample of
     the tuples with the oracle in every run, so a wrong comb table cannot hide.)"""
     from elliptic_amd import ints_to_be
@@ -106,14 +108,14 @@ def make_signatures(ctx, n, seed, corrupt_every=100):
     idx = np.arange(0, n, corrupt_every)
     pub = np.array(pub, copy=True)
     for j, i in enumerate(idx):
-        if j % 4 == 3:
+        if j % 4 == 3 and corrupt_q:
             if (j // 4) % 2 == 0:
                 x = (int.from_bytes(pub[i, :32].tobytes(), "big") + 1) % SECP_P
                 pub[i, :32] = np.frombuffer(x.to_bytes(32, "big"), np.uint8)
             else:
                 pub[i] = pub[(i + 1) % n]
         else:
-            which = (h, r, s)[j % 4]
+            which = (h, r, s)[j % 3]
             which[i, 31 - (j % 8)] ^= 1 << (j % 7)
         ok[i] = 0
     return h, r, s, pub, ok
@@ -145,7 +147,7 @@ def cached_signatures(ctx, n, seed):
             return d["h"], d["r"], d["s"], d["pub"], d["ok"]
         except Exception:
             pass
-    out = make_signatures(ctx, n, seed)
+    out = make_signatures(ctx, n, seed, corrupt_q=True)
     try:
         np.savez(path + ".tmp.npz", h=out[0], r=out[1], s=out[2], pub=out[3], ok=out[4])
         os.replace(path + ".tmp.npz", path)

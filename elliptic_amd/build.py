@@ -95,6 +95,29 @@ def library_digest(path=None):
     return out if p.returncode == 0 and out else None
 
 
+def kernel_count(path=None):
+    """distinct kernels in a built library: the kernel descriptors (`<mangled name>.kd`) of the code
+    objects embedded in it"""
+    import re
+    path = path or LIB
+    with open(path, "rb") as fh:
+        return len(set(re.findall(rb"(_ZN3ell\w+)\.kd\0", fh.read())))
+
+
+STATS = os.path.join(LIBDIR, "build_stats.json")
+
+
+def build_stats():
+    """what the last build of the library cost (written by build(): lib/build_stats.json, beside the
+    git-ignored .so): cold / warm seconds, translation units, kernels, bytes.  None before a build."""
+    import json
+    try:
+        with open(STATS) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
+
+
 def compile_one(args):
     name, src, defs, digest, extra = args
     obj = os.path.join(OBJ, "%s.%s.o" % (name, digest))
@@ -147,9 +170,14 @@ def build(jobs=None, force=False, verbose=True, remarks=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     digest = source_digest()
+    t_start = time.time()
     if not force and library_digest(LIB) == digest:
         if verbose:
-            print("libellgpu.so up to date (%s)" % digest)
+            st = build_stats() or {}
+            print("libellgpu.so up to date (%s): checked in %.1f s; %s kernels, %.1f MB; its build took %s s "
+                  "(%s translation units compiled, %d-way parallel)"
+                  % (digest, time.time() - t_start, kernel_count(), os.path.getsize(LIB) / 1e6,
+                     st.get("seconds", "?"), st.get("units_compiled", "?"), st.get("jobs", 0)))
         return LIB
     # drop objects of older source states
     for f in os.listdir(OBJ):
@@ -161,10 +189,14 @@ def build(jobs=None, force=False, verbose=True, remarks=False):
     objs = []
     log = []
     t0 = time.time()
+    compiled, cpu_s = 0, 0.0
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
         for name, obj, dt, err in ex.map(compile_one, work):
             objs.append(obj)
             log.append(err)
+            if dt:
+                compiled += 1
+                cpu_s += dt
             if verbose and dt:
                 print("  compiled %-28s %6.1fs" % (name, dt), flush=True)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
@@ -175,8 +207,18 @@ def build(jobs=None, force=False, verbose=True, remarks=False):
     if remarks:
         with open(os.path.join(OBJ, "resource_usage.log"), "w") as f:
             f.write("\n".join(log))
+    # what the build cost, for the record (README "Build"): a cold build compiles every unit
+    import json
+    stats = {"digest": digest, "seconds": round(time.time() - t0, 1), "units": len(work), "units_compiled": compiled,
+             "cold": compiled == len(work), "sum_of_unit_seconds": round(cpu_s, 1), "jobs": jobs,
+             "host_cpus": os.cpu_count(), "kernels": kernel_count(), "library_bytes": os.path.getsize(LIB)}
+    with open(STATS, "w") as fh:
+        json.dump(stats, fh)
     if verbose:
-        print("built %s in %.1fs" % (LIB, time.time() - t0))
+        print("built %s in %.1f s (%s: %d of %d translation units compiled, %.0f s of compiler time, %d-way parallel on "
+              "%d CPUs): %d kernels, %.1f MB" % (LIB, stats["seconds"], "cold" if stats["cold"] else "warm", compiled,
+                                                len(work), cpu_s, jobs, os.cpu_count() or 0, stats["kernels"],
+                                                stats["library_bytes"] / 1e6))
     return LIB
 
 

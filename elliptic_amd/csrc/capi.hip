@@ -3,6 +3,7 @@
 // are instantiated per (curve, operation) in inst.hip; all curve arithmetic is in
 // the headers; there is no vendor library and no CPU path behind this library.
 #include <type_traits>
+#include <vector>
 
 #include "engine_extern.h"
 
@@ -103,22 +104,24 @@ __global__ void __launch_bounds__(64) k_probe_field(u32* out, int iters, u32 see
 
 // the same chains on the lanes-per-item layer (coop.h; one item per wave): kind 20 product chain,
 // 24 Jacobian doublings, 25 mixed additions -- what ONE item's critical path pays per operation
-template <int KIND>
+// (PR: one item per ROW -- four items per wave, coop.h FpK256R: kinds 30 / 34 / 35)
+template <int KIND, bool PR = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_probe_row(u32* out, int iters, u32 seed) {
-  typedef FpK256C F;
-  typedef ShortOps<CvSecp256k1C> G;
+  typedef FpK256CT<PR> F;
+  typedef ShortOps<CvSecp256k1CT<PR>> G;
   u32 xs[8], ys[8], zs[8];
+  const u32 item = PR ? blockIdx.x * 4u + (threadIdx.x >> 4) : blockIdx.x;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    xs[i] = seed * (i + 1) + blockIdx.x * 2654435761u;
-    ys[i] = (seed ^ 0x9E3779B9u) * (i + 3) + blockIdx.x;
-    zs[i] = seed + i * 0x1234567u + blockIdx.x * 7u;
+    xs[i] = seed * (i + 1) + item * 2654435761u;
+    ys[i] = (seed ^ 0x9E3779B9u) * (i + 3) + item;
+    zs[i] = seed + i * 0x1234567u + item * 7u;
   }
   xs[7] &= 0x7FFFFFFFu; ys[7] &= 0x7FFFFFFFu; zs[7] &= 0x7FFFFFFFu;
-  F::El x = F::from_plain(xs), y = F::from_plain(ys), z = F::from_plain(zs);
-  G::J p;
+  typename F::El x = F::from_plain(xs), y = F::from_plain(ys), z = F::from_plain(zs);
+  typename G::J p;
   p.X = x; p.Y = y; p.Z = z;
-  G::A q;
+  typename G::A q;
   q.x = y; q.y = z;
   bool inf = false;
 #pragma nounroll
@@ -127,7 +130,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     else if (KIND == 24) p = G::dbl(p);
     else p = G::add_mixed_lean(p, q, inf, [&]() { return q; });
   }
-  out[(size_t)blockIdx.x * 64 + threadIdx.x] = x.v[0] ^ p.X.v[0] ^ p.Y.v[0] ^ p.Z.v[0] ^ (inf ? 1u : 0u);
+  // the canonical words of the results (row 0's item of a PR = false wave; every row's of a PR wave),
+  // so that the two forms can be compared: out[item * 32 + ...] = x, X, Y, Z
+  u32 w[4][8];
+  F::to_plain(w[0], x); F::to_plain(w[1], p.X); F::to_plain(w[2], p.Y); F::to_plain(w[3], p.Z);
+  if ((threadIdx.x & 15u) == 0 && (PR || threadIdx.x == 0)) {
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int l = 0; l < 8; l++) out[(size_t)item * 32 + c * 8 + l] = w[c][l] ^ (inf && c == 3 ? 1u : 0u);
+  }
 }
 
 // ---- white-box probe: one field operation per lane (tests/test_gpu_field.py) ----
@@ -271,6 +283,9 @@ extern "C" int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iter
       case 20: hipLaunchKernelGGL(ell::k_probe_row<20>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       case 24: hipLaunchKernelGGL(ell::k_probe_row<24>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       case 25: hipLaunchKernelGGL(ell::k_probe_row<25>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 30: hipLaunchKernelGGL((ell::k_probe_row<20, true>), dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 34: hipLaunchKernelGGL((ell::k_probe_row<24, true>), dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 35: hipLaunchKernelGGL((ell::k_probe_row<25, true>), dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       default: bk.free_(out); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
                return set_err(ELLGPU_E_ARG, "unknown probe kind");
     }
@@ -281,9 +296,20 @@ extern "C" int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iter
   (void)hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  // the row kinds leave their results (k_probe_row): with ELLGPU_PROBE_DIGEST set, a 53-bit digest of
+  // the first `blocks` ITEMS' words comes back in ops_out's place -- equal for kinds 2x and 3x when
+  // the one-item-per-row field computes what the one-item-per-wave field computes
+  double digest = -1.0;
+  if (kind >= 20 && getenv("ELLGPU_PROBE_DIGEST")) {
+    std::vector<ell::u32> h((size_t)blocks * (kind >= 30 ? 128 : 32));     // 32 words per item, four items per PR wave
+    (void)hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost);
+    unsigned long long d = 1469598103934665603ull;
+    for (ell::u32 v : h) { d ^= v; d *= 1099511628211ull; }
+    digest = (double)(d >> 11);
+  }
   bk.free_(out);
   *ms_out = ms;
-  *ops_out = kind < 10 ? (double)blocks * 256.0 * (double)iters * 16.0
+  *ops_out = digest >= 0 ? digest : kind < 10 ? (double)blocks * 256.0 * (double)iters * 16.0
                        : (double)blocks * 64.0 * (double)iters * (kind == 12 || kind == 13 ? 2.0 : 1.0);
   return finish(ctx, bk.sync());
 }

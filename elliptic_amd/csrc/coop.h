@@ -43,7 +43,20 @@ namespace ell {
 #define ELL_COOP_LANES 16
 #endif
 
-struct FpK256C {
+// PR = false: ONE item per wave -- the wave's four rows hold the same element (or, inside a step of
+// the group law, four different elements of that item: Q / mulq); what is read out of a row is
+// wave-uniform and travels through the scalar unit (v_readlane).
+// PR = true ("one item per ROW", FpK256R): each of the wave's four 16-lane rows holds a DIFFERENT
+// item, four items per wave.  Every product is the mulq instruction stream (operand limbs by DPP
+// row_newbcast along the item's own row), nothing crosses a row, what is read out of a row is a
+// vector register that differs from row to row, and control flow is row-coherent instead of
+// wave-uniform.  The group law then runs its products one after the other (no Q: the four rows are
+// taken), for about the instructions the PR = false form spends on ONE item (it pays for packing
+// and unpacking its Qs) -- the layer for batches that four waves per SIMD of one-item waves no
+// longer hold (Engine::Tuning::row_grid).
+template <bool PR>
+struct FpK256CT {
+  static constexpr bool PER_ROW = PR;
   static constexpr int CL = ELL_COOP_LANES;        // lanes of the row held by one El: 1 = the hardware lane
   static constexpr int ROW = 16;
   static constexpr int L = 8;                      // 32-bit words of a plain value
@@ -107,6 +120,17 @@ struct FpK256C {
     return __builtin_amdgcn_readlane((int)x.v[0], l);
 #else
     return s(x.v[l]);
+#endif
+  }
+  // the value of lane I of THIS lane's row: wave-uniform through the scalar unit (PR = false), a
+  // broadcast along the row (PR = true)
+  template <int I>
+  ELL_HD static i32 atc(const El& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (PR) return __builtin_amdgcn_update_dpp(0, (int)x.v[0], 0x150 + I, 0xF, 0xF, false);
+    else return __builtin_amdgcn_readlane((int)x.v[0], I);
+#else
+    return s(x.v[I]);
 #endif
   }
   // limb I as every lane of the row sees it.  RW = false: the element is the same in the four rows
@@ -175,7 +199,7 @@ struct FpK256C {
   // pairs (mulq) -- the group law below runs its independent products of a step that way
   // (short.h dbl_lazy / add_mixed_lazy).  On the device a Q is one register; host passes keep the
   // four rows as four elements.
-  static constexpr bool QUAD = true;
+  static constexpr bool QUAD = !PR;                // (one item per row: the rows are taken)
   static constexpr int QR = CL == 1 ? 1 : 4;
   struct Q { El r[QR]; };
   // rows (a, b, a, b)
@@ -273,8 +297,9 @@ struct FpK256C {
   // the row <-> the one-lane 29-bit field (cold paths: canonical tests, stores)
   ELL_HD static FpK256L::El gather(const El& a) {
     FpK256L::El r;
-    ELL_UNROLL
-    for (int i = 0; i < 9; i++) r.v[i] = (u32)at(a, i);
+    r.v[0] = (u32)atc<0>(a); r.v[1] = (u32)atc<1>(a); r.v[2] = (u32)atc<2>(a);
+    r.v[3] = (u32)atc<3>(a); r.v[4] = (u32)atc<4>(a); r.v[5] = (u32)atc<5>(a);
+    r.v[6] = (u32)atc<6>(a); r.v[7] = (u32)atc<7>(a); r.v[8] = (u32)atc<8>(a);
     return r;
   }
   ELL_HD static El scatter(const FpK256L::El& a) {
@@ -307,7 +332,7 @@ struct FpK256C {
   // bits are those of 0 or of p (one output in 2^28), V is not zero; the canonical test decides
   // the rest.
   ELL_HD static bool is_zero_w(const El& a) {
-    const u32 r0 = (u32)at(a, 0) & M;
+    const u32 r0 = (u32)atc<0>(a) & M;
     if (ELL_UNLIKELY(r0 == 0u || r0 == M - 976u)) return is_zero(a);
     return false;
   }
@@ -347,7 +372,7 @@ struct FpK256C {
     for (int t = 0; t < CL; t++) c.v[t] = (u32)(s(a.v[t]) >> 29);
     const El cin = up<1>(c);
     i32 r8;
-    const i32 f = FpK256L::top_fold(at(a, 8), r8);
+    const i32 f = FpK256L::top_fold(atc<8>(a), r8);
     El r;
     ELL_UNROLL
     for (int t = 0; t < CL; t++) {
@@ -366,7 +391,7 @@ struct FpK256C {
     for (int t = 0; t < CL; t++) c.v[t] = (u32)(s(a.v[t]) >> (29 - K));
     const El cin = up<1>(c);
     i32 r8;
-    const i32 f = FpK256L::top_fold(at(a, 8) << K, r8);
+    const i32 f = FpK256L::top_fold(atc<8>(a) << K, r8);
     El r;
     ELL_UNROLL
     for (int t = 0; t < CL; t++) {
@@ -379,7 +404,7 @@ struct FpK256C {
   // a / 2 mod p for a lazy value with |limbs| < 2^30 (fpk256l.h half_l)
   ELL_HD static El half_l(const El& a) {
     const El pv = c_p();
-    const u32 odd = 0u - ((u32)at(a, 0) & 1u);
+    const u32 odd = 0u - ((u32)atc<0>(a) & 1u);
     El tt;
     ELL_UNROLL
     for (int t = 0; t < CL; t++) tt.v[t] = a.v[t] + (odd & pv.v[t]);
@@ -497,8 +522,8 @@ struct FpK256C {
 #endif
     W64 acc = zero64();
     i64 col16 = 0;
-    columns(acc, col16, a, b);
-    return tail(acc, col16);
+    columns<PR>(acc, col16, a, b);
+    return tail<PR>(acc, col16);
   }
   ELL_HD static El sqr(const El& a) { return mul(a, a); }
   // row j of the result = row j of a * row j of b: four products for the instructions of one
@@ -521,9 +546,9 @@ struct FpK256C {
 #endif
     W64 acc = zero64();
     i64 col16 = 0;
-    columns(acc, col16, a, b);
-    columns(acc, col16, e, f);
-    return tail(acc, col16);
+    columns<PR>(acc, col16, a, b);
+    columns<PR>(acc, col16, e, f);
+    return tail<PR>(acc, col16);
   }
 
   // a^-1 (0 for 0): canonical words -> the division steps of the saturated field -> back (cold: once
@@ -544,9 +569,13 @@ struct FpK256C {
   ELL_HD static El mul_pow2(const El& a) { return shl_norm<K>(a); }
 };
 
+typedef FpK256CT<false> FpK256C;
+typedef FpK256CT<true> FpK256R;
+
 // the curve as the group-law templates see it (short.h ShortOps, ladder.h Ladder)
-struct CvSecp256k1C {
-  typedef FpK256C F;
+template <bool PR>
+struct CvSecp256k1CT {
+  typedef FpK256CT<PR> F;
   typedef FpMont<consts::SECP256K1_N> Fn;
   typedef consts::SECP256K1_C C;
   static constexpr int A_KIND = 0;
@@ -554,5 +583,7 @@ struct CvSecp256k1C {
   static constexpr bool JTABLE = false;
   static constexpr int ID = CURVE_SECP256K1;
 };
+typedef CvSecp256k1CT<false> CvSecp256k1C;
+typedef CvSecp256k1CT<true> CvSecp256k1R;
 
 }  // namespace ell

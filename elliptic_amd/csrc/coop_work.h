@@ -12,6 +12,7 @@
 
 #include "coop.h"
 #include "coop_mont.h"
+#include "coop_wide.h"
 
 namespace ell {
 
@@ -63,15 +64,23 @@ ELL_HD typename CW::J coop_comb_mul(const u32 (&k)[LK], const typename CW::W1::A
 // row layer, then THIS item's own inversion -- no Montgomery trick across items, on an idle machine
 // the chain counts -- and the affine point as the one-lane sign_finish reads it (big-endian x || y,
 // infinity flag).  CW = CoopK256 / CoopNist<...>.
-template <class CW>
+// NONCE: the scalar is an HmacDRBG draw and goes through _truncateToN(K, true) as EC#sign's does
+// (W1::load_nonce: p521 shifts a full-width draw by 7 bits); else it is Point#mul's scalar, any
+// BYTES-byte value as it stands.
+template <class CW, bool NONCE = true>
 ELL_HD void coop_sign_point(size_t i, const u8* nonces, const typename CW::W1::A* comb, u8* kg_xy, u8* kg_inf) {
   typedef typename CW::W1 W1;
   typedef typename CW::F F;
   constexpr int L = W1::L, LN = W1::LN, BYTES = W1::BYTES;
-  u32 k[LN], kk[L];
-  W1::load_nonce(k, nonces + i * W1::NBYTES);
-  ELL_UNROLL
-  for (int l = 0; l < L; l++) kk[l] = l < LN ? k[l] : 0u;
+  u32 kk[L];
+  if constexpr (NONCE) {
+    u32 k[LN];
+    W1::load_nonce(k, nonces + i * W1::NBYTES);
+    ELL_UNROLL
+    for (int l = 0; l < L; l++) kk[l] = l < LN ? k[l] : 0u;
+  } else {
+    load_be<L>(kk, nonces + i * BYTES, BYTES);
+  }
   typename CW::J r = coop_comb_mul<CW>(kk, comb);
   const bool inf = F::is_zero(r.Z);
   typename F::El zi = F::inv(r.Z);                      // inv(0) = 0
@@ -333,18 +342,28 @@ struct CoopK256 {
 // (work.h var_ladder's plain branch: co-Z table on the isomorphic curves, one inversion to map it
 // back to the curve whose a = -3 doubling the ladder needs) and u1*G by the comb -- joined by the
 // one-lane ecdsa_join2; Point#mul is the ladder alone, normalised by the one-lane kernel.
+// (p384 and p521 -- 14 / 19 digits: 27 / 37 product columns do not fit a 16-lane row -- take the
+// WIDE field, an element over the lanes of the whole wave: coop_wide.h FpMontW)
 template <class CV1>
-struct CoopConsts { static constexpr bool AVAILABLE = false; typedef consts::COOP_P256 MC; };
-template <> struct CoopConsts<CvP192> { static constexpr bool AVAILABLE = true; typedef consts::COOP_P192 MC; };
-template <> struct CoopConsts<CvP224> { static constexpr bool AVAILABLE = true; typedef consts::COOP_P224 MC; };
-template <> struct CoopConsts<CvP256> { static constexpr bool AVAILABLE = true; typedef consts::COOP_P256 MC; };
+struct CoopConsts { static constexpr bool AVAILABLE = false, WIDE = false; typedef consts::COOP_P256 MC; };
+template <> struct CoopConsts<CvP192> { static constexpr bool AVAILABLE = true, WIDE = false; typedef consts::COOP_P192 MC; };
+template <> struct CoopConsts<CvP224> { static constexpr bool AVAILABLE = true, WIDE = false; typedef consts::COOP_P224 MC; };
+template <> struct CoopConsts<CvP256> { static constexpr bool AVAILABLE = true, WIDE = false; typedef consts::COOP_P256 MC; };
+template <> struct CoopConsts<CvP384> { static constexpr bool AVAILABLE = true, WIDE = true; typedef consts::COOPW_P384 MC; };
+template <> struct CoopConsts<CvP521> { static constexpr bool AVAILABLE = true, WIDE = true; typedef consts::COOPW_P521 MC; };
+template <bool WIDE, class MC, class F1>
+struct CoopField { typedef FpMontC<MC, F1> type; };
+template <class MC, class F1>
+struct CoopField<true, MC, F1> { typedef FpMontW<MC, F1> type; };
 
 template <class CV1>
 struct CoopNist {
   typedef typename CoopConsts<CV1>::MC MC;
   static constexpr bool AVAILABLE = CoopConsts<CV1>::AVAILABLE;
+  static constexpr bool WIDE = CoopConsts<CV1>::WIDE;
+  static constexpr int LANES = WIDE ? 64 : 16;       // lanes an element lives on (a row, or the wave)
   struct CV {
-    typedef FpMontC<MC, typename CV1::F> F;
+    typedef typename CoopField<CoopConsts<CV1>::WIDE, MC, typename CV1::F>::type F;
     typedef typename CV1::Fn Fn;
     typedef typename CV1::C C;
     static constexpr int A_KIND = CV1::A_KIND;
@@ -362,11 +381,12 @@ struct CoopNist {
   static constexpr int L = W1::L;
   static constexpr int NE = W1::PLAIN_NE, NW = W1::PLAIN_NW, WB = W1::PLAIN_WB;
   static constexpr int SLOTS = 2 * NE;
-  static constexpr int ROW_BYTES = SLOTS * FpK256C::ROW * 16;
+  static constexpr int ROW_BYTES = SLOTS * LANES * 16;
+  static_assert(sizeof(A) * SLOTS * (F::CL == 1 ? LANES : 1) <= (size_t)ROW_BYTES, "row memory too small");
 
   ELL_HD static A* lane_table(void* row_mem) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return (A*)row_mem + (size_t)(threadIdx.x & 15u) * SLOTS;
+    return (A*)row_mem + (size_t)(threadIdx.x & (unsigned)(LANES - 1)) * SLOTS;
 #else
     return (A*)row_mem;
 #endif
@@ -437,13 +457,13 @@ struct CoopNist {
   // EC#verify's key does not depend on s^-1, so a unit of the launch in front builds it beside the
   // scalar-field prep (FnEcdsaPrepTableN) and the ladder's unit starts from it.  GROW lane-entries
   // per table entry (the device keeps a limb per lane, host passes a whole row per element).
-  static constexpr int GROW = FpK256C::CL == 1 ? 16 : 1;
+  static constexpr int GROW = F::CL == 1 ? LANES : 1;
   static constexpr size_t TABLE_BYTES = (size_t)NE * GROW * sizeof(A);
   ELL_HD static void table_out(A* g, const A* tbl) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (threadIdx.x < 16u) {
+    if (threadIdx.x < (unsigned)LANES) {
       ELL_NOUNROLL
-      for (int e = 0; e < NE; e++) g[e * 16 + threadIdx.x] = tbl[e];
+      for (int e = 0; e < NE; e++) g[e * LANES + threadIdx.x] = tbl[e];
     }
 #else
     for (int e = 0; e < NE; e++) g[e] = tbl[e];
@@ -452,7 +472,7 @@ struct CoopNist {
   ELL_HD static void table_in(A* tbl, const A* g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     ELL_NOUNROLL
-    for (int e = 0; e < NE; e++) tbl[e] = g[e * 16 + (threadIdx.x & 15u)];
+    for (int e = 0; e < NE; e++) tbl[e] = g[e * LANES + (threadIdx.x & (unsigned)(LANES - 1))];
 #else
     for (int e = 0; e < NE; e++) tbl[e] = g[e];
 #endif

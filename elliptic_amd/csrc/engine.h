@@ -524,7 +524,7 @@ struct FnMulFixedC {
   static constexpr int ROW_BYTES = 16;
   size_t n; const u8* k; const typename W::A* comb; u8* out_xy; u8* out_inf;
   ELL_HD void operator()(size_t unit, const DigitStore&, void*) const {
-    if (unit < n) coop_sign_point<CW>(unit, k, comb, out_xy, out_inf);
+    if (unit < n) coop_sign_point<CW, false>(unit, k, comb, out_xy, out_inf);
   }
 };
 // ShortCurve#pointFromX of a handful of secp256k1 abscissas: the square root's 266 products on a
@@ -2454,8 +2454,8 @@ template <class BK>
 template <class CV>
 int Engine<BK>::mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf) {
   typedef Work<CV> W;
-  // a handful of items: the comb and the item's own inversion on a wave, one launch (the scalar's
-  // byte width is the order's on these curves, which is what coop_sign_point reads)
+  // a handful of items: the comb and the item's own inversion on a wave, one launch (the scalar is
+  // Point#mul's: BYTES bytes as they stand -- coop_sign_point<CW, false>, no _truncateToN)
   constexpr bool row_k256 = CV::ENDO && W::L <= 8 && CoopK256::AVAILABLE;
   constexpr bool row_nist = !CV::ENDO && CoopNist<CV>::AVAILABLE;
   if constexpr ((row_k256 || row_nist) && W::NBYTES == W::BYTES) {

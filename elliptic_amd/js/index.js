@@ -770,8 +770,16 @@ function install(elliptic, options) {
     var c = ec.curve;
     if (ec.g !== c.g) return false;
     if (ec.n === undefined) return true;                       // EDDSA keeps no n of its own
-    if (ec.n !== c.n || !ec.nh || ec.nh.red || ec.nh.isNeg()) return false;
-    return ec.nh.ushln(1).iaddn(1).cmp(c.n) === 0;              // nh = n >> 1, n odd
+    var n = c.n, h = ec.nh;
+    if (ec.n !== n || !h || h.red || h.negative !== 0 || !n || n.negative !== 0) return false;
+    // nh = n >> 1, word by word (26-bit words, dist/elliptic.js:3998): no allocation on this path
+    var nw = n.words, hw = h.words, nl = n.length, hl = h.length;
+    if (hl !== nl && hl !== nl - 1) return false;
+    for (var i = 0; i < nl; i++) {
+      var want = (nw[i] >>> 1) | (i + 1 < nl ? (nw[i + 1] & 1) << 25 : 0);
+      if ((i < hl ? hw[i] : 0) !== want) return false;
+    }
+    return true;
   }
   // ---- the one-item calls: validate the tables WHILE the device computes ------------------------
   // call() is ONE engine call of a few items.  When any of `pts` carries precomputed tables, the
@@ -779,7 +787,10 @@ function install(elliptic, options) {
   // tables are compared with their witnesses (or checked from scratch the first time) while the
   // device works, and ellgpu_ctx_collect fetches the result -- which is DISCARDED (null: the caller
   // runs the reference's own method) when a table is not its point's multiples.
-  var canDefer = typeof addon.defer === 'function' && typeof addon.collect === 'function' && !eng.devices;
+  // (ELLGPU_NO_DEFER=1, developer switch: validate first, then call -- what the overlap saves shows
+  // as the difference, tools/bench_js_single_call.js)
+  var canDefer = typeof addon.defer === 'function' && typeof addon.collect === 'function' && !eng.devices &&
+    !process.env.ELLGPU_NO_DEFER;
   function guarded(curve, pts, call) {
     var any = false;
     for (var i = 0; i < pts.length; i++) if (pts[i] && pts[i].precomputed) any = true;
@@ -1338,6 +1349,13 @@ function install(elliptic, options) {
     groups.forEach(function(g) {
       var good = [], ms = [];
       var d = domain(g.ec.curve);
+      // G's tables: looked at once per batch (the calls of one tick see one state of the library)
+      if (!d || !tablesOK(g.ec.curve, g.ec.curve.g)) {
+        g.ps.forEach(function(p) {
+          try { p.resolve(g.ec.verify(p.item.msg, p.item.signature, p.item.key, p.item.enc, p.item.options)); } catch (e) { p.reject(e); }
+        });
+        return;
+      }
       g.ps.forEach(function(p) {           // a throwing item rejects alone
         try { ms.push(marshalOne(g.ec, d, p.item)); good.push(p); }
         catch (e) { p.reject(e); }
@@ -1365,7 +1383,7 @@ function install(elliptic, options) {
   }
   eng.verifyAsync = function verifyAsync(ec, msg, signature, key, enc, options) {
     if (typeof enc === 'object' && enc !== null && options === undefined) { options = enc; enc = undefined; }
-    var d = ecOK(ec) ? protocolDomain(ec.curve) : null;
+    var d = ecOK(ec) ? protocolDomainLazy(ec.curve) : null;        // (G's tables: flushVerify, once per batch)
     if (!d || ec.curve.type !== 'short' || !byteMessage(msg) || !plainMsgBits(options)) {
       // outside the engine's batch domain: the (patched) synchronous path, as a Promise
       return new Promise(function(resolve) { resolve(ec.verify(msg, signature, key, enc, options)); });

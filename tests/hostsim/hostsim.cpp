@@ -196,7 +196,7 @@ int hs_field_limbs(int field) {
   switch (field) {
     case 0: case 1: case 2: case 3: return 8;
     case 10: return 8; case 11: return 6; case 12: return 7; case 13: return 8; case 14: return 12; case 15: return 17;
-    case 31: return 6; case 32: return 7; case 33: return 8;
+    case 31: return 6; case 32: return 7; case 33: return 8; case 34: return 12; case 35: return 17;
     case 20: return 8; case 21: return 6; case 22: return 7; case 23: return 8; case 24: return 12; case 25: return 17;
     case 26: return 8;
   }
@@ -211,6 +211,9 @@ int hs_field_op(int field, int op, const u32* a, const u32* b, u32* r) {
     case 31: field_op<CoopNist<CvP192>::F>(op, a, b, r); break;
     case 32: field_op<CoopNist<CvP224>::F>(op, a, b, r); break;
     case 33: field_op<CoopNist<CvP256>::F>(op, a, b, r); break;
+    // the WIDE fields (csrc/coop_wide.h: 28-bit digits over the lanes of a wave), host simulation of the wave
+    case 34: field_op<CoopNist<CvP384>::F>(op, a, b, r); break;
+    case 35: field_op<CoopNist<CvP521>::F>(op, a, b, r); break;
     case 1:
       if (op == 10) {                      // mul_u32 by the one-limb constant b[0]
         u32 ta[8];

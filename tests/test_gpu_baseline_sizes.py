@@ -91,11 +91,19 @@ def test_config3_secp256k1_variable_base_and_verify_1M(ctx):
     # P*k (GLV): k = the r column, P = the public keys
     xy, inf = ctx.mul_var("secp256k1", r, pub)
     idx = sample_idx(n)
+    # (round 6: every 400th key of the bench batch is off the curve -- x + 1 -- and is reported as
+    # such, status 2 and a zeroed result, where the oracle computes with it as the reference does)
+    off = bench.expected_status(pub) == 2
+    assert 1000 < int(off.sum()) < 4000
+    assert (inf[off] == elliptic_amd.STATUS_OFF_CURVE).all() and not xy[off].any() and not (inf[~off] == 2).any()
+    idx = idx[~off[idx]]
     want, winf = C.mul_mt("secp256k1", r[idx], pub[idx], threads())
     assert np.array_equal(inf[idx], winf) and np.array_equal(xy[idx], want)
-    # verify: mask == expected on ALL tuples, expected == oracle on the sample
-    ok = ctx.ecdsa_verify("secp256k1", h, r, s, pub)
+    # verify: mask == expected on ALL tuples (and the status array), expected == oracle on the sample
+    ok, st = ctx.ecdsa_verify("secp256k1", h, r, s, pub, status=True)
     assert np.array_equal(np.asarray(ok).astype(np.uint8), expect)
+    assert np.array_equal(st, bench.expected_status(pub, r, s))
+    idx = sample_idx(n)
     wok = C.verify("secp256k1", h[idx], r[idx], s[idx], pub[idx], threads=threads())
     assert np.array_equal(wok, expect[idx])
 

@@ -577,11 +577,12 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
         c.close()
 
 
-@pytest.mark.parametrize("curve", ["p256", "p224", "p192"])
+@pytest.mark.parametrize("curve", ["p256", "p224", "p192", "p384", "p521"])
 def test_nist_small_batches_on_the_row_layer(monkeypatch, curve):
-    """Batches of at most ELLGPU_COOP_GRID items on the NIST curves up to 256 bits run every item's
-    ladder and comb on a wave of its own (csrc/coop_mont.h: a Montgomery field of nine 29-bit limbs
-    across a 16-lane DPP row; coop_work.h CoopNist), joined by one-lane kernels.  Same bytes as the
+    """Batches of at most ELLGPU_COOP_GRID items on the NIST curves run every item's ladder and comb
+    on a wave of its own -- up to 256 bits csrc/coop_mont.h (a Montgomery field of nine 29-bit limbs
+    across a 16-lane DPP row), p384 / p521 csrc/coop_wide.h (14 / 19 28-bit digits across the whole
+    wave: DPP wave_shr, ds_bpermute; round 6) -- coop_work.h CoopNist, joined by one-lane kernels.  Same bytes as the
     one-item-per-lane kernels (ELLGPU_COOP_GRID=0) for verify (valid, corrupted, off-curve keys, r
     or s out of range), P*k (k = 0, 1, n - 1, n, n + 1, 2^(8B) - 1 included), k1*G + k2*P, and the
     reference's fixtures through both."""
@@ -746,7 +747,7 @@ def test_eddsa_verify_small_batches_on_the_row_layer(monkeypatch):
         c.close()
 
 
-@pytest.mark.parametrize("curve", ["secp256k1", "p256", "p224", "p192"])
+@pytest.mark.parametrize("curve", ["secp256k1", "p256", "p224", "p192", "p384", "p521"])
 def test_small_batch_sign_on_the_row_layer(monkeypatch, curve):
     """EC#sign for a handful of items: k*G (comb + the item's own inversion) and k^-1 mod n on a
     wave each in ONE launch of the row layer (sign_parts_c), then sign_finish without an inversion

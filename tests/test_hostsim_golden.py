@@ -46,6 +46,8 @@ FIELDS = {
     26: O.get_curve("ed25519", False).n,
     # the row layer's Montgomery fields (csrc/coop_mont.h: nine 29-bit limbs across a 16-lane row, R = 2^261)
     31: O.get_curve("p192", False).p, 32: O.get_curve("p224", False).p, 33: O.get_curve("p256", False).p,
+    # the WIDE fields (csrc/coop_wide.h: 14 / 19 28-bit digits over the lanes of a wave, R = 2^392 / 2^532)
+    34: O.get_curve("p384", False).p, 35: O.get_curve("p521", False).p,
 }
 
 
@@ -398,11 +400,12 @@ def test_verify_golden_secp256k1_both_tunings(hs, monkeypatch):
     c.close()
 
 
-@pytest.mark.parametrize("curve", ["p192", "p224", "p256"])
+@pytest.mark.parametrize("curve", ["p192", "p224", "p256", "p384", "p521"])
 def test_nist_curves_one_lane_and_row_layer(hs, monkeypatch, curve):
-    """Small batches on the NIST curves up to 256 bits run their ladder and comb on the row layer
-    (csrc/coop_mont.h: a Montgomery field of nine 29-bit limbs across a 16-lane row, one item per
-    wave; work: coop_work.h CoopNist, joined by the one-lane ecdsa_join2 / mul_join);
+    """Small batches on the NIST curves run their ladder and comb on the lanes-per-item layer, one item
+    per wave -- up to 256 bits csrc/coop_mont.h (a Montgomery field of nine 29-bit limbs across a
+    16-lane row), p384 / p521 csrc/coop_wide.h (14 / 19 28-bit digits across the wave; round 6) --
+    work: coop_work.h CoopNist, joined by the one-lane ecdsa_join2 / mul_join;
     ELLGPU_COOP_GRID=0 keeps them on the one-item-per-lane kernels.  Same results from both."""
     for coop, rowk in (("0", False), (str(1 << 30), True)):
         c = _fresh_ctx(hs, monkeypatch, ELLGPU_COOP_GRID=coop)

@@ -7,7 +7,8 @@ var loader = require('./ref_loader');
 var crypto = require('crypto');
 var plain = loader.load().elliptic;
 var patched = loader.load().elliptic;
-var eng = require('../elliptic_amd/js').install(patched, { libPath: process.env.ELLGPU_LIB });
+// (ELLGPU_JS: another copy of the JavaScript layer, for A/B runs on one box)
+var eng = require(process.env.ELLGPU_JS || '../elliptic_amd/js').install(patched, { libPath: process.env.ELLGPU_LIB });
 
 function stats(ts) {
   ts.sort(function(a, b) { return a - b; });
