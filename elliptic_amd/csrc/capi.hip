@@ -142,6 +142,46 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
   }
 }
 
+// ... and on the WIDE layer (coop_wide.h: p384 / p521, an element over the lanes of the wave): kinds
+// 40 / 44 / 45 (p384 product / a = -3 doubling / mixed addition) and 50 / 54 / 55 (p521)
+template <class CV1, int KIND>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_probe_wide(u32* out, int iters, u32 seed) {
+  typedef CoopNist<CV1> CW;
+  typedef typename CW::F F;
+  typedef typename CW::G G;
+  constexpr int L = F::L;
+  u32 xs[L], ys[L], zs[L];
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    xs[i] = seed * (i + 1) + blockIdx.x * 2654435761u;
+    ys[i] = (seed ^ 0x9E3779B9u) * (i + 3) + blockIdx.x;
+    zs[i] = seed + i * 0x1234567u + blockIdx.x * 7u;
+  }
+  xs[L - 1] &= 0xFFu; ys[L - 1] &= 0xFFu; zs[L - 1] &= 0xFFu;
+  typename F::El x = F::from_plain(xs), y = F::from_plain(ys), z = F::from_plain(zs);
+  typename G::J p;
+  p.X = x; p.Y = y; p.Z = z;
+  typename G::A q;
+  q.x = y; q.y = z;
+  bool inf = false;
+#pragma nounroll
+  for (int it = 0; it < iters; it++) {
+    if (KIND == 0) x = F::mul(x, y);
+    else if (KIND == 4) p = G::dbl(p);
+    else p = G::add_mixed_lean(p, q, inf, [&]() { return q; });
+  }
+  u32 w[4][L];
+  F::to_plain(w[0], x); F::to_plain(w[1], p.X); F::to_plain(w[2], p.Y); F::to_plain(w[3], p.Z);
+  if (threadIdx.x == 0) {
+    u32 acc = inf ? 1u : 0u;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int l = 0; l < L; l++) acc ^= w[c][l] * (u32)(c * 31 + l + 1);
+    out[(size_t)blockIdx.x * 32] = acc;
+  }
+}
+
 // ---- white-box probe: one field operation per lane (tests/test_gpu_field.py) ----
 template <class F, class = void>
 struct ell_has_wide_probe { static constexpr bool value = false; };
@@ -283,6 +323,12 @@ extern "C" int ellgpu_probe_valu(ellgpu_ctx* ctx, int kind, int blocks, int iter
       case 20: hipLaunchKernelGGL(ell::k_probe_row<20>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       case 24: hipLaunchKernelGGL(ell::k_probe_row<24>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       case 25: hipLaunchKernelGGL(ell::k_probe_row<25>, dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 40: hipLaunchKernelGGL((ell::k_probe_wide<ell::CvP384, 0>), dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 44: hipLaunchKernelGGL((ell::k_probe_wide<ell::CvP384, 4>), dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 45: hipLaunchKernelGGL((ell::k_probe_wide<ell::CvP384, 5>), dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 50: hipLaunchKernelGGL((ell::k_probe_wide<ell::CvP521, 0>), dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 54: hipLaunchKernelGGL((ell::k_probe_wide<ell::CvP521, 4>), dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
+      case 55: hipLaunchKernelGGL((ell::k_probe_wide<ell::CvP521, 5>), dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       case 30: hipLaunchKernelGGL((ell::k_probe_row<20, true>), dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       case 34: hipLaunchKernelGGL((ell::k_probe_row<24, true>), dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;
       case 35: hipLaunchKernelGGL((ell::k_probe_row<25, true>), dim3(blocks), dim3(64), 0, bk.cur, out, iters, 12345u); break;

@@ -12,20 +12,19 @@
 //   * product: column c accumulates in lane c -- NL multiply-adds (v_mad_i64_i32) of the whole wave,
 //     operand a's digits as scalars (v_readlane), operand b moving up ONE lane per step (DPP
 //     wave_shr:1, which crosses the row boundaries a row_shr does not);
-//   * reduction: word-serial Montgomery (R = 2^(28 NL)) exactly as coop_mont.h: column i is made
-//     divisible by 2^28 by adding m_i * p shifted up i lanes (per-lane constants), m_i from the
-//     running column on the scalar unit; both primes are -1 mod 2^28, so m_i is the column's low
-//     digit and the carry is (v >> 28) + m_i;
-//   * the result's digits are columns NL .. 2 NL - 1: two carry passes where they stand, then ONE
-//     ds_bpermute_b32 brings them down NL lanes;
+//   * reduction by FOLDING, no serial chain: after two carry passes digit NL + j of the product is
+//     a 28-bit number worth fold[j] = 2^(28 (NL + j)) mod p, a per-lane constant vector -- NL more
+//     multiply-adds of the whole wave (the digit as a scalar: v_readlane); what then stands above
+//     2^PBITS (34 bits at most) is worth top = 2^PBITS mod p (2^128 + 2^96 - 2^32 + 1, or 1) and
+//     folds once more.  (The first version of this layer reduced word-serially as coop_mont.h does,
+//     Montgomery form with R = 2^(28 NL): 14 / 19 steps that each wait for v_readlane -> scalar ->
+//     v_mad_i64_i32 of the step before -- 240 / 320 instructions at 7 cycles each on a lone wave,
+//     p384 EC#verify 2.69 ms, p521 4.77; profiles/r06_wide_field.jsonl.)
 //   * an addition or subtraction is one instruction + a seven-instruction normalisation.
-// 28-bit digits (not 29): a column sums up to 19 products and 19 reduction rows -- 2^61.3.
-// Per product ~6 NL + 20 issue slots (104 / 134) against ~450 / ~650 on one lane.
-//
-// Signed digits, values in (-2^(PBITS-20), 2^PBITS + 2^(PBITS-20)), nothing conditionally
-// subtracted on the fast path (R exceeds 2^PBITS by 2^8 / 2^11: a product of two such values comes
-// out below 1.01 p).  The interface is coop_mont.h FpMontC's, so coop_work.h CoopNist, short.h and
-// ladder.h instantiate over it unchanged; QUAD is off (one element per wave, nothing to pack).
+// 28-bit digits (not 29): a column sums up to 19 products -- 2^61.3.  Plain residues (no Montgomery
+// form), signed digits, values in (-2^(PBITS-20), 2^PBITS + 2^(PBITS-20)), nothing conditionally
+// subtracted on the fast path.  The interface is coop_mont.h FpMontC's, so coop_work.h CoopNist,
+// short.h and ladder.h instantiate over it unchanged; QUAD is off (one element per wave).
 //
 // Host passes (tests/hostsim) simulate the wave: El holds all 64 lanes.
 //
@@ -45,7 +44,7 @@ namespace ell {
 #endif
 
 template <class MC, class F1>
-struct FpMontW {
+struct FpFoldW {
   static constexpr int CL = ELL_WIDE_LANES;
   static constexpr int SPAN = 64;                    // lanes an element may touch: the wave
   static constexpr int NL = MC::NL;
@@ -58,8 +57,7 @@ struct FpMontW {
   static constexpr u32 M = (1u << RB) - 1;
   static constexpr int TL = NL - 1;                  // the digit that holds bit PBITS - 1 ...
   static constexpr int TB = MC::PBITS - RB * TL;     // ... and how many bits of it belong to a value below 2^PBITS
-  static_assert((MC::PBITS - 1) / RB == TL && 2 * NL - 1 <= SPAN && MC::n0 == 1u && MC::pd[0] == (int)M,
-                "FpMontW: p = -1 (mod 2^RB), top digit NL - 1, columns within the wave");
+  static_assert((MC::PBITS - 1) / RB == TL && 2 * NL <= SPAN, "FpFoldW: top digit NL - 1, columns within the wave");
 
   ELL_HD static i32 s(u32 x) { return (i32)x; }
 
@@ -103,18 +101,6 @@ struct FpMontW {
 #endif
     return r;
   }
-  // lane l <- lane l + NL (the result's digits come down from columns NL ..): ds_bpermute_b32, the
-  // LDS crossbar without memory; lanes whose source lies past the wave read a wrapped lane and are
-  // masked by the caller (`live`)
-  ELL_HD static El down_nl(const El& x) {
-    El r;
-#if defined(__HIP_DEVICE_COMPILE__)
-    r.v[0] = (u32)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x + (unsigned)NL) & 63u) << 2), (int)x.v[0]);
-#else
-    for (int t = 0; t < CL; t++) r.v[t] = x.v[(t + NL) & 63];
-#endif
-    return r;
-  }
   // the (wave-uniform) value of lane I
   template <int I>
   ELL_HD static i32 at(const El& x) {
@@ -134,16 +120,6 @@ struct FpMontW {
     return x.w[I];
 #endif
   }
-  // lane LANE <- the wave-uniform value sv
-  template <int LANE>
-  ELL_HD static W64 put64(W64 x, i64 sv) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    x.w[0] = lane_of(0) == LANE ? sv : x.w[0];
-#else
-    x.w[LANE] = sv;
-#endif
-    return x;
-  }
 
   // ---- per-lane constants (loop-invariant registers on the device; masks, not ?: chains) ----------
   ELL_HD static u32 m_eq(int l, int i) { return 0u - (u32)(l == i); }
@@ -159,16 +135,15 @@ struct FpMontW {
     });
   }
   ELL_HD static El c_p() { return by_lane<0>(MC::pd); }
-  template <int I>
-  ELL_HD static El c_pshift() { return by_lane<I>(MC::pd); }
+  template <int J>
+  ELL_HD static El c_fold() { return by_lane<0>(MC::fold[J]); }   // what digit NL + J of a product is worth
+  ELL_HD static El c_top() { return by_lane<0>(MC::top); }        // 2^PBITS mod p ...
+  ELL_HD static El c_top1() { return by_lane<1>(MC::top); }       // ... and 2^(PBITS + RB) mod p (top is short)
   ELL_HD static El c_live() { return each([](int l) { return m_lt(l, NL); }); }
   ELL_HD static El c_mask() { return each([](int l) { return (m_lt(l, NL - 1) & M) | m_eq(l, NL - 1); }); }   // a carry pass keeps these bits
   ELL_HD static El c_carries() { return each([](int l) { return m_lt(l, NL - 1); }); }                          // digits that hand a carry up
-  ELL_HD static El c_hi_carries() { return each([](int l) { return m_lt(l, 2 * NL - 1) & ~m_lt(l, NL); }); }   // ... among columns NL .. 2 NL - 2
   ELL_HD static El zero() { return each([](int) { return 0; }); }
-  ELL_HD static El one() { return by_lane<0>(MC::one); }       // R mod p
-  ELL_HD static El c_rr() { return by_lane<0>(MC::rr); }        // R^2 mod p
-  ELL_HD static El plain_one() { return each([](int l) { return m_eq(l, 0) & 1u; }); }
+  ELL_HD static El one() { return each([](int l) { return m_eq(l, 0) & 1u; }); }
 
   // ---- lazy digit-wise forms ----------------------------------------------------------------------
   ELL_HD static El add_l(const El& a, const El& b) {
@@ -193,7 +168,7 @@ struct FpMontW {
 #if defined(ELL_BOUNDS_CHECK)
     for (int t = 0; t < CL; t++) {
       const i64 dd = (i64)s(a.v[t]) - (i64)k * (i64)s(pv.v[t]);
-      if (dd >= ((i64)1 << 31) || dd < -((i64)1 << 31)) { fprintf(stderr, "fpmontw norm: digit %d leaves 32 bits\n", t); assert(0); }
+      if (dd >= ((i64)1 << 31) || dd < -((i64)1 << 31)) { fprintf(stderr, "fpfoldw norm: digit %d leaves 32 bits\n", t); assert(0); }
     }
 #endif
     El d, c;
@@ -219,64 +194,55 @@ struct FpMontW {
         if (j < 0 || j >= NL) continue;
         __int128 pr = (__int128)s(a.v[i]) * (__int128)s(b.v[j]);
         sum += pr < 0 ? -pr : pr;
-        sum += ((__int128)1 << RB) * MC::pd[j];         // the reduction's row m_i p, |m_i| < 2^RB
       }
-      if (sum >= lim) { fprintf(stderr, "fpmontw %s: column %d exceeds 63 bits\n", what, c); assert(0); }
+      if (sum >= lim) { fprintf(stderr, "fpfoldw %s: column %d exceeds 63 bits\n", what, c); assert(0); }
     }
-    for (int t = NL; t < CL; t++) assert(a.v[t] == 0 && b.v[t] == 0 && "fpmontw: dead lane not zero");
+    for (int t = NL; t < CL; t++) assert(a.v[t] == 0 && b.v[t] == 0 && "fpfoldw: dead lane not zero");
+  }
+  static void check64(const W64& x, const char* what) {
+    const i64 lim = ((i64)1 << 62);
+    for (int t = 0; t < CL; t++)
+      if (x.w[t] >= lim || x.w[t] <= -lim) { fprintf(stderr, "fpfoldw %s: lane %d exceeds 62 bits\n", what, t); assert(0); }
   }
 #endif
-  // columns 0 .. 2 NL - 2 of a * b, one per lane: step I adds a_I * (b moved up I lanes)
+  // columns 0 .. 2 NL - 2 of a * b, one per lane: step I adds a_I * (b moved up I lanes); two
+  // accumulators (even / odd steps), so that a step does not wait for the one before it
   template <int I>
-  ELL_HD static void col_steps(W64& acc, const El& a, El bs) {
+  ELL_HD static void col_steps(W64& acc0, W64& acc1, const El& a, El bs) {
     if constexpr (I < NL) {
       const i32 ai = at<I>(a);
+      W64& acc = (I & 1) ? acc1 : acc0;
       ELL_UNROLL
       for (int t = 0; t < CL; t++) acc.w[t] += (i64)ai * (i64)s(bs.v[t]);
-      if constexpr (I + 1 < NL) col_steps<I + 1>(acc, a, up1(bs));
+      if constexpr (I + 1 < NL) col_steps<I + 1>(acc0, acc1, a, up1(bs));
     }
   }
-  // one step of the reduction: column I made divisible by 2^RB (p = -1 mod 2^RB: m is the column's
-  // low digit and v + m (2^RB - 1) = ((v >> RB) + m) 2^RB)
-  template <int I>
-  ELL_HD static void redc_steps(W64& acc, i64& carry) {
-    if constexpr (I < NL) {
-      const El ps = c_pshift<I>();                     // p moved up I lanes: a per-lane CONSTANT (hoisted out of the ladders' loops)
-      const i64 v = at64<I>(acc) + carry;
-      const i32 m = (i32)((u32)v & M);
+  // + h_J * fold[J], J = 0 .. NL - 1: h_J = digit NL + J of the carried product
+  template <int J>
+  ELL_HD static void fold_steps(W64& acc0, W64& acc1, const El& d) {
+    if constexpr (J < NL) {
+      const El cj = c_fold<J>();                       // a per-lane CONSTANT (hoisted out of the ladders' loops)
+      const i32 h = at<NL + J>(d);
+      W64& acc = (J & 1) ? acc1 : acc0;
       ELL_UNROLL
-      for (int t = 0; t < CL; t++) acc.w[t] += (i64)m * (i64)s(ps.v[t]);
-      carry = (v >> RB) + (i64)m;
-      redc_steps<I + 1>(acc, carry);
+      for (int t = 0; t < CL; t++) acc.w[t] += (i64)h * (i64)s(cj.v[t]);
+      fold_steps<J + 1>(acc0, acc1, d);
     }
   }
-  ELL_HD static El redc(W64 acc) {
-    const El live = c_live();
-    i64 carry = 0;
-    redc_steps<0>(acc, carry);
-    // columns NL .. 2 NL - 1 are the result's digits (the carry out of column NL - 1 enters column NL):
-    // two carry passes where they stand -- 64-bit, then 32-bit; the top digit keeps its carries --
-    // then down NL lanes
-    W64 c1;
-    El lo1;
+  // one carry pass over 64-bit lanes: low RB bits stay, the rest moves one lane up.  KEEP: the
+  // lanes whose value stays whole (the top of the range: it takes the carries and hands none on)
+  ELL_HD static W64 carry64(const W64& x, const El& keep) {
+    W64 c, lo;
     ELL_UNROLL
-    for (int t = 0; t < CL; t++) { c1.w[t] = acc.w[t] >> RB; lo1.v[t] = (u32)acc.w[t] & M; }
-    W64 cin1 = up1_64(c1);
-    cin1 = put64<NL>(cin1, carry);                     // (lane NL - 1 is a reduced column: what it hands up is `carry`)
-    W64 v1;
+    for (int t = 0; t < CL; t++) {
+      const bool k = keep.v[t] != 0;
+      c.w[t] = k ? 0 : (x.w[t] >> RB);
+      lo.w[t] = k ? x.w[t] : (i64)((u32)x.w[t] & M);
+    }
+    const W64 cin = up1_64(c);
+    W64 r;
     ELL_UNROLL
-    for (int t = 0; t < CL; t++) v1.w[t] = (i64)lo1.v[t] + cin1.w[t];
-    // (only columns NL .. 2 NL - 2 hand a carry on: below them stand reduced columns, the top keeps its own)
-    const El hc = c_hi_carries();
-    El c2, r;
-    ELL_UNROLL
-    for (int t = 0; t < CL; t++) c2.v[t] = (u32)(i32)(v1.w[t] >> RB) & hc.v[t];
-    const El cin2 = up1(c2);
-    ELL_UNROLL
-    for (int t = 0; t < CL; t++) r.v[t] = ((u32)v1.w[t] & (M | ~hc.v[t])) + cin2.v[t];
-    const El dn = down_nl(r);
-    ELL_UNROLL
-    for (int t = 0; t < CL; t++) r.v[t] = dn.v[t] & live.v[t];
+    for (int t = 0; t < CL; t++) r.w[t] = lo.w[t] + cin.w[t];
     return r;
   }
   ELL_HD static W64 zero64() {
@@ -285,13 +251,69 @@ struct FpMontW {
     for (int t = 0; t < CL; t++) z.w[t] = 0;
     return z;
   }
+  // Column sums below 2^62 in lanes 0 .. 2 NL - 2 -> the product's residue, digits in [0, 2^28 + 2^5),
+  // value in [0, 2^PBITS + 2^(PBITS - 200)).
+  ELL_HD static El reduce(const W64& cols) {
+    const El live = c_live();
+    const El top2 = each([](int l) { return m_eq(l, 2 * NL - 1); });     // column 2 NL - 1: carries only
+    const El topn = each([](int l) { return m_eq(l, NL - 1); });
+    // 1. the columns as digits: two carry passes (64-bit sums -> below 2^28 + 2^34 -> below 2^28 + 2^7);
+    //    lane 2 NL - 1 collects what leaves column 2 NL - 2 (below 2^29)
+    W64 v = carry64(cols, top2);
+    v = carry64(v, top2);
+    El d;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) d.v[t] = (u32)v.w[t];
+    // 2. digits NL .. 2 NL - 1 fold onto 0 .. NL - 1: each is worth a constant vector (digits below 2^28):
+    //    NL products below 2^58 per lane
+    W64 f0, f1 = zero64();
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) f0.w[t] = (i64)s(d.v[t] & live.v[t]);
+    fold_steps<0>(f0, f1, d);
+    W64 f;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) f.w[t] = f0.w[t] + f1.w[t];
+#if defined(ELL_BOUNDS_CHECK)
+    check64(f, "fold");
+#endif
+    // 3. exact digits again (two passes; the top digit keeps everything above it: below 2^62), then
+    //    what stands above 2^PBITS -- t, 35 bits at most -- is worth t * top: t = t1 2^28 + t0
+    f = carry64(f, topn);
+    f = carry64(f, topn);
+    const i64 tv = at64<TL>(f);
+    const i64 tt = tv >> TB;
+    const i32 t0 = (i32)((u32)tt & M), t1 = (i32)(tt >> RB);
+    const El ct = c_top(), ct1 = c_top1();
+    W64 g;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) {
+      i64 x = f.w[t];
+      if (lane_of(t) == TL) x = (i64)((u64)x & (((u64)1 << TB) - 1));
+      x += (i64)t0 * (i64)s(ct.v[t]);
+      x += (i64)t1 * (i64)s(ct1.v[t]);
+      g.w[t] = x;
+    }
+#if defined(ELL_BOUNDS_CHECK)
+    check64(g, "top fold");
+#endif
+    // 4. digits once more: below 2^57 -> two passes
+    g = carry64(g, topn);
+    g = carry64(g, topn);
+    El r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) r.v[t] = (u32)g.w[t] & live.v[t];
+    return r;
+  }
   ELL_HD static El mul(const El& a, const El& b) {
 #if defined(ELL_BOUNDS_CHECK)
     check(a, b, "mul");
 #endif
-    W64 acc = zero64();
-    col_steps<0>(acc, a, b);
-    return redc(acc);
+    W64 acc0 = zero64(), acc1 = zero64();
+    col_steps<0>(acc0, acc1, a, b);
+    W64 acc;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) acc.w[t] = acc0.w[t] + acc1.w[t];
+    return reduce(acc);
   }
   ELL_HD static El sqr(const El& a) { return mul(a, a); }
 
@@ -314,7 +336,7 @@ struct FpMontW {
     if constexpr (I < NL) { d[I] = (i64)at<I>(a); gather_steps<I + 1>(d, a); }
   }
   // the value's canonical residue in [0, p) as exact digits -> L plain words
-  ELL_HD static void canon(u32 (&out)[L], const El& a) {
+  ELL_HD static void to_plain(u32 (&out)[L], const El& a) {
     i64 d[NL];
     gather_steps<0>(d, a);
     // value in (-p, 2p): + p, sequential carry, then up to two conditional subtractions of p
@@ -353,16 +375,14 @@ struct FpMontW {
     ELL_UNROLL
     for (int j = 0; j < L; j++) out[j] = w[j];
   }
-  // plain words of the element (out of Montgomery form): REDC of a * 1, canonical
-  ELL_HD static void to_plain(u32 (&out)[L], const El& a) { canon(out, mul(a, plain_one())); }
-  // wave-uniform plain words -> the element: digits times R^2, reduced
+  // wave-uniform plain words (any L-word value: it may exceed p) -> the element's digits
   ELL_HD static El from_plain(const u32 (&a)[L]) {
     u32 dig[NL];
     ELL_UNROLL
     for (int i = 0; i < NL; i++) {
       const int bit = RB * i, k = bit >> 5, sh = bit & 31;
       const u64 two = (u64)(k < L ? a[k] : 0u) | ((u64)(k + 1 < L ? a[k + 1] : 0u) << 32);
-      dig[i] = (u32)(two >> sh) & M;
+      dig[i] = (u32)(two >> sh) & (i == NL - 1 ? 0xFFFFFFFFu : M);     // (the top digit takes what is left of the words)
     }
     const El digs = each([&](int l) {
       u32 v = 0;
@@ -370,12 +390,13 @@ struct FpMontW {
       for (int i = 0; i < NL; i++) v |= m_eq(l, i) & dig[i];
       return (i32)v;
     });
-    return mul(digs, c_rr());
+    // (an ABI value may exceed p by a factor of 2^7 on p521 -- 66 bytes -- : a product with 1 reduces it)
+    return mul(digs, one());
   }
-  // L plain words in memory (an entry of the one-lane kernels' tables) -> the element: lane l reads
-  // the two words its digit straddles
+  // L plain words in memory (an entry of the one-lane kernels' tables: canonical) -> the element: lane l
+  // reads the two words its digit straddles
   ELL_HD static El load_words(const u32* w) {
-    const El digs = each([&](int l) {
+    return each([&](int l) {
       const int ll = l >= NL ? NL - 1 : l;
       const int bit = RB * ll;
       const int k = bit >> 5, sh = bit & 31;
@@ -384,16 +405,15 @@ struct FpMontW {
       const u64 two = (u64)lo | ((u64)hi << 32);
       return l >= NL ? 0 : (i32)((u32)(two >> sh) & M);
     });
-    return mul(digs, c_rr());
   }
   // Zero test.  Every value of the interface lies in (-p, 2p): it is 0 (mod p) iff it is 0 or p, and
-  // then digit 0's low bits are 0's or p's -- anything else (all but one value in 2^27) is not zero;
-  // the canonical digits decide the rest.  (Montgomery form keeps 0 at 0.)
+  // then digit 0's low bits are 0's or p's -- anything else is not zero; the canonical digits decide
+  // the rest.
   ELL_HD static bool is_zero(const El& a) {
     const u32 r0 = (u32)at<0>(a) & M;
     if (ELL_UNLIKELY(r0 == 0u || r0 == ((u32)MC::pd[0] & M))) {
       u32 w[L];
-      canon(w, a);
+      to_plain(w, a);
       return bn_is_zero<L>(w);
     }
     return false;

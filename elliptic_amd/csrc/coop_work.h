@@ -343,7 +343,7 @@ struct CoopK256 {
 // back to the curve whose a = -3 doubling the ladder needs) and u1*G by the comb -- joined by the
 // one-lane ecdsa_join2; Point#mul is the ladder alone, normalised by the one-lane kernel.
 // (p384 and p521 -- 14 / 19 digits: 27 / 37 product columns do not fit a 16-lane row -- take the
-// WIDE field, an element over the lanes of the whole wave: coop_wide.h FpMontW)
+// WIDE field, an element over the lanes of the whole wave: coop_wide.h FpFoldW)
 template <class CV1>
 struct CoopConsts { static constexpr bool AVAILABLE = false, WIDE = false; typedef consts::COOP_P256 MC; };
 template <> struct CoopConsts<CvP192> { static constexpr bool AVAILABLE = true, WIDE = false; typedef consts::COOP_P192 MC; };
@@ -354,7 +354,7 @@ template <> struct CoopConsts<CvP521> { static constexpr bool AVAILABLE = true, 
 template <bool WIDE, class MC, class F1>
 struct CoopField { typedef FpMontC<MC, F1> type; };
 template <class MC, class F1>
-struct CoopField<true, MC, F1> { typedef FpMontW<MC, F1> type; };
+struct CoopField<true, MC, F1> { typedef FpFoldW<MC, F1> type; };
 
 template <class CV1>
 struct CoopNist {

@@ -1349,13 +1349,12 @@ function install(elliptic, options) {
     groups.forEach(function(g) {
       var good = [], ms = [];
       var d = domain(g.ec.curve);
-      // G's tables: looked at once per batch (the calls of one tick see one state of the library)
-      if (!d || !tablesOK(g.ec.curve, g.ec.curve.g)) {
-        g.ps.forEach(function(p) {
+      function each(ps) {                  // every call by itself, through the (patched) synchronous path
+        ps.forEach(function(p) {
           try { p.resolve(g.ec.verify(p.item.msg, p.item.signature, p.item.key, p.item.enc, p.item.options)); } catch (e) { p.reject(e); }
         });
-        return;
       }
+      if (!d) return each(g.ps);
       g.ps.forEach(function(p) {           // a throwing item rejects alone
         try { ms.push(marshalOne(g.ec, d, p.item)); good.push(p); }
         catch (e) { p.reject(e); }
@@ -1365,7 +1364,13 @@ function install(elliptic, options) {
       eng.stats.coalescedItems = (eng.stats.coalescedItems || 0) + good.length;
       var m = packVerify(ms, g.hl, g.mb);
       m.o.status = Buffer.alloc(good.length);
-      eng.ecdsaVerifyBatchAsync(d.id, m.o).then(function(ok) {
+      var job = eng.ecdsaVerifyBatchAsync(d.id, m.o);
+      // G's tables: looked at once per batch (the calls of one tick see one state of the library),
+      // HERE -- in the tick of the calls, while the worker thread already runs the batch; a table
+      // that is not G's multiples leaves every call to the synchronous path, the batch's verdicts unused
+      var trusted = tablesOK(g.ec.curve, g.ec.curve.g);
+      if (!trusted) { job.catch(function() {}); return each(good); }
+      job.then(function(ok) {
         good.forEach(function(p, i) {
           try { p.resolve(verdict(g.ec, p.item, m.pre[i], m.ref[i] || m.o.status[i] === OFF_CURVE ? OFF_CURVE : ok[i])); } catch (e) { p.reject(e); }
         });

@@ -777,7 +777,12 @@ def test_small_batch_sign_on_the_row_layer(monkeypatch, curve):
         a = c1.ecdsa_sign(curve, z[:m], d[:m], kn[:m])
         b = c0.ecdsa_sign(curve, z[:m], d[:m], kn[:m])
         assert all(np.array_equal(x, y) for x, y in zip(a, b)), (curve, m)
-    assert not a[3][20:23].any() and a[3][23:25].all()           # k = 0, 1, n - 1 rejected; 2 and n - 2 signed
+    if curve != "p521":
+        assert not a[3][20:23].any() and a[3][23:25].all()       # k = 0, 1, n - 1 rejected; 2 and n - 2 signed
+    else:
+        # (a 66-byte nonce with a non-zero top byte goes through _truncateToN(K, true) first, ec/index.js:
+        # 153-156: n - 1 and n - 2 arrive shifted right by 7 bits -- ordinary nonces, signed)
+        assert not a[3][20:22].any() and a[3][22:25].all()
     assert PC.check_sign_golden(c1, curve) > 10 and PC.check_signdet_golden(c1, curve) > 10
     c0.close()
     c1.close()

@@ -36,6 +36,15 @@ def main():
         "p256 mul_fixed": lambda: ctx.mul_fixed("p256", r),
     }
     p256q = ctx.mul_fixed("p256", r)[0]
+    # the wide NIST curves (round 6: one item per wave on csrc/coop_wide.h)
+    for cname, nb in (("p384", 48), ("p521", 66)):
+        kk = np.frombuffer(bytes((7 * i + 3) & 0xFF for i in range(nb)), np.uint8).reshape(1, nb).copy()
+        kk[0, 0] &= 1
+        qq = ctx.mul_fixed(cname, kk)[0]
+        ops["%s ecdsa_verify (any tuple)" % cname] = (lambda c=cname, k=kk, q_=qq: ctx.ecdsa_verify(c, k, k, k, q_))
+        ops["%s mul_var" % cname] = (lambda c=cname, k=kk, q_=qq: ctx.mul_var(c, k, q_))
+        ops["%s mul_fixed" % cname] = (lambda c=cname, k=kk: ctx.mul_fixed(c, k))
+        ops["%s ecdsa_sign_det" % cname] = (lambda c=cname, k=kk: ctx.ecdsa_sign_det(c, k, k))
     for name, fn in ops.items():
         for _ in range(3):
             fn()
