@@ -70,6 +70,7 @@ _SIGS = {
     "ellgpu_mul_var_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
     "ellgpu_mul_add2_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
     "ellgpu_ecdsa_verify_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, c_u8p, ctypes.c_int, ctypes.c_int, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
+    "ellgpu_x25519_derive": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p]),
     "ellgpu_x25519_ladder_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, c_u8p, c_u8p, c_u8p, c_u8p, ctypes.c_void_p]),
     "ellgpu_ctx_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "ellgpu_ctx_get_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]),

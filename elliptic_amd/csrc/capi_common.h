@@ -340,6 +340,19 @@ int ellgpu_x25519_ladder(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint
   return finish(ctx, ctx->eng->x25519_host(n, k, in_x, out_x, out_inf));
 }
 
+int ellgpu_x25519_derive(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* in_x,
+                         uint8_t* out_x, uint8_t* out_status) {
+  ELL_ENTER(ctx, nullptr);
+  if (n && !out_status) return set_err(ELLGPU_E_ARG, "null buffer");
+  // (never deferred: the status bytes are put together on the host)
+  ctx->eng->defer_collect();
+  std::vector<uint8_t> inf(n ? n : 1);
+  const int rc = ctx->eng->x25519_host(n, k, in_x, out_x, inf.data(), out_status);
+  if (!rc)
+    for (size_t i = 0; i < n; i++) out_status[i] = out_status[i] ? 1 : (inf[i] ? 2 : 0);
+  return finish(ctx, rc);
+}
+
 int ellgpu_decompress(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* v, const uint8_t* odd,
                       uint8_t* out_xy, uint8_t* out_ok) {
   ELL_ENTER(ctx, nullptr);

@@ -54,6 +54,17 @@ namespace ell {
 // taken), for about the instructions the PR = false form spends on ONE item (it pays for packing
 // and unpacking its Qs) -- the layer for batches that four waves per SIMD of one-item waves no
 // longer hold (Engine::Tuning::row_grid).
+// The rows / lanes of a wave as a functor of the one-item-per-ROW layer walks them: on the device a
+// lane IS one row / one lane (the loop body runs once, for this thread's); host passes walk all four
+// rows / sixty-four lanes, one after the other.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ELL_FOR_ROWS(r) for (int r = (int)(threadIdx.x >> 4), r##_once_ = 1; r##_once_; r##_once_ = 0)
+#define ELL_FOR_WAVE_LANES(l) for (int l = (int)(threadIdx.x & 63u), l##_once_ = 1; l##_once_; l##_once_ = 0)
+#else
+#define ELL_FOR_ROWS(r) for (int r = 0; r < 4; r++)
+#define ELL_FOR_WAVE_LANES(l) for (int l = 0; l < 64; l++)
+#endif
+
 template <bool PR>
 struct FpK256CT {
   static constexpr bool PER_ROW = PR;

@@ -500,6 +500,14 @@ struct CoopX25519 {
       }
     }
   }
+  // KeyPair#derive's pub.validate() (ec/key.js:102-105 -> mont.js:23-32) for one item on a wave of
+  // its own, beside the ladder's: mont.h MontWork::x_has_point over the row field
+  ELL_HD static void validate(size_t i, const u8* xs, u8* out_bad) {
+    u32 t[8];
+    load_be<8>(t, xs + i * 32, 32);
+    const bool ok = W1::template x_has_point<F>(t);
+    if (CoopK256::writer()) out_bad[i] = ok ? 0 : 1;
+  }
 };
 
 }  // namespace ell

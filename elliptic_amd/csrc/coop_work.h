@@ -97,16 +97,19 @@ ELL_HD void coop_sign_point(size_t i, const u8* nonces, const typename CW::W1::A
   }
 }
 
-struct CoopK256 {
-  typedef CvSecp256k1C CV;
-  typedef FpK256C F;
-  typedef F::El El;
+// PR = false: one item per WAVE (FpK256C); PR = true: one item per ROW, four items per wave
+// (FpK256R -- coop.h; batches between Tuning::coop_grid and Tuning::row_grid)
+template <bool PR>
+struct CoopK256T {
+  typedef CvSecp256k1CT<PR> CV;
+  typedef FpK256CT<PR> F;
+  typedef typename F::El El;
   typedef ShortOps<CV> G;
   typedef Ladder<CV> LD;
   typedef Jac<F> J;
   typedef Aff<F> A;
   typedef Work<CvSecp256k1> W1;                      // the one-lane layer: geometry, table and result formats
-  typedef W1::Endo<true> E;                          // the small-grid tuning's windows (5 bits)
+  typedef typename W1::template Endo<true> E;                          // the small-grid tuning's windows (5 bits)
   // the row layer reads and writes the SATURATED field's tables and results; the ELL_K256_LAZY
   // build (one-lane kernels on fpk256l.h) keeps its small batches on the one-lane parts
   static constexpr bool AVAILABLE = std::is_same<CvSecp256k1::F, FpK256>::value;
@@ -114,28 +117,31 @@ struct CoopK256 {
   static constexpr int SLOTS = 2 * E::NE;
   // bytes of row memory a unit needs (k_run_coop's LDS / the host loop's stack): SLOTS entries of
   // every lane of the row
-  static constexpr int ROW_BYTES = SLOTS * FpK256C::ROW * 16;
-  static_assert(sizeof(A) * (16 / FpK256C::CL) <= 256 && sizeof(A) * SLOTS * (FpK256C::CL == 1 ? 16 : 1) <= (size_t)ROW_BYTES, "row memory too small");
+  // (one item per row: the device keeps a table per LANE of the wave -- 64 of them; host passes walk the
+  // rows one after the other through the same memory)
+  static constexpr int TLANES = PR ? 64 : 16;
+  static constexpr int ROW_BYTES = SLOTS * TLANES * 16;
+  static_assert(sizeof(A) * SLOTS * (F::CL == 1 ? TLANES : 1) <= (size_t)ROW_BYTES, "row memory too small");
 
   // this lane's table: SLOTS entries of its own
   ELL_HD static A* lane_table(void* row_mem) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return (A*)row_mem + (size_t)(threadIdx.x & 15u) * SLOTS;
+    return (A*)row_mem + (size_t)(threadIdx.x & (unsigned)(TLANES - 1)) * SLOTS;
 #else
     return (A*)row_mem;
 #endif
   }
-  // does this thread store the (wave-uniform) results?
+  // does this thread store the results (wave-uniform; per row when every row has an item of its own)?
   ELL_HD static bool writer() {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return threadIdx.x == 0;
+    return PR ? (threadIdx.x & 15u) == 0 : threadIdx.x == 0;
 #else
     return true;
 #endif
   }
 
   // a point in the one-lane kernels' memory format (Aff<FpK256>: x, y as eight plain words) -> the row
-  ELL_HD static A load_entry(const W1::A* e) {
+  ELL_HD static A load_entry(const typename W1::A* e) {
     A q;
     q.x = F::load_words(e->x.v);
     q.y = F::load_words(e->y.v);
@@ -185,7 +191,7 @@ struct CoopK256 {
 
   // ---- EC#verify, parts 0 and 1: k1*Q or k2*(lambda Q) over the table ecdsa_prep_table built ----
   // (work.h ecdsa_half; the sum stays on the table's isomorphic curve, ecdsa_join scales Z by zg)
-  ELL_HD static void ecdsa_half(size_t i, size_t n, int half, const u32* u12, const W1::VT* tbl_all,
+  ELL_HD static void ecdsa_half(size_t i, size_t n, int half, const u32* u12, const typename W1::VT* tbl_all,
                                 const DigitStore& ds, u32* jac, void* row_mem) {
     u32 u2[8];
     ELL_UNROLL
@@ -193,7 +199,7 @@ struct CoopK256 {
     const bool lam = half != 0;
     const u32 negmask = half_digits(u2, lam, ds) ? 1u : 0u;
     A* tbl = lane_table(row_mem);
-    const W1::VT* src = tbl_all + i * W1::stride<true>();
+    const typename W1::VT* src = tbl_all + i * W1::template stride<true>();
     ELL_NOUNROLL
     for (int e = 0; e < E::NE; e++) tbl[e] = load_entry(src + e);
     El beta = load_beta();
@@ -218,11 +224,11 @@ struct CoopK256 {
       for (int l = 0; l < N; l++) dst[l] = l < 8 ? w[l] : 0u;
     }
   }
-  ELL_HD static void ecdsa_table(size_t i, const u8* pub_xy, W1::VT* tbl_all, void* row_mem) {
+  ELL_HD static void ecdsa_table(size_t i, const u8* pub_xy, typename W1::VT* tbl_all, void* row_mem) {
     A* tbl = lane_table(row_mem);
     El zg;
     LD::template build_table_odd8<E::NE>(tbl, load_affine(pub_xy, i), zg);
-    W1::VT* dst = tbl_all + i * W1::stride<true>();
+    typename W1::VT* dst = tbl_all + i * W1::template stride<true>();
     ELL_NOUNROLL
     for (int e = 0; e < E::NE; e++) {
       store_words(dst[e].x.v, tbl[e].x);
@@ -232,9 +238,9 @@ struct CoopK256 {
   }
 
   // ---- fixed base: k*G over the one-lane comb table ----
-  ELL_HD static J comb_mul(const u32 (&k)[8], const W1::A* comb) { return coop_comb_mul<CoopK256>(k, comb); }
+  ELL_HD static J comb_mul(const u32 (&k)[8], const typename W1::A* comb) { return coop_comb_mul<CoopK256T<PR>>(k, comb); }
   // EC#verify, part 2: u1*G
-  ELL_HD static void ecdsa_fixed(size_t i, size_t n, const u32* u12, const W1::A* comb, u32* jac) {
+  ELL_HD static void ecdsa_fixed(size_t i, size_t n, const u32* u12, const typename W1::A* comb, u32* jac) {
     u32 u1[8];
     ELL_UNROLL
     for (int l = 0; l < 8; l++) u1[l] = u12[(size_t)(0 * W1::LN + l) * n + i];
@@ -258,7 +264,7 @@ struct CoopK256 {
     store_jac(jac, n, i, b);
   }
   // third part of k1*G + k2*P: the comb of k1
-  ELL_HD static void mul_fixed_part(size_t i, size_t n, const u8* ks, const W1::A* comb, u32* jac) {
+  ELL_HD static void mul_fixed_part(size_t i, size_t n, const u8* ks, const typename W1::A* comb, u32* jac) {
     u32 k[8];
     load_be<8>(k, ks + i * 32, 32);
     store_jac(jac, n, i, comb_mul(k, comb));
@@ -335,6 +341,8 @@ struct CoopK256 {
     decompress_words(i, r, (jj & 1u) != 0, out_xy, out_ok);
   }
 };
+typedef CoopK256T<false> CoopK256;
+typedef CoopK256T<true> CoopK256R;
 
 
 // ---- the NIST curves up to 256 bits on the row layer (coop_mont.h) --------------------------------

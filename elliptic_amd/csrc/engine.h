@@ -376,6 +376,74 @@ struct FnMulPartsC {
   }
 };
 
+// The same parts with ONE ITEM PER ROW of the wave (coop.h FpK256R, coop_work.h CoopK256R): four
+// items per unit, for batches between Tuning::coop_grid and Tuning::row_grid -- too many for a wave
+// per part (that layer holds 1 365 verifies at four waves per SIMD), too few for the
+// one-item-per-lane kernels, whose chain is 4.4x longer (one 128-bit ladder: 573 us on a lone
+// one-lane wave, 130 us on the row layer; 4 096 verifies used 192 of the 1 024 SIMDs).
+// Unit u of a part takes items 4 u .. 4 u + 3; rows past the end redo the last item.
+ELL_HD size_t row_item(size_t group, int row, size_t n) {
+  const size_t i = group * 4 + (size_t)row;
+  return i < n ? i : n - 1;
+}
+struct FnEcdsaPartsR {
+  static constexpr const char* NAME = "ecdsa_parts_r";
+  typedef Work<CvSecp256k1> W;
+  static constexpr int DS_PER_LANE = CoopK256R::E::NW;
+  static constexpr int ROW_BYTES = CoopK256R::ROW_BYTES;
+  size_t n; const u32* u12; const typename W::A* comb; const typename W::VT* tbl; u32* jac;
+  ELL_HD void operator()(size_t unit, const DigitStore& ds, void* row_mem) const {
+    const size_t groups = (n + 3) / 4;
+    const int part = (int)(unit / groups);
+    const size_t g = unit - (size_t)part * groups;
+    u32* out = jac + (size_t)part * 3 * W::NS * n;
+    ELL_FOR_ROWS(row) {
+      const size_t i = row_item(g, row, n);
+      if (part == 2) CoopK256R::ecdsa_fixed(i, n, u12, comb, out);
+      else CoopK256R::ecdsa_half(i, n, part, u12, tbl, ds, out, row_mem);
+    }
+  }
+};
+// in front of them, ONE launch: the first units run the scalar-field prep one item per LANE (the
+// one-lane code: 64 items per wave, one inversion each -- the chain counts), the others build the
+// window tables of the keys four per wave
+struct FnEcdsaPrepTableR {
+  static constexpr const char* NAME = "ecdsa_prep_table_r";
+  typedef Work<CvSecp256k1> W;
+  static constexpr int DS_PER_LANE = 0;
+  static constexpr int ROW_BYTES = CoopK256R::ROW_BYTES;
+  size_t n; size_t prep_units; const u8* hash; int hash_len; int shift; const u8* r; const u8* s;
+  u32* pre; u32* u12; u8* valid; const u8* pub; typename W::VT* tbl;
+  ELL_HD void operator()(size_t unit, const DigitStore&, void* row_mem) const {
+    if (unit < prep_units) {
+      ELL_FOR_WAVE_LANES(lane) {
+        size_t t = unit * 64 + (size_t)lane;
+        if (fill_lane(t, n)) W::ecdsa_prep(t, n, n, 1, hash, hash_len, shift, r, s, pre, u12, valid);
+      }
+    } else {
+      ELL_FOR_ROWS(row) CoopK256R::ecdsa_table(row_item(unit - prep_units, row, n), pub, tbl, row_mem);
+    }
+  }
+};
+struct FnMulPartsR {
+  static constexpr const char* NAME = "mul_parts_r";
+  typedef Work<CvSecp256k1> W;
+  static constexpr int DS_PER_LANE = CoopK256R::E::NW;
+  static constexpr int ROW_BYTES = CoopK256R::ROW_BYTES;
+  size_t n; const u8* k; const u8* xy; u32* jac; const u8* kg; const typename W::A* comb;
+  ELL_HD void operator()(size_t unit, const DigitStore& ds, void* row_mem) const {
+    const size_t groups = (n + 3) / 4;
+    const int part = (int)(unit / groups);
+    const size_t g = unit - (size_t)part * groups;
+    u32* out = jac + (size_t)part * 3 * W::NS * n;
+    ELL_FOR_ROWS(row) {
+      const size_t i = row_item(g, row, n);
+      if (part == 2) CoopK256R::mul_fixed_part(i, n, kg, comb, out);
+      else CoopK256R::mul_half(i, n, part, k, xy, ds, out, row_mem);
+    }
+  }
+};
+
 // ... and for the NIST curves up to 256 bits (coop_mont.h, coop_work.h CoopNist): a verify is two
 // units (u2*Q ladder, u1*G comb), a Point#mul one, k1*G + k2*P two
 template <class CV>
@@ -779,8 +847,20 @@ struct FnX25519C {
   static constexpr const char* NAME = "x25519_c";
   static constexpr int DS_PER_LANE = 0;
   static constexpr int ROW_BYTES = CoopX25519::ROW_BYTES;
-  size_t n; const u8* k; const u8* x; u32* xz;
-  ELL_HD void operator()(size_t i, const DigitStore&, void*) const { CoopX25519::ladder(i, n, k, x, xz); }
+  // bad != null (KeyPair#derive): units n .. 2 n - 1 test the abscissas beside the ladders
+  size_t n; const u8* k; const u8* x; u32* xz; u8* bad;
+  ELL_HD void operator()(size_t i, const DigitStore&, void*) const {
+    if (i < n) CoopX25519::ladder(i, n, k, x, xz);
+    else CoopX25519::validate(i - n, x, bad);
+  }
+};
+struct FnX25519Validate {
+  static constexpr const char* NAME = "x25519_validate";
+  static constexpr int DS_PER_LANE = 0;
+  size_t n; const u8* x; u8* bad;
+  ELL_HD void operator()(size_t i, const DigitStore&) const {
+    if (i < n) MontWork::validate(i, x, bad);
+  }
 };
 struct FnEddsaJoin {
   static constexpr const char* NAME = "eddsa_join";
@@ -972,6 +1052,7 @@ class Engine {
     bool split_verify;
     size_t parted_grid;       // largest batch that takes the parted verify (three lanes per item)
     size_t coop_grid;         // largest batch whose parts run on the lanes-per-item layer (a wave per part)
+    size_t row_from, row_grid;  // batches of row_from < n <= row_grid items run their parts one item per ROW (four items per wave)
     size_t comb_max_bytes;    // ELLGPU_COMB_MAX_BYTES: fixed-base tables above this are treated as unallocatable (0 = no limit)
     int prep_k;
     int norm_k;
@@ -992,6 +1073,14 @@ class Engine {
     //                   that the waves share SIMDs and the one-lane parts (64 items per wave) win
     e = getenv("ELLGPU_COOP_GRID");
     tune_.coop_grid = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)bk.compute_units() * 4 * 4 / 3;
+    // One item per row (four items per wave, a wave 1.3x as long as the one-item wave): measured
+    // (profiles/r06_latency_rows_ab.txt) it passes the wave-per-part form at ~2.5 items per CU -- 768
+    // verifies 382 -> 310 us -- and holds against the one-lane parted form's single 573-us chain up to
+    // ~18 per CU: 4 096 verifies 768 -> 608 us, 4 778 a tie.  ELLGPU_ROW_FROM / ELLGPU_ROW_GRID.
+    e = getenv("ELLGPU_ROW_FROM");
+    tune_.row_from = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)bk.compute_units() * 5 / 2;
+    e = getenv("ELLGPU_ROW_GRID");
+    tune_.row_grid = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)bk.compute_units() * 18;
     e = getenv("ELLGPU_COMB_MAX_BYTES");
     tune_.comb_max_bytes = e ? (size_t)strtoull(e, nullptr, 10) : 0;
     e = getenv("ELLGPU_PREP_K");
@@ -1003,6 +1092,10 @@ class Engine {
   bool split_small_verify() const { return tune_.split_verify; }
   size_t parted_grid() const { return tune_.parted_grid; }
   size_t coop_grid() const { return CoopK256::AVAILABLE ? tune_.coop_grid : 0; }
+  size_t row_grid() const { return CoopK256::AVAILABLE ? tune_.row_grid : 0; }
+  // do the parts of a secp256k1 verify / Point#mul of n items run one item per row?  (else one item per
+  // wave up to coop_grid, one item per lane above)
+  bool rows_for(size_t n) const { return CoopK256::AVAILABLE && n > tune_.row_from && n <= tune_.row_grid; }
   // window width of the curve's fixed-base table in use (0 = not built; ellgpu_ctx_comb_bits)
   int comb_bits(int curve) const {
     if (curve < 0 || curve >= CURVE_COUNT || !comb_[curve]) return 0;
@@ -1051,7 +1144,7 @@ class Engine {
   // ---- scratch arena: a few grow-only device buffers ----------------------
   struct Buf { void* p = nullptr; size_t cap = 0; };
   enum { S_TBL = 0, S_JAC, S_PRE, S_U12, S_VALID, S_WIRE, S_COUNT };
-  enum { G_IN0 = 0, G_IN1, G_IN2, G_IN3, G_IN4, G_OUT0, G_OUT1, G_COUNT };
+  enum { G_IN0 = 0, G_IN1, G_IN2, G_IN3, G_IN4, G_OUT0, G_OUT1, G_OUT2, G_COUNT };
 
   void* grow(Buf& b, size_t bytes) {
     if (bytes <= b.cap) return b.p;
@@ -1106,7 +1199,7 @@ class Engine {
   int ed_mul_add2_chunk(size_t n, const u8* k1, const u8* xy1, const u8* k2, const u8* xy2,
                         u8* out_xy, u8* out_inf);
   template <int U = 0>
-  int x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf);
+  int x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf, u8* out_bad);
   // user-defined Edwards curves: op 0 = k*P, 1 = k1*P1 + k2*P2, 2 = P1 + P2 (a, b = the inf flags)
   template <int U = 0>
   int edc_chunk(int op, size_t n, const u8* k1, const u8* xy1, const u8* k2, const u8* xy2,
@@ -1448,12 +1541,13 @@ class Engine {
     return E_OK;
   }
 
-  int x25519_dev(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf) {
+  // out_bad (may be null): out_bad[i] = 1 where x[i] is no abscissa of the curve (KeyPair#derive's validate)
+  int x25519_dev(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf, u8* out_bad = nullptr) {
     if (n && (!k || !x || !out_x || !out_inf)) return fail(E_ARG, "null pointer");
     int rc = E_OK;
     for (size_t o = 0; o < n; o += CHUNK) {
       size_t m = n - o < CHUNK ? n - o : CHUNK;
-      rc = x25519_chunk(m, k + o * 32, x + o * 32, out_x + o * 32, out_inf + o);
+      rc = x25519_chunk(m, k + o * 32, x + o * 32, out_x + o * 32, out_inf + o, out_bad ? out_bad + o : nullptr);
       if (rc) return rc;
     }
     return E_OK;
@@ -2266,17 +2360,18 @@ class Engine {
                               dq + o * 2 * B, dok + o, dst ? dst + o : nullptr);
     });
   }
-  int x25519_host(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf) {
+  int x25519_host(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf, u8* out_bad = nullptr) {
     if (n && (!k || !x || !out_x || !out_inf)) return fail(E_ARG, "null pointer");
     u8* dk = out_buf(G_IN0, n * 32);
     u8* dx = out_buf(G_IN1, n * 32);
     u8* dox = out_buf(G_OUT0, n * 32);
     u8* dinf = out_buf(G_OUT1, n);
-    if (!dk || !dx || !dox || !dinf) return fail(E_NOMEM, "staging allocation failed");
+    u8* dbad = out_bad ? out_buf(G_OUT2, n) : nullptr;
+    if (!dk || !dx || !dox || !dinf || (out_bad && !dbad)) return fail(E_NOMEM, "staging allocation failed");
     HostIn ins[2] = {{dk, k, 32}, {dx, x, 32}};
-    HostOut outs[2] = {{out_x, dox, 32}, {out_inf, dinf, 1}};
-    return pipelined(n, ins, 2, outs, 2, [&](size_t o, size_t m) {
-      return x25519_dev(m, dk + o * 32, dx + o * 32, dox + o * 32, dinf + o);
+    HostOut outs[3] = {{out_x, dox, 32}, {out_inf, dinf, 1}, {out_bad, dbad, 1}};
+    return pipelined(n, ins, 2, outs, out_bad ? 3 : 2, [&](size_t o, size_t m) {
+      return x25519_dev(m, dk + o * 32, dx + o * 32, dox + o * 32, dinf + o, dbad ? dbad + o : nullptr);
     });
   }
 
@@ -2408,9 +2503,12 @@ int Engine<BK>::mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u
   bool launched = false;
   if constexpr (CV::ENDO && W::L <= 8) {
     if (parted) {                           // most SIMDs would idle: two lanes per item, then the join
-      if (n <= coop_grid()) {               // ... or two WAVES per item (coop.h)
+      if (!rows_for(n) && n <= coop_grid()) {   // ... or two WAVES per item (coop.h)
         FnMulPartsC fc{n, k, xy, jac, nullptr, nullptr};
         bk.launch_coop(fc, 2 * n);
+      } else if (rows_for(n)) {             // ... or one ROW per item and half: four items per wave
+        FnMulPartsR fr{n, k, xy, jac, nullptr, nullptr};
+        bk.launch_coop(fr, 2 * ((n + 3) / 4));
       } else {
       const size_t npad = (n + 127) & ~(size_t)127;            // whole workgroups per half
       FnMulParts<CV> fp{n, npad, k, xy, tbl, jac, nullptr, nullptr};
@@ -2509,9 +2607,12 @@ int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* 
       u32* pj = (u32*)scratch(S_JAC, 3 * n * 3 * W::NS * 4);
       typename W::VT* pt = (typename W::VT*)scratch(S_TBL, 2 * n * (size_t)W::template stride<true>() * sizeof(typename W::VT));
       if (!pt || !pj) return fail(E_NOMEM, "scratch allocation failed");
-      if (n <= coop_grid()) {
+      if (!rows_for(n) && n <= coop_grid()) {
         FnMulPartsC fc{n, k2, xy2, pj, k1, (const typename W::A*)comb_[CV::ID]};
         bk.launch_coop(fc, 3 * n);
+      } else if (rows_for(n)) {
+        FnMulPartsR fr{n, k2, xy2, pj, k1, (const typename W::A*)comb_[CV::ID]};
+        bk.launch_coop(fr, 3 * ((n + 3) / 4));
       } else {
       const size_t npad = (n + 127) & ~(size_t)127;
       FnMulParts<CV> fp{n, npad, k2, xy2, pt, pj, k1, (const typename W::A*)comb_[CV::ID]};
@@ -2615,10 +2716,15 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
       const int Ks = inv_batch_beside(n, INV_BATCH_N);
       const size_t Ts = (n + Ks - 1) / Ks;
       const size_t tpad = (Ts + 127) & ~(size_t)127;          // whole workgroups of either kind
-      if (n <= parted_grid() && n <= coop_grid()) {
+      const bool rows = n <= parted_grid() && rows_for(n);                           // one item per row
+      if (!rows && n <= parted_grid() && n <= coop_grid()) {
         // a handful of items: the prep on a wave per item, the table on another (row layer), one launch
         FnEcdsaPrepTableC fptc{n, hash, hash_len, shift, r, s, pre, u12, valid, pub, tbl};
         bk.launch_coop(fptc, 2 * n);
+      } else if (rows) {
+        const size_t pu = (n + 63) / 64;
+        FnEcdsaPrepTableR fptr{n, pu, hash, hash_len, shift, r, s, pre, u12, valid, pub, tbl};
+        bk.launch_coop(fptr, pu + (n + 3) / 4);
       } else {
         FnEcdsaPrepTable<CV> fpt{{Ts, n, Ks, hash, hash_len, shift, r, s, pre, u12, valid}, tpad, {n, pub, tbl}};
         launch_fn(fpt, tpad + n);
@@ -2627,10 +2733,13 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
         // most SIMDs would idle beside this batch: three lanes per item (FnEcdsaParts), then the join
         u32* jac = (u32*)scratch(S_JAC, n * 3 * 3 * W::NS * 4);
         if (!jac) return fail(E_NOMEM, "scratch allocation failed");
-        if (n <= coop_grid()) {
+        if (!rows && n <= coop_grid()) {
           // a handful of items: every part on a wave of its own, lanes-per-item arithmetic
           FnEcdsaPartsC fc{n, u12, (const typename W::A*)comb_[CV::ID], tbl, jac};
           bk.launch_coop(fc, 3 * n);
+        } else if (rows) {
+          FnEcdsaPartsR fr{n, u12, (const typename W::A*)comb_[CV::ID], tbl, jac};
+          bk.launch_coop(fr, 3 * ((n + 3) / 4));
         } else {
         const size_t npad = (n + 127) & ~(size_t)127;          // whole workgroups per part
         FnEcdsaParts<CV> fp{n, npad, u12, (const typename W::A*)comb_[CV::ID], tbl, jac};
@@ -2791,16 +2900,20 @@ int Engine<BK>::ed_mul_add2_chunk(size_t n, const u8* k1, const u8* xy1, const u
 
 template <class BK>
 template <int U>
-int Engine<BK>::x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf) {
+int Engine<BK>::x25519_chunk(size_t n, const u8* k, const u8* x, u8* out_x, u8* out_inf, u8* out_bad) {
   u32* xz = (u32*)scratch(S_JAC, n * 2 * 8 * 4);
   u32* pre = (u32*)scratch(S_PRE, n * 8 * 4);
   if (!xz || !pre) return fail(E_NOMEM, "scratch allocation failed");
   if (n <= coop_grid()) {
-    FnX25519C fc{n, k, x, xz};
-    bk.launch_coop(fc, n);
+    FnX25519C fc{n, k, x, xz, out_bad};
+    bk.launch_coop(fc, out_bad ? 2 * n : n);
   } else {
     FnX25519 f{n, k, x, xz};
     bk.launch(f, n);
+    if (out_bad) {
+      FnX25519Validate fv{n, x, out_bad};
+      bk.launch(fv, n);
+    }
   }
   const int K = norm_batch_for(n);
   size_t T = (n + K - 1) / K;

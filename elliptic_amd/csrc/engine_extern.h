@@ -102,7 +102,7 @@ namespace ell {
   KW template int Engine<HipBackend>::ed_mul_add2_chunk<0>(size_t, const u8*, const u8*,     \
                                                            const u8*, const u8*, u8*, u8*);
 #define ELL_DECL_X(KW) \
-  KW template int Engine<HipBackend>::x25519_chunk<0>(size_t, const u8*, const u8*, u8*, u8*);
+  KW template int Engine<HipBackend>::x25519_chunk<0>(size_t, const u8*, const u8*, u8*, u8*, u8*);
 
 // everything is extern by default ...
 #define ELL_EXT_ALL(CV) \

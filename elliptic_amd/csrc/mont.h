@@ -29,6 +29,31 @@ struct MontWork {
     bn_select<8>(r.z.v, c, a.z.v, b.z.v);
     return r;
   }
+  // MontCurve#validate (mont.js:23-32): is x^3 + a x^2 + x a square?  The reference takes the root
+  // (bn.js Red#sqrt: 0 for 0, Tonelli-Shanks otherwise -- which THROWS 'Assertion failed' on a
+  // non-residue, dist/elliptic.js:7242-7302) and squares it back.  Here Euler's criterion:
+  // rhs^((p-1)/2) = (rhs^(2^252-3))^4 rhs^2.  a = 4 a24 - 2.  F: Fp25519 or the row field Fp25519C.
+  template <class FF>
+  ELL_HD static bool x_has_point(const u32 (&xw)[8]) {
+    typedef typename FF::El E;
+    u32 aw[8] = {4u * C::a24[0] - 2u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    const E x = FF::from_plain(xw);
+    const E rhs = FF::mul(x, FF::add(FF::add(FF::sqr(x), FF::mul(x, FF::from_plain(aw))), FF::one()));
+    const E w = FF::pow22523(rhs);
+    const E e = FF::mul(FF::sqr(FF::sqr(w)), FF::sqr(rhs));
+    u32 ew[8], rw[8];
+    FF::to_plain(ew, e);
+    FF::to_plain(rw, rhs);
+    bool one = ew[0] == 1u;
+    ELL_UNROLL
+    for (int l = 1; l < 8; l++) one = one && ew[l] == 0u;
+    return one || bn_is_zero<8>(rw);
+  }
+  ELL_HD static void validate(size_t i, const u8* xs, u8* out_bad) {
+    u32 t[8];
+    load_be<8>(t, xs + i * 32, 32);
+    out_bad[i] = x_has_point<F>(t) ? 0 : 1;
+  }
   // a24 = (a + 2) / 4 = 121666 is a one-limb constant on curve25519: a 1 x 8 limb product
   static_assert(C::a24[1] == 0 && C::a24[2] == 0 && C::a24[3] == 0 && C::a24[4] == 0 && C::a24[5] == 0 &&
                 C::a24[6] == 0 && C::a24[7] == 0, "a24 must fit one limb");

@@ -589,6 +589,19 @@ class Context:
                                                       None if out_status is None else out_status.data_ptr(),
                                                       self._stream()))
 
+    def x25519_derive(self, k, x):
+        """KeyPair#derive on curve25519 per item: validate (is x an abscissa of the curve?) and the
+        ladder in one call -> (out_x (n, 32), status (n,)): 0 shared secret, 1 x has no point (the
+        reference throws 'Assertion failed' out of its square root), 2 the product is infinity"""
+        k = _u8(k, (-1, 32))
+        n = k.shape[0]
+        x = _u8(x, (n, 32))
+        out = np.zeros((n, 32), np.uint8)
+        st = np.zeros(n, np.uint8)
+        self._check(self._lib.ellgpu_x25519_derive(self._ctx, n, k.ctypes.data, x.ctypes.data, out.ctypes.data,
+                                                   st.ctypes.data))
+        return out, st
+
     def x25519_dev(self, k, x, out_x, out_inf):
         n = k.shape[0]
         self._check(self._lib.ellgpu_x25519_ladder_dev(self._ctx, n, k.data_ptr(), x.data_ptr(),

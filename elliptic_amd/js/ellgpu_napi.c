@@ -23,6 +23,7 @@
  *           mulAdd2(ctx, curve, k1, p1|null, k2, p2) -> {xy, inf}
  *           ecdsaVerify(ctx, curve, hash, hashLen, msgBits, r, s, pub) -> {ok, status}
  *           x25519(ctx, k, x) -> {x, inf}
+ *           x25519Derive(ctx, k, x) -> {x, status}   (KeyPair#derive: validate + ladder, one call)
  *           decompress(ctx, curve, v, odd) -> {xy, ok}
  *           ecdsaSign(ctx, curve, hash, hashLen, msgBits, priv, nonces, canonical)
  *             -> {r, s, recid, ok}
@@ -86,6 +87,7 @@ static struct {
   int (*ecdsa_verify)(ellgpu_ctx*, int, size_t, const uint8_t*, int, int, const uint8_t*,
                       const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
   int (*x25519)(ellgpu_ctx*, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
+  int (*x25519_derive)(ellgpu_ctx*, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
   int (*decompress)(ellgpu_ctx*, int, size_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*);
   int (*ecdsa_sign)(ellgpu_ctx*, int, size_t, const uint8_t*, int, int, const uint8_t*, const uint8_t*,
                     int, uint8_t*, uint8_t*, uint8_t*, uint8_t*);
@@ -149,6 +151,7 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   SYM(define_edwards, "ellgpu_curve_define_edwards");
   SYM(ctx_destroy, "ellgpu_ctx_destroy"); SYM(mul_fixed, "ellgpu_mul_fixed"); SYM(mul_var, "ellgpu_mul_var");
   SYM(mul_add2, "ellgpu_mul_add2"); SYM(ecdsa_verify, "ellgpu_ecdsa_verify"); SYM(x25519, "ellgpu_x25519_ladder");
+  SYM(x25519_derive, "ellgpu_x25519_derive");
   SYM(decompress, "ellgpu_decompress");
   SYM(eddsa_verify, "ellgpu_eddsa_verify");
   SYM(eddsa_sign, "ellgpu_eddsa_sign");
@@ -425,6 +428,23 @@ static napi_value fn_x25519(napi_env env, napi_callback_info info) {
   CHECK(env, result_buffer(env, n, &dinf, &binf));
   if (L.x25519(c, n, k, x, (uint8_t*)dx, (uint8_t*)dinf) != 0) return lib_error(env);
   return mk_result(env, "x", bx, "inf", binf);
+}
+
+/* x25519Derive(ctx, k, x) -> {x, status}: KeyPair#derive on curve25519 (ellgpu_x25519_derive) */
+static napi_value fn_x25519_derive(napi_env env, napi_callback_info info) {
+  if (!need_lib(env)) return NULL;
+  size_t argc = 3; napi_value argv[3];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  ellgpu_ctx* c = get_ctx(env, argv[0]); if (!c) return NULL;
+  const uint8_t *k, *x; size_t lk, lx;
+  if (!get_buf(env, argv[1], &k, &lk, 0) || !get_buf(env, argv[2], &x, &lx, 0)) return NULL;
+  if (lk % 32 || lx != lk) THROW(env, "buffer length mismatch");
+  size_t n = lk / 32;
+  napi_value bx, bst; void *dx, *dst;
+  CHECK(env, result_buffer(env, n * 32, &dx, &bx));
+  CHECK(env, result_buffer(env, n, &dst, &bst));
+  if (L.x25519_derive(c, n, k, x, (uint8_t*)dx, (uint8_t*)dst) != 0) return lib_error(env);
+  return mk_result(env, "x", bx, "status", bst);
 }
 
 static napi_value fn_decompress(napi_env env, napi_callback_info info) {
@@ -895,7 +915,7 @@ static napi_value init(napi_env env, napi_value exports) {
     {"defer", fn_defer}, {"collect", fn_collect}, {"combBits", fn_comb_bits},
     {"curveId", fn_curve_id}, {"fieldBytes", fn_field_bytes}, {"orderBytes", fn_order_bytes},
     {"deviceCount", fn_device_count}, {"groupSize", fn_group_size}, {"defineShort", fn_define_short}, {"defineEdwards", fn_define_edwards}, {"mulFixed", fn_mul_fixed}, {"mulVar", fn_mul_var},
-    {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519},
+    {"mulAdd2", fn_mul_add2}, {"ecdsaVerify", fn_verify}, {"x25519", fn_x25519}, {"x25519Derive", fn_x25519_derive},
     {"callAsync", fn_call_async}, {"decompress", fn_decompress},
     {"eddsaVerify", fn_eddsa_verify}, {"eddsaSign", fn_eddsa_sign}, {"ecdsaSign", fn_sign}, {"ecdsaRecover", fn_recover}, {"ecdsaSignDet", fn_sign_det},
     {"decodePoints", fn_decode_points}, {"encodePoints", fn_encode_points}, {"validate", fn_validate},

@@ -120,6 +120,14 @@ Engine.prototype.x25519Batch = function x25519Batch(scalars, xs) {
   return this.addon.x25519(this.ctx, scalars, xs);
 };
 
+// KeyPair#derive on curve25519 per item (ec/key.js:102-107): scalars, xs: Buffer(n x 32) ->
+// { x: Buffer(n x 32), status: Buffer(n) }; status 0 shared secret, 1 x is no abscissa of the curve
+// (the reference throws 'Assertion failed' out of its square root there), 2 the product is infinity
+Engine.prototype.x25519DeriveBatch = function x25519DeriveBatch(scalars, xs) {
+  this.stats.gpuCalls++; this.stats.gpuItems += scalars.length / 32;
+  return this.addon.x25519Derive(this.ctx, scalars, xs);
+};
+
 // pointFromX (short curves: values = x) / pointFromY (ed25519: values = y), parity per item
 // in `odd` (Buffer of 0/1) -> { xy: Buffer(n x 2B), ok: Buffer(n) }  (ok = 0: 'invalid point')
 Engine.prototype.decompressBatch = function decompressBatch(curve, values, odd) {
@@ -1225,7 +1233,33 @@ function install(elliptic, options) {
     return this.curve.point(new BN(r.x), new BN(1));
   };
 
+  // KeyPair#derive on curve25519 (ec/key.js:102-107): pub.validate() -- a square root in JavaScript,
+  // mont.js:23-32, 290 us -- and pub.mul(priv).getX() as ONE engine call (validity by Euler's criterion
+  // on a wave of its own beside the ladder's).  Everything else about the call is the reference's:
+  // short curves (their validate is two products), points of another curve object, infinity, and --
+  // through the original method -- the exception it throws where x has no point on the curve.
+  var kpProto = new elliptic.ec('curve25519').keyFromPrivate('01', 'hex').constructor.prototype;
+  orig.derive = kpProto.derive;
+  kpProto.derive = function derive(pub) {
+    var ec = this.ec, curve = ec && ec.curve;
+    if (!refOnly && curve && curve.type === 'mont' && pub && pub.curve === curve && this.priv &&
+        typeof pub.isInfinity === 'function' && !pub.isInfinity() && pub.x && pub.z &&
+        pub.x.red === curve.red && pub.z.red === curve.red) {
+      var d = domain(curve);
+      var kb = d && scalarBuf(this.priv, 32);
+      if (kb) {
+        // (the reference's validate() normalizes the caller's point in place, mont.js:24, 160-165: so does this)
+        var x = pub.normalize().x.fromRed();
+        var r = eng.x25519DeriveBatch(kb, Buffer.from(x.toArray('be', 32)));
+        if (r.status[0] === 0) return new BN(r.x);
+      }
+    }
+    eng.stats.passthrough++;
+    return orig.derive.apply(this, arguments);
+  };
+
   eng.uninstall = function uninstall() {
+    kpProto.derive = orig.derive;
     base._fixedNafMul = orig.fixedNafMul;
     base._wnafMul = orig.wnafMul;
     base._wnafMulAdd = orig.wnafMulAdd;

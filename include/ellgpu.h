@@ -232,6 +232,15 @@ int ellgpu_ecdsa_verify(ellgpu_ctx* ctx, int curve, size_t n, const uint8_t* has
  * reference's getX() would throw. */
 int ellgpu_x25519_ladder(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* in_x,
                          uint8_t* out_x, uint8_t* out_inf);
+/* KeyPair#derive on curve25519 (lib/elliptic/ec/key.js:102-107): pub.validate() -- MontCurve#validate,
+ * curve/mont.js:23-32: is x^3 + a x^2 + x a square? -- and pub.mul(priv).getX() in ONE call, the
+ * validity test (Euler's criterion) on lanes / a wave of its own beside the ladder.  out_status[i]:
+ * 0 out_x[i] is the shared secret; 1 in_x[i] is no abscissa of the curve (the reference's validate
+ * does not answer false there: bn.js's Tonelli-Shanks square root THROWS 'Assertion failed' on a
+ * non-residue, dist/elliptic.js:7242-7302 -- install() runs the reference's own derive on such an
+ * item so that the caller sees that exception); 2 the product is the point at infinity. */
+int ellgpu_x25519_derive(ellgpu_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* in_x,
+                         uint8_t* out_x, uint8_t* out_status);
 
 /* Point decompression.  Short curves: ShortCurve#pointFromX
  * (lib/elliptic/curve/short.js:187-204) -- v[i] is the abscissa, the result has

@@ -873,3 +873,37 @@ def check_deferred_calls(ctx):
     assert np.array_equal(big[:n], want)                    # complete already
     ctx.collect()
     assert np.array_equal(big[-n:], want)
+
+
+def check_x25519_derive(ctx, count=96):
+    """ellgpu_x25519_derive = KeyPair#derive on curve25519 (ec/key.js:102-107): status 1 exactly where
+    x^3 + 486662 x^2 + x is a non-residue mod 2^255 - 19 (the reference's validate throws out of its
+    square root there), else the ladder's x -- the same bytes as ellgpu_x25519_ladder -- and status 2
+    where that call reports infinity.  Small and large batches (the row layer and the one-lane kernels)."""
+    import random
+    rnd = random.Random(2519)
+    p = 2 ** 255 - 19
+    xs = [0, 1, 2, 3, 4, 9, p - 1, p - 2, p + 5, (1 << 256) - 1] + [rnd.randrange(p) for _ in range(count)]
+    ks = [rnd.randrange(1 << 255) for _ in xs]
+    ks[3] = 0
+    ks[4] = 1
+    kb, xb = ints_to_be(ks, 32), ints_to_be(xs, 32)
+    want_bad = []
+    for x in xs:
+        x %= p
+        rhs = (x * x * x + 486662 * x * x + x) % p
+        want_bad.append(0 if rhs == 0 or pow(rhs, (p - 1) // 2, p) == 1 else 1)
+    assert 20 < sum(want_bad) < len(xs) - 20
+    ref_x, ref_inf = ctx.x25519(kb, xb)
+    for reps in (1, 40):                                   # 106 items; 4 240: above the row layer's batch sizes
+        kk, xx = np.tile(kb, (reps, 1)), np.tile(xb, (reps, 1))
+        out, st = ctx.x25519_derive(kk, xx)
+        for i in range(len(xs) * reps):
+            j = i % len(xs)
+            assert st[i] == (1 if want_bad[j] else (2 if ref_inf[j] else 0)), (reps, i, hex(xs[j]))
+            assert np.array_equal(out[i], ref_x[j]), (reps, i)
+    # one item at a time (install()'s call)
+    for j in range(12):
+        out, st = ctx.x25519_derive(kb[j:j + 1], xb[j:j + 1])
+        assert st[0] == (1 if want_bad[j] else (2 if ref_inf[j] else 0)) and np.array_equal(out[0], ref_x[j]), j
+    return len(xs)

@@ -421,22 +421,32 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
     c0 = elliptic_amd.Context(0)                       # the whole ladder on one lane
     monkeypatch.setenv("ELLGPU_PARTED_GRID", str(1 << 30))
     monkeypatch.setenv("ELLGPU_COOP_GRID", "0")
+    monkeypatch.setenv("ELLGPU_ROW_GRID", "0")
     c1 = elliptic_amd.Context(0)                       # parts, one item per lane
+    monkeypatch.setenv("ELLGPU_ROW_GRID", str(1 << 30))
+    monkeypatch.setenv("ELLGPU_ROW_FROM", "0")
+    c3 = elliptic_amd.Context(0)                       # parts, one item per ROW of the wave (four per wave; round 6), whatever the batch
     monkeypatch.setenv("ELLGPU_COOP_GRID", str(1 << 30))
+    monkeypatch.setenv("ELLGPU_ROW_FROM", str(1 << 30))
     c2 = elliptic_amd.Context(0)                       # parts, one item per wave (the row layer), whatever the batch
     monkeypatch.delenv("ELLGPU_PARTED_GRID")
     monkeypatch.delenv("ELLGPU_COOP_GRID")
+    monkeypatch.delenv("ELLGPU_ROW_GRID")
+    monkeypatch.delenv("ELLGPU_ROW_FROM")
     cd = elliptic_amd.Context(0)                       # the default thresholds
     coop_default = 256 * 4 * 4 // 3                    # engine.h Tuning::coop_grid on 256 CUs
+    row_from, row_default = 256 * 5 // 2, 256 * 18     # ... Tuning::row_from / row_grid: the one-item-per-row window
+    SUFFIXES = ("", "_c", "_r")
 
     def forms(m):
         """(context, kernel of the parts or None) for a batch of m items"""
-        return ((c0, None), (c1, ""), (c2, "_c"), (cd, "_c" if m <= coop_default else ""))
+        return ((c0, None), (c1, ""), (c2, "_c"), (c3, "_r"),
+                (cd, "_r" if row_from < m <= row_default else ("_c" if m <= coop_default else "")))
 
     def row(c, m):
         """do the calls that have no parted one-lane form (fixed base, decompression, the front of
         the recovery) run on the row layer?  ELLGPU_COOP_GRID alone decides"""
-        return c is c2 or (c is not c1 and m <= coop_default)
+        return c is c2 or (c is not c1 and c is not c3 and m <= coop_default)
     n = 32768
     h, r, s, pub, expect = _make_sigs(c0, n, "gpu-test-parted")
     pub = pub.copy()
@@ -449,7 +459,7 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
     r = r.copy()
     r[11] = 0                                          # r = 0: rejected before the key is looked at
     want[11] = 0
-    for m in (1, 2, 3, 63, 64, 65, 127, 128, 129, 1000, 1365, 1366, 4096, 21845, 32768):
+    for m in (1, 2, 3, 63, 64, 65, 127, 128, 129, 640, 641, 1000, 1365, 1366, 1367, 4096, 4608, 4609, 21845, 32768):
         sl = (h[:m], r[:m], s[:m], pub[:m])
         for c, parts in forms(m):
             if c is c2 and m > 4096:
@@ -462,7 +472,7 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
             assert got.max(initial=0) <= 1 and not got[gst == 2].any(), (m, parts)
             assert np.array_equal(np.where(gst == 2, 2, got), want[:m]), (m, parts)
             assert ("ecdsa_join" in tm) == (parts is not None), (m, parts, sorted(tm))
-            for suffix in ("", "_c"):
+            for suffix in SUFFIXES:
                 assert ("ecdsa_parts" + suffix in tm) == (parts == suffix), (m, parts, sorted(tm))
     # above the default threshold: the one-lane small-grid ladder
     h2, r2, s2, pub2, expect2 = _make_sigs(c0, 40000, "gpu-test-parted-2")
@@ -491,7 +501,7 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
             tm = c.get_timing()
             c.set_timing(False)
             assert ("mul_join" in tm) == (parts is not None), (m, parts, sorted(tm))
-            for suffix in ("", "_c"):
+            for suffix in SUFFIXES:
                 assert ("mul_parts" + suffix in tm) == (parts == suffix), (m, parts, sorted(tm))
         for xy, inf in outs[1:]:
             assert np.array_equal(xy, outs[0][0]) and np.array_equal(inf, outs[0][1]), m
@@ -522,13 +532,13 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
     # ladder with the comb behind it
     for m in (1, 65, 4096):
         outs = []
-        for c, parts in ((c0, None), (c1, ""), (c2, "_c")):
+        for c, parts in ((c0, None), (c1, ""), (c2, "_c"), (c3, "_r")):
             c.set_timing(True)
             outs.append(c.mul_add2("secp256k1", s[:m], None, ks[:m], pub[:m]))
             tm = c.get_timing()
             c.set_timing(False)
             assert ("mul_add_g" in tm) == (parts is None), (m, parts, sorted(tm))
-            for suffix in ("", "_c"):
+            for suffix in SUFFIXES:
                 assert ("mul_parts" + suffix in tm) == (parts == suffix), (m, parts, sorted(tm))
         for o in outs[1:]:
             assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]), m
@@ -566,14 +576,14 @@ def test_parted_verify_and_mul_small_batches(monkeypatch):
             assert all(np.array_equal(a, b) for a, b in zip(outs_r[0], o)), ("recover", m)
     okd = outs_d[0][1]
     assert 0 < int(okd.sum()) < m and okd[0] == 1
-    for c in (c0, c1, c2):
+    for c in (c0, c1, c2, c3):
         assert PC.check_mul_golden(c, "secp256k1") > 50
         assert PC.check_decompress_golden(c, "secp256k1") > 40
         assert PC.check_recover_golden(c, "secp256k1") >= 30
         assert PC.check_exceptional_keys(c, "secp256k1") > 400
         assert PC.check_verify_golden(c, "secp256k1") > 15
         assert PC.check_offcurve_golden(c, "secp256k1") >= 29
-    for c in (c0, c1, c2, cd):
+    for c in (c0, c1, c2, c3, cd):
         c.close()
 
 
@@ -960,3 +970,11 @@ def test_deferred_small_calls_gpu(ctx):
     """ellgpu_ctx_defer / ellgpu_ctx_collect on the device: the call returns with its work in flight,
     collect() -- or any other entry point -- completes it; same bytes as the plain call"""
     PC.check_deferred_calls(ctx)
+
+
+@pytest.mark.gpu
+def test_x25519_derive_gpu(ctx):
+    """ellgpu_x25519_derive on the device: the validity test on a wave of its own beside the ladder's
+    (x25519_c, one launch) for a handful of items, one-lane kernels above that; statuses against
+    Python's Euler criterion, secrets against ellgpu_x25519_ladder"""
+    assert PC.check_x25519_derive(ctx) >= 100

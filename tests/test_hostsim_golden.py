@@ -353,24 +353,30 @@ def test_verify_golden_secp256k1_both_tunings(hs, monkeypatch):
     # ladder.  The parts themselves have two forms: one item per lane (work.h) and, for batches of
     # at most ELLGPU_COOP_GRID items, one item per WAVE with its field elements spread over a
     # 16-lane row (coop.h / coop_work.h; here the host simulation of the row) -- same join kernels.
-    for grid, coop, parts in (("0", "0", None), (str(1 << 30), "0", b"ecdsa_parts"), (str(1 << 30), str(1 << 30), b"ecdsa_parts_c")):
-        c = _fresh_ctx(hs, monkeypatch, ELLGPU_PARTED_GRID=grid, ELLGPU_COOP_GRID=coop)
-        mparts = {None: None, b"ecdsa_parts": b"mul_parts", b"ecdsa_parts_c": b"mul_parts_c"}[parts]
+    # Round 6: between the two, batches of at most ELLGPU_ROW_GRID items run one item per ROW of the
+    # wave, four items per wave (coop.h FpK256R / coop_work.h CoopK256R: ecdsa_prep_table_r, ecdsa_parts_r,
+    # mul_parts_r; the host passes walk the four rows one after the other).
+    big = str(1 << 30)
+    for grid, coop, row, parts in (("0", "0", "0", None), (big, "0", "0", b"ecdsa_parts"), (big, big, "0", b"ecdsa_parts_c"),
+                                   (big, "0", big, b"ecdsa_parts_r")):
+        c = _fresh_ctx(hs, monkeypatch, ELLGPU_PARTED_GRID=grid, ELLGPU_COOP_GRID=coop, ELLGPU_ROW_GRID=row, ELLGPU_ROW_FROM="0")
+        mparts = {None: None, b"ecdsa_parts": b"mul_parts", b"ecdsa_parts_c": b"mul_parts_c", b"ecdsa_parts_r": b"mul_parts_r"}[parts]
         hs.hs_launches_reset()
         assert PC.check_verify_golden(c, "secp256k1") > 15
         assert PC.check_offcurve_golden(c, "secp256k1") >= 29
         assert PC.check_exceptional_keys(c, "secp256k1") > 400
-        for name in (b"ecdsa_parts", b"ecdsa_parts_c"):
+        for name in (b"ecdsa_parts", b"ecdsa_parts_c", b"ecdsa_parts_r"):
             assert (hs.hs_launches(name) > 0) == (name == parts), name
         assert (hs.hs_launches(b"ecdsa_join") > 0) == (parts is not None)
         assert (hs.hs_launches(b"ecdsa_main") > 0) == (parts is None)
         # (the row layer also builds Q's window table, beside the prep: one launch)
         assert (hs.hs_launches(b"ecdsa_prep_table_c") > 0) == (parts == b"ecdsa_parts_c")
-        assert (hs.hs_launches(b"ecdsa_prep_table") > 0) == (parts != b"ecdsa_parts_c")
+        assert (hs.hs_launches(b"ecdsa_prep_table_r") > 0) == (parts == b"ecdsa_parts_r")
+        assert (hs.hs_launches(b"ecdsa_prep_table") > 0) == (parts not in (b"ecdsa_parts_c", b"ecdsa_parts_r"))
         # Point#mul likewise (Work::mul_half x 2, mul_join); k1 G + k2 P stays on its one ladder
         hs.hs_launches_reset()
         assert PC.check_mul_golden(c, "secp256k1") > 50
-        for name in (b"mul_parts", b"mul_parts_c"):
+        for name in (b"mul_parts", b"mul_parts_c", b"mul_parts_r"):
             assert (hs.hs_launches(name) > 0) == (name == mparts), name
         assert (hs.hs_launches(b"mul_join") > 0) == (parts is not None)
         # fixed base: the comb and the item's own inversion on a wave (mul_fixed_c), or mul_fixed -> normalize
@@ -381,7 +387,7 @@ def test_verify_golden_secp256k1_both_tunings(hs, monkeypatch):
         assert PC.check_exceptional_keys(c, "secp256k1") > 400
         assert PC.check_recover_golden(c, "secp256k1") >= 30
         assert (hs.hs_launches(b"mul_add_g") > 0) == (parts is None)
-        for name in (b"mul_parts", b"mul_parts_c"):
+        for name in (b"mul_parts", b"mul_parts_c", b"mul_parts_r"):
             assert (hs.hs_launches(name) > 0) == (name == mparts), name
         # ... whose front -- R's square root and r^-1 -- is one launch of the row layer, side by side
         assert (hs.hs_launches(b"recover_parts_c") > 0) == (parts == b"ecdsa_parts_c")
@@ -923,3 +929,8 @@ def test_user_defined_edwards_curves(ctx, idx):
 def test_deferred_small_calls(ctx):
     """the split form of a few-item call (ellgpu_ctx_defer / ellgpu_ctx_collect), CPU build"""
     PC.check_deferred_calls(ctx)
+
+
+def test_x25519_derive(ctx):
+    """KeyPair#derive on curve25519 as one call: validate (Euler's criterion) beside the ladder"""
+    assert PC.check_x25519_derive(ctx, count=40) >= 50

@@ -20,7 +20,10 @@ def main():
     ctx = elliptic_amd.Context(0)
     n_max = 1 << 16
     hz, hr, hs, hq, want = bench.make_signatures(ctx, n_max, "latency")
-    for n in (1, 16, 64, 256, 1024, 4096, 16384, 65536):
+    # ELLGPU_LATENCY_SIZES="512,2048,...": other batch sizes (the A/B of the one-item-per-row layer sets
+    # ELLGPU_ROW_GRID=0 beside it: that form off)
+    sizes = [int(x) for x in os.environ.get("ELLGPU_LATENCY_SIZES", "1,16,64,256,1024,2048,4096,8192,16384,65536").split(",")]
+    for n in sizes:
         z, r, s, q = hz[:n].copy(), hr[:n].copy(), hs[:n].copy(), hq[:n].copy()
         for name, fn in (("ecdsa_verify", lambda: ctx.ecdsa_verify("secp256k1", z, r, s, q)),
                          ("mul_var", lambda: ctx.mul_var("secp256k1", r, q)),

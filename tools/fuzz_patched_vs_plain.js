@@ -451,6 +451,7 @@ for (var it = 0; it < ITER && failures.length < 5; it++) {
     ['eddsa.verify', plain.eddsa.prototype.verify, patched.eddsa.prototype.verify],
     ['eddsa.sign', plain.eddsa.prototype.sign, patched.eddsa.prototype.sign],
     ['mont Point#mul', plain.curves.curve25519.curve.g.constructor.prototype.mul, patched.curves.curve25519.curve.g.constructor.prototype.mul],
+    ['KeyPair#derive', new plain.ec('p192').keyFromPrivate('01', 'hex').derive, new patched.ec('p192').keyFromPrivate('01', 'hex').derive],
   ];
   pairs.forEach(function(q) {
     if (String(q[1]) !== String(q[2])) failures.push({ op: 'uninstall', args: q[0], reference: String(q[1]).slice(0, 80), patched: String(q[2]).slice(0, 80) });
