@@ -325,4 +325,189 @@ struct FpMontC {
   }
 };
 
+// ---- the same row, reduced by FOLDING (round 6) ------------------------------------------------------
+// For a prime of more than 232 bits (p256) the nine-digit row holds plain residues and a product
+// is reduced without the word-serial chain above -- the reduction csrc/coop_wide.h uses for p384 /
+// p521: after two carry passes digit 9 + j of the product (lanes 9..15, column 16's two digits) is a
+// 29-bit number worth the constant vector fold29[j] = 2^(29 (9 + j)) mod p -- nine independent
+// multiply-adds of the row --, then what stands above 2^PBITS (34 bits at most) is worth top29 =
+// 2^PBITS mod p and folds once more.  No step waits for a v_readlane -> scalar -> v_mad of the step
+// before (FpMontC: 94 VALU + 61 SALU at 2.9 ns each on a lone wave).  Interface, value range
+// (-2^(PBITS-23), 2^PBITS + 2^(PBITS-23)), norm, the conversions' canonical digits: FpMontC's.
+template <class MC, class F1>
+struct FpFoldC : FpMontC<MC, F1> {
+  typedef FpMontC<MC, F1> B;
+  typedef FpK256C R_;
+  typedef typename B::El El;
+  typedef typename B::W64 W64;
+  typedef FpK256C::Q Q;
+  static constexpr int CL = B::CL;
+  static constexpr int L = B::L;
+  static constexpr u32 M = B::M;
+  static constexpr int TL = 8, TB = MC::PBITS - 29 * 8;
+  static_assert(MC::PBITS > 232 && MC::PBITS <= 261 - 5, "FpFoldC: the top digit holds bit PBITS - 1 and the fold's overflow");
+  static constexpr bool QUAD = true;
+
+  ELL_HD static i32 s(u32 x) { return (i32)x; }
+  ELL_HD static int lane_of(int t) { return R_::lane_of(t); }
+  template <int J>
+  ELL_HD static El c_fold() { return B::template by_lane<0>(MC::fold29[J]); }
+  ELL_HD static El c_top() { return B::template by_lane<0>(MC::top29); }
+  ELL_HD static El c_top1() { return B::template by_lane<1>(MC::top29); }
+  ELL_HD static El one() { return R_::one(); }
+
+  // one carry pass over 64-bit lanes; lane 8 (the top digit) keeps its value whole and hands nothing on
+  ELL_HD static W64 carry64(const W64& x) {
+    W64 c, lo;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) {
+      const bool k = lane_of(t) >= 8;
+      c.w[t] = k ? 0 : (x.w[t] >> 29);
+      lo.w[t] = k ? x.w[t] : (i64)((u32)x.w[t] & M);
+    }
+    const W64 cin = R_::template up64<1>(c);
+    W64 r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) r.w[t] = lo.w[t] + cin.w[t];
+    return r;
+  }
+  // columns 0..15 (one per lane) and 16 -> the product's residue (RW: every row reduces a product of its own)
+  template <bool RW = false>
+  ELL_HD static El reduce(const W64& acc, i64 col16) {
+    const El live = B::c_live();
+    // the columns as digits: two carry passes, as coop.h FpK256C::tail
+    W64 c1;
+    El lo1;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) { c1.w[t] = acc.w[t] >> 29; lo1.v[t] = (u32)acc.w[t] & M; }
+    const W64 cin1 = R_::template up64<1>(c1);
+    W64 v1;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) v1.w[t] = (i64)lo1.v[t] + cin1.w[t];
+    col16 += R_::template ln64<RW, 15>(c1);
+    El c2, v2;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) c2.v[t] = (u32)(i32)(v1.w[t] >> 29);
+    const El cin2 = R_::template up<1>(c2);
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) v2.v[t] = ((u32)v1.w[t] & M) + cin2.v[t];
+    col16 += (i64)R_::template ln<RW, 15>(c2);
+    const i32 p16 = (i32)((u32)col16 & M);
+    const i32 p17 = (i32)(col16 >> 29);
+    // digits 9 .. 17 fold onto 0 .. 8: nine products below 2^59 per lane, two accumulators
+    W64 f0, f1;
+    const El k0 = c_fold<0>(), k1 = c_fold<1>(), k2 = c_fold<2>(), k3 = c_fold<3>(), k4 = c_fold<4>(),
+             k5 = c_fold<5>(), k6 = c_fold<6>(), k7 = c_fold<7>(), k8 = c_fold<8>();
+    const i32 h0 = R_::template ln<RW, 9>(v2), h1 = R_::template ln<RW, 10>(v2), h2 = R_::template ln<RW, 11>(v2),
+              h3 = R_::template ln<RW, 12>(v2), h4 = R_::template ln<RW, 13>(v2), h5 = R_::template ln<RW, 14>(v2),
+              h6 = R_::template ln<RW, 15>(v2);
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) {
+      i64 x = (i64)s(v2.v[t] & live.v[t]);
+      x += (i64)h0 * (i64)s(k0.v[t]);
+      x += (i64)h2 * (i64)s(k2.v[t]);
+      x += (i64)h4 * (i64)s(k4.v[t]);
+      x += (i64)h6 * (i64)s(k6.v[t]);
+      x += (i64)p17 * (i64)s(k8.v[t]);
+      i64 y = (i64)h1 * (i64)s(k1.v[t]);
+      y += (i64)h3 * (i64)s(k3.v[t]);
+      y += (i64)h5 * (i64)s(k5.v[t]);
+      y += (i64)p16 * (i64)s(k7.v[t]);
+      f0.w[t] = x;
+      f1.w[t] = y;
+    }
+    W64 f;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) f.w[t] = f0.w[t] + f1.w[t];
+    // exact digits (the top digit keeps everything above it: below 2^58), then what stands above
+    // 2^PBITS -- 34 bits at most -- times top = 2^PBITS mod p
+    f = carry64(f);
+    f = carry64(f);
+    const i64 tv = R_::template ln64<RW, 8>(f);
+    const i64 tt = tv >> TB;
+    const i32 t0 = (i32)((u32)tt & M), t1 = (i32)(tt >> 29);
+    const El ct = c_top(), ct1 = c_top1();
+    W64 g;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) {
+      i64 x = f.w[t];
+      if (lane_of(t) == TL) x = (i64)((u64)x & (((u64)1 << TB) - 1));
+      x += (i64)t0 * (i64)s(ct.v[t]);
+      x += (i64)t1 * (i64)s(ct1.v[t]);
+      g.w[t] = x;
+    }
+    g = carry64(g);
+    g = carry64(g);
+    El r;
+    ELL_UNROLL
+    for (int t = 0; t < CL; t++) r.v[t] = (u32)g.w[t] & live.v[t];
+    return r;
+  }
+#if defined(ELL_BOUNDS_CHECK)
+  static void check(const El& a, const El& b, const char* what) {
+    __int128 col[17] = {0};
+    FpK256L::check_operands(R_::gather(a), R_::gather(b), col);
+    FpK256L::check_cols(col);
+    for (int t = 9; t < CL; t++) assert(a.v[t] == 0 && b.v[t] == 0 && "fpfoldc: dead lane not zero");
+    (void)what;
+  }
+#endif
+  ELL_HD static El mul(const El& a, const El& b) {
+#if defined(ELL_BOUNDS_CHECK)
+    check(a, b, "mul");
+#endif
+    W64 acc = R_::zero64();
+    i64 col16 = 0;
+    R_::columns(acc, col16, a, b);
+    return reduce(acc, col16);
+  }
+  ELL_HD static El sqr(const El& a) { return mul(a, a); }
+  ELL_HD static Q mulq(const Q& a, const Q& b) {
+    Q r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    W64 acc = R_::zero64();
+    i64 col16 = 0;
+    R_::template columns<true>(acc, col16, a.r[0], b.r[0]);
+    r.r[0] = reduce<true>(acc, col16);
+#else
+    for (int j = 0; j < R_::QR; j++) r.r[j] = mul(a.r[j], b.r[j]);
+#endif
+    return r;
+  }
+  // ---- conversions: plain residues, no Montgomery factor ---------------------------------------
+  ELL_HD static void to_plain(u32 (&out)[L], const El& a) {
+    u32 w[8];
+    B::canon(w, a);
+    ELL_UNROLL
+    for (int j = 0; j < L; j++) out[j] = w[j];
+  }
+  // (an ABI value may exceed p: a product with 1 reduces it)
+  ELL_HD static El from_plain(const u32 (&a)[L]) {
+    u32 w[8];
+    ELL_UNROLL
+    for (int j = 0; j < 8; j++) w[j] = j < L ? a[j] : 0u;
+    return mul(R_::scatter(FpK256L::from_plain(w)), one());
+  }
+  // an entry of the one-lane kernels' tables (canonical words) -> the digits, as they are
+  ELL_HD static El load_words(const u32* w) {
+    return B::each([&](int l) {
+      const int ll = l > 8 ? 8 : l;
+      const int bit = 29 * ll;
+      const int k = bit >> 5, sh = bit & 31;
+      const u32 lo = k < L ? w[k] : 0u;
+      const u32 hi = k + 1 < L ? w[k + 1] : 0u;
+      const u64 two = (u64)lo | ((u64)hi << 32);
+      return l > 8 ? 0 : (i32)((u32)(two >> sh) & M);
+    });
+  }
+  static ELL_HD_NOINLINE El inv(const El& a) {
+    u32 w[L];
+    to_plain(w, a);
+    typename F1::El y = F1::inv(F1::from_plain(w));
+    u32 v[L];
+    F1::to_plain(v, y);
+    return from_plain(v);
+  }
+};
+
 }  // namespace ell

@@ -352,17 +352,24 @@ typedef CoopK256T<true> CoopK256R;
 // one-lane ecdsa_join2; Point#mul is the ladder alone, normalised by the one-lane kernel.
 // (p384 and p521 -- 14 / 19 digits: 27 / 37 product columns do not fit a 16-lane row -- take the
 // WIDE field, an element over the lanes of the whole wave: coop_wide.h FpFoldW)
+// (FOLD: reduction by folding with constant vectors instead of the word-serial Montgomery chain --
+// coop_mont.h FpFoldC for p256 in the 16-lane row; the wide layer folds by construction)
+#ifndef ELL_P256_FOLD
+#define ELL_P256_FOLD 1
+#endif
 template <class CV1>
-struct CoopConsts { static constexpr bool AVAILABLE = false, WIDE = false; typedef consts::COOP_P256 MC; };
-template <> struct CoopConsts<CvP192> { static constexpr bool AVAILABLE = true, WIDE = false; typedef consts::COOP_P192 MC; };
-template <> struct CoopConsts<CvP224> { static constexpr bool AVAILABLE = true, WIDE = false; typedef consts::COOP_P224 MC; };
-template <> struct CoopConsts<CvP256> { static constexpr bool AVAILABLE = true, WIDE = false; typedef consts::COOP_P256 MC; };
-template <> struct CoopConsts<CvP384> { static constexpr bool AVAILABLE = true, WIDE = true; typedef consts::COOPW_P384 MC; };
-template <> struct CoopConsts<CvP521> { static constexpr bool AVAILABLE = true, WIDE = true; typedef consts::COOPW_P521 MC; };
-template <bool WIDE, class MC, class F1>
+struct CoopConsts { static constexpr bool AVAILABLE = false, WIDE = false, FOLD = false; typedef consts::COOP_P256 MC; };
+template <> struct CoopConsts<CvP192> { static constexpr bool AVAILABLE = true, WIDE = false, FOLD = false; typedef consts::COOP_P192 MC; };
+template <> struct CoopConsts<CvP224> { static constexpr bool AVAILABLE = true, WIDE = false, FOLD = false; typedef consts::COOP_P224 MC; };
+template <> struct CoopConsts<CvP256> { static constexpr bool AVAILABLE = true, WIDE = false, FOLD = ELL_P256_FOLD != 0; typedef consts::COOP_P256 MC; };
+template <> struct CoopConsts<CvP384> { static constexpr bool AVAILABLE = true, WIDE = true, FOLD = true; typedef consts::COOPW_P384 MC; };
+template <> struct CoopConsts<CvP521> { static constexpr bool AVAILABLE = true, WIDE = true, FOLD = true; typedef consts::COOPW_P521 MC; };
+template <bool WIDE, bool FOLD, class MC, class F1>
 struct CoopField { typedef FpMontC<MC, F1> type; };
 template <class MC, class F1>
-struct CoopField<true, MC, F1> { typedef FpFoldW<MC, F1> type; };
+struct CoopField<false, true, MC, F1> { typedef FpFoldC<MC, F1> type; };
+template <bool FOLD, class MC, class F1>
+struct CoopField<true, FOLD, MC, F1> { typedef FpFoldW<MC, F1> type; };
 
 template <class CV1>
 struct CoopNist {
@@ -371,7 +378,7 @@ struct CoopNist {
   static constexpr bool WIDE = CoopConsts<CV1>::WIDE;
   static constexpr int LANES = WIDE ? 64 : 16;       // lanes an element lives on (a row, or the wave)
   struct CV {
-    typedef typename CoopField<CoopConsts<CV1>::WIDE, MC, typename CV1::F>::type F;
+    typedef typename CoopField<CoopConsts<CV1>::WIDE, CoopConsts<CV1>::FOLD, MC, typename CV1::F>::type F;
     typedef typename CV1::Fn Fn;
     typedef typename CV1::C C;
     static constexpr int A_KIND = CV1::A_KIND;

@@ -1052,6 +1052,7 @@ class Engine {
     bool split_verify;
     size_t parted_grid;       // largest batch that takes the parted verify (three lanes per item)
     size_t coop_grid;         // largest batch whose parts run on the lanes-per-item layer (a wave per part)
+    size_t wide_grid;         // ... of p384 / p521 (one item per wave on the wide layer)
     size_t row_from, row_grid;  // batches of row_from < n <= row_grid items run their parts one item per ROW (four items per wave)
     size_t comb_max_bytes;    // ELLGPU_COMB_MAX_BYTES: fixed-base tables above this are treated as unallocatable (0 = no limit)
     int prep_k;
@@ -1077,6 +1078,8 @@ class Engine {
     // (profiles/r06_latency_rows_ab.txt) it passes the wave-per-part form at ~2.5 items per CU -- 768
     // verifies 382 -> 310 us -- and holds against the one-lane parted form's single 573-us chain up to
     // ~18 per CU: 4 096 verifies 768 -> 608 us, 4 778 a tie.  ELLGPU_ROW_FROM / ELLGPU_ROW_GRID.
+    e = getenv("ELLGPU_WIDE_GRID");
+    tune_.wide_grid = e ? (size_t)strtoull(e, nullptr, 10) : tune_.coop_grid;
     e = getenv("ELLGPU_ROW_FROM");
     tune_.row_from = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)bk.compute_units() * 5 / 2;
     e = getenv("ELLGPU_ROW_GRID");
@@ -1093,6 +1096,13 @@ class Engine {
   size_t parted_grid() const { return tune_.parted_grid; }
   size_t coop_grid() const { return CoopK256::AVAILABLE ? tune_.coop_grid : 0; }
   size_t row_grid() const { return CoopK256::AVAILABLE ? tune_.row_grid : 0; }
+  // ... of curve CV: p384 / p521 (the wide layer, coop_wide.h) have a threshold of their own
+  // (ELLGPU_WIDE_GRID; default: coop_grid)
+  template <class CV>
+  size_t coop_grid_of() const {
+    if constexpr (!CV::ENDO && CoopConsts<CV>::WIDE) return tune_.wide_grid;
+    else return coop_grid();
+  }
   // do the parts of a secp256k1 verify / Point#mul of n items run one item per row?  (else one item per
   // wave up to coop_grid, one item per lane above)
   bool rows_for(size_t n) const { return CoopK256::AVAILABLE && n > tune_.row_from && n <= tune_.row_grid; }
@@ -2525,7 +2535,7 @@ int Engine<BK>::mul_var_chunk(size_t n, const u8* k, const u8* xy, u8* out_xy, u
   if constexpr (!CV::ENDO && CoopNist<CV>::AVAILABLE) {
     // a handful of items: the ladder of every item on a wave of its own (the row layer); the
     // normalisation and the domain test below are the one-lane kernels'
-    if (!launched && n <= coop_grid() && out_inf) {
+    if (!launched && n <= coop_grid_of<CV>() && out_inf) {
       FnMulPartsN<CV> fc{n, k, xy, jac, nullptr, nullptr};
       bk.launch_coop(fc, n);
       launched = true;
@@ -2557,7 +2567,7 @@ int Engine<BK>::mul_fixed_chunk(size_t n, const u8* k, u8* out_xy, u8* out_inf) 
   constexpr bool row_k256 = CV::ENDO && W::L <= 8 && CoopK256::AVAILABLE;
   constexpr bool row_nist = !CV::ENDO && CoopNist<CV>::AVAILABLE;
   if constexpr ((row_k256 || row_nist) && W::NBYTES == W::BYTES) {
-    if (n <= coop_grid() && out_inf) {
+    if (n <= coop_grid_of<CV>() && out_inf) {
       typedef typename std::conditional<row_k256, CoopK256, CoopNist<CV>>::type CW;
       FnMulFixedC<CV, CW> fc{n, k, (const typename W::A*)comb_[CV::ID], out_xy, out_inf};
       bk.launch_coop(fc, n);
@@ -2623,7 +2633,7 @@ int Engine<BK>::mul_add_g_chunk(size_t n, const u8* k1, const u8* k2, const u8* 
     }
   }
   if constexpr (!CV::ENDO && CoopNist<CV>::AVAILABLE) {
-    if (n <= coop_grid()) {                 // the ladder of k2 and the comb of k1 on a wave each, joined on one lane
+    if (n <= coop_grid_of<CV>()) {                 // the ladder of k2 and the comb of k1 on a wave each, joined on one lane
       u32* pj = (u32*)scratch(S_JAC, 2 * n * 3 * W::NS * 4);
       if (!pj) return fail(E_NOMEM, "scratch allocation failed");
       FnMulPartsN<CV> fc{n, k2, xy2, pj, k1, (const typename W::A*)comb_[CV::ID]};
@@ -2753,7 +2763,7 @@ int Engine<BK>::ecdsa_chunk(size_t n, const u8* hash, int hash_len, int shift, c
     }
   }
   if constexpr (!CV::ENDO && CoopNist<CV>::AVAILABLE) {
-    if (n <= coop_grid()) {
+    if (n <= coop_grid_of<CV>()) {
       // a handful of items on a curve without an endomorphism: the scalar-field prep as it is
       // (one inversion per item), then the ladder and the comb of every item on a WAVE each (the
       // row layer, coop_mont.h), and the one-lane join
@@ -3166,7 +3176,7 @@ int Engine<BK>::sign_chunk(size_t n, const u8* hash, int hash_len, int shift, co
   constexpr bool row_k256 = CV::ENDO && W::L <= 8 && CoopK256::AVAILABLE;
   constexpr bool row_nist = !CV::ENDO && CoopNist<CV>::AVAILABLE;
   if constexpr (row_k256 || row_nist) {
-    if (n <= coop_grid()) {
+    if (n <= coop_grid_of<CV>()) {
       u32* kinv = (u32*)scratch(S_PRE, n * 2 * (W::LN > W::NS ? W::LN : W::NS) * 4);
       if (!kinv) return fail(E_NOMEM, "scratch allocation failed");
       u32* pre2 = kinv + n * (W::LN > W::NS ? W::LN : W::NS);

@@ -413,12 +413,16 @@ def test_nist_curves_one_lane_and_row_layer(hs, monkeypatch, curve):
     16-lane row), p384 / p521 csrc/coop_wide.h (14 / 19 28-bit digits across the wave; round 6) --
     work: coop_work.h CoopNist, joined by the one-lane ecdsa_join2 / mul_join;
     ELLGPU_COOP_GRID=0 keeps them on the one-item-per-lane kernels.  Same results from both."""
-    for coop, rowk in (("0", False), (str(1 << 30), True)):
+    wide = curve in ("p384", "p521")
+    # (the wide curves: the row-layer pass only, without the 400 exceptional keys -- the host simulation of
+    # a 64-lane wave is slow, their one-lane kernels are covered by the other tests of this file, and the
+    # GPU suite runs both forms on everything: test_nist_small_batches_on_the_row_layer)
+    for coop, rowk in ((str(1 << 30), True),) if wide else (("0", False), (str(1 << 30), True)):
         c = _fresh_ctx(hs, monkeypatch, ELLGPU_COOP_GRID=coop)
         hs.hs_launches_reset()
         assert PC.check_verify_golden(c, curve) > 15
         assert PC.check_offcurve_golden(c, curve) >= 29
-        if curve != "p192":
+        if curve != "p192" and not wide:
             assert PC.check_exceptional_keys(c, curve) > 400
         assert (hs.hs_launches(b"ecdsa_parts_c") > 0) == rowk and (hs.hs_launches(b"ecdsa_main") > 0) != rowk
         # (the key's window table is built beside the scalar-field prep, one launch in front)

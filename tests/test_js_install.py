@@ -23,6 +23,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# On the CPU build p384 / p521 single calls stay on the one-item-per-lane kernels: the host simulation of
+# their 64-lane wide layer (csrc/coop_wide.h) costs ~50 ms per verify, and these replays make hundreds;
+# tests/test_hostsim_golden.py runs the wide layer on the same fixtures, the -m gpu tests run it for real.
+HOSTSIM_ENV = {"ELLGPU_WIDE_GRID": "0"}
+
+
 def _reference():
     """directory of a reference copy (ELLIPTIC_REFERENCE for tools/ref_loader.js), or skip"""
     if os.path.exists("/root/reference/dist/elliptic.js"):
@@ -38,6 +44,7 @@ def _run_suite(lib):
     env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
     if lib:
         env["ELLGPU_LIB"] = lib
+        env.update(HOSTSIM_ENV)
     else:
         env.pop("ELLGPU_LIB", None)
     p = subprocess.run(["node", os.path.join(ROOT, "tools", "run_ref_tests_patched.js")], env=env,
@@ -55,6 +62,7 @@ def _run_replay(lib):
     env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
     if lib:
         env["ELLGPU_LIB"] = lib
+        env.update(HOSTSIM_ENV)
     else:
         env.pop("ELLGPU_LIB", None)
     p = subprocess.run(["node", os.path.join(ROOT, "tools", "check_patched_results.js")], env=env,
@@ -99,7 +107,7 @@ def test_custom_generator_curves_pass_through(custom):
     results equal the unpatched reference either way"""
     _addon()
     from hostsim.build import build as build_hostsim
-    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference(), ELLGPU_LIB=build_hostsim(), ELLGPU_CUSTOM=custom)
+    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference(), ELLGPU_LIB=build_hostsim(), ELLGPU_CUSTOM=custom, **HOSTSIM_ENV)
     p = subprocess.run(["node", os.path.join(ROOT, "tools", "check_custom_generator.js")], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
@@ -141,6 +149,7 @@ def _run_coalescing(lib):
     env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
     if lib:
         env["ELLGPU_LIB"] = lib
+        env.update(HOSTSIM_ENV)
     else:
         env.pop("ELLGPU_LIB", None)
     p = subprocess.run(["node", os.path.join(ROOT, "tools", "check_verify_coalescing.js")], env=env,
@@ -155,6 +164,7 @@ def _run_fuzz(lib, iterations, seed):
     env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
     if lib:
         env["ELLGPU_LIB"] = lib
+        env.update(HOSTSIM_ENV)
     else:
         env.pop("ELLGPU_LIB", None)
     p = subprocess.run(["node", os.path.join(ROOT, "tools", "fuzz_patched_vs_plain.js"), str(iterations), seed], env=env,
@@ -189,6 +199,7 @@ def _run_eddsa_edges(lib):
     env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
     if lib:
         env["ELLGPU_LIB"] = lib
+        env.update(HOSTSIM_ENV)
     else:
         env.pop("ELLGPU_LIB", None)
     p = subprocess.run(["node", os.path.join(ROOT, "tools", "check_eddsa_edge_encodings.js")], env=env,
@@ -258,6 +269,7 @@ def _run_toy_probe(lib, p, kind, min_calls):
     env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
     if lib:
         env["ELLGPU_LIB"] = lib
+        env.update(HOSTSIM_ENV)
     else:
         env.pop("ELLGPU_LIB", None)
     q = subprocess.run(["node", os.path.join(ROOT, "tools", "probe_toy_curves.js"), str(p), kind], env=env,
@@ -292,6 +304,7 @@ def _run_api_walk(lib):
     env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
     if lib:
         env["ELLGPU_LIB"] = lib
+        env.update(HOSTSIM_ENV)
     else:
         env.pop("ELLGPU_LIB", None)
     q = subprocess.run(["node", os.path.join(ROOT, "tools", "probe_api_walk.js")], env=env,

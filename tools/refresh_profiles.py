@@ -42,6 +42,10 @@ MAP = {
     "bench_selflaunch_two_ranks_one_gpu.jsonl": "bench_selflaunch_two_ranks_one_gpu.jsonl",
     "bench_selflaunch_eight_ranks_one_gpu.jsonl": "bench_selflaunch_eight_ranks_one_gpu.jsonl",
     "rccl_selftest.jsonl": "rccl_selftest.jsonl",
+    "row_items_gate.jsonl": "row_items_gate.jsonl",
+    "wide_field.jsonl": "wide_field.jsonl",
+    "single_call_breakdown.jsonl": "single_call_breakdown.jsonl",
+    "latency_rows_ab.txt": "latency_rows_ab.txt",
 }
 
 # kernel name in the summaries -> (key bench.py uses, units per dispatch in the profiled command)

@@ -10,7 +10,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/refresh
 MODE="$1"
 rm -rf $O && mkdir -p $O
-ROUND="${ELL_ROUND:-r04}"
+ROUND="${ELL_ROUND:-r06}"
 ( time timeout 900 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
 tail -3 $O/pytest_gpu.log
 # the workload of the PMC passes: one pass of every benchmarked kernel (headline + configs), 2 timed steps
@@ -67,5 +67,27 @@ if [ "$MODE" != "quick" ]; then
   timeout 120 node tools/bench_js_single_call.js 2>/dev/null | grep '^{' > $O/js_single_call.jsonl
   timeout 300 python tools/bench_custom.py 18 > $O/custom_curve_bench.jsonl 2>/dev/null
   timeout 300 python tests/soak.py --seconds 40 > $O/soak.log 2>&1
+  # round 6: the one-item-per-row gate, the wide layer's chains, where a lone call spends its time,
+  # and the one-item-per-row window switched on and off (each leg its own process)
+  timeout 300 python tools/microbench/row_items.py $O/row_items_gate.jsonl > $O/row_items_gate.log 2>&1
+  timeout 300 python tools/microbench/wide_field.py $O/wide_field.jsonl > $O/wide_field.log 2>&1
+  timeout 300 python tools/single_call_breakdown.py > $O/single_call_breakdown.jsonl 2> $O/single_call_breakdown.err
+  export ELLGPU_LATENCY_SIZES="256,512,640,768,1024,1366,2048,3072,4096,4608,6144,8192,16384"
+  timeout 300 python tools/bench_latency.py > $O/latency_rows_on.jsonl 2> $O/latency_rows.err
+  ELLGPU_ROW_GRID=0 timeout 300 python tools/bench_latency.py > $O/latency_rows_off.jsonl 2>> $O/latency_rows.err
+  unset ELLGPU_LATENCY_SIZES
+  python - > $O/latency_rows_ab.txt <<'PY'
+import json, os
+O = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "refresh")
+def load(f):
+    d = {}
+    for l in open(os.path.join(O, f)):
+        o = json.loads(l); d[(o["op"], o["n"])] = o["median_us"]
+    return d
+a, b = load("latency_rows_on.jsonl"), load("latency_rows_off.jsonl")
+print("# host-buffer call latency, median of 30, us: default thresholds (one item per row for 641 .. 4 608 items) against ELLGPU_ROW_GRID=0")
+for k in sorted(a, key=lambda k: (k[0], k[1])):
+    print("%-14s %6d   rows on %8.1f   rows off %8.1f" % (k[0], k[1], a[k], b.get(k, 0)))
+PY
 fi
 ls -la $O
