@@ -17,6 +17,7 @@
 
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "edwards.h"
@@ -1749,7 +1750,7 @@ class Engine {
       int rc = E_OK;
       if (small_call(si, 4, so, 2, [&]() { return eddsa_verify_dev(n, dm, doff, msg_len, dsg, dpk, dok, derr); }, &rc)) return rc;
     }
-    defer_.armed = false;
+    defer_skip();
     u8* dm = put(G_IN0, msgs ? msgs : (const u8*)"", total);
     u64* doff = off ? (u64*)put(G_IN1, off, (n + 1) * sizeof(u64)) : nullptr;
     u8* dsg = put(G_IN2, sigs, n * 64);
@@ -1800,7 +1801,7 @@ class Engine {
       int rc = E_OK;
       if (small_call(si, 3, so, 2, [&]() { return eddsa_sign_dev(n, dsec, dm, doff, msg_len, dsig, dpub); }, &rc)) return rc;
     }
-    defer_.armed = false;
+    defer_skip();
     u8* dm = put(G_IN0, msgs ? msgs : (const u8*)"", total);
     u64* doff = off ? (u64*)put(G_IN1, off, (n + 1) * sizeof(u64)) : nullptr;
     u8* dsec = put(G_IN2, secrets, n * 32);
@@ -2177,16 +2178,28 @@ class Engine {
   // enters the context first completes the pending call (capi_common.h ELL_LOCK).
   struct Deferred {
     bool armed = false, on = false;
+    std::thread::id owner;         // the thread that armed: only ITS next call is deferred (a libuv worker's
+                                   // batch that slips in between must run to completion as usual)
     struct Out { u8* host; size_t bytes; } outs[4];
     int nout = 0;
     size_t out0 = 0;
     u8* pin = nullptr;
   } defer_;
-  void defer_arm() { defer_.armed = true; }
+  void defer_arm() { defer_.armed = true; defer_.owner = std::this_thread::get_id(); }
   bool defer_pending() const { return defer_.on; }
+  // is the next small call of THIS thread to be deferred?  (consumes the arming if so)
+  bool defer_take() {
+    if (!defer_.armed || defer_.owner != std::this_thread::get_id()) return false;
+    defer_skip();
+    return true;
+  }
+  // a call of the arming thread that cannot be deferred disarms; another thread's call leaves it armed
+  void defer_skip() {
+    if (defer_.armed && defer_.owner == std::this_thread::get_id()) defer_.armed = false;
+  }
   static size_t pad64(size_t b) { return (b + 63) & ~(size_t)63; }
   int defer_collect() {
-    defer_.armed = false;
+    defer_skip();
     if (!defer_.on) return E_OK;
     defer_.on = false;
     bk.select_lane(0);
@@ -2206,13 +2219,12 @@ class Engine {
   struct SpanOut { u8* host; const u8* dev; size_t bytes; };
   template <class Body>
   bool small_call(const SpanIn* ins, int nin, const SpanOut* outs, int nout, Body body, int* result) {
-    const bool defer = defer_.armed;
     size_t tot = 0;
     for (int i = 0; i < nin; i++) if (ins[i].host) tot += pad64(ins[i].bytes);
     for (int i = 0; i < nout; i++) if (outs[i].host) tot += pad64(outs[i].bytes);
     u8* pin = tot <= SMALL_HOST_BYTES ? (u8*)bk.pinned(SMALL_HOST_BYTES) : nullptr;
     if (!pin) return false;
-    defer_.armed = false;
+    const bool defer = defer_take();
     size_t off = 0;
     for (int i = 0; i < nin; i++)
       if (ins[i].host) {
@@ -2257,7 +2269,7 @@ class Engine {
       int rc = E_OK;
       if (small_call(si, nin, so, nout, [&]() { return body(0, n); }, &rc)) return rc;
     }
-    defer_.armed = false;
+    defer_skip();
     size_t q = bk.pipeline_quantum(), step = q;
     size_t o = 0, po = 0, pm = 0;
     int pev = -1, rc = E_OK;

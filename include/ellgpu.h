@@ -164,7 +164,9 @@ void* ellgpu_ctx_stream(ellgpu_ctx* ctx);
  * ellgpu_ctx_collect(ctx), which waits for the device and returns the call's status -- the host
  * validates while the device computes.  The result buffers must stay valid until then.  A call
  * that cannot be deferred runs to completion as usual and ellgpu_ctx_collect has nothing to do;
- * any other entry point on the context completes a pending call first.  collect also disarms. */
+ * any other entry point on the context completes a pending call first.  collect also disarms.
+ * Only the ARMING THREAD's next call is deferred: a call another host thread makes in between (the
+ * N-API worker running a Promise-form batch beside the JS thread) runs to completion as usual. */
 int ellgpu_ctx_defer(ellgpu_ctx* ctx);
 int ellgpu_ctx_collect(ellgpu_ctx* ctx);
 

@@ -864,6 +864,18 @@ def check_deferred_calls(ctx):
     ok3, err3 = ctx.eddsa_verify(msgs, sig0, pub0)
     ctx.collect()
     assert ok2.all() and np.array_equal(ok2, ok3) and np.array_equal(err2, err3)
+    # 4b. only the ARMING thread's next call is deferred: another thread's call that slips in between
+    #     (the N-API worker running a Promise-form batch beside the JS thread) runs to completion
+    import threading
+    ctx.defer()
+    box = []
+    th = threading.Thread(target=lambda: box.append(ctx.mul_var("secp256k1", ks, pts)))
+    th.start()
+    th.join()
+    assert np.array_equal(box[0][0], want) and np.array_equal(box[0][1], winf)      # complete when it returned
+    got4, ginf4 = ctx.mul_var("secp256k1", ks, pts)                                  # this thread's: still deferred
+    ctx.collect()
+    assert np.array_equal(got4, want) and np.array_equal(ginf4, winf)
     # 5. a batch that does not fit the pinned buffer is simply not deferred
     m = 6000
     kk = np.tile(ks, (m // n, 1))

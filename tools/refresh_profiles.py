@@ -46,6 +46,8 @@ MAP = {
     "wide_field.jsonl": "wide_field.jsonl",
     "single_call_breakdown.jsonl": "single_call_breakdown.jsonl",
     "latency_rows_ab.txt": "latency_rows_ab.txt",
+    "fuzz_gpu.log": "fuzz_gpu.log",
+    "soak_long.log": "soak_long.log",
 }
 
 # kernel name in the summaries -> (key bench.py uses, units per dispatch in the profiled command)

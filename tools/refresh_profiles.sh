@@ -76,6 +76,10 @@ if [ "$MODE" != "quick" ]; then
   timeout 300 python tools/bench_latency.py > $O/latency_rows_on.jsonl 2> $O/latency_rows.err
   ELLGPU_ROW_GRID=0 timeout 300 python tools/bench_latency.py > $O/latency_rows_off.jsonl 2>> $O/latency_rows.err
   unset ELLGPU_LATENCY_SIZES
+  # the seeded differential fuzz of the public API (unpatched against patched reference) on the device,
+  # and a longer soak against the C oracle
+  for seed in r6-gpu-a r6-gpu-b r6-gpu-c; do timeout 600 node tools/fuzz_patched_vs_plain.js 600 $seed 2>&1 | tail -c 1200; echo; done > $O/fuzz_gpu.log
+  timeout 400 python tests/soak.py --seconds 150 > $O/soak_long.log 2>&1
   python - > $O/latency_rows_ab.txt <<'PY'
 import json, os
 O = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "refresh")
