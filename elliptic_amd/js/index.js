@@ -108,12 +108,17 @@ Engine.prototype.mulAddBatch = function mulAddBatch(curve, k1, points1, k2,
 // 0 there, the safe answer; the reference computes with such keys and can answer true, and
 // install() runs the reference on exactly those items -- else 0.
 Engine.prototype.ecdsaVerifyBatch = function ecdsaVerifyBatch(curve, o) {
-  var id = this._id(curve);
-  this.stats.gpuCalls++; this.stats.gpuItems += o.hashes.length / o.hashLen;
-  var res = this.addon.ecdsaVerify(this.ctx, id, o.hashes, o.hashLen,
-    o.msgBits | 0, o.r, o.s, o.pub);
+  var res = this.ecdsaVerifyRaw(curve, o);
   if (o.status) res.status.copy(o.status);
   return res.ok;
+};
+// the same, returning the addon's own result { ok: Buffer(n), status: Buffer(n) }.  The form a SPLIT call
+// (addon.defer / addon.collect) must use: both Buffers are filled by collect(), so nothing may be read
+// out of them -- and neither may be dropped -- before it
+Engine.prototype.ecdsaVerifyRaw = function ecdsaVerifyRaw(curve, o) {
+  var id = this._id(curve);
+  this.stats.gpuCalls++; this.stats.gpuItems += o.hashes.length / o.hashLen;
+  return this.addon.ecdsaVerify(this.ctx, id, o.hashes, o.hashLen, o.msgBits | 0, o.r, o.s, o.pub);
 };
 Engine.prototype.x25519Batch = function x25519Batch(scalars, xs) {
   this.stats.gpuCalls++; this.stats.gpuItems += scalars.length / 32;
@@ -797,6 +802,8 @@ function install(elliptic, options) {
   // runs the reference's own method) when a table is not its point's multiples.
   // (ELLGPU_NO_DEFER=1, developer switch: validate first, then call -- what the overlap saves shows
   // as the difference, tools/bench_js_single_call.js)
+  // RULE for call(): it returns the addon's result object as it is -- every result Buffer stays
+  // referenced, and nothing is read out of them, until guarded() has collected.
   var canDefer = typeof addon.defer === 'function' && typeof addon.collect === 'function' && !eng.devices &&
     !process.env.ELLGPU_NO_DEFER;
   function guarded(curve, pts, call) {
@@ -1085,12 +1092,12 @@ function install(elliptic, options) {
       m = marshalOne(this, d, item, true);
       if (m.ref) throw null;                   // a key the engine does not take (see marshalOne)
       var pk = packVerify([ m ], msg.length, msgBitsOf(item)).o;
-      pk.status = Buffer.alloc(1);
-      // G's tables, and the key's if it has any: looked at while the device works
-      var res = guarded(this.curve, [this.curve.g, pub], function() { return eng.ecdsaVerifyBatch(d.id, pk); });
+      // G's tables, and the key's if it has any: looked at while the device works (the result's two
+      // Buffers are filled when guarded() collects: read only after it has returned)
+      var res = guarded(this.curve, [this.curve.g, pub], function() { return eng.ecdsaVerifyRaw(d.id, pk); });
       if (!res) throw null;                    // a table that is not its point's multiples
-      ok = res[0];
-      if (pk.status[0] === OFF_CURVE) ok = OFF_CURVE;
+      ok = res.ok[0];
+      if (res.status[0] === OFF_CURVE) ok = OFF_CURVE;
     } catch (e) {
       eng.stats.passthrough++;
       return orig.verify.apply(this, arguments);

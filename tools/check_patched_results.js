@@ -150,6 +150,11 @@ var pendingAsync = [];
     } else {
       var key = { x: c.qx, y: c.qy };
       if (ec.verify(c.z, { r: c.r, s: c.s }, key) !== c.ok) throw new Error('off-curve verify mismatch: ' + name + ' ' + c.note);
+      // ... and with the digest as BYTES, the form the patched EC#verify sends to the engine as one
+      // (split) call: the off-curve status comes back beside the verdict and must be read after the
+      // call has been collected (round 6: it was read before, and the reference's `true` was lost)
+      if (c.z.length % 2 === 0 && ec.verify(Buffer.from(c.z, 'hex'), { r: c.r, s: c.s }, key) !== c.ok)
+        throw new Error('off-curve verify mismatch (byte digest): ' + name + ' ' + c.note);
       items.push({ msg: Buffer.from(c.z, 'hex'), signature: { r: c.r, s: c.s }, key: key });
       wants.push(c.ok);
     }
