@@ -347,11 +347,18 @@ function install(elliptic, options) {
   // generator AND order equal one of the reference's presets (the engine's fixed-base tables,
   // GLV constants and scalar field belong to the preset's G and n: a curve over a preset field
   // with another generator -- or without one -- is passed through to the reference's own code)
+  // (the presets' numbers are COPIED here, when install() runs: the library's own preset objects are as
+  // reachable to the caller as any other curve object -- `ec.curve` of `new EC('secp256k1')` IS
+  // elliptic.curves.secp256k1.curve -- and a preset edited afterwards must stop being recognised)
   var presets = {};
   CURVES.forEach(function(name) {
     var c = elliptic.curves[name].curve;
+    var g = genCoords(c, c.g);
     presets[c.type + ':' + c.p.toString(16)] = { name: name, id: addon.curveId(name),
-      B: addon.fieldBytes(addon.curveId(name)), g: c.g };
+      B: addon.fieldBytes(addon.curveId(name)), g: c.g, hash: elliptic.curves[name].hash,
+      ref: { a: c.a.fromRed().clone(), b: c.b && c.b.red ? c.b.fromRed().clone() : null,
+        d: c.d && c.d.red ? c.d.fromRed().clone() : null, n: c.n.clone(),
+        g: g && g.map(function(v) { return v.clone(); }) } };
   });
   // affine coordinates of a generator as plain BNs, without touching the point object
   function genCoords(curve, g) {
@@ -363,16 +370,22 @@ function install(elliptic, options) {
     var m = curve.point(g.x, g.z);
     return m.isInfinity() ? null : [m.getX()];
   }
+  // (ref: the numbers install() copied from the preset)
   function sameGenerator(curve, ref) {
-    if (!curve.g || !curve.n || !ref.n || curve.n.cmp(ref.n) !== 0) return false;
-    var a = genCoords(curve, curve.g), b = genCoords(ref, ref.g);
+    if (!curve.g || !curve.n || !BN.isBN(curve.n) || curve.n.red || curve.n.cmp(ref.n) !== 0) return false;
+    var a = genCoords(curve, curve.g), b = ref.g;
     if (!a || !b || a.length !== b.length) return false;
     for (var i = 0; i < a.length; i++) if (a[i].cmp(b[i]) !== 0) return false;
     return true;
   }
+  // What is remembered is kept in WeakMaps of this install(), keyed by the caller's object: nothing is
+  // written onto the caller's objects (frozen ones included), and nobody else can plant a verdict.
+  var memo = { _ellgpu: new WeakMap(), _ellgpuCustom: new WeakMap(), _ellgpuEndo: new WeakMap(), _ellgpuOK: new WeakMap() };
   function hide(o, k, v) {
-    try { Object.defineProperty(o, k, { value: v, enumerable: false, writable: true, configurable: true }); }
-    catch (e) { /* a frozen object: checked again next time */ }
+    if (o !== null && (typeof o === 'object' || typeof o === 'function')) memo[k].set(o, v);
+  }
+  function recall(o, k) {
+    return o !== null && (typeof o === 'object' || typeof o === 'function') ? memo[k].get(o) : undefined;
   }
   // ---- witnesses: what a remembered verdict stands on ---------------------------------------------
   // install() remembers what it has established about the caller's objects -- "this curve object is
@@ -457,24 +470,21 @@ function install(elliptic, options) {
     return pos === s.length;
   }
   function domain(curve) {
-    var c = curve._ellgpu;
+    var c = recall(curve, '_ellgpu');
     if (c !== undefined && c.red === curve.red && sameCurve(curve, c.snap, true)) return c.d;
     var d = presets[curve.type + ':' + curve.p.toString(16)] || null;
     // (methods of a curve under construction -- ShortCurve#_getEndomorphism multiplies g before
     // the constructor returns -- see every field this test reads: p, n, g, a, b are set first)
     if (d && curve.type === 'short') {
-      var ref = elliptic.curves[d.name].curve;
-      if (!curve.a || !curve.b || curve.a.fromRed().cmp(ref.a.fromRed()) !== 0 ||
-          curve.b.fromRed().cmp(ref.b.fromRed()) !== 0) d = null;
+      if (!curve.a || !curve.b || curve.a.fromRed().cmp(d.ref.a) !== 0 ||
+          curve.b.fromRed().cmp(d.ref.b) !== 0) d = null;
     } else if (d && curve.type === 'edwards') {
-      var re = elliptic.curves[d.name].curve;
-      if (curve.a.fromRed().cmp(re.a.fromRed()) !== 0 ||
-          curve.d.fromRed().cmp(re.d.fromRed()) !== 0 || !curve.extended) d = null;
+      if (curve.a.fromRed().cmp(d.ref.a) !== 0 ||
+          curve.d.fromRed().cmp(d.ref.d) !== 0 || !curve.extended) d = null;
     } else if (d && curve.type === 'mont') {
-      if (curve.a.fromRed().cmp(elliptic.curves[d.name].curve.a.fromRed()) !== 0)
-        d = null;
+      if (curve.a.fromRed().cmp(d.ref.a) !== 0 || !curve.b || curve.b.fromRed().cmp(d.ref.b) !== 0) d = null;
     }
-    if (d && !sameGenerator(curve, elliptic.curves[d.name].curve)) d = null;
+    if (d && !sameGenerator(curve, d.ref)) d = null;
     var snap = null;
     try { snap = snapCurve(curve, true); } catch (e) { snap = null; }
     if (snap) hide(curve, '_ellgpu', { d: d, red: curve.red, snap: snap });
@@ -523,7 +533,7 @@ function install(elliptic, options) {
     return true;
   }
   function customDomain(curve) {
-    var cc = curve._ellgpuCustom;
+    var cc = recall(curve, '_ellgpuCustom');
     if (cc !== undefined && cc.red === curve.red && sameCurve(curve, cc.snap, false)) return cc.d;
     var d = null;
     if (options && options.customCurves === false) return null;
@@ -610,7 +620,8 @@ function install(elliptic, options) {
   // computes k * P from (x, y) alone, so it answers only for points whose tables ARE their
   // multiples: each table is checked once (the reference's Jacobian / projective dbl() and add(), a
   // few milliseconds per curve -- 6 for secp256k1, 65 for p521 --), and the verdict
-  // is remembered on the table object; anything else is left to the reference's own ladders.
+  // is remembered FOR the table object (a WeakMap of this install(), beside a witness of what it was
+  // reached on: `recall` / `hide`); anything else is left to the reference's own ladders.
   function canonical(curve, v) { return !!v && v.red === curve.red && !v.isNeg() && v.cmp(curve.p) < 0; }
   function entryOK(curve, e) {
     if (!e || e.curve !== curve || !canonical(curve, e.x) || !canonical(curve, e.y)) return false;
@@ -667,7 +678,7 @@ function install(elliptic, options) {
   }
   function tableOK(curve, p, tbl, kind) {
     if (!tbl) return true;
-    var c = tbl._ellgpuOK;
+    var c = recall(tbl, '_ellgpuOK');
     var w = kind === 'naf' ? tbl.wnd : tbl.step;
     if (c && c.p === p && c.pts === tbl.points && c.w === w && sameTable(curve, p, c.pts, c)) return c.ok;
     var ok = false;
@@ -748,7 +759,7 @@ function install(elliptic, options) {
   function endoOK(curve) {
     var e = curve.endo;
     if (!e) return true;
-    var c = curve._ellgpuEndo;
+    var c = recall(curve, '_ellgpuEndo');
     if (c && c.red === curve.red && sameEndo(curve, c.snap)) return c.ok;
     var ok = false;
     refOnly++;
@@ -1042,7 +1053,7 @@ function install(elliptic, options) {
       if (!d || !ecOK(this) || options.k || options.pers !== undefined || typeof msg !== 'object' || BN.isBN(msg) ||
           !msg || typeof msg.length !== 'number' || msg.length === 0 || !plainMsgBits(options)) throw null;
       // new EC({ curve, hash }) may carry another DRBG hash than the preset's (ec/index.js:31)
-      if (this.hash !== elliptic.curves[d.name].hash) throw null;
+      if (this.hash !== d.hash) throw null;                 // (the preset's hash as install() found it)
       for (var i = 0; i < msg.length; i++) if ((msg[i] & 255) !== msg[i]) throw null;
       var priv = this.keyFromPrivate(key, enc).getPrivate();
       var NB = this.n.byteLength();
@@ -1263,6 +1274,13 @@ function install(elliptic, options) {
     }
     eng.stats.passthrough++;
     return orig.derive.apply(this, arguments);
+  };
+
+  // what install() takes a curve object for (tests; nothing is stored on the object itself):
+  // { preset: name | null, custom: curve id | null }
+  eng.recognised = function recognised(curve) {
+    var d = domain(curve), c = d ? null : customDomain(curve);
+    return { preset: d ? d.name : null, custom: c ? c.id : null };
   };
 
   eng.uninstall = function uninstall() {

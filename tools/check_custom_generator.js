@@ -59,8 +59,11 @@ function same(a, b, what) {
     throw new Error(name + ': a custom-generator curve reached the engine');
   if (CUSTOM && eng.stats.gpuCalls === before)
     throw new Error(name + ': the user-defined curve did not reach the engine');
-  // (the remembered verdicts, each beside its witness: { d, red, snap } -- index.js `domain`, `customDomain`)
-  if (CUSTOM && (!cq._ellgpu || cq._ellgpu.d !== null || !cq._ellgpuCustom || !cq._ellgpuCustom.d || cq._ellgpuCustom.d.id < 16))
+  // (what install() takes the curve object for -- kept in its own WeakMaps, nothing is written on the object)
+  var rec = eng.recognised(cq);
+  if (Object.keys(cq).some(function(k) { return /ellgpu/i.test(k); }) || Object.getOwnPropertyNames(cq).some(function(k) { return /ellgpu/i.test(k); }))
+    throw new Error(name + ': install() wrote on the caller\'s curve object');
+  if (CUSTOM && (rec.preset !== null || rec.custom === null || rec.custom < 16))
     throw new Error(name + ': a custom-generator curve was taken for the preset');
 });
 // the general forms of _wnafMulAdd / _endoWnafMulAdd: 3 and 4 points (paired up on the device)

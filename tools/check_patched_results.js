@@ -202,7 +202,7 @@ var pendingAsync = [];
     byOp[o.op] = (byOp[o.op] || 0) + 1;
     checked++;
   });
-  if ((byOp.tables || 0) < 500 || (byOp['g-tables'] || 0) < 30 || (byOp.endo || 0) < 20 || (byOp.toy || 0) < 25 || (byOp['toy-endo'] || 0) < 6 || (byOp['foreign-red'] || 0) < 10 || (byOp.mutate || 0) < 100)
+  if ((byOp.tables || 0) < 500 || (byOp['g-tables'] || 0) < 30 || (byOp.endo || 0) < 20 || (byOp.toy || 0) < 25 || (byOp['toy-endo'] || 0) < 6 || (byOp['foreign-red'] || 0) < 10 || (byOp.mutate || 0) < 130)
     throw new Error('trusted_inputs.json is not the file tools/gen_golden.js writes: ' + JSON.stringify(byOp));
 })();
 Promise.all(pendingAsync).then(function() {

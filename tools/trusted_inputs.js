@@ -290,9 +290,11 @@ var MUTATE = [ 'entry', 'coord', 'words', 'y-words', 'width', 'beta-entry', 'bet
   'endo-lambda', 'curve-n-words', 'curve-n-replace', 'curve-g', 'curve-b-words', 'ec-g', 'ec-n', 'ec-nh', 'none' ];
 function mutateAfterUse(L, o) {
   var BN = L.curves.secp256k1.curve.p.constructor;
-  var c = o.curve === 'secp256k1' ? endoCurve(L, 'auto') : cloneCurve(L, o.curve);
+  // (o.preset: the library's OWN preset object -- what `new EC(name).curve` is -- instead of a copy; the
+  // change is always undone before the recipe returns, whatever throws in between)
+  var c = o.preset ? L.curves[o.curve].curve : o.curve === 'secp256k1' ? endoCurve(L, 'auto') : cloneCurve(L, o.curve);
   var k = new BN(o.k, 16), k2 = new BN(o.k2, 16), one = new BN(1);
-  var ec = c.type === 'short' ? ecOn(L, c, o.curve) : null;
+  var ec = c.type !== 'short' ? null : o.preset ? new L.ec(o.curve) : ecOn(L, c, o.curve);
   if (!ec) c.g.precompute(c.n.bitLength() + 1);
   var S, other = c.g.mul(new BN(11));
   if (o.subject === 'G') S = c.g;
@@ -355,8 +357,8 @@ function mutateAfterUse(L, o) {
     case 'ec-nh': if (ec) swap(ec, 'nh', ec.nh.ushrn(3)); else flip(c.n, 0, 2); break;
     default: throw new Error('unknown mutation ' + o.mutation);
   }
-  var second = calls();
-  undo();
+  var second;
+  try { second = calls(); } finally { undo(); }
   return [ first, second, calls() ];
 }
 
@@ -425,6 +427,13 @@ function recipes(rng) {
         out.push({ op: 'mutate', curve: curve, subject: subject, mutation: mutation, table: (ci + mi + si) % 2 ? 'naf' : 'doubles',
           at: small(), mult: 5 + (mi % 3), k: hex(31), k2: hex(1 + mi % 2 * 15), d: hex(20), msg: arr(32) });
       });
+    });
+  });
+  // ... and the library's own preset objects (`new EC(name).curve` IS elliptic.curves[name].curve)
+  [ 'secp256k1', 'p256', 'ed25519' ].forEach(function(curve, ci) {
+    [ 'curve-n-words', 'curve-b-words', 'endo-basis', 'endo-beta', 'curve-g', 'entry', 'words', 'none' ].forEach(function(mutation, mi) {
+      out.push({ op: 'mutate', preset: true, curve: curve, subject: mi % 2 ? 'G' : 'P', mutation: mutation, table: mi % 3 ? 'naf' : 'doubles',
+        at: small(), mult: 5 + (mi % 3), k: hex(31), k2: hex(1 + mi % 2 * 15), d: hex(20), msg: arr(32) });
     });
   });
   return out;
