@@ -350,6 +350,10 @@ function install(elliptic, options) {
   // (the presets' numbers are COPIED here, when install() runs: the library's own preset objects are as
   // reachable to the caller as any other curve object -- `ec.curve` of `new EC('secp256k1')` IS
   // elliptic.curves.secp256k1.curve -- and a preset edited afterwards must stop being recognised)
+  // hash.js's sha512 as the EDDSA constructor assigns it to every instance (eddsa/index.js:24): taken
+  // from a fresh instance made at the first patched EDDSA call -- by then the caller's own instance
+  // exists, so the constructor's one side effect (G's precompute) has already happened
+  var HASH512 = null;
   var presets = {};
   CURVES.forEach(function(name) {
     var c = elliptic.curves[name].curve;
@@ -790,10 +794,14 @@ function install(elliptic, options) {
   }
   // an EC / EDDSA instance multiplies ITS g and reduces by ITS n (ec/index.js:37-45, eddsa/index.js:
   // 17-20): they are the curve's unless somebody replaced them
+  // (an EDDSA instance also carries its hash, the encoding length and the point class: eddsa/index.js:22-24)
   function ecOK(ec) {
     var c = ec.curve;
     if (ec.g !== c.g) return false;
-    if (ec.n === undefined) return true;                       // EDDSA keeps no n of its own
+    if (ec.n === undefined) {                                  // EDDSA keeps no n of its own
+      if (!HASH512) HASH512 = new elliptic.eddsa('ed25519').hash;
+      return ec.hash === HASH512 && ec.encodingLength === 32 && ec.pointClass === c.point().constructor;
+    }
     var n = c.n, h = ec.nh;
     if (ec.n !== n || !h || h.red || h.negative !== 0 || !n || n.negative !== 0) return false;
     // nh = n >> 1, word by word (26-bit words, dist/elliptic.js:3998): no allocation on this path

@@ -278,6 +278,25 @@ function run(L, o) {
       render(function() { return kp.getPublic().mul(k.toRed(c.red)); }), render(function() { return kp.getPublic().mul(k.toRed(c2.red)); }) ];
   });
   if (o.op === 'mutate') return render(function() { return mutateAfterUse(L, o); });
+  if (o.op === 'mutate-eddsa') return render(function() {
+    // an EDDSA instance's own fields, changed after its first use (eddsa/index.js:17-24)
+    var ed = new L.eddsa('ed25519'), key = ed.keyFromSecret(o.secret);
+    function calls() {
+      return [ render(function() { var sg = ed.sign(o.msg, key); return [ sg.toHex(), ed.verify(o.msg, sg, key.getPublic()) ]; }),
+        render(function() { return ed.verify(o.msg, o.sig, o.pub); }) ];
+    }
+    var first = calls(), undo = function() {}, second;
+    function swap(obj, prop, val) { var old = obj[prop]; obj[prop] = val; undo = function() { obj[prop] = old; }; }
+    switch (o.mutation) {
+      case 'hash': swap(ed, 'hash', L.curves.ed25519.hash); break;                 // sha256 instead of sha512
+      case 'g': swap(ed, 'g', ed.curve.g.mul(new BN(3))); break;
+      case 'encodingLength': swap(ed, 'encodingLength', 31); break;
+      case 'none': break;
+      default: throw new Error('unknown mutation ' + o.mutation);
+    }
+    try { second = calls(); } finally { undo(); }
+    return [ first, second, calls() ];
+  });
   throw new Error('unknown op ' + o.op);
 }
 
@@ -428,6 +447,11 @@ function recipes(rng) {
           at: small(), mult: 5 + (mi % 3), k: hex(31), k2: hex(1 + mi % 2 * 15), d: hex(20), msg: arr(32) });
       });
     });
+  });
+  [ 'hash', 'g', 'encodingLength', 'none' ].forEach(function(mutation) {
+    out.push({ op: 'mutate-eddsa', mutation: mutation, secret: hex(32), msg: arr(24),
+      sig: '92a009a9f0d4cab8720e820b5f642540a2b27b5416503f8fb3762223ebdb69da085ac1e43e15996e458f3613d0f11d8c387b2eaeb4302aeeb00d291612bb0c00',
+      pub: 'fc51cd8e6218a1a38da47ed00230f0580816ed13ba3303ac5deb911548908025' });
   });
   // ... and the library's own preset objects (`new EC(name).curve` IS elliptic.curves[name].curve)
   [ 'secp256k1', 'p256', 'ed25519' ].forEach(function(curve, ci) {
