@@ -885,11 +885,18 @@ def main():
 
         drain, gathered = og.drain, og.result
 
+        torch.cuda.synchronize()                        # the shard's copies were made on the default stream; the steps run on the lanes
         for _ in range(max(args.warmup, 2)):
             strong_step()
         drain()
         torch.cuda.synchronize()
         mask_ok = all(bool(torch.equal(gathered(b).to(exp_all.device), exp_all)) for b in (0, 1))
+        if not mask_ok:                                # say where, before every rank exits on the reduced flag
+            for b in (0, 1):
+                bad = torch.nonzero(gathered(b).to(exp_all.device) != exp_all).flatten()
+                if bad.numel():
+                    sys.stderr.write("rank %d: gathered mask of buffer %d differs from the expected mask at %d of %d tuples "
+                                     "(first %s; shards of %d)\n" % (rank, b, bad.numel(), nb, bad[:8].tolist(), hi - lo))
         flag = torch.tensor([1 if mask_ok else 0], dtype=torch.int64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) != 1:

@@ -155,6 +155,12 @@ class OverlappedGather:
         self.pending = [None, None]
         self.turn = 0
         self.cur = None
+        # The zero fills above were queued on the stream that is current HERE; the caller's steps
+        # may run on other (non-blocking) streams, which do not order themselves after it -- a
+        # fill that lands after the first step's kernels wipes that step's shard.  Seen with eight
+        # processes sharing one device (3 of 16 runs); one device-wide wait at construction ends it.
+        if torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)
 
     def begin(self):
         b = self.turn
