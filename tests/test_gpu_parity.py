@@ -910,6 +910,7 @@ def test_dev_calls_on_alternating_streams(ctx):
     streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     torch.cuda.synchronize()
     for rep in range(3):
+        torch.cuda.synchronize()                        # the zero_() calls below run on the default stream
         for i, k in enumerate(dk):
             with torch.cuda.stream(streams[i & 1]):
                 ctx.mul_var_dev("secp256k1", k, dp, outs[i][0], outs[i][1])
@@ -926,6 +927,7 @@ def test_dev_calls_on_alternating_streams(ctx):
     oks = [torch.zeros(m, dtype=torch.uint8, device=dev) for m in sizes]
     torch.cuda.synchronize()
     for rep in range(3):
+        torch.cuda.synchronize()                        # as above: zero_() is queued on the default stream
         for i, k in enumerate(dk):
             m = sizes[i]
             with torch.cuda.stream(streams[i % 3]):
