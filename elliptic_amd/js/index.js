@@ -448,10 +448,45 @@ function install(elliptic, options) {
   function coeffs(curve) {
     return curve.type === 'edwards' ? [curve.a, curve.d, curve.c] : [curve.a, curve.b];
   }
+  // ... and what the constructors DERIVE from them and the formulas read (base.js:20-23 zero / one /
+  // two, short.js:20-25 tinv / zeroA / threeA, edwards.js:15-32 c2 / dd / oneC / twisted / mOneA /
+  // extended, mont.js:14-19 i4 / a24): part of every witness, and right -- derivedOK -- or the curve
+  // object is the reference's own
+  function derived(curve) {
+    if (curve.type === 'short') return [curve.zero, curve.one, curve.two, curve.tinv];
+    if (curve.type === 'edwards') return [curve.zero, curve.one, curve.two, curve.c2, curve.dd];
+    return [curve.zero, curve.one, curve.two, curve.i4, curve.a24];
+  }
+  function flagsOf(curve) {
+    if (curve.type === 'short') return (curve.zeroA ? 1 : 0) | (curve.threeA ? 2 : 0);
+    if (curve.type === 'edwards') return (curve.twisted ? 1 : 0) | (curve.mOneA ? 2 : 0) | (curve.extended ? 4 : 0) | (curve.oneC ? 8 : 0);
+    return 0;
+  }
+  function derivedOK(curve) {
+    var red = curve.red, one = new BN(1).toRed(red), two = one.redAdd(one);
+    function is(v, w) { return !!v && v.red === red && v.negative === 0 && v.cmp(w) === 0; }
+    if (!is(curve.zero, new BN(0).toRed(red)) || !is(curve.one, one) || !is(curve.two, two)) return false;
+    var a = curve.a, m1 = one.redNeg();
+    if (!a || a.red !== red || a.negative !== 0) return false;
+    if (curve.type === 'short') {
+      return is(curve.tinv, two.redInvm()) && !!curve.zeroA === (a.cmpn(0) === 0) &&
+        !!curve.threeA === (a.cmp(m1.redSub(two)) === 0);
+    }
+    if (curve.type === 'edwards') {
+      var c = curve.c, d = curve.d;
+      if (!c || c.red !== red || !d || d.red !== red || c.negative !== 0 || d.negative !== 0) return false;
+      return is(curve.c2, c.redSqr()) && is(curve.dd, d.redAdd(d)) && !!curve.oneC === (c.cmp(one) === 0) &&
+        !!curve.extended === !!curve.mOneA && (!curve.mOneA || (!!curve.twisted && a.cmp(m1) === 0)) && (!!curve.twisted || a.cmp(one) === 0);
+    }
+    var i4 = two.redAdd(two).redInvm();
+    return is(curve.i4, i4) && is(curve.a24, i4.redMul(a.redAdd(two)));
+  }
   function snapCurve(curve, withGen) {
     var v = [];
     snapBN(v, curve.p);
     coeffs(curve).forEach(function(c) { snapBN(v, c); });
+    derived(curve).forEach(function(c) { snapBN(v, c); });
+    v.push(flagsOf(curve));
     if (withGen) {
       snapBN(v, curve.n);
       var g = curve.g;
@@ -464,6 +499,9 @@ function install(elliptic, options) {
   function sameCurve(curve, s, withGen) {
     var red = curve.red, pos = sameBN(s, 0, curve.p, null), cs = coeffs(curve);
     for (var i = 0; pos >= 0 && i < cs.length; i++) pos = sameBN(s, pos, cs[i], red);
+    var ds = derived(curve);
+    for (i = 0; pos >= 0 && i < ds.length; i++) pos = sameBN(s, pos, ds[i], red);
+    if (pos >= 0) pos = s[pos] === flagsOf(curve) ? pos + 1 : -1;
     if (pos >= 0 && withGen) {
       pos = sameBN(s, pos, curve.n, null);
       var g = curve.g;
@@ -473,7 +511,12 @@ function install(elliptic, options) {
     }
     return pos === s.length;
   }
+  // (whatever the caller's objects make these checks throw -- a coefficient that is no BN any more, a
+  // sign bit set on a reduced number -- is an object the patch cannot vouch for: the reference's own code)
   function domain(curve) {
+    try { return domain0(curve); } catch (e) { return null; }
+  }
+  function domain0(curve) {
     var c = recall(curve, '_ellgpu');
     if (c !== undefined && c.red === curve.red && sameCurve(curve, c.snap, true)) return c.d;
     var d = presets[curve.type + ':' + curve.p.toString(16)] || null;
@@ -489,6 +532,7 @@ function install(elliptic, options) {
       if (curve.a.fromRed().cmp(d.ref.a) !== 0 || !curve.b || curve.b.fromRed().cmp(d.ref.b) !== 0) d = null;
     }
     if (d && !sameGenerator(curve, d.ref)) d = null;
+    if (d && !derivedOK(curve)) d = null;
     var snap = null;
     try { snap = snapCurve(curve, true); } catch (e) { snap = null; }
     if (snap) hide(curve, '_ellgpu', { d: d, red: curve.red, snap: snap });
@@ -537,6 +581,9 @@ function install(elliptic, options) {
     return true;
   }
   function customDomain(curve) {
+    try { return customDomain0(curve); } catch (e) { return null; }
+  }
+  function customDomain0(curve) {
     var cc = recall(curve, '_ellgpuCustom');
     if (cc !== undefined && cc.red === curve.red && sameCurve(curve, cc.snap, false)) return cc.d;
     var d = null;
@@ -549,6 +596,7 @@ function install(elliptic, options) {
     }
     if (curve.p && curve.p.bitLength() <= 256 && curve.p.isOdd() && curve.p.cmpn(3) > 0 &&
         !probablyPrime(curve.p)) return remember(null);
+    if (!derivedOK(curve)) return remember(null);
     // A singular cubic (4 a^3 + 27 b^2 = 0) has no group law at its singular point, and an Edwards
     // curve whose addition law is not complete (complete: a a square, d not -- Bernstein et al.,
     // "Twisted Edwards curves", section 6) has pairs of points on which the projective formulas give
@@ -592,9 +640,12 @@ function install(elliptic, options) {
     // curve object over the same field, which is also what ec.keyFromPublic(Q) does, ec/key.js:96 --
     // make bn.js throw 'red works only with red numbers' in the reference's first field operation)
     if (!p.x || !p.y || p.x.red !== curve.red || p.y.red !== curve.red) return null;
+    // (a reduced number with its sign bit set: bn.js throws 'red works only with positives' at the first product)
+    if (p.x.negative !== 0 || p.y.negative !== 0) return null;
     if (curve.type === 'short') { if (p.type !== 'affine') return null; x = p.getX(); y = p.getY(); }
     else {
       if (!p.z || p.z.red !== curve.red || (p.t && p.t.red !== curve.red)) return null;
+      if (p.z.negative !== 0 || (p.t && p.t.negative !== 0)) return null;
       // extended coordinates carry T = X Y / Z, which the reference's _extAdd / _extDbl USE
       // (edwards.js:279-309): a point built with any other T (curve.point(x, y, z, t) takes what
       // it is given) is not the point its (x, y) says -- the reference's own, like a point that is
@@ -657,6 +708,9 @@ function install(elliptic, options) {
         q = q.add(two);
         if (!samePoint(curve, pts[i], q)) return false;
       }
+      // (entries no digit reaches are never ADDED, but _getBeta and neg(true) map the whole array,
+      // short.js:282-310, 437-462: each must be something those maps do not throw on)
+      for (; i < pts.length; i++) if (!entryOK(curve, pts[i])) return false;
       return true;
     }
     // doubles: entry j is 2^(step j) * P, every one of them within reach of _hasDoubles
@@ -697,6 +751,9 @@ function install(elliptic, options) {
     return ok;
   }
   function tablesOK(curve, p, inner) {
+    try { return tablesOK0(curve, p, inner); } catch (e) { return false; }
+  }
+  function tablesOK0(curve, p, inner) {
     var pre = p && p.precomputed;
     if (!pre) return true;
     if (typeof pre !== 'object') return false;
@@ -705,7 +762,7 @@ function install(elliptic, options) {
       // lambda * P as _getBeta caches it: (beta x, y), with the tables of THAT point
       var b = pre.beta;
       if (inner || !entryOK(curve, b) || b.x.cmp(p.x.redMul(curve.endo.beta)) !== 0 || b.y.cmp(p.y) !== 0) return false;
-      if (!tablesOK(curve, b, true)) return false;
+      if (!tablesOK0(curve, b, true)) return false;
     }
     return true;
   }
@@ -761,6 +818,9 @@ function install(elliptic, options) {
     return pos === s.length;
   }
   function endoOK(curve) {
+    try { return endoOK0(curve); } catch (e) { return false; }
+  }
+  function endoOK0(curve) {
     var e = curve.endo;
     if (!e) return true;
     var c = recall(curve, '_ellgpuEndo');
@@ -796,6 +856,9 @@ function install(elliptic, options) {
   // 17-20): they are the curve's unless somebody replaced them
   // (an EDDSA instance also carries its hash, the encoding length and the point class: eddsa/index.js:22-24)
   function ecOK(ec) {
+    try { return ecOK0(ec); } catch (e) { return false; }
+  }
+  function ecOK0(ec) {
     var c = ec.curve;
     if (ec.g !== c.g) return false;
     if (ec.n === undefined) {                                  // EDDSA keeps no n of its own
@@ -839,6 +902,31 @@ function install(elliptic, options) {
     try { r = call(); good = ok(); } finally { addon.collect(eng.ctx); }
     return good ? r : null;
   }
+  // The reference's GLV ladder fills a table-carrying operand's `precomputed.beta` the first time it
+  // meets it (short.js:225 -> 282-310: lambda * P and ALL its table entries, from curve.endo.beta as
+  // it is at that moment) -- state that its later calls read.  A call the engine answers in the GLV
+  // ladder's place leaves that state behind as the reference's call would have: with the reference's
+  // own _getBeta, at the same moment.  (Otherwise an edit of curve.endo.beta or of G's coordinates
+  // between two calls meets a cache made at another time than the reference's: found by
+  // tools/probe_mutation_walk.js.)  false: _getBeta threw -- what it half-did is taken back, and the
+  // caller runs the reference's own method, which throws the same and leaves the same behind.
+  // (... and false where the ladder's scratch arrays are no arrays any more: base.js:128-136,
+  // short.js:218-221 write into curve._wnafT1..4 / _endoWnafT1..2 -- a TypeError of the reference's own)
+  function scratchOK(curve) {
+    return Array.isArray(curve._wnafT1) && Array.isArray(curve._wnafT2) && Array.isArray(curve._wnafT3) && Array.isArray(curve._wnafT4) &&
+      (!curve.endo || (Array.isArray(curve._endoWnafT1) && Array.isArray(curve._endoWnafT2)));
+  }
+  function lazyBeta(curve, pts) {
+    if (!scratchOK(curve)) return false;
+    if (!curve.endo) return true;
+    for (var i = 0; i < pts.length; i++) {
+      var p = pts[i], pre = p && p.precomputed;
+      if (!pre || typeof pre !== 'object' || pre.beta || typeof p._getBeta !== 'function') continue;
+      var was = pre.beta;
+      try { p._getBeta(); } catch (e) { try { pre.beta = was; } catch (x) { /* frozen */ } return false; }
+    }
+    return true;
+  }
   // an operand as the engine takes it, or null where the reference must compute by itself
   function operandBuf(curve, p, B) {
     var b = affineBuf(curve, p, B);
@@ -876,10 +964,11 @@ function install(elliptic, options) {
     refOnly++;
     try { return origFn.apply(curve, origArgs); } finally { refOnly--; }
   }
-  function mul1(curve, p, k, origFn, origArgs) {
+  function mul1(curve, p, k, origFn, origArgs, glv) {
     var d = ladderDomain(curve);
     var kb = d && scalarBuf(k, d.B);
     var pb = kb && affineBuf(curve, p, d.B);
+    if (pb && glv && !lazyBeta(curve, [p])) pb = null;
     var r = pb && guarded(curve, [p], function() {
       return isG(curve, d, p) ? eng.mulBatch(d.id, kb, null) : eng.mulBatch(d.id, kb, pb);
     });
@@ -887,12 +976,13 @@ function install(elliptic, options) {
     if (r.inf[0] === OFF_CURVE) return offCurve(curve, origFn, origArgs);
     return resultPoint(curve, d, r, false);
   }
-  function mulAdd(curve, p1, k1, p2, k2, jacobian, origFn, origArgs) {
+  function mulAdd(curve, p1, k1, p2, k2, jacobian, origFn, origArgs, glv) {
     var d = ladderDomain(curve);
     var b1 = d && scalarBuf(k1, d.B);
     var b2 = b1 && scalarBuf(k2, d.B);
     var q1 = b2 && affineBuf(curve, p1, d.B);
     var q2 = q1 && affineBuf(curve, p2, d.B);
+    if (q2 && !(glv ? lazyBeta(curve, [p1, p2]) : scratchOK(curve))) q2 = null;
     var r = q2 && guarded(curve, [p1, p2], function() {
       return eng.mulAddBatch(d.id, b1, isG(curve, d, p1) ? null : q1, b2, q2);
     });
@@ -906,10 +996,15 @@ function install(elliptic, options) {
   // own callers pass at most two points): the points
   // are paired up, every pair is one item of ONE k1*P1 + k2*P2 launch, and the partial sums are
   // added with the reference's Point#add.
-  function mulAddMany(curve, points, coeffs, len, jacobian, origFn, origArgs) {
+  function mulAddMany(curve, points, coeffs, len, jacobian, origFn, origArgs, glv) {
     var d = ladderDomain(curve);
     var k1 = [], p1 = [], k2 = [], p2 = [];
     var ok = !!d && len >= 3 && len <= 8;
+    if (ok && !glv) ok = scratchOK(curve);
+    if (ok && glv) {
+      for (var c = 0; ok && c < len; c++) ok = !!scalarBuf(coeffs[c], d.B) && !!affineBuf(curve, points[c], d.B);
+      ok = ok && lazyBeta(curve, Array.prototype.slice.call(points, 0, len));
+    }
     for (var i = 0; ok && i < len; i += 2) {
       var j = i + 1 < len ? i + 1 : i;               // odd tail: k * P + 0 * P
       var a = scalarBuf(coeffs[i], d.B), pa = operandBuf(curve, points[i], d.B);
@@ -973,14 +1068,14 @@ function install(elliptic, options) {
     jacobianResult) {
     if (refOnly) return orig.endoWnafMulAdd.apply(this, arguments);
     if (points.length === 1) {
-      var r = mul1(this, points[0], coeffs[0], orig.endoWnafMulAdd, arguments);
+      var r = mul1(this, points[0], coeffs[0], orig.endoWnafMulAdd, arguments, true);
       return jacobianResult && r.toJ ? r.toJ() : r;
     }
     if (points.length === 2)
       return mulAdd(this, points[0], coeffs[0], points[1], coeffs[1],
-        !!jacobianResult, orig.endoWnafMulAdd, arguments);
+        !!jacobianResult, orig.endoWnafMulAdd, arguments, true);
     return mulAddMany(this, points, coeffs, points.length, !!jacobianResult,
-      orig.endoWnafMulAdd, arguments);
+      orig.endoWnafMulAdd, arguments, true);
   };
 
   // point decompression: ShortCurve#pointFromX (short.js:187-204) and
@@ -1110,6 +1205,8 @@ function install(elliptic, options) {
       var item = { msg: msg, signature: signature, key: kp, options: options || undefined };
       m = marshalOne(this, d, item, true);
       if (m.ref) throw null;                   // a key the engine does not take (see marshalOne)
+      // (ec/index.js:202-225: past its range checks the reference multiplies through the GLV ladder)
+      if (m.pre && !lazyBeta(this.curve, [this.curve.g, pub])) throw null;
       var pk = packVerify([ m ], msg.length, msgBitsOf(item)).o;
       // G's tables, and the key's if it has any: looked at while the device works (the result's two
       // Buffers are filled when guarded() collects: read only after it has returned)
@@ -1152,6 +1249,8 @@ function install(elliptic, options) {
     if (!res) { eng.stats.passthrough++; return orig.recoverPubKey.apply(this, arguments); }
     // status 2 / 3: the reference throws, or inverts an unreduced r -- let it
     if (res.status[0] >= 2) return orig.recoverPubKey.apply(this, arguments);
+    // (ec/index.js:252: g.mulAdd(s1, r, s2), reached once r has its point)
+    if (!lazyBeta(this.curve, [this.curve.g])) return orig.recoverPubKey.apply(this, arguments);
     if (res.status[0] === 1) return this.curve.point(null, null);
     return this.curve.point(new BN(res.xy.slice(0, d.B)), new BN(res.xy.slice(d.B, 2 * d.B)));
   };
@@ -1313,7 +1412,7 @@ function install(elliptic, options) {
   // items: [{ msg: Buffer|Array, signature, key, enc? }] -> [bool]
   // a preset whose G carries tables that are not G's multiples, or whose endomorphism constants are
   // not the curve's (protocolDomain): every item through EC#verify, whose ladders decide by themselves
-  function untrusted(ec, d) { return d && !(protocolDomain(ec.curve) && ecOK(ec)); }
+  function untrusted(ec, d) { return d && !(lazyBeta(ec.curve, [ec.curve.g]) && protocolDomain(ec.curve) && ecOK(ec)); }
   function verifyEach(ec, items) {
     return items.map(function(it) { return ec.verify(it.msg, it.signature, it.key, it.enc, it.options); });
   }
@@ -1435,7 +1534,7 @@ function install(elliptic, options) {
       // G's tables: looked at once per batch (the calls of one tick see one state of the library),
       // HERE -- in the tick of the calls, while the worker thread already runs the batch; a table
       // that is not G's multiples leaves every call to the synchronous path, the batch's verdicts unused
-      var trusted = tablesOK(g.ec.curve, g.ec.curve.g);
+      var trusted = lazyBeta(g.ec.curve, [g.ec.curve.g]) && tablesOK(g.ec.curve, g.ec.curve.g);
       if (!trusted) { job.catch(function() {}); return each(good); }
       job.then(function(ok) {
         good.forEach(function(p, i) {

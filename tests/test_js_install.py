@@ -195,6 +195,57 @@ def test_differential_fuzz_of_the_public_api_gpu():
     _run_fuzz(None, 600, "gpu-1")
 
 
+def _run_walk(lib, families, stride=1, offset=0, timeout=3000):
+    """tools/probe_mutation_walk.js: ONE reachable property of the caller's objects changed after their
+    first use -- every property the walk finds from an EC / EDDSA instance, its curve, the generator's and
+    an operand's tables, a key pair, a signature -- calls, undo, calls: the patched library answers what the
+    reference answers, except inside what INTEGRATION.md section 2 lists as treated as immutable"""
+    # (a change that makes the REFERENCE loop costs two time limits: a path takes well under a second)
+    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference(), WALK_STRIDE=str(stride), WALK_OFFSET=str(offset),
+               WALK_LIMIT_MS=os.environ.get("WALK_LIMIT_MS", "15000"))
+    if lib:
+        env["ELLGPU_LIB"] = lib
+        env.update(HOSTSIM_ENV)
+    else:
+        env.pop("ELLGPU_LIB", None)
+    procs = [subprocess.Popen(["node", os.path.join(ROOT, "tools", "probe_mutation_walk.js"), f], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for f in families]
+    rows = []
+    for f, p in zip(families, procs):
+        try:
+            out, err = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise
+        assert p.returncode == 0, f + "\n" + out[-3000:] + err[-2000:]
+        res = json.loads(out.strip().splitlines()[-1])
+        row = json.loads([l for l in out.splitlines() if l.startswith('{"family"')][0])
+        assert res["failures"] == 0 and row["failures"] == 0 and row["same"] > 0, out[-3000:]
+        # most changes DO change the reference's answers: the walk is not comparing two constants
+        assert row["same_and_the_reference_answer_changed"] * 4 > row["same"], row
+        rows.append(row)
+    return rows
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_mutation_walk_over_everything_reachable():
+    """every seventh path of the secp256k1 and ed25519 walks and the whole curve25519 one on the CPU build
+    of the device code (the GPU suite runs all of them, p256 too)"""
+    _addon()
+    from hostsim.build import build as build_hostsim
+    rows = _run_walk(build_hostsim(), ["short:secp256k1", "edwards:ed25519", "mont:curve25519"], stride=7, offset=3)
+    assert rows[0]["paths"] >= 60 and rows[1]["paths"] >= 80 and rows[2]["paths"] >= 10, rows
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_mutation_walk_over_everything_reachable_gpu():
+    from elliptic_amd.js import build as jb
+    jb.build()
+    rows = _run_walk(None, ["short:secp256k1", "short:p256", "edwards:ed25519", "mont:curve25519"])
+    assert sum(r["paths"] for r in rows) >= 1400, rows
+
+
 def _run_eddsa_edges(lib):
     env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
     if lib:
