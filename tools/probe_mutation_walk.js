@@ -188,7 +188,12 @@ function child(family, from, to, listOnly) {
   var A = loader.load(), B = loader.load();
   var eng = require('../elliptic_amd/js').install(B.elliptic, { libPath: process.env.ELLGPU_LIB });
   var a = setup(A.elliptic, family), b = setup(B.elliptic, family);
+  // (WALK_FRESH=1: the change comes BEFORE the operand's and the instance's first use in the calls
+  // below -- no remembered verdict to go stale, the checks themselves are what is exercised; setup has
+  // used the curve and G)
+  var fresh = process.env.WALK_FRESH === '1';
   var first = a.calls(), firstB = b.calls();
+  if (fresh && !listOnly) { a = setup(A.elliptic, family); b = setup(B.elliptic, family); }
   var items = walk(a.roots, 8);
   var stride = Number(process.env.WALK_STRIDE || 1), offset = Number(process.env.WALK_OFFSET || 0);
   if (stride > 1) items = items.filter(function(_, i) { return i % stride === offset % stride; });
@@ -216,6 +221,7 @@ function child(family, from, to, listOnly) {
     var changed = 0;
     for (j = 0; j < ra.length; j++) if (ra[j] !== first[j]) changed++;
     say({ done: i, path: it.path.join('.'), form: it.form, changed: changed, drift: drift, diff: diff, stale: stale });
+    if (fresh) { say({ restart: i + 1 }); break; }
     if (diff.length || stale.length) { say({ restart: i + 1 }); break; }   // after a difference the next path starts from fresh objects
     first = na;
   }
