@@ -12,7 +12,8 @@
 // `curve.type`, `_maxwellTrick` / `redN`, an EDDSA KeyPair's cached secret material); anything else is a
 // parity failure.
 //   ELLGPU_LIB=<hostsim or real library> node tools/probe_mutation_walk.js [family ...]
-// families: short:secp256k1 short:p256 short:p384 edwards:ed25519 mont:curve25519 (default: the
+// families: short:<preset> edwards:ed25519 mont:curve25519 custom:<name of tests/golden/custom_short.json>
+// customed:<name of custom_edwards.json> (default: short:secp256k1 short:p256 edwards:ed25519 mont:curve25519 -- the
 // first, second, fourth and fifth; WALK_STRIDE=n WALK_OFFSET=k: every n-th path only).  Every path runs in a child process under a time limit (a
 // change may make the REFERENCE loop -- e.g. a signing loop that never finds a nonce); a path that
 // runs out of time on both libraries alike is reported as `hang` and skipped.
@@ -103,6 +104,40 @@ function setup(L, family) {
   var kind = family.split(':')[0], name = family.split(':')[1];
   var BN = L.curves.secp256k1.curve.p.constructor;
   var k = new BN(K, 16), k2 = new BN(K2, 16);
+  if (kind === 'custom' || kind === 'customed') {
+    // a USER-DEFINED curve (tests/golden/custom_short.json / custom_edwards.json: run-time modulus on the
+    // device, Point#mul / mulAdd / jmulAdd only -- its protocol calls are the reference's own)
+    var path = require('path');
+    var specs = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'tests', 'golden', kind === 'custom' ? 'custom_short.json' : 'custom_edwards.json')));
+    var sp = specs.filter(function(x) { return x.name === name; })[0];
+    var cc = kind === 'custom' ? new L.curve.short({ p: sp.p, a: sp.a, b: sp.b, n: sp.n, g: [ sp.g.x, sp.g.y ] }) :
+      new L.curve.edwards({ p: sp.p, a: sp.a, c: '1', d: sp.d, n: sp.n || null, g: [ sp.g.x, sp.g.y ] });
+    var nb = cc.n ? cc.n.bitLength() : cc.p.bitLength();
+    var bc = cc.g.mul(new BN(7)), Sc = cc.point(bc.getX(), bc.getY());
+    Sc.precompute(nb + 1);
+    cc.g.precompute(nb + 1);
+    var oc = cc.g.mul(new BN(11)), otherc = cc.point(oc.getX(), oc.getY());
+    var wc = cc.g.mul(new BN(3)), wrongc = cc.point(wc.getX(), wc.getY());
+    var kc = k.ushrn(256 - Math.min(nb, 256) + 2);
+    var ecc = kind === 'custom' && cc.n ? new L.ec({ curve: { curve: cc, g: cc.g, n: cc.n, hash: L.curves.p256.hash } }) : null;
+    var keyc = ecc && ecc.keyFromPrivate(kc.toString(16), 'hex'), goodc = ecc && ecc.sign(MSG, keyc, { canonical: true });
+    var rootsC = { curve: cc, S: Sc, other: otherc };
+    if (ecc) { rootsC = { ec: ecc, S: Sc, other: otherc, key: keyc, good: goodc }; }
+    return { roots: rootsC, wrong: wrongc, BN: BN, calls: function() {
+      var out = [ render(function() { return Sc.mul(kc); }), render(function() { return Sc.mul(k2); }), render(function() { return cc.g.mul(kc); }),
+        render(function() { return otherc.mulAdd(kc, Sc, k2); }), render(function() { return cc.g.mulAdd(k2, otherc, kc); }),
+        render(function() { return cc.validate(Sc); }), render(function() { return Sc.add(otherc); }) ];
+      if (typeof otherc.jmulAdd === 'function') out.push(render(function() { return otherc.jmulAdd(kc, Sc, k2); }));
+      if (ecc) {
+        out.push(render(function() { return ecc.sign(MSG, keyc, { canonical: true }); }));
+        out.push(render(function() { return ecc.verify(MSG, goodc, keyc.getPublic()); }));
+        out.push(render(function() { return ecc.keyFromPrivate(kc.toString(16), 'hex').getPublic(); }));
+        out.push(render(function() { return ecc.recoverPubKey(MSG, goodc, goodc.recoveryParam); }));
+        out.push(render(function() { return keyc.derive(Sc); }));
+      }
+      return out;
+    } };
+  }
   if (kind === 'short') {
     var ec = new L.ec(name), c = ec.curve;
     var b = c.g.mul(new BN(7)), S = c.point(b.getX(), b.getY());
