@@ -1417,9 +1417,10 @@ function install(elliptic, options) {
     return items.map(function(it) { return ec.verify(it.msg, it.signature, it.key, it.enc, it.options); });
   }
   eng.verifyMany = function verifyMany(ec, items) {
-    var d = domain(ec.curve);
-    if (!d || ec.curve.type !== 'short') throw new Error('verifyMany: unsupported curve');
-    if (untrusted(ec, d)) return verifyEach(ec, items);
+    // (a curve object that is no preset -- or is one no longer --: EC#verify of every item, which is what
+    // this call stands for in every case)
+    var d = ec && ec.curve ? domain(ec.curve) : null;
+    if (!d || ec.curve.type !== 'short' || untrusted(ec, d)) return verifyEach(ec, items);
     var m = marshalVerify(ec, d, items);
     m.o.status = Buffer.alloc(items.length);
     var ok = eng.ecdsaVerifyBatch(d.id, m.o);
@@ -1480,10 +1481,8 @@ function install(elliptic, options) {
     }), hl, mb);
   }
   eng.verifyManyAsync = function verifyManyAsync(ec, items) {
-    var d = domain(ec.curve);
-    if (!d || ec.curve.type !== 'short')
-      return Promise.reject(new Error('verifyMany: unsupported curve'));
-    if (untrusted(ec, d)) return new Promise(function(resolve) { resolve(verifyEach(ec, items)); });
+    var d = ec && ec.curve ? domain(ec.curve) : null;
+    if (!d || ec.curve.type !== 'short' || untrusted(ec, d)) return new Promise(function(resolve) { resolve(verifyEach(ec, items)); });
     var m;
     try { m = marshalVerify(ec, d, items); } catch (e) { return Promise.reject(e); }
     if (!items.length) return Promise.resolve([]);

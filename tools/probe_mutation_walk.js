@@ -100,7 +100,7 @@ var K = 'a3f1c29b7d5e08416c2a9f13e57b8d60412f9a7c3e5b1d08f6a2c4e19b3d5f71', K2 =
 var D2 = '0b1c2d3e4f5061728394a5b6c7d8e9fa0b1c2d3e4f5061728394a5b6c7d8e9f1';
 var MSG = []; for (var mi = 0; mi < 32; mi++) MSG.push((mi * 37 + 11) & 255);
 
-function setup(L, family) {
+function setup(L, family, eng) {
   var kind = family.split(':')[0], name = family.split(':')[1];
   var BN = L.curves.secp256k1.curve.p.constructor;
   var k = new BN(K, 16), k2 = new BN(K2, 16);
@@ -159,7 +159,22 @@ function setup(L, family) {
         render(function() { return ec.getKeyRecoveryParam(MSG, good, key.getPublic()); }),
         render(function() { return key.derive(S); }),
         render(function() { return c.pointFromX(xs, true); }),
-        render(function() { return c.decodePoint(pubHex, 'hex'); }) ];
+        render(function() { return c.decodePoint(pubHex, 'hex'); }),
+        // the patch's own batch call against what it stands for: EC#verify of every item
+        render(function() {
+          var items = [ { msg: MSG, signature: good, key: key.getPublic() }, { msg: MSG, signature: good, key: S },
+            { msg: MSG, signature: good.toDER('hex'), key: pubHex, enc: 'hex' } ];
+          return eng ? eng.verifyMany(ec, items) : items.map(function(it) { return ec.verify(it.msg, it.signature, it.key, it.enc); });
+        }) ];
+    }, later: function() {
+      // ... and its coalescing Promise form: three calls in one tick against three EC#verify
+      var items = [ [ MSG, good, key.getPublic() ], [ MSG, good, S ], [ MSG, good.toDER('hex'), pubHex, 'hex' ] ];
+      if (!eng) return Promise.resolve(items.map(function(it) { return render(function() { return ec.verify(it[0], it[1], it[2], it[3]); }); }).join(';'));
+      return Promise.all(items.map(function(it) {
+        var pr;
+        try { pr = eng.verifyAsync(ec, it[0], it[1], it[2], it[3]); } catch (e) { return 'e:' + String(e && e.message).slice(0, 120); }
+        return pr.then(function(v) { return 'v:' + str(v); }, function(e) { return 'e:' + String(e && e.message).slice(0, 120); });
+      })).then(function(r) { return r.join(';'); });
     } };
   }
   if (kind === 'edwards') {
@@ -218,17 +233,18 @@ function apply(ctx, item) {                               // -> undo()
 }
 
 // ---- child: paths [from, to) of one family ----------------------------------------------------------
-function child(family, from, to, listOnly) {
+async function child(family, from, to, listOnly) {
+  async function all(ctx) { var r = ctx.calls(); if (ctx.later) r.push(await ctx.later()); return r; }
   var loader = require('./ref_loader');
   var A = loader.load(), B = loader.load();
   var eng = require('../elliptic_amd/js').install(B.elliptic, { libPath: process.env.ELLGPU_LIB });
-  var a = setup(A.elliptic, family), b = setup(B.elliptic, family);
+  var a = setup(A.elliptic, family, null), b = setup(B.elliptic, family, eng);
   // (WALK_FRESH=1: the change comes BEFORE the operand's and the instance's first use in the calls
   // below -- no remembered verdict to go stale, the checks themselves are what is exercised; setup has
   // used the curve and G)
   var fresh = process.env.WALK_FRESH === '1';
-  var first = a.calls(), firstB = b.calls();
-  if (fresh && !listOnly) { a = setup(A.elliptic, family); b = setup(B.elliptic, family); }
+  var first = await all(a), firstB = await all(b);
+  if (fresh && !listOnly) { a = setup(A.elliptic, family, null); b = setup(B.elliptic, family, eng); }
   var items = walk(a.roots, 8);
   var stride = Number(process.env.WALK_STRIDE || 1), offset = Number(process.env.WALK_OFFSET || 0);
   if (stride > 1) items = items.filter(function(_, i) { return i % stride === offset % stride; });
@@ -240,10 +256,10 @@ function child(family, from, to, listOnly) {
     say({ start: i, path: it.path.join('.'), form: it.form });
     var ua, ub, ra, rb, na, nb;
     try { ua = apply(a, it); ub = apply(b, it); } catch (e) { say({ done: i, skipped: String(e.message) }); if (ua) ua(); continue; }
-    if (process.env.WALK_ONLY === 'plain') { ra = a.calls(); ua(); ub(); a.calls(); say({ done: i, plainOnly: true }); continue; }
-    ra = a.calls(); rb = b.calls();
+    if (process.env.WALK_ONLY === 'plain') { ra = await all(a); ua(); ub(); await all(a); say({ done: i, plainOnly: true }); continue; }
+    ra = await all(a); rb = await all(b);
     ua(); ub();
-    na = a.calls(); nb = b.calls();
+    na = await all(a); nb = await all(b);
     var diff = [], stale = [];
     for (var j = 0; j < ra.length; j++) if (ra[j] !== rb[j]) diff.push({ call: j, reference: ra[j], patched: rb[j] });
     // (after the undo: the two libraries must agree again; where BOTH moved away from their first
@@ -330,5 +346,5 @@ async function parent(families) {
   process.exit(bad ? 1 : 0);
 }
 
-if (process.argv[2] === '--child') child(process.argv[3], Number(process.argv[4]), Number(process.argv[5]), process.argv[6] === 'list');
+if (process.argv[2] === '--child') child(process.argv[3], Number(process.argv[4]), Number(process.argv[5]), process.argv[6] === 'list').catch(function(e) { console.error(e); process.exit(3); });
 else parent(process.argv.slice(2).length ? process.argv.slice(2) : [ 'short:secp256k1', 'short:p256', 'edwards:ed25519', 'mont:curve25519' ]);
