@@ -48,6 +48,8 @@ MAP = {
     "latency_rows_ab.txt": "latency_rows_ab.txt",
     "fuzz_gpu.log": "fuzz_gpu.log",
     "soak_long.log": "soak_long.log",
+    "mutation_walk.log": "mutation_walk.log",
+    "mid_batch_breakdown.jsonl": "mid_batch_breakdown.jsonl",
 }
 
 # kernel name in the summaries -> (key bench.py uses, units per dispatch in the profiled command)

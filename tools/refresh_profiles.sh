@@ -80,6 +80,14 @@ if [ "$MODE" != "quick" ]; then
   # and a longer soak against the C oracle
   for seed in r6-gpu-a r6-gpu-b r6-gpu-c; do timeout 600 node tools/fuzz_patched_vs_plain.js 600 $seed 2>&1 | tail -c 1200; echo; done > $O/fuzz_gpu.log
   timeout 400 python tests/soak.py --seconds 150 > $O/soak_long.log 2>&1
+  # everything reachable from a protocol call's objects, changed one property at a time after first use
+  # (four families side by side) and the kernel times of mid-size calls
+  for f in short:secp256k1 short:p256 edwards:ed25519 mont:curve25519; do
+    ( WALK_LIMIT_MS=20000 timeout 1500 node tools/probe_mutation_walk.js $f > $O/walk_${f#*:}.log 2>&1 ) &
+  done
+  wait
+  cat $O/walk_secp256k1.log $O/walk_p256.log $O/walk_ed25519.log $O/walk_curve25519.log > $O/mutation_walk.log
+  timeout 300 python tools/mid_batch_breakdown.py > $O/mid_batch_breakdown.jsonl 2>/dev/null
   python - > $O/latency_rows_ab.txt <<'PY'
 import json, os
 O = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "refresh")
