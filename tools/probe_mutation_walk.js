@@ -308,15 +308,18 @@ async function parent(families) {
       var r = await runChild([ family, String(at), String(Math.min(at + chunk, info.count)) ], limit);
       var lastStart = null, doneUpTo = at;
       var restartAt = -1;
-      r.lines.forEach(function(l) {
-        if (l.start !== undefined) { lastStart = l; return; }
-        if (l.restart !== undefined) { restartAt = l.restart; return; }
-        doneUpTo = l.done + 1;
+      var take = function(l) {
         if (l.skipped) { skipped++; skippedWhy[l.skipped] = (skippedWhy[l.skipped] || 0) + 1; return; }
         var path = l.path.split('.');
         if (!l.diff.length && !l.stale.length) { same++; if (l.changed) changedSame++; return; }
         var rec = { path: l.path, form: l.form, diff: l.diff.slice(0, 2), stale: l.stale.slice(0, 2), ndiff: l.diff.length, nstale: l.stale.length };
         if (documentedImmutable(path, family)) immutable.push(rec); else failures.push(rec);
+      };
+      r.lines.forEach(function(l) {
+        if (l.start !== undefined) { lastStart = l; return; }
+        if (l.restart !== undefined) { restartAt = l.restart; return; }
+        doneUpTo = l.done + 1;
+        take(l);
       });
       if (r.killed || r.code !== 0) {
         if (lastStart && lastStart.start >= doneUpTo) {
@@ -324,10 +327,19 @@ async function parent(families) {
           var alone = await runChild([ family, String(lastStart.start), String(lastStart.start + 1) ], limit, { WALK_ONLY: 'plain' });
           var rec2 = { path: lastStart.path, form: lastStart.form, exit: r.killed ? 'time limit' : r.code,
             reference_alone: alone.killed ? 'time limit' : alone.code !== 0 ? 'exit ' + alone.code : 'returns' };
-          if (rec2.reference_alone === 'returns') failures.push({ path: rec2.path, form: rec2.form, diff: [], stale: [], ndiff: 0, nstale: 0, hang: 'the patched library does not return, the reference does' });
-          else hangs.push(rec2);
+          if (rec2.reference_alone === 'returns') {
+            // (a slow moment of the machine, or the patched library's hang: once more, by itself, with four times the limit)
+            var again = await runChild([ family, String(lastStart.start), String(lastStart.start + 1) ], 4 * limit);
+            var line = again.lines.filter(function(l) { return l.done === lastStart.start; })[0];
+            if (line && !again.killed) take(line);
+            else failures.push({ path: rec2.path, form: rec2.form, diff: [], stale: [], ndiff: 0, nstale: 0, hang: 'the patched library does not return, the reference does' });
+          } else hangs.push(rec2);
           at = lastStart.start + 1;
-        } else at = doneUpTo + (doneUpTo === at ? 1 : 0);
+        } else {
+          // (the child ended between two paths, or before its first: nothing is skipped silently)
+          if (doneUpTo === at) hangs.push({ path: '(path ' + at + ': the child ended before it started)', form: '-', exit: r.killed ? 'time limit' : r.code, reference_alone: '-' });
+          at = doneUpTo + (doneUpTo === at ? 1 : 0);
+        }
       } else if (restartAt >= 0) at = restartAt;
       else at = Math.min(at + chunk, info.count);
     }
