@@ -458,14 +458,17 @@ function install(elliptic, options) {
     return [curve.zero, curve.one, curve.two, curve.i4, curve.a24];
   }
   function flagsOf(curve) {
-    if (curve.type === 'short') return (curve.zeroA ? 1 : 0) | (curve.threeA ? 2 : 0);
-    if (curve.type === 'edwards') return (curve.twisted ? 1 : 0) | (curve.mOneA ? 2 : 0) | (curve.extended ? 4 : 0) | (curve.oneC ? 8 : 0);
-    return 0;
+    // (bit 4: getNAF(k, w, curve._bitLength), base.js:56, 96, sizes an array with it -- any integer will do)
+    var b = Number.isInteger(curve._bitLength) ? 16 : 0;
+    if (curve.type === 'short') return b | (curve.zeroA ? 1 : 0) | (curve.threeA ? 2 : 0);
+    if (curve.type === 'edwards') return b | (curve.twisted ? 1 : 0) | (curve.mOneA ? 2 : 0) | (curve.extended ? 4 : 0) | (curve.oneC ? 8 : 0);
+    return b;
   }
   function derivedOK(curve) {
     var red = curve.red, one = new BN(1).toRed(red), two = one.redAdd(one);
     function is(v, w) { return !!v && v.red === red && v.negative === 0 && v.cmp(w) === 0; }
     if (!is(curve.zero, new BN(0).toRed(red)) || !is(curve.one, one) || !is(curve.two, two)) return false;
+    if (curve.type !== 'mont' && !Number.isInteger(curve._bitLength)) return false;
     var a = curve.a, m1 = one.redNeg();
     if (!a || a.red !== red || a.negative !== 0) return false;
     if (curve.type === 'short') {
@@ -631,6 +634,11 @@ function install(elliptic, options) {
   }
   // affine (x, y) of a point without mutating it; null for infinity
   function affineBuf(curve, p, B) {
+    // (a point object with a coordinate missing, or a number whose bn.js invariants are broken: whatever
+    // looking at it throws, the reference's own method throws its own way)
+    try { return affineBuf0(curve, p, B); } catch (e) { return null; }
+  }
+  function affineBuf0(curve, p, B) {
     // (a point of ANOTHER curve object -- the public half of a KeyPair made by another EC instance:
     // the reference's field operations throw 'red works only with red numbers' on it, its own to throw)
     if (!p || p.curve !== curve || p.isInfinity()) return null;
@@ -1348,7 +1356,10 @@ function install(elliptic, options) {
   montProto.mul = function mul(k) {
     var d = domain(this.curve);
     var kb = d && scalarBuf(k, 32);
-    if (!kb || this.isInfinity() || this.x.red !== this.curve.red || this.z.red !== this.curve.red) {
+    var mine = false;
+    try { mine = !!kb && !this.isInfinity() && this.x.red === this.curve.red && this.z.red === this.curve.red &&
+      this.x.negative === 0 && this.z.negative === 0; } catch (e) { mine = false; }
+    if (!mine) {
       eng.stats.passthrough++;
       return orig.montMul.apply(this, arguments);
     }
@@ -1367,9 +1378,11 @@ function install(elliptic, options) {
   orig.derive = kpProto.derive;
   kpProto.derive = function derive(pub) {
     var ec = this.ec, curve = ec && ec.curve;
-    if (!refOnly && curve && curve.type === 'mont' && pub && pub.curve === curve && this.priv &&
+    var mine = false;
+    try { mine = !refOnly && curve && curve.type === 'mont' && pub && pub.curve === curve && this.priv &&
         typeof pub.isInfinity === 'function' && !pub.isInfinity() && pub.x && pub.z &&
-        pub.x.red === curve.red && pub.z.red === curve.red) {
+        pub.x.red === curve.red && pub.z.red === curve.red && pub.x.negative === 0 && pub.z.negative === 0; } catch (e) { mine = false; }
+    if (mine) {
       var d = domain(curve);
       var kb = d && scalarBuf(this.priv, 32);
       if (kb) {
