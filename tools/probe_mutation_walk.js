@@ -295,7 +295,7 @@ async function child(family, from, to, listOnly) {
 // ---- parent ---------------------------------------------------------------------------------------------
 function runChild(args, limitMs, env) {
   return new Promise(function(resolveP) {
-    var p = cp.spawn(process.execPath, [ __filename, '--child' ].concat(args),
+    var p = cp.spawn(process.execPath, [ '--max-old-space-size=1024', __filename, '--child' ].concat(args),
       { stdio: [ 'ignore', 'pipe', 'inherit' ], env: Object.assign({}, process.env, env || {}) });
     var buf = '', lines = [], timer = null, killed = false;
     function arm() { if (timer) clearTimeout(timer); timer = setTimeout(function() { killed = true; p.kill('SIGKILL'); }, limitMs); }
@@ -303,7 +303,14 @@ function runChild(args, limitMs, env) {
     p.stdout.on('data', function(d) {
       buf += d;
       var at;
-      while ((at = buf.indexOf('\n')) >= 0) { lines.push(JSON.parse(buf.slice(0, at))); buf = buf.slice(at + 1); arm(); }
+      while ((at = buf.indexOf('\n')) >= 0) {
+        // (a child that runs out of heap -- a change can make the reference allocate without end -- dies with
+        // half a line, or V8's own text, on its stdout: not ours to parse; its exit code tells)
+        var ln = null;
+        try { ln = JSON.parse(buf.slice(0, at)); } catch (e) { ln = null; }
+        if (ln && typeof ln === 'object') lines.push(ln);
+        buf = buf.slice(at + 1); arm();
+      }
     });
     p.on('close', function(code) { clearTimeout(timer); resolveP({ lines: lines, killed: killed, code: code }); });
   });
