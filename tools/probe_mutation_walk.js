@@ -13,7 +13,7 @@
 // parity failure.
 //   ELLGPU_LIB=<hostsim or real library> node tools/probe_mutation_walk.js [family ...]
 // families: short:<preset> edwards:ed25519 mont:curve25519 custom:<name of tests/golden/custom_short.json>
-// customed:<name of custom_edwards.json> (default: short:secp256k1 short:p256 edwards:ed25519 mont:curve25519 -- the
+// customed:<name of custom_edwards.json> ec:ed25519 (the EC class over the Edwards curve) (default: short:secp256k1 short:p256 edwards:ed25519 mont:curve25519 -- the
 // first, second, fourth and fifth; WALK_STRIDE=n WALK_OFFSET=k: every n-th path only).  Every path runs in a child process under a time limit (a
 // change may make the REFERENCE loop -- e.g. a signing loop that never finds a nonce); a path that
 // runs out of time on both libraries alike is reported as `hang` and skipped.
@@ -141,6 +141,24 @@ function setup(L, family, eng) {
         out.push(render(function() { return keyc.derive(Sc); }));
       }
       return out;
+    } };
+  }
+  if (kind === 'ec') {
+    // the EC class over a curve of ANOTHER model (`new EC('ed25519')`: ECDSA over the Edwards curve, which
+    // the reference supports -- test/ecdsa-test.js -- and whose protocol calls are its own; the ladders
+    // under them are the engine's)
+    var e2 = new L.ec(name), c2 = e2.curve;
+    var key2 = e2.keyFromPrivate(D.slice(0, 40), 'hex'), good2 = e2.sign(MSG, key2, { canonical: true });
+    var other2 = e2.keyFromPrivate(D2.slice(0, 40), 'hex').getPublic();
+    var w2 = c2.g.mul(new BN(3));
+    return { roots: { ec: e2, key: key2, good: good2, other: other2 }, wrong: w2, BN: BN, calls: function() {
+      return [ render(function() { return e2.sign(MSG, key2, { canonical: true }); }),
+        render(function() { return e2.verify(MSG, good2, key2.getPublic()); }),
+        render(function() { return e2.verify(MSG, good2, other2); }),
+        render(function() { return e2.keyFromPrivate(D.slice(0, 40), 'hex').getPublic(); }),
+        render(function() { return key2.derive(other2); }),
+        render(function() { return c2.g.mul(k); }), render(function() { return other2.mul(k2); }),
+        render(function() { return c2.validate(other2); }) ];
     } };
   }
   if (kind === 'short') {
