@@ -170,8 +170,19 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
   return t;
 }
 
+/* Environment teardown (the script has ended, node is about to exit): finalizers still run then
+ * (node >= 12.17), in no useful order with respect to the HIP runtime's own exit handlers and its
+ * helper threads.  A context that is still alive at that point is not torn down piece by piece --
+ * the process ends, the driver reclaims its device memory -- and the result-buffer pool stops
+ * telling V8 about memory V8 no longer tracks.  (One of ~ 40 fuzz processes on a loaded GPU box
+ * ended with SIGSEGV AFTER its last line of output; nothing but teardown was left to run.)
+ * g_closing is set by an environment cleanup hook, which node runs before the finalizers. */
+static int g_closing = 0;
+static void on_env_cleanup(void* arg) { (void)arg; g_closing = 1; }
 static void ctx_finalize(napi_env env, void* data, void* hint) {
   (void)env; (void)hint;
+  if (getenv("ELLGPU_NAPI_TRACE")) fprintf(stderr, "ellgpu_napi: ctx_finalize closing=%d\n", g_closing);
+  if (g_closing) return;
   if (data && L.ctx_destroy) L.ctx_destroy((ellgpu_ctx*)data);
 }
 static napi_value fn_create(napi_env env, napi_callback_info info) {
@@ -232,6 +243,7 @@ static void pool_release(napi_env env, void* data, void* hint) {
   (void)data;
   pool_blk* b = (pool_blk*)hint;
   int64_t adj;
+  if (g_closing) { free(b->p); free(b); return; }
   napi_adjust_external_memory(env, -(int64_t)b->cap, &adj);
   if (g_pool_bytes + b->cap > POOL_MAX_BYTES) { free(b->p); free(b); return; }
   b->next = g_pool; g_pool = b; g_pool_bytes += b->cap;
@@ -921,6 +933,7 @@ static napi_value init(napi_env env, napi_value exports) {
     {"decodePoints", fn_decode_points}, {"encodePoints", fn_encode_points}, {"validate", fn_validate},
     {"pointAdd", fn_point_add}, {"sigFromDer", fn_sig_from_der}, {"sigToDer", fn_sig_to_der}, {"ecdsaVerifyWire", fn_verify_wire},
   };
+  napi_add_env_cleanup_hook(env, on_env_cleanup, NULL);
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;
     if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
