@@ -250,6 +250,7 @@ static void pool_release(napi_env env, void* data, void* hint) {
 }
 static napi_status result_buffer(napi_env env, size_t size, void** data, napi_value* out) {
   if (size < POOL_MIN_BYTES) return napi_create_buffer(env, size, data, out);
+  if (getenv("ELLGPU_NAPI_TRACE")) fprintf(stderr, "ellgpu_napi: pooled result buffer of %zu bytes\n", size);
   pool_blk **pp = &g_pool, **best = NULL;
   for (; *pp; pp = &(*pp)->next)                         /* best fit, at most 2x the request */
     if ((*pp)->cap >= size && (*pp)->cap <= 2 * size && (!best || (*pp)->cap < (*best)->cap)) best = pp;

@@ -329,5 +329,6 @@ lc.forEach(function(c, i) {
       if (r[3].indexOf('rejected') !== 0) throw new Error('bad-length async call was not rejected');
       checked += fixed.length + vr.length + vs.length;
       console.log(JSON.stringify({ ok: true, checked: checked, async: true, engine: eng.stats }));
+      process.exit(0);   // (explicit exit: node 12's environment teardown can crash in a pending N-API second-pass weak callback -- INTEGRATION.md, known issues)
     }).catch(function(e) { console.error(e); process.exit(1); });
 })();

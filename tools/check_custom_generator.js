@@ -123,3 +123,4 @@ var b0 = eng.stats.gpuCalls;
 same(patched.curves.secp256k1.curve.g.mul(new BN(5)), plain.curves.secp256k1.curve.g.mul(new BN(5)), 'preset');
 if (eng.stats.gpuCalls === b0) throw new Error('the preset did not reach the engine');
 console.log(JSON.stringify({ ok: true, custom: CUSTOM, checked: checked, engine: eng.stats }));
+process.exit(0);   // (explicit exit: node 12's environment teardown can crash in a pending N-API second-pass weak callback -- INTEGRATION.md, known issues)

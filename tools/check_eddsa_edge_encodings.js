@@ -43,3 +43,4 @@ ys.forEach(function(yA) { [false, true].forEach(function(oA) {
 }); });
 if (nTrue < 10 || nThrow < 100) { console.log(JSON.stringify({ ok: false, error: 'degenerate test set', accepted: nTrue, thrown: nThrow })); process.exit(1); }
 console.log(JSON.stringify({ ok: true, cases: n, accepted: nTrue, thrown: nThrow, engine: eng.stats }));
+process.exit(0);   // (explicit exit: node 12's environment teardown can crash in a pending N-API second-pass weak callback -- INTEGRATION.md, known issues)

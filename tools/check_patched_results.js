@@ -207,4 +207,5 @@ var pendingAsync = [];
 })();
 Promise.all(pendingAsync).then(function() {
   console.log(JSON.stringify({ ok: true, checked: checked, thrown: thrown, engine: eng.stats }));
+  process.exit(0);   // (explicit exit: node 12's environment teardown can crash in a pending N-API second-pass weak callback -- INTEGRATION.md, known issues)
 }, function(e) { console.error(e.stack || e); process.exit(1); });

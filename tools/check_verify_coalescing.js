@@ -74,5 +74,6 @@ Promise.all(ps).then(function(got) {
     if (v !== want[0].v) die('second tick verdict');
     console.log(JSON.stringify({ ok: true, calls: calls.length, engine_calls: launches, valid: nTrue, rejected: nThrow,
       coalescedBatches: eng.stats.coalescedBatches, coalescedItems: eng.stats.coalescedItems }));
+    process.exit(0);   // (explicit exit: node 12's environment teardown can crash in a pending N-API second-pass weak callback -- INTEGRATION.md, known issues)
   });
 }).catch(function(e) { die(String(e && e.stack || e)); });

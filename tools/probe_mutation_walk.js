@@ -396,5 +396,6 @@ async function parent(families) {
   process.exit(bad ? 1 : 0);
 }
 
-if (process.argv[2] === '--child') child(process.argv[3], Number(process.argv[4]), Number(process.argv[5]), process.argv[6] === 'list').catch(function(e) { console.error(e); process.exit(3); });
+if (process.argv[2] === '--child') child(process.argv[3], Number(process.argv[4]), Number(process.argv[5]), process.argv[6] === 'list').then(function() { process.exit(0); },   // (explicit exit: node 12's environment teardown can crash in a pending N-API second-pass weak callback -- INTEGRATION.md, known issues)
+  function(e) { console.error(e); process.exit(3); });
 else parent(process.argv.slice(2).length ? process.argv.slice(2) : [ 'short:secp256k1', 'short:p256', 'edwards:ed25519', 'mont:curve25519' ]);
