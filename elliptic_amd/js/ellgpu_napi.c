@@ -179,11 +179,29 @@ static napi_value fn_open(napi_env env, napi_callback_info info) {
  * g_closing is set by an environment cleanup hook, which node runs before the finalizers. */
 static int g_closing = 0;
 static void on_env_cleanup(void* arg) { (void)arg; g_closing = 1; }
+/* Contexts are PINNED: the addon holds a strong reference to every context external until
+ * destroyContext(ctx) is called (Engine#close in index.js).  Left to the garbage collector, the
+ * external of a script that has just run off its end is garbage a moment before node frees the
+ * environment; when a collection falls into that moment, the reference's first-pass weak callback
+ * has run and its second pass is a pending task while napi_env's teardown finalizes and deletes
+ * the same reference -- and node 12.22 then runs the pending second pass on freed memory (caught
+ * under rocgdb: FreeEnvironment -> RunCleanup -> CleanupHandles -> uv_run ->
+ * InvokeSecondPassPhantomCallbacks -> N-API's reference helpers; fixed in node >= 14.17).  A strong
+ * reference has no weak callback.  A context owns gigabytes of device memory anyway: its lifetime
+ * is explicit, like that of the stream it wraps. */
+#define MAX_CTX 64
+static struct { ellgpu_ctx* c; napi_ref pin; } g_ctx[MAX_CTX];
+static int g_jobs_in_flight = 0;
+static int ctx_slot(ellgpu_ctx* c) {
+  for (int i = 0; i < MAX_CTX; i++) if (g_ctx[i].c == c) return i;
+  return -1;
+}
 static void ctx_finalize(napi_env env, void* data, void* hint) {
   (void)env; (void)hint;
   if (getenv("ELLGPU_NAPI_TRACE")) fprintf(stderr, "ellgpu_napi: ctx_finalize closing=%d\n", g_closing);
-  if (g_closing) return;
-  if (data && L.ctx_destroy) L.ctx_destroy((ellgpu_ctx*)data);
+  /* (reached for the external of a context that destroyContext has released -- only then is it
+   * unpinned and collectable -- and for every external at environment teardown: nothing is left to do) */
+  (void)data;
 }
 static napi_value fn_create(napi_env env, napi_callback_info info) {
   if (!need_lib(env)) return NULL;
@@ -209,12 +227,18 @@ static napi_value fn_create(napi_env env, napi_callback_info info) {
     if (argc >= 1) napi_get_value_int32(env, argv[0], &dev);
     if (L.ctx_create(dev, &c) != 0) return lib_error(env);
   }
-  napi_value ext; CHECK(env, napi_create_external(env, c, ctx_finalize, NULL, &ext));
+  int slot = ctx_slot(NULL);
+  if (slot < 0) { L.ctx_destroy(c); THROW(env, "ellgpu: too many live contexts (destroyContext / Engine#close releases one)"); }
+  napi_value ext;
+  if (napi_create_external(env, c, ctx_finalize, NULL, &ext) != napi_ok ||
+      napi_create_reference(env, ext, 1, &g_ctx[slot].pin) != napi_ok) { L.ctx_destroy(c); THROW(env, "ellgpu: could not wrap the context"); }
+  g_ctx[slot].c = c;
   return ext;
 }
 static ellgpu_ctx* get_ctx(napi_env env, napi_value v) {
   void* p = NULL;
   if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_error(env, NULL, "ellgpu: bad context"); return NULL; }
+  if (ctx_slot((ellgpu_ctx*)p) < 0) { napi_throw_error(env, NULL, "ellgpu: the context has been destroyed"); return NULL; }
   return (ellgpu_ctx*)p;
 }
 static int get_buf(napi_env env, napi_value v, const uint8_t** p, size_t* len, int allow_null) {
@@ -327,9 +351,23 @@ static napi_value define_common(napi_env env, napi_callback_info info, int edwar
 }
 static napi_value fn_define_short(napi_env e, napi_callback_info i) { return define_common(e, i, 0); }
 static napi_value fn_define_edwards(napi_env e, napi_callback_info i) { return define_common(e, i, 1); }
+/* destroyContext(ctx): releases the context's device memory and streams (ellgpu_ctx_destroy) and the
+ * addon's pin on the external; any later call with that external throws.  Refused while Promise-form
+ * batches are in flight (a worker thread is inside the context). */
 static napi_value fn_destroy(napi_env env, napi_callback_info info) {
-  /* contexts are released by the GC finalizer; explicit destroy is a no-op hook */
-  (void)info; napi_value u; napi_get_undefined(env, &u); return u;
+  if (!need_lib(env)) return NULL;
+  size_t argc = 1; napi_value argv[1];
+  CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  void* p = NULL;
+  napi_value u; napi_get_undefined(env, &u);
+  if (argc < 1 || napi_get_value_external(env, argv[0], &p) != napi_ok || !p) THROW(env, "destroyContext(ctx)");
+  int i = ctx_slot((ellgpu_ctx*)p);
+  if (i < 0) return u;                                  /* destroyed already */
+  if (g_jobs_in_flight > 0) THROW(env, "ellgpu: batches are in flight on a worker thread; destroy the context when their Promises have settled");
+  L.ctx_destroy(g_ctx[i].c);
+  napi_delete_reference(env, g_ctx[i].pin);
+  g_ctx[i].c = NULL; g_ctx[i].pin = NULL;
+  return u;
 }
 
 /* defer(ctx) / collect(ctx): the split form of a few-item call (ellgpu_ctx_defer / _collect) */
@@ -836,6 +874,7 @@ static void job_complete(napi_env env, napi_status status, void* data) {
     napi_reject_deferred(env, j->deferred, errv);
   }
   for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
+  g_jobs_in_flight--;
   napi_delete_async_work(env, j->work);
   free(j->out0); free(j->out1); free(j->out2); free(j->out3); free(j);
 }
@@ -919,6 +958,7 @@ static napi_value fn_call_async(napi_env env, napi_callback_info info) {
   CHECK(env, napi_create_string_utf8(env, "ellgpu", NAPI_AUTO_LENGTH, &name));
   CHECK(env, napi_create_async_work(env, NULL, name, job_execute, job_complete, j, &j->work));
   CHECK(env, napi_queue_async_work(env, j->work));
+  g_jobs_in_flight++;
   return promise;
 }
 

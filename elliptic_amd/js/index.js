@@ -47,6 +47,12 @@ function Engine(options) {
   this.stats = { gpuCalls: 0, gpuItems: 0, passthrough: 0, offCurve: 0 };
 }
 
+// The context owns the device's memory for this engine (fixed-base tables: 1.6 GB for secp256k1 at
+// the default width) and is pinned by the addon until close(): call it when the engine is no
+// longer needed (install(): eng.uninstall() first).  A process that simply ends needs no close().
+Engine.prototype.close = function close() {
+  if (this.ctx) { var c = this.ctx; this.ctx = null; this.addon.destroyContext(c); }
+};
 Engine.prototype._id = function _id(curve) {
   var id = typeof curve === 'number' ? curve : this.addon.curveId(curve);
   if (id < 0) throw new Error('Unknown curve ' + curve);

@@ -466,4 +466,4 @@ for (var it = 0; it < ITER && failures.length < 5; it++) {
 })();
 if (failures.length) { console.log(JSON.stringify({ ok: false, seed: SEED, failures: failures }, null, 1)); process.exit(1); }
 console.log(JSON.stringify({ ok: true, seed: SEED, calls: stats.calls, reference_threw: stats.threw, by_op: stats.byOp, engine: eng.stats }));
-process.exit(0);   // (explicit exit: node 12's environment teardown can crash in a pending N-API second-pass weak callback -- INTEGRATION.md, known issues)
+if (!process.env.ELLGPU_NATURAL_EXIT) process.exit(0);   // (explicit exit: node 12's environment teardown can crash in a pending N-API second-pass weak callback -- INTEGRATION.md, known issues)
