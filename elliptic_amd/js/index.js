@@ -51,7 +51,11 @@ function Engine(options) {
 // the default width) and is pinned by the addon until close(): call it when the engine is no
 // longer needed (install(): eng.uninstall() first).  A process that simply ends needs no close().
 Engine.prototype.close = function close() {
-  if (this.ctx) { var c = this.ctx; this.ctx = null; this.addon.destroyContext(c); }
+  if (!this.ctx) return;
+  // (Promise-form batches are chained on the JS side before a worker thread gets them: _async)
+  if (this._pending > 0) throw new Error('ellgpu: batches are in flight; close the engine when their Promises have settled');
+  this.addon.destroyContext(this.ctx);
+  this.ctx = null;
 };
 Engine.prototype._id = function _id(curve) {
   var id = typeof curve === 'number' ? curve : this.addon.curveId(curve);
@@ -312,6 +316,9 @@ Engine.prototype._async = function _async(op, curve, hashLen, msgBits, b0, b1, b
   };
   var p = (this._tail || Promise.resolve()).then(run, run);
   this._tail = p.catch(function() {});
+  this._pending = (this._pending | 0) + 1;
+  var settled = function() { self._pending--; };
+  p.then(settled, settled);
   return p;
 };
 Engine.prototype.mulBatchAsync = function(curve, scalars, points) {

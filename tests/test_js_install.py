@@ -195,6 +195,39 @@ def test_differential_fuzz_of_the_public_api_gpu():
     _run_fuzz(None, 600, "gpu-1")
 
 
+def _run_close(lib):
+    env = dict(os.environ, ELLIPTIC_REFERENCE=_reference())
+    if lib:
+        env["ELLGPU_LIB"] = lib
+        env.update(HOSTSIM_ENV)
+    else:
+        env.pop("ELLGPU_LIB", None)
+    p = subprocess.run(["node", os.path.join(ROOT, "tools", "check_engine_close.js")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["refused_while_in_flight"] and res["engines_opened_and_closed"] == 70
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_engine_close_releases_the_pinned_context():
+    """the addon pins a context until destroyContext (node 12 frees an environment with a pending
+    weak callback of a collected external otherwise: INTEGRATION.md section 2): Engine#close releases it,
+    is refused while a Promise-form batch is in flight, leaves the library the reference's after
+    uninstall(), and more engines than the addon pins at once can be opened one after the other"""
+    _addon()
+    from hostsim.build import build as build_hostsim
+    _run_close(build_hostsim())
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_engine_close_releases_the_pinned_context_gpu():
+    from elliptic_amd.js import build as jb
+    jb.build()
+    _run_close(None)
+
+
 def _run_walk(lib, families, stride=1, offset=0, timeout=3000):
     """tools/probe_mutation_walk.js: ONE reachable property of the caller's objects changed after their
     first use -- every property the walk finds from an EC / EDDSA instance, its curve, the generator's and
