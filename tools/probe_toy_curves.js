@@ -57,6 +57,7 @@ for (var s = 0; s < specs.length; s += 12) {
   }
   engineCalls += eng.stats.gpuCalls;
   eng.uninstall();
+  eng.close();                       // (the addon pins a context until it is closed)
 }
 console.log(JSON.stringify({ ok: bad === 0, type: TYPE, p: P, curves: specs.length, calls: total, mismatches: bad, engine_calls: engineCalls,
   first_mismatch_per_curve: firstBad }));
