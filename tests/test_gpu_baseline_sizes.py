@@ -352,3 +352,23 @@ def test_user_defined_curve_large_batch(ctx):
     idx = sample_idx(m)
     want, winf = C.mul_add(name, ka[idx], pts[:m][idx], kb[idx], pts[m:2 * m][idx])
     assert np.array_equal(oinf[idx], winf) and np.array_equal(out[idx], want)
+
+
+def test_bench_flow_with_four_ranks_on_one_device():
+    """`bench.py --gpus 4` as the driver launches it, with all four ranks on THIS device over gloo (a one-GPU
+    box cannot give RCCL four devices): weak + strong blocks, the gathered mask compared with the expected
+    mask on every rank.  Three runs: the processes race each other for the device, which is what found the
+    unordered zero fill in OverlappedGather (round 6: 3 of 16 eight-rank runs failed the mask check)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for run in range(3):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "2",
+                            "--dist-backend", "gloo", "--force-device", "0", "--batch", "65536", "--sustain", "0",
+                            "--no-cpu", "--no-configs", "--no-live-counters"], capture_output=True, text=True, timeout=900, cwd=root)
+        assert p.returncode == 0 and "PARITY FAILURE" not in p.stderr, (run, p.stdout[-1500:], p.stderr[-3000:])
+        line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 4 and line["rccl"]["nranks_seen"] == 4, line.get("rccl")
+        assert "equals the global batch's expected mask" in line["strong"]["parity"], line["strong"]
+        assert len(line["per_rank"]) == 4
